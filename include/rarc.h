@@ -1,0 +1,174 @@
+/*
+ * rarc.h — C-ABI of librarc_hip.so, the MI355X (gfx950) backend for RAG-ARC's
+ * dense-retrieval hot path.
+ *
+ * The reference (DataArcTech/RAG-ARC) has no FFI of its own: the hot path is
+ * Python that calls faiss / numpy.  Each entry point below replaces the
+ * arithmetic behind one reference call site (cited as file:line relative to the
+ * reference tree).  INTEGRATION.md shows the ctypes stubs a maintainer adds on
+ * the reference side.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM); h_* is a host pointer.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - every function returns 0 on success, a negative RARC_E_* code otherwise;
+ *     nothing throws across the boundary; rarc_last_error() returns a
+ *     thread-local human-readable message for the last failure.
+ *   - the library allocates nothing: the caller owns all buffers, including the
+ *     scratch workspace whose size rarc_search_workspace_bytes() reports.
+ *   - functions are re-entrant per (device, stream); the caller selects the
+ *     device (hipSetDevice) before calling.
+ *   - doc ids are row indices (int64); scores are fp32.
+ *   - ordering everywhere: score descending, ties by id ascending.
+ */
+#ifndef RARC_H
+#define RARC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RARC_VERSION 100 /* 0.1.0 */
+
+#define RARC_OK 0
+#define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
+#define RARC_E_HIP -2         /* a HIP runtime call or kernel launch failed */
+#define RARC_E_WORKSPACE -3   /* workspace too small / misaligned */
+#define RARC_E_UNSUPPORTED -4 /* shape outside what the kernels were built for */
+
+/* Limits of the fused scan kernel. */
+#define RARC_MAX_QUERIES 256 /* queries per scan pass (register-resident) */
+#define RARC_MAX_K 1024      /* largest k' the finalize kernel selects */
+#define RARC_DIM_ALIGN 128   /* stored row length is a multiple of this */
+
+/* status bits written per query by rarc_search_f16 (d_status[q]) */
+#define RARC_Q_OK 0u
+#define RARC_Q_UNCERTAIN 1u /* exactness certificate failed: call rarc_repair_f16 */
+#define RARC_Q_OVERFLOW 2u  /* candidate buffer overflowed: call rarc_repair_f16 */
+
+int rarc_version(void);
+const char* rarc_last_error(void);
+
+/* Smallest multiple of RARC_DIM_ALIGN that is >= d. */
+int rarc_padded_dim(int d);
+
+/*
+ * L2-normalise rows in fp32, in place or out of place (d_out may equal d_in).
+ * Replaces faiss.normalize_L2 at
+ *   encapsulation/database/vector_db/VectorStore_Faiss.py:150-154 (called from :178, :259).
+ * Semantics (restated from faiss fvec_renorm_L2): nr = sum x^2 in fp32;
+ * if nr > 0: x *= (float)(1.0 / sqrt(nr)); zero rows are left unchanged.
+ * The summation order is the canonical 8-lane order documented in DESIGN.md.
+ * ld_in / ld_out are row strides in elements.
+ */
+int rarc_l2norm_rows_f32(const float* d_in, int64_t ld_in, float* d_out, int64_t ld_out,
+                         int64_t n_rows, int d, void* stream);
+
+/*
+ * Ingest: fp32 rows -> (optionally L2-normalised) -> fp16 corpus rows of length
+ * d_pad (zero padded).  Replaces `_normalize_vectors` + `index.add` at
+ *   VectorStore_Faiss.py:178, :199-202
+ * for an HBM-resident fp16 flat index.  d_row_norm2 (optional, n_rows floats)
+ * receives the squared L2 norm of each stored (fp16-rounded) row.
+ */
+int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_corpus_f16, int d_pad,
+                    float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream);
+
+/*
+ * Query preparation: fp32 queries [nq][ld_in] -> (optionally normalised) fp32
+ * copy [RARC_MAX_QUERIES][d_pad] (zero padded), fp16 copy of the same shape for
+ * the MFMA scan, and the per-query error bound d_eps[q] used by the exactness
+ * certificate.  Replaces `np.array([embedding]).astype(np.float32)` +
+ * `_normalize_vectors` at VectorStore_Faiss.py:258-259.
+ */
+int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad, int normalize,
+                      float corpus_max_norm, float* d_q32, uint16_t* d_q16, float* d_eps,
+                      void* stream);
+
+/* Bytes of device scratch rarc_search_f16 / rarc_repair_f16 need (16-byte aligned base). */
+size_t rarc_search_workspace_bytes(int cand_cap);
+
+/*
+ * Flat inner-product search over an fp16 corpus shard resident in HBM.
+ * Replaces faiss.IndexFlatIP.search at VectorStore_Faiss.py:262-263 for
+ * nq <= RARC_MAX_QUERIES queries at once (the reference calls it with nq = 1).
+ *
+ *   d_corpus_f16 : [n_rows][d_pad] fp16, row-major
+ *   d_q32, d_q16, d_eps : outputs of rarc_prep_queries
+ *   k            : results per query (k <= kprime)
+ *   kprime       : candidates kept by the approximate MFMA scan before the
+ *                  canonical fp32 rescore (k <= kprime <= RARC_MAX_K)
+ *   id_base      : added to local row indices (global id of this shard's row 0)
+ *   d_out_ids    : [nq][k] int64, -1 where fewer than k rows exist
+ *   d_out_scores : [nq][k] fp32 canonical scores, -inf padding
+ *   d_status     : [nq] RARC_Q_* bits; a query whose bit is set must be
+ *                  repaired with rarc_repair_f16 before its row is trusted
+ *   bin_lo/bin_hi: score range covered by the pruning histogram
+ *                  (cosine: -1, +1; ip: -/+ max|q|*max|d|)
+ */
+int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad,
+                    const float* d_q32, const uint16_t* d_q16, const float* d_eps, int nq,
+                    int k, int kprime, int64_t id_base, float bin_lo, float bin_hi,
+                    int64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
+                    void* d_workspace, size_t workspace_bytes, int cand_cap, void* stream);
+
+/*
+ * Exact repair / verification of ONE query row: scans the whole shard with the
+ * canonical fp32 scorer, collects every row that beats the current k-th result
+ * and re-sorts.  After it returns the row is exact regardless of d_status.
+ * d_found (1 uint32) receives the number of rows that beat the previous k-th
+ * entry (0 == the previous answer was already exact).
+ */
+int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_q32,
+                    int q, int k, int64_t id_base, int64_t* d_out_ids, float* d_out_scores,
+                    uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Merge G sorted candidate lists per query into the global top-k
+ * (score desc, id asc).  Used after the RCCL all-gather of per-shard results
+ * (SURVEY.md §8e).  Inputs are [G][nq][k]; outputs [nq][k].
+ */
+int rarc_topk_merge(const int64_t* d_ids, const float* d_scores, int n_lists, int nq, int k,
+                    int64_t* d_out_ids, float* d_out_scores, void* stream);
+
+/*
+ * Reciprocal-rank fusion, bit-exact with RRFusion.fuse at core/utils/Fusion.py:45-76.
+ * For query b, list r holds d_len[b*n_lists + r] keys at
+ * d_keys[(b*n_lists + r)*max_len ...] in rank order (rank = position + 1).
+ * score(key) = sum over occurrences, in (list, position) order, of
+ * 1.0 / (rrf_k + rank) in fp64; output order = score desc, ties in first-insertion
+ * order; d_out_n[b] = number of fused entries written (<= top_k).
+ */
+int rarc_rrf_fuse(const int64_t* d_keys, const int32_t* d_len, int nq, int n_lists, int max_len,
+                  double rrf_k, int top_k, int64_t* d_out_keys, double* d_out_scores,
+                  int32_t* d_out_n, void* stream);
+
+/*
+ * Reranker score -> order step of Qwen3Reranker (core/rerank/Reranker_Qwen3.py:41-49, :70-74):
+ * p_yes = exp(log_softmax([z_no, z_yes])[1]) evaluated the way the reference's
+ * fp16 tensors evaluate it, then a stable descending sort.  Inputs are fp16
+ * logits [nq][n]; outputs: fp16 scores (as uint16 bit patterns) and the
+ * permutation (int32) per query.
+ */
+int rarc_rerank_order(const uint16_t* d_z_no, const uint16_t* d_z_yes, int nq, int n,
+                      uint16_t* d_out_scores_f16, int32_t* d_out_perm, void* stream);
+
+/*
+ * Deterministic synthetic corpus / query generator (bench + full-size property
+ * tests): counter-based integer hash -> Irwin-Hall(4) approx-normal -> exact
+ * integer sum of squares -> fp64 scale -> fp16 (RNE).  Bit-identical to
+ * oracle/rarc_oracle.c:synth_rows_f16.  Row r of the stream `seed` depends only
+ * on (seed, first_row + r, d).
+ */
+int rarc_synth_rows_f16(uint16_t* d_out_f16, int d_pad, int d, int64_t first_row, int64_t n_rows,
+                        uint64_t seed, void* stream);
+int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_row,
+                        int64_t n_rows, uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RARC_H */

@@ -1,0 +1,213 @@
+"""cpu_ref.py — CPU ORACLE, python side.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package (rag-arc_amd/) never does and fails loudly without its HIP library.
+
+What is restated here, and how it is pinned:
+
+* flat inner-product search / L2 normalisation (faiss arithmetic reached from
+  encapsulation/database/vector_db/VectorStore_Faiss.py:150-154, :170-202, :258-272):
+  thin ctypes wrappers over oracle/rarc_oracle.c.  faiss is not vendored in /root/reference, no
+  version is pinned there and the reference holds no golden vector for it -> "parity unpinned"
+  (see the header of rarc_oracle.c and DESIGN.md).  A float64 numpy cross-check
+  (`flat_search_f64`) bounds the canonical fp32 scores to the 1e-5 the north star asks for.
+* reciprocal-rank fusion (core/utils/Fusion.py:45-76), the relevance-score quirk
+  (encapsulation/database/vector_db/VectorStoreBase.py:263-266) and the reranker's
+  score->order step (core/rerank/Reranker_Qwen3.py:41-49, :70-74): pure python / numpy below,
+  PINNED against outputs of the reference's own importable code, committed under tests/golden/
+  by tests/golden/make_golden.py.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from collections import defaultdict
+from typing import Hashable, List, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "librarc_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile rarc_oracle.c with gcc (oracle/Makefile).  Returns the .so path."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        if not L.oracle_cpu_ok():
+            raise RuntimeError("oracle needs an x86-64 CPU with AVX2 + FMA + F16C")
+        L.oracle_canon_dot_f16.restype = ctypes.c_float
+        L.oracle_canon_dot_f16_scalar.restype = ctypes.c_float
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def padded_dim(d: int, align: int = 128) -> int:
+    return ((d + align - 1) // align) * align
+
+
+# ----------------------------------------------------------------------------- normalise / ingest
+def normalize_L2(x: np.ndarray) -> np.ndarray:
+    """faiss.normalize_L2 (VectorStore_Faiss.py:153): returns a normalised fp32 copy."""
+    y = np.array(x, dtype=np.float32, order="C", copy=True)
+    if y.ndim != 2:
+        raise ValueError("expected a 2-d array")
+    if y.size:
+        lib().oracle_normalize_rows_f32(_p(y), ctypes.c_int64(y.shape[1]), ctypes.c_int64(y.shape[0]),
+                                        ctypes.c_int(y.shape[1]))
+    return y
+
+
+def ingest_f16(x: np.ndarray, normalize: bool = True, d_pad: int | None = None) -> Tuple[np.ndarray, np.ndarray]:
+    """add_texts side (VectorStore_Faiss.py:170-202) for an fp16 flat index: returns
+    (rows as uint16 bit patterns [n][d_pad], squared norms of the stored rows [n])."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, d = x.shape
+    d_pad = d_pad or padded_dim(d)
+    out = np.zeros((n, d_pad), dtype=np.uint16)
+    n2 = np.zeros(n, dtype=np.float32)
+    if n:
+        lib().oracle_ingest_f16(_p(x), ctypes.c_int64(d), _p(out), ctypes.c_int(d_pad), _p(n2),
+                                ctypes.c_int64(n), ctypes.c_int(d), ctypes.c_int(1 if normalize else 0))
+    return out, n2
+
+
+def pad_queries(q: np.ndarray, d_pad: int) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    out = np.zeros((q.shape[0], d_pad), dtype=np.float32)
+    out[:, : q.shape[1]] = q
+    return out
+
+
+# ----------------------------------------------------------------------------------- flat search
+def flat_search_f16(corpus_u16: np.ndarray, q32: np.ndarray, k: int, id_base: int = 0) -> Tuple[np.ndarray, np.ndarray, int]:
+    """IndexFlatIP.search (VectorStore_Faiss.py:263) over fp16 rows with the canonical fp32 scorer.
+    Ties: id ascending.  Returns (ids int64 [nq][k], scores fp32 [nq][k], threads used)."""
+    corpus_u16 = np.ascontiguousarray(corpus_u16, dtype=np.uint16)
+    n, d_pad = corpus_u16.shape
+    q32 = np.ascontiguousarray(q32, dtype=np.float32)
+    if q32.shape[1] != d_pad:
+        q32 = pad_queries(q32, d_pad)
+    nq = q32.shape[0]
+    ids = np.full((nq, k), -1, dtype=np.int64)
+    sc = np.full((nq, k), -np.inf, dtype=np.float32)
+    L = lib()
+    L.oracle_flat_search_f16.restype = ctypes.c_int
+    nt = L.oracle_flat_search_f16(_p(corpus_u16), ctypes.c_int64(n), ctypes.c_int(d_pad), _p(q32),
+                                  ctypes.c_int(nq), ctypes.c_int(k), ctypes.c_int64(id_base), _p(ids), _p(sc))
+    return ids, sc, int(nt)
+
+
+def flat_search_f64(corpus_u16: np.ndarray, q32: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """float64 numpy cross-check (small sizes): scores = q @ D^T in float64, (score desc, id asc)."""
+    D = corpus_u16.view(np.float16).astype(np.float64)
+    q = np.asarray(q32, dtype=np.float64)
+    if q.shape[1] != D.shape[1]:
+        q = np.pad(q, ((0, 0), (0, D.shape[1] - q.shape[1])))
+    S = q @ D.T
+    order = np.lexsort((np.arange(S.shape[1])[None, :].repeat(S.shape[0], 0), -S), axis=1)[:, :k]
+    return order.astype(np.int64), np.take_along_axis(S, order, axis=1)
+
+
+def score_rows_f16(corpus_u16: np.ndarray, qv: np.ndarray, rows: np.ndarray) -> np.ndarray:
+    corpus_u16 = np.ascontiguousarray(corpus_u16, dtype=np.uint16)
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    qv = np.ascontiguousarray(qv, dtype=np.float32)
+    out = np.zeros(rows.shape[0], dtype=np.float32)
+    lib().oracle_score_rows_f16(_p(corpus_u16), ctypes.c_int(corpus_u16.shape[1]), _p(qv), _p(rows),
+                                ctypes.c_int(rows.shape[0]), _p(out))
+    return out
+
+
+def topk_merge(ids: np.ndarray, scores: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Merge [G][nq][k] per-shard results into [nq][k]: score desc, id asc; id -1 entries ignored."""
+    G, nq, kk = ids.shape
+    I = np.transpose(ids, (1, 0, 2)).reshape(nq, G * kk)
+    S = np.transpose(scores, (1, 0, 2)).reshape(nq, G * kk).astype(np.float32)
+    out_i = np.full((nq, k), -1, dtype=np.int64)
+    out_s = np.full((nq, k), -np.inf, dtype=np.float32)
+    for q in range(nq):
+        valid = I[q] >= 0
+        ii, ss = I[q][valid], S[q][valid]
+        order = np.lexsort((ii, -ss.astype(np.float64)))[:k]
+        out_i[q, : order.size] = ii[order]
+        out_s[q, : order.size] = ss[order]
+    return out_i, out_s
+
+
+# ------------------------------------------------------------------------------------- synthetic
+def synth_rows_f16(n: int, d: int, first_row: int = 0, seed: int = 1234, d_pad: int | None = None) -> np.ndarray:
+    d_pad = d_pad or padded_dim(d)
+    out = np.zeros((n, d_pad), dtype=np.uint16)
+    if n:
+        lib().oracle_synth_rows_f16(_p(out), ctypes.c_int(d_pad), ctypes.c_int(d), ctypes.c_int64(first_row),
+                                    ctypes.c_int64(n), ctypes.c_uint64(seed))
+    return out
+
+
+def synth_rows_f32(n: int, d: int, first_row: int = 0, seed: int = 4321) -> np.ndarray:
+    out = np.zeros((n, d), dtype=np.float32)
+    if n:
+        lib().oracle_synth_rows_f32(_p(out), ctypes.c_int64(d), ctypes.c_int(d), ctypes.c_int64(first_row),
+                                    ctypes.c_int64(n), ctypes.c_uint64(seed))
+    return out
+
+
+# ------------------------------------------------------------------------------------------- RRF
+def rrf_fuse(lists: Sequence[Sequence[Hashable]], rrf_k: float = 60.0, top_k: int = 10) -> List[Tuple[Hashable, float]]:
+    """RRFusion.fuse (core/utils/Fusion.py:45-76) on bare keys (the reference keys on
+    `document.content`): rank = position + 1 in every list; score[key] += 1.0 / (k + rank) in list
+    order then position order (python float = fp64, first add is 0.0 + x); stable sort descending
+    (ties keep first-insertion order); top_k.  Returns [(key, score)]."""
+    scores = defaultdict(float)
+    for one in lists:
+        for i, key in enumerate(one):
+            scores[key] += 1.0 / (rrf_k + (i + 1))
+    ranked = sorted(scores.items(), key=lambda kv: kv[1], reverse=True)
+    return ranked[:top_k]
+
+
+def cosine_relevance(score: float) -> float:
+    """VectorStoreBase._cosine_relevance_score_fn (VectorStoreBase.py:263-266): 1.0 - score, applied
+    by the reference to what is already a similarity (quirk kept)."""
+    return 1.0 - score
+
+
+def max_inner_product_relevance(score: float) -> float:
+    """VectorStoreBase._max_inner_product_relevance_score_fn (VectorStoreBase.py:268-273)."""
+    if score > 0:
+        return 1.0 - score
+    return -1.0 * score
+
+
+# --------------------------------------------------------------------------------------- rerank
+def rerank_scores_f16(z_no: np.ndarray, z_yes: np.ndarray) -> np.ndarray:
+    """Reranker_Qwen3.py:41-49 on fp16 logits: exp(log_softmax([no, yes])[1]) where the
+    log_softmax output and the exp output are fp16 tensors (math in fp32).  Returns float16."""
+    zn = np.asarray(z_no, dtype=np.float16).astype(np.float32)
+    zy = np.asarray(z_yes, dtype=np.float16).astype(np.float32)
+    m = np.maximum(zn, zy)
+    s = np.exp(zn - m, dtype=np.float32) + np.exp(zy - m, dtype=np.float32)
+    ls = ((zy - m) - np.log(s, dtype=np.float32)).astype(np.float16)
+    return np.exp(ls.astype(np.float32), dtype=np.float32).astype(np.float16)
+
+
+def stable_desc_order(scores: np.ndarray) -> np.ndarray:
+    """Reranker_Qwen3.py:70-72: list.sort(key=score, reverse=True) — stable, ties keep input order."""
+    s = np.asarray(scores, dtype=np.float64)
+    return np.argsort(-s, kind="stable").astype(np.int32)

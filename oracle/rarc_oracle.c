@@ -1,0 +1,298 @@
+/*
+ * rarc_oracle.c — CPU ORACLE (test infrastructure, never shipped, never on the product path).
+ *
+ * A restatement of the arithmetic of RAG-ARC's dense-retrieval hot path, used only by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker / timed CPU baseline.
+ *
+ * PARITY STATUS: the reference reaches this arithmetic through faiss, which is NOT vendored in
+ * /root/reference (requirements.txt is empty, no version pinned) and is not installed here, and
+ * the reference holds no test, fixture or golden vector for it.  The flat
+ * search / normalise parts of this oracle are therefore "parity unpinned": they restate faiss's
+ * published contract — normalize_L2 = x * (1/sqrt(sum x^2)) in fp32 with zero rows untouched
+ * (fvec_renorm_L2), IndexFlatIP.search = exact fp32 inner products sorted by score descending,
+ * int64 labels, -1 padding — at the reference's call sites:
+ *   encapsulation/database/vector_db/VectorStore_Faiss.py:150-154  (_normalize_vectors)
+ *   encapsulation/database/vector_db/VectorStore_Faiss.py:170-202  (add_texts: astype(f32), normalise, add)
+ *   encapsulation/database/vector_db/VectorStore_Faiss.py:258-272  (query: astype(f32), normalise, k=min(k,ntotal), search)
+ * Two things faiss leaves implementation-defined are DEFINED here (and in DESIGN.md):
+ *   - summation order of an fp32 inner product / squared norm: the "canonical" order below
+ *     (8 interleaved fma chains + a fixed add tree; it is what an AVX2 loop computes);
+ *   - order among equal scores: id ascending.
+ * The RRF / retriever-control-flow / relevance-score parts of the oracle live in cpu_ref.py and
+ * ARE pinned against the reference's own importable code (tests/golden/make_golden.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -mavx2 -mfma -mf16c -fopenmp).
+ */
+#include <immintrin.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- fp16 <-> fp32, bit exact (IEEE round-to-nearest-even) ---------------------------------- */
+static inline float h2f(uint16_t h) { return _cvtsh_ss(h); }
+static inline uint16_t f2h(float f) { return _cvtss_sh(f, _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC); }
+
+/* portable versions, used by the self test to pin the intrinsics */
+static float h2f_soft(uint16_t h) {
+  uint32_t s = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff, u;
+  if (e == 0) {
+    if (m == 0) u = s;
+    else {
+      int sh = 0;
+      while (!(m & 0x400)) { m <<= 1; ++sh; }
+      u = s | ((uint32_t)(127 - 15 - sh + 1) << 23) | ((m & 0x3ff) << 13);
+    }
+  } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+  else u = s | ((e + 112) << 23) | (m << 13);
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/* ---- canonical fp32 reductions ---------------------------------------------------------------
+ * acc[j] (j = 0..7) = fma chain over elements 8m + j, m ascending, starting from +0;
+ * result = ((acc0 + acc4) + (acc2 + acc6)) + ((acc1 + acc5) + (acc3 + acc7)).
+ * d must be a multiple of 8 (rows are stored zero-padded).                                      */
+static inline float tree8(__m256 acc) {
+  __m128 lo = _mm256_castps256_ps128(acc), hi = _mm256_extractf128_ps(acc, 1);
+  __m128 s = _mm_add_ps(lo, hi);                       /* a0+a4, a1+a5, a2+a6, a3+a7 */
+  __m128 t = _mm_add_ps(s, _mm_movehl_ps(s, s));        /* (a0+a4)+(a2+a6), (a1+a5)+(a3+a7) */
+  return _mm_cvtss_f32(_mm_add_ss(t, _mm_shuffle_ps(t, t, 1)));
+}
+
+float oracle_canon_dot_f16(const float* q, const uint16_t* row, int d) {
+  __m256 acc = _mm256_setzero_ps();
+  for (int m = 0; m < d; m += 8) {
+    __m256 x = _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(row + m)));
+    acc = _mm256_fmadd_ps(_mm256_loadu_ps(q + m), x, acc);
+  }
+  return tree8(acc);
+}
+
+/* scalar statement of the same definition (self test: must equal the AVX2 version bit for bit) */
+float oracle_canon_dot_f16_scalar(const float* q, const uint16_t* row, int d) {
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = 0; m < d; m += 8)
+    for (int j = 0; j < 8; ++j) a[j] = fmaf(q[m + j], h2f_soft(row[m + j]), a[j]);
+  return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+}
+
+static float canon_sumsq_f32(const float* x, int d) { /* d arbitrary: tail treated as zeros */
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = 0; m < d; ++m) a[m & 7] = fmaf(x[m], x[m], a[m & 7]);
+  return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+}
+
+/* faiss.normalize_L2 (fvec_renorm_L2): in place, zero rows untouched */
+void oracle_normalize_rows_f32(float* x, int64_t ld, int64_t n, int d) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) {
+    float* v = x + r * ld;
+    const float nr = canon_sumsq_f32(v, d);
+    if (nr > 0) {
+      const float inv = (float)(1.0 / sqrtf(nr));
+      for (int m = 0; m < d; ++m) v[m] *= inv;
+    }
+  }
+}
+
+/* add_texts side: (normalise) -> fp16 rows of length d_pad, zero padded; optional squared norms */
+void oracle_ingest_f16(const float* in, int64_t ld, uint16_t* out, int d_pad, float* norm2, int64_t n, int d,
+                       int normalize) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) {
+    const float* v = in + r * ld;
+    uint16_t* o = out + r * (int64_t)d_pad;
+    float inv = 1.0f;
+    int scale = 0;
+    if (normalize) {
+      const float nr = canon_sumsq_f32(v, d);
+      if (nr > 0) { inv = (float)(1.0 / sqrtf(nr)); scale = 1; }
+    }
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < d_pad; ++m) {
+      uint16_t h = 0;
+      if (m < d) h = f2h(scale ? v[m] * inv : v[m]);
+      o[m] = h;
+      const float f = h2f(h);
+      a[m & 7] = fmaf(f, f, a[m & 7]);
+    }
+    if (norm2) norm2[r] = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+  }
+}
+
+/* ---- exact flat inner-product search (IndexFlatIP.search) ------------------------------------ */
+static inline uint32_t ordkey(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+static inline float unordkey(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+/* larger key == better: score descending, then row ascending */
+static inline uint64_t candkey(float s, uint32_t row) { return ((uint64_t)ordkey(s) << 32) | (uint64_t)(~row); }
+
+/* min-heap of the k best keys */
+static inline void heap_push(uint64_t* h, int* n, int k, uint64_t key) {
+  if (*n < k) {
+    int i = (*n)++;
+    while (i > 0 && h[(i - 1) / 2] > key) { h[i] = h[(i - 1) / 2]; i = (i - 1) / 2; }
+    h[i] = key;
+  } else if (key > h[0]) {
+    int i = 0;
+    for (;;) {
+      int c = 2 * i + 1;
+      if (c >= k) break;
+      if (c + 1 < k && h[c + 1] < h[c]) ++c;
+      if (h[c] >= key) break;
+      h[i] = h[c];
+      i = c;
+    }
+    h[i] = key;
+  }
+}
+static int cmp_desc_u64(const void* a, const void* b) {
+  const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return x < y ? 1 : (x > y ? -1 : 0);
+}
+
+/*
+ * corpus: [n][d_pad] fp16; q: [nq][d_pad] fp32 (already normalised if the metric needs it).
+ * out_ids / out_scores: [nq][k]; entries beyond min(k, n) are -1 / -inf.
+ * Returns the number of threads used.  Rows are blocked 4 at a time so a query vector load is
+ * shared by four accumulator chains (each chain is still exactly the canonical order).
+ */
+int oracle_flat_search_f16(const uint16_t* corpus, int64_t n, int d_pad, const float* q, int nq, int k,
+                           int64_t id_base, int64_t* out_ids, float* out_scores) {
+  int nthreads = 1;
+#ifdef _OPENMP
+  nthreads = omp_get_max_threads();
+#endif
+  if (k < 1 || nq < 1) return nthreads;
+  uint64_t* heaps = (uint64_t*)malloc((size_t)nthreads * nq * k * sizeof(uint64_t));
+  int* hn = (int*)calloc((size_t)nthreads * nq, sizeof(int));
+#pragma omp parallel
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    uint64_t* H = heaps + (size_t)tid * nq * k;
+    int* N = hn + (size_t)tid * nq;
+    float* rowf = (float*)aligned_alloc(32, (size_t)4 * d_pad * sizeof(float));
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t r0 = 0; r0 < n; r0 += 4) {
+      const int nr = (n - r0) < 4 ? (int)(n - r0) : 4;
+      for (int i = 0; i < 4; ++i) {
+        const uint16_t* src = corpus + (r0 + (i < nr ? i : 0)) * (int64_t)d_pad;
+        for (int m = 0; m < d_pad; m += 8)
+          _mm256_store_ps(rowf + i * d_pad + m, _mm256_cvtph_ps(_mm_loadu_si128((const __m128i*)(src + m))));
+      }
+      for (int qi = 0; qi < nq; ++qi) {
+        const float* qv = q + (size_t)qi * d_pad;
+        __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
+        for (int m = 0; m < d_pad; m += 8) {
+          const __m256 qq = _mm256_loadu_ps(qv + m);
+          a0 = _mm256_fmadd_ps(qq, _mm256_load_ps(rowf + m), a0);
+          a1 = _mm256_fmadd_ps(qq, _mm256_load_ps(rowf + d_pad + m), a1);
+          a2 = _mm256_fmadd_ps(qq, _mm256_load_ps(rowf + 2 * d_pad + m), a2);
+          a3 = _mm256_fmadd_ps(qq, _mm256_load_ps(rowf + 3 * d_pad + m), a3);
+        }
+        const float s[4] = {tree8(a0), tree8(a1), tree8(a2), tree8(a3)};
+        for (int i = 0; i < nr; ++i) heap_push(H + (size_t)qi * k, &N[qi], k, candkey(s[i], (uint32_t)(r0 + i)));
+      }
+    }
+    free(rowf);
+  }
+  uint64_t* all = (uint64_t*)malloc((size_t)nthreads * k * sizeof(uint64_t));
+  for (int qi = 0; qi < nq; ++qi) {
+    int c = 0;
+    for (int t = 0; t < nthreads; ++t) {
+      const int m = hn[(size_t)t * nq + qi];
+      memcpy(all + c, heaps + ((size_t)t * nq + qi) * k, (size_t)m * sizeof(uint64_t));
+      c += m;
+    }
+    qsort(all, (size_t)c, sizeof(uint64_t), cmp_desc_u64);
+    for (int i = 0; i < k; ++i) {
+      if (i < c) {
+        out_ids[(size_t)qi * k + i] = id_base + (int64_t)(uint32_t)(~(uint32_t)all[i]);
+        out_scores[(size_t)qi * k + i] = unordkey((uint32_t)(all[i] >> 32));
+      } else {
+        out_ids[(size_t)qi * k + i] = -1;
+        out_scores[(size_t)qi * k + i] = -INFINITY;
+      }
+    }
+  }
+  free(all);
+  free(heaps);
+  free(hn);
+  return nthreads;
+}
+
+/* canonical scores of selected rows (spot checks at sizes where a full search is too slow) */
+void oracle_score_rows_f16(const uint16_t* corpus, int d_pad, const float* qv, const int64_t* rows, int n,
+                           float* out) {
+  for (int i = 0; i < n; ++i) out[i] = oracle_canon_dot_f16(qv, corpus + rows[i] * (int64_t)d_pad, d_pad);
+}
+
+/* ---- deterministic synthetic rows (mirrors rag-arc_amd/csrc/prep.hip: rarc_synth_kernel) ------ */
+static inline uint64_t synth_mix(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+static inline int32_t synth_val(uint64_t seed, uint64_t row, uint32_t col) {
+  const uint64_t h = synth_mix(synth_mix(seed ^ (row * 0xd1342543de82ef95ull)) + col);
+  return (int32_t)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48)) - 131070;
+}
+static void synth_row(float* tmp, int d, uint64_t seed, uint64_t row) {
+  uint64_t ss = 0;
+  for (int c = 0; c < d; ++c) {
+    const int64_t v = synth_val(seed, row, (uint32_t)c);
+    ss += (uint64_t)(v * v);
+  }
+  const double scale = ss > 0 ? 1.0 / sqrt((double)ss) : 0.0;
+  for (int c = 0; c < d; ++c) tmp[c] = (float)((double)synth_val(seed, row, (uint32_t)c) * scale);
+}
+void oracle_synth_rows_f16(uint16_t* out, int d_pad, int d, int64_t first_row, int64_t n, uint64_t seed) {
+#pragma omp parallel
+  {
+    float* tmp = (float*)malloc((size_t)d * sizeof(float));
+#pragma omp for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+      synth_row(tmp, d, seed, (uint64_t)(first_row + r));
+      for (int c = 0; c < d_pad; ++c) out[r * (int64_t)d_pad + c] = c < d ? f2h(tmp[c]) : 0;
+    }
+    free(tmp);
+  }
+}
+void oracle_synth_rows_f32(float* out, int64_t ld, int d, int64_t first_row, int64_t n, uint64_t seed) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) synth_row(out + r * ld, d, seed, (uint64_t)(first_row + r));
+}
+
+/* ---- helpers exported for the python wrapper -------------------------------------------------- */
+void oracle_f32_to_f16(const float* in, uint16_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = f2h(in[i]);
+}
+int oracle_selftest(void) {
+  /* the F16C conversions must agree with the portable bit-level ones on every half value */
+  for (uint32_t h = 0; h < 65536; ++h) {
+    const float a = h2f((uint16_t)h), b = h2f_soft((uint16_t)h);
+    if (memcmp(&a, &b, 4) != 0 && !(a != a && b != b)) return 1;
+    if (a == a && f2h(a) != (uint16_t)h) return 2;
+  }
+  return 0;
+}
+int oracle_cpu_ok(void) {
+  return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma") && __builtin_cpu_supports("f16c");
+}

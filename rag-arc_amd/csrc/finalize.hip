@@ -1,0 +1,350 @@
+// finalize.hip — per-query: select the k' best scan candidates, rescore them with the
+// canonical fp32 scorer, certify exactness, sort (score desc, id asc), emit top-k.
+//
+// Completes faiss.IndexFlatIP.search (VectorStore_Faiss.py:263): the MFMA scan only
+// NOMINATES rows; the scores and order returned to the caller come from the canonical fp32
+// inner product of DESIGN.md §canonical-score, which oracle/rarc_oracle.c evaluates in the
+// same order, so ids and scores are bit-identical to the oracle's.
+//
+// Also: rarc_repair (exact single-query rescan) and rarc_topk_merge (multi-shard merge).
+#include "rarc_common.h"
+
+constexpr int FIN_THREADS = 256;
+
+// canonical fp32 dot of a fp32 query with an fp16 row (d multiple of 8)
+__device__ __forceinline__ float canon_dot_f16(const float* __restrict__ q,
+                                               const half_t* __restrict__ row, int d) {
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < d; m += 8) {
+    const half8 x = *(const half8*)(row + m);
+    const float4 q0 = *(const float4*)(q + m);
+    const float4 q1 = *(const float4*)(q + m + 4);
+    a[0] = __builtin_fmaf(q0.x, (float)x[0], a[0]);
+    a[1] = __builtin_fmaf(q0.y, (float)x[1], a[1]);
+    a[2] = __builtin_fmaf(q0.z, (float)x[2], a[2]);
+    a[3] = __builtin_fmaf(q0.w, (float)x[3], a[3]);
+    a[4] = __builtin_fmaf(q1.x, (float)x[4], a[4]);
+    a[5] = __builtin_fmaf(q1.y, (float)x[5], a[5]);
+    a[6] = __builtin_fmaf(q1.z, (float)x[6], a[6]);
+    a[7] = __builtin_fmaf(q1.w, (float)x[7], a[7]);
+  }
+  return rarc_canon_tree(a);
+}
+
+// in-LDS bitonic sort, descending, n = power of two, all threads of the block participate
+__device__ __forceinline__ void bitonic_desc(uint64_t* a, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t x = a[i], y = a[ixj];
+          const bool up = ((i & k) == 0);  // descending block
+          if (up ? (x < y) : (x > y)) {
+            a[i] = y;
+            a[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+struct FinParams {
+  const half_t* corpus;
+  const float* q32;  // [256][d]
+  const float* eps;  // [256]
+  const uint32_t* cnt;
+  const uint64_t* cand;
+  const uint32_t* hist;
+  uint32_t cap;
+  float bin_lo, bin_inv_scale;
+  int d;
+  int k, kprime;
+  int64_t id_base;
+  int64_t* out_ids;
+  float* out_scores;
+  uint32_t* status;
+};
+
+constexpr int FIN_SURV = 4096;  // survivors of the final-threshold compaction that get sorted
+
+// one workgroup per query
+__global__ __launch_bounds__(FIN_THREADS) void rarc_finalize_kernel(const FinParams p) {
+  __shared__ uint64_t keys[FIN_SURV];
+  __shared__ uint64_t fin[RARC_MAX_K];
+  __shared__ float s_thr, s_tmin;
+  __shared__ uint32_t s_ns;
+  const int q = blockIdx.x;
+  const uint32_t total = p.cnt[q];
+  const uint32_t n = total < p.cap ? total : p.cap;
+
+  // ---- tightest valid threshold from the final histogram (same rule as the scan's owner) ----
+  if (threadIdx.x == 0) {
+    const uint32_t* hq = p.hist + (size_t)q * RARC_NB;
+    uint32_t suf = 0;
+    int b = -1;
+    for (int i = RARC_NB - 1; i >= 0; --i) {
+      suf += hq[i];
+      if (suf >= (uint32_t)p.kprime) { b = i; break; }
+    }
+    s_thr = (b >= 2) ? p.bin_lo + (float)(b - 1) * p.bin_inv_scale : -INFINITY;
+    s_ns = 0;
+  }
+  __syncthreads();
+  const float thr = s_thr;
+  const uint64_t* src = p.cand + (size_t)q * p.cap;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const uint64_t key = src[i];
+    if (rarc_candscore(key) >= thr) {
+      const uint32_t pos = atomicAdd(&s_ns, 1u);
+      if (pos < FIN_SURV) keys[pos] = key;
+    }
+  }
+  __syncthreads();
+  const uint32_t ns_all = s_ns;
+  const int ns = ns_all < FIN_SURV ? (int)ns_all : FIN_SURV;
+  int np2 = 2;
+  while (np2 < ns) np2 <<= 1;
+  for (int i = ns + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0ull;
+  __syncthreads();
+  bitonic_desc(keys, np2);
+
+  // ---- the kp best by approximate score -> canonical rescore ----
+  const int kp = ns < p.kprime ? ns : p.kprime;
+  int fp2 = 2;
+  while (fp2 < kp) fp2 <<= 1;
+  const float* qv = p.q32 + (size_t)q * p.d;
+  for (int i = threadIdx.x; i < fp2; i += blockDim.x) {
+    uint64_t out = 0ull;
+    if (i < kp) {
+      const uint32_t row = rarc_candrow(keys[i]);
+      const float c = canon_dot_f16(qv, p.corpus + (size_t)row * p.d, p.d);
+      out = rarc_candkey(c, row);
+    }
+    fin[i] = out;
+  }
+  if (threadIdx.x == 0) s_tmin = (kp > 0) ? rarc_candscore(keys[kp - 1]) : -INFINITY;
+  __syncthreads();
+  bitonic_desc(fin, fp2);
+
+  // ---- certificate: no unselected row can reach the k-th canonical score ----
+  // every unselected row has approximate score <= t_min, hence canonical <= t_min + eps.
+  uint32_t st = RARC_Q_OK;
+  if (total > p.cap || ns_all > (uint32_t)FIN_SURV) st |= RARC_Q_OVERFLOW;
+  if ((int)n >= p.kprime && kp >= 1) {  // rows may have been left out: need the margin
+    const int kk = (p.k < kp ? p.k : kp) - 1;
+    const float sk = rarc_candscore(fin[kk]);
+    if (!(s_tmin + p.eps[q] < sk)) st |= RARC_Q_UNCERTAIN;
+  }
+  for (int i = threadIdx.x; i < p.k; i += blockDim.x) {
+    int64_t id = -1;
+    float sc = -INFINITY;
+    if (i < kp) {
+      id = p.id_base + (int64_t)rarc_candrow(fin[i]);
+      sc = rarc_candscore(fin[i]);
+    }
+    p.out_ids[(size_t)q * p.k + i] = id;
+    p.out_scores[(size_t)q * p.k + i] = sc;
+  }
+  if (threadIdx.x == 0) p.status[q] = st;
+}
+
+int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps, int nq,
+                         int k, int kprime, int64_t id_base, float bin_lo, float bin_hi, const RarcWs& ws,
+                         int cap, int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s) {
+  FinParams p;
+  p.corpus = (const half_t*)corpus;
+  p.q32 = q32;
+  p.eps = eps;
+  p.cnt = ws.cnt;
+  p.cand = ws.cand;
+  p.hist = ws.hist;
+  p.cap = (uint32_t)cap;
+  p.bin_lo = bin_lo;
+  p.bin_inv_scale = (bin_hi - bin_lo) / (float)RARC_NB;
+  p.d = d_pad;
+  p.k = k;
+  p.kprime = kprime;
+  p.id_base = id_base;
+  p.out_ids = out_ids;
+  p.out_scores = out_scores;
+  p.status = status;
+  hipLaunchKernelGGL(rarc_finalize_kernel, dim3(nq), dim3(FIN_THREADS), 0, s, p);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+// ============================================================================================
+// Exact repair of one query: full canonical scan of the shard; rows that beat the current k-th
+// entry are appended; then the row is re-sorted.  O(n_rows * d) reads — the rare path.
+// ============================================================================================
+struct RepairParams {
+  const half_t* corpus;
+  const float* qv;  // [d]
+  uint32_t n_rows;
+  int d, k;
+  int64_t id_base;
+  int64_t* ids;   // [k] in/out
+  float* scores;  // [k] in/out
+  uint64_t* list; // scratch [cap]
+  uint32_t* count;
+  uint32_t cap;
+};
+
+__global__ __launch_bounds__(256) void rarc_repair_scan_kernel(const RepairParams p) {
+  // current k-th entry (worst kept).  -1 id == "fewer than k rows so far": everything beats it.
+  const int64_t kid = p.ids[p.k - 1];
+  const float ks = p.scores[p.k - 1];
+  const uint64_t kth = (kid < 0) ? 0ull : rarc_candkey(ks, (uint32_t)(kid - p.id_base));
+  for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < p.n_rows; r += gridDim.x * blockDim.x) {
+    const float c = canon_dot_f16(p.qv, p.corpus + (size_t)r * p.d, p.d);
+    const uint64_t key = rarc_candkey(c, r);
+    if (key > kth) {
+      const uint32_t pos = atomicAdd(p.count, 1u);
+      if (pos < p.cap) p.list[pos] = key;
+    }
+  }
+}
+
+// merge: list holds every row strictly better than the old k-th (it includes the old top k-1
+// themselves, because they also beat the old k-th), so top-k(list ∪ {old k-th}) is exact.
+__global__ __launch_bounds__(256) void rarc_repair_merge_kernel(const RepairParams p, uint32_t* found) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* keys = (uint64_t*)smem;
+  const uint32_t total = *p.count;
+  const uint32_t n = total < p.cap ? total : p.cap;
+  int np2 = 2;
+  while (np2 < (int)n + 1) np2 <<= 1;
+  const int64_t kid = p.ids[p.k - 1];
+  const uint64_t kth = (kid < 0) ? 0ull : rarc_candkey(p.scores[p.k - 1], (uint32_t)(kid - p.id_base));
+  for (int i = threadIdx.x; i < np2; i += blockDim.x)
+    keys[i] = (i < (int)n) ? p.list[i] : (i == (int)n ? kth : 0ull);
+  __syncthreads();
+  bitonic_desc(keys, np2);
+  // rows found beyond the k-1 that were already listed
+  if (threadIdx.x == 0) {
+    uint32_t old_better = 0;  // old entries 0..k-2 that are real
+    for (int i = 0; i < p.k - 1; ++i) old_better += (p.ids[i] >= 0);
+    *found = (total > old_better) ? (total - old_better) : 0u;
+    if (total > p.cap) *found |= 0x80000000u;  // scratch overflow: result not trustworthy
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.k; i += blockDim.x) {
+    const uint64_t key = keys[i];
+    if (key != 0ull) {
+      p.ids[i] = p.id_base + (int64_t)rarc_candrow(key);
+      p.scores[i] = rarc_candscore(key);
+    } else {
+      p.ids[i] = -1;
+      p.scores[i] = -INFINITY;
+    }
+  }
+}
+
+int rarc_repair_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const float* qv, int k,
+                       int64_t id_base, int64_t* ids, float* scores, uint32_t* found, const RarcWs& ws,
+                       int cap, hipStream_t s) {
+  RepairParams p;
+  p.corpus = (const half_t*)corpus;
+  p.qv = qv;
+  p.n_rows = (uint32_t)n_rows;
+  p.d = d_pad;
+  p.k = k;
+  p.id_base = id_base;
+  p.ids = ids;
+  p.scores = scores;
+  p.list = ws.cand;
+  p.count = ws.cnt;  // cnt[0] reused as the append counter
+  p.cap = (uint32_t)(cap < 8192 ? cap : 8192);
+  RARC_HIP_CHECK(hipMemsetAsync(p.count, 0, 4, s));
+  const int grid = 2048;
+  hipLaunchKernelGGL(rarc_repair_scan_kernel, dim3(grid), dim3(256), 0, s, p);
+  RARC_HIP_CHECK(hipGetLastError());
+  int np2 = 2;
+  while (np2 < (int)p.cap + 1) np2 <<= 1;
+  const size_t lds = (size_t)np2 * 8;
+  static size_t lds_attr = 0;
+  if (lds > lds_attr) {
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_repair_merge_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_attr = lds;
+  }
+  hipLaunchKernelGGL(rarc_repair_merge_kernel, dim3(1), dim3(256), lds, s, p, found);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+// ============================================================================================
+// Multi-shard merge: [G][nq][k] sorted lists -> [nq][k]  (score desc, id asc)
+// ============================================================================================
+__global__ __launch_bounds__(256) void rarc_merge_kernel(const int64_t* ids, const float* scores, int G,
+                                                         int nq, int k, int64_t* out_ids,
+                                                         float* out_scores) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // 128-bit sort key split in two arrays: (ordkey(score), ~id) compared lexicographically
+  uint32_t* sk = (uint32_t*)smem;
+  const int q = blockIdx.x;
+  const int n = G * k;
+  int np2 = 2;
+  while (np2 < n) np2 <<= 1;
+  int64_t* sid = (int64_t*)(smem + (size_t)np2 * 4);
+  for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+    uint32_t key = 0;
+    int64_t id = INT64_MAX;
+    if (i < n) {
+      const int g = i / k, j = i % k;
+      const size_t o = ((size_t)g * nq + q) * k + j;
+      id = ids[o];
+      if (id >= 0) key = rarc_ordkey(scores[o]);
+      else id = INT64_MAX;
+    }
+    sk[i] = key;
+    sid[i] = id;
+  }
+  __syncthreads();
+  for (int kk = 2; kk <= np2; kk <<= 1) {
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t ka = sk[i], kb = sk[ixj];
+          const int64_t ia = sid[i], ib = sid[ixj];
+          // "x better than y": higher score, then lower id
+          const bool a_better = (ka > kb) || (ka == kb && ia < ib);
+          const bool b_better = (kb > ka) || (ka == kb && ib < ia);
+          const bool up = ((i & kk) == 0);
+          if (up ? b_better : a_better) {
+            sk[i] = kb; sk[ixj] = ka;
+            sid[i] = ib; sid[ixj] = ia;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    const bool valid = (i < n) && sid[i] != INT64_MAX;
+    out_ids[(size_t)q * k + i] = valid ? sid[i] : -1;
+    out_scores[(size_t)q * k + i] = valid ? rarc_unordkey(sk[i]) : -INFINITY;
+  }
+}
+
+int rarc_merge_launch(const int64_t* ids, const float* scores, int G, int nq, int k, int64_t* out_ids,
+                      float* out_scores, hipStream_t s) {
+  int np2 = 2;
+  while (np2 < G * k) np2 <<= 1;
+  const size_t lds = (size_t)np2 * 12;
+  RARC_REQUIRE(lds <= 160 * 1024, RARC_E_UNSUPPORTED, "rarc_topk_merge: %d lists x k=%d too large", G, k);
+  static size_t lds_attr = 0;
+  if (lds > lds_attr) {
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_merge_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_attr = lds;
+  }
+  hipLaunchKernelGGL(rarc_merge_kernel, dim3(nq), dim3(256), lds, s, ids, scores, G, nq, k, out_ids,
+                     out_scores);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

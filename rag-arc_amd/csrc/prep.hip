@@ -1,0 +1,219 @@
+// prep.hip — row-wise kernels either side of the scan:
+//   rarc_l2norm_rows_f32   faiss.normalize_L2            (VectorStore_Faiss.py:150-154)
+//   rarc_ingest_f16        normalise + index.add as fp16 (VectorStore_Faiss.py:178, :199-202)
+//   rarc_prep_queries      np.array([q]).astype(f32) + normalise (VectorStore_Faiss.py:258-259)
+//   rarc_synth_rows_*      deterministic synthetic data (bench / property tests)
+//
+// All reductions use the canonical 8-lane order: lane j of an 8-lane group owns elements
+// 8m+j (m ascending, one fma per element), then tree ((a0+a4)+(a2+a6))+((a1+a5)+(a3+a7)).
+// oracle/rarc_oracle.c uses the same order, so normalised rows are bit-identical.
+// HBM-bound streaming kernels: 8 rows per wave, 32 contiguous bytes per row per step.
+#include "rarc_common.h"
+
+__device__ __forceinline__ float group8_tree_f32(float acc, int lane) {
+  const int base = lane & ~7;
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = __shfl(acc, base + j, 64);
+  return rarc_canon_tree(a);
+}
+__device__ __forceinline__ double group8_tree_f64(double acc, int lane) {
+  const int base = lane & ~7;
+  double a[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = __shfl(acc, base + j, 64);
+  return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+}
+
+// inv norm exactly as faiss: (float)(1.0 / sqrtf(nr)), evaluated in double like the C expression
+__device__ __forceinline__ float inv_norm(float nr) { return (float)(1.0 / (double)__fsqrt_rn(nr)); }
+
+__global__ __launch_bounds__(256) void rarc_l2norm_kernel(const float* in, int64_t ld_in, float* out,
+                                                          int64_t ld_out, int64_t n_rows, int d) {
+  const int lane = threadIdx.x & 63, j = threadIdx.x & 7;
+  const int64_t rows_per_block = blockDim.x / 8;
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < n_rows; r0 += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t r = r0 + threadIdx.x / 8;
+    const bool live = r < n_rows;
+    const float* x = in + (live ? r : 0) * ld_in;
+    float acc = 0.f;
+    if (live)
+      for (int m = j; m < d; m += 8) acc = __builtin_fmaf(x[m], x[m], acc);
+    const float nr = group8_tree_f32(acc, lane);
+    if (live) {
+      float* y = out + r * ld_out;
+      if (nr > 0.f) {
+        const float inv = inv_norm(nr);
+        for (int m = j; m < d; m += 8) y[m] = x[m] * inv;
+      } else if (y != x) {
+        for (int m = j; m < d; m += 8) y[m] = x[m];
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rarc_ingest_kernel(const float* in, int64_t ld_in, half_t* out,
+                                                          int d_pad, float* row_norm2, int64_t n_rows,
+                                                          int d, int normalize) {
+  const int lane = threadIdx.x & 63, j = threadIdx.x & 7;
+  const int64_t rows_per_block = blockDim.x / 8;
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < n_rows; r0 += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t r = r0 + threadIdx.x / 8;
+    const bool live = r < n_rows;
+    const float* x = in + (live ? r : 0) * ld_in;
+    float acc = 0.f;
+    if (live && normalize)
+      for (int m = j; m < d; m += 8) acc = __builtin_fmaf(x[m], x[m], acc);
+    const float nr = group8_tree_f32(acc, lane);
+    const float inv = (normalize && nr > 0.f) ? inv_norm(nr) : 1.f;
+    float acc2 = 0.f;
+    if (live) {
+      half_t* y = out + r * d_pad;
+      for (int m = j; m < d_pad; m += 8) {
+        half_t hv = (half_t)0.f;
+        if (m < d) hv = (half_t)((normalize && nr > 0.f) ? x[m] * inv : x[m]);
+        y[m] = hv;
+        const float f = (float)hv;
+        acc2 = __builtin_fmaf(f, f, acc2);
+      }
+    }
+    const float n2 = group8_tree_f32(acc2, lane);
+    if (live && row_norm2 && j == 0) row_norm2[r] = n2;
+  }
+}
+
+// one 8-lane group per query row (all RARC_MAX_QUERIES rows are written; padding rows are zero)
+__global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in, int64_t ld_in, int nq, int d,
+                                                                int d_pad, int normalize, float corpus_max_norm,
+                                                                float* q32, half_t* q16, float* eps) {
+  const int lane = threadIdx.x & 63, j = threadIdx.x & 7;
+  const int r = blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
+  if (r >= RARC_MAX_QUERIES) return;  // whole groups exit together
+  const bool live = r < nq;
+  const float* x = in + (size_t)(live ? r : 0) * ld_in;
+  float acc = 0.f;
+  if (live && normalize)
+    for (int m = j; m < d; m += 8) acc = __builtin_fmaf(x[m], x[m], acc);
+  const float nr = group8_tree_f32(acc, lane);
+  const bool scale = live && normalize && nr > 0.f;
+  const float inv = scale ? inv_norm(nr) : 1.f;
+  double dn = 0.0, qn = 0.0;
+  float* y32 = q32 + (size_t)r * d_pad;
+  half_t* y16 = q16 + (size_t)r * d_pad;
+  for (int m = j; m < d_pad; m += 8) {
+    float v = 0.f;
+    if (live && m < d) v = scale ? x[m] * inv : x[m];
+    const half_t hv = (half_t)v;
+    y32[m] = v;
+    y16[m] = hv;
+    const double df = (double)v - (double)(float)hv;
+    dn += df * df;
+    qn += (double)v * (double)v;
+  }
+  dn = group8_tree_f64(dn, lane);
+  qn = group8_tree_f64(qn, lane);
+  if (j == 0) {
+    // |approx - canonical| <= ||q32 - q16||·||d|| + (fp32 accumulation, both sides) ||q||·||d||
+    const double acc_err = 8.0 * (double)d_pad * 5.9604644775390625e-08;  // 8·d·2^-24
+    const double e = (sqrt(dn) + acc_err * sqrt(qn)) * (double)corpus_max_norm * 1.01 + 1e-30;
+    eps[r] = live ? (float)e * 1.0001f : 0.f;
+  }
+}
+
+// ---- synthetic rows ---------------------------------------------------------------------------
+// v(seed,row,col) = sum of four 16-bit uniforms - 131070 (Irwin-Hall, approx normal, exact int)
+__host__ __device__ static inline uint64_t synth_mix(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__host__ __device__ static inline int32_t synth_val(uint64_t seed, uint64_t row, uint32_t col) {
+  const uint64_t h = synth_mix(synth_mix(seed ^ (row * 0xd1342543de82ef95ull)) + col);
+  return (int32_t)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48)) - 131070;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void rarc_synth_kernel(void* out, int64_t ld_out, int d_fill, int d,
+                                                         int64_t first_row, int64_t n_rows, uint64_t seed) {
+  // one wave per row: exact integer sum of squares (order free), fp64 scale, one rounding to f32
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t r = (int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64; r < n_rows; r += waves) {
+    const uint64_t row = (uint64_t)(first_row + r);
+    uint64_t ss = 0;
+    for (int c = lane; c < d; c += 64) {
+      const int64_t v = synth_val(seed, row, (uint32_t)c);
+      ss += (uint64_t)(v * v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const double scale = (ss > 0) ? 1.0 / sqrt((double)ss) : 0.0;
+    for (int c = lane; c < d_fill; c += 64) {
+      float f = 0.f;
+      if (c < d) f = (float)((double)synth_val(seed, row, (uint32_t)c) * scale);
+      if (F16) ((half_t*)out)[r * ld_out + c] = (half_t)f;
+      else ((float*)out)[r * ld_out + c] = f;
+    }
+  }
+}
+
+static int grid_for(int64_t units, int per_block, int cap = 4096) {
+  int64_t g = (units + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+extern "C" int rarc_l2norm_rows_f32(const float* d_in, int64_t ld_in, float* d_out, int64_t ld_out,
+                                    int64_t n_rows, int d, void* stream) {
+  RARC_REQUIRE(d_in && d_out && d > 0 && n_rows >= 0, RARC_E_INVALID, "rarc_l2norm_rows_f32: bad arguments");
+  if (n_rows == 0) return RARC_OK;
+  hipLaunchKernelGGL(rarc_l2norm_kernel, dim3(grid_for(n_rows, 32)), dim3(256), 0, (hipStream_t)stream,
+                     d_in, ld_in, d_out, ld_out, n_rows, d);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_corpus_f16, int d_pad,
+                               float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream) {
+  RARC_REQUIRE(d_in && d_corpus_f16 && d > 0 && d_pad >= d && d_pad % 8 == 0 && n_rows >= 0, RARC_E_INVALID,
+               "rarc_ingest_f16: bad arguments");
+  if (n_rows == 0) return RARC_OK;
+  hipLaunchKernelGGL(rarc_ingest_kernel, dim3(grid_for(n_rows, 32)), dim3(256), 0, (hipStream_t)stream, d_in,
+                     ld_in, (half_t*)d_corpus_f16, d_pad, d_row_norm2, n_rows, d, normalize);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad, int normalize,
+                                 float corpus_max_norm, float* d_q32, uint16_t* d_q16, float* d_eps,
+                                 void* stream) {
+  RARC_REQUIRE(d_in && d_q32 && d_q16 && d_eps && d > 0 && d_pad >= d && d_pad % 8 == 0 && nq >= 0 &&
+                   nq <= RARC_MAX_QUERIES,
+               RARC_E_INVALID, "rarc_prep_queries: bad arguments (nq=%d d=%d d_pad=%d)", nq, d, d_pad);
+  hipLaunchKernelGGL(rarc_prep_queries_kernel, dim3(RARC_MAX_QUERIES / 32), dim3(256), 0, (hipStream_t)stream,
+                     d_in, ld_in, nq, d, d_pad, normalize, corpus_max_norm, d_q32, (half_t*)d_q16, d_eps);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_synth_rows_f16(uint16_t* d_out_f16, int d_pad, int d, int64_t first_row, int64_t n_rows,
+                                   uint64_t seed, void* stream) {
+  RARC_REQUIRE(d_out_f16 && d > 0 && d_pad >= d && n_rows >= 0, RARC_E_INVALID, "rarc_synth_rows_f16: bad arguments");
+  if (n_rows == 0) return RARC_OK;
+  hipLaunchKernelGGL(rarc_synth_kernel<true>, dim3(grid_for(n_rows, 4, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (void*)d_out_f16, (int64_t)d_pad, d_pad, d, first_row, n_rows, seed);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_row, int64_t n_rows,
+                                   uint64_t seed, void* stream) {
+  RARC_REQUIRE(d_out_f32 && d > 0 && ld_out >= d && n_rows >= 0, RARC_E_INVALID, "rarc_synth_rows_f32: bad arguments");
+  if (n_rows == 0) return RARC_OK;
+  hipLaunchKernelGGL(rarc_synth_kernel<false>, dim3(grid_for(n_rows, 4, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (void*)d_out_f32, ld_out, d, d, first_row, n_rows, seed);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

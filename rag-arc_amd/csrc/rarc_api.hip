@@ -1,0 +1,95 @@
+// rarc_api.hip — C-ABI entry points that chain the kernels (see include/rarc.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include "rarc_common.h"
+
+int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq,
+                         int kprime, float bin_lo, float bin_hi, const RarcWs& ws, int cap, hipStream_t s);
+int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps, int nq,
+                         int k, int kprime, int64_t id_base, float bin_lo, float bin_hi, const RarcWs& ws,
+                         int cap, int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s);
+int rarc_repair_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const float* qv, int k,
+                       int64_t id_base, int64_t* ids, float* scores, uint32_t* found, const RarcWs& ws,
+                       int cap, hipStream_t s);
+int rarc_merge_launch(const int64_t* ids, const float* scores, int G, int nq, int k, int64_t* out_ids,
+                      float* out_scores, hipStream_t s);
+
+static thread_local char g_err[512] = "";
+
+void rarc_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int rarc_version(void) { return RARC_VERSION; }
+extern "C" const char* rarc_last_error(void) { return g_err; }
+extern "C" int rarc_padded_dim(int d) {
+  return d <= 0 ? 0 : ((d + RARC_DIM_ALIGN - 1) / RARC_DIM_ALIGN) * RARC_DIM_ALIGN;
+}
+
+extern "C" size_t rarc_search_workspace_bytes(int cand_cap) {
+  if (cand_cap < 1024) cand_cap = 1024;
+  return RARC_WS_CAND + (size_t)RARC_MAX_QUERIES * (size_t)cand_cap * 8;
+}
+
+static int check_ws(void* ws, size_t bytes, int cap, const char* who) {
+  RARC_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256) == 0, RARC_E_WORKSPACE,
+               "%s: workspace must be a 256-byte aligned device pointer", who);
+  RARC_REQUIRE(cap >= 1024 && bytes >= rarc_search_workspace_bytes(cap), RARC_E_WORKSPACE,
+               "%s: workspace of %zu bytes too small for cand_cap=%d (need %zu)", who, bytes, cap,
+               rarc_search_workspace_bytes(cap));
+  return RARC_OK;
+}
+
+extern "C" int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_q32,
+                               const uint16_t* d_q16, const float* d_eps, int nq, int k, int kprime,
+                               int64_t id_base, float bin_lo, float bin_hi, int64_t* d_out_ids,
+                               float* d_out_scores, uint32_t* d_status, void* d_workspace,
+                               size_t workspace_bytes, int cand_cap, void* stream) {
+  RARC_REQUIRE(d_q32 && d_q16 && d_eps && d_out_ids && d_out_scores && d_status, RARC_E_INVALID,
+               "rarc_search_f16: null pointer");
+  RARC_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll, RARC_E_INVALID,
+               "rarc_search_f16: n_rows=%lld outside [0, 2^32-32)", (long long)n_rows);
+  RARC_REQUIRE(d_corpus_f16 || n_rows == 0, RARC_E_INVALID, "rarc_search_f16: null corpus");
+  RARC_REQUIRE(nq >= 0 && nq <= RARC_MAX_QUERIES, RARC_E_INVALID, "rarc_search_f16: nq=%d outside [0,%d]", nq,
+               RARC_MAX_QUERIES);
+  RARC_REQUIRE(k >= 1 && k <= kprime && kprime <= RARC_MAX_K, RARC_E_INVALID,
+               "rarc_search_f16: need 1 <= k (%d) <= kprime (%d) <= %d", k, kprime, RARC_MAX_K);
+  RARC_REQUIRE(bin_hi > bin_lo, RARC_E_INVALID, "rarc_search_f16: empty histogram range");
+  int rc = check_ws(d_workspace, workspace_bytes, cand_cap, "rarc_search_f16");
+  if (rc) return rc;
+  if (nq == 0) return RARC_OK;
+  const RarcWs ws = rarc_ws_carve(d_workspace);
+  hipStream_t s = (hipStream_t)stream;
+  rc = rarc_scan_f16_launch(d_corpus_f16, n_rows, d_pad, d_q16, nq, kprime, bin_lo, bin_hi, ws, cand_cap, s);
+  if (rc) return rc;
+  return rarc_finalize_launch(d_corpus_f16, d_pad, d_q32, d_eps, nq, k, kprime, id_base, bin_lo, bin_hi, ws,
+                              cand_cap, d_out_ids, d_out_scores, d_status, s);
+}
+
+extern "C" int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_q32,
+                               int q, int k, int64_t id_base, int64_t* d_out_ids, float* d_out_scores,
+                               uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream) {
+  RARC_REQUIRE(d_corpus_f16 && d_q32 && d_out_ids && d_out_scores && d_found, RARC_E_INVALID,
+               "rarc_repair_f16: null pointer");
+  RARC_REQUIRE(q >= 0 && q < RARC_MAX_QUERIES && k >= 1 && k <= RARC_MAX_K && d_pad % 8 == 0 && n_rows >= 0 &&
+                   n_rows < (int64_t)0xffffffe0ll,
+               RARC_E_INVALID, "rarc_repair_f16: bad arguments (q=%d k=%d)", q, k);
+  int rc = check_ws(d_workspace, workspace_bytes, 1024, "rarc_repair_f16");
+  if (rc) return rc;
+  const int cap = (int)((workspace_bytes - RARC_WS_CAND) / 8);
+  const RarcWs ws = rarc_ws_carve(d_workspace);
+  return rarc_repair_launch(d_corpus_f16, n_rows, d_pad, d_q32 + (size_t)q * d_pad, k, id_base,
+                            d_out_ids + (size_t)q * k, d_out_scores + (size_t)q * k, d_found, ws, cap,
+                            (hipStream_t)stream);
+}
+
+extern "C" int rarc_topk_merge(const int64_t* d_ids, const float* d_scores, int n_lists, int nq, int k,
+                               int64_t* d_out_ids, float* d_out_scores, void* stream) {
+  RARC_REQUIRE(d_ids && d_scores && d_out_ids && d_out_scores, RARC_E_INVALID, "rarc_topk_merge: null pointer");
+  RARC_REQUIRE(n_lists >= 1 && nq >= 0 && k >= 1, RARC_E_INVALID, "rarc_topk_merge: bad sizes");
+  if (nq == 0) return RARC_OK;
+  return rarc_merge_launch(d_ids, d_scores, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream);
+}

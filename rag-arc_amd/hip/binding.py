@@ -1,0 +1,82 @@
+"""ctypes binding of librarc_hip.so (C-ABI declared in include/rarc.h).
+
+There is no CPU fallback: if the library is missing or a call fails, a RarcError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = os.path.join(_PKG, "lib", "librarc_hip.so")
+
+MAX_QUERIES = 256
+MAX_K = 1024
+DIM_ALIGN = 128
+Q_UNCERTAIN = 1
+Q_OVERFLOW = 2
+
+
+class RarcError(RuntimeError):
+    """Raised for every non-zero status returned by librarc_hip.so."""
+
+
+_lock = threading.Lock()
+_lib = None
+
+# name -> (restype, argtypes); every symbol include/rarc.h declares is listed here
+SIGNATURES = {
+    "rarc_version": (c_int, []),
+    "rarc_last_error": (ctypes.c_char_p, []),
+    "rarc_padded_dim": (c_int, [c_int]),
+    "rarc_l2norm_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "rarc_ingest_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rarc_prep_queries": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
+    "rarc_search_workspace_bytes": (c_size_t, [c_int]),
+    "rarc_search_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_int, c_void_p]),
+    "rarc_repair_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rarc_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_rrf_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p,
+                              c_void_p, c_void_p]),
+    "rarc_rerank_order": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_synth_rows_f16": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_uint64, c_void_p]),
+    "rarc_synth_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_uint64, c_void_p]),
+}
+
+
+def library_path() -> str:
+    return _LIB
+
+
+def load_library() -> ctypes.CDLL:
+    """Load librarc_hip.so once; raise RarcError if it is not built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(_LIB):
+                raise RarcError(
+                    f"{_LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(there is no CPU fallback)")
+            lib = ctypes.CDLL(_LIB)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load_library().rarc_last_error()
+        raise RarcError(f"{what or 'librarc_hip'} failed ({rc}): {msg.decode() if msg else '?'}")
+
+
+def padded_dim(d: int) -> int:
+    return ((d + DIM_ALIGN - 1) // DIM_ALIGN) * DIM_ALIGN

@@ -1,0 +1,223 @@
+"""HBM-resident flat inner-product index (fp16 rows) driven through librarc_hip.so.
+
+This is the device-side replacement for the `faiss.IndexFlatIP` object that
+`FaissVectorStore` holds (encapsulation/database/vector_db/VectorStore_Faiss.py:112-136, :199-202,
+:262-263): `add` == normalise + index.add, `search` == normalise + index.search.  torch is used for
+device memory and streams only; all arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import threading
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import binding as B
+
+_ROW_ALIGN = 32  # the scan reads whole 32-row tiles
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise B.RarcError("no ROCm device visible: the HIP backend has no CPU fallback")
+    return torch
+
+
+class FlatIndexF16:
+    """Exact top-k inner-product search over fp16 rows resident in HBM.
+
+    metric "cosine": rows and queries are L2-normalised in fp32 before use (faiss.normalize_L2);
+    metric "ip": raw inner product.  Returned scores are the canonical fp32 inner products of the
+    fp32 query with the stored fp16 rows; ties are ordered by id ascending.
+    """
+
+    def __init__(self, dim: int, metric: str = "cosine", device: int = 0, capacity: int = 0,
+                 id_base: int = 0, cand_cap: int = 16384):
+        if metric not in ("cosine", "ip"):
+            raise ValueError(f"unsupported metric: {metric}")
+        if dim <= 0:
+            raise ValueError("dim must be positive")
+        self.torch = _torch()
+        self.lib = B.load_library()
+        self.dim = int(dim)
+        self.d_pad = B.padded_dim(self.dim)
+        if self.d_pad > 768:
+            raise B.RarcError(f"dim {dim} pads to {self.d_pad} > 768: not supported by the fp16 scan kernel yet")
+        self.metric = metric
+        self.device = self.torch.device("cuda", device)
+        self.id_base = int(id_base)
+        self.cand_cap = int(cand_cap)
+        self.ntotal = 0
+        self.max_norm = 0.0
+        self._rows = None  # torch.float16 [capacity][d_pad]
+        self._lock = threading.Lock()  # callers may be pool threads (core/retrieval/base.py:92-96)
+        self._ws = None
+        self._qbuf = None
+        if capacity:
+            self.reserve(capacity)
+
+    # ------------------------------------------------------------------ memory
+    def reserve(self, n_rows: int) -> None:
+        t = self.torch
+        cap = ((int(n_rows) + _ROW_ALIGN - 1) // _ROW_ALIGN) * _ROW_ALIGN
+        if self._rows is not None and self._rows.shape[0] >= cap:
+            return
+        new = t.zeros((cap, self.d_pad), dtype=t.float16, device=self.device)
+        if self._rows is not None and self.ntotal:
+            new[: self.ntotal].copy_(self._rows[: self.ntotal])
+        self._rows = new
+
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _workspace(self):
+        t = self.torch
+        if self._ws is None:
+            nbytes = self.lib.rarc_search_workspace_bytes(self.cand_cap)
+            self._ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+            mq = B.MAX_QUERIES
+            self._qbuf = dict(
+                q32=t.empty((mq, self.d_pad), dtype=t.float32, device=self.device),
+                q16=t.empty((mq, self.d_pad), dtype=t.float16, device=self.device),
+                eps=t.empty(mq, dtype=t.float32, device=self.device),
+                status=t.empty(mq, dtype=t.int32, device=self.device),
+                found=t.empty(1, dtype=t.int32, device=self.device),
+            )
+        return self._ws
+
+    @property
+    def rows(self):
+        """The stored fp16 rows as a torch view [ntotal][d_pad]."""
+        return None if self._rows is None else self._rows[: self.ntotal]
+
+    # ------------------------------------------------------------------ add
+    def add(self, vectors) -> None:
+        """index.add: fp32 vectors [n][dim] (numpy or torch) -> normalise (cosine) -> fp16 rows."""
+        t = self.torch
+        with self._lock, t.cuda.device(self.device):
+            x = t.as_tensor(vectors, dtype=t.float32).to(self.device).contiguous()
+            if x.ndim != 2 or x.shape[1] != self.dim:
+                raise ValueError(f"expected [n][{self.dim}] vectors, got {tuple(x.shape)}")
+            n = x.shape[0]
+            if n == 0:
+                return
+            if self._rows is None or self.ntotal + n > self._rows.shape[0]:
+                self.reserve(max(self.ntotal + n, 2 * self.ntotal))
+            norm2 = t.empty(n, dtype=t.float32, device=self.device)
+            dst = self._rows[self.ntotal: self.ntotal + n]
+            B.check(self.lib.rarc_ingest_f16(x.data_ptr(), x.shape[1], dst.data_ptr(), self.d_pad,
+                                             norm2.data_ptr(), n, self.dim,
+                                             1 if self.metric == "cosine" else 0, self._stream()),
+                    "rarc_ingest_f16")
+            self.max_norm = max(self.max_norm, float(norm2.max().sqrt().item()))
+            self.ntotal += n
+
+    def add_rows_f16(self, rows_f16, max_norm: float) -> None:
+        """Adopt rows that are already in storage format ([n][d_pad] fp16 on this device)."""
+        t = self.torch
+        with self._lock:
+            if rows_f16.dtype != t.float16 or rows_f16.shape[1] != self.d_pad:
+                raise ValueError("rows must be float16 [n][d_pad]")
+            if self.ntotal == 0 and rows_f16.shape[0] % _ROW_ALIGN == 0 and rows_f16.is_contiguous():
+                self._rows = rows_f16
+            else:
+                self.reserve(self.ntotal + rows_f16.shape[0])
+                self._rows[self.ntotal: self.ntotal + rows_f16.shape[0]].copy_(rows_f16)
+            self.ntotal += rows_f16.shape[0]
+            self.max_norm = max(self.max_norm, float(max_norm))
+
+    def reset(self) -> None:
+        with self._lock:
+            self.ntotal = 0
+            self.max_norm = 0.0
+
+    # ------------------------------------------------------------------ search
+    @staticmethod
+    def kprime_for(k: int) -> int:
+        return min(B.MAX_K, max(k + 28, (k * 5 + 3) // 4))
+
+    def search(self, queries, k: int, repair: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+        """index.search: returns (scores fp32 [nq][k], ids int64 [nq][k]) like faiss (D, I);
+        entries beyond ntotal are (-inf, -1)."""
+        ids, scores = self.search_device(queries, k, repair=repair)
+        return scores.cpu().numpy(), ids.cpu().numpy()
+
+    def search_device(self, queries, k: int, repair: bool = True):
+        """Same as search() but returns device tensors (ids int64, scores fp32)."""
+        t = self.torch
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        if k > B.MAX_K:
+            raise B.RarcError(f"k={k} exceeds the kernel limit {B.MAX_K}")
+        with self._lock, t.cuda.device(self.device):
+            q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
+            if q.ndim == 1:
+                q = q[None, :]
+            if q.shape[1] != self.dim:
+                raise ValueError(f"expected [nq][{self.dim}] queries, got {tuple(q.shape)}")
+            nq = q.shape[0]
+            out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
+            out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
+            for s in range(0, nq, B.MAX_QUERIES):
+                e = min(nq, s + B.MAX_QUERIES)
+                self._search_chunk(q[s:e], k, out_ids[s:e], out_sc[s:e], repair)
+            return out_ids, out_sc
+
+    def _bins(self, q) -> Tuple[float, float]:
+        if self.metric == "cosine":
+            return -1.0, 1.0
+        bound = float(q.norm(dim=1).max().item()) * max(self.max_norm, 1e-30) * 1.001
+        return -bound, bound
+
+    def _search_chunk(self, q, k, out_ids, out_sc, repair) -> None:
+        t = self.torch
+        ws = self._workspace()
+        b = self._qbuf
+        nq = q.shape[0]
+        stream = self._stream()
+        norm = 1 if self.metric == "cosine" else 0
+        B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], nq, self.dim, self.d_pad, norm,
+                                           max(self.max_norm, 1.0) if norm else self.max_norm,
+                                           b["q32"].data_ptr(), b["q16"].data_ptr(), b["eps"].data_ptr(), stream),
+                "rarc_prep_queries")
+        lo, hi = self._bins(q)
+        kp = self.kprime_for(k)
+        rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
+        B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, b["q32"].data_ptr(),
+                                         b["q16"].data_ptr(), b["eps"].data_ptr(), nq, k, kp, self.id_base,
+                                         lo, hi, out_ids.data_ptr(), out_sc.data_ptr(), b["status"].data_ptr(),
+                                         ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+                "rarc_search_f16")
+        self.last_status = b["status"][:nq]
+        if not repair or self.ntotal == 0:
+            return
+        flagged = t.nonzero(b["status"][:nq]).flatten().tolist()  # syncs; almost always empty
+        self.last_repaired = flagged
+        for qi in flagged:
+            B.check(self.lib.rarc_repair_f16(rows_ptr, self.ntotal, self.d_pad, b["q32"].data_ptr(), qi, k,
+                                             self.id_base, out_ids.data_ptr(), out_sc.data_ptr(),
+                                             b["found"].data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                    "rarc_repair_f16")
+            if int(b["found"].item()) & 0x80000000:
+                raise B.RarcError(f"repair of query {qi} overflowed its scratch list")
+
+    def verify_query(self, queries, qi: int, ids, scores) -> int:
+        """Run the exact repair scan on row `qi` of (ids, scores) [device tensors from search_device]
+        and return how many rows beat the stored k-th entry (0 == the answer was already exact)."""
+        t = self.torch
+        with self._lock, t.cuda.device(self.device):
+            ws = self._workspace()
+            b = self._qbuf
+            q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
+            norm = 1 if self.metric == "cosine" else 0
+            B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
+                                               max(self.max_norm, 1.0), b["q32"].data_ptr(), b["q16"].data_ptr(),
+                                               b["eps"].data_ptr(), self._stream()), "rarc_prep_queries")
+            k = ids.shape[1]
+            B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["q32"].data_ptr(),
+                                             qi, k, self.id_base, ids.data_ptr(), scores.data_ptr(),
+                                             b["found"].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
+                    "rarc_repair_f16")
+            return int(b["found"].item())
