@@ -15,6 +15,7 @@ constexpr int FIN_THREADS = 256;
 __device__ __forceinline__ float canon_dot_f16(const float* __restrict__ q,
                                                const half_t* __restrict__ row, int d) {
   float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
   for (int m = 0; m < d; m += 8) {
     const half8 x = *(const half8*)(row + m);
     const float4 q0 = *(const float4*)(q + m);
@@ -55,11 +56,13 @@ struct FinParams {
   const half_t* corpus;
   const float* q32;  // [256][d]
   const float* eps;  // [256]
-  const uint32_t* cnt;
-  const uint64_t* cand;
+  const uint32_t* cnt2;  // [256 wg][256 q]
+  const uint64_t* cand;  // [256 q][256 wg][seg]
   const uint32_t* hist;
-  uint32_t cap;
-  float bin_lo, bin_inv_scale;
+  const float* binlo;
+  const float* bininv;
+  uint32_t seg;
+  uint32_t n_wg;
   int d;
   int k, kprime;
   int64_t id_base;
@@ -68,102 +71,134 @@ struct FinParams {
   uint32_t* status;
 };
 
-constexpr int FIN_SURV = 4096;  // survivors of the final-threshold compaction that get sorted
+constexpr int FIN_SURV = 4096;  // survivors of the final-threshold compaction that get ranked
 
 // one workgroup per query
 __global__ __launch_bounds__(FIN_THREADS) void rarc_finalize_kernel(const FinParams p) {
   __shared__ uint64_t keys[FIN_SURV];
+  __shared__ uint64_t sel[RARC_MAX_K];
   __shared__ uint64_t fin[RARC_MAX_K];
-  __shared__ float s_thr, s_tmin;
-  __shared__ uint32_t s_ns;
-  const int q = blockIdx.x;
-  const uint32_t total = p.cnt[q];
-  const uint32_t n = total < p.cap ? total : p.cap;
+  __shared__ uint32_t s_hist[RARC_NB];
+  __shared__ __attribute__((aligned(16))) float s_q[768];
+  __shared__ float s_thr;
+  __shared__ uint32_t s_ns, s_total, s_over, s_maxn;
+  const int q = blockIdx.x, tid = threadIdx.x;
 
-  // ---- tightest valid threshold from the final histogram (same rule as the scan's owner) ----
-  if (threadIdx.x == 0) {
-    const uint32_t* hq = p.hist + (size_t)q * RARC_NB;
-    uint32_t suf = 0;
-    int b = -1;
-    for (int i = RARC_NB - 1; i >= 0; --i) {
-      suf += hq[i];
-      if (suf >= (uint32_t)p.kprime) { b = i; break; }
-    }
-    s_thr = (b >= 2) ? p.bin_lo + (float)(b - 1) * p.bin_inv_scale : -INFINITY;
-    s_ns = 0;
+  // ---- tightest valid threshold from the final histogram (same rule as the scan's owners) ----
+  for (int i = tid; i < RARC_NB; i += blockDim.x) s_hist[i] = p.hist[(size_t)q * RARC_NB + i];
+  for (int i = tid; i < p.d; i += blockDim.x) s_q[i] = p.q32[(size_t)q * p.d + i];
+  if (tid == 0) { s_ns = 0; s_total = 0; s_over = 0; s_maxn = 0; }
+  __syncthreads();
+  if (tid < 64) {
+    uint32_t above;
+    const int b = rarc_wave_find_from_top(s_hist, RARC_NB, (uint32_t)p.kprime, &above);
+    if (tid == 0) s_thr = rarc_bin_threshold(b, p.binlo[q], p.bininv[q]);
   }
   __syncthreads();
   const float thr = s_thr;
-  const uint64_t* src = p.cand + (size_t)q * p.cap;
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const uint64_t key = src[i];
-    if (rarc_candscore(key) >= thr) {
-      const uint32_t pos = atomicAdd(&s_ns, 1u);
-      if (pos < FIN_SURV) keys[pos] = key;
-    }
-  }
-  __syncthreads();
-  const uint32_t ns_all = s_ns;
-  const int ns = ns_all < FIN_SURV ? (int)ns_all : FIN_SURV;
-  int np2 = 2;
-  while (np2 < ns) np2 <<= 1;
-  for (int i = ns + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0ull;
-  __syncthreads();
-  bitonic_desc(keys, np2);
 
-  // ---- the kp best by approximate score -> canonical rescore ----
-  const int kp = ns < p.kprime ? ns : p.kprime;
-  int fp2 = 2;
-  while (fp2 < kp) fp2 <<= 1;
-  const float* qv = p.q32 + (size_t)q * p.d;
-  for (int i = threadIdx.x; i < fp2; i += blockDim.x) {
-    uint64_t out = 0ull;
-    if (i < kp) {
-      const uint32_t row = rarc_candrow(keys[i]);
-      const float c = canon_dot_f16(qv, p.corpus + (size_t)row * p.d, p.d);
-      out = rarc_candkey(c, row);
+  // ---- gather this query's segments (thread w <-> scan workgroup w), keep what clears the threshold ----
+  {
+    uint32_t n = 0;
+    const uint64_t* src = p.cand;
+    if ((uint32_t)tid < p.n_wg) {
+      const uint32_t c = p.cnt2[(size_t)tid * RARC_MAX_QUERIES + q];
+      n = c < p.seg ? c : p.seg;
+      if (c > p.seg) atomicOr(&s_over, 1u);
+      atomicAdd(&s_total, c);
+      src = p.cand + ((size_t)q * RARC_MAX_WG + tid) * p.seg;
     }
-    fin[i] = out;
+    // first 16 slots of the segment in one memory round trip (8 x 16 B), the rest (rare) one by one
+    uint64_t first[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const ulonglong2 v = ((const ulonglong2*)src)[i];
+      first[2 * i] = v.x;
+      first[2 * i + 1] = v.y;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < 16; ++i) {
+      if (i < n && rarc_candscore(first[i]) >= thr) {
+        const uint32_t pos = atomicAdd(&s_ns, 1u);
+        if (pos < FIN_SURV) keys[pos] = first[i];
+      }
+    }
+    for (uint32_t i = 16; i < n; ++i) {
+      const uint64_t key = src[i];
+      if (rarc_candscore(key) >= thr) {
+        const uint32_t pos = atomicAdd(&s_ns, 1u);
+        if (pos < FIN_SURV) keys[pos] = key;
+      }
+    }
   }
-  if (threadIdx.x == 0) s_tmin = (kp > 0) ? rarc_candscore(keys[kp - 1]) : -INFINITY;
   __syncthreads();
-  bitonic_desc(fin, fp2);
+  const uint32_t ns_all = s_ns, total = s_total;
+  const int ns = ns_all < FIN_SURV ? (int)ns_all : FIN_SURV;
+
+  // ---- the kp best by approximate score: rank by counting (keys are distinct) ----
+  const int kp = ns < p.kprime ? ns : p.kprime;
+  for (int i = tid; i < ns; i += blockDim.x) {
+    const uint64_t mine = keys[i];
+    int rank = 0;
+    for (int j = 0; j < ns; ++j) rank += (keys[j] > mine);
+    if (rank < kp) sel[rank] = mine;
+  }
+  __syncthreads();
+
+  // ---- canonical rescore of the selected rows (query vector staged in LDS: shared by all rows) ----
+  const float* qv = s_q;
+  for (int i = tid; i < kp; i += blockDim.x) {
+    const uint32_t row = rarc_candrow(sel[i]);
+    fin[i] = rarc_candkey(canon_dot_f16(qv, p.corpus + (size_t)row * p.d, p.d), row);
+  }
+  __syncthreads();
+  // final order (canonical score desc, id asc) by counting; written straight to the outputs
+  for (int i = tid; i < p.k; i += blockDim.x) {
+    if (i >= kp) {
+      p.out_ids[(size_t)q * p.k + i] = -1;
+      p.out_scores[(size_t)q * p.k + i] = -INFINITY;
+    }
+  }
+  __shared__ float s_sk;
+  for (int i = tid; i < kp; i += blockDim.x) {
+    const uint64_t mine = fin[i];
+    int rank = 0;
+    for (int j = 0; j < kp; ++j) rank += (fin[j] > mine);
+    if (rank < p.k) {
+      p.out_ids[(size_t)q * p.k + rank] = p.id_base + (int64_t)rarc_candrow(mine);
+      p.out_scores[(size_t)q * p.k + rank] = rarc_candscore(mine);
+    }
+    if (rank == (p.k < kp ? p.k : kp) - 1) s_sk = rarc_candscore(mine);
+  }
+  __syncthreads();
 
   // ---- certificate: no unselected row can reach the k-th canonical score ----
   // every unselected row has approximate score <= t_min, hence canonical <= t_min + eps.
-  uint32_t st = RARC_Q_OK;
-  if (total > p.cap || ns_all > (uint32_t)FIN_SURV) st |= RARC_Q_OVERFLOW;
-  if ((int)n >= p.kprime && kp >= 1) {  // rows may have been left out: need the margin
-    const int kk = (p.k < kp ? p.k : kp) - 1;
-    const float sk = rarc_candscore(fin[kk]);
-    if (!(s_tmin + p.eps[q] < sk)) st |= RARC_Q_UNCERTAIN;
-  }
-  for (int i = threadIdx.x; i < p.k; i += blockDim.x) {
-    int64_t id = -1;
-    float sc = -INFINITY;
-    if (i < kp) {
-      id = p.id_base + (int64_t)rarc_candrow(fin[i]);
-      sc = rarc_candscore(fin[i]);
+  if (tid == 0) {
+    uint32_t st = RARC_Q_OK;
+    if (s_over || ns_all > (uint32_t)FIN_SURV) st |= RARC_Q_OVERFLOW;
+    if (total >= (uint32_t)p.kprime && kp >= 1) {  // rows may have been left out: need the margin
+      const float tmin = rarc_candscore(sel[kp - 1]);
+      if (!(tmin + p.eps[q] < s_sk)) st |= RARC_Q_UNCERTAIN;
     }
-    p.out_ids[(size_t)q * p.k + i] = id;
-    p.out_scores[(size_t)q * p.k + i] = sc;
+    p.status[q] = st;
   }
-  if (threadIdx.x == 0) p.status[q] = st;
 }
 
 int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps, int nq,
-                         int k, int kprime, int64_t id_base, float bin_lo, float bin_hi, const RarcWs& ws,
-                         int cap, int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s) {
+                         int k, int kprime, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
+                         int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s) {
   FinParams p;
   p.corpus = (const half_t*)corpus;
   p.q32 = q32;
   p.eps = eps;
-  p.cnt = ws.cnt;
+  p.cnt2 = ws.cnt2;
   p.cand = ws.cand;
   p.hist = ws.hist;
-  p.cap = (uint32_t)cap;
-  p.bin_lo = bin_lo;
-  p.bin_inv_scale = (bin_hi - bin_lo) / (float)RARC_NB;
+  p.binlo = ws.binlo;
+  p.bininv = ws.bininv;
+  p.seg = (uint32_t)(cap / RARC_MAX_WG);
+  p.n_wg = (uint32_t)n_wg;
   p.d = d_pad;
   p.k = k;
   p.kprime = kprime;

@@ -25,8 +25,10 @@ __device__ __forceinline__ double group8_tree_f64(double acc, int lane) {
   return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
 }
 
-// inv norm exactly as faiss: (float)(1.0 / sqrtf(nr)), evaluated in double like the C expression
-__device__ __forceinline__ float inv_norm(float nr) { return (float)(1.0 / (double)__fsqrt_rn(nr)); }
+// inv norm exactly as faiss: (float)(1.0 / sqrtf(nr)), evaluated in double like the C expression.
+// sqrtf is taken as (float)sqrt((double)nr): correctly rounded (53 >= 2*24+2 makes the double
+// rounding innocuous), whereas HIP's __fsqrt_rn is the 1-ulp native v_sqrt_f32.
+__device__ __forceinline__ float inv_norm(float nr) { return (float)(1.0 / (double)(float)sqrt((double)nr)); }
 
 __global__ __launch_bounds__(256) void rarc_l2norm_kernel(const float* in, int64_t ld_in, float* out,
                                                           int64_t ld_out, int64_t n_rows, int d) {
@@ -82,37 +84,51 @@ __global__ __launch_bounds__(256) void rarc_ingest_kernel(const float* in, int64
   }
 }
 
-// one 8-lane group per query row (all RARC_MAX_QUERIES rows are written; padding rows are zero)
+// One block per query slot (all RARC_MAX_QUERIES rows are written; padding rows are zero).  Only the
+// squared-norm has a prescribed order (8 lanes run the canonical chains out of LDS); scaling, the
+// fp16 copy and the error-bound sums are order-free and use the whole block.
 __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in, int64_t ld_in, int nq, int d,
                                                                 int d_pad, int normalize, float corpus_max_norm,
                                                                 float* q32, half_t* q16, float* eps) {
-  const int lane = threadIdx.x & 63, j = threadIdx.x & 7;
-  const int r = blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
-  if (r >= RARC_MAX_QUERIES) return;  // whole groups exit together
+  __shared__ float row[768];
+  __shared__ float s_nr;
+  __shared__ double s_dn[4], s_qn[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int r = blockIdx.x;
   const bool live = r < nq;
-  const float* x = in + (size_t)(live ? r : 0) * ld_in;
-  float acc = 0.f;
-  if (live && normalize)
-    for (int m = j; m < d; m += 8) acc = __builtin_fmaf(x[m], x[m], acc);
-  const float nr = group8_tree_f32(acc, lane);
+  for (int m = tid; m < d_pad; m += 256) row[m] = (live && m < d) ? in[(size_t)r * ld_in + m] : 0.f;
+  __syncthreads();
+  if (tid < 64) {
+    float acc = 0.f;
+    if (tid < 8 && live && normalize)
+      for (int m = tid; m < d; m += 8) acc = __builtin_fmaf(row[m], row[m], acc);
+    const float nr = group8_tree_f32(acc, lane);
+    if (tid == 0) s_nr = nr;
+  }
+  __syncthreads();
+  const float nr = s_nr;
   const bool scale = live && normalize && nr > 0.f;
   const float inv = scale ? inv_norm(nr) : 1.f;
   double dn = 0.0, qn = 0.0;
-  float* y32 = q32 + (size_t)r * d_pad;
-  half_t* y16 = q16 + (size_t)r * d_pad;
-  for (int m = j; m < d_pad; m += 8) {
-    float v = 0.f;
-    if (live && m < d) v = scale ? x[m] * inv : x[m];
+  for (int m = tid; m < d_pad; m += 256) {
+    const float v = scale ? row[m] * inv : row[m];
     const half_t hv = (half_t)v;
-    y32[m] = v;
-    y16[m] = hv;
+    q32[(size_t)r * d_pad + m] = v;
+    q16[(size_t)r * d_pad + m] = hv;
     const double df = (double)v - (double)(float)hv;
     dn += df * df;
     qn += (double)v * (double)v;
   }
-  dn = group8_tree_f64(dn, lane);
-  qn = group8_tree_f64(qn, lane);
-  if (j == 0) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dn += __shfl_xor(dn, o, 64);
+    qn += __shfl_xor(qn, o, 64);
+  }
+  if (lane == 0) { s_dn[tid >> 6] = dn; s_qn[tid >> 6] = qn; }
+  __syncthreads();
+  if (tid == 0) {
+    dn = (s_dn[0] + s_dn[1]) + (s_dn[2] + s_dn[3]);
+    qn = (s_qn[0] + s_qn[1]) + (s_qn[2] + s_qn[3]);
     // |approx - canonical| <= ||q32 - q16||·||d|| + (fp32 accumulation, both sides) ||q||·||d||
     const double acc_err = 8.0 * (double)d_pad * 5.9604644775390625e-08;  // 8·d·2^-24
     const double e = (sqrt(dn) + acc_err * sqrt(qn)) * (double)corpus_max_norm * 1.01 + 1e-30;
@@ -189,10 +205,10 @@ extern "C" int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_cor
 extern "C" int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad, int normalize,
                                  float corpus_max_norm, float* d_q32, uint16_t* d_q16, float* d_eps,
                                  void* stream) {
-  RARC_REQUIRE(d_in && d_q32 && d_q16 && d_eps && d > 0 && d_pad >= d && d_pad % 8 == 0 && nq >= 0 &&
-                   nq <= RARC_MAX_QUERIES,
+  RARC_REQUIRE(d_in && d_q32 && d_q16 && d_eps && d > 0 && d_pad >= d && d_pad % 8 == 0 && d_pad <= 768 &&
+                   nq >= 0 && nq <= RARC_MAX_QUERIES,
                RARC_E_INVALID, "rarc_prep_queries: bad arguments (nq=%d d=%d d_pad=%d)", nq, d, d_pad);
-  hipLaunchKernelGGL(rarc_prep_queries_kernel, dim3(RARC_MAX_QUERIES / 32), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(rarc_prep_queries_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, (hipStream_t)stream,
                      d_in, ld_in, nq, d, d_pad, normalize, corpus_max_norm, d_q32, (half_t*)d_q16, d_eps);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;

@@ -4,10 +4,11 @@
 #include "rarc_common.h"
 
 int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq,
-                         int kprime, float bin_lo, float bin_hi, const RarcWs& ws, int cap, hipStream_t s);
+                         int kprime, float bin_lo, float bin_hi, const RarcWs& ws, int cap, int* grid_out,
+                         hipStream_t s);
 int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps, int nq,
-                         int k, int kprime, int64_t id_base, float bin_lo, float bin_hi, const RarcWs& ws,
-                         int cap, int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s);
+                         int k, int kprime, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
+                         int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s);
 int rarc_repair_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const float* qv, int k,
                        int64_t id_base, int64_t* ids, float* scores, uint32_t* found, const RarcWs& ws,
                        int cap, hipStream_t s);
@@ -30,14 +31,14 @@ extern "C" int rarc_padded_dim(int d) {
 }
 
 extern "C" size_t rarc_search_workspace_bytes(int cand_cap) {
-  if (cand_cap < 1024) cand_cap = 1024;
+  if (cand_cap < 4096) cand_cap = 4096;
   return RARC_WS_CAND + (size_t)RARC_MAX_QUERIES * (size_t)cand_cap * 8;
 }
 
 static int check_ws(void* ws, size_t bytes, int cap, const char* who) {
   RARC_REQUIRE(ws != nullptr && ((uintptr_t)ws % 256) == 0, RARC_E_WORKSPACE,
                "%s: workspace must be a 256-byte aligned device pointer", who);
-  RARC_REQUIRE(cap >= 1024 && bytes >= rarc_search_workspace_bytes(cap), RARC_E_WORKSPACE,
+  RARC_REQUIRE(cap >= 4096 && cap % RARC_MAX_WG == 0 && bytes >= rarc_search_workspace_bytes(cap), RARC_E_WORKSPACE,
                "%s: workspace of %zu bytes too small for cand_cap=%d (need %zu)", who, bytes, cap,
                rarc_search_workspace_bytes(cap));
   return RARC_OK;
@@ -63,10 +64,11 @@ extern "C" int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
   if (nq == 0) return RARC_OK;
   const RarcWs ws = rarc_ws_carve(d_workspace);
   hipStream_t s = (hipStream_t)stream;
-  rc = rarc_scan_f16_launch(d_corpus_f16, n_rows, d_pad, d_q16, nq, kprime, bin_lo, bin_hi, ws, cand_cap, s);
+  int n_wg = 0;
+  rc = rarc_scan_f16_launch(d_corpus_f16, n_rows, d_pad, d_q16, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s);
   if (rc) return rc;
-  return rarc_finalize_launch(d_corpus_f16, d_pad, d_q32, d_eps, nq, k, kprime, id_base, bin_lo, bin_hi, ws,
-                              cand_cap, d_out_ids, d_out_scores, d_status, s);
+  return rarc_finalize_launch(d_corpus_f16, d_pad, d_q32, d_eps, nq, k, kprime, id_base, ws, cand_cap, n_wg,
+                              d_out_ids, d_out_scores, d_status, s);
 }
 
 extern "C" int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_q32,
@@ -77,7 +79,7 @@ extern "C" int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
   RARC_REQUIRE(q >= 0 && q < RARC_MAX_QUERIES && k >= 1 && k <= RARC_MAX_K && d_pad % 8 == 0 && n_rows >= 0 &&
                    n_rows < (int64_t)0xffffffe0ll,
                RARC_E_INVALID, "rarc_repair_f16: bad arguments (q=%d k=%d)", q, k);
-  int rc = check_ws(d_workspace, workspace_bytes, 1024, "rarc_repair_f16");
+  int rc = check_ws(d_workspace, workspace_bytes, 4096, "rarc_repair_f16");
   if (rc) return rc;
   const int cap = (int)((workspace_bytes - RARC_WS_CAND) / 8);
   const RarcWs ws = rarc_ws_carve(d_workspace);

@@ -13,35 +13,155 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RARC_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // ---- workspace layout (bytes from a 256-byte aligned base) -------------------------------
-// thr   : float   [256]        running per-query pruning threshold (monotone increasing)
-// cnt   : uint32  [256]        candidates appended per query
-// flags : uint32  [64]         [0] = any overflow
-// hist  : uint32  [256][NB]    per-query score histogram of appended candidates
-// cand  : uint64  [256][cap]   appended candidates, key = ordkey(score)<<32 | ~local_row
-constexpr int RARC_NB = 256;  // histogram bins per query
+// thr      : float   [256]         running per-query pruning threshold (monotone increasing)
+// binlo    : float   [256]         per-query histogram window: bin(s) = floor((s - lo) * scale)
+// binscale : float   [256]
+// bininv   : float   [256]         1 / scale (bin width)
+// cnt      : uint32  [256]         (repair scratch counter lives in cnt[0])
+// flags    : uint32  [64]
+// hist     : uint32  [256][NB]     per-query score histogram of appended candidates
+// cnt2     : uint32  [256 wg][256] candidates appended per (workgroup, query)
+// seed     : float   [256][4096]   scores of the strided seed sample (initial thresholds)
+// cand     : uint64  [256][cap]    query q, workgroup w owns slots [w*seg, (w+1)*seg), seg = cap/256;
+//                                  key = ordkey(score)<<32 | ~local_row
+constexpr int RARC_NB = 256;          // histogram bins per query
+constexpr int RARC_MAX_WG = 256;      // scan workgroups (one per CU); owners of candidate segments
+constexpr int RARC_SEED_TILES = 128;  // strided sample tiles scored before the scan (4096 rows)
 constexpr size_t RARC_WS_THR = 0;
-constexpr size_t RARC_WS_CNT = 1024;
-constexpr size_t RARC_WS_FLAGS = 2048;
-constexpr size_t RARC_WS_HIST = 4096;
-constexpr size_t RARC_WS_CAND = RARC_WS_HIST + (size_t)RARC_MAX_QUERIES * RARC_NB * 4;
+constexpr size_t RARC_WS_BINLO = 1024;
+constexpr size_t RARC_WS_BINSCALE = 2048;
+constexpr size_t RARC_WS_BININV = 3072;
+constexpr size_t RARC_WS_CNT = 4096;
+constexpr size_t RARC_WS_FLAGS = 5120;
+constexpr size_t RARC_WS_HIST = 8192;
+constexpr size_t RARC_WS_CNT2 = RARC_WS_HIST + (size_t)RARC_MAX_QUERIES * RARC_NB * 4;
+constexpr size_t RARC_WS_SEED = RARC_WS_CNT2 + (size_t)RARC_MAX_WG * RARC_MAX_QUERIES * 4;
+constexpr size_t RARC_WS_CAND = RARC_WS_SEED + (size_t)RARC_MAX_QUERIES * RARC_SEED_TILES * 32 * 4;
 
 struct RarcWs {
   float* thr;
+  float* binlo;
+  float* binscale;
+  float* bininv;
   uint32_t* cnt;
   uint32_t* flags;
   uint32_t* hist;
+  uint32_t* cnt2;
+  float* seed;
   uint64_t* cand;
 };
 static inline RarcWs rarc_ws_carve(void* base) {
   char* b = (char*)base;
   RarcWs w;
   w.thr = (float*)(b + RARC_WS_THR);
+  w.binlo = (float*)(b + RARC_WS_BINLO);
+  w.binscale = (float*)(b + RARC_WS_BINSCALE);
+  w.bininv = (float*)(b + RARC_WS_BININV);
   w.cnt = (uint32_t*)(b + RARC_WS_CNT);
   w.flags = (uint32_t*)(b + RARC_WS_FLAGS);
   w.hist = (uint32_t*)(b + RARC_WS_HIST);
+  w.cnt2 = (uint32_t*)(b + RARC_WS_CNT2);
+  w.seed = (float*)(b + RARC_WS_SEED);
   w.cand = (uint64_t*)(b + RARC_WS_CAND);
   return w;
 }
+
+// Threshold implied by a histogram: highest bin b whose suffix count reaches k'.  Every row whose
+// score is below lo + (b-1)*width is provably in a bin < b (one bin of slack absorbs the fp32
+// rounding of the bin computation), and at least k' appended rows sit in bins >= b, so dropping
+// rows below the returned value never drops a top-k' row.  Returns -inf when no bin qualifies.
+__host__ __device__ static inline float rarc_bin_threshold(int b, float lo, float width) {
+  return (b >= 2) ? lo + (float)(b - 1) * width : -__builtin_inff();
+}
+__host__ __device__ static inline int rarc_bin_of(float s, float lo, float scale) {
+  const float x = (s - lo) * scale;
+  int b = (x >= (float)(RARC_NB - 1)) ? RARC_NB - 1 : (x > 0.f ? (int)x : 0);
+  return b;
+}
+
+// Wave-level search used by the seed-threshold and finalize kernels: over `nbins` counters in LDS
+// (nbins multiple of 64), find the highest bin b with sum(cnt[b..nbins)) >= need.  Called by ONE
+// full wave (64 lanes); returns b (or -1) and the count strictly above b through *above.
+#ifdef __HIPCC__
+// lane id recomputed on the spot (volatile: never hoisted out of a rarely executed block, so it
+// does not occupy a VGPR across a register-starved hot loop)
+__device__ __forceinline__ int rarc_fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+// LDS accesses the compiler must not see: with LDS-DMA (global_load_lds) in flight hipcc puts
+// s_waitcnt vmcnt(0) in front of every DS access it knows about (possible alias with the DMA
+// destination), which drains the whole HBM pipeline.  These touch disjoint bookkeeping words.
+__device__ __forceinline__ uint32_t rarc_lds_add_rtn(uint32_t byte_addr, uint32_t v) {
+  uint32_t old;
+  asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(byte_addr), "v"(v) : "memory");
+  return old;
+}
+__device__ __forceinline__ float rarc_lds_read_f32(uint32_t byte_addr) {
+  float x;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(x) : "v"(byte_addr) : "memory");
+  return x;
+}
+__device__ __forceinline__ void rarc_lds_read_u32x4(uint32_t byte_addr, uint32_t& a, uint32_t& b, uint32_t& c,
+                                                    uint32_t& d) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(byte_addr) : "memory");
+  a = v[0]; b = v[1]; c = v[2]; d = v[3];
+}
+// 256-bin variant of rarc_wave_find_from_top on register-held counts (lane holds bins 4*lane..+3)
+__device__ static inline int rarc_wave_find_from_top_256(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                         uint32_t need) {
+  const int lane = rarc_fresh_lane();
+  const uint32_t mine = c0 + c1 + c2 + c3;
+  uint32_t suf = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_down(suf, d, 64);
+    if (lane + d < 64) suf += o;
+  }
+  const unsigned long long ge = __builtin_amdgcn_ballot_w64(suf >= need);
+  if (!ge) return -1;
+  const int hl = 63 - __builtin_clzll(ge);
+  const uint32_t above = __shfl(suf - mine, hl, 64);
+  const uint32_t h3 = __shfl(c3, hl, 64), h2 = __shfl(c2, hl, 64), h1 = __shfl(c1, hl, 64);
+  int b = 4 * hl;
+  if (above + h3 >= need) b += 3;
+  else if (above + h3 + h2 >= need) b += 2;
+  else if (above + h3 + h2 + h1 >= need) b += 1;
+  return b;
+}
+__device__ static inline int rarc_wave_find_from_top(const uint32_t* cnt, int nbins, uint32_t need,
+                                                     uint32_t* above_out) {
+  const int lane = rarc_fresh_lane();
+  const int per = nbins / 64;
+  const uint32_t* mine = cnt + lane * per;
+  uint32_t tot = 0;
+  for (int i = 0; i < per; ++i) tot += mine[i];
+  uint32_t suf = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_down(suf, d, 64);
+    if (lane + d < 64) suf += o;
+  }
+  const unsigned long long ge = __builtin_amdgcn_ballot_w64(suf >= need);
+  if (!ge) return -1;
+  const int hl = 63 - __builtin_clzll(ge);
+  uint32_t above = __shfl(suf - tot, hl, 64);
+  int b = -1;
+  if (lane == hl) {
+    for (int i = per - 1; i >= 0; --i) {
+      const uint32_t c = mine[i];
+      if (above + c >= need) { b = lane * per + i; break; }
+      above += c;
+    }
+  }
+  b = __shfl(b, hl, 64);
+  *above_out = __shfl(above, hl, 64);
+  return b;
+}
+#endif
 
 // ---- order-preserving float <-> uint32 map ------------------------------------------------
 __host__ __device__ static inline uint32_t rarc_ordkey(float f) {

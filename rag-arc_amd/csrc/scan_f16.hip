@@ -13,10 +13,12 @@
 //     ds_read_b128 of every 16-lane group hits 16 distinct 16-B slots (conflict free).
 //   * per tile each wave issues D/16 × v_mfma_f32_32x32x16_f16 (A = 32 corpus rows from LDS,
 //     B = its resident query fragments): lane l ends with 16 scores of query (l & 31).
-//   * epilogue: one max + compare against the lane's query threshold; survivors (rare) go
-//     through a per-wave LDS queue to global candidate lists, and a per-query histogram lets
-//     the owning workgroup raise that query's threshold (always a valid lower bound of the
-//     k'-th best score, so pruning never drops a true top-k' row).
+//   * epilogue: one max + compare against the lane's query threshold.  Survivors (≈1 per
+//     wave-tile) take a slot in the workgroup's private segment of that query's candidate list
+//     (slot counter in LDS — no returning global atomic, nothing to wait for) and bump the
+//     query's global histogram; the workgroup that owns the query turns the histogram into a
+//     higher threshold (always a valid lower bound of the k'-th best score, so pruning never
+//     drops a true top-k' row).
 //
 // Algorithmic HBM bytes per launch: n_rows × D × 2  (DESIGN.md §kernels).
 #include "rarc_common.h"
@@ -26,57 +28,108 @@ struct ScanParams {
   const half_t* q16;     // [256][D]
   uint32_t n_rows;
   uint32_t n_tiles;
-  uint32_t* thr;   // float bits [256]
-  uint32_t* hist;  // [256][RARC_NB]
-  uint32_t* cnt;   // [256]
-  uint64_t* cand;  // [256][cap]
-  uint32_t* flags;
-  uint32_t cap;
+  uint32_t* thr;          // float bits [256]
+  const float* binlo;     // [256]
+  const float* binscale;  // [256]
+  const float* bininv;    // [256]
+  uint32_t* hist;         // [256][RARC_NB]
+  uint32_t* cnt2;         // [256 wg][256 q]
+  uint64_t* cand;         // [256 q][256 wg][seg]
+  uint32_t seg;           // slots per (query, workgroup)
   uint32_t kprime;
   uint32_t nq;
-  float bin_lo, bin_scale, bin_inv_scale;
 };
 
 constexpr int SCAN_WAVES = 8;
-constexpr int SCAN_PF = 4;     // A-fragment ring depth (ds_read_b128 in flight per wave)
-constexpr int SCAN_WQ = 128;   // per-wave candidate queue entries
 
-// ---- inline-asm pipeline steps (hipcc will not software-pipeline this loop at 240+ VGPRs) ----
-// Every step names the registers it touches, so ordering between steps is by data flow.
-#define RARC_DSREAD(dst, addr, off) \
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-// wait for the oldest ring slot, multiply, refill the slot with fragment s+PF
-#define RARC_STEP_FIRST(acc, r, q, addr, off)                                       \
-  asm volatile("s_waitcnt lgkmcnt(3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\t"  \
-               "ds_read_b128 %1, %3 offset:%4"                                      \
-               : "=&v"(acc), "+v"(r) : "v"(q), "v"(addr), "n"(off))
-#define RARC_STEP_MID(acc, r, q, addr, off)                                          \
-  asm volatile("s_waitcnt lgkmcnt(3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\t"  \
-               "ds_read_b128 %1, %3 offset:%4"                                       \
-               : "+v"(acc), "+v"(r) : "v"(q), "v"(addr), "n"(off))
-#define RARC_STEP_TAIL(acc, r, q, n)                                                  \
-  asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0"      \
-               : "+v"(acc) : "v"(r), "v"(q), "n"(n))
+// ---- inline-asm MFMA pipeline (hipcc will not software-pipeline this loop at 240+ VGPRs) ----
+// One tile = KS chained v_mfma_f32_32x32x16_f16 fed by an R-deep ring of ds_read_b128.
+// Step S: wait until ring slot S%R has landed (in-order LDS returns: lgkmcnt(R-1)), multiply,
+// refill the slot with fragment S+R.  Every asm statement names the registers it touches, so the
+// order between steps is fixed by data flow; immediates come from template parameters.
+constexpr int SCAN_RING = 6;
+
+template <int S, int KS, int R>
+struct ScanSteps {
+  static __device__ __forceinline__ void run(f32x16& acc, half8 (&rg)[R], const half8 (&qf)[KS], int a0, int a1,
+                                             int a2, int a3) {
+    constexpr int slot = S % R;
+    if constexpr (S + R < KS) {
+      constexpr int S2 = S + R;  // fragment that refills this slot
+      const int addr = (S2 & 3) == 0 ? a0 : (S2 & 3) == 1 ? a1 : (S2 & 3) == 2 ? a2 : a3;
+      if constexpr (S == 0)
+        asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\t"
+                     "ds_read_b128 %1, %3 offset:%4"
+                     : "=&v"(acc), "+v"(rg[slot]) : "v"(qf[S]), "v"(addr), "n"((S2 >> 2) * 4096), "n"(R - 1));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\t"
+                     "ds_read_b128 %1, %3 offset:%4"
+                     : "+v"(acc), "+v"(rg[slot]) : "v"(qf[S]), "v"(addr), "n"((S2 >> 2) * 4096), "n"(R - 1));
+    } else if constexpr (S == 0) {
+      asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
+                   : "=&v"(acc) : "v"(rg[slot]), "v"(qf[S]), "n"(KS - 1 - S));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
+                   : "+v"(acc) : "v"(rg[slot]), "v"(qf[S]), "n"(KS - 1 - S));
+    }
+    if constexpr (S + 1 < KS) ScanSteps<S + 1, KS, R>::run(acc, rg, qf, a0, a1, a2, a3);
+  }
+};
+template <int S, int R>
+struct ScanPrologue {
+  static __device__ __forceinline__ void run(half8 (&rg)[R], int a0, int a1, int a2, int a3) {
+    const int addr = (S & 3) == 0 ? a0 : (S & 3) == 1 ? a1 : (S & 3) == 2 ? a2 : a3;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rg[S]) : "v"(addr), "n"((S >> 2) * 4096));
+    if constexpr (S + 1 < R) ScanPrologue<S + 1, R>::run(rg, a0, a1, a2, a3);
+  }
+};
 // MFMA result -> VALU read needs software wait states when the producer is inside asm
 #define RARC_MFMA_DRAIN(acc) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc))
 
+// LDS carve (bytes): 3 tile buffers | slot counters [256] | binlo | binscale | bininv | owner landing [256]
 template <int D>
+struct ScanLds {
+  static constexpr int TILE_BYTES = 32 * D * 2;
+  static constexpr int CNT = 3 * TILE_BYTES;
+  static constexpr int BINLO = CNT + 1024;
+  static constexpr int BINSCALE = BINLO + 1024;
+  static constexpr int BININV = BINSCALE + 1024;
+  static constexpr int HLAND = BININV + 1024;  // owner: histogram of the owned query, filled by DMA
+  static constexpr int TLAND = HLAND + 1024;   // per wave 64 x 4 B: refreshed thresholds, filled by DMA
+  static constexpr int TOTAL = TLAND + 2048;
+};
+
+// ABL: ablation bits for tools/scan_bench (0 in the product build)
+//   1 = no pruning epilogue, 2 = no DMA after the prologue, 4 = no MFMA loop, 8 = no refresh events
+template <int D, int ABL = 0>
 __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const ScanParams p) {
   static_assert(D % 128 == 0 && D >= 128 && D <= 768, "D must be a multiple of 128, <= 768");
+  static_assert(D / 16 >= SCAN_RING, "ring deeper than the k-loop");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = ScanLds<D>;
   constexpr int NP = D / 64;            // 64-element (128-B) panels per row
   constexpr int KS = NP * 4;            // MFMA k-steps (K = 16 each)
-  constexpr int TILE_BYTES = 32 * D * 2;
+  constexpr int TILE_BYTES = L::TILE_BYTES;
   constexpr int NDMA = TILE_BYTES / 1024;  // 1-KiB DMA wave-instructions per tile
   constexpr int DPW = NDMA / SCAN_WAVES;   // ... per wave
   static_assert(NDMA % SCAN_WAVES == 0, "tile must split evenly over the waves");
-  constexpr int WQ_OFF = 3 * TILE_BYTES;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int row = lane & 31, h = lane >> 5;
   const uint32_t qidx = wave * 32 + row;  // this lane's query
+
+  uint32_t* s_cnt = (uint32_t*)(smem + L::CNT);
+  float* s_binlo = (float*)(smem + L::BINLO);
+  float* s_binscale = (float*)(smem + L::BINSCALE);
+  float* s_bininv = (float*)(smem + L::BININV);
+  if (tid < RARC_MAX_QUERIES) {
+    s_cnt[tid] = 0;
+    s_binlo[tid] = p.binlo[tid];
+    s_binscale[tid] = p.binscale[tid];
+    s_bininv[tid] = p.bininv[tid];
+  }
 
   // resident query fragments: B operand, lane holds Q[qidx][16*ks + 8*h .. +8)
   half8 qf[KS];
@@ -88,26 +141,25 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
 
   // A-fragment LDS offsets: element (r, chunk c) of a panel sits at r*128 + ((c ^ sw(r))<<4),
   // sw(r) = (r >> 1) & 7; k-step kk of a panel reads chunks 2kk (lanes 0-31) / 2kk+1 (32-63).
-  int xk[4];
+  // a0..a3 always point into the CURRENT tile buffer (advanced by one buffer per iteration).
+  int a0, a1, a2, a3;
   {
     const int sw = (row >> 1) & 7;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + h) ^ sw) << 4);
+    a0 = row * 128 + (((0 + h) ^ sw) << 4);
+    a1 = row * 128 + (((2 + h) ^ sw) << 4);
+    a2 = row * 128 + (((4 + h) ^ sw) << 4);
+    a3 = row * 128 + (((6 + h) ^ sw) << 4);
   }
   // DMA source offsets: instruction (panel pn, row-block b) moves rows 8b..8b+7 × 128 B;
   // lane = 8*(row in block) + slot, and fetches chunk slot ^ sw(row).
   const int drow = lane >> 3, dslot = lane & 7;
+  // (odd row-blocks: sw differs by 4, i.e. the chunk offset by 64 bytes -> voff ^ 64)
   const uint32_t voff_even = drow * (D * 2) + ((dslot ^ ((drow >> 1) & 7)) << 4);
-  const uint32_t voff_odd = drow * (D * 2) + ((dslot ^ ((4 + (drow >> 1)) & 7)) << 4);
 
-  uint64_t* wq_key = (uint64_t*)(smem + WQ_OFF) + wave * SCAN_WQ;
-  uint32_t* wq_q = (uint32_t*)(smem + WQ_OFF + SCAN_WAVES * SCAN_WQ * 8) + wave * SCAN_WQ;
-  int wq_n = 0;
-
-  float thr = __uint_as_float(p.thr[qidx]);  // -inf for live queries, +inf for padding
-  uint32_t thr_pend = __float_as_uint(thr);
-  uint32_t hp0 = 0, hp1 = 0, hp2 = 0, hp3 = 0;  // owner: pending histogram words (wave 0)
-  int own_q = -1;                                // owner: query whose histogram is in flight
+  float thr = __uint_as_float(p.thr[qidx]);  // seed threshold; +inf for padding queries
+  const float my_binlo = p.binlo[qidx], my_binscale = p.binscale[qidx];  // this lane's query window
+  bool pend = false;  // a threshold refresh (and, on wave 0, an owned histogram) is in flight to LDS
+  int own_q = -1;     // owner (wave 0): query whose histogram is in flight
   int event = 0;
 
   auto issue = [&](int buf, uint32_t tile) {
@@ -116,28 +168,45 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     for (int j = 0; j < DPW; ++j) {
       const int i = wave * DPW + j;
       const int pn = i >> 2, b = i & 3;
-      const char* g = gbase + (size_t)(8 * b) * (D * 2) + pn * 128 + ((b & 1) ? voff_odd : voff_even);
+      const char* g = gbase + (size_t)(8 * b) * (D * 2) + pn * 128 + ((b & 1) ? (voff_even ^ 64u) : voff_even);
       __builtin_amdgcn_global_load_lds(RARC_GPTR(g), RARC_LPTR(smem + buf * TILE_BYTES + i * 1024),
                                        16, 0, 0);
     }
   };
 
-  auto flush = [&]() {
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < wq_n; i += 64) {
-      const uint64_t key = wq_key[i];
-      const uint32_t q = wq_q[i];
-      const uint32_t pos = atomicAdd(&p.cnt[q], 1u);
-      if (pos < p.cap) p.cand[(size_t)q * p.cap + pos] = key;
-      else atomicOr(&p.flags[0], 1u);
-      const float s = rarc_candscore(key);
-      int bin = (int)floorf((s - p.bin_lo) * p.bin_scale);
-      bin = bin < 0 ? 0 : (bin > RARC_NB - 1 ? RARC_NB - 1 : bin);
-      atomicAdd(&p.hist[q * RARC_NB + bin], 1u);
-    }
-    // keep the DMA vmcnt bookkeeping exact: nothing but DMAs may stay in flight
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+  // one surviving score: slot from the LDS counter, key to the private segment, histogram bump.
+  // Nothing here returns data through the vector-memory queue, so nothing has to be waited for.
+  auto append = [&](float s, uint32_t doc, uint32_t q) {
+    const uint32_t slot = rarc_lds_add_rtn(L::CNT + 4 * q, 1u);
+    if (slot < p.seg)
+      p.cand[((size_t)q * RARC_MAX_WG + blockIdx.x) * p.seg + slot] = rarc_candkey(s, doc);
+    const int bin = rarc_bin_of(s, my_binlo, my_binscale);
+    atomicAdd(&p.hist[q * RARC_NB + bin], 1u);
+  };
+
+  // prune one tile's scores: lane holds 16 scores of its query (rows 8*(r>>2) + 4*h + (r&3))
+  auto prune = [&](const f32x16& acc, uint32_t tile) {
+      const float m0 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+      const float m1 = fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7]));
+      const float m2 = fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11]));
+      const float m3 = fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]));
+      const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+      if (__builtin_amdgcn_ballot_w64(m >= thr) != 0) {
+        const int ln = rarc_fresh_lane();
+        const uint32_t q = wave * 32 + (ln & 31);
+        const uint32_t row0 = tile * 32 + 4 * (ln >> 5);
+        const float mg[4] = {m0, m1, m2, m3};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (__builtin_amdgcn_ballot_w64(mg[g] >= thr) != 0) {
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) {
+              const uint32_t doc = row0 + (r & 3) + 8 * (r >> 2);
+              if (acc[r] >= thr && doc < p.n_rows) append(acc[r], doc, q);
+            }
+          }
+        }
+      }
   };
 
   const uint32_t t0 = blockIdx.x, stride = gridDim.x;
@@ -145,149 +214,257 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
   if (t0 + stride < p.n_tiles) issue(1, t0 + stride);
   int buf = 0;
   uint32_t it = 0;
+  // Ping-pong: waves w and w+4 share a SIMD.  Group A (waves 0-3) runs MFMA(t) then prune(t);
+  // group B (waves 4-7) runs prune(t-1) then MFMA(t).  Each wave's VALU/LDS/VMEM epilogue thus
+  // overlaps its SIMD partner's MFMA stream instead of idling the matrix pipe.
+  const bool grp_b = wave >= SCAN_WAVES / 2;
+  uint32_t prev = 0xffffffffu;  // group B: tile whose scores are still in acc
+  f32x16 acc;
   for (uint32_t cur = t0; cur < p.n_tiles; cur += stride) {
-    if (cur + stride < p.n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // DMA(cur) landed: loads return in order, so "at most DPW outstanding" == everything but the
+    // newest tile's DPW instructions has completed (stores/atomics in between only tighten it)
+    if ((ABL & 2) || cur + stride >= p.n_tiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    const bool issued = !(ABL & 2) && cur + 2 * stride < p.n_tiles;
     {
       int nb = buf + 2;
       if (nb >= 3) nb -= 3;
-      if (cur + 2 * stride < p.n_tiles) issue(nb, cur + 2 * stride);
+      if (issued) issue(nb, cur + 2 * stride);
     }
 
-    // ---- 32 rows × 32 queries per wave: KS chained MFMAs fed by a 4-deep LDS read ring ----
-    f32x16 acc;
-    {
-      const int tb = buf * TILE_BYTES;
-      const int a0 = tb + xk[0], a1 = tb + xk[1], a2 = tb + xk[2], a3 = tb + xk[3];
-      half8 r0, r1, r2, r3;
-      RARC_DSREAD(r0, a0, 0);
-      RARC_DSREAD(r1, a1, 0);
-      RARC_DSREAD(r2, a2, 0);
-      RARC_DSREAD(r3, a3, 0);
-      RARC_STEP_FIRST(acc, r0, qf[0], a0, 4096);
-      RARC_STEP_MID(acc, r1, qf[1], a1, 4096);
-      RARC_STEP_MID(acc, r2, qf[2], a2, 4096);
-      RARC_STEP_MID(acc, r3, qf[3], a3, 4096);
-#pragma unroll
-      for (int pn = 1; pn < NP - 1; ++pn) {
-        RARC_STEP_MID(acc, r0, qf[4 * pn + 0], a0, (pn + 1) * 4096);
-        RARC_STEP_MID(acc, r1, qf[4 * pn + 1], a1, (pn + 1) * 4096);
-        RARC_STEP_MID(acc, r2, qf[4 * pn + 2], a2, (pn + 1) * 4096);
-        RARC_STEP_MID(acc, r3, qf[4 * pn + 3], a3, (pn + 1) * 4096);
-      }
-      RARC_STEP_TAIL(acc, r0, qf[KS - 4], 3);
-      RARC_STEP_TAIL(acc, r1, qf[KS - 3], 2);
-      RARC_STEP_TAIL(acc, r2, qf[KS - 2], 1);
-      RARC_STEP_TAIL(acc, r3, qf[KS - 1], 0);
+    if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
+
+    // ---- 32 rows × 32 queries per wave: KS chained MFMAs fed by a 6-deep LDS read ring ----
+    if (ABL & 4) {
+      acc = (f32x16){0};
+      asm volatile("" : "+v"(acc));
+    } else {
+      half8 rg[SCAN_RING];
+      ScanPrologue<0, SCAN_RING>::run(rg, a0, a1, a2, a3);
+      ScanSteps<0, KS, SCAN_RING>::run(acc, rg, qf, a0, a1, a2, a3);
       RARC_MFMA_DRAIN(acc);
     }
 
-    // ---- pending threshold work issued one iteration ago (latency already covered) ----
-    if (own_q >= 0) {  // wave 0 only: suffix-scan the owned query's histogram
-      const uint32_t mine = hp0 + hp1 + hp2 + hp3;  // bins 4*lane .. 4*lane+3
-      uint32_t suf = mine;                           // inclusive suffix sum over lanes >= lane
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_down(suf, d, 64);
-        if (lane + d < 64) suf += o;
-      }
-      const uint64_t ge = __builtin_amdgcn_ballot_w64(suf >= p.kprime);
-      if (ge) {
-        const int hl = 63 - __builtin_clzll(ge);  // highest lane whose suffix reaches k'
-        const uint32_t above = __shfl(suf - mine, hl, 64);
-        const uint32_t c3 = __shfl(hp3, hl, 64), c2 = __shfl(hp2, hl, 64), c1 = __shfl(hp1, hl, 64);
-        int b = 4 * hl;
-        if (above + c3 >= p.kprime) b += 3;
-        else if (above + c3 + c2 >= p.kprime) b += 2;
-        else if (above + c3 + c2 + c1 >= p.kprime) b += 1;
-        // every row dropped below lo + (b-1)/scale is provably in a bin < b
-        if (b >= 2 && lane == 0) {
-          const float t = p.bin_lo + (float)(b - 1) * p.bin_inv_scale;
-          const float old = __uint_as_float(
-              __hip_atomic_load(&p.thr[own_q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-          if (t > old)
-            __hip_atomic_store(&p.thr[own_q], __float_as_uint(t), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+    // ---- threshold refresh issued one iteration ago: its DMAs are older than this iteration's
+    // tile DMAs, so "at most DPW outstanding" (or 0 if none were issued) means they have landed ----
+    if (pend) {
+      if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      thr = fmaxf(thr, rarc_lds_read_f32(L::TLAND + wave * 256 + 4 * rarc_fresh_lane()));
+      if (own_q >= 0) {  // wave 0: turn the owned query's histogram into a threshold
+        uint32_t c0, c1, c2, c3;
+        rarc_lds_read_u32x4(L::HLAND + 16 * rarc_fresh_lane(), c0, c1, c2, c3);
+        const int b = rarc_wave_find_from_top_256(c0, c1, c2, c3, p.kprime);
+        if (b >= 2 && rarc_fresh_lane() == 0) {
+          // counts only grow, so b (hence t) never decreases; t > lo >= the seed threshold
+          const float t = rarc_bin_threshold(b, rarc_lds_read_f32(L::BINLO + 4 * own_q),
+                                             rarc_lds_read_f32(L::BININV + 4 * own_q));
+          __hip_atomic_store(&p.thr[own_q], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        own_q = -1;
       }
-      own_q = -1;
-    }
-    thr = fmaxf(thr, __uint_as_float(thr_pend));
-
-    // ---- prune: lane holds 16 scores of query qidx (rows 8*(r>>2) + 4*h + (r&3)) ----
-    float m = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])),
-                    fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7])));
-    m = fmaxf(m, fmaxf(fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11])),
-                       fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]))));
-    if (__builtin_amdgcn_ballot_w64(m >= thr) != 0) {
-      const uint32_t row0 = cur * 32 + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t doc = row0 + (r & 3) + 8 * (r >> 2);
-        const bool pass = (acc[r] >= thr) && (doc < p.n_rows);
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
-        if (mask) {
-          const int n = __builtin_popcountll(mask);
-          if (wq_n + n > SCAN_WQ) {
-            flush();
-            wq_n = 0;
-          }
-          if (pass) {
-            const int off = wq_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
-            wq_key[off] = rarc_candkey(acc[r], doc);
-            wq_q[off] = qidx;
-          }
-          wq_n += n;
-        }
-      }
+      pend = false;
     }
 
-    // ---- threshold refresh events: it = 1,2,4,8,... then every 64 tiles ----
+    // ---- prune (group A: this tile, right away; group B: deferred to the next iteration) ----
+    if (!(ABL & 1)) {
+      if (!grp_b) prune(acc, cur);
+      else prev = cur;
+    }
+
+    // ---- threshold refresh events: every tile up to 8, then every 4th ----
     ++it;
-    if ((it & (it - 1)) == 0 || (it & 63) == 0) {
-      if (wq_n > 0) {  // publish what we have so the histograms see it
-        flush();
-        wq_n = 0;
-      }
+    if (!(ABL & 8) && (it <= 8 || (it & 3) == 0)) {
       if (wave == 0) {
         const uint32_t owned = (p.nq + stride - 1 - blockIdx.x) / stride;  // queries ≡ blockIdx (mod grid)
         if (owned > 0) {
           own_q = blockIdx.x + stride * (event % owned);
-          const uint32_t* hq = p.hist + (size_t)own_q * RARC_NB + 4 * lane;
-          hp0 = __hip_atomic_load(hq + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hp1 = __hip_atomic_load(hq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hp2 = __hip_atomic_load(hq + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          hp3 = __hip_atomic_load(hq + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // 256 bins x 4 B = one 1-KiB LDS-DMA (sc1: served coherently from L2), consumed next tile
+          __builtin_amdgcn_global_load_lds(RARC_GPTR(p.hist + (size_t)own_q * RARC_NB + 4 * rarc_fresh_lane()),
+                                           RARC_LPTR(smem + L::HLAND), 16, 0, 16);
         }
         ++event;
       }
-      thr_pend = __hip_atomic_load(&p.thr[qidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(p.thr + wave * 32 + (rarc_fresh_lane() & 31)),
+                                       RARC_LPTR(smem + L::TLAND + wave * 256), 4, 0, 16);
+      pend = true;
     }
 
-    buf = buf + 1;
-    if (buf >= 3) buf = 0;
+    if (buf == 2) {
+      buf = 0;
+      a0 -= 2 * TILE_BYTES; a1 -= 2 * TILE_BYTES; a2 -= 2 * TILE_BYTES; a3 -= 2 * TILE_BYTES;
+    } else {
+      ++buf;
+      a0 += TILE_BYTES; a1 += TILE_BYTES; a2 += TILE_BYTES; a3 += TILE_BYTES;
+    }
   }
-  if (wq_n > 0) flush();
+  if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
+  __syncthreads();
+  {
+    const int t2 = wave * 64 + rarc_fresh_lane();
+    if (t2 < RARC_MAX_QUERIES) p.cnt2[(size_t)blockIdx.x * RARC_MAX_QUERIES + t2] = s_cnt[t2];
+  }
 }
 
-// ---- init: thresholds, counters, histograms ------------------------------------------------
-__global__ void rarc_scan_init_kernel(uint32_t* thr, uint32_t* cnt, uint32_t* flags, uint32_t* hist,
-                                      uint32_t nq) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < RARC_MAX_QUERIES) {
-    thr[i] = (i < nq) ? 0xff800000u : 0x7f800000u;  // -inf : +inf (padding never passes)
-    cnt[i] = 0;
+// ---- seed pass: score a strided sample of tiles so the scan starts with a real threshold ----
+// Without it every workgroup passes everything until the histogram feedback loop closes
+// (~4 tiles x 256 workgroups x 32 rows = 32K candidates per query).  grid = (8 query blocks,
+// seed_tiles); one block scores one 32-row tile against 32 queries, its 4 waves splitting the
+// k range (all fragment loads of a wave are issued at once: one memory round trip), partial
+// accumulators summed through LDS.  Rows come straight from global memory (6 MB, L2-shared by
+// the 8 query blocks).
+template <int D>
+__global__ __launch_bounds__(256) void rarc_seed_kernel(const half_t* __restrict__ corpus,
+                                                        const half_t* __restrict__ q16, uint32_t n_rows,
+                                                        uint32_t n_tiles, uint32_t seed_tiles,
+                                                        float* __restrict__ seed) {
+  constexpr int KS = D / 16, KW = KS / 4;  // k-steps per wave (D multiple of 128 -> KS multiple of 8)
+  __shared__ float part[3][16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 31, h = lane >> 5;
+  const uint32_t ti = blockIdx.y;
+  const uint32_t step = n_tiles / seed_tiles;  // >= 1 (seed_tiles <= n_tiles)
+  const uint32_t tile = ti * step;
+  const uint32_t qidx = blockIdx.x * 32 + row;
+  uint32_t arow = tile * 32 + row;
+  if (arow >= n_rows) arow = n_rows - 1;
+  const half_t* qp = q16 + (size_t)qidx * D + 8 * h + 16 * KW * wave;
+  const half_t* ap = corpus + (size_t)arow * D + 8 * h + 16 * KW * wave;
+  half8 af[KW], bf[KW];
+#pragma unroll
+  for (int ks = 0; ks < KW; ++ks) {
+    af[ks] = *(const half8*)(ap + 16 * ks);
+    bf[ks] = *(const half8*)(qp + 16 * ks);
   }
-  if (i < 64) flags[i] = 0;
-  for (uint32_t j = i; j < RARC_MAX_QUERIES * RARC_NB; j += gridDim.x * blockDim.x) hist[j] = 0;
+  f32x16 acc = {0};
+#pragma unroll
+  for (int ks = 0; ks < KW; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[ks], acc, 0, 0, 0);
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = seed + (size_t)qidx * (RARC_SEED_TILES * 32) + ti * 32;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
+      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+      out[rr] = (tile * 32 + rr < n_rows) ? v : -INFINITY;
+    }
+  }
+}
+
+// One workgroup per query slot.  thr[q] = (a hair below) the k'-th largest seed score — a lower
+// bound of the k'-th best score of the whole shard: one 11-bit radix pass on the order-preserving
+// keys finds the bin holding it, the few keys of that bin are ranked directly.  Also sets the
+// query's histogram window [lo, lo + 4·(max − lo)] and clears its histogram.
+__global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, uint32_t seed_rows, uint32_t kprime,
+                                                            uint32_t nq, float bin_lo_dflt, float bin_hi_dflt,
+                                                            uint32_t* thr, float* binlo, float* binscale,
+                                                            float* bininv, uint32_t* flags, uint32_t* hist) {
+  constexpr int PER = RARC_SEED_TILES * 32 / 256;  // 16 keys per thread
+  __shared__ uint32_t s_hist[2048];
+  __shared__ uint32_t s_list[RARC_SEED_TILES * 32];
+  __shared__ uint32_t s_bin, s_need, s_max, s_min, s_nlist, s_key;
+  const uint32_t q = blockIdx.x, tid = threadIdx.x;
+  for (uint32_t i = tid; i < RARC_NB; i += blockDim.x) hist[q * RARC_NB + i] = 0;
+  if (q == 0 && tid < 64) flags[tid] = 0;
+  float t = -INFINITY, mx = -INFINITY;
+  if (q < nq && seed_rows > 0) {  // block-uniform
+    uint32_t key[PER];
+    uint32_t lmax = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const uint32_t j = tid + i * 256;
+      float v = (j < seed_rows) ? seed[(size_t)q * (RARC_SEED_TILES * 32) + j] : -INFINITY;
+      if (!(v == v)) v = -INFINITY;  // NaN never becomes a threshold
+      key[i] = rarc_ordkey(v);
+      lmax = key[i] > lmax ? key[i] : lmax;
+    }
+    for (uint32_t i = tid; i < 2048; i += 256) s_hist[i] = 0;
+    if (tid == 0) { s_max = 0; s_min = 0xffffffffu; s_nlist = 0; s_key = 0; s_bin = 0; s_need = kprime; }
+    __syncthreads();
+    {  // block min / max of the keys: wave reduction first, one LDS atomic per wave
+      uint32_t lmin = 0xffffffffu;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) lmin = (key[i] > 0x007fffffu && key[i] < lmin) ? key[i] : lmin;  // skip -inf padding
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(lmax, o, 64), b2 = __shfl_xor(lmin, o, 64);
+        lmax = a > lmax ? a : lmax;
+        lmin = b2 < lmin ? b2 : lmin;
+      }
+      if ((tid & 63) == 0) { atomicMax(&s_max, lmax); atomicMin(&s_min, lmin); }
+    }
+    __syncthreads();
+    // 2048 linear bins over [min, max] of the (monotone) keys: spreads the values, so the LDS
+    // atomics do not pile up on a few addresses the way the keys' top bits would
+    const uint32_t kmin = s_min < s_max ? s_min : s_max, krange = s_max - kmin;
+    const float kscale = krange ? 2047.f / (float)krange : 0.f;
+    uint32_t kb[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      uint32_t b2 = key[i] > kmin ? (uint32_t)((float)(key[i] - kmin) * kscale) : 0u;  // monotone in key
+      kb[i] = b2 > 2047u ? 2047u : b2;
+      atomicAdd(&s_hist[kb[i]], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {  // wave 0: bin holding the k'-th largest, count above it
+      uint32_t above = 0;
+      const int b = rarc_wave_find_from_top(s_hist, 2048, kprime, &above);
+      if (tid == 0) { s_bin = b < 0 ? 0u : (uint32_t)b; s_need = kprime - above; }
+    }
+    __syncthreads();
+    const uint32_t bin = s_bin, need = s_need;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (kb[i] == bin) s_list[atomicAdd(&s_nlist, 1u)] = key[i];
+    __syncthreads();
+    const uint32_t nl = s_nlist;
+    for (uint32_t i = tid; i < nl; i += 256) {  // the need-th largest of the bin (ties share a value)
+      const uint32_t mine = s_list[i];
+      uint32_t gt = 0, ge = 0;
+      for (uint32_t j = 0; j < nl; ++j) { gt += s_list[j] > mine; ge += s_list[j] >= mine; }
+      if (gt < need && need <= ge) s_key = mine;
+    }
+    __syncthreads();
+    if (kprime <= seed_rows) {
+      t = rarc_unordkey(s_key);
+      t -= fabsf(t) * 1e-5f + 1e-7f;  // the seed's 4-way k split rounds differently from the scan's chain
+    }
+    mx = rarc_unordkey(s_max);
+  }
+  if (tid == 0) {
+    float lo = bin_lo_dflt, hi = bin_hi_dflt;
+    if (q >= nq) t = INFINITY;  // padding queries never pass
+    else if (t > -INFINITY && mx > t) {
+      float w = 4.f * (mx - t);
+      const float wmin = 1e-3f * fabsf(t) + 1e-20f;  // keeps fp32 rounding of the bin map below one bin
+      if (w < wmin) w = wmin;
+      lo = t;
+      hi = t + w;
+    }
+    thr[q] = __float_as_uint(t);
+    binlo[q] = lo;
+    binscale[q] = (float)RARC_NB / (hi - lo);
+    bininv[q] = (hi - lo) / (float)RARC_NB;
+  }
+}
+
+template <int D>
+static int launch_seed(const ScanParams& p, uint32_t seed_tiles, float* seed, hipStream_t s) {
+  hipLaunchKernelGGL(rarc_seed_kernel<D>, dim3(RARC_MAX_QUERIES / 32, seed_tiles), dim3(256), 0, s,
+                     p.corpus, p.q16, p.n_rows, p.n_tiles, seed_tiles, seed);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
 }
 
 template <int D>
 static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
-  constexpr size_t lds = 3 * 32 * D * 2 + SCAN_WAVES * SCAN_WQ * 12;
+  constexpr size_t lds = ScanLds<D>::TOTAL;
   static bool attr_done = false;
   if (!attr_done) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_f16_kernel<D>,
@@ -299,9 +476,9 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
   return RARC_OK;
 }
 
-// Host entry used by rarc_api.cpp.
+// Host entry used by rarc_api.hip.  *grid_out = workgroups launched (owners of candidate segments).
 int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq,
-                         int kprime, float bin_lo, float bin_hi, const RarcWs& ws, int cap,
+                         int kprime, float bin_lo, float bin_hi, const RarcWs& ws, int cap, int* grid_out,
                          hipStream_t s) {
   ScanParams p;
   p.corpus = (const half_t*)corpus;
@@ -309,36 +486,48 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
   p.n_rows = (uint32_t)n_rows;
   p.n_tiles = (uint32_t)((n_rows + 31) / 32);
   p.thr = (uint32_t*)ws.thr;
+  p.binlo = ws.binlo;
+  p.binscale = ws.binscale;
+  p.bininv = ws.bininv;
   p.hist = ws.hist;
-  p.cnt = ws.cnt;
+  p.cnt2 = ws.cnt2;
   p.cand = ws.cand;
-  p.flags = ws.flags;
-  p.cap = (uint32_t)cap;
+  p.seg = (uint32_t)(cap / RARC_MAX_WG);
   p.kprime = (uint32_t)kprime;
   p.nq = (uint32_t)nq;
-  p.bin_lo = bin_lo;
-  p.bin_scale = (float)RARC_NB / (bin_hi - bin_lo);
-  p.bin_inv_scale = (bin_hi - bin_lo) / (float)RARC_NB;
 
-  hipLaunchKernelGGL(rarc_scan_init_kernel, dim3(64), dim3(256), 0, s, (uint32_t*)ws.thr, ws.cnt,
-                     ws.flags, ws.hist, (uint32_t)nq);
+  const uint32_t seed_tiles = p.n_tiles < (uint32_t)RARC_SEED_TILES ? p.n_tiles : (uint32_t)RARC_SEED_TILES;
+#define RARC_DISPATCH_D(CALL)                                                                         \
+  switch (d_pad) {                                                                                    \
+    case 128: rc = CALL(128); break;                                                                  \
+    case 256: rc = CALL(256); break;                                                                  \
+    case 384: rc = CALL(384); break;                                                                  \
+    case 512: rc = CALL(512); break;                                                                  \
+    case 640: rc = CALL(640); break;                                                                  \
+    case 768: rc = CALL(768); break;                                                                  \
+    default:                                                                                          \
+      rarc_set_error("rarc_scan_f16: padded dim %d unsupported (multiple of 128, <= 768)", d_pad);    \
+      rc = RARC_E_UNSUPPORTED;                                                                        \
+  }
+  int rc = RARC_OK;
+  if (seed_tiles > 0) {
+#define SEED_CALL(DD) launch_seed<DD>(p, seed_tiles, ws.seed, s)
+    RARC_DISPATCH_D(SEED_CALL)
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, s, ws.seed, seed_tiles * 32,
+                     (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, (uint32_t*)ws.thr, ws.binlo, ws.binscale,
+                     ws.bininv, ws.flags, ws.hist);
   RARC_HIP_CHECK(hipGetLastError());
-  if (p.n_tiles == 0) return RARC_OK;
 
   int dev = 0, cus = 256;
   RARC_HIP_CHECK(hipGetDevice(&dev));
   RARC_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  int grid = cus;
+  int grid = cus < RARC_MAX_WG ? cus : RARC_MAX_WG;
   if ((uint32_t)grid > p.n_tiles) grid = (int)p.n_tiles;
-  switch (d_pad) {
-    case 128: return launch_scan<128>(p, grid, s);
-    case 256: return launch_scan<256>(p, grid, s);
-    case 384: return launch_scan<384>(p, grid, s);
-    case 512: return launch_scan<512>(p, grid, s);
-    case 640: return launch_scan<640>(p, grid, s);
-    case 768: return launch_scan<768>(p, grid, s);
-    default:
-      rarc_set_error("rarc_scan_f16: padded dim %d unsupported (multiple of 128, <= 768)", d_pad);
-      return RARC_E_UNSUPPORTED;
-  }
+  *grid_out = grid;
+  if (p.n_tiles == 0) return RARC_OK;
+#define SCAN_CALL(DD) launch_scan<DD>(p, grid, s)
+  RARC_DISPATCH_D(SCAN_CALL)
+  return rc;
 }

@@ -44,7 +44,7 @@ def _check(hip, oracle, X, Q, k, metric="cosine"):
     assert np.array_equal(D.view(np.uint32), ref_D.view(np.uint32)), "scores not bit-identical"
     # and within 1e-5 of float64 truth (north-star tolerance)
     i64, s64 = oracle.flat_search_f64(ref_rows, qn, kk)
-    assert np.max(np.abs(s64 - D)) < 1e-5
+    assert np.max(np.abs(s64 - D) / np.maximum(1.0, np.abs(s64))) < 1e-5
     return idx
 
 
