@@ -168,6 +168,15 @@ int rarc_synth_rows_f16(uint16_t* d_out_f16, int d_pad, int d, int64_t first_row
 int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_row,
                         int64_t n_rows, uint64_t seed, void* stream);
 
+/*
+ * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan
+ * kernel with a pair of HIP events recorded on the search's own stream.  rarc_profile_end
+ * synchronises, returns the summed scan time and the number of launches measured, and releases
+ * the events.  Not thread safe; one profiling session at a time.
+ */
+int rarc_profile_begin(int max_launches);
+int rarc_profile_end(double* total_scan_ms, int* n_launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,43 @@ int rarc_merge_launch(const int64_t* ids, const float* scores, int G, int nq, in
 
 static thread_local char g_err[512] = "";
 
+// ---- scan timing hooks -------------------------------------------------------------------------
+#include <vector>
+static std::vector<hipEvent_t> g_prof_ev;  // pairs: [2i] start, [2i+1] stop
+static int g_prof_n = 0;
+static bool g_prof_on = false;
+bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof_on || (size_t)(2 * g_prof_n + 1) >= g_prof_ev.size()) return false;
+  *start = g_prof_ev[2 * g_prof_n];
+  *stop = g_prof_ev[2 * g_prof_n + 1];
+  ++g_prof_n;
+  return true;
+}
+extern "C" int rarc_profile_begin(int max_launches) {
+  RARC_REQUIRE(max_launches > 0 && max_launches <= 65536 && !g_prof_on, RARC_E_INVALID, "rarc_profile_begin: bad state");
+  g_prof_ev.resize((size_t)2 * max_launches);
+  for (auto& e : g_prof_ev) RARC_HIP_CHECK(hipEventCreate(&e));
+  g_prof_n = 0;
+  g_prof_on = true;
+  return RARC_OK;
+}
+extern "C" int rarc_profile_end(double* total_scan_ms, int* n_launches) {
+  RARC_REQUIRE(g_prof_on && total_scan_ms && n_launches, RARC_E_INVALID, "rarc_profile_end: not profiling");
+  double tot = 0;
+  for (int i = 0; i < g_prof_n; ++i) {
+    RARC_HIP_CHECK(hipEventSynchronize(g_prof_ev[2 * i + 1]));
+    float ms = 0;
+    RARC_HIP_CHECK(hipEventElapsedTime(&ms, g_prof_ev[2 * i], g_prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *total_scan_ms = tot;
+  *n_launches = g_prof_n;
+  for (auto& e : g_prof_ev) hipEventDestroy(e);
+  g_prof_ev.clear();
+  g_prof_on = false;
+  return RARC_OK;
+}
+
 void rarc_set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -462,6 +462,8 @@ static int launch_seed(const ScanParams& p, uint32_t seed_tiles, float* seed, hi
   return RARC_OK;
 }
 
+bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop);  // rarc_api.hip
+
 template <int D>
 static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
   constexpr size_t lds = ScanLds<D>::TOTAL;
@@ -471,8 +473,12 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
+  hipEvent_t e0, e1;
+  const bool prof = rarc_prof_next(&e0, &e1);
+  if (prof) RARC_HIP_CHECK(hipEventRecord(e0, s));
   hipLaunchKernelGGL(rarc_scan_f16_kernel<D>, dim3(grid), dim3(SCAN_WAVES * 64), lds, s, p);
   RARC_HIP_CHECK(hipGetLastError());
+  if (prof) RARC_HIP_CHECK(hipEventRecord(e1, s));
   return RARC_OK;
 }
 

@@ -6,6 +6,7 @@
 #include <vector>
 #include "../rag-arc_amd/csrc/scan_f16.hip"
 void rarc_set_error(const char* fmt, ...) { (void)fmt; }
+bool rarc_prof_next(hipEvent_t*, hipEvent_t*) { return false; }
 
 template <int ABL>
 static float run(const ScanParams& p, int grid, int iters, uint32_t nq, int kprime, RarcWs ws, uint32_t seed_tiles) {
