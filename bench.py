@@ -123,7 +123,7 @@ def main():
     B.check(lib.rarc_profile_end(ctypes.byref(tot_ms), ctypes.byref(n_l)), "rarc_profile_end")
     scan_ms = tot_ms.value / max(1, n_l.value)
     shard_bytes = (hi - lo) * d_pad * 2  # algorithmic bytes of one scan launch on this rank
-    flagged = int((idx.last_status != 0).sum().item())
+    flagged = len(getattr(idx, "last_repaired", []))
 
     result = None
     if rank == 0:

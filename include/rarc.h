@@ -88,7 +88,10 @@ int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad
                       float corpus_max_norm, float* d_q32, uint16_t* d_q16, float* d_eps,
                       void* stream);
 
-/* Bytes of device scratch rarc_search_f16 / rarc_repair_f16 need (16-byte aligned base). */
+/* Bytes of device scratch rarc_search_f16 / rarc_repair_f16 need (256-byte aligned base).
+ * After a search, the uint32 at byte offset RARC_WS_ANYFLAG_OFFSET of the workspace is the OR of
+ * all d_status words of that search (0 == nothing to repair). */
+#define RARC_WS_ANYFLAG_OFFSET 5124
 size_t rarc_search_workspace_bytes(int cand_cap);
 
 /*

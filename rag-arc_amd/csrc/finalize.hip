@@ -61,6 +61,7 @@ struct FinParams {
   const uint32_t* hist;
   const float* binlo;
   const float* bininv;
+  uint32_t* flags;
   uint32_t seg;
   uint32_t n_wg;
   int d;
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(FIN_THREADS) void rarc_finalize_kernel(const FinPar
       if (!(tmin + p.eps[q] < s_sk)) st |= RARC_Q_UNCERTAIN;
     }
     p.status[q] = st;
+    if (st) atomicOr(&p.flags[1], st);  // one word the host can poll instead of scanning d_status
   }
 }
 
@@ -197,6 +199,7 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
   p.hist = ws.hist;
   p.binlo = ws.binlo;
   p.bininv = ws.bininv;
+  p.flags = ws.flags;
   p.seg = (uint32_t)(cap / RARC_MAX_WG);
   p.n_wg = (uint32_t)n_wg;
   p.d = d_pad;

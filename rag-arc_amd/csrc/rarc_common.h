@@ -33,6 +33,7 @@ constexpr size_t RARC_WS_BINSCALE = 2048;
 constexpr size_t RARC_WS_BININV = 3072;
 constexpr size_t RARC_WS_CNT = 4096;
 constexpr size_t RARC_WS_FLAGS = 5120;
+static_assert(RARC_WS_FLAGS + 4 == RARC_WS_ANYFLAG_OFFSET, "include/rarc.h out of sync");
 constexpr size_t RARC_WS_HIST = 8192;
 constexpr size_t RARC_WS_CNT2 = RARC_WS_HIST + (size_t)RARC_MAX_QUERIES * RARC_NB * 4;
 constexpr size_t RARC_WS_SEED = RARC_WS_CNT2 + (size_t)RARC_MAX_WG * RARC_MAX_QUERIES * 4;

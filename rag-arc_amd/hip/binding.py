@@ -17,6 +17,7 @@ MAX_K = 1024
 DIM_ALIGN = 128
 Q_UNCERTAIN = 1
 Q_OVERFLOW = 2
+WS_ANYFLAG_OFFSET = 5124
 
 
 class RarcError(RuntimeError):

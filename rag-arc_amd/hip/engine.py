@@ -193,7 +193,9 @@ class FlatIndexF16:
         self.last_status = b["status"][:nq]
         if not repair or self.ntotal == 0:
             return
-        flagged = t.nonzero(b["status"][:nq]).flatten().tolist()  # syncs; almost always empty
+        # one 4-byte read-back per batch (syncs); the per-query words are fetched only if it is set
+        any_flag = int(ws[B.WS_ANYFLAG_OFFSET: B.WS_ANYFLAG_OFFSET + 4].view(t.int32).item())
+        flagged = t.nonzero(b["status"][:nq]).flatten().tolist() if any_flag else []
         self.last_repaired = flagged
         for qi in flagged:
             B.check(self.lib.rarc_repair_f16(rows_ptr, self.ntotal, self.d_pad, b["q32"].data_ptr(), qi, k,
