@@ -196,14 +196,21 @@ def max_inner_product_relevance(score: float) -> float:
 
 
 # --------------------------------------------------------------------------------------- rerank
-def rerank_scores_f16(z_no: np.ndarray, z_yes: np.ndarray) -> np.ndarray:
-    """Reranker_Qwen3.py:41-49 on fp16 logits: exp(log_softmax([no, yes])[1]) where the
-    log_softmax output and the exp output are fp16 tensors (math in fp32).  Returns float16."""
+def rerank_logsoftmax_yes_f16(z_no: np.ndarray, z_yes: np.ndarray) -> np.ndarray:
+    """log_softmax([no, yes])[1] as an fp16 tensor (math in fp32): (yes - max) - log(sum exp(x - max))."""
     zn = np.asarray(z_no, dtype=np.float16).astype(np.float32)
     zy = np.asarray(z_yes, dtype=np.float16).astype(np.float32)
     m = np.maximum(zn, zy)
     s = np.exp(zn - m, dtype=np.float32) + np.exp(zy - m, dtype=np.float32)
-    ls = ((zy - m) - np.log(s, dtype=np.float32)).astype(np.float16)
+    return ((zy - m) - np.log(s, dtype=np.float32)).astype(np.float16)
+
+
+def rerank_scores_f16(z_no: np.ndarray, z_yes: np.ndarray) -> np.ndarray:
+    """Reranker_Qwen3.py:41-49 on fp16 logits: exp(log_softmax([no, yes])[1]) where the
+    log_softmax output and the exp output are fp16 tensors (math in fp32).  Returns float16.
+    expf/logf are not bit-identical across libm / SLEEF / ocml, so a last-place difference in the
+    fp16 log-softmax (amplified by exp) is the parity limit of this step; ORDER is what is pinned."""
+    ls = rerank_logsoftmax_yes_f16(z_no, z_yes)
     return np.exp(ls.astype(np.float32), dtype=np.float32).astype(np.float16)
 
 

@@ -1,0 +1,14 @@
+"""Counterpart of the reference's config/app_registration.py:1-5: the registry singleton plus a
+helper that registers this backend's retriever stacks under the framework's own mechanism."""
+from ..framework.register import Register
+from .modules import MultiPathRetrieverConfig, VectorStoreRetrieverConfig
+
+registrator = Register()
+
+
+def register_dense_retriever(config_path: str, app_name: str = "hip_dense_retriever") -> None:
+    registrator.register(config_path, app_name, VectorStoreRetrieverConfig)
+
+
+def register_multipath_retriever(config_path: str, app_name: str = "hip_multipath_retriever") -> None:
+    registrator.register(config_path, app_name, MultiPathRetrieverConfig)

@@ -1,0 +1,104 @@
+"""Tagged configs + modules that register this backend through the framework (the pattern of
+framework/config.py + framework/module.py in the reference; pinned by its 21 framework tests).
+
+JSON -> <Config>(**data).build() -> module graph, e.g.
+
+    {"type": "multipath_retriever", "top_k_per_retriever": 50, "fusion": {"type": "rrf", "k": 60.0},
+     "retrievers": [{"type": "vectorstore_retriever", "search_type": "similarity",
+                     "vectorstore": {"type": "hip_flat_vectorstore", "metric": "cosine",
+                                     "embedding": {"type": "table_embeddings", "path": "emb.npz"},
+                                     "corpus_path": "corpus.npz"}}]}
+"""
+from dataclasses import dataclass, field
+from typing import Annotated, Any, Dict, List, Literal, Optional, Union
+
+from pydantic import Field
+
+from ..framework.config import AbstractConfig
+from ..framework.module import AbstractModule
+
+
+@dataclass
+class BuiltModule(AbstractModule):
+    """A module that owns one built object (`impl`) and forwards attribute access to it."""
+    impl: Any = field(default=None, repr=False)
+
+    def __getattr__(self, name):
+        impl = self.__dict__.get("impl")
+        if impl is None:
+            raise AttributeError(name)
+        return getattr(impl, name)
+
+
+class TableEmbeddingsConfig(AbstractConfig):
+    type: Literal["table_embeddings"] = "table_embeddings"
+    path: str
+
+    def build(self) -> AbstractModule:
+        from ..encapsulation.embeddings.table import TableEmbeddings
+
+        return BuiltModule(config=self, impl=TableEmbeddings.from_npz(self.path))
+
+
+EmbeddingsConfig = Annotated[Union[TableEmbeddingsConfig], Field(discriminator="type")]
+
+
+class HipFlatVectorStoreConfig(AbstractConfig):
+    type: Literal["hip_flat_vectorstore"] = "hip_flat_vectorstore"
+    embedding: TableEmbeddingsConfig
+    metric: Literal["cosine", "ip"] = "cosine"
+    normalize_L2: bool = False
+    device: int = 0
+    corpus_path: Optional[str] = None  # .npz with `texts` (and optional `ids`) to ingest at build time
+
+    def build(self) -> AbstractModule:
+        import numpy as np
+
+        from ..encapsulation.database.vector_db.hip_flat import HipFlatVectorStore
+
+        store = HipFlatVectorStore(self.embedding.build().impl, metric=self.metric, normalize_L2=self.normalize_L2,
+                                   device=self.device)
+        if self.corpus_path:
+            data = np.load(self.corpus_path, allow_pickle=False)
+            ids = [str(i) for i in data["ids"]] if "ids" in data else None
+            store.add_texts([str(t) for t in data["texts"]], ids=ids)
+        return BuiltModule(config=self, impl=store)
+
+
+class VectorStoreRetrieverConfig(AbstractConfig):
+    type: Literal["vectorstore_retriever"] = "vectorstore_retriever"
+    vectorstore: HipFlatVectorStoreConfig
+    search_type: str = "similarity"
+    search_kwargs: Dict[str, Any] = Field(default_factory=dict)
+
+    def build(self) -> AbstractModule:
+        from ..core.retrieval.dense import VectorStoreRetriever
+
+        return BuiltModule(config=self, impl=VectorStoreRetriever(self.vectorstore.build().impl,
+                                                                  search_type=self.search_type,
+                                                                  search_kwargs=dict(self.search_kwargs)))
+
+
+class RRFusionConfig(AbstractConfig):
+    type: Literal["rrf"] = "rrf"
+    k: float = 60.0
+    device: int = 0
+
+    def build(self) -> AbstractModule:
+        from ..core.utils.fusion import HipRRFusion
+
+        return BuiltModule(config=self, impl=HipRRFusion(k=self.k, device=self.device))
+
+
+class MultiPathRetrieverConfig(AbstractConfig):
+    type: Literal["multipath_retriever"] = "multipath_retriever"
+    retrievers: List[Annotated[Union[VectorStoreRetrieverConfig], Field(discriminator="type")]]
+    fusion: RRFusionConfig = Field(default_factory=RRFusionConfig)
+    top_k_per_retriever: int = 50
+
+    def build(self) -> AbstractModule:
+        from ..core.retrieval.multipath import MultiPathRetriever
+
+        return BuiltModule(config=self, impl=MultiPathRetriever([r.build().impl for r in self.retrievers],
+                                                                fusion_method=self.fusion.build().impl,
+                                                                top_k_per_retriever=self.top_k_per_retriever))

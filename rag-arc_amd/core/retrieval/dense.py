@@ -1,0 +1,94 @@
+"""Vector-store backed retriever (reference: core/retrieval/dense.py:13-380).
+
+search_type: "similarity" | "similarity_score_threshold" | "mmr".  Sync path: k defaults to 5 and
+the result is cut to k; the async path neither defaults k nor truncates (reference quirk, kept).
+Unknown keyword arguments (e.g. the `top_k` that MultiPathRetriever leaks down) are passed on to
+the store untouched.  Errors are logged and re-raised.
+"""
+import logging
+from typing import Any, Dict, List
+
+from ..utils.data_model import Document
+from .base import BaseRetriever
+
+logger = logging.getLogger(__name__)
+
+_SEARCH_TYPES = ("similarity", "similarity_score_threshold", "mmr")
+
+
+class VectorStoreRetriever(BaseRetriever):
+    allowed_search_types = _SEARCH_TYPES
+
+    def __init__(self, vectorstore, **kwargs):
+        self.vectorstore = vectorstore
+        self.search_type = kwargs.get("search_type", "similarity")
+        self.search_kwargs = kwargs.get("search_kwargs", {})
+        self._validate_search_config()
+        super().__init__(**kwargs)
+
+    def _validate_search_config(self) -> None:
+        if self.search_type not in self.allowed_search_types:
+            raise ValueError(f"search_type '{self.search_type}' is not allowed; valid: {self.allowed_search_types}")
+        if self.search_type == "similarity_score_threshold":
+            thr = self.search_kwargs.get("score_threshold")
+            if thr is None or not isinstance(thr, (int, float)) or not (0 <= thr <= 1):
+                raise ValueError("'similarity_score_threshold' needs search_kwargs['score_threshold'] in [0, 1]")
+
+    # ------------------------------------------------------------------ sync
+    def _get_relevant_documents(self, query: str, **kwargs: Any) -> List[Document]:
+        params: Dict[str, Any] = {**self.search_kwargs, **kwargs}
+        k = params.get("k", getattr(self, "k", 5))
+        params["k"] = k
+        try:
+            if self.search_type == "similarity":
+                docs = self.vectorstore.similarity_search(query, **params)
+            elif self.search_type == "similarity_score_threshold":
+                docs = [d for d, _ in self.vectorstore.similarity_search_with_relevance_scores(query, **params)]
+            elif self.search_type == "mmr":
+                docs = self.vectorstore.max_marginal_relevance_search(query, **params)
+            else:
+                raise ValueError(f"unsupported search type: {self.search_type}")
+            return docs[:k]
+        except Exception as exc:
+            logger.error("retrieval failed: %s", exc)
+            raise
+
+    # ------------------------------------------------------------------ async
+    async def _aget_relevant_documents(self, query: str, **kwargs: Any) -> List[Document]:
+        params: Dict[str, Any] = {**self.search_kwargs, **kwargs}
+        try:
+            if self.search_type == "similarity":
+                return await self.vectorstore.asimilarity_search(query, **params)
+            if self.search_type == "similarity_score_threshold":
+                pairs = await self.vectorstore.asimilarity_search_with_relevance_scores(query, **params)
+                return [d for d, _ in pairs]
+            if self.search_type == "mmr":
+                return await self.vectorstore.amax_marginal_relevance_search(query, **params)
+            raise ValueError(f"unsupported search type: {self.search_type}")
+        except Exception as exc:
+            logger.error("async retrieval failed: %s", exc)
+            raise
+
+    # ------------------------------------------------------------------ passthroughs
+    def add_documents(self, documents: List[Document], **kwargs: Any) -> List[str]:
+        return self.vectorstore.add_documents(documents, **kwargs)
+
+    async def aadd_documents(self, documents: List[Document], **kwargs: Any) -> List[str]:
+        return await self.vectorstore.aadd_documents(documents, **kwargs)
+
+    def delete_documents(self, ids: List[str], **kwargs: Any):
+        return self.vectorstore.delete(ids, **kwargs)
+
+    def get_by_ids(self, ids: List[str]) -> List[Document]:
+        return self.vectorstore.get_by_ids(ids)
+
+    def get_vectorstore_info(self) -> Dict[str, Any]:
+        return {"vectorstore_type": type(self.vectorstore).__name__, "search_type": self.search_type,
+                "search_kwargs": dict(self.search_kwargs)}
+
+    def update_search_params(self, **kwargs: Any) -> None:
+        if "search_type" in kwargs:
+            self.search_type = kwargs.pop("search_type")
+        if "search_kwargs" in kwargs:
+            self.search_kwargs = kwargs.pop("search_kwargs")
+        self._validate_search_config()

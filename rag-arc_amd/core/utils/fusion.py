@@ -1,0 +1,87 @@
+"""Result fusion (reference: core/utils/Fusion.py:9-76).
+
+RRFusion.fuse semantics kept bit for bit: ranks are re-numbered 1.. inside every input list (the
+inputs are mutated, as in the reference); score(content) = sum over occurrences — lists in order,
+positions in order — of 1.0 / (k + rank) in fp64; the Document kept for a content is the LAST one
+seen; order = score descending, ties in first-insertion order; output ranks 1...
+
+The arithmetic runs in the rarc_rrf_fuse HIP kernel (rag-arc_amd/csrc/fuse.hip): contents are
+mapped to integer keys in first-seen order on the host, the kernel returns keys + fp64 scores.
+`fuse_ids` is the batched form used when retrieval results are already ids on the device.
+"""
+from abc import ABC, abstractmethod
+from dataclasses import dataclass
+from typing import List
+
+from .data_model import Document
+
+
+@dataclass
+class RetrievalResult:
+    document: Document
+    score: float
+    rank: int = 0
+
+
+class FusionMethod(ABC):
+    @abstractmethod
+    def fuse(self, results: List[List[RetrievalResult]], top_k: int) -> List[RetrievalResult]:
+        """Merge the per-retriever result lists into one ranked list of at most top_k entries."""
+
+
+class HipRRFusion(FusionMethod):
+    """Reciprocal-rank fusion on the MI355X."""
+
+    def __init__(self, k: float = 60.0, device: int = 0):
+        self.k = k
+        self.device = device
+
+    # -- batched, id-keyed ------------------------------------------------------------------
+    def fuse_ids(self, keys, lengths, top_k: int):
+        """keys: int64 [nq][n_lists][max_len] device tensor, lengths: int32 [nq][n_lists].
+        Returns (fused keys int64 [nq][top_k], scores fp64 [nq][top_k], counts int32 [nq])."""
+        import torch
+
+        from ...hip import binding as B
+
+        lib = B.load_library()
+        nq, n_lists, max_len = keys.shape
+        out_k = torch.full((nq, max(top_k, 1)), -1, dtype=torch.int64, device=keys.device)
+        out_s = torch.zeros((nq, max(top_k, 1)), dtype=torch.float64, device=keys.device)
+        out_n = torch.zeros(nq, dtype=torch.int32, device=keys.device)
+        B.check(lib.rarc_rrf_fuse(keys.contiguous().data_ptr(), lengths.contiguous().data_ptr(), nq, n_lists,
+                                  max_len, float(self.k), int(top_k), out_k.data_ptr(), out_s.data_ptr(),
+                                  out_n.data_ptr(), torch.cuda.current_stream(keys.device).cuda_stream),
+                "rarc_rrf_fuse")
+        return out_k[:, :top_k], out_s[:, :top_k], out_n
+
+    # -- the FusionMethod contract --------------------------------------------------------------
+    def fuse(self, results: List[List[RetrievalResult]], top_k: int) -> List[RetrievalResult]:
+        import torch
+
+        for one in results:
+            for pos, item in enumerate(one):
+                item.rank = pos + 1
+        key_of, doc_of = {}, {}
+        max_len = max((len(one) for one in results), default=0)
+        if max_len == 0 or top_k <= 0:
+            return []
+        table = [[0] * max_len for _ in results]
+        for li, one in enumerate(results):
+            for pi, item in enumerate(one):
+                content = item.document.content
+                key = key_of.setdefault(content, len(key_of))
+                doc_of[key] = item.document  # last occurrence wins
+                table[li][pi] = key
+        dev = torch.device("cuda", self.device)
+        keys = torch.tensor([table], dtype=torch.int64, device=dev)
+        lens = torch.tensor([[len(one) for one in results]], dtype=torch.int32, device=dev)
+        fk, fs, fn = self.fuse_ids(keys, lens, min(top_k, len(key_of)))
+        n = int(fn[0].item())
+        fk, fs = fk[0, :n].tolist(), fs[0, :n].tolist()
+        return [RetrievalResult(document=doc_of[key], score=score, rank=i + 1)
+                for i, (key, score) in enumerate(zip(fk, fs))]
+
+
+# the name the reference exports
+RRFusion = HipRRFusion

@@ -1,0 +1,2 @@
+from .base import VectorStore  # noqa: F401
+from .hip_flat import HipFlatVectorStore  # noqa: F401

@@ -1,0 +1,224 @@
+"""HBM-resident exact vector store — the MI355X answer to the reference's
+"TODO: needs GPU support to go faster" (encapsulation/database/vector_db/VectorStore_Faiss.py:14).
+
+Same behaviour as FaissVectorStore for index_type "flat" with metric "cosine" or "ip"
+(VectorStore_Faiss.py:65-512): embed -> fp32 -> (L2-normalise) -> add; query -> fp32 ->
+(normalise) -> k = min(k, ntotal) -> search -> (Document, float(score)).  Rows are stored as fp16
+in HBM and scored by the HIP kernels behind `FlatIndexF16`; scores are the canonical fp32 inner
+products defined in DESIGN.md, ties ordered by insertion index.  IVF / HNSW / L2 are out of scope
+(SURVEY.md §8 a4).  There is no CPU fallback: without a GPU the default engine raises.
+"""
+import os
+import pickle
+import uuid
+from typing import Any, Callable, List, Optional, Tuple
+
+import numpy as np
+
+from ....core.utils.data_model import Document
+from .base import VectorStore
+
+
+def _default_engine(dim: int, metric: str, device: int):
+    from ....hip.engine import FlatIndexF16
+
+    return FlatIndexF16(dim, metric=metric, device=device)
+
+
+def _mmr_select(scored, embeddings, query_embedding, k, lambda_mult=0.5):
+    """Greedy maximal-marginal-relevance pick (reference: VectorStore_Faiss.py:16-62)."""
+    if k >= len(scored):
+        return [d for d, _ in scored]
+    emb = np.asarray(embeddings, dtype=np.float64)
+    qv = np.asarray(query_embedding, dtype=np.float64)
+    chosen, rest = [0], list(range(1, len(scored)))
+    while len(chosen) < k and rest:
+        best, best_val = None, None
+        for i in rest:
+            redundancy = max(0, max(float(np.dot(emb[j], emb[i])) for j in chosen))
+            val = lambda_mult * float(np.dot(qv, emb[i])) - (1 - lambda_mult) * redundancy
+            if best_val is None or val > best_val:
+                best, best_val = i, val
+        chosen.append(best)
+        rest.remove(best)
+    return [scored[i][0] for i in chosen]
+
+
+class HipFlatVectorStore(VectorStore):
+    def __init__(self, embedding, metric: str = "cosine", normalize_L2: bool = False, index_type: str = "flat",
+                 device: int = 0, engine_factory: Optional[Callable] = None, **kwargs: Any):
+        super().__init__(**kwargs)
+        if index_type != "flat":
+            raise ValueError(f"unsupported index type: {index_type} (exact flat scan only)")
+        if metric not in ("cosine", "ip"):
+            raise ValueError(f"unsupported metric: {metric}")
+        self.embedding = embedding
+        self.metric, self.normalize_L2, self.index_type, self.device = metric, normalize_L2, index_type, device
+        self._engine_factory = engine_factory or _default_engine
+        self.index = None  # created on first add, like the reference
+        self.docstore: dict = {}
+        self.index_to_docstore_id: dict = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _engine_metric(self) -> str:
+        return "cosine" if (self.metric == "cosine" or self.normalize_L2) else "ip"
+
+    @property
+    def ntotal(self) -> int:
+        return 0 if self.index is None else self.index.ntotal
+
+    # ------------------------------------------------------------------ ingestion
+    def add_texts(self, texts, metadatas=None, *, ids=None, **kwargs: Any) -> List[str]:
+        texts = list(texts)
+        if not texts:
+            return []
+        vectors = np.array(self.embedding.embed_documents(texts)).astype(np.float32)
+        if ids is None:
+            ids = [str(uuid.uuid4()) for _ in texts]
+        elif len(ids) != len(texts):
+            raise ValueError("number of ids must match number of texts")
+        if metadatas is None:
+            metadatas = [{} for _ in texts]
+        elif len(metadatas) != len(texts):
+            raise ValueError("number of metadatas must match number of texts")
+        if self.index is None:
+            self.index = self._engine_factory(vectors.shape[1], self._engine_metric(), self.device)
+        start = self.index.ntotal
+        self.index.add(vectors)
+        for i, (text, meta, doc_id) in enumerate(zip(texts, metadatas, ids)):
+            self.docstore[doc_id] = Document(content=text, metadata=meta, id=doc_id)
+            self.index_to_docstore_id[start + i] = doc_id
+        return list(ids)
+
+    # ------------------------------------------------------------------ search
+    def similarity_search(self, query: str, k: int = 4, **kwargs: Any) -> List[Document]:
+        return [d for d, _ in self.similarity_search_with_score(query, k, **kwargs)]
+
+    def similarity_search_with_score(self, query: str, k: int = 4, **kwargs: Any) -> List[Tuple[Document, float]]:
+        if self.ntotal == 0:
+            return []
+        return self.similarity_search_by_vector_with_score(self.embedding.embed_query(query), k, **kwargs)
+
+    def similarity_search_by_vector(self, embedding: List[float], k: int = 4, **kwargs: Any) -> List[Document]:
+        return [d for d, _ in self.similarity_search_by_vector_with_score(embedding, k, **kwargs)]
+
+    def similarity_search_by_vector_with_score(self, embedding, k: int = 4, **kwargs: Any):
+        if self.ntotal == 0:
+            return []
+        qv = np.array([embedding]).astype(np.float32)
+        k = min(k, self.ntotal)
+        scores, rows = self.index.search(qv, k)
+        out = []
+        for score, row in zip(scores[0], rows[0]):
+            if row == -1:
+                continue
+            out.append((self.docstore[self.index_to_docstore_id[int(row)]], float(score)))
+        return out
+
+    def batch_search_by_vector(self, embeddings, k: int = 4):
+        """Extension over the reference (which only has nq = 1): many queries in one scan.
+        Returns (scores fp32 [nq][k], row indices int64 [nq][k])."""
+        if self.ntotal == 0:
+            nq = len(embeddings)
+            return np.zeros((nq, 0), np.float32), np.zeros((nq, 0), np.int64)
+        return self.index.search(np.asarray(embeddings, dtype=np.float32), min(k, self.ntotal))
+
+    def max_marginal_relevance_search(self, query: str, k: int = 4, fetch_k: int = 20, lambda_mult: float = 0.5,
+                                      **kwargs: Any) -> List[Document]:
+        if self.ntotal == 0:
+            return []
+        return self.max_marginal_relevance_search_by_vector(self.embedding.embed_query(query), k, fetch_k,
+                                                            lambda_mult, **kwargs)
+
+    def max_marginal_relevance_search_by_vector(self, embedding, k: int = 4, fetch_k: int = 20,
+                                                lambda_mult: float = 0.5, **kwargs: Any) -> List[Document]:
+        scored = self.similarity_search_by_vector_with_score(embedding, fetch_k, **kwargs)
+        if not scored:
+            return []
+        cand = np.array([self.embedding.embed_query(d.content) for d, _ in scored])  # re-embedded, as the reference
+        qv = np.array(embedding)
+        if self.normalize_L2 or self.metric == "cosine":
+            qv = qv / np.linalg.norm(qv)
+            cand = cand / np.linalg.norm(cand, axis=1, keepdims=True)
+        return _mmr_select(scored, cand.tolist(), qv.tolist(), k, lambda_mult)
+
+    # ------------------------------------------------------------------ maintenance
+    def delete(self, ids: Optional[List[str]] = None, **kwargs: Any) -> Optional[bool]:
+        if ids is None:
+            self.docstore.clear()
+            self.index_to_docstore_id.clear()
+            if self.index is not None:
+                self.index.reset()
+            return True
+        if not ids:
+            return True
+        if any(i not in self.docstore for i in ids):
+            return False
+        keep = [d for i, d in self.docstore.items() if i not in ids]
+        self.docstore.clear()
+        self.index_to_docstore_id.clear()
+        if self.index is not None:
+            self.index.reset()
+        if keep:  # a flat index has no holes: rebuild from the surviving texts, as the reference does
+            self.add_texts([d.content for d in keep], [d.metadata for d in keep], ids=[d.id for d in keep])
+        return True
+
+    def get_by_ids(self, ids: List[str]) -> List[Document]:
+        return [self.docstore[i] for i in ids if i in self.docstore]
+
+    def _select_relevance_score_fn(self):
+        if self.metric == "cosine" or self.normalize_L2:
+            return self._cosine_relevance_score_fn
+        if self.metric == "ip":
+            return self._max_inner_product_relevance_score_fn
+        raise ValueError(f"unsupported metric: {self.metric}")
+
+    # ------------------------------------------------------------------ persistence
+    def save_local(self, folder_path: str, index_name: str = "index") -> None:
+        """Flat shard file (fp16 rows, mmap-able) + pickled docstore; cf. VectorStore_Faiss.py:432-450."""
+        os.makedirs(folder_path, exist_ok=True)
+        if self.index is not None and self.index.ntotal:
+            rows = self.index.rows
+            rows = rows.cpu().numpy() if hasattr(rows, "cpu") else np.asarray(rows)
+            rows = np.ascontiguousarray(rows).view(np.float16)
+            header = np.array([0x43524152, 1, rows.shape[0], self.index.dim, rows.shape[1]], dtype=np.int64)
+            with open(os.path.join(folder_path, f"{index_name}.rarc"), "wb") as fh:
+                fh.write(header.tobytes())
+                fh.write(np.float32(self.index.max_norm).tobytes())
+                fh.write(b"\0" * (64 - header.nbytes - 4))
+                fh.write(rows.tobytes())
+        meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
+                "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2}
+        with open(os.path.join(folder_path, f"{index_name}.pkl"), "wb") as fh:
+            pickle.dump(meta, fh)
+
+    @classmethod
+    def load_local(cls, folder_path: str, embeddings, index_name: str = "index", **kwargs: Any):
+        with open(os.path.join(folder_path, f"{index_name}.pkl"), "rb") as fh:
+            meta = pickle.load(fh)
+        store = cls(embedding=embeddings, index_type=meta["index_type"], metric=meta["metric"],
+                    normalize_L2=meta["normalize_L2"], **kwargs)
+        store.docstore, store.index_to_docstore_id = meta["docstore"], meta["index_to_docstore_id"]
+        path = os.path.join(folder_path, f"{index_name}.rarc")
+        if os.path.exists(path):
+            header = np.fromfile(path, dtype=np.int64, count=5)
+            if header[0] != 0x43524152 or header[1] != 1:
+                raise ValueError(f"{path}: not a rarc shard file")
+            n, dim, d_pad = int(header[2]), int(header[3]), int(header[4])
+            max_norm = float(np.fromfile(path, dtype=np.float32, count=1, offset=40)[0])
+            rows = np.memmap(path, dtype=np.float16, mode="r", offset=64, shape=(n, d_pad))
+            store.index = store._engine_factory(dim, store._engine_metric(), store.device)
+            store.index.load_rows(rows, max_norm)
+        return store
+
+    @classmethod
+    def from_texts(cls, texts, embedding, metadatas=None, *, ids=None, **kwargs: Any):
+        store = cls(embedding=embedding, **kwargs)
+        store.add_texts(texts, metadatas=metadatas, ids=ids)
+        return store
+
+    @classmethod
+    async def afrom_texts(cls, texts, embedding, metadatas=None, *, ids=None, **kwargs: Any):
+        store = cls(embedding=embedding, **kwargs)
+        await store.aadd_texts(texts, metadatas=metadatas, ids=ids)
+        return store

@@ -128,6 +128,21 @@ class FlatIndexF16:
             self.ntotal += rows_f16.shape[0]
             self.max_norm = max(self.max_norm, float(max_norm))
 
+    def load_rows(self, rows_f16_host, max_norm: float) -> None:
+        """Upload rows already in storage format (host array [n][d_pad] float16, e.g. a memmap)."""
+        t = self.torch
+        with self._lock, t.cuda.device(self.device):
+            n = rows_f16_host.shape[0]
+            if rows_f16_host.shape[1] != self.d_pad:
+                raise ValueError("rows must be [n][d_pad]")
+            self.reserve(self.ntotal + n)
+            step = 1 << 20
+            for s in range(0, n, step):  # bounded pinned staging instead of one huge host tensor
+                chunk = t.from_numpy(np.ascontiguousarray(rows_f16_host[s:s + step]))
+                self._rows[self.ntotal + s: self.ntotal + s + chunk.shape[0]].copy_(chunk)
+            self.ntotal += n
+            self.max_norm = max(self.max_norm, float(max_norm))
+
     def reset(self) -> None:
         with self._lock:
             self.ntotal = 0

@@ -71,7 +71,9 @@ class ShardedFlatSearch:
         if self.world == 1:
             return ids, scores
         mine = pack_results(t, ids, scores)
-        gathered = t.empty((self.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        g_ids, g_scores = unpack_results(t, gathered)
+        # concatenated layout ([world*nq][k][3]) is the form both RCCL and gloo accept
+        gathered = t.empty((self.world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype,
+                           device=mine.device)
+        self.dist.all_gather_into_tensor(gathered, mine.contiguous(), group=self.group)
+        g_ids, g_scores = unpack_results(t, gathered.view((self.world,) + tuple(mine.shape)))
         return self.merge_fn(g_ids, g_scores, k)

@@ -1,0 +1,138 @@
+"""Test-only helpers: an oracle-backed stand-in for the HIP index (so host logic can run without a
+GPU), scripted retrievers / stores, and a FusionMethod that runs the oracle's RRF."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+
+from oracle import cpu_ref
+from rag_arc_amd.core.retrieval.base import BaseRetriever
+from rag_arc_amd.core.utils.data_model import Document
+from rag_arc_amd.core.utils.fusion import FusionMethod, RetrievalResult
+from rag_arc_amd.encapsulation.database.vector_db.base import VectorStore
+from rag_arc_amd.encapsulation.embeddings.base import Embeddings
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden(name):
+    with open(os.path.join(GOLDEN, name)) as fh:
+        return json.load(fh)
+
+
+def unhex(h: str) -> float:
+    return struct.unpack(">d", bytes.fromhex(h))[0]
+
+
+class OracleIndex:
+    """Same surface as rag_arc_amd.hip.engine.FlatIndexF16, computed by the CPU oracle."""
+
+    def __init__(self, dim, metric="cosine", device=0):
+        self.dim, self.metric, self.ntotal, self.max_norm = dim, metric, 0, 0.0
+        self.d_pad = cpu_ref.padded_dim(dim)
+        self._rows = np.zeros((0, self.d_pad), np.uint16)
+
+    @property
+    def rows(self):
+        return self._rows
+
+    def add(self, vectors):
+        r, n2 = cpu_ref.ingest_f16(np.asarray(vectors, np.float32), normalize=(self.metric == "cosine"))
+        self._rows = np.concatenate([self._rows, r])
+        self.ntotal = self._rows.shape[0]
+        self.max_norm = max(self.max_norm, float(np.sqrt(n2.max()))) if len(n2) else self.max_norm
+
+    def load_rows(self, rows, max_norm):
+        self._rows = np.concatenate([self._rows, np.asarray(rows).view(np.uint16)])
+        self.ntotal = self._rows.shape[0]
+        self.max_norm = max(self.max_norm, max_norm)
+
+    def reset(self):
+        self._rows = np.zeros((0, self.d_pad), np.uint16)
+        self.ntotal = 0
+
+    def search(self, queries, k):
+        q = np.asarray(queries, np.float32)
+        if self.metric == "cosine":
+            q = cpu_ref.normalize_L2(q)
+        ids, scores, _ = cpu_ref.flat_search_f16(self._rows, q, k)
+        return scores, ids
+
+
+class HashEmbeddings(Embeddings):
+    """Deterministic text -> vector map (no model weights exist offline)."""
+
+    def __init__(self, dim=384):
+        super().__init__()
+        self.dim = dim
+
+    def _one(self, text):
+        seed = int.from_bytes(hashlib.sha256(text.encode()).digest()[:8], "little")
+        return np.random.default_rng(seed).standard_normal(self.dim).astype(np.float32)
+
+    def embed_documents(self, texts):
+        return [self._one(t.replace("\n", " ")).tolist() for t in texts]
+
+    def embed_query(self, text):
+        return self.embed_documents([text])[0]
+
+
+class OracleFusion(FusionMethod):
+    """RRF through oracle.cpu_ref.rrf_fuse with the reference's side effects (ranks, last doc wins)."""
+
+    def __init__(self, k=60.0):
+        self.k = k
+
+    def fuse(self, results, top_k):
+        docs = {}
+        for one in results:
+            for i, r in enumerate(one):
+                r.rank = i + 1
+                docs[r.document.content] = r.document
+        fused = cpu_ref.rrf_fuse([[r.document.content for r in one] for one in results], self.k, top_k)
+        return [RetrievalResult(document=docs[c], score=s, rank=i + 1) for i, (c, s) in enumerate(fused)]
+
+
+class ScriptedRetriever(BaseRetriever):
+    def __init__(self, docs, fail=False):
+        super().__init__()
+        self.docs, self.fail, self.seen = docs, fail, []
+
+    def _get_relevant_documents(self, query, **kwargs):
+        self.seen.append({"query": query, "kwargs": dict(kwargs)})
+        if self.fail:
+            raise RuntimeError("boom")
+        return self.docs[: kwargs.get("k", len(self.docs))]
+
+
+class ScriptedStore(VectorStore):
+    def __init__(self, scored, relevance="cosine"):
+        super().__init__()
+        self.scored, self.calls, self.relevance = scored, [], relevance
+
+    def similarity_search(self, query, k=4, **kwargs):
+        self.calls.append(["similarity_search", query, k, dict(kwargs)])
+        return [d for d, _ in self.scored][:k]
+
+    def similarity_search_with_score(self, query, k=4, **kwargs):
+        self.calls.append(["similarity_search_with_score", query, k, dict(kwargs)])
+        return self.scored[:k]
+
+    def max_marginal_relevance_search(self, query, k=4, fetch_k=20, lambda_mult=0.5, **kwargs):
+        self.calls.append(["max_marginal_relevance_search", query, k, fetch_k, lambda_mult, dict(kwargs)])
+        return [d for d, _ in self.scored][::-1][:k]
+
+    def _select_relevance_score_fn(self):
+        return {"cosine": self._cosine_relevance_score_fn, "ip": self._max_inner_product_relevance_score_fn,
+                "l2": self._euclidean_relevance_score_fn}[self.relevance]
+
+    @classmethod
+    def from_texts(cls, texts, embedding, metadatas=None, *, ids=None, **kwargs):
+        raise NotImplementedError
+
+
+def scripted_scored():
+    return [(Document(content=f"doc{i}", metadata={}, id=str(i)), s)
+            for i, s in enumerate([0.9, 0.75, 0.5, 0.25, 0.1, 0.05, -0.2, 0.0])]

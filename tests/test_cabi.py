@@ -1,0 +1,54 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/rarc.h declares.
+(No compute calls here: those need a GPU and live in the -m gpu tests.)"""
+import ctypes
+import os
+import re
+
+from rag_arc_amd.hip import binding as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "rarc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rarc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(B.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = B.load_library()
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} missing from librarc_hip.so"
+    assert lib.rarc_version() == 100
+    assert lib.rarc_padded_dim(1) == 128 and lib.rarc_padded_dim(768) == 768 and lib.rarc_padded_dim(769) == 896
+    assert lib.rarc_search_workspace_bytes(16384) > 256 * 16384 * 8
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = B.load_library()
+    rc = lib.rarc_search_f16(None, 10, 768, None, None, None, 1, 10, 128, 0, -1.0, 1.0, None, None, None, None, 0, 16384, None)
+    assert rc == -1 and b"null pointer" in lib.rarc_last_error()
+    rc = lib.rarc_rrf_fuse(None, None, 1, 1, 1, 60.0, 1, None, None, None, None)
+    assert rc == -1
+    try:
+        B.check(rc, "rarc_rrf_fuse")
+    except B.RarcError as e:
+        assert "rarc_rrf_fuse" in str(e)
+    else:
+        raise AssertionError("check() must raise")
+
+
+def test_engine_refuses_to_run_without_a_gpu():
+    import pytest
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    with pytest.raises(B.RarcError):
+        FlatIndexF16(384)

@@ -1,0 +1,152 @@
+"""GPU parity for the rank-level kernels and the registered-backend surface, through the C-ABI.
+  rarc_rrf_fuse      vs goldens recorded from the reference's RRFusion.fuse   (core/utils/Fusion.py:45-76)
+  rarc_rerank_order  vs the oracle restatement                                (core/rerank/Reranker_Qwen3.py:41-49,:70-74)
+  rarc_topk_merge    vs the oracle merge
+  HipFlatVectorStore / registry end to end vs the oracle-backed store
+"""
+import json
+
+import numpy as np
+import pytest
+
+from tests.helpers import HashEmbeddings, OracleIndex, golden, unhex
+
+pytestmark = pytest.mark.gpu
+
+
+def _rr(contents):
+    from rag_arc_amd.core.utils import Document, RetrievalResult
+
+    return [RetrievalResult(document=Document(content=c, metadata={"pos": i}), score=1.0) for i, c in enumerate(contents)]
+
+
+def test_rrf_kernel_matches_reference_goldens_bit_for_bit():
+    from rag_arc_amd.core.utils import HipRRFusion
+
+    for case in golden("rrf.json"):
+        res = [_rr(one) for one in case["lists"]]
+        fused = HipRRFusion(k=case["k"]).fuse(res, case["top_k"])
+        assert [f.document.content for f in fused] == [g["content"] for g in case["fused"]]
+        assert [f.score for f in fused] == [unhex(g["score_hex"]) for g in case["fused"]]      # exact fp64
+        assert [f.rank for f in fused] == [g["rank"] for g in case["fused"]]
+        assert [[r.rank for r in one] for one in res] == case["input_ranks_after"]             # inputs re-ranked
+        # "last occurrence wins" for the returned Document object
+        for f, g in zip(fused, case["fused"]):
+            assert f.document.metadata["pos"] == g["doc_pos"]
+
+
+def test_rrf_batched_ids_c3_shape(oracle):
+    """256 queries x (dense top-100, supplied lexical top-100 with ~30 % overlap): ids and fp64 scores."""
+    import torch
+
+    from rag_arc_amd.core.utils import HipRRFusion
+
+    rng = np.random.default_rng(777)
+    B, L = 256, 100
+    keys = np.zeros((B, 2, L), np.int64)
+    for b in range(B):
+        dense = rng.choice(1_000_000, L, replace=False)
+        over = rng.choice(dense, 30, replace=False)
+        rest = rng.choice(np.arange(1_000_000, 2_000_000), L - 30, replace=False)
+        lex = np.concatenate([over, rest])
+        rng.shuffle(lex)
+        keys[b, 0], keys[b, 1] = dense, lex
+    lens = np.full((B, 2), L, np.int32)
+    lens[3, 1] = 0
+    lens[4] = (17, 55)
+    fk, fs, fn = HipRRFusion().fuse_ids(torch.from_numpy(keys).cuda(), torch.from_numpy(lens).cuda(), 100)
+    fk, fs, fn = fk.cpu().numpy(), fs.cpu().numpy(), fn.cpu().numpy()
+    for b in range(B):
+        want = oracle.rrf_fuse([keys[b, r, : lens[b, r]].tolist() for r in range(2)], 60.0, 100)
+        assert fn[b] == len(want)
+        assert fk[b, : fn[b]].tolist() == [k for k, _ in want]
+        assert fs[b, : fn[b]].tolist() == [s for _, s in want]
+
+
+def test_rerank_order_kernel(oracle):
+    from rag_arc_amd.core.rerank import HipLogitReranker
+    from rag_arc_amd.core.utils import Document
+
+    rng = np.random.default_rng(9)
+    zn = (rng.standard_normal((32, 100)) * 4).astype(np.float16)
+    zy = (rng.standard_normal((32, 100)) * 4).astype(np.float16)
+    zy[0, 10:20] = zy[0, 10]
+    zn[0, 10:20] = zn[0, 10]                                         # exact ties keep retrieval order
+    rr = HipLogitReranker(lambda q, texts: (None, None))
+    scores, perm = rr.score_order(zn, zy)
+    scores, perm = scores.cpu().numpy(), perm.cpu().numpy()
+    want = oracle.rerank_scores_f16(zn, zy)
+    tol = np.maximum(np.abs(want.astype(np.float64)) * 2.0 ** -6, 2.0 ** -24)   # exp amplifies a last-place ls flip
+    assert np.all(np.abs(scores.astype(np.float64) - want.astype(np.float64)) <= tol)
+    assert (scores == want).mean() > 0.98
+    for b in range(32):
+        assert perm[b].tolist() == oracle.stable_desc_order(scores[b]).tolist()   # stable sort of ITS scores
+    # the Reranker contract: same Document objects, reordered, optional k, batches of 8
+    docs = [Document(content=f"d{i}") for i in range(100)]
+    table = {f"d{i}": (zn[1, i], zy[1, i]) for i in range(100)}
+    calls = []
+
+    def logit_fn(query, texts):
+        calls.append(len(texts))
+        return [table[t][0] for t in texts], [table[t][1] for t in texts]
+
+    out = HipLogitReranker(logit_fn).rerank("q", docs, k=7)
+    assert [d.content for d in out] == [f"d{i}" for i in perm[1][:7]] and all(o is docs[int(o.content[1:])] for o in out)
+    assert calls == [8] * 12 + [4]
+
+
+def test_topk_merge_kernel(oracle):
+    import torch
+
+    from rag_arc_amd.hip.sharded import ShardedFlatSearch
+
+    rng = np.random.default_rng(4)
+    G, nq, k = 8, 64, 100
+    ids = rng.integers(0, 10 ** 9, (G, nq, k)).astype(np.int64)
+    sc = np.sort(rng.standard_normal((G, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    sc[:, 0, :] = 0.25                                   # a query where everything ties: id ascending
+    ids[2, 1, 50:] = -1
+    sc[2, 1, 50:] = -np.inf                              # a short shard
+    s = ShardedFlatSearch.__new__(ShardedFlatSearch)
+    s.torch = torch
+    mi, ms = s._hip_merge(torch.from_numpy(ids).cuda(), torch.from_numpy(sc).cuda(), k)
+    wi, ws = oracle.topk_merge(ids, sc, k)
+    assert np.array_equal(mi.cpu().numpy(), wi) and np.array_equal(ms.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+
+
+def test_store_end_to_end_and_registry(tmp_path, oracle):
+    from rag_arc_amd.config.app_registration import register_multipath_retriever, registrator
+    from rag_arc_amd.core.retrieval import VectorStoreRetriever
+    from rag_arc_amd.encapsulation.database.vector_db import HipFlatVectorStore
+
+    emb = HashEmbeddings(384)
+    texts = [f"passage {i}" for i in range(10_000)]
+    ids = [str(i) for i in range(10_000)]
+    hip = HipFlatVectorStore.from_texts(texts, emb, ids=ids)                       # real HIP engine
+    ref = HipFlatVectorStore.from_texts(texts, emb, ids=ids, engine_factory=lambda d, m, dev: OracleIndex(d, m))
+    for q in ("passage 77", "passage 9999", "something else entirely"):
+        a, b = hip.similarity_search_with_score(q, k=10), ref.similarity_search_with_score(q, k=10)
+        assert [(d.id, s) for d, s in a] == [(d.id, s) for d, s in b]
+    sc, rows = hip.batch_search_by_vector(emb.embed_documents(texts[:300]), k=10)   # nq > 256: two scan passes
+    sc2, rows2 = ref.batch_search_by_vector(emb.embed_documents(texts[:300]), k=10)
+    assert np.array_equal(rows, rows2) and np.array_equal(sc.view(np.uint32), sc2.view(np.uint32))
+    assert [d.id for d in VectorStoreRetriever(hip).invoke("passage 5")] == [d.id for d in VectorStoreRetriever(ref).invoke("passage 5")]
+    hip.save_local(str(tmp_path / "idx"))
+    again = HipFlatVectorStore.load_local(str(tmp_path / "idx"), emb)
+    assert [(d.id, s) for d, s in again.similarity_search_with_score("passage 77", k=10)] == \
+           [(d.id, s) for d, s in hip.similarity_search_with_score("passage 77", k=10)]
+
+    # JSON -> Register -> module graph -> invoke (the framework surface, with HIP fusion)
+    qs = ["passage 1", "passage 2"]
+    np.savez(tmp_path / "emb.npz", texts=np.array(texts + ["query a"]), vectors=np.array(emb.embed_documents(texts + ["query a"]), np.float32))
+    np.savez(tmp_path / "corpus.npz", texts=np.array(texts[:2000]), ids=np.array(ids[:2000]))
+    vs = {"type": "hip_flat_vectorstore", "metric": "cosine", "embedding": {"type": "table_embeddings", "path": str(tmp_path / "emb.npz")},
+          "corpus_path": str(tmp_path / "corpus.npz")}
+    cfg = {"type": "multipath_retriever", "top_k_per_retriever": 20, "fusion": {"type": "rrf", "k": 60.0},
+           "retrievers": [{"type": "vectorstore_retriever", "vectorstore": vs, "search_kwargs": {}},
+                          {"type": "vectorstore_retriever", "vectorstore": vs, "search_type": "mmr", "search_kwargs": {"fetch_k": 30}}]}
+    (tmp_path / "app.json").write_text(json.dumps(cfg))
+    register_multipath_retriever(str(tmp_path / "app.json"), "t_app")
+    app = registrator.get_object("t_app")
+    out = app.invoke("passage 1", top_k=5)
+    assert out[0].content == "passage 1" and len(out) == 5

@@ -1,0 +1,105 @@
+"""The oracle's python restatements vs outputs of the reference's own code (tests/golden/*.json)."""
+import numpy as np
+
+from tests.helpers import golden, unhex
+
+
+def test_rrf_matches_reference_bit_for_bit(oracle):
+    for case in golden("rrf.json"):
+        got = oracle.rrf_fuse(case["lists"], case["k"], case["top_k"])
+        want = [(f["content"], unhex(f["score_hex"])) for f in case["fused"]]
+        assert [c for c, _ in got] == [c for c, _ in want]
+        assert [s for _, s in got] == [s for _, s in want]  # exact fp64 equality
+        assert [f["rank"] for f in case["fused"]] == list(range(1, len(want) + 1))
+
+
+def test_relevance_functions_match_reference(oracle):
+    rel = golden("relevance.json")
+    for f in rel["fns"]:
+        s = unhex(f["score_hex"])
+        assert oracle.cosine_relevance(s) == unhex(f["cosine_hex"])
+        assert oracle.max_inner_product_relevance(s) == unhex(f["ip_hex"])
+
+
+def test_cosine_scores_within_1e5_of_reference_float64(oracle):
+    """Secondary arithmetic pin: the reference's own numpy cosine (spliter.py:326-332, float64) on
+    fp16-representable inputs vs the oracle's canonical fp32 path."""
+    g = golden("cosine.json")
+    X = np.array(g["X_f16_bits"], dtype=np.uint16).view(np.float16).astype(np.float32)
+    Y = np.array(g["Y_f16_bits"], dtype=np.uint16).view(np.float16).astype(np.float32)
+    want = np.array([[unhex(v) for v in row] for row in g["cos_hex"]])
+    rows, _ = oracle.ingest_f16(Y, normalize=True)       # corpus side: normalise -> fp16
+    qn = oracle.normalize_L2(X)
+    ids, scores, _ = oracle.flat_search_f16(rows, qn, Y.shape[0])
+    got = np.zeros_like(want)
+    for q in range(X.shape[0]):
+        got[q, ids[q]] = scores[q]
+    # fp16 storage of the normalised rows costs ~2^-12 relative per element; stay well inside 2e-3 absolute
+    assert np.max(np.abs(got - want)) < 2e-3
+    # with the SAME stored rows the canonical fp32 scorer is within 1e-5 of float64
+    i64, s64 = oracle.flat_search_f64(rows, qn, Y.shape[0])
+    assert np.array_equal(ids, i64)
+    assert np.max(np.abs(scores - s64)) < 1e-5
+
+
+def test_canonical_dot_avx_equals_scalar_definition(oracle):
+    import ctypes
+    rng = np.random.default_rng(1)
+    L = oracle.lib()
+    for d in (8, 128, 384, 768):
+        q = rng.standard_normal(d).astype(np.float32)
+        r = rng.standard_normal(d).astype(np.float16).view(np.uint16)
+        a = L.oracle_canon_dot_f16(oracle._p(q), oracle._p(r), ctypes.c_int(d))
+        b = L.oracle_canon_dot_f16_scalar(oracle._p(q), oracle._p(r), ctypes.c_int(d))
+        assert np.float32(a).tobytes() == np.float32(b).tobytes()
+    assert L.oracle_selftest() == 0
+
+
+def test_normalize_and_search_edge_cases(oracle):
+    x = np.zeros((3, 16), np.float32)
+    x[1, 3] = 2.0
+    y = oracle.normalize_L2(x)
+    assert np.array_equal(y[0], x[0]) and y[1, 3] == 1.0           # zero rows untouched
+    rows, n2 = oracle.ingest_f16(np.eye(4, 8, dtype=np.float32))
+    ids, sc, _ = oracle.flat_search_f16(rows, np.ones((1, 8), np.float32), 6)
+    assert ids.tolist() == [[0, 1, 2, 3, -1, -1]]                  # ties by id, -1 padding like faiss
+    assert np.isneginf(sc[0, 4:]).all()
+    empty_ids, empty_sc, _ = oracle.flat_search_f16(np.zeros((0, 128), np.uint16), np.ones((2, 128), np.float32), 3)
+    assert (empty_ids == -1).all()
+
+
+def test_rerank_restatement_matches_torch(oracle):
+    """The reference runs its fp16 LM on a GPU, where half log_softmax / exp are evaluated in fp32 and
+    rounded to fp16 once (torch's CPU half kernels round more often, so they are not the model)."""
+    import torch
+    rng = np.random.default_rng(5)
+    zn = (rng.standard_normal(2000) * 4).astype(np.float16)
+    zy = (rng.standard_normal(2000) * 4).astype(np.float16)
+    t = torch.stack([torch.from_numpy(zn), torch.from_numpy(zy)], dim=1).float()
+    want_ls = torch.nn.functional.log_softmax(t, dim=1)[:, 1].half()
+    got_ls = oracle.rerank_logsoftmax_yes_f16(zn, zy)
+    diff = np.abs(got_ls.astype(np.float64) - want_ls.numpy().astype(np.float64))
+    ulp = np.maximum(np.abs(want_ls.numpy().astype(np.float64)) * 2.0 ** -10, 2.0 ** -24)
+    assert np.all(diff <= ulp)                                  # libm vs SLEEF: last place at most
+    same = diff == 0
+    assert same.mean() > 0.99
+    got = oracle.rerank_scores_f16(zn, zy)
+    want = want_ls.float().exp().half().numpy()
+    dp = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    assert np.all(dp[same] <= np.maximum(np.abs(want[same].astype(np.float64)) * 2.0 ** -10, 2.0 ** -24))
+    order = oracle.stable_desc_order(got)
+    pairs = sorted(zip(range(len(got)), got.tolist()), key=lambda p: p[1], reverse=True)  # python stable sort
+    assert order.tolist() == [i for i, _ in pairs]
+
+
+def test_topk_merge_is_sharding_invariant(oracle):
+    rows = oracle.synth_rows_f16(3000, 128)
+    q = oracle.synth_rows_f32(5, 128)
+    full_i, full_s, _ = oracle.flat_search_f16(rows, q, 10)
+    parts_i, parts_s = [], []
+    for lo, hi in ((0, 1000), (1000, 2000), (2000, 3000)):
+        i, s, _ = oracle.flat_search_f16(rows[lo:hi], q, 10, id_base=lo)
+        parts_i.append(i)
+        parts_s.append(s)
+    mi, ms = oracle.topk_merge(np.stack(parts_i), np.stack(parts_s), 10)
+    assert np.array_equal(mi, full_i) and np.array_equal(ms.view(np.uint32), full_s.view(np.uint32))
