@@ -133,9 +133,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                if tj.get("rows_per_launch") == hi - lo and tj.get("dim") == a.dim:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                for ent in json.load(open(tpath)).get("entries", []):  # PMC passes recorded per shard size
+                    if ent.get("rows_per_launch") == hi - lo and ent.get("dim") == a.dim:
+                        traffic = ent.get("hbm_bytes_per_launch")
             except Exception:
                 pass
         result = {

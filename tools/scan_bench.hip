@@ -5,6 +5,7 @@
 #include <string.h>
 #include <vector>
 #include "../rag-arc_amd/csrc/scan_f16.hip"
+#include "../rag-arc_amd/csrc/prep.hip"
 void rarc_set_error(const char* fmt, ...) { (void)fmt; }
 bool rarc_prof_next(hipEvent_t*, hipEvent_t*) { return false; }
 
@@ -34,13 +35,10 @@ int main(int argc, char** argv) {
   half_t *corpus, *q16; void* wsb;
   hipMalloc(&corpus, (size_t)(N + 32) * D * 2); hipMalloc(&q16, 256 * D * 2);
   size_t wsbytes = RARC_WS_CAND + (size_t)256 * CAP * 8; hipMalloc(&wsb, wsbytes);
-  // synthetic unit rows via the product generator kernels would need prep.hip; use a cheap LCG on host instead
-  std::vector<uint16_t> h((size_t)4096 * D);
-  uint32_t s = 12345;
-  for (auto& v : h) { s = s * 1664525u + 1013904223u; float f = ((int)(s >> 8) % 2001 - 1000) * (0.036f / 577.f); _Float16 x = (_Float16)f; memcpy(&v, &x, 2); }
-  for (int64_t r = 0; r < N; r += 4096) { int64_t n = (N - r) < 4096 ? (N - r) : 4096; hipMemcpy(corpus + r * D, h.data() + ((r / 4096) % 7) * 64, 0, hipMemcpyHostToDevice); hipMemcpy(corpus + r * D, h.data(), (size_t)n * D * 2, hipMemcpyHostToDevice); }
-  // decorrelate blocks cheaply: xor a per-block pattern on device is overkill; rows repeat every 4096 (fine for timing)
-  hipMemcpy(q16, h.data() + 1000 * D, 256 * D * 2, hipMemcpyHostToDevice);
+  rarc_synth_rows_f16((uint16_t*)corpus, D, D, 0, N, 1234, 0);
+  { float* qf; hipMalloc(&qf, 256 * D * 4); rarc_synth_rows_f32(qf, D, D, 0, 256, 4321, 0);
+    float* q32; float* eps; hipMalloc(&q32, 256 * D * 4); hipMalloc(&eps, 1024);
+    rarc_prep_queries(qf, D, 256, D, D, 1, 1.001f, q32, (uint16_t*)q16, eps, 0); hipDeviceSynchronize(); }
   RarcWs ws = rarc_ws_carve(wsb);
   ScanParams p; p.corpus = corpus; p.q16 = q16; p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32);
   p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
