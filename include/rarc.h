@@ -172,6 +172,31 @@ int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_r
                         int64_t n_rows, uint64_t seed, void* stream);
 
 /*
+ * Encoder forward (BERT family) — what HuggingFaceEmbeddings reaches through
+ * sentence-transformers at core/file_management/embeddings/huggingface.py:122-126
+ * ([external] BERT forward -> CLS pooling -> optional normalise).  Token ids in, embeddings out.
+ * All tensors fp16 (uint16 bit patterns) unless noted; weights use torch.nn.Linear layout [out][in].
+ *   rarc_enc_embed_ln : out[t] = LayerNorm(word[ids[t]] + pos[t % seq_len] + type0)
+ *   rarc_enc_gemm     : C[M][N] = A[M][K] · W[N][K]^T + bias[N], act 0 = none, 1 = erf-GELU;
+ *                       M, N multiples of 128, K multiple of 64 (MFMA 32x32x16 f16, fp32 accumulate)
+ *   rarc_enc_attention: ctx = softmax(Q K^T / sqrt(dh) + key mask) V per (sequence, head) from the
+ *                       fused qkv [n_seq*seq_len][3*hidden]; keys >= d_lens[seq] are masked; dh 32 or 64
+ *   rarc_enc_add_ln   : out = LayerNorm(x + resid)
+ *   rarc_enc_pool     : out[b] = hidden[b*seq_len + 0] as fp32 (optionally L2-normalised)
+ */
+int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,
+                      const uint16_t* d_type0, const uint16_t* d_gamma, const uint16_t* d_beta, float eps,
+                      int n_tokens, int seq_len, int hidden, uint16_t* d_out, void* stream);
+int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
+                  int n, int k, int act, void* stream);
+int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
+                       int n_heads, uint16_t* d_ctx, void* stream);
+int rarc_enc_add_ln(const uint16_t* d_x, const uint16_t* d_resid, const uint16_t* d_gamma,
+                    const uint16_t* d_beta, float eps, int n_rows, int hidden, uint16_t* d_out, void* stream);
+int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, int hidden, int normalize,
+                  float* d_out, void* stream);
+
+/*
  * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan
  * kernel with a pair of HIP events recorded on the search's own stream.  rarc_profile_end
  * synchronises, returns the summed scan time and the number of launches measured, and releases

@@ -218,3 +218,71 @@ def stable_desc_order(scores: np.ndarray) -> np.ndarray:
     """Reranker_Qwen3.py:70-72: list.sort(key=score, reverse=True) — stable, ties keep input order."""
     s = np.asarray(scores, dtype=np.float64)
     return np.argsort(-s, kind="stable").astype(np.int32)
+
+
+# --------------------------------------------------------------------------------------- encoder
+def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=True):
+    """BERT encoder forward in float32 numpy, CLS pooling (what SentenceTransformer.encode computes
+    for bge-style models reached from huggingface.py:122-126).  `sd` = HuggingFace BertModel state
+    dict (numpy arrays).  Pinned against transformers.BertModel in tests/test_oracle_golden.py."""
+    from math import sqrt
+
+    try:
+        from scipy.special import erf
+    except Exception:  # pragma: no cover
+        import math
+        erf = np.vectorize(math.erf)
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    ids = np.asarray(input_ids)
+    n, L = ids.shape
+    lens = np.asarray(lengths)
+
+    def ln(x, w, b):
+        mu = x.mean(-1, keepdims=True)
+        var = ((x - mu) ** 2).mean(-1, keepdims=True)
+        return (x - mu) / np.sqrt(var + eps) * w + b
+
+    x = g("embeddings.word_embeddings.weight")[ids] + g("embeddings.position_embeddings.weight")[None, :L] \
+        + g("embeddings.token_type_embeddings.weight")[0]
+    x = ln(x, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"))
+    H = x.shape[-1]
+    dh = H // num_heads
+    mask = np.where(np.arange(L)[None, :] < lens[:, None], 0.0, -np.inf).astype(np.float32)   # [n][L] keys
+    i = 0
+    while f"encoder.layer.{i}.attention.self.query.weight" in sd:
+        p = f"encoder.layer.{i}."
+        lin = lambda t, name: t @ g(p + name + ".weight").T + g(p + name + ".bias")
+        q = lin(x, "attention.self.query").reshape(n, L, num_heads, dh).transpose(0, 2, 1, 3)
+        k = lin(x, "attention.self.key").reshape(n, L, num_heads, dh).transpose(0, 2, 1, 3)
+        v = lin(x, "attention.self.value").reshape(n, L, num_heads, dh).transpose(0, 2, 1, 3)
+        s = q @ k.transpose(0, 1, 3, 2) / sqrt(dh) + mask[:, None, None, :]
+        s = s - s.max(-1, keepdims=True)
+        pr = np.exp(s)
+        pr = pr / pr.sum(-1, keepdims=True)
+        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(n, L, H)
+        x = ln(lin(ctx, "attention.output.dense") + x, g(p + "attention.output.LayerNorm.weight"),
+               g(p + "attention.output.LayerNorm.bias"))
+        h = lin(x, "intermediate.dense")
+        h = 0.5 * h * (1.0 + erf(h / np.sqrt(2.0)))
+        x = ln(lin(h.astype(np.float32), "output.dense") + x, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))
+        i += 1
+    cls = x[:, 0, :].astype(np.float32)
+    return normalize_L2(cls) if normalize else cls
+
+
+def random_bert_state_dict(hidden, layers, heads, inter, vocab=1000, max_pos=128, seed=0, scale=0.05):
+    """Seeded synthetic BertModel weights (HuggingFace names); LayerNorm weights near 1."""
+    rng = np.random.default_rng(seed)
+    r = lambda *shape: (rng.standard_normal(shape) * scale).astype(np.float32)
+    sd = {"embeddings.word_embeddings.weight": r(vocab, hidden) * 4, "embeddings.position_embeddings.weight": r(max_pos, hidden),
+          "embeddings.token_type_embeddings.weight": r(2, hidden),
+          "embeddings.LayerNorm.weight": 1 + r(hidden), "embeddings.LayerNorm.bias": r(hidden)}
+    for i in range(layers):
+        p = f"encoder.layer.{i}."
+        for nme in ("attention.self.query", "attention.self.key", "attention.self.value", "attention.output.dense"):
+            sd[p + nme + ".weight"], sd[p + nme + ".bias"] = r(hidden, hidden), r(hidden)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = r(inter, hidden), r(inter)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = r(hidden, inter), r(hidden)
+        for nme in ("attention.output.LayerNorm", "output.LayerNorm"):
+            sd[p + nme + ".weight"], sd[p + nme + ".bias"] = 1 + r(hidden), r(hidden)
+    return sd

@@ -1,0 +1,320 @@
+// encoder.hip — BERT-family encoder forward (the embedding provider's hot loop).
+//
+// Replaces what HuggingFaceEmbeddings reaches through sentence-transformers:
+//   core/file_management/embeddings/huggingface.py:122-126 (SentenceTransformer.encode)
+//   [external] tokenizer -> BERT forward -> CLS pooling -> optional L2 normalise -> fp32
+// Token ids in, embeddings out (tokenisation stays on the host; no vocab ships offline).
+//
+// Kernels (fp16 storage, fp32 accumulate / statistics):
+//   rarc_enc_embed_ln   word + position + type embeddings -> LayerNorm            (HBM-bound)
+//   rarc_enc_gemm       C = A·Wᵀ + bias [, GELU]   A [M][K], W [N][K] (torch Linear layout)
+//                       128x128x64 tiles, 4 waves x (2x2) v_mfma_f32_32x32x16_f16, operands staged
+//                       HBM -> LDS by LDS-DMA with the same source-side XOR swizzle as the scan   (MFMA-bound)
+//   rarc_enc_attention  softmax(Q·Kᵀ/sqrt(dh) + mask)·V per (sequence, head), keys streamed in
+//                       LDS tiles with an online softmax (sequence lengths <= 512)
+//   rarc_enc_add_ln     LayerNorm(x + residual)                                   (HBM-bound)
+//   rarc_enc_pool       CLS row -> fp32 [, L2 normalise with the canonical sum order of prep.hip]
+#include "rarc_common.h"
+
+// ------------------------------------------------------------------------------------------
+// GEMM  C[M][N] = A[M][K] · W[N][K]ᵀ + bias[N]   (M, N multiples of 128; K multiple of 64)
+// ------------------------------------------------------------------------------------------
+constexpr int GM = 128, GN = 128, GK = 64;
+constexpr int G_TILE_BYTES = GM * GK * 2;  // 16 KiB per operand per stage
+
+template <int ACT>  // 0 = bias only, 1 = bias + exact (erf) GELU
+__global__ __launch_bounds__(256, 2) void rarc_gemm_f16_kernel(const half_t* __restrict__ A,
+                                                               const half_t* __restrict__ W,
+                                                               const half_t* __restrict__ bias,
+                                                               half_t* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | W 16K]
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int row = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: consecutive block ids (same XCD = id % 8) walk down a column of C tiles
+  const int tiles_m = M / GM;
+  const int bid = blockIdx.x;
+  const int tm = bid % tiles_m, tn = bid / tiles_m;
+  const half_t* Ab = A + (size_t)tm * GM * K;
+  const half_t* Wb = W + (size_t)tn * GN * K;
+
+  // DMA: per stage 16 instructions per operand (8 rows x 128 B each); wave issues 4 + 4
+  const int drow = lane >> 3, dslot = lane & 7;
+  auto issue = [&](int stage, int kt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wave * 4 + j;  // row-block of 8 rows: rows 8i .. 8i+7
+      const int r = 8 * i + drow;
+      const int c = dslot ^ ((r >> 1) & 7);
+      const half_t* ga = Ab + (size_t)r * K + kt * GK + c * 8;
+      const half_t* gw = Wb + (size_t)r * K + kt * GK + c * 8;
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(ga), RARC_LPTR(smem + stage * 2 * G_TILE_BYTES + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(gw),
+                                       RARC_LPTR(smem + stage * 2 * G_TILE_BYTES + G_TILE_BYTES + i * 1024), 16, 0, 0);
+    }
+  };
+  // fragment offsets inside a 32-row group (4 KiB): row*128 + ((chunk ^ sw) << 4)
+  const int sw = (row >> 1) & 7;
+  int xk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + h) ^ sw) << 4);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+
+  const int KT = K / GK;
+  issue(0, 0);
+  for (int kt = 0; kt < KT; ++kt) {
+    const int st = kt & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 1 < KT) issue(st ^ 1, kt + 1);
+    const int abase = st * 2 * G_TILE_BYTES + (2 * wm) * 4096;
+    const int wbase = st * 2 * G_TILE_BYTES + G_TILE_BYTES + (2 * wn) * 4096;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      half8 a0, a1, b0, b1;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"
+                   "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:4096\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
+                   : "v"(abase + xk[kk]), "v"(wbase + xk[kk])
+                   : "memory");
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+  // epilogue: lane holds column n = lane & 31, rows 8*(r>>2) + 4*h + (r&3) of each 32x32 block
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = tn * GN + (2 * wn + j) * 32 + row;
+      const float b = (float)bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tm * GM + (2 * wm + i) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        float v = acc[i][j][r] + b;
+        if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        C[(size_t)m * N + n] = (half_t)v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm helpers: one wave per row, fp32 statistics, H <= 1024 (H multiple of 64)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int MAXPER>
+__device__ __forceinline__ void ln_row(float (&x)[MAXPER], int per, int H, const half_t* gamma, const half_t* beta,
+                                       float eps, half_t* out, int lane) {
+  float s = 0.f;
+  for (int i = 0; i < per; ++i) s += x[i];
+  const float mean = wave_sum(s) / (float)H;
+  float v = 0.f;
+  for (int i = 0; i < per; ++i) { const float d = x[i] - mean; v += d * d; }
+  const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
+  for (int i = 0; i < per; ++i) {
+    const int c = lane + 64 * i;
+    out[c] = (half_t)((x[i] - mean) * rstd * (float)gamma[c] + (float)beta[c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void rarc_embed_ln_kernel(const int32_t* ids, const half_t* word, const half_t* pos,
+                                                            const half_t* type0, const half_t* gamma,
+                                                            const half_t* beta, float eps, int n_tokens, int L, int H,
+                                                            half_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_tokens) return;
+  const int per = H / 64;
+  float x[16];
+  const half_t* w = word + (size_t)ids[t] * H;
+  const half_t* p = pos + (size_t)(t % L) * H;
+  for (int i = 0; i < per; ++i) {
+    const int c = lane + 64 * i;
+    x[i] = (float)w[c] + (float)p[c] + (float)type0[c];
+  }
+  ln_row<16>(x, per, H, gamma, beta, eps, out + (size_t)t * H, lane);
+}
+
+__global__ __launch_bounds__(256) void rarc_add_ln_kernel(const half_t* x_in, const half_t* resid, const half_t* gamma,
+                                                          const half_t* beta, float eps, int n_rows, int H,
+                                                          half_t* out) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= n_rows) return;
+  const int per = H / 64;
+  float x[16];
+  for (int i = 0; i < per; ++i) {
+    const int c = lane + 64 * i;
+    x[i] = (float)x_in[(size_t)t * H + c] + (float)resid[(size_t)t * H + c];
+  }
+  ln_row<16>(x, per, H, gamma, beta, eps, out + (size_t)t * H, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention: qkv [n_seq*L][3H] (q | k | v, heads contiguous inside each), ctx [n_seq*L][H].
+// One workgroup per (sequence, head); wave w handles query rows w, w+4, ...; lane l owns output
+// dimension l (head_dim = 64) and, for the scores, key l of the current 64-key tile.
+// Keys/values of a tile sit in LDS; softmax is online (running max / sum per query row).
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void rarc_attention_kernel(const half_t* qkv, const int32_t* lens, int L, int H,
+                                                             int n_heads, half_t* ctx) {
+  constexpr int KT = 64;
+  __shared__ float ks[KT][DH + 1];
+  __shared__ float vs[KT][DH + 1];
+  __shared__ float qs[4][DH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / n_heads, hd = blockIdx.x % n_heads;
+  const int len = lens[b];
+  const size_t base = (size_t)b * L * 3 * H;
+  const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;  // 1/sqrt(DH)
+  for (int q0 = 0; q0 < L; q0 += 4) {
+    const int qi = q0 + wave;
+    const bool qlive = qi < L;
+    __syncthreads();
+    if (qlive && lane < DH) qs[wave][lane] = (float)qkv[base + (size_t)qi * 3 * H + hd * DH + lane];
+    float m = -INFINITY, l = 0.f, o = 0.f;
+    for (int k0 = 0; k0 < len; k0 += KT) {
+      __syncthreads();
+      for (int i = threadIdx.x; i < KT * DH; i += 256) {
+        const int kr = i / DH, kc = i % DH;
+        const int kj = k0 + kr;
+        float kv = 0.f, vv = 0.f;
+        if (kj < len) {
+          kv = (float)qkv[base + (size_t)kj * 3 * H + H + hd * DH + kc];
+          vv = (float)qkv[base + (size_t)kj * 3 * H + 2 * H + hd * DH + kc];
+        }
+        ks[kr][kc] = kv;
+        vs[kr][kc] = vv;
+      }
+      __syncthreads();
+      if (qlive) {
+        float s = -INFINITY;
+        if (k0 + lane < len) {
+          float a = 0.f;
+#pragma unroll 16
+          for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qs[wave][d], ks[lane][d], a);
+          s = a * scale;
+        }
+        float tmax = s;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
+        const float mnew = fmaxf(m, tmax);
+        const float p = (s == -INFINITY) ? 0.f : __expf(s - mnew);
+        const float corr = (m == -INFINITY) ? 0.f : __expf(m - mnew);
+        l = l * corr + wave_sum(p);
+        o *= corr;
+        for (int j = 0; j < KT; ++j) o = __builtin_fmaf(__shfl(p, j, 64), vs[j][lane & (DH - 1)], o);
+        m = mnew;
+      }
+    }
+    if (qlive && lane < DH) ctx[((size_t)b * L + qi) * H + hd * DH + lane] = (half_t)(l > 0.f ? o / l : 0.f);
+  }
+}
+
+// CLS pooling (+ optional L2 normalisation with the canonical order of prep.hip)
+__global__ __launch_bounds__(64) void rarc_pool_kernel(const half_t* hidden, int L, int H, int normalize, float* out) {
+  const int lane = threadIdx.x, j = lane & 7;
+  const int b = blockIdx.x;
+  const half_t* x = hidden + (size_t)b * L * H;  // row of the [CLS] token
+  float acc = 0.f;
+  if (lane < 8)
+    for (int m2 = j; m2 < H; m2 += 8) { const float f = (float)x[m2]; acc = __builtin_fmaf(f, f, acc); }
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = __shfl(acc, i, 64);
+  const float nr = rarc_canon_tree(a);
+  const float inv = (normalize && nr > 0.f) ? (float)(1.0 / (double)(float)sqrt((double)nr)) : 1.f;
+  for (int c = lane; c < H; c += 64) out[(size_t)b * H + c] = (float)x[c] * inv;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
+                             int n, int k, int act, void* stream) {
+  RARC_REQUIRE(d_a && d_w && d_bias && d_c, RARC_E_INVALID, "rarc_enc_gemm: null pointer");
+  RARC_REQUIRE(m > 0 && n > 0 && k > 0 && m % GM == 0 && n % GN == 0 && k % GK == 0, RARC_E_UNSUPPORTED,
+               "rarc_enc_gemm: need M,N multiples of 128 and K multiple of 64 (got %d,%d,%d)", m, n, k);
+  const size_t lds = 4 * G_TILE_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  const int grid = (m / GM) * (n / GN);
+  if (act == 1)
+    hipLaunchKernelGGL(rarc_gemm_f16_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const half_t*)d_a,
+                       (const half_t*)d_w, (const half_t*)d_bias, (half_t*)d_c, m, n, k);
+  else
+    hipLaunchKernelGGL(rarc_gemm_f16_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const half_t*)d_a,
+                       (const half_t*)d_w, (const half_t*)d_bias, (half_t*)d_c, m, n, k);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,
+                                 const uint16_t* d_type0, const uint16_t* d_gamma, const uint16_t* d_beta, float eps,
+                                 int n_tokens, int seq_len, int hidden, uint16_t* d_out, void* stream) {
+  RARC_REQUIRE(d_ids && d_word && d_pos && d_type0 && d_gamma && d_beta && d_out, RARC_E_INVALID, "rarc_enc_embed_ln: null pointer");
+  RARC_REQUIRE(hidden % 64 == 0 && hidden <= 1024 && n_tokens > 0 && seq_len > 0, RARC_E_UNSUPPORTED,
+               "rarc_enc_embed_ln: hidden must be a multiple of 64, <= 1024");
+  hipLaunchKernelGGL(rarc_embed_ln_kernel, dim3((n_tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_ids,
+                     (const half_t*)d_word, (const half_t*)d_pos, (const half_t*)d_type0, (const half_t*)d_gamma,
+                     (const half_t*)d_beta, eps, n_tokens, seq_len, hidden, (half_t*)d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_enc_add_ln(const uint16_t* d_x, const uint16_t* d_resid, const uint16_t* d_gamma,
+                               const uint16_t* d_beta, float eps, int n_rows, int hidden, uint16_t* d_out,
+                               void* stream) {
+  RARC_REQUIRE(d_x && d_resid && d_gamma && d_beta && d_out, RARC_E_INVALID, "rarc_enc_add_ln: null pointer");
+  RARC_REQUIRE(hidden % 64 == 0 && hidden <= 1024 && n_rows > 0, RARC_E_UNSUPPORTED,
+               "rarc_enc_add_ln: hidden must be a multiple of 64, <= 1024");
+  hipLaunchKernelGGL(rarc_add_ln_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)d_x,
+                     (const half_t*)d_resid, (const half_t*)d_gamma, (const half_t*)d_beta, eps, n_rows, hidden,
+                     (half_t*)d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
+                                  int n_heads, uint16_t* d_ctx, void* stream) {
+  RARC_REQUIRE(d_qkv && d_lens && d_ctx, RARC_E_INVALID, "rarc_enc_attention: null pointer");
+  RARC_REQUIRE(n_heads > 0 && (hidden == n_heads * 64 || hidden == n_heads * 32) && seq_len > 0 && seq_len <= 512 &&
+                   n_seq > 0,
+               RARC_E_UNSUPPORTED, "rarc_enc_attention: head_dim must be 32 or 64 and seq_len <= 512");
+  if (hidden == n_heads * 64)
+    hipLaunchKernelGGL(rarc_attention_kernel<64>, dim3(n_seq * n_heads), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, (half_t*)d_ctx);
+  else
+    hipLaunchKernelGGL(rarc_attention_kernel<32>, dim3(n_seq * n_heads), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, (half_t*)d_ctx);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, int hidden, int normalize,
+                             float* d_out, void* stream) {
+  RARC_REQUIRE(d_hidden && d_out && n_seq > 0 && hidden % 8 == 0, RARC_E_INVALID, "rarc_enc_pool: bad arguments");
+  hipLaunchKernelGGL(rarc_pool_kernel, dim3(n_seq), dim3(64), 0, (hipStream_t)stream, (const half_t*)d_hidden, seq_len,
+                     hidden, normalize, d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

@@ -101,6 +101,7 @@ struct ScanLds {
 
 // ABL: ablation bits for tools/scan_bench (0 in the product build)
 //   1 = no pruning epilogue, 2 = no DMA after the prologue, 4 = no MFMA loop, 8 = no refresh events
+//   16 = non-temporal tile DMA, 32 = s_setprio 1 during the MFMA phase (experiments)
 template <int D, int ABL = 0>
 __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const ScanParams p) {
   static_assert(D % 128 == 0 && D >= 128 && D <= 768, "D must be a multiple of 128, <= 768");
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       const int pn = i >> 2, b = i & 3;
       const char* g = gbase + (size_t)(8 * b) * (D * 2) + pn * 128 + ((b & 1) ? (voff_even ^ 64u) : voff_even);
       __builtin_amdgcn_global_load_lds(RARC_GPTR(g), RARC_LPTR(smem + buf * TILE_BYTES + i * 1024),
-                                       16, 0, 0);
+                                       16, 0, (ABL & 16) ? 2 : 0);
     }
   };
 
@@ -242,8 +243,10 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       asm volatile("" : "+v"(acc));
     } else {
       half8 rg[SCAN_RING];
+      if (ABL & 32) __builtin_amdgcn_s_setprio(1);
       ScanPrologue<0, SCAN_RING>::run(rg, a0, a1, a2, a3);
       ScanSteps<0, KS, SCAN_RING>::run(acc, rg, qf, a0, a1, a2, a3);
+      if (ABL & 32) __builtin_amdgcn_s_setprio(0);
       RARC_MFMA_DRAIN(acc);
     }
 

@@ -1,0 +1,144 @@
+"""BERT-family embedding provider on the MI355X (fills the reference's empty
+`encapsulation/embeddings/` slot; behaviour of HuggingFaceEmbeddings,
+core/file_management/embeddings/huggingface.py:105-145: newline -> space, encode, CLS pooling,
+optional normalisation, python float lists out).
+
+The forward pass runs in the rarc_enc_* HIP kernels (csrc/encoder.hip); weights are taken from a
+HuggingFace `BertModel` state dict (same tensor names), stored fp16 in HBM.  Tokenisation is a host
+callable `tokenize(text) -> list[int]` (WordPiece vocabularies do not ship offline).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from ...hip import binding as B
+from .base import Embeddings
+
+
+class HipBertEncoder:
+    """token ids [n_seq][seq_len] (+ lengths) -> fp32 embeddings [n_seq][hidden] on the device."""
+
+    def __init__(self, state_dict: Dict[str, "np.ndarray"], num_heads: int, layer_norm_eps: float = 1e-12,
+                 device: int = 0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise B.RarcError("no ROCm device visible: the HIP encoder has no CPU fallback")
+        self.torch, self.lib = torch, B.load_library()
+        self.device = torch.device("cuda", device)
+        self.eps = float(layer_norm_eps)
+        sd = {k.replace("bert.", "", 1) if k.startswith("bert.") else k: v for k, v in state_dict.items()}
+
+        def f16(name):
+            return torch.as_tensor(np.asarray(sd[name]), dtype=torch.float32).to(self.device).half().contiguous()
+
+        self.word = f16("embeddings.word_embeddings.weight")
+        self.pos = f16("embeddings.position_embeddings.weight")
+        self.type0 = f16("embeddings.token_type_embeddings.weight")[0].contiguous()
+        self.emb_g, self.emb_b = f16("embeddings.LayerNorm.weight"), f16("embeddings.LayerNorm.bias")
+        self.hidden = int(self.word.shape[1])
+        self.heads = int(num_heads)
+        if self.hidden % 128 or self.hidden // self.heads not in (32, 64) or self.hidden > 1024:
+            raise B.RarcError(f"unsupported encoder shape: hidden={self.hidden}, heads={self.heads}")
+        self.layers = []
+        i = 0
+        while f"encoder.layer.{i}.attention.self.query.weight" in sd:
+            p = f"encoder.layer.{i}."
+            qkv_w = torch.cat([f16(p + f"attention.self.{n}.weight") for n in ("query", "key", "value")]).contiguous()
+            qkv_b = torch.cat([f16(p + f"attention.self.{n}.bias") for n in ("query", "key", "value")]).contiguous()
+            self.layers.append(dict(
+                qkv_w=qkv_w, qkv_b=qkv_b,
+                o_w=f16(p + "attention.output.dense.weight"), o_b=f16(p + "attention.output.dense.bias"),
+                ln1_g=f16(p + "attention.output.LayerNorm.weight"), ln1_b=f16(p + "attention.output.LayerNorm.bias"),
+                f1_w=f16(p + "intermediate.dense.weight"), f1_b=f16(p + "intermediate.dense.bias"),
+                f2_w=f16(p + "output.dense.weight"), f2_b=f16(p + "output.dense.bias"),
+                ln2_g=f16(p + "output.LayerNorm.weight"), ln2_b=f16(p + "output.LayerNorm.bias")))
+            i += 1
+        if not self.layers:
+            raise B.RarcError("state dict holds no encoder.layer.* tensors")
+        self.inter = int(self.layers[0]["f1_w"].shape[0])
+        if self.inter % 128:
+            raise B.RarcError("intermediate size must be a multiple of 128")
+        self.max_pos = int(self.pos.shape[0])
+
+    def _gemm(self, a, w, bias, out, act, stream):
+        m, k = a.shape
+        n = w.shape[0]
+        B.check(self.lib.rarc_enc_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, act, stream),
+                "rarc_enc_gemm")
+
+    def forward(self, input_ids, lengths=None, normalize: bool = True):
+        t = self.torch
+        ids = np.asarray(input_ids, dtype=np.int32)
+        if ids.ndim != 2:
+            raise ValueError("input_ids must be [n_seq][seq_len]")
+        n_seq, L = ids.shape
+        if L > self.max_pos or L > 512:
+            raise ValueError(f"sequence length {L} exceeds the model limit")
+        lens = np.full(n_seq, L, np.int32) if lengths is None else np.asarray(lengths, np.int32)
+        step = 128 // math.gcd(L, 128)                      # GEMM rows (tokens) must be a multiple of 128
+        n_pad = -(-n_seq // step) * step
+        if n_pad != n_seq:
+            ids = np.concatenate([ids, np.zeros((n_pad - n_seq, L), np.int32)])
+            lens = np.concatenate([lens, np.ones(n_pad - n_seq, np.int32)])
+        M, H, I = n_pad * L, self.hidden, self.inter
+        with t.cuda.device(self.device):
+            st = t.cuda.current_stream(self.device).cuda_stream
+            d_ids = t.from_numpy(np.ascontiguousarray(ids)).to(self.device)
+            d_lens = t.from_numpy(np.ascontiguousarray(lens)).to(self.device)
+            x = t.empty((M, H), dtype=t.float16, device=self.device)
+            y = t.empty((M, H), dtype=t.float16, device=self.device)
+            ctx = t.empty((M, H), dtype=t.float16, device=self.device)
+            qkv = t.empty((M, 3 * H), dtype=t.float16, device=self.device)
+            mid = t.empty((M, I), dtype=t.float16, device=self.device)
+            out = t.empty((n_pad, H), dtype=t.float32, device=self.device)
+            L_ = self.lib
+            B.check(L_.rarc_enc_embed_ln(d_ids.data_ptr(), self.word.data_ptr(), self.pos.data_ptr(), self.type0.data_ptr(),
+                                         self.emb_g.data_ptr(), self.emb_b.data_ptr(), self.eps, M, L, H, x.data_ptr(), st),
+                    "rarc_enc_embed_ln")
+            for w in self.layers:
+                self._gemm(x, w["qkv_w"], w["qkv_b"], qkv, 0, st)
+                B.check(L_.rarc_enc_attention(qkv.data_ptr(), d_lens.data_ptr(), n_pad, L, H, self.heads, ctx.data_ptr(), st),
+                        "rarc_enc_attention")
+                self._gemm(ctx, w["o_w"], w["o_b"], y, 0, st)
+                B.check(L_.rarc_enc_add_ln(y.data_ptr(), x.data_ptr(), w["ln1_g"].data_ptr(), w["ln1_b"].data_ptr(), self.eps,
+                                           M, H, x.data_ptr(), st), "rarc_enc_add_ln")
+                self._gemm(x, w["f1_w"], w["f1_b"], mid, 1, st)
+                self._gemm(mid, w["f2_w"], w["f2_b"], y, 0, st)
+                B.check(L_.rarc_enc_add_ln(y.data_ptr(), x.data_ptr(), w["ln2_g"].data_ptr(), w["ln2_b"].data_ptr(), self.eps,
+                                           M, H, x.data_ptr(), st), "rarc_enc_add_ln")
+            B.check(L_.rarc_enc_pool(x.data_ptr(), n_pad, L, H, 1 if normalize else 0, out.data_ptr(), st), "rarc_enc_pool")
+            return out[:n_seq]
+
+
+class HipBertEmbeddings(Embeddings):
+    """Embeddings provider: tokenizer callable + HipBertEncoder."""
+
+    def __init__(self, encoder: HipBertEncoder, tokenize: Callable[[str], Sequence[int]], max_length: int = 512,
+                 batch_size: int = 32, normalize_embeddings: bool = True, pad_id: int = 0, **kwargs):
+        super().__init__(**kwargs)
+        self.encoder, self.tokenize = encoder, tokenize
+        self.max_length, self.batch_size = min(max_length, encoder.max_pos), batch_size
+        self.normalize, self.pad_id = normalize_embeddings, pad_id
+
+    def embed_documents(self, texts: List[str]) -> List[List[float]]:
+        texts = [t.replace("\n", " ") for t in texts]
+        out: List[Optional[List[float]]] = [None] * len(texts)
+        order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))   # longest first, like sentence-transformers
+        for s in range(0, len(order), self.batch_size):
+            chunk = order[s:s + self.batch_size]
+            toks = [list(self.tokenize(texts[i]))[: self.max_length] or [self.pad_id] for i in chunk]
+            L = max(len(t) for t in toks)
+            ids = np.full((len(toks), L), self.pad_id, np.int32)
+            for r, tk in enumerate(toks):
+                ids[r, : len(tk)] = tk
+            emb = self.encoder.forward(ids, [len(t) for t in toks], self.normalize).cpu().numpy()
+            for r, i in enumerate(chunk):
+                out[i] = emb[r].tolist()
+        return out
+
+    def embed_query(self, text: str) -> List[float]:
+        return self.embed_documents([text])[0]

@@ -48,6 +48,12 @@ SIGNATURES = {
     "rarc_rerank_order": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rarc_synth_rows_f16": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_uint64, c_void_p]),
     "rarc_synth_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_uint64, c_void_p]),
+    "rarc_enc_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
+                                  c_int, c_void_p, c_void_p]),
+    "rarc_enc_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rarc_enc_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rarc_enc_add_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p]),
+    "rarc_enc_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rarc_profile_begin": (c_int, [c_int]),
     "rarc_profile_end": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
 }

@@ -1,0 +1,85 @@
+"""GPU parity of the encoder forward (csrc/encoder.hip, through the C-ABI) vs the float32 oracle
+(oracle.bert_forward_f32, itself pinned against transformers.BertModel).
+
+Tolerance (floating point, stated here as the contract): weights, activations and GEMM operands are
+fp16 with fp32 accumulation, so the L2-normalised embedding is compared with
+  max |Δ| <= 4e-3  and  cosine(hip, oracle) >= 0.9995   per sequence.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(oracle, H, layers, heads, I, n_seq, L, seed):
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+
+    sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=800, max_pos=128, seed=seed)
+    enc = HipBertEncoder(sd, num_heads=heads)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(1, 800, (n_seq, L)).astype(np.int32)
+    lens = rng.integers(1, L + 1, n_seq).astype(np.int32)
+    lens[0] = L
+    for r, l in enumerate(lens):
+        ids[r, l:] = 0
+    got = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    # the oracle sees the same fp16-rounded weights (storage format), computes in fp32
+    sd16 = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    want = oracle.bert_forward_f32(sd16, ids, lens, heads, normalize=True)
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want)) <= 4e-3
+    cos = np.sum(got * want, axis=1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    assert cos.min() >= 0.9995
+
+
+@pytest.mark.parametrize("H,layers,heads,I,n_seq,L", [
+    (128, 1, 2, 256, 3, 8),        # head_dim 64, tiny
+    (128, 2, 4, 256, 5, 24),       # head_dim 32 (bge-small style heads)
+    (384, 2, 12, 1536, 9, 32),     # bge-small shape, 2 layers
+    (256, 1, 4, 512, 2, 100),      # keys span two 64-key tiles
+])
+def test_encoder_matches_oracle(oracle, H, layers, heads, I, n_seq, L):
+    _check(oracle, H, layers, heads, I, n_seq, L, seed=H + L)
+
+
+def test_gemm_kernel_alone(oracle):
+    """A=I check with asymmetric W (catches transposes), then random data with bias + GELU."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    M, N, K = 256, 384, 128
+    rng = np.random.default_rng(1)
+    A = np.zeros((M, K), np.float16)
+    A[np.arange(K), np.arange(K)] = 1.0                       # rows 0..K-1 form the identity
+    W = rng.standard_normal((N, K)).astype(np.float16)
+    bias = np.zeros(N, np.float16)
+    dA, dW, db = (torch.from_numpy(x).cuda() for x in (A, W, bias))
+    dC = torch.empty((M, N), dtype=torch.float16, device="cuda")
+    B.check(lib.rarc_enc_gemm(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), dC.data_ptr(), M, N, K, 0, 0))
+    C = dC.cpu().numpy()
+    assert np.array_equal(C[:K], W.T) and not C[K:].any()
+    A = (rng.standard_normal((M, K)) * 0.5).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16)
+    dA, db = torch.from_numpy(A).cuda(), torch.from_numpy(bias).cuda()
+    B.check(lib.rarc_enc_gemm(dA.data_ptr(), dW.data_ptr(), db.data_ptr(), dC.data_ptr(), M, N, K, 1, 0))
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias.astype(np.float64)
+    from scipy.special import erf
+    ref = 0.5 * ref * (1 + erf(ref / np.sqrt(2)))
+    assert np.max(np.abs(dC.cpu().numpy().astype(np.float64) - ref)) < 2e-2 * max(1.0, np.abs(ref).max() / 8)
+
+
+def test_embeddings_provider_contract(oracle):
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEmbeddings, HipBertEncoder
+
+    sd = oracle.random_bert_state_dict(128, 1, 2, 256, vocab=300, max_pos=64, seed=2)
+    tok = lambda text: [1 + (ord(c) % 250) for c in text][:40]
+    emb = HipBertEmbeddings(HipBertEncoder(sd, num_heads=2), tok, batch_size=4)
+    texts = ["alpha", "a much longer piece of text\nwith a newline", "b", "gamma delta", "e"]
+    vecs = emb.embed_documents(texts)
+    assert len(vecs) == 5 and all(len(v) == 128 and isinstance(v[0], float) for v in vecs)
+    assert all(abs(np.linalg.norm(v) - 1.0) < 1e-3 for v in vecs)
+    q = emb.embed_query("gamma delta")
+    assert np.allclose(q, vecs[3], atol=2e-3)                      # batch composition does not matter
+    assert np.allclose(emb.embed_query("x\ny"), emb.embed_query("x y"), atol=1e-6)   # newline -> space

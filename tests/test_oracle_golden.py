@@ -103,3 +103,27 @@ def test_topk_merge_is_sharding_invariant(oracle):
         parts_s.append(s)
     mi, ms = oracle.topk_merge(np.stack(parts_i), np.stack(parts_s), 10)
     assert np.array_equal(mi, full_i) and np.array_equal(ms.view(np.uint32), full_s.view(np.uint32))
+
+
+def test_bert_oracle_matches_transformers(oracle):
+    """Pins oracle.bert_forward_f32 against transformers.BertModel (fp32, seeded weights, padding mask)."""
+    import torch
+    from transformers import BertConfig, BertModel
+
+    H, Lyr, heads, I = 128, 2, 4, 256
+    sd = oracle.random_bert_state_dict(H, Lyr, heads, I, vocab=500, max_pos=64, seed=3)
+    cfg = BertConfig(vocab_size=500, hidden_size=H, num_hidden_layers=Lyr, num_attention_heads=heads, intermediate_size=I,
+                     max_position_embeddings=64, hidden_act="gelu", layer_norm_eps=1e-12, attn_implementation="eager")
+    model = BertModel(cfg, add_pooling_layer=False).eval()
+    missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not [m for m in missing.missing_keys if "position_ids" not in m]
+    rng = np.random.default_rng(0)
+    ids = rng.integers(1, 500, (5, 24))
+    lens = np.array([24, 7, 1, 16, 24])
+    for r, l in enumerate(lens):
+        ids[r, l:] = 0
+    att = (np.arange(24)[None, :] < lens[:, None]).astype(np.int64)
+    with torch.no_grad():
+        want = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(att)).last_hidden_state[:, 0].numpy()
+    got = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=False)
+    assert np.max(np.abs(got - want)) < 2e-5
