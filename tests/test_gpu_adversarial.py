@@ -1,0 +1,83 @@
+"""Data the pruning heuristics hate: results must stay bit-identical to the oracle, whatever path
+(certificate, overflow flag, exact repair) gets there."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oracle, X, Q, k, metric="cosine"):
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    idx = FlatIndexF16(X.shape[1], metric=metric)
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    rows, _ = oracle.ingest_f16(X, normalize=(metric == "cosine"))
+    qn = oracle.normalize_L2(Q) if metric == "cosine" else Q
+    rI, rD, _ = oracle.flat_search_f16(rows, qn, k)
+    assert np.array_equal(I, rI), "ids differ"
+    assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), "scores differ"
+    return idx
+
+
+def test_corpus_sorted_by_similarity_to_a_query(oracle):
+    """Every later tile beats every earlier one for query 0: thresholds chase the data the whole scan."""
+    rng = np.random.default_rng(0)
+    n, d = 60_000, 768
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((8, d)).astype(np.float32)
+    order = np.argsort(X @ Q[0])          # ascending similarity to query 0
+    idx = _run(oracle, X[order], Q, 100)
+    print("repaired:", getattr(idx, "last_repaired", None))
+
+
+def test_tight_cluster_of_near_duplicates(oracle):
+    rng = np.random.default_rng(1)
+    n, d = 40_000, 384
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    c = rng.standard_normal(d).astype(np.float32)
+    X[5000:7000] = c + 0.01 * rng.standard_normal((2000, d)).astype(np.float32)   # 2000 rows within ~1e-4 in cosine
+    Q = np.stack([c, c + 0.02 * rng.standard_normal(d).astype(np.float32), rng.standard_normal(d).astype(np.float32)])
+    _run(oracle, X, Q, 100)
+
+
+def test_all_rows_identical(oracle):
+    rng = np.random.default_rng(2)
+    X = np.tile(rng.standard_normal((1, 256)).astype(np.float32), (6000, 1))
+    Q = rng.standard_normal((3, 256)).astype(np.float32)
+    _run(oracle, X, Q, 50)
+
+
+def test_scores_spanning_many_magnitudes_ip(oracle):
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((20_000, 512)).astype(np.float32) * np.exp(rng.uniform(-6, 3, (20_000, 1))).astype(np.float32)
+    Q = rng.standard_normal((5, 512)).astype(np.float32) * 3
+    _run(oracle, X, Q, 64, metric="ip")
+
+
+def test_k_equals_one_and_large_k(oracle):
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((30_000, 768)).astype(np.float32)
+    Q = rng.standard_normal((4, 768)).astype(np.float32)
+    _run(oracle, X, Q, 1)
+    _run(oracle, X, Q, 900)
+
+
+def test_flags_are_raised_and_repair_fixes_them(oracle):
+    """Force the certificate to fail (k' == k leaves no margin) and check repair restores exactness."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((50_000, 768)).astype(np.float32)
+    Q = rng.standard_normal((16, 768)).astype(np.float32)
+    idx = FlatIndexF16(768)
+    idx.add(X)
+    idx.kprime_for = lambda k: k            # no margin: every query is UNCERTAIN by construction
+    D, I = idx.search(Q, 100)
+    assert len(idx.last_repaired) == 16
+    rows, _ = oracle.ingest_f16(X)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), 100)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
