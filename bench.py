@@ -124,6 +124,10 @@ def main():
     scan_ms = tot_ms.value / max(1, n_l.value)
     shard_bytes = (hi - lo) * d_pad * 2  # algorithmic bytes of one scan launch on this rank
     flagged = len(getattr(idx, "last_repaired", []))
+    # full-size exactness property on this rank's shard: the exact repair scan must find no row
+    # beating the returned k-th entry (local results, before the cross-shard merge)
+    l_ids, l_sc = idx.search_device(q, a.k)
+    beat = sum(idx.verify_query(q, b, l_ids, l_sc) for b in (0, a.batch - 1))
 
     result = None
     if rank == 0:
@@ -146,7 +150,8 @@ def main():
             "config": {"workload": f"{rows}x{a.dim} fp16 corpus resident in HBM, row-sharded over {world} GPU(s), "
                                    f"batch {a.batch} queries, cosine top-{a.k}, exact (canonical fp32 rescore)",
                        "n_corpus": rows, "d": a.dim, "batch": a.batch, "k": a.k, "rows_per_gpu": hi - lo,
-                       "repaired_queries_last_step": flagged},
+                       "repaired_queries_last_step": flagged,
+                       "full_size_check": {"queries_verified_by_exact_rescan": 2, "rows_beating_kth": beat}},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "rarc_scan_f16_kernel", "avg_launch_ms": round(scan_ms, 4),
