@@ -163,16 +163,33 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
   int own_q = -1;     // owner (wave 0): query whose histogram is in flight
   int event = 0;
 
-  auto issue = [&](int buf, uint32_t tile) {
-    const char* gbase = (const char*)p.corpus + (size_t)tile * TILE_BYTES;
+  // Per-wave constants of its DPW DMA instructions: source offset inside the tile (SGPR soffset),
+  // LDS landing offset, and which of the two per-lane source patterns (even / odd row-block) applies.
+  const uint32_t voff_odd = voff_even ^ 64u;
+  int dma_soff[DPW], dma_loff[DPW];
+  bool dma_odd[DPW];
 #pragma unroll
-    for (int j = 0; j < DPW; ++j) {
-      const int i = wave * DPW + j;
-      const int pn = i >> 2, b = i & 3;
-      const char* g = gbase + (size_t)(8 * b) * (D * 2) + pn * 128 + ((b & 1) ? (voff_even ^ 64u) : voff_even);
-      __builtin_amdgcn_global_load_lds(RARC_GPTR(g), RARC_LPTR(smem + buf * TILE_BYTES + i * 1024),
-                                       16, 0, (ABL & 16) ? 2 : 0);
-    }
+  for (int j = 0; j < DPW; ++j) {
+    const int i = wave * DPW + j;
+    const int pn = i >> 2, b = i & 3;
+    dma_soff[j] = 8 * b * (D * 2) + pn * 128;
+    dma_loff[j] = i * 1024;
+    dma_odd[j] = (b & 1) != 0;
+  }
+  // one tile = DPW buffer_load_dwordx4 ... lds per wave: descriptor rebased per tile (2 SALU), the
+  // rest of the address is an SGPR offset + a per-lane VGPR offset -> ~2 scalar ops per instruction
+  auto issue = [&](int buf, uint32_t tile) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer builtins exist only in the device pass of this file
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.corpus + (size_t)tile * TILE_BYTES), 0,
+                                                  TILE_BYTES, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < DPW; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, RARC_LPTR(smem + buf * TILE_BYTES + dma_loff[j]), 16,
+                                               dma_odd[j] ? voff_odd : voff_even, dma_soff[j], 0,
+                                               (ABL & 16) ? 2 : 0);
+#else
+    (void)buf; (void)tile;
+#endif
   };
 
   // one surviving score: slot from the LDS counter, key to the private segment, histogram bump.
@@ -229,15 +246,13 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const bool issued = !(ABL & 2) && cur + 2 * stride < p.n_tiles;
-    {
-      int nb = buf + 2;
-      if (nb >= 3) nb -= 3;
-      if (issued) issue(nb, cur + 2 * stride);
-    }
-
+    int nb = buf + 2;
+    if (nb >= 3) nb -= 3;
+    if (issued) issue(nb, cur + 2 * stride);
+    // group B prunes the PREVIOUS tile now, while group A (same SIMDs) already streams MFMAs
     if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
 
-    // ---- 32 rows × 32 queries per wave: KS chained MFMAs fed by a 6-deep LDS read ring ----
+    // ---- 32 rows x 32 queries per wave: KS chained MFMAs fed by a 6-deep LDS read ring ----
     if (ABL & 4) {
       acc = (f32x16){0};
       asm volatile("" : "+v"(acc));
@@ -248,6 +263,10 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       ScanSteps<0, KS, SCAN_RING>::run(acc, rg, qf, a0, a1, a2, a3);
       if (ABL & 32) __builtin_amdgcn_s_setprio(0);
       RARC_MFMA_DRAIN(acc);
+    }
+    if (!(ABL & 1)) {  // group A prunes this tile right away; group B defers it to the next iteration
+      if (!grp_b) prune(acc, cur);
+      else prev = cur;
     }
 
     // ---- threshold refresh issued one iteration ago: its DMAs are older than this iteration's
@@ -269,12 +288,6 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
         own_q = -1;
       }
       pend = false;
-    }
-
-    // ---- prune (group A: this tile, right away; group B: deferred to the next iteration) ----
-    if (!(ABL & 1)) {
-      if (!grp_b) prune(acc, cur);
-      else prev = cur;
     }
 
     // ---- threshold refresh events: every tile up to 8, then every 4th ----

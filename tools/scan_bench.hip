@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
   int grid = 256; uint32_t st = p.n_tiles < 128 ? p.n_tiles : 128;
   const double gb = (double)N * D * 2 / 1e9;
 #define RUN(A) { float us = run<A>(p, grid, 8, NQ, KP, ws, st); printf("ABL=%2d  %8.1f us  %6.2f TB/s\n", A, us, gb / us * 1e-3); }
-  RUN(0) RUN(16) RUN(32) RUN(48) RUN(0) RUN(16) RUN(32) RUN(48) RUN(9) RUN(25) RUN(11)
+  RUN(0) RUN(0) RUN(0) RUN(9) RUN(11) RUN(13)
   run<0>(p, grid, 1, NQ, KP, ws, st);
   std::vector<uint32_t> cnt(256 * 256); hipMemcpy(cnt.data(), ws.cnt2, 256 * 256 * 4, hipMemcpyDeviceToHost);
   uint64_t tot = 0; uint32_t mx = 0; for (auto c : cnt) { tot += c; mx = c > mx ? c : mx; }
