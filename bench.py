@@ -54,22 +54,23 @@ def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234):
     return idx
 
 
-def timed_steps(torch, dist, searcher, q, k, steps, warmup, world):
+def timed_steps(torch, dist, searcher, q, k, steps, warmup, world, use_dist=False):
+    use_dist = use_dist or world > 1
     for _ in range(warmup):
         searcher.search_device(q, k)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = searcher.search_device(q, k)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=q.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -85,9 +86,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RARC_FORCE_DIST") == "1"   # the env var exercises RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if a.gpus != world and rank == 0 and world > 1:
         print(f"# note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -107,7 +110,7 @@ def main():
             rows //= 10
     lo, hi = shard_range(rows, rank, world)
     idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi)
-    searcher = ShardedFlatSearch(idx)
+    searcher = ShardedFlatSearch(idx, force_collective=use_dist)
     q = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev)
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), a.dim, a.dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
     torch.cuda.synchronize()
@@ -117,7 +120,7 @@ def main():
         searcher.search_device(q, a.k)
     torch.cuda.synchronize()
     B.check(lib.rarc_profile_begin(a.steps * ((a.batch + 255) // 256) + 8), "rarc_profile_begin")
-    dt, (ids, scores) = timed_steps(torch, dist, searcher, q, a.k, a.steps, 0, world)
+    dt, (ids, scores) = timed_steps(torch, dist, searcher, q, a.k, a.steps, 0, world, use_dist)
     import ctypes
     tot_ms, n_l = ctypes.c_double(0), ctypes.c_int(0)
     B.check(lib.rarc_profile_end(ctypes.byref(tot_ms), ctypes.byref(n_l)), "rarc_profile_end")
@@ -163,7 +166,7 @@ def main():
         n2 = min(1_000_000, rows)
         idx2 = idx if (world == 1 and rows == n2) else build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, 0, n2)
         s2 = ShardedFlatSearch.__new__(ShardedFlatSearch)
-        s2.torch, s2.dist, s2.local, s2.group, s2.world, s2.rank = torch, dist, idx2, None, 1, 0
+        s2.torch, s2.dist, s2.local, s2.group, s2.world, s2.rank, s2.force_collective = torch, dist, idx2, None, 1, 0, False
         steps2 = max(a.steps, 50)
         B.check(lib.rarc_profile_begin(steps2 + 8), "rarc_profile_begin")
         dt2, (ids2, sc2) = timed_steps(torch, dist, s2, q, a.k, steps2, max(a.warmup, 5), 1)
@@ -189,7 +192,7 @@ def main():
                 "parity_vs_gpu": {"ids_bit_exact": same_ids, "scores_bit_exact": same_sc}}
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

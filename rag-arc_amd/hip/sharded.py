@@ -40,7 +40,7 @@ class ShardedFlatSearch:
     """Wraps a local index (anything with search_device(q, k) -> (ids, scores) device tensors whose
     ids are already global) and a torch.distributed process group."""
 
-    def __init__(self, local_index, group=None, merge_fn: Optional[Callable] = None):
+    def __init__(self, local_index, group=None, merge_fn: Optional[Callable] = None, force_collective: bool = False):
         import torch
         import torch.distributed as dist
 
@@ -50,6 +50,7 @@ class ShardedFlatSearch:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.merge_fn = merge_fn or self._hip_merge
+        self.force_collective = force_collective  # run gather + merge even with a single rank (testing)
 
     def _hip_merge(self, ids, scores, k):
         """ids/scores: [G][nq][k] device tensors -> [nq][k] via rarc_topk_merge."""
@@ -68,7 +69,7 @@ class ShardedFlatSearch:
     def search_device(self, queries, k: int):
         t = self.torch
         ids, scores = self.local.search_device(queries, k)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return ids, scores
         mine = pack_results(t, ids, scores)
         # concatenated layout ([world*nq][k][3]) is the form both RCCL and gloo accept
