@@ -107,8 +107,10 @@ size_t rarc_search_workspace_bytes(int cand_cap);
  *   id_base      : added to local row indices (global id of this shard's row 0)
  *   d_out_ids    : [nq][k] int64, -1 where fewer than k rows exist
  *   d_out_scores : [nq][k] fp32 canonical scores, -inf padding
- *   d_status     : [nq] RARC_Q_* bits; a query whose bit is set must be
- *                  repaired with rarc_repair_f16 before its row is trusted
+ *   d_status     : [RARC_MAX_QUERIES + 1] uint32, ZEROED BY THE CALLER: entry q < nq receives
+ *                  the RARC_Q_* bits of query q (a query whose bit is set must be repaired
+ *                  with rarc_repair_f16 before its row is trusted); the last entry
+ *                  receives the OR of all of them (one word to read back per batch)
  *   bin_lo/bin_hi: score range covered by the pruning histogram
  *                  (cosine: -1, +1; ip: -/+ max|q|*max|d|)
  */

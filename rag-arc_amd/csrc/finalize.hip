@@ -183,7 +183,10 @@ __global__ __launch_bounds__(FIN_THREADS) void rarc_finalize_kernel(const FinPar
       if (!(tmin + p.eps[q] < s_sk)) st |= RARC_Q_UNCERTAIN;
     }
     p.status[q] = st;
-    if (st) atomicOr(&p.flags[1], st);  // one word the host can poll instead of scanning d_status
+    if (st) {  // one word the host can poll instead of scanning d_status
+      atomicOr(&p.flags[1], st);
+      atomicOr(&p.status[RARC_MAX_QUERIES], st);
+    }
   }
 }
 

@@ -82,7 +82,7 @@ class FlatIndexF16:
                 q32=t.empty((mq, self.d_pad), dtype=t.float32, device=self.device),
                 q16=t.empty((mq, self.d_pad), dtype=t.float16, device=self.device),
                 eps=t.empty(mq, dtype=t.float32, device=self.device),
-                status=t.empty(mq, dtype=t.int32, device=self.device),
+                status=t.zeros(mq + 1, dtype=t.int32, device=self.device),
                 found=t.empty(1, dtype=t.int32, device=self.device),
             )
         return self._ws
@@ -180,16 +180,55 @@ class FlatIndexF16:
                 self._search_chunk(q[s:e], k, out_ids[s:e], out_sc[s:e], repair)
             return out_ids, out_sc
 
+    # ------------------------------------------------------------------ pipelined search
+    def search_async(self, queries, k: int) -> "PendingSearch":
+        """Enqueue one batch (<= 256 queries) and return at once; `.result()` later performs the
+        status read-back (and the rare repair).  Lets a caller keep the GPU queue full: launch batch
+        i+1, then collect batch i.  Results are identical to search_device()."""
+        t = self.torch
+        if not (1 <= k <= B.MAX_K):
+            raise ValueError("k out of range")
+        with self._lock, t.cuda.device(self.device):
+            q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
+            if q.ndim != 2 or q.shape[1] != self.dim or q.shape[0] > B.MAX_QUERIES:
+                raise ValueError(f"expected [nq<=256][{self.dim}] queries, got {tuple(q.shape)}")
+            nq = q.shape[0]
+            out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
+            out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
+            status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this batch's own words
+            self._search_chunk(q, k, out_ids, out_sc, repair=False, status=status)
+            return PendingSearch(self, q, k, out_ids, out_sc, status[B.MAX_QUERIES:], status[:nq])
+
+    def _repair_rows(self, q, k, out_ids, out_sc, flagged) -> None:
+        """Re-prepare `q` (the shared query buffers may hold a later batch by now) and repair rows."""
+        t = self.torch
+        ws, b = self._workspace(), self._qbuf
+        norm = 1 if self.metric == "cosine" else 0
+        stream = self._stream()
+        B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
+                                           max(self.max_norm, 1.0) if norm else self.max_norm,
+                                           b["q32"].data_ptr(), b["q16"].data_ptr(), b["eps"].data_ptr(), stream),
+                "rarc_prep_queries")
+        for qi in flagged:
+            B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["q32"].data_ptr(), qi, k,
+                                             self.id_base, out_ids.data_ptr(), out_sc.data_ptr(), b["found"].data_ptr(),
+                                             ws.data_ptr(), ws.numel(), stream), "rarc_repair_f16")
+            if int(b["found"].item()) & 0x80000000:
+                raise B.RarcError(f"repair of query {qi} overflowed its scratch list")
+
     def _bins(self, q) -> Tuple[float, float]:
         if self.metric == "cosine":
             return -1.0, 1.0
         bound = float(q.norm(dim=1).max().item()) * max(self.max_norm, 1e-30) * 1.001
         return -bound, bound
 
-    def _search_chunk(self, q, k, out_ids, out_sc, repair) -> None:
+    def _search_chunk(self, q, k, out_ids, out_sc, repair, status=None) -> None:
         t = self.torch
         ws = self._workspace()
         b = self._qbuf
+        if status is None:
+            status = b["status"]
+            status.zero_()
         nq = q.shape[0]
         stream = self._stream()
         norm = 1 if self.metric == "cosine" else 0
@@ -202,15 +241,15 @@ class FlatIndexF16:
         rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
         B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, b["q32"].data_ptr(),
                                          b["q16"].data_ptr(), b["eps"].data_ptr(), nq, k, kp, self.id_base,
-                                         lo, hi, out_ids.data_ptr(), out_sc.data_ptr(), b["status"].data_ptr(),
+                                         lo, hi, out_ids.data_ptr(), out_sc.data_ptr(), status.data_ptr(),
                                          ws.data_ptr(), ws.numel(), self.cand_cap, stream),
                 "rarc_search_f16")
-        self.last_status = b["status"][:nq]
+        self.last_status = status[:nq]
         if not repair or self.ntotal == 0:
             return
         # one 4-byte read-back per batch (syncs); the per-query words are fetched only if it is set
-        any_flag = int(ws[B.WS_ANYFLAG_OFFSET: B.WS_ANYFLAG_OFFSET + 4].view(t.int32).item())
-        flagged = t.nonzero(b["status"][:nq]).flatten().tolist() if any_flag else []
+        any_flag = int(status[B.MAX_QUERIES].item())
+        flagged = t.nonzero(status[:nq]).flatten().tolist() if any_flag else []
         self.last_repaired = flagged
         for qi in flagged:
             B.check(self.lib.rarc_repair_f16(rows_ptr, self.ntotal, self.d_pad, b["q32"].data_ptr(), qi, k,
@@ -238,3 +277,23 @@ class FlatIndexF16:
                                              b["found"].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                     "rarc_repair_f16")
             return int(b["found"].item())
+
+
+class PendingSearch:
+    """Handle returned by FlatIndexF16.search_async."""
+
+    def __init__(self, index, q, k, ids, scores, flag, status):
+        self.index, self.q, self.k, self.ids, self.scores, self.flag, self.status = index, q, k, ids, scores, flag, status
+        self.repaired = None
+
+    def result(self):
+        """(ids int64 [nq][k], scores fp32 [nq][k]) device tensors, exact."""
+        if self.repaired is None:
+            t = self.index.torch
+            self.repaired = []
+            if int(self.flag.item()):  # syncs on this batch only
+                self.repaired = t.nonzero(self.status).flatten().tolist()
+                with self.index._lock, t.cuda.device(self.index.device):
+                    self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired)
+            self.index.last_repaired = self.repaired
+        return self.ids, self.scores

@@ -66,9 +66,21 @@ class ShardedFlatSearch:
                                     t.cuda.current_stream(ids.device).cuda_stream), "rarc_topk_merge")
         return out_i, out_s
 
+    def search_async(self, queries, k: int):
+        """Pipelined form: enqueue the local scan now; `finish(handle)` does the status check, the
+        all-gather and the merge.  Lets batch i+1 scan while batch i is collected."""
+        return self.local.search_async(queries, k)
+
+    def finish(self, handle, k: int):
+        ids, scores = handle.result()
+        return self._exchange(ids, scores, k)
+
     def search_device(self, queries, k: int):
-        t = self.torch
         ids, scores = self.local.search_device(queries, k)
+        return self._exchange(ids, scores, k)
+
+    def _exchange(self, ids, scores, k: int):
+        t = self.torch
         if self.world == 1 and not self.force_collective:
             return ids, scores
         mine = pack_results(t, ids, scores)

@@ -121,3 +121,21 @@ def test_verify_finds_nothing_on_exact_answer(hip, oracle):
     for qi in (0, 5, 15):
         assert idx.verify_query(Q, qi, ids, sc) == 0
     assert bool((ids == before).all())
+
+
+def test_async_pipeline_gives_identical_results(hip, oracle):
+    X, Q = _data(30_000, 768, 256, seed=21)
+    idx = hip.FlatIndexF16(768)
+    idx.add(X)
+    want_i, want_s = idx.search_device(Q, 50)
+    handles = [idx.search_async(Q[i * 64:(i + 1) * 64], 50) for i in range(4)]     # four batches in flight
+    for i, h in enumerate(handles):
+        ids, sc = h.result()
+        assert bool((ids == want_i[i * 64:(i + 1) * 64]).all()) and bool((sc == want_s[i * 64:(i + 1) * 64]).all())
+    # forced repair through the deferred path
+    idx.kprime_for = lambda k: k
+    h1, h2 = idx.search_async(Q[:16], 50), idx.search_async(Q[16:32], 50)
+    for h, lo in ((h1, 0), (h2, 16)):
+        ids, sc = h.result()
+        assert len(h.repaired) == 16
+        assert bool((ids == want_i[lo:lo + 16]).all()) and bool((sc == want_s[lo:lo + 16]).all())

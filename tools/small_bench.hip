@@ -11,7 +11,7 @@ int main() {
   const int64_t N = 1000000; const int D = 768, NQ = 256, K = 100, KP = 128, CAP = 16384;
   uint16_t *corpus, *q16; float *q32, *eps, *qin, *osc; int64_t* oid; uint32_t* st; void* ws;
   hipMalloc(&corpus, (size_t)(N + 32) * D * 2); hipMalloc(&q16, 256 * D * 2); hipMalloc(&q32, 256 * D * 4);
-  hipMalloc(&eps, 1024); hipMalloc(&qin, 256 * D * 4); hipMalloc(&osc, 256 * K * 4); hipMalloc(&oid, 256 * K * 8); hipMalloc(&st, 1024);
+  hipMalloc(&eps, 1024); hipMalloc(&qin, 256 * D * 4); hipMalloc(&osc, 256 * K * 4); hipMalloc(&oid, 256 * K * 8); hipMalloc(&st, 1028); hipMemset(st, 0, 1028);
   size_t wsb = rarc_search_workspace_bytes(CAP); hipMalloc(&ws, wsb);
   rarc_synth_rows_f16(corpus, D, D, 0, N, 1234, 0); rarc_synth_rows_f32(qin, D, D, 0, NQ, 4321, 0);
   hipDeviceSynchronize();
