@@ -38,6 +38,7 @@ struct ScanParams {
   uint32_t seg;           // slots per (query, workgroup)
   uint32_t kprime;
   uint32_t nq;
+  unsigned long long* dbg;  // tools/scan_bench timeline (ABL & 64), else null
 };
 
 constexpr int SCAN_WAVES = 8;
@@ -51,9 +52,14 @@ constexpr int SCAN_RING = 6;
 
 template <int S, int KS, int R>
 struct ScanSteps {
+  // `dma(j)` issues this wave's j-th LDS-DMA piece of a later tile (group A only): one call per step
+  // during the first steps, so the (slow, CU-serialised) VMEM issue hides in MFMA shadows instead of
+  // delaying the tile's first MFMA, yet the pieces still get two tile periods to land
+  template <class Dma>
   static __device__ __forceinline__ void run(f32x16& acc, half8 (&rg)[R], const half8 (&qf)[KS], int a0, int a1,
-                                             int a2, int a3) {
+                                             int a2, int a3, Dma& dma) {
     constexpr int slot = S % R;
+    if constexpr (S >= 1 && S <= KS / 8) dma(S - 1);
     if constexpr (S + R < KS) {
       constexpr int S2 = S + R;  // fragment that refills this slot
       const int addr = (S2 & 3) == 0 ? a0 : (S2 & 3) == 1 ? a1 : (S2 & 3) == 2 ? a2 : a3;
@@ -72,7 +78,7 @@ struct ScanSteps {
       asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0"
                    : "+v"(acc) : "v"(rg[slot]), "v"(qf[S]), "n"(KS - 1 - S));
     }
-    if constexpr (S + 1 < KS) ScanSteps<S + 1, KS, R>::run(acc, rg, qf, a0, a1, a2, a3);
+    if constexpr (S + 1 < KS) ScanSteps<S + 1, KS, R>::run(acc, rg, qf, a0, a1, a2, a3, dma);
   }
 };
 template <int S, int R>
@@ -102,6 +108,7 @@ struct ScanLds {
 // ABL: ablation bits for tools/scan_bench (0 in the product build)
 //   1 = no pruning epilogue, 2 = no DMA after the prologue, 4 = no MFMA loop, 8 = no refresh events
 //   16 = non-temporal tile DMA, 32 = s_setprio 1 during the MFMA phase (experiments)
+//   64 = record s_memtime stamps of workgroup 0 into p.dbg[iter][wave][8]
 template <int D, int ABL = 0>
 __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const ScanParams p) {
   static_assert(D % 128 == 0 && D >= 128 && D <= 768, "D must be a multiple of 128, <= 768");
@@ -178,18 +185,19 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
   }
   // one tile = DPW buffer_load_dwordx4 ... lds per wave: descriptor rebased per tile (2 SALU), the
   // rest of the address is an SGPR offset + a per-lane VGPR offset -> ~2 scalar ops per instruction
-  auto issue = [&](int buf, uint32_t tile) {
+  auto issue_piece = [&](int buf, uint32_t tile, int j) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer builtins exist only in the device pass of this file
     auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.corpus + (size_t)tile * TILE_BYTES), 0,
                                                   TILE_BYTES, 0x00020000);
-#pragma unroll
-    for (int j = 0; j < DPW; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, RARC_LPTR(smem + buf * TILE_BYTES + dma_loff[j]), 16,
-                                               dma_odd[j] ? voff_odd : voff_even, dma_soff[j], 0,
-                                               (ABL & 16) ? 2 : 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, RARC_LPTR(smem + buf * TILE_BYTES + dma_loff[j]), 16,
+                                             dma_odd[j] ? voff_odd : voff_even, dma_soff[j], 0, (ABL & 16) ? 2 : 0);
 #else
-    (void)buf; (void)tile;
+    (void)buf; (void)tile; (void)j;
 #endif
+  };
+  auto issue = [&](int buf, uint32_t tile) {
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) issue_piece(buf, tile, j);
   };
 
   // one surviving score: slot from the LDS counter, key to the private segment, histogram bump.
@@ -239,16 +247,38 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
   uint32_t prev = 0xffffffffu;  // group B: tile whose scores are still in acc
   f32x16 acc;
   for (uint32_t cur = t0; cur < p.n_tiles; cur += stride) {
-    // DMA(cur) landed: loads return in order, so "at most DPW outstanding" == everything but the
-    // newest tile's DPW instructions has completed (stores/atomics in between only tighten it)
-    if ((ABL & 2) || cur + stride >= p.n_tiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+    // DMA(cur) landed?  Loads return in order, so "at most N outstanding" == everything older than
+    // the newest N vector-memory ops has completed.  The newest ops of this wave are, by
+    // construction, the DPW pieces of the next tile followed by the refresh-event DMAs (0, 1 or 2)
+    // issued at the end of the previous iteration (group A's prune stores may sit in between: they
+    // only make the wait stricter, and have long been acknowledged by the time we get here).
+    {
+      const int ev = (pend ? 1 : 0) + (own_q >= 0 ? 1 : 0);
+      if ((ABL & 2) || cur + stride >= p.n_tiles) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (ev == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
+      else if (ev == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 2) : "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+#define RARC_STAMP(slot)                                                                         \
+  if ((ABL & 64) && blockIdx.x == 0 && it < 64 && rarc_fresh_lane() == 0)                         \
+    p.dbg[(it * SCAN_WAVES + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+    RARC_STAMP(0)
     const bool issued = !(ABL & 2) && cur + 2 * stride < p.n_tiles;
     int nb = buf + 2;
     if (nb >= 3) nb -= 3;
-    if (issued) issue(nb, cur + 2 * stride);
+    // the DMA of tile cur+2 is issued piecewise from inside the MFMA loop (see ScanSteps)
+    const uint32_t dma_tile = cur + 2 * stride;
+    auto dma = [&](int j) {
+      if (issued && !grp_b) {  // group B issued all its pieces right after the barrier
+        asm volatile("" ::: "memory");
+        issue_piece(nb, dma_tile, j);
+        asm volatile("" ::: "memory");
+      }
+    };
+    if (issued && (grp_b || (ABL & 4))) issue(nb, dma_tile);  // group B (it prunes first anyway)
+    RARC_STAMP(1)
     // group B prunes the PREVIOUS tile now, while group A (same SIMDs) already streams MFMAs
     if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
 
@@ -259,16 +289,19 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     } else {
       half8 rg[SCAN_RING];
       if (ABL & 32) __builtin_amdgcn_s_setprio(1);
+      RARC_STAMP(2)
       ScanPrologue<0, SCAN_RING>::run(rg, a0, a1, a2, a3);
-      ScanSteps<0, KS, SCAN_RING>::run(acc, rg, qf, a0, a1, a2, a3);
+      ScanSteps<0, KS, SCAN_RING>::run(acc, rg, qf, a0, a1, a2, a3, dma);
       if (ABL & 32) __builtin_amdgcn_s_setprio(0);
       RARC_MFMA_DRAIN(acc);
+      RARC_STAMP(3)
     }
     if (!(ABL & 1)) {  // group A prunes this tile right away; group B defers it to the next iteration
       if (!grp_b) prune(acc, cur);
       else prev = cur;
     }
 
+    RARC_STAMP(4)
     // ---- threshold refresh issued one iteration ago: its DMAs are older than this iteration's
     // tile DMAs, so "at most DPW outstanding" (or 0 if none were issued) means they have landed ----
     if (pend) {
@@ -308,6 +341,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       pend = true;
     }
 
+    RARC_STAMP(5)
     if (buf == 2) {
       buf = 0;
       a0 -= 2 * TILE_BYTES; a1 -= 2 * TILE_BYTES; a2 -= 2 * TILE_BYTES; a3 -= 2 * TILE_BYTES;
@@ -517,6 +551,7 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
   p.seg = (uint32_t)(cap / RARC_MAX_WG);
   p.kprime = (uint32_t)kprime;
   p.nq = (uint32_t)nq;
+  p.dbg = nullptr;
 
   const uint32_t seed_tiles = p.n_tiles < (uint32_t)RARC_SEED_TILES ? p.n_tiles : (uint32_t)RARC_SEED_TILES;
 #define RARC_DISPATCH_D(CALL)                                                                         \

@@ -43,10 +43,18 @@ int main(int argc, char** argv) {
   ScanParams p; p.corpus = corpus; p.q16 = q16; p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32);
   p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
   p.binlo = ws.binlo; p.binscale = ws.binscale; p.bininv = ws.bininv;
+  unsigned long long* dbg; hipMalloc(&dbg, 64 * 8 * 8 * 8); hipMemset(dbg, 0, 64 * 8 * 8 * 8); p.dbg = dbg;
   int grid = 256; uint32_t st = p.n_tiles < 128 ? p.n_tiles : 128;
   const double gb = (double)N * D * 2 / 1e9;
 #define RUN(A) { float us = run<A>(p, grid, 8, NQ, KP, ws, st); printf("ABL=%2d  %8.1f us  %6.2f TB/s\n", A, us, gb / us * 1e-3); }
-  RUN(0) RUN(0) RUN(0) RUN(9) RUN(11) RUN(13)
+  RUN(0) RUN(0)
+  run<64>(p, grid, 2, NQ, KP, ws, st);
+  { std::vector<unsigned long long> h(64 * 8 * 8); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    printf("timeline of workgroup 0 (s_memtime ticks, 100 MHz => x10 ns), relative to wave 0 stamp 0 of each iteration\n");
+    printf("iter wave:  barrier->dmaissued ->mfma_start ->mfma_end ->pruned(A) ->events_done   | next barrier\n");
+    for (int it = 57; it < 62; ++it) for (int w = 0; w < 8; ++w) { const unsigned long long* r = &h[(it * 8 + w) * 8]; unsigned long long b0 = h[(it * 8) * 8];
+      unsigned long long nb = h[((it + 1) * 8 + w) * 8];
+      printf("%3d %d: %6lld %6lld %6lld %6lld %6lld %6lld | %6lld\n", it, w, (long long)(r[0] - b0), (long long)(r[1] - b0), (long long)(r[2] - b0), (long long)(r[3] - b0), (long long)(r[4] - b0), (long long)(r[5] - b0), (long long)(nb - b0)); } }
   run<0>(p, grid, 1, NQ, KP, ws, st);
   std::vector<uint32_t> cnt(256 * 256); hipMemcpy(cnt.data(), ws.cnt2, 256 * 256 * 4, hipMemcpyDeviceToHost);
   uint64_t tot = 0; uint32_t mx = 0; for (auto c : cnt) { tot += c; mx = c > mx ? c : mx; }
