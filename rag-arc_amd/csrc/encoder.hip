@@ -168,63 +168,75 @@ __global__ __launch_bounds__(256) void rarc_add_ln_kernel(const half_t* x_in, co
 
 // ------------------------------------------------------------------------------------------
 // Attention: qkv [n_seq*L][3H] (q | k | v, heads contiguous inside each), ctx [n_seq*L][H].
-// One workgroup per (sequence, head); wave w handles query rows w, w+4, ...; lane l owns output
-// dimension l (head_dim = 64) and, for the scores, key l of the current 64-key tile.
-// Keys/values of a tile sit in LDS; softmax is online (running max / sum per query row).
+// One workgroup per (sequence, head, block of 64 query rows); wave w owns rows w, w+4, ... (16 of
+// them) and keeps their online-softmax state in registers (running max, running sum, and the output
+// accumulator with lane <-> output dimension).  Keys/values stream through LDS in 64-key tiles, each
+// loaded ONCE per workgroup; for the scores lane <-> key of the tile.
 // ------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void rarc_attention_kernel(const half_t* qkv, const int32_t* lens, int L, int H,
-                                                             int n_heads, half_t* ctx) {
-  constexpr int KT = 64;
+                                                             int n_heads, int q_blocks, half_t* ctx) {
+  constexpr int KT = 64, RPW = 16;  // keys per tile, query rows per wave
   __shared__ float ks[KT][DH + 1];
   __shared__ float vs[KT][DH + 1];
-  __shared__ float qs[4][DH];
+  __shared__ float qs[64][DH + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / n_heads, hd = blockIdx.x % n_heads;
+  const int qb = blockIdx.x % q_blocks, bh = blockIdx.x / q_blocks;
+  const int b = bh / n_heads, hd = bh % n_heads;
   const int len = lens[b];
   const size_t base = (size_t)b * L * 3 * H;
   const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;  // 1/sqrt(DH)
-  for (int q0 = 0; q0 < L; q0 += 4) {
-    const int qi = q0 + wave;
-    const bool qlive = qi < L;
-    __syncthreads();
-    if (qlive && lane < DH) qs[wave][lane] = (float)qkv[base + (size_t)qi * 3 * H + hd * DH + lane];
-    float m = -INFINITY, l = 0.f, o = 0.f;
-    for (int k0 = 0; k0 < len; k0 += KT) {
-      __syncthreads();
-      for (int i = threadIdx.x; i < KT * DH; i += 256) {
-        const int kr = i / DH, kc = i % DH;
-        const int kj = k0 + kr;
-        float kv = 0.f, vv = 0.f;
-        if (kj < len) {
-          kv = (float)qkv[base + (size_t)kj * 3 * H + H + hd * DH + kc];
-          vv = (float)qkv[base + (size_t)kj * 3 * H + 2 * H + hd * DH + kc];
-        }
-        ks[kr][kc] = kv;
-        vs[kr][kc] = vv;
-      }
-      __syncthreads();
-      if (qlive) {
-        float s = -INFINITY;
-        if (k0 + lane < len) {
-          float a = 0.f;
-#pragma unroll 16
-          for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qs[wave][d], ks[lane][d], a);
-          s = a * scale;
-        }
-        float tmax = s;
+  const int q0 = qb * 64;
+  for (int i = threadIdx.x; i < 64 * DH; i += 256) {
+    const int r = i / DH, c = i % DH;
+    qs[r][c] = (q0 + r < L) ? (float)qkv[base + (size_t)(q0 + r) * 3 * H + hd * DH + c] : 0.f;
+  }
+  float m[RPW], l[RPW], o[RPW];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
-        const float mnew = fmaxf(m, tmax);
-        const float p = (s == -INFINITY) ? 0.f : __expf(s - mnew);
-        const float corr = (m == -INFINITY) ? 0.f : __expf(m - mnew);
-        l = l * corr + wave_sum(p);
-        o *= corr;
-        for (int j = 0; j < KT; ++j) o = __builtin_fmaf(__shfl(p, j, 64), vs[j][lane & (DH - 1)], o);
-        m = mnew;
+  for (int r = 0; r < RPW; ++r) { m[r] = -INFINITY; l[r] = 0.f; o[r] = 0.f; }
+  for (int k0 = 0; k0 < len; k0 += KT) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < KT * DH; i += 256) {
+      const int kr = i / DH, kc = i % DH;
+      const int kj = k0 + kr;
+      float kv = 0.f, vv = 0.f;
+      if (kj < len) {
+        kv = (float)qkv[base + (size_t)kj * 3 * H + H + hd * DH + kc];
+        vv = (float)qkv[base + (size_t)kj * 3 * H + 2 * H + hd * DH + kc];
       }
+      ks[kr][kc] = kv;
+      vs[kr][kc] = vv;
     }
-    if (qlive && lane < DH) ctx[((size_t)b * L + qi) * H + hd * DH + lane] = (half_t)(l > 0.f ? o / l : 0.f);
+    __syncthreads();
+    const bool klive = k0 + lane < len;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int qr = 4 * r + wave;  // row inside the 64-row block
+      if (q0 + qr >= L) continue;   // wave-uniform
+      float s = -INFINITY;
+      if (klive) {
+        float a = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qs[qr][d], ks[lane][d], a);
+        s = a * scale;
+      }
+      float tmax = s;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off, 64));
+      const float mnew = fmaxf(m[r], tmax);
+      const float p = (s == -INFINITY) ? 0.f : __expf(s - mnew);
+      const float corr = (m[r] == -INFINITY) ? 0.f : __expf(m[r] - mnew);
+      l[r] = l[r] * corr + wave_sum(p);
+      float acc = o[r] * corr;
+      for (int j = 0; j < KT; ++j) acc = __builtin_fmaf(__shfl(p, j, 64), vs[j][lane & (DH - 1)], acc);
+      o[r] = acc;
+      m[r] = mnew;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int qi = q0 + 4 * r + wave;
+    if (qi < L && lane < DH) ctx[((size_t)b * L + qi) * H + hd * DH + lane] = (half_t)(l[r] > 0.f ? o[r] / l[r] : 0.f);
   }
 }
 
@@ -300,12 +312,13 @@ extern "C" int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, 
   RARC_REQUIRE(n_heads > 0 && (hidden == n_heads * 64 || hidden == n_heads * 32) && seq_len > 0 && seq_len <= 512 &&
                    n_seq > 0,
                RARC_E_UNSUPPORTED, "rarc_enc_attention: head_dim must be 32 or 64 and seq_len <= 512");
+  const int q_blocks = (seq_len + 63) / 64;
   if (hidden == n_heads * 64)
-    hipLaunchKernelGGL(rarc_attention_kernel<64>, dim3(n_seq * n_heads), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, (half_t*)d_ctx);
+    hipLaunchKernelGGL(rarc_attention_kernel<64>, dim3(n_seq * n_heads * q_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, (half_t*)d_ctx);
   else
-    hipLaunchKernelGGL(rarc_attention_kernel<32>, dim3(n_seq * n_heads), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, (half_t*)d_ctx);
+    hipLaunchKernelGGL(rarc_attention_kernel<32>, dim3(n_seq * n_heads * q_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, (half_t*)d_ctx);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

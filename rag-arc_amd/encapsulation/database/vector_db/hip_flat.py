@@ -72,7 +72,10 @@ class HipFlatVectorStore(VectorStore):
         texts = list(texts)
         if not texts:
             return []
-        vectors = np.array(self.embedding.embed_documents(texts)).astype(np.float32)
+        if hasattr(self.embedding, "embed_documents_device"):
+            vectors = self.embedding.embed_documents_device(texts)   # stays in HBM: fp32 [n][d] device tensor
+        else:
+            vectors = np.array(self.embedding.embed_documents(texts)).astype(np.float32)
         if ids is None:
             ids = [str(uuid.uuid4()) for _ in texts]
         elif len(ids) != len(texts):

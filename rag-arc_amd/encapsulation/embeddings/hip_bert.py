@@ -124,21 +124,27 @@ class HipBertEmbeddings(Embeddings):
         self.max_length, self.batch_size = min(max_length, encoder.max_pos), batch_size
         self.normalize, self.pad_id = normalize_embeddings, pad_id
 
-    def embed_documents(self, texts: List[str]) -> List[List[float]]:
-        texts = [t.replace("\n", " ") for t in texts]
-        out: List[Optional[List[float]]] = [None] * len(texts)
+    def embed_documents_device(self, texts: List[str]):
+        """Same embeddings as embed_documents, left on the device as one fp32 tensor [n][hidden]
+        (lets a device-resident store ingest them without the python-list round trip of
+        VectorStore_Faiss.py:169-170)."""
+        t = self.encoder.torch
+        texts = [x.replace("\n", " ") for x in texts]
+        out = t.empty((len(texts), self.encoder.hidden), dtype=t.float32, device=self.encoder.device)
         order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))   # longest first, like sentence-transformers
         for s in range(0, len(order), self.batch_size):
             chunk = order[s:s + self.batch_size]
             toks = [list(self.tokenize(texts[i]))[: self.max_length] or [self.pad_id] for i in chunk]
-            L = max(len(t) for t in toks)
+            L = max(len(tk) for tk in toks)
             ids = np.full((len(toks), L), self.pad_id, np.int32)
             for r, tk in enumerate(toks):
                 ids[r, : len(tk)] = tk
-            emb = self.encoder.forward(ids, [len(t) for t in toks], self.normalize).cpu().numpy()
-            for r, i in enumerate(chunk):
-                out[i] = emb[r].tolist()
+            emb = self.encoder.forward(ids, [len(tk) for tk in toks], self.normalize)
+            out[t.as_tensor(chunk, device=out.device)] = emb
         return out
+
+    def embed_documents(self, texts: List[str]) -> List[List[float]]:
+        return self.embed_documents_device(texts).cpu().numpy().tolist() if texts else []
 
     def embed_query(self, text: str) -> List[float]:
         return self.embed_documents([text])[0]

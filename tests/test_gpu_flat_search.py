@@ -139,3 +139,30 @@ def test_async_pipeline_gives_identical_results(hip, oracle):
         ids, sc = h.result()
         assert len(h.repaired) == 16
         assert bool((ids == want_i[lo:lo + 16]).all()) and bool((sc == want_s[lo:lo + 16]).all())
+
+
+def test_l2norm_rows_kernel_matches_oracle(hip, oracle):
+    """rarc_l2norm_rows_f32 == faiss.normalize_L2 restated (VectorStore_Faiss.py:150-154): bit-exact,
+    zero rows untouched, in place and strided."""
+    import torch
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    rng = np.random.default_rng(8)
+    for n, d in ((1, 8), (37, 100), (1000, 384), (300, 768)):
+        x = (rng.standard_normal((n, d)) * rng.uniform(0.01, 50, (n, 1))).astype(np.float32)
+        if n > 5:
+            x[3] = 0.0
+        want = oracle.normalize_L2(x)
+        dx = torch.from_numpy(x).cuda()
+        out = torch.empty_like(dx)
+        B.check(lib.rarc_l2norm_rows_f32(dx.data_ptr(), d, out.data_ptr(), d, n, d, 0))
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        B.check(lib.rarc_l2norm_rows_f32(dx.data_ptr(), d, dx.data_ptr(), d, n, d, 0))          # in place
+        assert np.array_equal(dx.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    wide = torch.from_numpy(rng.standard_normal((50, 200)).astype(np.float32)).cuda()           # ld > d
+    out = torch.zeros((50, 128), dtype=torch.float32, device="cuda")
+    B.check(lib.rarc_l2norm_rows_f32(wide.data_ptr(), 200, out.data_ptr(), 128, 50, 96, 0))
+    assert np.array_equal(out.cpu().numpy()[:, :96].view(np.uint32),
+                          oracle.normalize_L2(wide.cpu().numpy()[:, :96].copy()).view(np.uint32))
+    assert not out.cpu().numpy()[:, 96:].any()
