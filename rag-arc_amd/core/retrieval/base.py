@@ -1,12 +1,14 @@
 """Retriever contract (reference: core/retrieval/base.py:8-100).
 
-A retriever maps a query string to an ordered list of Documents.  Callers use invoke / ainvoke;
-implementations provide _get_relevant_documents (and optionally a native async twin; the default
-one runs the sync method on a throw-away thread pool, so backends may be entered from any thread).
+query string in, ordered Documents out.  `invoke` / `ainvoke` are the entry points; subclasses
+implement `_get_relevant_documents`; unless they also provide a native coroutine, `ainvoke` runs
+the sync method on a fresh ThreadPoolExecutor (so a backend may be entered from any thread —
+the HIP engine takes a lock and selects its device per call for that reason).
 """
 import asyncio
 from abc import ABC, abstractmethod
 from concurrent.futures import ThreadPoolExecutor
+from functools import partial
 from typing import Any, List
 
 from ..utils.data_model import Document
@@ -18,20 +20,22 @@ class BaseRetriever(ABC):
         self.tags = kwargs.get("tags")
         self.metadata = kwargs.get("metadata")
 
+    # -- entry points ------------------------------------------------------------------------
     def invoke(self, input: str, **kwargs: Any) -> List[Document]:
         return self._get_relevant_documents(input, **kwargs)
 
     async def ainvoke(self, input: str, **kwargs: Any) -> List[Document]:
         return await self._aget_relevant_documents(input, **kwargs)
 
+    # -- to implement ------------------------------------------------------------------------
     @abstractmethod
     def _get_relevant_documents(self, query: str, **kwargs: Any) -> List[Document]:
         ...
 
     async def _aget_relevant_documents(self, query: str, **kwargs: Any) -> List[Document]:
-        loop = asyncio.get_event_loop()
+        work = partial(self._get_relevant_documents, query, **kwargs)
         with ThreadPoolExecutor() as pool:
-            return await loop.run_in_executor(pool, lambda: self._get_relevant_documents(query, **kwargs))
+            return await asyncio.get_event_loop().run_in_executor(pool, work)
 
     def get_name(self) -> str:
         return type(self).__name__
