@@ -52,5 +52,4 @@ class HipLogitReranker(RerankerBase):
             z_no.extend(list(a))
             z_yes.extend(list(b))
         _, perm = self.score_order(z_no, z_yes)
-        ordered = [documents[i] for i in perm[0].tolist()]
-        return ordered if k is None else ordered[:k]
+        return self.apply_order(documents, perm[0].tolist(), k)
