@@ -38,7 +38,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234):
+def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="q8"):
     """HBM-resident shard holding global rows [lo, hi) of the synthetic corpus."""
     n = hi - lo
     d_pad = B.padded_dim(dim)
@@ -47,10 +47,8 @@ def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234):
     B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d_pad, dim, lo, n, seed, 0), "rarc_synth_rows_f16")
     if cap > n:
         rows[n:].zero_()
-    idx = FlatIndexF16(dim, metric="cosine", device=dev_index, id_base=lo)
-    idx._rows = rows
-    idx.ntotal = n
-    idx.max_norm = 1.001  # unit rows rounded to fp16
+    idx = FlatIndexF16(dim, metric="cosine", device=dev_index, id_base=lo, scan=scan)
+    idx.add_rows_f16(rows, 1.001, n_valid=n)  # adopts the buffer (no copy); unit rows rounded to fp16
     return idx
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 100 /* 0.1.0 */
+#define RARC_VERSION 200 /* 0.2.0: query block, int8 prefilter scan */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
@@ -39,14 +39,14 @@ extern "C" {
 #define RARC_E_WORKSPACE -3   /* workspace too small / misaligned */
 #define RARC_E_UNSUPPORTED -4 /* shape outside what the kernels were built for */
 
-/* Limits of the fused scan kernel. */
+/* Limits of the fused scan kernels (int8 prefilter: d_pad <= 1024; fp16 scan: d_pad <= 768). */
 #define RARC_MAX_QUERIES 256 /* queries per scan pass (register-resident) */
 #define RARC_MAX_K 1024      /* largest k' the finalize kernel selects */
 #define RARC_DIM_ALIGN 128   /* stored row length is a multiple of this */
 
 /* status bits written per query by rarc_search_f16 (d_status[q]) */
 #define RARC_Q_OK 0u
-#define RARC_Q_UNCERTAIN 1u /* exactness certificate failed: call rarc_repair_f16 */
+#define RARC_Q_UNCERTAIN 1u /* exactness certificate failed (fp16 scan only): call rarc_repair_f16 */
 #define RARC_Q_OVERFLOW 2u  /* candidate buffer overflowed: call rarc_repair_f16 */
 
 int rarc_version(void);
@@ -78,15 +78,35 @@ int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_corpus_f16, in
                     float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream);
 
 /*
- * Query preparation: fp32 queries [nq][ld_in] -> (optionally normalised) fp32
- * copy [RARC_MAX_QUERIES][d_pad] (zero padded), fp16 copy of the same shape for
- * the MFMA scan, and the per-query error bound d_eps[q] used by the exactness
- * certificate.  Replaces `np.array([embedding]).astype(np.float32)` +
- * `_normalize_vectors` at VectorStore_Faiss.py:258-259.
+ * Quantisation metadata of an fp16 corpus shard, needed by the int8-prefilter scan of
+ * rarc_search_f16 (no reference counterpart: it is part of `index.add`,
+ * VectorStore_Faiss.py:199-202, for this backend).  d_qmeta is a caller-owned float array of
+ * rarc_quant_meta_floats(n_rows) elements, ZEROED by the caller before the first call:
+ *   [0]            R = max over stored rows of ||d - d8/s||_2 (the int8 image's residual norm);
+ *                  only ever raised, so it stays valid when rows are appended
+ *   [1..3]         reserved
+ *   [4+2t], [5+2t] scale s_t of the 32-row tile t (127 / max|x| rounded down to fp16) and 1/s_t
+ * The call (re)computes the entries of every tile that intersects rows [first_row, n_rows): after
+ * appending rows, pass the old row count as first_row.  The corpus buffer must hold ceil32(n_rows)
+ * rows (the rows beyond n_rows may hold anything finite).
  */
+size_t rarc_quant_meta_floats(int64_t n_rows);
+int rarc_quant_meta_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, int64_t first_row,
+                        float* d_qmeta, void* stream);
+
+/*
+ * Query preparation: fp32 queries [nq][ld_in] -> the "query block" the search reads:
+ * (optionally L2-normalised) fp32 copy [RARC_MAX_QUERIES][d_pad] (zero padded), fp16 copy (seed
+ * pass / fp16 scan), int8 copy + scale (int8 prefilter), and the per-query error bounds of both
+ * approximate scorers.  Replaces `np.array([embedding]).astype(np.float32)` +
+ * `_normalize_vectors` at VectorStore_Faiss.py:258-259.
+ *   d_qmeta  : the corpus' quantisation metadata (its R enters the int8 error bound); NULL when
+ *              the search will be run without it
+ *   d_qblock : rarc_query_block_bytes(d_pad) bytes, 256-byte aligned, caller-owned
+ */
+size_t rarc_query_block_bytes(int d_pad);
 int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad, int normalize,
-                      float corpus_max_norm, float* d_q32, uint16_t* d_q16, float* d_eps,
-                      void* stream);
+                      float corpus_max_norm, const float* d_qmeta, void* d_qblock, void* stream);
 
 /* Bytes of device scratch rarc_search_f16 / rarc_repair_f16 need (256-byte aligned base).
  * After a search, the uint32 at byte offset RARC_WS_ANYFLAG_OFFSET of the workspace is the OR of
@@ -99,11 +119,16 @@ size_t rarc_search_workspace_bytes(int cand_cap);
  * Replaces faiss.IndexFlatIP.search at VectorStore_Faiss.py:262-263 for
  * nq <= RARC_MAX_QUERIES queries at once (the reference calls it with nq = 1).
  *
- *   d_corpus_f16 : [n_rows][d_pad] fp16, row-major
- *   d_q32, d_q16, d_eps : outputs of rarc_prep_queries
+ *   d_corpus_f16 : [ceil32(n_rows)][d_pad] fp16, row-major
+ *   d_qmeta      : quantisation metadata (rarc_quant_meta_f16).  Non-NULL selects the int8
+ *                  prefilter scan: rows are discarded on int8 MFMA scores under a rigorous error
+ *                  bound, every possible top-k row is rescored canonically (exact by construction).
+ *                  NULL selects the fp16 MFMA scan with k' selection + exactness certificate
+ *                  (d_pad <= 768 only; kept for comparison).
+ *   d_qblock     : output of rarc_prep_queries for these queries (same d_pad, same d_qmeta)
  *   k            : results per query (k <= kprime)
- *   kprime       : candidates kept by the approximate MFMA scan before the
- *                  canonical fp32 rescore (k <= kprime <= RARC_MAX_K)
+ *   kprime       : rows the pruning thresholds are built on (k <= kprime <= RARC_MAX_K); the fp16
+ *                  path also rescored exactly this many
  *   id_base      : added to local row indices (global id of this shard's row 0)
  *   d_out_ids    : [nq][k] int64, -1 where fewer than k rows exist
  *   d_out_scores : [nq][k] fp32 canonical scores, -inf padding
@@ -114,10 +139,9 @@ size_t rarc_search_workspace_bytes(int cand_cap);
  *   bin_lo/bin_hi: score range covered by the pruning histogram
  *                  (cosine: -1, +1; ip: -/+ max|q|*max|d|)
  */
-int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad,
-                    const float* d_q32, const uint16_t* d_q16, const float* d_eps, int nq,
-                    int k, int kprime, int64_t id_base, float bin_lo, float bin_hi,
-                    int64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
+int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_qmeta,
+                    const void* d_qblock, int nq, int k, int kprime, int64_t id_base, float bin_lo,
+                    float bin_hi, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                     void* d_workspace, size_t workspace_bytes, int cand_cap, void* stream);
 
 /*
@@ -127,7 +151,7 @@ int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad,
  * d_found (1 uint32) receives the number of rows that beat the previous k-th
  * entry (0 == the previous answer was already exact).
  */
-int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_q32,
+int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const void* d_qblock,
                     int q, int k, int64_t id_base, int64_t* d_out_ids, float* d_out_scores,
                     uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream);
 

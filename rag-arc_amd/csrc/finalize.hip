@@ -218,6 +218,191 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
 }
 
 // ============================================================================================
+// Finalize for the int8-prefilter scan (scan_q8.hip).  The candidate list of a query holds every row
+// whose int8 score a satisfies a >= thr, with thr <= a_(k) − 2·eps (a_(k): k-th best int8 score,
+// eps: the query's bound on |canonical − a|).  Per query:
+//   1. T1 = histogram edge with >= k candidates at or above it; G1 = {a >= T1}: rescore canonically,
+//      L = k-th best canonical score in G1  (a lower bound of the true k-th best score, no eps in it;
+//      L >= T1 − eps)
+//   2. G2 = {a + eps >= L} \ G1: rescore canonically.  Every other row has canonical <= a + eps < L,
+//      so it is not in the top-k; and a >= L − eps >= T1 − 2·eps >= thr, so G2 is inside the list.
+//   3. exact top-k of G1 ∪ G2 by (canonical score desc, id asc).
+// Nothing here is probabilistic: the only failure mode is running out of buffer space, which sets
+// RARC_Q_OVERFLOW and sends the query to rarc_repair_f16.
+// ============================================================================================
+constexpr int FIN8_THREADS = 1024;
+constexpr int FIN8_SURV = 8192;   // candidates kept after the final-threshold compaction
+constexpr int FIN8_RS = 3072;     // rows rescored canonically (G1 ∪ G2)
+constexpr int FIN8_MAXD = 1024;
+
+struct Fin8Params {
+  const half_t* corpus;
+  const float* q32;   // [256][d]
+  const float* eps8;  // [256]
+  const uint32_t* cnt2;
+  const uint64_t* cand;
+  const uint32_t* hist;
+  const float* binlo;
+  const float* bininv;
+  uint32_t* flags;
+  uint32_t seg;
+  uint32_t n_wg;
+  int d;
+  int k;
+  int64_t id_base;
+  int64_t* out_ids;
+  float* out_scores;
+  uint32_t* status;
+};
+
+__global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fin8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char fsm[];
+  uint64_t* keys = (uint64_t*)fsm;                                     // [FIN8_SURV] approx keys
+  uint64_t* ex = (uint64_t*)(fsm + (size_t)FIN8_SURV * 8);             // [FIN8_RS] canonical keys
+  float* s_q = (float*)(fsm + (size_t)(FIN8_SURV + FIN8_RS) * 8);      // [d]
+  __shared__ uint32_t s_hist[RARC_NB];
+  __shared__ float s_t1, s_L;
+  __shared__ uint32_t s_ns, s_ne, s_over;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const float eps = p.eps8[q];
+
+  for (int i = tid; i < RARC_NB; i += blockDim.x) s_hist[i] = p.hist[(size_t)q * RARC_NB + i];
+  for (int i = tid; i < p.d; i += blockDim.x) s_q[i] = p.q32[(size_t)q * p.d + i];
+  if (tid == 0) { s_ns = 0; s_ne = 0; s_over = 0; s_L = -INFINITY; }
+  __syncthreads();
+  if (tid < 64) {
+    uint32_t above;
+    const int b = rarc_wave_find_from_top(s_hist, RARC_NB, (uint32_t)p.k, &above);
+    if (tid == 0) s_t1 = rarc_bin_threshold(b, p.binlo[q], p.bininv[q]);
+  }
+  __syncthreads();
+  const float t1 = s_t1;
+  const float thr_f = t1 - 2.0002f * eps;  // -inf stays -inf
+
+  // ---- gather the query's segments; keep what clears the final threshold ----
+  for (uint32_t w = tid; w < p.n_wg * 4; w += blockDim.x) {  // 4 threads per segment
+    const uint32_t wg = w >> 2, part = w & 3;
+    const uint32_t c = p.cnt2[(size_t)wg * RARC_MAX_QUERIES + q];
+    const uint32_t n = c < p.seg ? c : p.seg;
+    if (c > p.seg && part == 0) atomicOr(&s_over, 1u);
+    const uint64_t* src = p.cand + ((size_t)q * RARC_MAX_WG + wg) * p.seg;
+    for (uint32_t i = part; i < n; i += 4) {
+      const uint64_t key = src[i];
+      if (rarc_candscore(key) >= thr_f) {
+        const uint32_t pos = atomicAdd(&s_ns, 1u);
+        if (pos < FIN8_SURV) keys[pos] = key;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t ns_all = s_ns;
+  const int ns = ns_all < FIN8_SURV ? (int)ns_all : FIN8_SURV;
+
+  // ---- step 1: G1 = {a >= T1}, canonical scores ----
+  for (int i = tid; i < ns; i += blockDim.x) {
+    const uint64_t key = keys[i];
+    if (rarc_candscore(key) >= t1) {
+      const uint32_t e = atomicAdd(&s_ne, 1u);
+      if (e < FIN8_RS) {
+        const uint32_t row = rarc_candrow(key);
+        ex[e] = rarc_candkey(canon_dot_f16(s_q, p.corpus + (size_t)row * p.d, p.d), row);
+      }
+      keys[i] = 0ull;  // done
+    }
+  }
+  __syncthreads();
+  const uint32_t ne1_all = s_ne;
+  const int ne1 = ne1_all < FIN8_RS ? (int)ne1_all : FIN8_RS;
+  if (ne1 >= p.k) {  // L = k-th best canonical score of G1 (rank by counting; keys are distinct)
+    for (int i = tid; i < ne1; i += blockDim.x) {
+      const uint64_t mine = ex[i];
+      int rank = 0;
+      for (int j = 0; j < ne1; ++j) rank += (ex[j] > mine);
+      if (rank == p.k - 1) s_L = rarc_candscore(mine);
+    }
+  }
+  __syncthreads();
+  const float L = s_L;  // -inf when fewer than k candidates exist: then everything is rescored
+
+  // ---- step 2: G2 = {a + eps >= L} not yet done ----
+  for (int i = tid; i < ns; i += blockDim.x) {
+    const uint64_t key = keys[i];
+    if (key != 0ull && rarc_candscore(key) + eps * 1.0001f >= L) {
+      const uint32_t e = atomicAdd(&s_ne, 1u);
+      if (e < FIN8_RS) {
+        const uint32_t row = rarc_candrow(key);
+        ex[e] = rarc_candkey(canon_dot_f16(s_q, p.corpus + (size_t)row * p.d, p.d), row);
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t ne_all = s_ne;
+  const int ne = ne_all < FIN8_RS ? (int)ne_all : FIN8_RS;
+
+  // ---- step 3: exact order (canonical score desc, id asc) by counting ----
+  const int kk = ne < p.k ? ne : p.k;
+  for (int i = tid; i < p.k; i += blockDim.x) {
+    if (i >= kk) {
+      p.out_ids[(size_t)q * p.k + i] = -1;
+      p.out_scores[(size_t)q * p.k + i] = -INFINITY;
+    }
+  }
+  for (int i = tid; i < ne; i += blockDim.x) {
+    const uint64_t mine = ex[i];
+    if (rarc_candscore(mine) < L) continue;  // cannot rank inside the top k (k rows of G1 are >= L)
+    int rank = 0;
+    for (int j = 0; j < ne; ++j) rank += (ex[j] > mine);
+    if (rank < p.k) {
+      p.out_ids[(size_t)q * p.k + rank] = p.id_base + (int64_t)rarc_candrow(mine);
+      p.out_scores[(size_t)q * p.k + rank] = rarc_candscore(mine);
+    }
+  }
+  if (tid == 0) {
+    uint32_t st = RARC_Q_OK;
+    if (s_over || ns_all > (uint32_t)FIN8_SURV || ne_all > (uint32_t)FIN8_RS) st |= RARC_Q_OVERFLOW;
+    p.status[q] = st;
+    if (st) {
+      atomicOr(&p.flags[1], st);
+      atomicOr(&p.status[RARC_MAX_QUERIES], st);
+    }
+  }
+}
+
+int rarc_finalize_q8_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps8, int nq, int k,
+                            int64_t id_base, const RarcWs& ws, int cap, int n_wg, int64_t* out_ids,
+                            float* out_scores, uint32_t* status, hipStream_t s) {
+  RARC_REQUIRE(d_pad <= FIN8_MAXD, RARC_E_UNSUPPORTED, "rarc_finalize_q8: d_pad %d > %d", d_pad, FIN8_MAXD);
+  Fin8Params p;
+  p.corpus = (const half_t*)corpus;
+  p.q32 = q32;
+  p.eps8 = eps8;
+  p.cnt2 = ws.cnt2;
+  p.cand = ws.cand;
+  p.hist = ws.hist;
+  p.binlo = ws.binlo;
+  p.bininv = ws.bininv;
+  p.flags = ws.flags;
+  p.seg = (uint32_t)(cap / RARC_MAX_WG);
+  p.n_wg = (uint32_t)n_wg;
+  p.d = d_pad;
+  p.k = k;
+  p.id_base = id_base;
+  p.out_ids = out_ids;
+  p.out_scores = out_scores;
+  p.status = status;
+  const size_t lds = (size_t)(FIN8_SURV + FIN8_RS) * 8 + (size_t)FIN8_MAXD * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_finalize_q8_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(rarc_finalize_q8_kernel, dim3(nq), dim3(FIN8_THREADS), lds, s, p);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+// ============================================================================================
 // Exact repair of one query: full canonical scan of the shard; rows that beat the current k-th
 // entry are appended; then the row is re-sorted.  O(n_rows * d) reads — the rare path.
 // ============================================================================================

@@ -86,17 +86,21 @@ __global__ __launch_bounds__(256) void rarc_ingest_kernel(const float* in, int64
 
 // One block per query slot (all RARC_MAX_QUERIES rows are written; padding rows are zero).  Only the
 // squared-norm has a prescribed order (8 lanes run the canonical chains out of LDS); scaling, the
-// fp16 copy and the error-bound sums are order-free and use the whole block.
+// fp16 / int8 copies and the error-bound sums are order-free and use the whole block.
+constexpr int PREP_MAX_D = 2048;
 __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in, int64_t ld_in, int nq, int d,
                                                                 int d_pad, int normalize, float corpus_max_norm,
-                                                                float* q32, half_t* q16, float* eps) {
-  __shared__ float row[768];
+                                                                const float* qmeta, float* q32, half_t* q16,
+                                                                int8_t* q8, float* eps, float* eps8, float* qinv) {
+  __shared__ float row[PREP_MAX_D];
   __shared__ float s_nr;
-  __shared__ double s_dn[4], s_qn[4];
+  __shared__ uint32_t s_amax;
+  __shared__ double s_red[4][4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int r = blockIdx.x;
   const bool live = r < nq;
   for (int m = tid; m < d_pad; m += 256) row[m] = (live && m < d) ? in[(size_t)r * ld_in + m] : 0.f;
+  if (tid == 0) s_amax = 0;
   __syncthreads();
   if (tid < 64) {
     float acc = 0.f;
@@ -110,29 +114,71 @@ __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in,
   const bool scale = live && normalize && nr > 0.f;
   const float inv = scale ? inv_norm(nr) : 1.f;
   double dn = 0.0, qn = 0.0;
+  uint32_t am = 0;
   for (int m = tid; m < d_pad; m += 256) {
     const float v = scale ? row[m] * inv : row[m];
+    row[m] = v;  // each thread rewrites only the elements it owns
     const half_t hv = (half_t)v;
     q32[(size_t)r * d_pad + m] = v;
     q16[(size_t)r * d_pad + m] = hv;
     const double df = (double)v - (double)(float)hv;
     dn += df * df;
     qn += (double)v * (double)v;
+    const uint32_t a = __float_as_uint(v) & 0x7fffffffu;
+    am = a > am ? a : am;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t x = __shfl_xor(am, o, 64);
+    am = x > am ? x : am;
+  }
+  if (lane == 0) atomicMax(&s_amax, am);
+  __syncthreads();
+  // int8 image for the prefilter: q8 = rint(v * s_q), s_q = 127 / max|v|; the scan dequantises with
+  // the fp32 number qi = 1/s_q, so the quantised query is DEFINED as q8 * qi and the residual below
+  // is taken against exactly that
+  const float mx = __uint_as_float(s_amax);
+  float sq = (mx > 0.f && mx < INFINITY) ? 127.f / mx : 1.f;
+  while ((double)mx * (double)sq > 127.4) sq *= 0.9999f;
+  const float qi = 1.0f / sq;
+  double rn = 0.0, hn = 0.0;
+  for (int m = tid; m < d_pad; m += 256) {
+    const float v = row[m];
+    float t = __builtin_rintf(v * sq);
+    t = t > 127.f ? 127.f : (t < -127.f ? -127.f : t);
+    if (q8) q8[(size_t)r * d_pad + m] = (int8_t)(int)t;
+    const double qh = (double)t * (double)qi;
+    const double df = (double)v - qh;
+    rn += df * df;
+    hn += qh * qh;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     dn += __shfl_xor(dn, o, 64);
     qn += __shfl_xor(qn, o, 64);
+    rn += __shfl_xor(rn, o, 64);
+    hn += __shfl_xor(hn, o, 64);
   }
-  if (lane == 0) { s_dn[tid >> 6] = dn; s_qn[tid >> 6] = qn; }
+  if (lane == 0) { s_red[tid >> 6][0] = dn; s_red[tid >> 6][1] = qn; s_red[tid >> 6][2] = rn; s_red[tid >> 6][3] = hn; }
   __syncthreads();
   if (tid == 0) {
-    dn = (s_dn[0] + s_dn[1]) + (s_dn[2] + s_dn[3]);
-    qn = (s_qn[0] + s_qn[1]) + (s_qn[2] + s_qn[3]);
-    // |approx - canonical| <= ||q32 - q16||·||d|| + (fp32 accumulation, both sides) ||q||·||d||
+    dn = (s_red[0][0] + s_red[1][0]) + (s_red[2][0] + s_red[3][0]);
+    qn = (s_red[0][1] + s_red[1][1]) + (s_red[2][1] + s_red[3][1]);
+    rn = (s_red[0][2] + s_red[1][2]) + (s_red[2][2] + s_red[3][2]);
+    hn = (s_red[0][3] + s_red[1][3]) + (s_red[2][3] + s_red[3][3]);
+    // fp16 MFMA scores (seed pass): |approx - canonical| <= ||q32 - q16||·||d|| + fp32 accumulation
     const double acc_err = 8.0 * (double)d_pad * 5.9604644775390625e-08;  // 8·d·2^-24
     const double e = (sqrt(dn) + acc_err * sqrt(qn)) * (double)corpus_max_norm * 1.01 + 1e-30;
     eps[r] = live ? (float)e * 1.0001f : 0.f;
+    // int8 prefilter (quant.hip): |<q,d> - approx| <= ||q^||·R + ||q - q^||·max||d||, plus the fp32
+    // rounding of the canonical score and of the dequantisation
+    if (eps8 && qinv) {
+      const double R = qmeta ? (double)qmeta[0] : 0.0;
+      const double e8 = (sqrt(hn) * R * 1.0001 + sqrt(rn) * (double)corpus_max_norm) * 1.0001 +
+                        (acc_err + 1e-6) * sqrt(qn) * (double)corpus_max_norm + 1e-30;
+      eps8[r] = live ? (float)e8 * 1.0001f : 0.f;
+      qinv[r] = qi;
+    }
   }
 }
 
@@ -202,14 +248,17 @@ extern "C" int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_cor
   return RARC_OK;
 }
 
+extern "C" size_t rarc_query_block_bytes(int d_pad) { return d_pad > 0 ? rarc_qb_bytes(d_pad) : 0; }
+
 extern "C" int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad, int normalize,
-                                 float corpus_max_norm, float* d_q32, uint16_t* d_q16, float* d_eps,
-                                 void* stream) {
-  RARC_REQUIRE(d_in && d_q32 && d_q16 && d_eps && d > 0 && d_pad >= d && d_pad % 8 == 0 && d_pad <= 768 &&
-                   nq >= 0 && nq <= RARC_MAX_QUERIES,
+                                 float corpus_max_norm, const float* d_qmeta, void* d_qblock, void* stream) {
+  RARC_REQUIRE(d_in && d_qblock && ((uintptr_t)d_qblock % 256) == 0 && d > 0 && d_pad >= d &&
+                   d_pad % RARC_DIM_ALIGN == 0 && d_pad <= PREP_MAX_D && nq >= 0 && nq <= RARC_MAX_QUERIES,
                RARC_E_INVALID, "rarc_prep_queries: bad arguments (nq=%d d=%d d_pad=%d)", nq, d, d_pad);
+  const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipLaunchKernelGGL(rarc_prep_queries_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, (hipStream_t)stream,
-                     d_in, ld_in, nq, d, d_pad, normalize, corpus_max_norm, d_q32, (half_t*)d_q16, d_eps);
+                     d_in, ld_in, nq, d, d_pad, normalize, corpus_max_norm, d_qmeta, qb.q32, (half_t*)qb.q16,
+                     qb.q8, qb.eps16, qb.eps8, qb.qinv);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

@@ -1,0 +1,120 @@
+// quant.hip — quantisation metadata for the int8 prefilter of the flat scan.
+//
+// The scan (scan_q8.hip) never trusts int8 scores: it uses them to DISCARD rows, and a row may only
+// be discarded when   approx + eps < (a lower bound of the k-th best canonical score),   where
+//   approx = <q8, d8> / (s_q * s_t)             (exact integer dot product, int8 MFMA)
+//   |<q, d> - approx| <= ||q8/s_q|| * R + ||q - q8/s_q|| * max||d||        (Cauchy-Schwarz)
+//   R = max over stored rows of ||d - d8/s_t||_2.
+// This file computes s_t (one scale per 32-row tile: 127 / max|x| rounded DOWN to fp16, so that
+// |x * s_t| <= 127) and R, with the very same rarc_quant8_chunk() the scan uses.  Runs once per
+// ingest (index.add, VectorStore_Faiss.py:199-202): one extra streaming pass over the new rows.
+#include "rarc_common.h"
+
+// largest fp16 value <= v (v > 0, finite)
+__device__ __forceinline__ half_t half_round_down(float v) {
+  half_t h = (half_t)v;  // RNE
+  if ((float)h > v) {
+    uint16_t b = __builtin_bit_cast(uint16_t, h);
+    b -= 1;  // positive, non-zero: previous representable value
+    h = __builtin_bit_cast(half_t, b);
+  }
+  return h;
+}
+
+// one workgroup (256 threads) per tile of 32 rows x d_pad fp16 (contiguous 64*d_pad bytes)
+__global__ __launch_bounds__(256) void rarc_quant_meta_kernel(const uint4* __restrict__ corpus, int d_pad,
+                                                              uint32_t first_tile, uint32_t n_tiles,
+                                                              float* __restrict__ meta) {
+  __shared__ uint32_t s_max;
+  __shared__ uint32_t s_res[32];
+  const int tid = threadIdx.x;
+  const int cpr = d_pad / 8;       // chunks per row
+  const int nchunk = 32 * cpr;     // chunks per tile
+  for (uint32_t t = first_tile + blockIdx.x; t < first_tile + n_tiles; t += gridDim.x) {
+    if (tid == 0) s_max = 0;
+    if (tid < 32) s_res[tid] = 0;
+    __syncthreads();
+    const uint4* src = corpus + (size_t)t * nchunk;
+    uint32_t m = 0;
+    for (int c = tid; c < nchunk; c += 256) {
+      const uint4 v = src[c];
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = w[i] & 0x7fffu, hi = (w[i] >> 16) & 0x7fffu;  // |x| bit patterns: monotone
+        m = lo > m ? lo : m;
+        m = hi > m ? hi : m;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t x = __shfl_xor(m, o, 64);
+      m = x > m ? x : m;
+    }
+    if ((tid & 63) == 0) atomicMax(&s_max, m);
+    __syncthreads();
+    uint32_t mb = s_max;
+    if (mb > 0x7bffu) mb = 0x7bffu;  // inf/nan rows: undefined results, but no undefined behaviour
+    const float mx = (float)__builtin_bit_cast(half_t, (uint16_t)mb);
+    half_t s = (half_t)1.f;
+    if (mx > 0.f) {
+      float sv = 127.f / mx;
+      if (sv > 32768.f) sv = 32768.f;
+      s = half_round_down(sv);
+      // 127/mx was rounded to fp32 first: make sure mx * s <= 127 holds exactly
+      while ((double)mx * (double)(float)s > 127.0) s = half_round_down((float)s * 0.999f);
+    }
+    const float sf = (float)s;
+    // residuals in quantised units u = x*s - d8 (|u| <= 0.5, exact in fp32), accumulated per row as
+    // integers (order free): ui = ceil(|u| * 1024) <= 512, sum over a row < 2^32 for d_pad <= 16384
+    for (int c = tid; c < nchunk; c += 256) {
+      const uint4 v = src[c];
+      const uint2 q = rarc_quant8_chunk(v, s);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      const uint32_t qb[2] = {q.x, q.y};
+      uint32_t acc = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const uint16_t hb = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+        const float x = (float)__builtin_bit_cast(half_t, hb);
+        const int d8 = (int)(int8_t)(qb[e >> 2] >> (8 * (e & 3)));
+        const float u = __builtin_fabsf(__builtin_fmaf(x, sf, -(float)d8));
+        const uint32_t ui = (uint32_t)__builtin_ceilf(u * 1024.f);
+        acc += ui * ui;
+      }
+      atomicAdd(&s_res[c / cpr], acc);
+    }
+    __syncthreads();
+    if (tid < 32) {
+      // ||d - d8/s|| <= sqrt(sum ui^2) / (1024 * s); rounded up
+      const float r = (float)(sqrt((double)s_res[tid]) / (1024.0 * (double)sf) * 1.000001);
+      atomicMax((uint32_t*)meta, __float_as_uint(r));  // non-negative floats order like their bits
+    }
+    if (tid == 0) {
+      meta[RARC_QMETA_HDR + 2 * (size_t)t] = sf;
+      meta[RARC_QMETA_HDR + 2 * (size_t)t + 1] = 1.0f / sf;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t rarc_quant_meta_floats(int64_t n_rows) {
+  return (size_t)RARC_QMETA_HDR + 2 * (size_t)((n_rows + 31) / 32);
+}
+
+extern "C" int rarc_quant_meta_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, int64_t first_row,
+                                   float* d_qmeta, void* stream) {
+  RARC_REQUIRE(d_qmeta && (d_corpus_f16 || n_rows == 0), RARC_E_INVALID, "rarc_quant_meta_f16: null pointer");
+  RARC_REQUIRE(d_pad > 0 && d_pad % RARC_DIM_ALIGN == 0 && n_rows >= 0 && first_row >= 0 && first_row <= n_rows &&
+                   n_rows < (int64_t)0xffffffe0ll,
+               RARC_E_INVALID, "rarc_quant_meta_f16: bad arguments (n_rows=%lld first_row=%lld d_pad=%d)",
+               (long long)n_rows, (long long)first_row, d_pad);
+  const uint32_t t0 = (uint32_t)(first_row / 32), t1 = (uint32_t)((n_rows + 31) / 32);
+  if (t1 <= t0) return RARC_OK;
+  const uint32_t nt = t1 - t0;
+  const int grid = nt < 8192u ? (int)nt : 8192;
+  hipLaunchKernelGGL(rarc_quant_meta_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)d_corpus_f16, d_pad, t0, nt, d_qmeta);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

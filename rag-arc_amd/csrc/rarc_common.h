@@ -21,12 +21,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // flags    : uint32  [64]
 // hist     : uint32  [256][NB]     per-query score histogram of appended candidates
 // cnt2     : uint32  [256 wg][256] candidates appended per (workgroup, query)
-// seed     : float   [256][4096]   scores of the strided seed sample (initial thresholds)
+// seed     : float   [256][65536]  scores of the strided seed sample (initial thresholds)
 // cand     : uint64  [256][cap]    query q, workgroup w owns slots [w*seg, (w+1)*seg), seg = cap/256;
 //                                  key = ordkey(score)<<32 | ~local_row
 constexpr int RARC_NB = 256;          // histogram bins per query
 constexpr int RARC_MAX_WG = 256;      // scan workgroups (one per CU); owners of candidate segments
-constexpr int RARC_SEED_TILES = 128;  // strided sample tiles scored before the scan (4096 rows)
+constexpr int RARC_SEED_TILES = 128;  // strided sample tiles scored before the fp16 scan (4096 rows)
+constexpr int RARC_SEED_MAX_TILES = 2048;  // ... before the int8 scan: n_tiles/128 clamped to [128, 2048]
 constexpr size_t RARC_WS_THR = 0;
 constexpr size_t RARC_WS_BINLO = 1024;
 constexpr size_t RARC_WS_BINSCALE = 2048;
@@ -37,7 +38,7 @@ static_assert(RARC_WS_FLAGS + 4 == RARC_WS_ANYFLAG_OFFSET, "include/rarc.h out o
 constexpr size_t RARC_WS_HIST = 8192;
 constexpr size_t RARC_WS_CNT2 = RARC_WS_HIST + (size_t)RARC_MAX_QUERIES * RARC_NB * 4;
 constexpr size_t RARC_WS_SEED = RARC_WS_CNT2 + (size_t)RARC_MAX_WG * RARC_MAX_QUERIES * 4;
-constexpr size_t RARC_WS_CAND = RARC_WS_SEED + (size_t)RARC_MAX_QUERIES * RARC_SEED_TILES * 32 * 4;
+constexpr size_t RARC_WS_CAND = RARC_WS_SEED + (size_t)RARC_MAX_QUERIES * RARC_SEED_MAX_TILES * 32 * 4;
 
 struct RarcWs {
   float* thr;
@@ -65,6 +66,32 @@ static inline RarcWs rarc_ws_carve(void* base) {
   w.seed = (float*)(b + RARC_WS_SEED);
   w.cand = (uint64_t*)(b + RARC_WS_CAND);
   return w;
+}
+
+
+// ---- query block (written by rarc_prep_queries, read by search / repair) ------------------------
+// q32 f32 [256][d_pad] | q16 f16 [256][d_pad] | q8 i8 [256][d_pad] | eps16 f32 [256] | eps8 f32 [256]
+// | qinv f32 [256].  d_pad is a multiple of 128, so every part starts 256-byte aligned.
+struct RarcQb {
+  float* q32;
+  uint16_t* q16;
+  int8_t* q8;
+  float* eps16;
+  float* eps8;
+  float* qinv;
+};
+static inline size_t rarc_qb_bytes(int d_pad) { return (size_t)RARC_MAX_QUERIES * (size_t)d_pad * 7 + 3 * 1024; }
+static inline RarcQb rarc_qb_carve(const void* base, int d_pad) {
+  char* b = (char*)base;
+  const size_t n = (size_t)RARC_MAX_QUERIES * (size_t)d_pad;
+  RarcQb q;
+  q.q32 = (float*)b;
+  q.q16 = (uint16_t*)(b + n * 4);
+  q.q8 = (int8_t*)(b + n * 6);
+  q.eps16 = (float*)(b + n * 7);
+  q.eps8 = (float*)(b + n * 7 + 1024);
+  q.qinv = (float*)(b + n * 7 + 2048);
+  return q;
 }
 
 // Threshold implied by a histogram: highest bin b whose suffix count reaches k'.  Every row whose
@@ -189,6 +216,35 @@ __host__ __device__ static inline float rarc_candscore(uint64_t key) {
 __host__ __device__ static inline float rarc_canon_tree(const float a[8]) {
   return ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
 }
+
+
+// ---- int8 prefilter: shared quantisation of an fp16 chunk ------------------------------------
+// The q8 scan scores int8 images of the fp16 rows.  One 16-byte chunk (8 fp16 values of one row)
+// becomes 8 int8 values d8 = RNE(x * s) with the tile's scale s (an fp16 number, x*s <= 127 by
+// construction): fp16 fma(x, s, 1536) lands in [1409, 1663] where the fp16 ulp is 1, so the low byte
+// of the result's bit pattern is the two's-complement int8 (1536 = 6*256 leaves the low byte alone).
+// rarc_quant_meta_f16 (which derives the error bound) and the scan kernel both call this function,
+// so they agree on every byte.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+#ifdef __HIPCC__
+__device__ __forceinline__ uint2 rarc_quant8_chunk(const uint4 v, const half_t s) {
+  const half2_t s2 = {s, s}, c2 = {(half_t)1536.f, (half_t)1536.f};
+  const half2_t y0 = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, v.x), s2, c2);
+  const half2_t y1 = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, v.y), s2, c2);
+  const half2_t y2 = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, v.z), s2, c2);
+  const half2_t y3 = __builtin_elementwise_fma(__builtin_bit_cast(half2_t, v.w), s2, c2);
+  uint2 o;
+  o.x = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, y1), __builtin_bit_cast(uint32_t, y0), 0x06040200u);
+  o.y = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, y3), __builtin_bit_cast(uint32_t, y2), 0x06040200u);
+  return o;
+}
+#endif
+// quantisation metadata (float array owned by the caller, see include/rarc.h):
+//   [0] max over rows of ||d - d8/s||_2 (as float bits, raised by atomicMax)   [1..3] reserved
+//   [4 + 2t], [5 + 2t] : scale s_t of 32-row tile t (an fp16-representable float) and 1/s_t
+constexpr int RARC_QMETA_HDR = 4;
 
 // ---- error plumbing (host) ------------------------------------------------------------------
 void rarc_set_error(const char* fmt, ...);

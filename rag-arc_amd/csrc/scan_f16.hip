@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const half_t* __restrict
   }
   __syncthreads();
   if (wave == 0) {
-    float* out = seed + (size_t)qidx * (RARC_SEED_TILES * 32) + ti * 32;
+    float* out = seed + (size_t)qidx * (RARC_SEED_MAX_TILES * 32) + ti * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float v = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
@@ -408,39 +408,40 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const half_t* __restrict
 }
 
 // One workgroup per query slot.  thr[q] = (a hair below) the k'-th largest seed score — a lower
-// bound of the k'-th best score of the whole shard: one 11-bit radix pass on the order-preserving
-// keys finds the bin holding it, the few keys of that bin are ranked directly.  Also sets the
-// query's histogram window [lo, lo + 4·(max − lo)] and clears its histogram.
+// bound of the k'-th best score of the whole shard.  Three sweeps over the query's seed scores (up to
+// 65536 floats, L2 resident): min/max, a 2048-bin histogram of the order-preserving keys over
+// [min, max], then the few keys of the bin holding the k'-th largest are ranked directly.  Also sets
+// the query's histogram window and clears its histogram.
 __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, uint32_t seed_rows, uint32_t kprime,
                                                             uint32_t nq, float bin_lo_dflt, float bin_hi_dflt,
+                                                            const float* sub_a, const float* sub_b,
                                                             uint32_t* thr, float* binlo, float* binscale,
                                                             float* bininv, uint32_t* flags, uint32_t* hist) {
-  constexpr int PER = RARC_SEED_TILES * 32 / 256;  // 16 keys per thread
+  constexpr int LIST = 4096;
   __shared__ uint32_t s_hist[2048];
-  __shared__ uint32_t s_list[RARC_SEED_TILES * 32];
+  __shared__ uint32_t s_list[LIST];
   __shared__ uint32_t s_bin, s_need, s_max, s_min, s_nlist, s_key;
   const uint32_t q = blockIdx.x, tid = threadIdx.x;
   for (uint32_t i = tid; i < RARC_NB; i += blockDim.x) hist[q * RARC_NB + i] = 0;
   if (q == 0 && tid < 64) flags[tid] = 0;
   float t = -INFINITY, mx = -INFINITY;
   if (q < nq && seed_rows > 0) {  // block-uniform
-    uint32_t key[PER];
-    uint32_t lmax = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const uint32_t j = tid + i * 256;
-      float v = (j < seed_rows) ? seed[(size_t)q * (RARC_SEED_TILES * 32) + j] : -INFINITY;
+    const float* sq = seed + (size_t)q * (RARC_SEED_MAX_TILES * 32);
+    auto key_at = [&](uint32_t j) {
+      float v = sq[j];
       if (!(v == v)) v = -INFINITY;  // NaN never becomes a threshold
-      key[i] = rarc_ordkey(v);
-      lmax = key[i] > lmax ? key[i] : lmax;
-    }
+      return rarc_ordkey(v);
+    };
     for (uint32_t i = tid; i < 2048; i += 256) s_hist[i] = 0;
     if (tid == 0) { s_max = 0; s_min = 0xffffffffu; s_nlist = 0; s_key = 0; s_bin = 0; s_need = kprime; }
     __syncthreads();
     {  // block min / max of the keys: wave reduction first, one LDS atomic per wave
-      uint32_t lmin = 0xffffffffu;
-#pragma unroll
-      for (int i = 0; i < PER; ++i) lmin = (key[i] > 0x007fffffu && key[i] < lmin) ? key[i] : lmin;  // skip -inf padding
+      uint32_t lmax = 0, lmin = 0xffffffffu;
+      for (uint32_t j = tid; j < seed_rows; j += 256) {
+        const uint32_t k = key_at(j);
+        lmax = k > lmax ? k : lmax;
+        lmin = (k > 0x007fffffu && k < lmin) ? k : lmin;  // skip -inf padding
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         const uint32_t a = __shfl_xor(lmax, o, 64), b2 = __shfl_xor(lmin, o, 64);
@@ -454,13 +455,11 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
     // atomics do not pile up on a few addresses the way the keys' top bits would
     const uint32_t kmin = s_min < s_max ? s_min : s_max, krange = s_max - kmin;
     const float kscale = krange ? 2047.f / (float)krange : 0.f;
-    uint32_t kb[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      uint32_t b2 = key[i] > kmin ? (uint32_t)((float)(key[i] - kmin) * kscale) : 0u;  // monotone in key
-      kb[i] = b2 > 2047u ? 2047u : b2;
-      atomicAdd(&s_hist[kb[i]], 1u);
-    }
+    auto bin_of_key = [&](uint32_t k) {
+      uint32_t b2 = k > kmin ? (uint32_t)((float)(k - kmin) * kscale) : 0u;  // monotone in key
+      return b2 > 2047u ? 2047u : b2;
+    };
+    for (uint32_t j = tid; j < seed_rows; j += 256) atomicAdd(&s_hist[bin_of_key(key_at(j))], 1u);
     __syncthreads();
     if (tid < 64) {  // wave 0: bin holding the k'-th largest, count above it
       uint32_t above = 0;
@@ -469,16 +468,28 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
     }
     __syncthreads();
     const uint32_t bin = s_bin, need = s_need;
-#pragma unroll
-    for (int i = 0; i < PER; ++i)
-      if (kb[i] == bin) s_list[atomicAdd(&s_nlist, 1u)] = key[i];
+    for (uint32_t j = tid; j < seed_rows; j += 256) {
+      const uint32_t k = key_at(j);
+      if (bin_of_key(k) == bin) {
+        const uint32_t pos = atomicAdd(&s_nlist, 1u);
+        if (pos < (uint32_t)LIST) s_list[pos] = k;
+      }
+    }
     __syncthreads();
-    const uint32_t nl = s_nlist;
-    for (uint32_t i = tid; i < nl; i += 256) {  // the need-th largest of the bin (ties share a value)
-      const uint32_t mine = s_list[i];
-      uint32_t gt = 0, ge = 0;
-      for (uint32_t j = 0; j < nl; ++j) { gt += s_list[j] > mine; ge += s_list[j] >= mine; }
-      if (gt < need && need <= ge) s_key = mine;
+    const uint32_t nl_all = s_nlist, nl = nl_all < (uint32_t)LIST ? nl_all : (uint32_t)LIST;
+    if (nl_all <= (uint32_t)LIST) {
+      for (uint32_t i = tid; i < nl; i += 256) {  // the need-th largest of the bin (ties share a value)
+        const uint32_t mine = s_list[i];
+        uint32_t gt = 0, ge = 0;
+        for (uint32_t j = 0; j < nl; ++j) { gt += s_list[j] > mine; ge += s_list[j] >= mine; }
+        if (gt < need && need <= ge) s_key = mine;
+      }
+    } else if (tid == 0) {
+      // (a bin too crowded to rank — near-identical scores: its lower edge is still a valid bound)
+      // (minus a margin covering the fp32 rounding of the bin map: 24-bit floats of 32-bit key offsets)
+      const uint32_t edge = (uint32_t)((float)bin / (kscale > 0.f ? kscale : 1.f));
+      const uint32_t margin = (krange >> 10) + 1024u;
+      s_key = edge > margin ? kmin + (edge - margin) : kmin;
     }
     __syncthreads();
     if (kprime <= seed_rows) {
@@ -490,12 +501,20 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
   if (tid == 0) {
     float lo = bin_lo_dflt, hi = bin_hi_dflt;
     if (q >= nq) t = INFINITY;  // padding queries never pass
-    else if (t > -INFINITY && mx > t) {
-      float w = 4.f * (mx - t);
-      const float wmin = 1e-3f * fabsf(t) + 1e-20f;  // keeps fp32 rounding of the bin map below one bin
-      if (w < wmin) w = wmin;
-      lo = t;
-      hi = t + w;
+    else if (t > -INFINITY) {
+      // int8 prefilter: the threshold lives in approx-score space, below the sample statistic by the
+      // error bounds of both scorers (scan_q8.hip); the histogram window starts there
+      float ts = t;
+      if (sub_a) ts -= sub_a[q] * 1.0001f;
+      if (sub_b) ts -= sub_b[q] * 1.0001f;
+      if (mx > t) {
+        float w = 4.f * (mx - t);
+        const float wmin = 1e-3f * fabsf(t) + 1e-20f;  // keeps fp32 rounding of the bin map below one bin
+        if (w < wmin) w = wmin;
+        lo = ts;
+        hi = t + w;
+      }
+      t = ts;
     }
     thr[q] = __float_as_uint(t);
     binlo[q] = lo;
@@ -529,6 +548,42 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
   hipLaunchKernelGGL(rarc_scan_f16_kernel<D>, dim3(grid), dim3(SCAN_WAVES * 64), lds, s, p);
   RARC_HIP_CHECK(hipGetLastError());
   if (prof) RARC_HIP_CHECK(hipEventRecord(e1, s));
+  return RARC_OK;
+}
+
+// Seed pass alone (used by the int8 scan, scan_q8.hip): thr[q] = sample statistic − sub_a[q] − sub_b[q].
+int rarc_seed_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq, int kprime,
+                     float bin_lo, float bin_hi, const float* sub_a, const float* sub_b, const RarcWs& ws,
+                     hipStream_t s) {
+  ScanParams p;
+  p.corpus = (const half_t*)corpus;
+  p.q16 = (const half_t*)q16;
+  p.n_rows = (uint32_t)n_rows;
+  p.n_tiles = (uint32_t)((n_rows + 31) / 32);
+  // sample size grows with the shard (1/128 of the tiles, at least 4096 and at most 65536 rows): the
+  // scan starts from the k'-th best of the sample, and with the int8 error margin taken off it a
+  // 4096-row sample would let several per cent of a large shard through before feedback takes over
+  uint32_t seed_tiles = p.n_tiles / 128;
+  if (seed_tiles < (uint32_t)RARC_SEED_TILES) seed_tiles = (uint32_t)RARC_SEED_TILES;
+  if (seed_tiles > (uint32_t)RARC_SEED_MAX_TILES) seed_tiles = (uint32_t)RARC_SEED_MAX_TILES;
+  if (seed_tiles > p.n_tiles) seed_tiles = p.n_tiles;
+  int rc = RARC_OK;
+  if (seed_tiles > 0) {
+    switch (d_pad) {
+#define SEED_CASE(DD) case DD: rc = launch_seed<DD>(p, seed_tiles, ws.seed, s); break;
+      SEED_CASE(128) SEED_CASE(256) SEED_CASE(384) SEED_CASE(512) SEED_CASE(640) SEED_CASE(768) SEED_CASE(896)
+      SEED_CASE(1024)
+#undef SEED_CASE
+      default:
+        rarc_set_error("rarc_seed: padded dim %d unsupported (multiple of 128, <= 1024)", d_pad);
+        rc = RARC_E_UNSUPPORTED;
+    }
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, s, ws.seed, seed_tiles * 32,
+                     (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, sub_a, sub_b, (uint32_t*)ws.thr, ws.binlo,
+                     ws.binscale, ws.bininv, ws.flags, ws.hist);
+  RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
 
@@ -573,8 +628,8 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
     if (rc) return rc;
   }
   hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, s, ws.seed, seed_tiles * 32,
-                     (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, (uint32_t*)ws.thr, ws.binlo, ws.binscale,
-                     ws.bininv, ws.flags, ws.hist);
+                     (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, (const float*)nullptr, (const float*)nullptr,
+                     (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist);
   RARC_HIP_CHECK(hipGetLastError());
 
   int dev = 0, cus = 256;

@@ -34,10 +34,13 @@ SIGNATURES = {
     "rarc_padded_dim": (c_int, [c_int]),
     "rarc_l2norm_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "rarc_ingest_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rarc_quant_meta_floats": (c_size_t, [c_int64]),
+    "rarc_quant_meta_f16": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "rarc_query_block_bytes": (c_size_t, [c_int]),
     "rarc_prep_queries": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
-                                  c_void_p, c_void_p]),
+                                  c_void_p]),
     "rarc_search_workspace_bytes": (c_size_t, [c_int]),
-    "rarc_search_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+    "rarc_search_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                 c_int, c_void_p]),
     "rarc_repair_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,

@@ -34,7 +34,7 @@ class FlatIndexF16:
     """
 
     def __init__(self, dim: int, metric: str = "cosine", device: int = 0, capacity: int = 0,
-                 id_base: int = 0, cand_cap: int = 16384):
+                 id_base: int = 0, cand_cap: int = 65536, scan: str = "q8"):
         if metric not in ("cosine", "ip"):
             raise ValueError(f"unsupported metric: {metric}")
         if dim <= 0:
@@ -43,8 +43,12 @@ class FlatIndexF16:
         self.lib = B.load_library()
         self.dim = int(dim)
         self.d_pad = B.padded_dim(self.dim)
-        if self.d_pad > 768:
-            raise B.RarcError(f"dim {dim} pads to {self.d_pad} > 768: not supported by the fp16 scan kernel yet")
+        if scan not in ("q8", "mfma16"):
+            raise ValueError(f"unknown scan mode: {scan}")
+        limit = 1024 if scan == "q8" else 768
+        if self.d_pad > limit:
+            raise B.RarcError(f"dim {dim} pads to {self.d_pad} > {limit}: not supported by the {scan} scan kernel")
+        self.scan = scan  # "q8": int8 prefilter (default); "mfma16": fp16 MFMA scan + certificate
         self.metric = metric
         self.device = self.torch.device("cuda", device)
         self.id_base = int(id_base)
@@ -52,6 +56,7 @@ class FlatIndexF16:
         self.ntotal = 0
         self.max_norm = 0.0
         self._rows = None  # torch.float16 [capacity][d_pad]
+        self._qmeta = None  # torch.float32 [4 + 2*capacity/32]: quantisation metadata (include/rarc.h)
         self._lock = threading.Lock()  # callers may be pool threads (core/retrieval/base.py:92-96)
         self._ws = None
         self._qbuf = None
@@ -68,6 +73,23 @@ class FlatIndexF16:
         if self._rows is not None and self.ntotal:
             new[: self.ntotal].copy_(self._rows[: self.ntotal])
         self._rows = new
+        self._fit_qmeta()
+
+    def _fit_qmeta(self) -> None:
+        """Size the quantisation metadata for the current row buffer (keeps what is already there)."""
+        t = self.torch
+        need = int(self.lib.rarc_quant_meta_floats(self._rows.shape[0]))
+        if self._qmeta is None or self._qmeta.numel() < need:
+            new = t.zeros(need, dtype=t.float32, device=self.device)
+            if self._qmeta is not None:
+                new[: self._qmeta.numel()].copy_(self._qmeta)
+            self._qmeta = new
+
+    def _requant(self, first_row: int) -> None:
+        """(Re)compute tile scales + residual bound for the tiles touched by rows [first_row, ntotal)."""
+        self._fit_qmeta()
+        B.check(self.lib.rarc_quant_meta_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, int(first_row),
+                                             self._qmeta.data_ptr(), self._stream()), "rarc_quant_meta_f16")
 
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
@@ -79,13 +101,19 @@ class FlatIndexF16:
             self._ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
             mq = B.MAX_QUERIES
             self._qbuf = dict(
-                q32=t.empty((mq, self.d_pad), dtype=t.float32, device=self.device),
-                q16=t.empty((mq, self.d_pad), dtype=t.float16, device=self.device),
-                eps=t.empty(mq, dtype=t.float32, device=self.device),
+                qblock=t.empty(int(self.lib.rarc_query_block_bytes(self.d_pad)), dtype=t.uint8, device=self.device),
                 status=t.zeros(mq + 1, dtype=t.int32, device=self.device),
                 found=t.empty(1, dtype=t.int32, device=self.device),
             )
         return self._ws
+
+    def _prep(self, q) -> None:
+        """rarc_prep_queries into the shared query block (caller holds the lock)."""
+        norm = 1 if self.metric == "cosine" else 0
+        qm = self._qmeta.data_ptr() if (self.scan == "q8" and self._qmeta is not None) else 0
+        B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
+                                           max(self.max_norm, 1.0) if norm else self.max_norm, qm,
+                                           self._qbuf["qblock"].data_ptr(), self._stream()), "rarc_prep_queries")
 
     @property
     def rows(self):
@@ -112,21 +140,31 @@ class FlatIndexF16:
                                              1 if self.metric == "cosine" else 0, self._stream()),
                     "rarc_ingest_f16")
             self.max_norm = max(self.max_norm, float(norm2.max().sqrt().item()))
+            old = self.ntotal
             self.ntotal += n
+            self._requant(old)
 
-    def add_rows_f16(self, rows_f16, max_norm: float) -> None:
-        """Adopt rows that are already in storage format ([n][d_pad] fp16 on this device)."""
+    def add_rows_f16(self, rows_f16, max_norm: float, n_valid: Optional[int] = None) -> None:
+        """Adopt rows that are already in storage format ([n][d_pad] fp16 on this device).  A buffer
+        whose length is a multiple of 32 is adopted without a copy when the index is empty;
+        `n_valid` (default: all) says how many of its rows are real."""
         t = self.torch
-        with self._lock:
+        with self._lock, t.cuda.device(self.device):
             if rows_f16.dtype != t.float16 or rows_f16.shape[1] != self.d_pad:
                 raise ValueError("rows must be float16 [n][d_pad]")
+            n = rows_f16.shape[0] if n_valid is None else int(n_valid)
+            if not (0 <= n <= rows_f16.shape[0]):
+                raise ValueError("n_valid out of range")
+            old = self.ntotal
             if self.ntotal == 0 and rows_f16.shape[0] % _ROW_ALIGN == 0 and rows_f16.is_contiguous():
                 self._rows = rows_f16
+                self._qmeta = None
             else:
-                self.reserve(self.ntotal + rows_f16.shape[0])
-                self._rows[self.ntotal: self.ntotal + rows_f16.shape[0]].copy_(rows_f16)
-            self.ntotal += rows_f16.shape[0]
+                self.reserve(self.ntotal + n)
+                self._rows[self.ntotal: self.ntotal + n].copy_(rows_f16[:n])
+            self.ntotal += n
             self.max_norm = max(self.max_norm, float(max_norm))
+            self._requant(old)
 
     def load_rows(self, rows_f16_host, max_norm: float) -> None:
         """Upload rows already in storage format (host array [n][d_pad] float16, e.g. a memmap)."""
@@ -140,13 +178,17 @@ class FlatIndexF16:
             for s in range(0, n, step):  # bounded pinned staging instead of one huge host tensor
                 chunk = t.from_numpy(np.ascontiguousarray(rows_f16_host[s:s + step]))
                 self._rows[self.ntotal + s: self.ntotal + s + chunk.shape[0]].copy_(chunk)
+            old = self.ntotal
             self.ntotal += n
             self.max_norm = max(self.max_norm, float(max_norm))
+            self._requant(old)
 
     def reset(self) -> None:
         with self._lock:
             self.ntotal = 0
             self.max_norm = 0.0
+            if self._qmeta is not None:
+                self._qmeta[:4].zero_()
 
     # ------------------------------------------------------------------ search
     @staticmethod
@@ -201,16 +243,11 @@ class FlatIndexF16:
 
     def _repair_rows(self, q, k, out_ids, out_sc, flagged) -> None:
         """Re-prepare `q` (the shared query buffers may hold a later batch by now) and repair rows."""
-        t = self.torch
         ws, b = self._workspace(), self._qbuf
-        norm = 1 if self.metric == "cosine" else 0
         stream = self._stream()
-        B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
-                                           max(self.max_norm, 1.0) if norm else self.max_norm,
-                                           b["q32"].data_ptr(), b["q16"].data_ptr(), b["eps"].data_ptr(), stream),
-                "rarc_prep_queries")
+        self._prep(q)
         for qi in flagged:
-            B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["q32"].data_ptr(), qi, k,
+            B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["qblock"].data_ptr(), qi, k,
                                              self.id_base, out_ids.data_ptr(), out_sc.data_ptr(), b["found"].data_ptr(),
                                              ws.data_ptr(), ws.numel(), stream), "rarc_repair_f16")
             if int(b["found"].item()) & 0x80000000:
@@ -231,18 +268,14 @@ class FlatIndexF16:
             status.zero_()
         nq = q.shape[0]
         stream = self._stream()
-        norm = 1 if self.metric == "cosine" else 0
-        B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], nq, self.dim, self.d_pad, norm,
-                                           max(self.max_norm, 1.0) if norm else self.max_norm,
-                                           b["q32"].data_ptr(), b["q16"].data_ptr(), b["eps"].data_ptr(), stream),
-                "rarc_prep_queries")
+        self._prep(q)
         lo, hi = self._bins(q)
         kp = self.kprime_for(k)
         rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
-        B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, b["q32"].data_ptr(),
-                                         b["q16"].data_ptr(), b["eps"].data_ptr(), nq, k, kp, self.id_base,
-                                         lo, hi, out_ids.data_ptr(), out_sc.data_ptr(), status.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+        qm = self._qmeta.data_ptr() if (self.scan == "q8" and self._qmeta is not None and self.ntotal) else 0
+        B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k, kp,
+                                         self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
+                                         status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),
                 "rarc_search_f16")
         self.last_status = status[:nq]
         if not repair or self.ntotal == 0:
@@ -252,7 +285,7 @@ class FlatIndexF16:
         flagged = t.nonzero(status[:nq]).flatten().tolist() if any_flag else []
         self.last_repaired = flagged
         for qi in flagged:
-            B.check(self.lib.rarc_repair_f16(rows_ptr, self.ntotal, self.d_pad, b["q32"].data_ptr(), qi, k,
+            B.check(self.lib.rarc_repair_f16(rows_ptr, self.ntotal, self.d_pad, b["qblock"].data_ptr(), qi, k,
                                              self.id_base, out_ids.data_ptr(), out_sc.data_ptr(),
                                              b["found"].data_ptr(), ws.data_ptr(), ws.numel(), stream),
                     "rarc_repair_f16")
@@ -267,12 +300,9 @@ class FlatIndexF16:
             ws = self._workspace()
             b = self._qbuf
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
-            norm = 1 if self.metric == "cosine" else 0
-            B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
-                                               max(self.max_norm, 1.0), b["q32"].data_ptr(), b["q16"].data_ptr(),
-                                               b["eps"].data_ptr(), self._stream()), "rarc_prep_queries")
+            self._prep(q)
             k = ids.shape[1]
-            B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["q32"].data_ptr(),
+            B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["qblock"].data_ptr(),
                                              qi, k, self.id_base, ids.data_ptr(), scores.data_ptr(),
                                              b["found"].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
                     "rarc_repair_f16")

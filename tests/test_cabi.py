@@ -23,14 +23,14 @@ def test_library_exports_every_declared_symbol():
     lib = B.load_library()
     for name in _declared():
         assert hasattr(lib, name), f"{name} missing from librarc_hip.so"
-    assert lib.rarc_version() == 100
+    assert lib.rarc_version() == 200
     assert lib.rarc_padded_dim(1) == 128 and lib.rarc_padded_dim(768) == 768 and lib.rarc_padded_dim(769) == 896
     assert lib.rarc_search_workspace_bytes(16384) > 256 * 16384 * 8
 
 
 def test_argument_validation_needs_no_gpu():
     lib = B.load_library()
-    rc = lib.rarc_search_f16(None, 10, 768, None, None, None, 1, 10, 128, 0, -1.0, 1.0, None, None, None, None, 0, 16384, None)
+    rc = lib.rarc_search_f16(None, 10, 768, None, None, 1, 10, 128, 0, -1.0, 1.0, None, None, None, None, 0, 16384, None)
     assert rc == -1 and b"null pointer" in lib.rarc_last_error()
     rc = lib.rarc_rrf_fuse(None, None, 1, 1, 1, 60.0, 1, None, None, None, None)
     assert rc == -1

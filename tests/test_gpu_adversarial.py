@@ -73,7 +73,7 @@ def test_flags_are_raised_and_repair_fixes_them(oracle):
     rng = np.random.default_rng(5)
     X = rng.standard_normal((50_000, 768)).astype(np.float32)
     Q = rng.standard_normal((16, 768)).astype(np.float32)
-    idx = FlatIndexF16(768)
+    idx = FlatIndexF16(768, scan="mfma16")  # the fp16 scan is the one with a certificate to fail
     idx.add(X)
     idx.kprime_for = lambda k: k            # no margin: every query is UNCERTAIN by construction
     D, I = idx.search(Q, 100)

@@ -25,9 +25,9 @@ def _data(n, d, nq, seed):
             rng.standard_normal((nq, d)).astype(np.float32) * 0.5)
 
 
-def _check(hip, oracle, X, Q, k, metric="cosine"):
+def _check(hip, oracle, X, Q, k, metric="cosine", scan="q8"):
     n, d = X.shape
-    idx = hip.FlatIndexF16(d, metric=metric)
+    idx = hip.FlatIndexF16(d, metric=metric, scan=scan)
     idx.add(X)
     # ingest parity: stored rows are bit-identical to the oracle's
     ref_rows, ref_n2 = oracle.ingest_f16(X, normalize=(metric == "cosine"))
@@ -54,7 +54,27 @@ def _check(hip, oracle, X, Q, k, metric="cosine"):
 ])
 def test_search_matches_oracle(hip, oracle, n, d, nq, k):
     X, Q = _data(n, d, nq, seed=n * 7 + d)
+    _check(hip, oracle, X, Q, k)                    # int8 prefilter scan (default)
+    _check(hip, oracle, X, Q, k, scan="mfma16")     # fp16 MFMA scan + certificate
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(3000, 1024, 40, 10), (20000, 1024, 256, 100), (777, 896, 5, 20)])
+def test_search_wide_rows_q8(hip, oracle, n, d, nq, k):
+    """d up to 1024 (bge-large, BASELINE config 5's dimension) runs on the int8-prefilter scan."""
+    X, Q = _data(n, d, nq, seed=n + d)
     _check(hip, oracle, X, Q, k)
+
+
+def test_q8_overflow_is_flagged_and_repaired(hip, oracle):
+    """A candidate buffer far too small for the batch: every query overflows, is flagged and repaired."""
+    X, Q = _data(50_000, 768, 16, seed=77)
+    idx = hip.FlatIndexF16(768, cand_cap=4096)      # 16 slots per (workgroup, query)
+    idx.add(X)
+    D, I = idx.search(Q, 900)
+    assert len(idx.last_repaired) == 16
+    rows, _ = oracle.ingest_f16(X)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), 900)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
 
 
 def test_inner_product_metric(hip, oracle):
@@ -132,7 +152,9 @@ def test_async_pipeline_gives_identical_results(hip, oracle):
     for i, h in enumerate(handles):
         ids, sc = h.result()
         assert bool((ids == want_i[i * 64:(i + 1) * 64]).all()) and bool((sc == want_s[i * 64:(i + 1) * 64]).all())
-    # forced repair through the deferred path
+    # forced repair through the deferred path (fp16 scan: k' == k leaves the certificate no margin)
+    idx = hip.FlatIndexF16(768, scan="mfma16")
+    idx.add(X)
     idx.kprime_for = lambda k: k
     h1, h2 = idx.search_async(Q[:16], 50), idx.search_async(Q[16:32], 50)
     for h, lo in ((h1, 0), (h2, 16)):

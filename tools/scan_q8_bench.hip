@@ -1,0 +1,70 @@
+// tools/scan_q8_bench.hip — ablation timing of the int8-prefilter scan kernel (development tool).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/scan_q8_bench.hip -o tools/scan_q8_bench
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../rag-arc_amd/csrc/scan_f16.hip"
+#include "../rag-arc_amd/csrc/scan_q8.hip"
+#include "../rag-arc_amd/csrc/quant.hip"
+#include "../rag-arc_amd/csrc/prep.hip"
+void rarc_set_error(const char* fmt, ...) { (void)fmt; }
+bool rarc_prof_next(hipEvent_t*, hipEvent_t*) { return false; }
+
+#ifndef BD
+#define BD 768
+#endif
+template <int ABL>
+static float run(const ScanQ8Params& p, int grid, int iters, const uint16_t* corpus, int64_t N, const RarcQb& qb,
+                 int kprime, RarcWs ws) {
+  constexpr int D = BD;
+  constexpr size_t lds = ScanQ8Lds<D>::TOTAL;
+  hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int it = 0; it < iters; ++it) {
+    rarc_seed_launch(corpus, N, D, qb.q16, 256, kprime, -1.f, 1.f, qb.eps16, qb.eps8, ws, 0);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL((rarc_scan_q8_kernel<D, ABL>), dim3(grid), dim3(Q8_THREADS), lds, 0, p);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  return best * 1000.f;
+}
+
+int main(int argc, char** argv) {
+  const int64_t N = argc > 1 ? atoll(argv[1]) : 1000000;
+  const int D = BD, NQ = 256, KP = 128, CAP = 65536;
+  uint16_t* corpus; void* wsb; void* qblock; float* qmeta;
+  hipMalloc(&corpus, (size_t)(N + 32) * D * 2); hipMemset(corpus, 0, (size_t)(N + 32) * D * 2);
+  size_t wsbytes = RARC_WS_CAND + (size_t)256 * CAP * 8; hipMalloc(&wsb, wsbytes);
+  hipMalloc(&qblock, rarc_qb_bytes(D));
+  size_t nm = rarc_quant_meta_floats(N); hipMalloc(&qmeta, nm * 4); hipMemset(qmeta, 0, nm * 4);
+  rarc_synth_rows_f16(corpus, D, D, 0, N, 1234, 0);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, 0);
+  rarc_quant_meta_f16(corpus, N, D, 0, qmeta, 0);
+  hipEventRecord(e1, 0); hipEventSynchronize(e1);
+  { float ms; hipEventElapsedTime(&ms, e0, e1); printf("quant_meta: %.1f us (%.2f TB/s)\n", ms * 1000, (double)N * D * 2 / ms * 1e-9); }
+  { float* qf; hipMalloc(&qf, 256 * D * 4); rarc_synth_rows_f32(qf, D, D, 0, 256, 4321, 0);
+    rarc_prep_queries(qf, D, 256, D, D, 1, 1.001f, qmeta, qblock, 0); hipDeviceSynchronize(); }
+  RarcQb qb = rarc_qb_carve(qblock, D);
+  { float h[4]; hipMemcpy(h, qmeta, 16, hipMemcpyDeviceToHost); float e8[4], e16[4]; hipMemcpy(e8, qb.eps8, 16, hipMemcpyDeviceToHost); hipMemcpy(e16, qb.eps16, 16, hipMemcpyDeviceToHost);
+    printf("R = %.5f  eps8[0..1] = %.5f %.5f  eps16[0] = %.6f\n", h[0], e8[0], e8[1], e16[0]); }
+  RarcWs ws = rarc_ws_carve(wsb);
+  ScanQ8Params p; p.corpus = (const uint4*)corpus; p.tmeta = (const float2*)(qmeta + RARC_QMETA_HDR); p.q8 = qb.q8; p.qinv = qb.qinv; p.eps8 = qb.eps8;
+  p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32);
+  p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
+  p.binlo = ws.binlo; p.binscale = ws.binscale; p.bininv = ws.bininv;
+  int grid = 256;
+  const double gb = (double)N * D * 2 / 1e9;
+#define RUN(A) { float us = run<A>(p, grid, 6, corpus, N, qb, KP, ws); printf("ABL=%2d  %8.1f us  %6.2f TB/s\n", A, us, gb / us * 1e3); }
+  RUN(0) RUN(0) RUN(1) RUN(32) RUN(64) RUN(8) RUN(4) RUN(21)
+  run<0>(p, grid, 1, corpus, N, qb, KP, ws);
+  std::vector<uint32_t> cnt(256 * 256); hipMemcpy(cnt.data(), ws.cnt2, 256 * 256 * 4, hipMemcpyDeviceToHost);
+  uint64_t tot = 0; uint32_t mx = 0; for (auto c : cnt) { tot += c; mx = c > mx ? c : mx; }
+  printf("mean candidates/query: %.0f   max per (wg,query) segment: %u (seg %u)\n", tot / 256.0, mx, p.seg);
+  return 0;
+}
