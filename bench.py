@@ -38,7 +38,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="q8"):
+def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="auto"):
     """HBM-resident shard holding global rows [lo, hi) of the synthetic corpus."""
     n = hi - lo
     d_pad = B.padded_dim(dim)
@@ -144,10 +144,12 @@ def main():
         ach = shard_bytes / (scan_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        kname = "rarc_scan_q8_kernel" if idx._use_q8() else "rarc_scan_f16_kernel"
         if os.path.exists(tpath):
             try:
                 for ent in json.load(open(tpath)).get("entries", []):  # PMC passes recorded per shard size
-                    if ent.get("rows_per_launch") == hi - lo and ent.get("dim") == a.dim:
+                    if (ent.get("rows_per_launch") == hi - lo and ent.get("dim") == a.dim
+                            and ent.get("kernel", "rarc_scan_f16_kernel") == kname):
                         traffic = ent.get("hbm_bytes_per_launch")
             except Exception:
                 pass
@@ -163,7 +165,8 @@ def main():
                        "full_size_check": {"queries_verified_by_exact_rescan": 2, "rows_beating_kth": beat}},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "rarc_scan_f16_kernel", "avg_launch_ms": round(scan_ms, 4),
+                         "kernel": "rarc_scan_q8_kernel" if idx._use_q8() else "rarc_scan_f16_kernel",
+                         "avg_launch_ms": round(scan_ms, 4),
                          "algorithmic_bytes_per_launch": shard_bytes, "launches_timed": n_l.value},
         }
 

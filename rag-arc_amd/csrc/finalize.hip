@@ -231,8 +231,7 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
 // RARC_Q_OVERFLOW and sends the query to rarc_repair_f16.
 // ============================================================================================
 constexpr int FIN8_THREADS = 1024;
-constexpr int FIN8_SURV = 8192;   // candidates kept after the final-threshold compaction
-constexpr int FIN8_RS = 3072;     // rows rescored canonically (G1 ∪ G2)
+constexpr int FIN8_RS = 4096;     // rows rescored canonically per query (G1 ∪ G2)
 constexpr int FIN8_MAXD = 1024;
 
 struct Fin8Params {
@@ -256,19 +255,17 @@ struct Fin8Params {
 };
 
 __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fin8Params p) {
-  extern __shared__ __attribute__((aligned(16))) char fsm[];
-  uint64_t* keys = (uint64_t*)fsm;                                     // [FIN8_SURV] approx keys
-  uint64_t* ex = (uint64_t*)(fsm + (size_t)FIN8_SURV * 8);             // [FIN8_RS] canonical keys
-  float* s_q = (float*)(fsm + (size_t)(FIN8_SURV + FIN8_RS) * 8);      // [d]
+  __shared__ uint64_t ex[FIN8_RS];  // candidate keys; rescored in place (approx key -> canonical key)
+  __shared__ __attribute__((aligned(16))) float s_q[FIN8_MAXD];
   __shared__ uint32_t s_hist[RARC_NB];
   __shared__ float s_t1, s_L;
-  __shared__ uint32_t s_ns, s_ne, s_over;
+  __shared__ uint32_t s_ne, s_over;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float eps = p.eps8[q];
 
   for (int i = tid; i < RARC_NB; i += blockDim.x) s_hist[i] = p.hist[(size_t)q * RARC_NB + i];
   for (int i = tid; i < p.d; i += blockDim.x) s_q[i] = p.q32[(size_t)q * p.d + i];
-  if (tid == 0) { s_ns = 0; s_ne = 0; s_over = 0; s_L = -INFINITY; }
+  if (tid == 0) { s_ne = 0; s_over = 0; s_L = -INFINITY; }
   __syncthreads();
   if (tid < 64) {
     uint32_t above;
@@ -276,44 +273,40 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
     if (tid == 0) s_t1 = rarc_bin_threshold(b, p.binlo[q], p.bininv[q]);
   }
   __syncthreads();
-  const float t1 = s_t1;
-  const float thr_f = t1 - 2.0002f * eps;  // -inf stays -inf
+  const float t1 = s_t1;  // -inf when fewer than k candidates exist: then G1 is everything
 
-  // ---- gather the query's segments; keep what clears the final threshold ----
-  for (uint32_t w = tid; w < p.n_wg * 4; w += blockDim.x) {  // 4 threads per segment
-    const uint32_t wg = w >> 2, part = w & 3;
-    const uint32_t c = p.cnt2[(size_t)wg * RARC_MAX_QUERIES + q];
-    const uint32_t n = c < p.seg ? c : p.seg;
-    if (c > p.seg && part == 0) atomicOr(&s_over, 1u);
-    const uint64_t* src = p.cand + ((size_t)q * RARC_MAX_WG + wg) * p.seg;
-    for (uint32_t i = part; i < n; i += 4) {
-      const uint64_t key = src[i];
-      if (rarc_candscore(key) >= thr_f) {
-        const uint32_t pos = atomicAdd(&s_ns, 1u);
-        if (pos < FIN8_SURV) keys[pos] = key;
+  // walk the query's segments (4 threads per segment) and append the keys `want` accepts to ex[]
+  auto collect = [&](auto want) {
+    for (uint32_t w = tid; w < p.n_wg * 4; w += blockDim.x) {
+      const uint32_t wg = w >> 2, part = w & 3;
+      const uint32_t c = p.cnt2[(size_t)wg * RARC_MAX_QUERIES + q];
+      const uint32_t n = c < p.seg ? c : p.seg;
+      if (c > p.seg && part == 0) atomicOr(&s_over, 1u);
+      const uint64_t* src = p.cand + ((size_t)q * RARC_MAX_WG + wg) * p.seg;
+      for (uint32_t i = part; i < n; i += 4) {
+        const uint64_t key = src[i];
+        if (want(rarc_candscore(key))) {
+          const uint32_t e = atomicAdd(&s_ne, 1u);
+          if (e < FIN8_RS) ex[e] = key;
+        }
       }
     }
-  }
-  __syncthreads();
-  const uint32_t ns_all = s_ns;
-  const int ns = ns_all < FIN8_SURV ? (int)ns_all : FIN8_SURV;
-
-  // ---- step 1: G1 = {a >= T1}, canonical scores ----
-  for (int i = tid; i < ns; i += blockDim.x) {
-    const uint64_t key = keys[i];
-    if (rarc_candscore(key) >= t1) {
-      const uint32_t e = atomicAdd(&s_ne, 1u);
-      if (e < FIN8_RS) {
-        const uint32_t row = rarc_candrow(key);
-        ex[e] = rarc_candkey(canon_dot_f16(s_q, p.corpus + (size_t)row * p.d, p.d), row);
-      }
-      keys[i] = 0ull;  // done
+  };
+  auto rescore = [&](int from, int to) {  // dense: one row per thread
+    for (int i = from + tid; i < to; i += blockDim.x) {
+      const uint32_t row = rarc_candrow(ex[i]);
+      ex[i] = rarc_candkey(canon_dot_f16(s_q, p.corpus + (size_t)row * p.d, p.d), row);
     }
-  }
+  };
+
+  // ---- step 1: G1 = {a >= T1}: canonical scores, L = k-th best of them ----
+  collect([&](float a) { return a >= t1; });
   __syncthreads();
   const uint32_t ne1_all = s_ne;
   const int ne1 = ne1_all < FIN8_RS ? (int)ne1_all : FIN8_RS;
-  if (ne1 >= p.k) {  // L = k-th best canonical score of G1 (rank by counting; keys are distinct)
+  rescore(0, ne1);
+  __syncthreads();
+  if (ne1 >= p.k) {  // rank by counting; keys are distinct
     for (int i = tid; i < ne1; i += blockDim.x) {
       const uint64_t mine = ex[i];
       int rank = 0;
@@ -322,22 +315,15 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
     }
   }
   __syncthreads();
-  const float L = s_L;  // -inf when fewer than k candidates exist: then everything is rescored
+  const float L = s_L;  // -inf when fewer than k candidates exist (then G1 already holds them all)
 
-  // ---- step 2: G2 = {a + eps >= L} not yet done ----
-  for (int i = tid; i < ns; i += blockDim.x) {
-    const uint64_t key = keys[i];
-    if (key != 0ull && rarc_candscore(key) + eps * 1.0001f >= L) {
-      const uint32_t e = atomicAdd(&s_ne, 1u);
-      if (e < FIN8_RS) {
-        const uint32_t row = rarc_candrow(key);
-        ex[e] = rarc_candkey(canon_dot_f16(s_q, p.corpus + (size_t)row * p.d, p.d), row);
-      }
-    }
-  }
+  // ---- step 2: G2 = {a < T1, a + eps >= L}: canonical scores ----
+  if (ne1_all <= (uint32_t)FIN8_RS && t1 > -INFINITY) collect([&](float a) { return a < t1 && a + eps * 1.0001f >= L; });
   __syncthreads();
   const uint32_t ne_all = s_ne;
   const int ne = ne_all < FIN8_RS ? (int)ne_all : FIN8_RS;
+  rescore(ne1, ne);
+  __syncthreads();
 
   // ---- step 3: exact order (canonical score desc, id asc) by counting ----
   const int kk = ne < p.k ? ne : p.k;
@@ -359,7 +345,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   }
   if (tid == 0) {
     uint32_t st = RARC_Q_OK;
-    if (s_over || ns_all > (uint32_t)FIN8_SURV || ne_all > (uint32_t)FIN8_RS) st |= RARC_Q_OVERFLOW;
+    if (s_over || ne_all > (uint32_t)FIN8_RS) st |= RARC_Q_OVERFLOW;
     p.status[q] = st;
     if (st) {
       atomicOr(&p.flags[1], st);
@@ -390,14 +376,7 @@ int rarc_finalize_q8_launch(const uint16_t* corpus, int d_pad, const float* q32,
   p.out_ids = out_ids;
   p.out_scores = out_scores;
   p.status = status;
-  const size_t lds = (size_t)(FIN8_SURV + FIN8_RS) * 8 + (size_t)FIN8_MAXD * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_finalize_q8_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(rarc_finalize_q8_kernel, dim3(nq), dim3(FIN8_THREADS), lds, s, p);
+  hipLaunchKernelGGL(rarc_finalize_q8_kernel, dim3(nq), dim3(FIN8_THREADS), 0, s, p);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

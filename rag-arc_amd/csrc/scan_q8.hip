@@ -49,12 +49,14 @@ struct ScanQ8Params {
   uint32_t seg;
   uint32_t kprime;
   uint32_t nq;
+  unsigned long long* dbg;  // tools/scan_q8_bench: {shader cycles, 100 MHz ticks} of workgroup 0; else null
 };
 
 constexpr int Q8_WAVES = 8;
 constexpr int Q8_THREADS = Q8_WAVES * 64;
 
-constexpr int Q8_STAGE = 6144;  // staged (query, key) appends per workgroup between flushes
+constexpr int Q8_WSTAGE = 768;            // staged (query, key) survivors per wave between flushes
+constexpr int Q8_STAGE = 8 * Q8_WSTAGE;   // ... per workgroup
 
 template <int D>
 struct ScanQ8Lds {
@@ -66,8 +68,7 @@ struct ScanQ8Lds {
   static constexpr int BININV = BINSCALE + 1024;
   static constexpr int EPS8 = BININV + 1024;
   static constexpr int HLAND = EPS8 + 1024;     // uint32 [256]: the owned query's histogram, as last fetched
-  static constexpr int MISC = HLAND + 1024;     // [0] staged count
-  static constexpr int SKEY = MISC + 64;        // uint64 [Q8_STAGE]
+  static constexpr int SKEY = HLAND + 1024;     // uint64 [Q8_STAGE]
   static constexpr int SQ = SKEY + 8 * Q8_STAGE;  // uint8 [Q8_STAGE]
   static constexpr int TOTAL = SQ + Q8_STAGE;
 };
@@ -79,7 +80,8 @@ __device__ __forceinline__ void q8_lds_barrier() {
 }
 
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
-// 8 = no threshold refresh, 16 = no conversion, 32 = prune fast path only, 64 = never flush
+// 8 = no threshold refresh, 16 = no conversion, 32 = prune fast path only, 64 = never flush,
+// 1024 = s_memtime timeline of workgroup 0 into p.dbg
 //
 // Vector-memory discipline.  The prefetched tile registers are consumed with counted waits
 // ("all but the newest N operations have returned"), which the compiler derives per program path and
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   const int lane = tid & 63;
   const int row = lane & 31, h = lane >> 5;
   const uint32_t qidx = wave * 32 + row;  // this lane's query
+  const unsigned long long dbg_c0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long dbg_r0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   uint32_t* s_cnt = (uint32_t*)(smem + L::CNT);
   float* s_binlo = (float*)(smem + L::BINLO);
@@ -112,7 +116,6 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   float* s_bininv = (float*)(smem + L::BININV);
   float* s_eps8 = (float*)(smem + L::EPS8);
   uint32_t* s_hland = (uint32_t*)(smem + L::HLAND);
-  uint32_t* s_nstage = (uint32_t*)(smem + L::MISC);
   uint64_t* s_skey = (uint64_t*)(smem + L::SKEY);
   uint8_t* s_sq = (uint8_t*)(smem + L::SQ);
   if (tid < RARC_MAX_QUERIES) {
@@ -123,7 +126,6 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     s_eps8[tid] = p.eps8[tid];
     s_hland[tid] = 0;
   }
-  if (tid == 0) *s_nstage = 0;
 
   // resident query fragments (B operand): lane holds Q8[qidx][32*ks + 16*h .. +16)
   i32x4 qf[KS];
@@ -133,17 +135,23 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const i32x4*)(qp + 32 * ks);
   }
   const float my_qinv = p.qinv[qidx];
+  const float my_sq8 = 1.0f / my_qinv;  // the query's int8 scale
   float thr = __uint_as_float(p.thr[qidx]);  // seed threshold; +inf for padding queries
   // everything fetched so far has landed before the first tile load is issued: the compiler's wait
   // counters then never tie a query fragment to the (deliberately long-lived) tile prefetches
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 
   // this thread's chunks of a tile: c = j*512 + tid -> LDS byte offset of its 8 int8 values
-  uint32_t woff[CPT];
-#pragma unroll
-  for (int j = 0; j < CPT; ++j) {
+  // (kept in registers up to D = 768; recomputed per use beyond that, where registers are short)
+  constexpr bool WOFF_REGS = (D <= 768);
+  auto woff_of = [&](int j) {
     const uint32_t c = j * Q8_THREADS + tid;
-    woff[j] = (c / CPR) * L::RS + (c % CPR) * 8;
+    return (c / CPR) * L::RS + (c % CPR) * 8;
+  };
+  uint32_t woff[WOFF_REGS ? CPT : 1];
+  if constexpr (WOFF_REGS) {
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) woff[j] = woff_of(j);
   }
   const uint32_t aoff = row * L::RS + 16 * h;  // A fragment of k-step ks: + 32*ks
 
@@ -164,13 +172,17 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     uint32_t hw;
   };
   auto clamp_tile = [&](uint32_t t) { return t < p.n_tiles ? t : 0u; };  // past the end: tile 0 (an L2 hit)
+  // (small items first: if the register allocator decides to move one of these long-lived values
+  // while it is still in flight, the wait it needs then is for the OLDEST entries of the newest group,
+  // i.e. no more than the wait for the group about to be consumed anyway)
   auto fetch = [&](Fetch& f, uint32_t tile) {
-    const uint4* src = p.corpus + (size_t)tile * TCH + tid;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) f.c[j] = src[j * Q8_THREADS];
     f.meta = p.tmeta[tile];
     f.thr = __hip_atomic_load(&p.thr[qidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f.hw = __hip_atomic_load(hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_sched_barrier(0);
+    const uint4* src = p.corpus + (size_t)tile * TCH + tid;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) f.c[j] = src[j * Q8_THREADS];
   };
   auto convert_tile = [&](const Fetch& f, int buf) {
     const half_t s = (half_t)f.meta.x;
@@ -180,8 +192,43 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       uint2 o;
       if (ABL & 16) { o.x = f.c[j].x ^ f.c[j].z; o.y = f.c[j].y ^ f.c[j].w; }
       else o = rarc_quant8_chunk(f.c[j], s);
-      *(uint2*)(dst + woff[j]) = o;
+      *(uint2*)(dst + (WOFF_REGS ? woff[WOFF_REGS ? j : 0] : woff_of(j))) = o;
     }
+  };
+
+  // 32 rows x 32 queries per wave: D/32 chained int8 MFMAs, A fragments read a few steps ahead —
+  // and, in the shadow of those MFMAs (the matrix pipe takes 32 cycles per instruction, the wave is
+  // free in between), the conversion of the NEXT tile's chunks (fetched two iterations ago) into the
+  // other LDS buffer.  Unconditional: past the end of the shard the chunks are the tile-0 dummy.
+  // (Two accumulators, or running waves w / w+4 of a SIMD in opposite phase order, changed cycles per
+  // tile by a few per cent and the clock the other way: the kernel runs at its power limit.)
+  auto mfma_convert = [&](int buf, const Fetch& nx) -> i32x16 {
+    i32x16 c0 = {0};
+    const char* a_base = smem + buf * L::TILE + aoff;
+    char* dst = smem + (buf ^ 1) * L::TILE;
+    const half_t s = (half_t)nx.meta.x;
+    constexpr int PF = (D <= 768) ? 4 : 2;
+    constexpr int CSTEP = KS / CPT;  // one chunk converted every CSTEP MFMAs (KS = 4·CPT)
+    i32x4 a[PF];
+    if (!(ABL & 4)) {
+#pragma unroll
+      for (int i = 0; i < PF; ++i) a[i] = *(const i32x4*)(a_base + 32 * i);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (!(ABL & 4)) {
+        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks % PF], qf[ks], c0, 0, 0, 0);
+        if (ks + PF < KS) a[ks % PF] = *(const i32x4*)(a_base + 32 * (ks + PF));
+      }
+      if (ks % CSTEP == CSTEP / 2) {
+        const int j = ks / CSTEP;
+        uint2 o;
+        if (ABL & 16) { o.x = nx.c[j].x ^ nx.c[j].z; o.y = nx.c[j].y ^ nx.c[j].w; }
+        else o = rarc_quant8_chunk(nx.c[j], s);
+        *(uint2*)(dst + (WOFF_REGS ? woff[WOFF_REGS ? j : 0] : woff_of(j))) = o;
+      }
+    }
+    return c0;
   };
 
   // one survivor straight to global memory (flush, and the overflow path of the staging buffer)
@@ -190,99 +237,132 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     if (slot < p.seg) p.cand[((size_t)q * RARC_MAX_WG + blockIdx.x) * p.seg + slot] = key;
     atomicAdd(&p.hist[q * RARC_NB + rarc_bin_of(rarc_candscore(key), s_binlo[q], s_binscale[q])], 1u);
   };
+  // Survivors go to an LDS staging area (no vector-memory traffic), one region per wave so that
+  // slots are handed out with lane arithmetic (ballot + mbcnt) instead of an LDS atomic round trip;
+  // a full region sends the survivor straight to global memory.
+  uint32_t wcount = 0;  // wave-uniform: entries staged by this wave since the last flush
+  uint64_t* my_skey = s_skey + wave * Q8_WSTAGE;
+  uint8_t* my_sq = s_sq + wave * Q8_WSTAGE;
+  auto stage_n = [&](bool want, float a, uint32_t doc) {  // called by the whole wave (want: this lane has one)
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(want);
+    if (b == 0) return;
+    const uint32_t pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    if (want) {
+      const uint64_t key = rarc_candkey(a, doc);
+      if (pos < (uint32_t)Q8_WSTAGE) {
+        my_skey[pos] = key;
+        my_sq[pos] = (uint8_t)qidx;
+      } else {
+        emit(qidx, key);
+      }
+    }
+    wcount += (uint32_t)__builtin_popcountll(b);
+  };
   // lane holds 16 integer scores of its query: rows 8*(r>>2) + 4*h + (r&3) of the tile.
-  // Fast path: integer max, one compare.  Slow path (some lane has a survivor): the lane counts its
-  // survivors, reserves that many staging entries with one LDS atomic and writes (query, key) pairs
-  // to LDS — no vector-memory traffic.
-  auto prune = [&](const i32x16& acc, uint32_t tile, float tinv) {
-    int m = acc[0];
+  // Fast path (every tile): max of (score << 4 | r) — the best score and where it sits — and one
+  // compare.  When some lane's best clears its threshold, the wave counts per lane how many of the 16
+  // scores clear a (conservative) integer threshold: when no lane has more than one — by far the usual
+  // case — each passing lane's best is its only survivor and is staged directly; otherwise all 16
+  // positions are walked.
+  auto prune = [&](const i32x16& acc, uint32_t tile, float tinv, float tsc) {
+    int pm = acc[0] << 4;
 #pragma unroll
-    for (int r = 1; r < 16; ++r) m = acc[r] > m ? acc[r] : m;
+    for (int r = 1; r < 16; ++r) {
+      const int v = (acc[r] << 4) | r;  // |score| < 2^24: no overflow
+      pm = v > pm ? v : pm;
+    }
+    const int m = pm >> 4;
     const float sc = my_qinv * tinv;
+    const bool pass = (float)m * sc >= thr;
     if (ABL & 32) {
       if (__builtin_amdgcn_ballot_w64((float)m * sc >= 1e30f) != 0) p.cnt2[1] = 1;
       return;
     }
-    if (__builtin_amdgcn_ballot_w64((float)m * sc >= thr) != 0) {
+    if (__builtin_amdgcn_ballot_w64(pass) != 0) {
       const uint32_t row0 = tile * 32 + 4 * h;
-      uint32_t mask = 0;
+      // every score s with (float)s*sc >= thr satisfies s >= ti (one unit + 1e-6 relative of slack)
+      const float tq = thr * (my_sq8 * tsc);  // thr / sc up to rounding
+      const int ti = pass ? (int)__builtin_floorf(tq - 1.0f - __builtin_fabsf(tq) * 2e-6f) : 0x7fffffff;
+      int c = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t doc = row0 + (r & 3) + 8 * (r >> 2);
-        mask |= ((float)acc[r] * sc >= thr && doc < p.n_rows) ? (1u << r) : 0u;
-      }
-      if (mask) {
-        uint32_t pos = atomicAdd(s_nstage, (uint32_t)__builtin_popcount(mask));
+      for (int r = 0; r < 16; ++r) c += (acc[r] >= ti) ? 1 : 0;
+      if (__builtin_amdgcn_ballot_w64(c > 1) == 0) {
+        const uint32_t rs = (uint32_t)pm & 15u;
+        const uint32_t doc = row0 + (rs & 3) + 8 * (rs >> 2);
+        stage_n(pass && doc < p.n_rows, (float)m * sc, doc);
+      } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          if (mask & (1u << r)) {
-            const uint64_t key = rarc_candkey((float)acc[r] * sc, row0 + (r & 3) + 8 * (r >> 2));
-            if (pos < (uint32_t)Q8_STAGE) {
-              s_skey[pos] = key;
-              s_sq[pos] = (uint8_t)qidx;
-            } else {
-              emit(qidx, key);  // staging full (a tile where almost everything passes): go direct
-            }
-            ++pos;
-          }
+          const float a = (float)acc[r] * sc;
+          const uint32_t doc = row0 + (r & 3) + 8 * (r >> 2);
+          stage_n(a >= thr && doc < p.n_rows, a, doc);
         }
       }
     }
   };
-  // all threads; staged entries -> private candidate segments + global histogram
+  // all threads; staged entries -> private candidate segments + global histogram.  Each wave drains
+  // its own region (it knows its count; nothing to exchange), so no barrier is needed around it.
   auto flush = [&]() {
-    uint32_t n = *s_nstage;
-    n = n < (uint32_t)Q8_STAGE ? n : (uint32_t)Q8_STAGE;
-    for (uint32_t e = tid; e < n; e += Q8_THREADS) emit(s_sq[e], s_skey[e]);
-    q8_lds_barrier();
-    if (tid == 0) *s_nstage = 0;
-    q8_lds_barrier();
+    const uint32_t n = wcount < (uint32_t)Q8_WSTAGE ? wcount : (uint32_t)Q8_WSTAGE;
+    for (uint32_t e = lane; e < n; e += 64) emit(my_sq[e], my_skey[e]);
+    wcount = 0;
   };
 
+  // fetch groups in flight: two up to D = 896; one beyond (a group is 36 registers at D = 1024 and a
+  // spill would put scratch traffic into the very queue the counted waits rely on)
+  constexpr int NG = (D <= 896) ? 2 : 1;
   // ---- prologue: tile t0 straight into LDS buffer 0; tiles t0+stride, t0+2·stride in flight ----
   // (the launch guarantees gridDim.x <= n_tiles, so tile t0 exists)
-  Fetch f[2];
+  Fetch f[NG];
   fetch(f[0], t0);
   convert_tile(f[0], 0);
-  float tinv_cur = f[0].meta.y;  // 1/scale of the tile in the LDS buffer about to be read
+  float2 mcur[2];   // (scale, 1/scale) of the tile sitting in LDS buffer 0 / 1
+  mcur[0] = f[0].meta;
   // (scheduling fences: the groups must be ISSUED in this order, or the counted waits the compiler
   // derives for the first loop iteration assume the wrong group is the newest)
   __builtin_amdgcn_sched_barrier(0);
-  fetch(f[1], clamp_tile(t0 + stride));
-  __builtin_amdgcn_sched_barrier(0);
-  fetch(f[0], clamp_tile(t0 + 2 * stride));
+  if constexpr (NG == 2) {
+    fetch(f[1], clamp_tile(t0 + stride));
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(f[0], clamp_tile(t0 + 2 * stride));
+  } else {
+    fetch(f[0], clamp_tile(t0 + stride));
+  }
   __builtin_amdgcn_sched_barrier(0);
   float last_pub = -INFINITY;  // owner lane: last threshold it published
+  // Drain once before the loop.  Otherwise the loop header sees, from this path only, prologue loads in
+  // flight, and the wait the compiler places there for them (an absolute "at most N outstanding") is
+  // executed on every trip and empties the prefetch queue each time.  Costs one memory latency per launch.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   q8_lds_barrier();
 
   uint32_t it = 0;
   // one iteration = one tile; PAR (its parity) names the LDS buffer read and the fetch group consumed
+#define Q8_STAMP(slot)                                                                                        \
+  if ((ABL & 1024) && blockIdx.x == 0 && it >= 1000 && it < 1016 && lane == 0)                                 \
+    p.dbg[8 + ((it - 1000) * Q8_WAVES + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+#define Q8_G(PAR) (NG == 2 ? ((PAR) ^ 1) : 0)
 #define Q8_ITER(PAR)                                                                                          \
   {                                                                                                           \
-    const float tinv = tinv_cur;                                                                              \
-    i32x16 acc = {0};                                                                                         \
-    if (!(ABL & 4)) {                                                                                         \
-      const char* a_base = smem + (PAR) * L::TILE + aoff;                                                     \
-      _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                     \
-        const i32x4 a = *(const i32x4*)(a_base + 32 * ks);                                                    \
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], acc, 0, 0, 0);                                 \
-      }                                                                                                       \
-    }                                                                                                         \
-    /* fetch group of tile cur+stride (issued two iterations ago): chunks -> int8 -> the other buffer */      \
-    if (cur + stride < p.n_tiles) {                                                                           \
-      convert_tile(f[(PAR) ^ 1], (PAR) ^ 1);                                                                  \
-      tinv_cur = f[(PAR) ^ 1].meta.y;                                                                         \
-    }                                                                                                         \
+    Q8_STAMP(0)                                                                                               \
+    const float tinv = mcur[PAR].y, tsc = mcur[PAR].x;                                                        \
+    i32x16 acc;                                                                                               \
+    acc = mfma_convert(PAR, f[Q8_G(PAR)]);                                                                    \
+    mcur[(PAR) ^ 1] = f[Q8_G(PAR)].meta;                                                                      \
+    Q8_STAMP(1)                                                                                               \
     if (!(ABL & 8)) {                                                                                         \
-      thr = fmaxf(thr, __uint_as_float(f[(PAR) ^ 1].thr));                                                    \
-      if (lane < 32) s_hland[32 * wave + lane] = f[(PAR) ^ 1].hw;                                             \
+      thr = fmaxf(thr, __uint_as_float(f[Q8_G(PAR)].thr));                                                    \
+      if (lane < 32) s_hland[32 * wave + lane] = f[Q8_G(PAR)].hw;                                             \
     }                                                                                                         \
-    if (!(ABL & 1) && live) prune(acc, cur, tinv);                                                            \
+    if (!(ABL & 1) && live) prune(acc, cur, tinv, tsc);                                                            \
     else if (acc[0] == 0x7fffffff) p.cnt2[0] = 1; /* keep the MFMAs alive */                                  \
+    Q8_STAMP(2)                                                                                               \
     /* refill that group with tile cur+3·stride */                                                            \
-    if (!(ABL & 2)) fetch(f[(PAR) ^ 1], clamp_tile(cur + 3 * stride));                                        \
-    ++it;                                                                                                     \
+    if (!(ABL & 2)) fetch(f[Q8_G(PAR)], clamp_tile(cur + (NG + 1) * stride));                                        \
+    Q8_STAMP(3)                                                                                               \
     q8_lds_barrier();                                                                                         \
+    Q8_STAMP(4)                                                                                               \
+    ++it;                                                                                                     \
     /* owner: the histogram landed by all waves before this barrier -> a higher threshold */                  \
     if (!(ABL & 8) && wave == 0 && has_own && (it <= 16 || (it & 3) == 0)) {                                  \
       const int b = rarc_wave_find_from_top_256(s_hland[4 * lane], s_hland[4 * lane + 1],                     \
@@ -297,11 +377,9 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       }                                                                                                       \
     }                                                                                                         \
     /* flush the staged survivors: every tile while thresholds are still forming, then rarely */              \
-    if (!(ABL & 64)) {                                                                                        \
-      const uint32_t ns = *s_nstage; /* same value in every thread: read after the barrier */                 \
-      if (ns > 0 && (it <= 16 || (it & (it - 1)) == 0 || (it & 127) == 0 || ns > (uint32_t)Q8_STAGE / 2))     \
-        flush();                                                                                              \
-    }                                                                                                         \
+    if (!(ABL & 64) && wcount > 0 &&                                                                          \
+        (it <= 16 || (it & (it - 1)) == 0 || (it & 127) == 0 || wcount > (uint32_t)Q8_WSTAGE / 2))            \
+      flush();                                                                                                \
   }
 
   // Always whole pairs of iterations, no exit from the middle of the loop body (a mid-body break makes
@@ -321,9 +399,14 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     }
   }
 #undef Q8_ITER
-  __syncthreads();
+#undef Q8_G
   flush();
+  __syncthreads();
   if (tid < RARC_MAX_QUERIES) p.cnt2[(size_t)blockIdx.x * RARC_MAX_QUERIES + tid] = s_cnt[tid];
+  if (p.dbg && blockIdx.x == 0 && tid == 0) {
+    p.dbg[0] = __builtin_amdgcn_s_memtime() - dbg_c0;
+    p.dbg[1] = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+  }
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -373,6 +456,7 @@ int rarc_scan_q8_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const
   p.seg = (uint32_t)(cap / RARC_MAX_WG);
   p.kprime = (uint32_t)kprime;
   p.nq = (uint32_t)nq;
+  p.dbg = nullptr;
 
   // seed pass (fp16 MFMA on a strided sample): t = k'-th best sample score, accurate to eps16, so
   // t − eps16 bounds the k-th best canonical score from below; rows whose int8 score is under

@@ -34,7 +34,7 @@ class FlatIndexF16:
     """
 
     def __init__(self, dim: int, metric: str = "cosine", device: int = 0, capacity: int = 0,
-                 id_base: int = 0, cand_cap: int = 65536, scan: str = "q8"):
+                 id_base: int = 0, cand_cap: int = 131072, scan: str = "auto"):
         if metric not in ("cosine", "ip"):
             raise ValueError(f"unsupported metric: {metric}")
         if dim <= 0:
@@ -43,12 +43,15 @@ class FlatIndexF16:
         self.lib = B.load_library()
         self.dim = int(dim)
         self.d_pad = B.padded_dim(self.dim)
-        if scan not in ("q8", "mfma16"):
+        if scan not in ("auto", "q8", "mfma16"):
             raise ValueError(f"unknown scan mode: {scan}")
-        limit = 1024 if scan == "q8" else 768
+        limit = 768 if scan == "mfma16" else 1024
         if self.d_pad > limit:
             raise B.RarcError(f"dim {dim} pads to {self.d_pad} > {limit}: not supported by the {scan} scan kernel")
-        self.scan = scan  # "q8": int8 prefilter (default); "mfma16": fp16 MFMA scan + certificate
+        # "q8": int8-prefilter scan (HBM-bound; its error margin costs candidates, which only matters on
+        # small shards); "mfma16": fp16 MFMA scan + certificate (tight margin, matrix-pipe bound);
+        # "auto": q8 from AUTO_Q8_ROWS rows up (and always beyond 768 dims), mfma16 below
+        self.scan = scan
         self.metric = metric
         self.device = self.torch.device("cuda", device)
         self.id_base = int(id_base)
@@ -107,10 +110,17 @@ class FlatIndexF16:
             )
         return self._ws
 
+    AUTO_Q8_ROWS = 4_000_000
+
+    def _use_q8(self) -> bool:
+        if self.scan == "auto":
+            return self.d_pad > 768 or self.ntotal >= self.AUTO_Q8_ROWS
+        return self.scan == "q8"
+
     def _prep(self, q) -> None:
         """rarc_prep_queries into the shared query block (caller holds the lock)."""
         norm = 1 if self.metric == "cosine" else 0
-        qm = self._qmeta.data_ptr() if (self.scan == "q8" and self._qmeta is not None) else 0
+        qm = self._qmeta.data_ptr() if (self._use_q8() and self._qmeta is not None) else 0
         B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
                                            max(self.max_norm, 1.0) if norm else self.max_norm, qm,
                                            self._qbuf["qblock"].data_ptr(), self._stream()), "rarc_prep_queries")
@@ -272,7 +282,7 @@ class FlatIndexF16:
         lo, hi = self._bins(q)
         kp = self.kprime_for(k)
         rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
-        qm = self._qmeta.data_ptr() if (self.scan == "q8" and self._qmeta is not None and self.ntotal) else 0
+        qm = self._qmeta.data_ptr() if (self._use_q8() and self._qmeta is not None and self.ntotal) else 0
         B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k, kp,
                                          self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
                                          status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),

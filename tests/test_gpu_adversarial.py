@@ -9,14 +9,15 @@ pytestmark = pytest.mark.gpu
 def _run(oracle, X, Q, k, metric="cosine"):
     from rag_arc_amd.hip.engine import FlatIndexF16
 
-    idx = FlatIndexF16(X.shape[1], metric=metric)
-    idx.add(X)
-    D, I = idx.search(Q, k)
     rows, _ = oracle.ingest_f16(X, normalize=(metric == "cosine"))
     qn = oracle.normalize_L2(Q) if metric == "cosine" else Q
     rI, rD, _ = oracle.flat_search_f16(rows, qn, k)
-    assert np.array_equal(I, rI), "ids differ"
-    assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), "scores differ"
+    for scan in ("q8", "mfma16"):        # both scan kernels must survive the same abuse
+        idx = FlatIndexF16(X.shape[1], metric=metric, scan=scan)
+        idx.add(X)
+        D, I = idx.search(Q, k)
+        assert np.array_equal(I, rI), f"ids differ ({scan})"
+        assert np.array_equal(D.view(np.uint32), rD.view(np.uint32)), f"scores differ ({scan})"
     return idx
 
 

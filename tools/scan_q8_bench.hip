@@ -31,6 +31,7 @@ static float run(const ScanQ8Params& p, int grid, int iters, const uint16_t* cor
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
+  { unsigned long long h[2]; hipMemcpy(h, p.dbg, 16, hipMemcpyDeviceToHost); printf("  [wg0: %.0f kcycles, clock %.0f MHz] ", h[0] / 1e3, h[1] ? 100.0 * h[0] / h[1] : 0.0); }
   return best * 1000.f;
 }
 
@@ -58,10 +59,16 @@ int main(int argc, char** argv) {
   p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32);
   p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
   p.binlo = ws.binlo; p.binscale = ws.binscale; p.bininv = ws.bininv;
+  { unsigned long long* d; hipMalloc(&d, 65536); hipMemset(d, 0, 65536); p.dbg = d; }
   int grid = 256;
   const double gb = (double)N * D * 2 / 1e9;
 #define RUN(A) { float us = run<A>(p, grid, 6, corpus, N, qb, KP, ws); printf("ABL=%2d  %8.1f us  %6.2f TB/s\n", A, us, gb / us * 1e3); }
-  RUN(0) RUN(0) RUN(1) RUN(32) RUN(64) RUN(8) RUN(4) RUN(21)
+  RUN(0) RUN(0) RUN(1) RUN(4)
+  for (int v = 0; v < 2; ++v) { if (v == 0) run<1024>(p, grid, 1, corpus, N, qb, KP, ws); else run<1025>(p, grid, 1, corpus, N, qb, KP, ws);
+    std::vector<unsigned long long> h(8192); hipMemcpy(h.data(), p.dbg, 65536, hipMemcpyDeviceToHost);
+    printf("\ntimeline wg0 (%s), shader cycles relative to wave0 stamp0 of the iteration:  start  mfma+conv  pruned  fetched  barrier_out | next_start\n", v ? "no prune" : "full");
+    for (int it = 4; it < 8; ++it) for (int w = 0; w < 8; ++w) { const unsigned long long* r = &h[8 + (it * 8 + w) * 8]; unsigned long long b0 = h[8 + (it * 8) * 8]; unsigned long long nb = h[8 + ((it + 1) * 8 + w) * 8];
+      printf("%2d w%d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", it, w, (long long)(r[0] - b0), (long long)(r[1] - b0), (long long)(r[2] - b0), (long long)(r[3] - b0), (long long)(r[4] - b0), (long long)(nb - b0)); } }
   run<0>(p, grid, 1, corpus, N, qb, KP, ws);
   std::vector<uint32_t> cnt(256 * 256); hipMemcpy(cnt.data(), ws.cnt2, 256 * 256 * 4, hipMemcpyDeviceToHost);
   uint64_t tot = 0; uint32_t mx = 0; for (auto c : cnt) { tot += c; mx = c > mx ? c : mx; }
