@@ -14,5 +14,5 @@ for db in glob.glob(os.path.join(root, "**", "*.db"), recursive=True):
             join {info[0]} i on e.pmc_id = i.id join {kd[0]} d on e.event_id = d.event_id
             join {ks[0]} s on d.kernel_id = s.id group by s.kernel_name, i.name"""
     for r in c.execute(q):
-        if "scan_f16" in r[0] or len(sys.argv) > 2:
+        if "rarc_scan" in r[0] or len(sys.argv) > 2:
             print("%-40s %-34s n=%3d mean=%.4g" % (r[0][:40], r[1], r[2], r[3]))
