@@ -230,7 +230,7 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
 // Nothing here is probabilistic: the only failure mode is running out of buffer space, which sets
 // RARC_Q_OVERFLOW and sends the query to rarc_repair_f16.
 // ============================================================================================
-constexpr int FIN8_THREADS = 1024;
+constexpr int FIN8_THREADS = 512;
 constexpr int FIN8_RS = 4096;     // rows rescored canonically per query (G1 ∪ G2)
 constexpr int FIN8_MAXD = 1024;
 
@@ -252,21 +252,31 @@ struct Fin8Params {
   int64_t* out_ids;
   float* out_scores;
   uint32_t* status;
+  unsigned long long* dbg;  // tools: phase stamps of block 0 (100 MHz ticks), else null
 };
 
 __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fin8Params p) {
+  extern __shared__ __attribute__((aligned(16))) char fsm[];  // row staging: [waves][8 rows][2d + 16]
   __shared__ uint64_t ex[FIN8_RS];  // candidate keys; rescored in place (approx key -> canonical key)
   __shared__ __attribute__((aligned(16))) float s_q[FIN8_MAXD];
   __shared__ uint32_t s_hist[RARC_NB];
+  __shared__ uint32_t s_cnt[RARC_MAX_WG];  // candidates each scan workgroup produced for this query
   __shared__ float s_t1, s_L;
   __shared__ uint32_t s_ne, s_over;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float eps = p.eps8[q];
+#define FIN8_STAMP(i) if (p.dbg && q == 0 && tid == 0) p.dbg[i] = __builtin_amdgcn_s_memrealtime();
+  FIN8_STAMP(0)
 
   for (int i = tid; i < RARC_NB; i += blockDim.x) s_hist[i] = p.hist[(size_t)q * RARC_NB + i];
   for (int i = tid; i < p.d; i += blockDim.x) s_q[i] = p.q32[(size_t)q * p.d + i];
   if (tid == 0) { s_ne = 0; s_over = 0; s_L = -INFINITY; }
   __syncthreads();
+  for (int i = tid; i < RARC_MAX_WG; i += blockDim.x) {
+    const uint32_t c = (uint32_t)i < p.n_wg ? p.cnt2[(size_t)i * RARC_MAX_QUERIES + q] : 0u;
+    s_cnt[i] = c;
+    if (c > p.seg) atomicOr(&s_over, 1u);
+  }
   if (tid < 64) {
     uint32_t above;
     const int b = rarc_wave_find_from_top(s_hist, RARC_NB, (uint32_t)p.k, &above);
@@ -275,37 +285,98 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   __syncthreads();
   const float t1 = s_t1;  // -inf when fewer than k candidates exist: then G1 is everything
 
-  // walk the query's segments (4 threads per segment) and append the keys `want` accepts to ex[]
+  // walk the query's segments and append the keys `want` accepts to ex[].  One wave per segment at a
+  // time, 64 consecutive keys per load (coalesced); a wave issues the loads of four segments before it
+  // looks at any of them, so a sweep over ~30K keys costs a handful of memory round trips.
   auto collect = [&](auto want) {
-    for (uint32_t w = tid; w < p.n_wg * 4; w += blockDim.x) {
-      const uint32_t wg = w >> 2, part = w & 3;
-      const uint32_t c = p.cnt2[(size_t)wg * RARC_MAX_QUERIES + q];
-      const uint32_t n = c < p.seg ? c : p.seg;
-      if (c > p.seg && part == 0) atomicOr(&s_over, 1u);
-      const uint64_t* src = p.cand + ((size_t)q * RARC_MAX_WG + wg) * p.seg;
-      for (uint32_t i = part; i < n; i += 4) {
-        const uint64_t key = src[i];
-        if (want(rarc_candscore(key))) {
-          const uint32_t e = atomicAdd(&s_ne, 1u);
-          if (e < FIN8_RS) ex[e] = key;
+    const int lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
+    for (uint32_t wg0 = wv * 4; wg0 < p.n_wg; wg0 += nwv * 4) {
+      uint32_t n[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t wg = wg0 + u;
+        const uint32_t c = wg < p.n_wg ? s_cnt[wg] : 0u;
+        n[u] = c < p.seg ? c : p.seg;
+      }
+      const uint32_t nmax = max(max(n[0], n[1]), max(n[2], n[3]));
+      for (uint32_t base = 0; base < nmax; base += 64) {
+        uint64_t key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t i = base + lane;
+          key[u] = i < n[u] ? p.cand[((size_t)q * RARC_MAX_WG + wg0 + u) * p.seg + i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (base + lane < n[u] && want(rarc_candscore(key[u]))) {
+            const uint32_t e = atomicAdd(&s_ne, 1u);
+            if (e < FIN8_RS) ex[e] = key[u];
+          }
         }
       }
     }
   };
-  auto rescore = [&](int from, int to) {  // dense: one row per thread
-    for (int i = from + tid; i < to; i += blockDim.x) {
-      const uint32_t row = rarc_candrow(ex[i]);
-      ex[i] = rarc_candkey(canon_dot_f16(s_q, p.corpus + (size_t)row * p.d, p.d), row);
+  // Canonical rescore of ex[from..to): 8 lanes per row, lane j runs chain j (elements 8m+j, m
+  // ascending, one fma each — the order the oracle uses), then the canonical tree over the 8 lanes.
+  // A wave stages its 8 rows in LDS with coalesced loads (one instruction covers 8 rows x 128
+  // contiguous bytes) and reads them back transposed, 2 bytes per lane per step; the loads of the
+  // next 64 rows are in flight while the current ones are reduced.  (One row per THREAD, 16 bytes at
+  // a time from 64 different rows per instruction, took 260 µs for 670 rows per query.)
+  auto rescore = [&](int from, int to) {
+    const int lane = tid & 63, wv = tid >> 6, j = lane & 7, rr = lane >> 3;
+    const int rstride = p.d * 2 + 16;                      // +16: the 8 rows of a wave start in 8 different bank groups
+    char* stage = fsm + (size_t)wv * 8 * rstride;          // this wave's 8 rows
+    const int nt = p.d / 64;                               // 16-byte loads per lane per row (8 lanes x 16 B = 128 B per step)
+    uint4 pre[FIN8_MAXD / 64];
+    auto issue = [&](int i) {                              // lane fetches chunks t*8 + j of row ex[i]
+      if (i < to) {
+        const uint4* src = (const uint4*)(p.corpus + (size_t)rarc_candrow(ex[i]) * p.d) + j;
+#pragma unroll
+        for (int t = 0; t < FIN8_MAXD / 64; ++t)
+          if (t < nt) pre[t] = src[t * 8];
+      }
+    };
+    int i = from + wv * 8 + rr;
+    issue(i);
+    for (; i - rr - wv * 8 < to; i += (blockDim.x >> 6) * 8) {  // wave-uniform trip count
+#pragma unroll
+      for (int t = 0; t < FIN8_MAXD / 64; ++t)
+        if (t < nt) *(uint4*)(stage + rr * rstride + (t * 8 + j) * 16) = pre[t];
+      const int cur = i;
+      issue(i + (blockDim.x >> 6) * 8);
+      __builtin_amdgcn_wave_barrier();
+      float acc = 0.f;
+      if (cur < to) {
+        const char* rowp = stage + rr * rstride + 2 * j;
+        for (int m0 = 0; m0 < p.d / 8; m0 += 16) {  // d is a multiple of 128: 16 chain steps per trip
+          float xs[16], qs[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {  // all 32 LDS reads of the trip issued before the first fma
+            xs[u] = (float)*(const half_t*)(rowp + 16 * (m0 + u));
+            qs[u] = s_q[8 * (m0 + u) + j];
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(qs[u], xs[u], acc);
+        }
+      }
+      float a8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] = __shfl(acc, (lane & ~7) + u, 64);
+      if (cur < to && j == 0) ex[cur] = rarc_candkey(rarc_canon_tree(a8), rarc_candrow(ex[cur]));
+      __builtin_amdgcn_wave_barrier();
     }
   };
 
   // ---- step 1: G1 = {a >= T1}: canonical scores, L = k-th best of them ----
+  FIN8_STAMP(1)
   collect([&](float a) { return a >= t1; });
   __syncthreads();
+  FIN8_STAMP(2)
   const uint32_t ne1_all = s_ne;
   const int ne1 = ne1_all < FIN8_RS ? (int)ne1_all : FIN8_RS;
   rescore(0, ne1);
   __syncthreads();
+  FIN8_STAMP(3)
   if (ne1 >= p.k) {  // rank by counting; keys are distinct
     for (int i = tid; i < ne1; i += blockDim.x) {
       const uint64_t mine = ex[i];
@@ -316,14 +387,17 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   }
   __syncthreads();
   const float L = s_L;  // -inf when fewer than k candidates exist (then G1 already holds them all)
+  FIN8_STAMP(4)
 
   // ---- step 2: G2 = {a < T1, a + eps >= L}: canonical scores ----
   if (ne1_all <= (uint32_t)FIN8_RS && t1 > -INFINITY) collect([&](float a) { return a < t1 && a + eps * 1.0001f >= L; });
   __syncthreads();
+  FIN8_STAMP(5)
   const uint32_t ne_all = s_ne;
   const int ne = ne_all < FIN8_RS ? (int)ne_all : FIN8_RS;
   rescore(ne1, ne);
   __syncthreads();
+  FIN8_STAMP(6)
 
   // ---- step 3: exact order (canonical score desc, id asc) by counting ----
   const int kk = ne < p.k ? ne : p.k;
@@ -343,6 +417,8 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       p.out_scores[(size_t)q * p.k + rank] = rarc_candscore(mine);
     }
   }
+  FIN8_STAMP(7)
+  if (p.dbg && q == 0 && tid == 0) { p.dbg[8] = ne1_all; p.dbg[9] = ne_all; }
   if (tid == 0) {
     uint32_t st = RARC_Q_OK;
     if (s_over || ne_all > (uint32_t)FIN8_RS) st |= RARC_Q_OVERFLOW;
@@ -354,6 +430,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   }
 }
 
+unsigned long long* g_fin8_dbg = nullptr;  // set by tools only
 int rarc_finalize_q8_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps8, int nq, int k,
                             int64_t id_base, const RarcWs& ws, int cap, int n_wg, int64_t* out_ids,
                             float* out_scores, uint32_t* status, hipStream_t s) {
@@ -376,7 +453,17 @@ int rarc_finalize_q8_launch(const uint16_t* corpus, int d_pad, const float* q32,
   p.out_ids = out_ids;
   p.out_scores = out_scores;
   p.status = status;
-  hipLaunchKernelGGL(rarc_finalize_q8_kernel, dim3(nq), dim3(FIN8_THREADS), 0, s, p);
+  p.dbg = g_fin8_dbg;
+  // 8 waves stage 8 rows each up to d = 768 (97 KB); wider rows: 4 waves (66 KB at d = 1024)
+  const int threads = d_pad <= 768 ? FIN8_THREADS : FIN8_THREADS / 2;
+  const size_t lds = (size_t)(threads / 64) * 8 * ((size_t)d_pad * 2 + 16);
+  static size_t lds_attr = 0;
+  if (lds > lds_attr) {
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_finalize_q8_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_attr = lds;
+  }
+  hipLaunchKernelGGL(rarc_finalize_q8_kernel, dim3(nq), dim3(threads), lds, s, p);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

@@ -8,6 +8,7 @@
 #include "../rag-arc_amd/csrc/scan_q8.hip"
 #include "../rag-arc_amd/csrc/quant.hip"
 #include "../rag-arc_amd/csrc/prep.hip"
+#include "../rag-arc_amd/csrc/finalize.hip"
 void rarc_set_error(const char* fmt, ...) { (void)fmt; }
 bool rarc_prof_next(hipEvent_t*, hipEvent_t*) { return false; }
 
@@ -63,13 +64,26 @@ int main(int argc, char** argv) {
   int grid = 256;
   const double gb = (double)N * D * 2 / 1e9;
 #define RUN(A) { float us = run<A>(p, grid, 6, corpus, N, qb, KP, ws); printf("ABL=%2d  %8.1f us  %6.2f TB/s\n", A, us, gb / us * 1e3); }
-  RUN(0) RUN(0) RUN(1) RUN(4)
-  for (int v = 0; v < 2; ++v) { if (v == 0) run<1024>(p, grid, 1, corpus, N, qb, KP, ws); else run<1025>(p, grid, 1, corpus, N, qb, KP, ws);
+  RUN(0) RUN(0)
+  for (int v = 0; v < 0; ++v) { if (v == 0) run<1024>(p, grid, 1, corpus, N, qb, KP, ws); else run<1025>(p, grid, 1, corpus, N, qb, KP, ws);
     std::vector<unsigned long long> h(8192); hipMemcpy(h.data(), p.dbg, 65536, hipMemcpyDeviceToHost);
     printf("\ntimeline wg0 (%s), shader cycles relative to wave0 stamp0 of the iteration:  start  mfma+conv  pruned  fetched  barrier_out | next_start\n", v ? "no prune" : "full");
     for (int it = 4; it < 8; ++it) for (int w = 0; w < 8; ++w) { const unsigned long long* r = &h[8 + (it * 8 + w) * 8]; unsigned long long b0 = h[8 + (it * 8) * 8]; unsigned long long nb = h[8 + ((it + 1) * 8 + w) * 8];
       printf("%2d w%d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", it, w, (long long)(r[0] - b0), (long long)(r[1] - b0), (long long)(r[2] - b0), (long long)(r[3] - b0), (long long)(r[4] - b0), (long long)(nb - b0)); } }
   run<0>(p, grid, 1, corpus, N, qb, KP, ws);
+  { // finalize timing
+    int64_t* oi; float* os; uint32_t* st; hipMalloc(&oi, 256 * 100 * 8); hipMalloc(&os, 256 * 100 * 4); hipMalloc(&st, 257 * 4); hipMemset(st, 0, 257 * 4);
+    unsigned long long* fd; hipMalloc(&fd, 256); hipMemset(fd, 0, 256); g_fin8_dbg = fd;
+    hipEvent_t f0, f1; hipEventCreate(&f0); hipEventCreate(&f1);
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(f0, 0);
+      rarc_finalize_q8_launch(corpus, D, qb.q32, qb.eps8, 256, 100, 0, ws, CAP, grid, oi, os, st, 0);
+      hipEventRecord(f1, 0); hipEventSynchronize(f1); float ms; hipEventElapsedTime(&ms, f0, f1);
+      unsigned long long h[10]; hipMemcpy(h, fd, 80, hipMemcpyDeviceToHost);
+      printf("finalize: %.1f us; block0 phases (us): init %.1f collect1 %.1f rescore1 %.1f rankL %.1f collect2 %.1f rescore2 %.1f final %.1f; |G1|=%llu |G1+G2|=%llu\n", ms * 1000,
+             (h[1]-h[0])/100.0, (h[2]-h[1])/100.0, (h[3]-h[2])/100.0, (h[4]-h[3])/100.0, (h[5]-h[4])/100.0, (h[6]-h[5])/100.0, (h[7]-h[6])/100.0, h[8], h[9]);
+    }
+  }
   std::vector<uint32_t> cnt(256 * 256); hipMemcpy(cnt.data(), ws.cnt2, 256 * 256 * 4, hipMemcpyDeviceToHost);
   uint64_t tot = 0; uint32_t mx = 0; for (auto c : cnt) { tot += c; mx = c > mx ? c : mx; }
   printf("mean candidates/query: %.0f   max per (wg,query) segment: %u (seg %u)\n", tot / 256.0, mx, p.seg);
