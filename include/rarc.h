@@ -95,6 +95,14 @@ int rarc_quant_meta_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad,
                         float* d_qmeta, void* stream);
 
 /*
+ * Test hook: the dense matrix of int8-prefilter scores of a small shard (n_rows <= 2^22),
+ * d_out [nq][n_rows] fp32, computed with the scan's own quantisation routine.  Lets a test check
+ * |canonical - approx| <= eps8[q] for every (query, row) pair; not used by any search.
+ */
+int rarc_debug_q8_scores(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_qmeta,
+                         const void* d_qblock, int nq, float* d_out, void* stream);
+
+/*
  * Query preparation: fp32 queries [nq][ld_in] -> the "query block" the search reads:
  * (optionally L2-normalised) fp32 copy [RARC_MAX_QUERIES][d_pad] (zero padded), fp16 copy (seed
  * pass / fp16 scan), int8 copy + scale (int8 prefilter), and the per-query error bounds of both

@@ -118,3 +118,43 @@ extern "C" int rarc_quant_meta_f16(const uint16_t* d_corpus_f16, int64_t n_rows,
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
+
+// ---- test hook: the dense int8 score matrix of a small shard -------------------------------------
+// approx[q][r] = <q8[q], d8[r]> * qinv[q] / s_tile(r), computed with the same rarc_quant8_chunk() as
+// the scan (one thread per (query, row); no MFMA).  tests/ compare it with canonical scores to check
+// the error bound eps8 on adversarial data: |canonical - approx| <= eps8[q] for EVERY pair.
+__global__ __launch_bounds__(256) void rarc_q8_scores_kernel(const uint4* __restrict__ corpus, int d_pad,
+                                                             uint32_t n_rows, const float* __restrict__ meta,
+                                                             const int8_t* __restrict__ q8,
+                                                             const float* __restrict__ qinv, int nq,
+                                                             float* __restrict__ out) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = blockIdx.y;
+  if (r >= n_rows || q >= nq) return;
+  const uint32_t t = r / 32;
+  const half_t s = (half_t)meta[RARC_QMETA_HDR + 2 * (size_t)t];
+  const float tinv = meta[RARC_QMETA_HDR + 2 * (size_t)t + 1];
+  const uint4* row = corpus + (size_t)r * (d_pad / 8);
+  const int8_t* qp = q8 + (size_t)q * d_pad;
+  int acc = 0;
+  for (int c = 0; c < d_pad / 8; ++c) {
+    const uint2 o = rarc_quant8_chunk(row[c], s);
+    const uint32_t w[2] = {o.x, o.y};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += (int)(int8_t)(w[e >> 2] >> (8 * (e & 3))) * (int)qp[8 * c + e];
+  }
+  out[(size_t)q * n_rows + r] = (float)acc * (qinv[q] * tinv);
+}
+
+extern "C" int rarc_debug_q8_scores(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const float* d_qmeta,
+                                    const void* d_qblock, int nq, float* d_out, void* stream) {
+  RARC_REQUIRE(d_corpus_f16 && d_qmeta && d_qblock && d_out && n_rows > 0 && n_rows <= (1 << 22) && nq >= 1 &&
+                   nq <= RARC_MAX_QUERIES && d_pad > 0 && d_pad % RARC_DIM_ALIGN == 0,
+               RARC_E_INVALID, "rarc_debug_q8_scores: bad arguments");
+  const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
+  hipLaunchKernelGGL(rarc_q8_scores_kernel, dim3((unsigned)((n_rows + 255) / 256), (unsigned)nq), dim3(256), 0,
+                     (hipStream_t)stream, (const uint4*)d_corpus_f16, d_pad, (uint32_t)n_rows, d_qmeta, qb.q8, qb.qinv,
+                     nq, d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     if (__builtin_amdgcn_ballot_w64(pass) != 0) {
       const uint32_t row0 = tile * 32 + 4 * h;
       // every score s with (float)s*sc >= thr satisfies s >= ti (one unit + 1e-6 relative of slack)
-      const float tq = thr * (my_sq8 * tsc);  // thr / sc up to rounding
+      const float tq = fmaxf(thr * (my_sq8 * tsc), -2.0e9f);  // thr / sc up to rounding; -inf (no threshold yet) clamped
       const int ti = pass ? (int)__builtin_floorf(tq - 1.0f - __builtin_fabsf(tq) * 2e-6f) : 0x7fffffff;
       int c = 0;
 #pragma unroll

@@ -36,6 +36,7 @@ SIGNATURES = {
     "rarc_ingest_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rarc_quant_meta_floats": (c_size_t, [c_int64]),
     "rarc_quant_meta_f16": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "rarc_debug_q8_scores": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "rarc_query_block_bytes": (c_size_t, [c_int]),
     "rarc_prep_queries": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                   c_void_p]),
