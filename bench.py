@@ -33,14 +33,25 @@ def parse():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--storage", choices=("f16", "f8"), default="f16",
+                    help="row storage: fp16 (default) or fp8 e4m3fn + per-row scale (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true")
     return ap.parse_args()
 
 
-def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="auto"):
+def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="auto", storage="f16"):
     """HBM-resident shard holding global rows [lo, hi) of the synthetic corpus."""
     n = hi - lo
+    if storage == "f8":  # synthetic fp32 rows -> ingest kernel (normalise, per-row scale, e4m3fn), in slabs
+        idx = FlatIndexF16(dim, metric="cosine", device=dev_index, id_base=lo, storage="f8", capacity=n)
+        slab = 1 << 18
+        buf = torch.empty((min(slab, max(n, 1)), dim), dtype=torch.float32, device=torch.device("cuda", dev_index))
+        for s0 in range(0, n, slab):
+            m = min(slab, n - s0)
+            B.check(lib.rarc_synth_rows_f32(buf.data_ptr(), dim, dim, lo + s0, m, seed, 0), "rarc_synth_rows_f32")
+            idx.add(buf[:m])
+        return idx
     d_pad = B.padded_dim(dim)
     cap = ((n + 31) // 32) * 32
     rows = torch.empty((max(cap, 32), d_pad), dtype=torch.float16, device=torch.device("cuda", dev_index))
@@ -107,15 +118,16 @@ def main():
     from rag_arc_amd.hip.sharded import ShardedFlatSearch, shard_range
 
     lib = B.load_library()
-    d_pad = B.padded_dim(a.dim)
+    d_pad = B.padded_dim(a.dim, 256 if a.storage == "f8" else 128)
+    esize = 1 if a.storage == "f8" else 2
     rows = a.rows
     if rows <= 0:  # auto: config 4's corpus if every rank's shard (+ slack) fits its HBM
         free = torch.cuda.mem_get_info(dev)[0]
         rows = 100_000_000
-        while rows > 1_000_000 and (rows / world) * d_pad * 2 > 0.85 * free:
+        while rows > 1_000_000 and (rows / world) * d_pad * esize > 0.85 * free:
             rows //= 10
     lo, hi = shard_range(rows, rank, world)
-    idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi)
+    idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi, storage=a.storage)
     searcher = ShardedFlatSearch(idx, force_collective=use_dist)
     q = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev)
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), a.dim, a.dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
@@ -131,7 +143,7 @@ def main():
     tot_ms, n_l = ctypes.c_double(0), ctypes.c_int(0)
     B.check(lib.rarc_profile_end(ctypes.byref(tot_ms), ctypes.byref(n_l)), "rarc_profile_end")
     scan_ms = tot_ms.value / max(1, n_l.value)
-    shard_bytes = (hi - lo) * d_pad * 2  # algorithmic bytes of one scan launch on this rank
+    shard_bytes = (hi - lo) * d_pad * esize  # algorithmic bytes of one scan launch on this rank
     flagged = len(getattr(idx, "last_repaired", []))
     # full-size exactness property on this rank's shard: the exact repair scan must find no row
     # beating the returned k-th entry (local results, before the cross-shard merge)
@@ -157,8 +169,8 @@ def main():
             "metric": "queries/sec at fixed (N_corpus, d), exact top-k (ids bit-exact vs CPU oracle)",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{rows}x{a.dim} fp16 corpus resident in HBM, row-sharded over {world} GPU(s), "
+            "vs_baseline": None, "dtype": a.storage, "data": "synthetic",
+            "config": {"workload": f"{rows}x{a.dim} {'fp8 (e4m3fn + row scale)' if a.storage == 'f8' else 'fp16'} corpus resident in HBM, row-sharded over {world} GPU(s), "
                                    f"batch {a.batch} queries, cosine top-{a.k}, exact (canonical fp32 rescore)",
                        "n_corpus": rows, "d": a.dim, "batch": a.batch, "k": a.k, "rows_per_gpu": hi - lo,
                        "repaired_queries_last_step": flagged,
@@ -171,7 +183,7 @@ def main():
         }
 
     # ---- config 2 (1M x 768, one GPU) for reference, and the CPU baseline on the same sample -----
-    if rank == 0 and not a.no_c2:
+    if rank == 0 and not a.no_c2 and a.storage == "f16":
         n2 = min(1_000_000, rows)
         idx2 = idx if (world == 1 and rows == n2) else build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, 0, n2)
         s2 = ShardedFlatSearch.__new__(ShardedFlatSearch)

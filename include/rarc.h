@@ -164,6 +164,33 @@ int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, con
                     uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * fp8 corpus (BASELINE.json config 5's storage): rows of OCP e4m3fn bytes, d_pad a multiple of 256
+ * (rarc_padded_dim_f8), plus one fp32 scale per row: value[m] = d_row_scale[r] * decode(byte[m]).
+ * Half the HBM footprint and scan traffic of fp16.  The calls mirror their fp16 counterparts:
+ *   rarc_ingest_f8      normalise (as rarc_ingest_f16), scale = max|x| / 448, byte = encode(x / scale)
+ *                       (round to nearest even, saturating); d_row_norm2 optional
+ *   rarc_quant_meta_f8  metadata for the int8-prefilter scan: rarc_quant_meta_floats_f8(n_rows) floats,
+ *                       [0] = R as for fp16, then per 32-row tile: scale, 1/scale, 32 row multipliers
+ *   rarc_search_f8      int8-prefilter scan + canonical finalize; the canonical score of a row is
+ *                       d_row_scale[r] * (canonical fp32 dot of the query with the decoded bytes)
+ *   rarc_repair_f8      exact single-query repair / verification
+ * The query block is the one rarc_prep_queries writes (same d_pad; pass the fp8 d_qmeta).
+ */
+int rarc_padded_dim_f8(int d);
+int rarc_ingest_f8(const float* d_in, int64_t ld_in, uint8_t* d_corpus_f8, int d_pad, float* d_row_scale,
+                   float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream);
+size_t rarc_quant_meta_floats_f8(int64_t n_rows);
+int rarc_quant_meta_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t n_rows, int d_pad,
+                       int64_t first_row, float* d_qmeta, void* stream);
+int rarc_search_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t n_rows, int d_pad,
+                   const float* d_qmeta, const void* d_qblock, int nq, int k, int kprime, int64_t id_base,
+                   float bin_lo, float bin_hi, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
+                   void* d_workspace, size_t workspace_bytes, int cand_cap, void* stream);
+int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t n_rows, int d_pad,
+                   const void* d_qblock, int q, int k, int64_t id_base, int64_t* d_out_ids, float* d_out_scores,
+                   uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Merge G sorted candidate lists per query into the global top-k
  * (score desc, id asc).  Used after the RCCL all-gather of per-shard results
  * (SURVEY.md §8e).  Inputs are [G][nq][k]; outputs [nq][k].

@@ -87,6 +87,57 @@ def ingest_f16(x: np.ndarray, normalize: bool = True, d_pad: int | None = None) 
     return out, n2
 
 
+def ingest_f8(x: np.ndarray, normalize: bool = True, d_pad: int | None = None):
+    """add_texts side for an fp8 (e4m3fn + per-row fp32 scale) flat index — BASELINE config 5's storage.
+    Returns (bytes uint8 [n][d_pad], scales fp32 [n], squared norms of the stored rows [n]).
+    d_pad defaults to the next multiple of 256 (the fp8 scan reads 16-byte chunks of 16 values)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, d = x.shape
+    d_pad = d_pad or padded_dim(d, 256)
+    out = np.zeros((n, d_pad), dtype=np.uint8)
+    sc = np.ones(n, dtype=np.float32)
+    n2 = np.zeros(n, dtype=np.float32)
+    if n:
+        lib().oracle_ingest_f8(_p(x), ctypes.c_int64(d), _p(out), ctypes.c_int(d_pad), _p(sc), _p(n2),
+                               ctypes.c_int64(n), ctypes.c_int(d), ctypes.c_int(1 if normalize else 0))
+    return out, sc, n2
+
+
+def f8_decode(b: np.ndarray) -> np.ndarray:
+    """e4m3fn bytes -> fp32 (exact)."""
+    L = lib()
+    L.oracle_f8_decode.restype = ctypes.c_float
+    lut = np.array([L.oracle_f8_decode(ctypes.c_uint8(i)) for i in range(256)], dtype=np.float32)
+    return lut[np.asarray(b, dtype=np.uint8)]
+
+
+def f8_encode(x: np.ndarray) -> np.ndarray:
+    """fp32 -> e4m3fn bytes: round to nearest even, saturating at 448 (scalar loop: small inputs only)."""
+    L = lib()
+    L.oracle_f8_encode.restype = ctypes.c_uint8
+    flat = np.asarray(x, dtype=np.float32).ravel()
+    return np.array([L.oracle_f8_encode(ctypes.c_float(float(v))) for v in flat], dtype=np.uint8).reshape(np.shape(x))
+
+
+def flat_search_f8(corpus_u8: np.ndarray, scales: np.ndarray, q32: np.ndarray, k: int, id_base: int = 0):
+    """IndexFlatIP.search over fp8 rows: score = scale[r] * canonical fp32 dot(q, decoded bytes).
+    Ties: id ascending.  Returns (ids int64 [nq][k], scores fp32 [nq][k], threads used)."""
+    corpus_u8 = np.ascontiguousarray(corpus_u8, dtype=np.uint8)
+    scales = np.ascontiguousarray(scales, dtype=np.float32)
+    n, d_pad = corpus_u8.shape
+    q32 = np.ascontiguousarray(q32, dtype=np.float32)
+    if q32.shape[1] != d_pad:
+        q32 = pad_queries(q32, d_pad)
+    nq = q32.shape[0]
+    ids = np.full((nq, k), -1, dtype=np.int64)
+    sc = np.full((nq, k), -np.inf, dtype=np.float32)
+    L = lib()
+    L.oracle_flat_search_f8.restype = ctypes.c_int
+    nt = L.oracle_flat_search_f8(_p(corpus_u8), _p(scales), ctypes.c_int64(n), ctypes.c_int(d_pad), _p(q32),
+                                 ctypes.c_int(nq), ctypes.c_int(k), ctypes.c_int64(id_base), _p(ids), _p(sc))
+    return ids, sc, int(nt)
+
+
 def pad_queries(q: np.ndarray, d_pad: int) -> np.ndarray:
     q = np.ascontiguousarray(q, dtype=np.float32)
     out = np.zeros((q.shape[0], d_pad), dtype=np.float32)

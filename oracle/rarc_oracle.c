@@ -243,6 +243,139 @@ void oracle_score_rows_f16(const uint16_t* corpus, int d_pad, const float* qv, c
   for (int i = 0; i < n; ++i) out[i] = oracle_canon_dot_f16(qv, corpus + rows[i] * (int64_t)d_pad, d_pad);
 }
 
+/* ---- fp8 (OCP e4m3fn) storage: BASELINE config 5's corpus format -----------------------------------
+ * A stored row is d_pad bytes of e4m3fn (1 sign, 4 exponent bits bias 7, 3 mantissa bits, no inf,
+ * max 448, subnormals m*2^-9) plus one fp32 scale per row: value[m] = scale * decode(byte[m]).
+ * Ingest (the fp8 form of add_texts, VectorStore_Faiss.py:170-202): normalise as for fp16, scale =
+ * max|x| / 448 (1 for a zero row), byte = encode(x / scale), encode = round to nearest even with
+ * saturation at 448.  Canonical score = scale * (canonical fp32 dot of q with the decoded bytes): the
+ * decoded values are exact in fp32 (and in fp16), the one multiply by the scale rounds once.
+ * The HIP kernels (prep.hip: rarc_f8_encode / rarc_f8_decode) use the same integer algorithm.       */
+static inline float f8_decode(uint8_t b) {
+  const uint32_t e = (b >> 3) & 15, m = b & 7;
+  float v = e ? ldexpf((float)(8 + m), (int)e - 10) : ldexpf((float)m, -9);
+  if (e == 15 && m == 7) v = 0.0f; /* NaN code: never produced by the encoder; decodes to 0 */
+  return (b & 0x80) ? -v : v;
+}
+static inline uint8_t f8_encode(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+  u &= 0x7fffffffu;
+  float a;
+  memcpy(&a, &u, 4);
+  if (!(a == a)) return sign;          /* NaN -> 0 */
+  if (a >= 448.0f) return sign | 0x7e; /* saturate (also +-inf) */
+  if (a < 0.015625f) {                 /* below 2^-6: subnormal grid of 2^-9; 8 -> 0x08 = 2^-6 */
+    return sign | (uint8_t)(int)rintf(a * 512.0f);
+  }
+  uint32_t r = u + 0x0007ffffu + ((u >> 20) & 1u); /* RNE at mantissa bit 20 */
+  r >>= 20;                                        /* (exp8 << 3) | mant3 */
+  uint32_t code = r - ((127u - 7u) << 3);
+  if (code > 0x7eu) code = 0x7eu;
+  return sign | (uint8_t)code;
+}
+uint8_t oracle_f8_encode(float x) { return f8_encode(x); }
+float oracle_f8_decode(uint8_t b) { return f8_decode(b); }
+
+void oracle_ingest_f8(const float* in, int64_t ld, uint8_t* out, int d_pad, float* scale_out, float* norm2,
+                      int64_t n, int d, int normalize) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) {
+    const float* v = in + r * ld;
+    uint8_t* o = out + r * (int64_t)d_pad;
+    float inv = 1.0f;
+    int sc = 0;
+    if (normalize) {
+      const float nr = canon_sumsq_f32(v, d);
+      if (nr > 0) { inv = (float)(1.0 / sqrtf(nr)); sc = 1; }
+    }
+    float mx = 0.0f;
+    for (int m = 0; m < d; ++m) {
+      const float x = fabsf(sc ? v[m] * inv : v[m]);
+      if (x > mx) mx = x;
+    }
+    const float scale = (mx > 0.0f && mx < INFINITY) ? mx / 448.0f : 1.0f;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < d_pad; ++m) {
+      uint8_t b = 0;
+      if (m < d) b = f8_encode((sc ? v[m] * inv : v[m]) / scale);
+      o[m] = b;
+      const float f = f8_decode(b);
+      a[m & 7] = fmaf(f, f, a[m & 7]);
+    }
+    scale_out[r] = scale;
+    /* squared norm of the stored row: scale^2 * canonical sum of squares of the decoded bytes */
+    if (norm2) norm2[r] = (scale * scale) * (((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7])));
+  }
+}
+
+float oracle_canon_dot_f8(const float* q, const uint8_t* row, float scale, int d) {
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int m = 0; m < d; m += 8)
+    for (int j = 0; j < 8; ++j) a[j] = fmaf(q[m + j], f8_decode(row[m + j]), a[j]);
+  return scale * (((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7])));
+}
+
+/* exact flat search over an fp8 corpus; same contract as oracle_flat_search_f16 */
+int oracle_flat_search_f8(const uint8_t* corpus, const float* scales, int64_t n, int d_pad, const float* q, int nq,
+                          int k, int64_t id_base, int64_t* out_ids, float* out_scores) {
+  int nthreads = 1;
+#ifdef _OPENMP
+  nthreads = omp_get_max_threads();
+#endif
+  if (k < 1 || nq < 1) return nthreads;
+  float lut[256];
+  for (int b = 0; b < 256; ++b) lut[b] = f8_decode((uint8_t)b);
+  uint64_t* heaps = (uint64_t*)malloc((size_t)nthreads * nq * k * sizeof(uint64_t));
+  int* hn = (int*)calloc((size_t)nthreads * nq, sizeof(int));
+#pragma omp parallel
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    uint64_t* H = heaps + (size_t)tid * nq * k;
+    int* N = hn + (size_t)tid * nq;
+    float* rowf = (float*)aligned_alloc(32, (size_t)d_pad * sizeof(float));
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t r = 0; r < n; ++r) {
+      const uint8_t* src = corpus + r * (int64_t)d_pad;
+      for (int m = 0; m < d_pad; ++m) rowf[m] = lut[src[m]];
+      for (int qi = 0; qi < nq; ++qi) {
+        const float* qv = q + (size_t)qi * d_pad;
+        __m256 a0 = _mm256_setzero_ps();
+        for (int m = 0; m < d_pad; m += 8) a0 = _mm256_fmadd_ps(_mm256_loadu_ps(qv + m), _mm256_load_ps(rowf + m), a0);
+        heap_push(H + (size_t)qi * k, &N[qi], k, candkey(scales[r] * tree8(a0), (uint32_t)r));
+      }
+    }
+    free(rowf);
+  }
+  uint64_t* all = (uint64_t*)malloc((size_t)nthreads * k * sizeof(uint64_t));
+  for (int qi = 0; qi < nq; ++qi) {
+    int c = 0;
+    for (int t = 0; t < nthreads; ++t) {
+      const int m = hn[(size_t)t * nq + qi];
+      memcpy(all + c, heaps + ((size_t)t * nq + qi) * k, (size_t)m * sizeof(uint64_t));
+      c += m;
+    }
+    qsort(all, (size_t)c, sizeof(uint64_t), cmp_desc_u64);
+    for (int i = 0; i < k; ++i) {
+      if (i < c) {
+        out_ids[(size_t)qi * k + i] = id_base + (int64_t)(uint32_t)(~(uint32_t)all[i]);
+        out_scores[(size_t)qi * k + i] = unordkey((uint32_t)(all[i] >> 32));
+      } else {
+        out_ids[(size_t)qi * k + i] = -1;
+        out_scores[(size_t)qi * k + i] = -INFINITY;
+      }
+    }
+  }
+  free(all);
+  free(heaps);
+  free(hn);
+  return nthreads;
+}
+
 /* ---- deterministic synthetic rows (mirrors rag-arc_amd/csrc/prep.hip: rarc_synth_kernel) ------ */
 static inline uint64_t synth_mix(uint64_t z) {
   z += 0x9e3779b97f4a7c15ull;

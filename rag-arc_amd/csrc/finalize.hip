@@ -235,7 +235,9 @@ constexpr int FIN8_RS = 4096;     // rows rescored canonically per query (G1 ∪
 constexpr int FIN8_MAXD = 1024;
 
 struct Fin8Params {
-  const half_t* corpus;
+  const void* corpus;      // fp16 rows (fmt 0) or fp8 rows (fmt 1)
+  const float* rowscale;   // fmt 1: per-row scales
+  int fmt;
   const float* q32;   // [256][d]
   const float* eps8;  // [256]
   const uint32_t* cnt2;
@@ -324,13 +326,14 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   // a time from 64 different rows per instruction, took 260 µs for 670 rows per query.)
   auto rescore = [&](int from, int to) {
     const int lane = tid & 63, wv = tid >> 6, j = lane & 7, rr = lane >> 3;
-    const int rstride = p.d * 2 + 16;                      // +16: the 8 rows of a wave start in 8 different bank groups
+    const int rbytes = p.fmt ? p.d : p.d * 2;              // bytes of one stored row
+    const int rstride = rbytes + 16;                       // +16: the 8 rows of a wave start in 8 different bank groups
     char* stage = fsm + (size_t)wv * 8 * rstride;          // this wave's 8 rows
-    const int nt = p.d / 64;                               // 16-byte loads per lane per row (8 lanes x 16 B = 128 B per step)
+    const int nt = rbytes / 128;                           // 16-byte loads per lane per row (8 lanes x 16 B = 128 B per step)
     uint4 pre[FIN8_MAXD / 64];
     auto issue = [&](int i) {                              // lane fetches chunks t*8 + j of row ex[i]
       if (i < to) {
-        const uint4* src = (const uint4*)(p.corpus + (size_t)rarc_candrow(ex[i]) * p.d) + j;
+        const uint4* src = (const uint4*)((const char*)p.corpus + (size_t)rarc_candrow(ex[i]) * rbytes) + j;
 #pragma unroll
         for (int t = 0; t < FIN8_MAXD / 64; ++t)
           if (t < nt) pre[t] = src[t * 8];
@@ -347,22 +350,41 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       __builtin_amdgcn_wave_barrier();
       float acc = 0.f;
       if (cur < to) {
-        const char* rowp = stage + rr * rstride + 2 * j;
-        for (int m0 = 0; m0 < p.d / 8; m0 += 16) {  // d is a multiple of 128: 16 chain steps per trip
-          float xs[16], qs[16];
+        if (p.fmt) {  // fp8: element 8m + j is byte 8m + j of the row
+          const char* rowp = stage + rr * rstride + j;
+          for (int m0 = 0; m0 < p.d / 8; m0 += 16) {
+            float xs[16], qs[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {  // all 32 LDS reads of the trip issued before the first fma
-            xs[u] = (float)*(const half_t*)(rowp + 16 * (m0 + u));
-            qs[u] = s_q[8 * (m0 + u) + j];
+            for (int u = 0; u < 16; ++u) {
+              xs[u] = __builtin_amdgcn_cvt_f32_fp8((uint32_t) * (const uint8_t*)(rowp + 8 * (m0 + u)), 0);
+              qs[u] = s_q[8 * (m0 + u) + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(qs[u], xs[u], acc);
           }
+        } else {
+          const char* rowp = stage + rr * rstride + 2 * j;
+          for (int m0 = 0; m0 < p.d / 8; m0 += 16) {  // d is a multiple of 128: 16 chain steps per trip
+            float xs[16], qs[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(qs[u], xs[u], acc);
+            for (int u = 0; u < 16; ++u) {  // all 32 LDS reads of the trip issued before the first fma
+              xs[u] = (float)*(const half_t*)(rowp + 16 * (m0 + u));
+              qs[u] = s_q[8 * (m0 + u) + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(qs[u], xs[u], acc);
+          }
         }
       }
       float a8[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) a8[u] = __shfl(acc, (lane & ~7) + u, 64);
-      if (cur < to && j == 0) ex[cur] = rarc_candkey(rarc_canon_tree(a8), rarc_candrow(ex[cur]));
+      if (cur < to && j == 0) {
+        const uint32_t row = rarc_candrow(ex[cur]);
+        float sc = rarc_canon_tree(a8);
+        if (p.fmt) sc = p.rowscale[row] * sc;
+        ex[cur] = rarc_candkey(sc, row);
+      }
       __builtin_amdgcn_wave_barrier();
     }
   };
@@ -431,12 +453,14 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
 }
 
 unsigned long long* g_fin8_dbg = nullptr;  // set by tools only
-int rarc_finalize_q8_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps8, int nq, int k,
-                            int64_t id_base, const RarcWs& ws, int cap, int n_wg, int64_t* out_ids,
-                            float* out_scores, uint32_t* status, hipStream_t s) {
+int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
+                            const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
+                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s) {
   RARC_REQUIRE(d_pad <= FIN8_MAXD, RARC_E_UNSUPPORTED, "rarc_finalize_q8: d_pad %d > %d", d_pad, FIN8_MAXD);
   Fin8Params p;
-  p.corpus = (const half_t*)corpus;
+  p.corpus = corpus;
+  p.rowscale = rowscale;
+  p.fmt = fmt;
   p.q32 = q32;
   p.eps8 = eps8;
   p.cnt2 = ws.cnt2;
@@ -455,8 +479,8 @@ int rarc_finalize_q8_launch(const uint16_t* corpus, int d_pad, const float* q32,
   p.status = status;
   p.dbg = g_fin8_dbg;
   // 8 waves stage 8 rows each up to d = 768 (97 KB); wider rows: 4 waves (66 KB at d = 1024)
-  const int threads = d_pad <= 768 ? FIN8_THREADS : FIN8_THREADS / 2;
-  const size_t lds = (size_t)(threads / 64) * 8 * ((size_t)d_pad * 2 + 16);
+  const int threads = (fmt || d_pad <= 768) ? FIN8_THREADS : FIN8_THREADS / 2;
+  const size_t lds = (size_t)(threads / 64) * 8 * ((size_t)d_pad * (fmt ? 1 : 2) + 16);
   static size_t lds_attr = 0;
   if (lds > lds_attr) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_finalize_q8_kernel,
@@ -472,8 +496,30 @@ int rarc_finalize_q8_launch(const uint16_t* corpus, int d_pad, const float* q32,
 // Exact repair of one query: full canonical scan of the shard; rows that beat the current k-th
 // entry are appended; then the row is re-sorted.  O(n_rows * d) reads — the rare path.
 // ============================================================================================
+// canonical fp32 dot of a fp32 query with an fp8 (e4m3fn) row, times the row's scale (d multiple of 16)
+__device__ __forceinline__ float canon_dot_f8(const float* __restrict__ q, const uint8_t* __restrict__ row, int d,
+                                              float scale) {
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int m = 0; m < d; m += 16) {
+    const uint4 v = *(const uint4*)(row + m);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[4];
+      rarc_f8x4_to_f32(w[i], f);
+      const int e0 = 4 * i;  // elements m + e0 .. m + e0 + 3: chains (e0 & 7) ..
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[(e0 + e) & 7] = __builtin_fmaf(q[m + e0 + e], f[e], a[(e0 + e) & 7]);
+    }
+  }
+  return scale * rarc_canon_tree(a);
+}
+
 struct RepairParams {
   const half_t* corpus;
+  const uint8_t* corpus8;   // fp8 rows (then corpus is null)
+  const float* rowscale;
   const float* qv;  // [d]
   uint32_t n_rows;
   int d, k;
@@ -491,7 +537,8 @@ __global__ __launch_bounds__(256) void rarc_repair_scan_kernel(const RepairParam
   const float ks = p.scores[p.k - 1];
   const uint64_t kth = (kid < 0) ? 0ull : rarc_candkey(ks, (uint32_t)(kid - p.id_base));
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < p.n_rows; r += gridDim.x * blockDim.x) {
-    const float c = canon_dot_f16(p.qv, p.corpus + (size_t)r * p.d, p.d);
+    const float c = p.corpus8 ? canon_dot_f8(p.qv, p.corpus8 + (size_t)r * p.d, p.d, p.rowscale[r])
+                              : canon_dot_f16(p.qv, p.corpus + (size_t)r * p.d, p.d);
     const uint64_t key = rarc_candkey(c, r);
     if (key > kth) {
       const uint32_t pos = atomicAdd(p.count, 1u);
@@ -535,11 +582,13 @@ __global__ __launch_bounds__(256) void rarc_repair_merge_kernel(const RepairPara
   }
 }
 
-int rarc_repair_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const float* qv, int k,
-                       int64_t id_base, int64_t* ids, float* scores, uint32_t* found, const RarcWs& ws,
-                       int cap, hipStream_t s) {
+int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
+                       const float* qv, int k, int64_t id_base, int64_t* ids, float* scores, uint32_t* found,
+                       const RarcWs& ws, int cap, hipStream_t s) {
   RepairParams p;
-  p.corpus = (const half_t*)corpus;
+  p.corpus = fmt ? nullptr : (const half_t*)corpus;
+  p.corpus8 = fmt ? (const uint8_t*)corpus : nullptr;
+  p.rowscale = rowscale;
   p.qv = qv;
   p.n_rows = (uint32_t)n_rows;
   p.d = d_pad;

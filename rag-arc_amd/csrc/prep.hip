@@ -84,6 +84,55 @@ __global__ __launch_bounds__(256) void rarc_ingest_kernel(const float* in, int64
   }
 }
 
+// fp8 (e4m3fn + per-row scale) form of the ingest: same normalisation, then scale = max|x| / 448 and
+// byte = encode(x / scale).  8 lanes per row; bit-identical to oracle_ingest_f8.
+__device__ __forceinline__ float group8_max_f32(float v, int lane) {
+  const int base = lane & ~7;
+  float m = v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m = fmaxf(m, __shfl(v, base + j, 64));
+  return m;
+}
+__global__ __launch_bounds__(256) void rarc_ingest_f8_kernel(const float* in, int64_t ld_in, uint8_t* out, int d_pad,
+                                                             float* row_scale, float* row_norm2, int64_t n_rows,
+                                                             int d, int normalize) {
+  const int lane = threadIdx.x & 63, j = threadIdx.x & 7;
+  const int64_t rows_per_block = blockDim.x / 8;
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < n_rows; r0 += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t r = r0 + threadIdx.x / 8;
+    const bool live = r < n_rows;
+    const float* x = in + (live ? r : 0) * ld_in;
+    float acc = 0.f;
+    if (live && normalize)
+      for (int m = j; m < d; m += 8) acc = __builtin_fmaf(x[m], x[m], acc);
+    const float nr = group8_tree_f32(acc, lane);
+    const bool sc = normalize && nr > 0.f;
+    const float inv = sc ? inv_norm(nr) : 1.f;
+    float mx = 0.f;
+    if (live)
+      for (int m = j; m < d; m += 8) mx = fmaxf(mx, __builtin_fabsf(sc ? x[m] * inv : x[m]));
+    mx = group8_max_f32(mx, lane);
+    const float scale = (mx > 0.f && mx < INFINITY) ? mx / 448.0f : 1.0f;
+    float acc2 = 0.f;
+    if (live) {
+      uint8_t* y = out + r * d_pad;
+      for (int m = j; m < d_pad; m += 8) {
+        uint8_t b = 0;
+        if (m < d) b = rarc_f8_encode((sc ? x[m] * inv : x[m]) / scale);
+        y[m] = b;
+        float f4[4];
+        rarc_f8x4_to_f32((uint32_t)b, f4);
+        acc2 = __builtin_fmaf(f4[0], f4[0], acc2);
+      }
+    }
+    const float n2 = group8_tree_f32(acc2, lane);
+    if (live && j == 0) {
+      row_scale[r] = scale;
+      if (row_norm2) row_norm2[r] = (scale * scale) * n2;
+    }
+  }
+}
+
 // One block per query slot (all RARC_MAX_QUERIES rows are written; padding rows are zero).  Only the
 // squared-norm has a prescribed order (8 lanes run the canonical chains out of LDS); scaling, the
 // fp16 / int8 copies and the error-bound sums are order-free and use the whole block.
@@ -244,6 +293,22 @@ extern "C" int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_cor
   if (n_rows == 0) return RARC_OK;
   hipLaunchKernelGGL(rarc_ingest_kernel, dim3(grid_for(n_rows, 32)), dim3(256), 0, (hipStream_t)stream, d_in,
                      ld_in, (half_t*)d_corpus_f16, d_pad, d_row_norm2, n_rows, d, normalize);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_padded_dim_f8(int d) {
+  return d <= 0 ? 0 : ((d + RARC_DIM_ALIGN_F8 - 1) / RARC_DIM_ALIGN_F8) * RARC_DIM_ALIGN_F8;
+}
+
+extern "C" int rarc_ingest_f8(const float* d_in, int64_t ld_in, uint8_t* d_corpus_f8, int d_pad, float* d_row_scale,
+                              float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream) {
+  RARC_REQUIRE(d_in && d_corpus_f8 && d_row_scale && d > 0 && d_pad >= d && d_pad % RARC_DIM_ALIGN_F8 == 0 &&
+                   n_rows >= 0,
+               RARC_E_INVALID, "rarc_ingest_f8: bad arguments");
+  if (n_rows == 0) return RARC_OK;
+  hipLaunchKernelGGL(rarc_ingest_f8_kernel, dim3(grid_for(n_rows, 32)), dim3(256), 0, (hipStream_t)stream, d_in,
+                     ld_in, d_corpus_f8, d_pad, d_row_scale, d_row_norm2, n_rows, d, normalize);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

@@ -119,6 +119,140 @@ extern "C" int rarc_quant_meta_f16(const uint16_t* d_corpus_f16, int64_t n_rows,
   return RARC_OK;
 }
 
+// ---- fp8 corpus: tile scales, per-row multipliers, residual bound ----------------------------------
+// A stored value is x = rowscale * val (val = decoded e4m3fn byte).  Tile scale s_t = 127 / max|x| over the
+// tile's 32 rows (rounded down to fp16); row multiplier mul_r = rowscale_r * s_t rounded down to fp16, so
+// that d8 = RNE(val * mul_r) is one fp16 fma per pair of values in the scan and |val * mul_r| <= 127.
+// Residual of a row: x - d8/s_t = (val*mul_r - d8)/s_t + x*(1 - mul_r/(rowscale_r*s_t)); the first part is
+// summed exactly in integers as for fp16, the second is at most 2^-10 ||x||.  One workgroup per tile, 8
+// lanes per row.
+__global__ __launch_bounds__(256) void rarc_quant_meta_f8_kernel(const uint4* __restrict__ corpus,
+                                                                 const float* __restrict__ rowscale, int d_pad,
+                                                                 uint32_t n_rows, uint32_t first_tile,
+                                                                 uint32_t n_tiles, float* __restrict__ meta) {
+  __shared__ float s_rowmax[32];
+  __shared__ float s_tmax;
+  const int tid = threadIdx.x, lane = tid & 63, j = tid & 7, rr = tid >> 3;  // 32 rows x 8 lanes
+  const int cpr = d_pad / 16;  // 16-byte chunks per row
+  for (uint32_t t = first_tile + blockIdx.x; t < first_tile + n_tiles; t += gridDim.x) {
+    const uint32_t row = t * 32 + rr;
+    const float rs = row < n_rows ? rowscale[row] : 0.f;  // rows past the end count as zero rows
+    const uint4* src = corpus + (size_t)row * cpr;
+    // pass 1: max |val| of the row -> max |x| of the tile
+    float vmax = 0.f;
+    double vsq = 0.0;
+    if (row < n_rows) {
+      for (int c = j; c < cpr; c += 8) {
+        const uint4 v = src[c];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f[4];
+          rarc_f8x4_to_f32(w[i], f);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            vmax = fmaxf(vmax, __builtin_fabsf(f[e]));
+            vsq += (double)f[e] * (double)f[e];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+      vsq += __shfl_xor(vsq, o, 64);
+    }
+    if (j == 0) s_rowmax[rr] = vmax * rs;
+    __syncthreads();
+    if (tid == 0) {
+      float m = 0.f;
+      for (int i = 0; i < 32; ++i) m = fmaxf(m, s_rowmax[i]);
+      s_tmax = m;
+    }
+    __syncthreads();
+    const float mx = s_tmax;
+    half_t s = (half_t)1.f;
+    if (mx > 0.f && mx < INFINITY) {
+      float sv = 127.f / mx;
+      if (sv > 32768.f) sv = 32768.f;
+      s = half_round_down(sv);
+      while ((double)mx * (double)(float)s > 127.0) s = half_round_down((float)s * 0.999f);
+    }
+    const float sf = (float)s;
+    // row multiplier: rowscale * s_t rounded down to fp16 (0 when it underflows: the row quantises to zeros)
+    float mulf = rs * sf;
+    half_t mul = (half_t)0.f;
+    if (mulf > 0.f) {
+      mul = half_round_down(mulf < 65504.f ? mulf : 65504.f);
+      while ((double)vmax * (double)(float)mul > 127.0) mul = half_round_down((float)mul * 0.999f);
+    }
+    const float mulq = (float)mul;
+    // pass 2: quantisation residual in units of 1/mul, exactly as the scan quantises
+    uint32_t acc = 0;
+    if (row < n_rows && mulq > 0.f) {
+      for (int c = j; c < cpr; c += 8) {
+        const uint4 v = src[c];
+        const uint4 q = rarc_quant8_chunk_f8(v, mul);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w}, qb[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f[4];
+          rarc_f8x4_to_f32(w[i], f);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int d8 = (int)(int8_t)(qb[i] >> (8 * e));
+            const float u = __builtin_fabsf(__builtin_fmaf(f[e], mulq, -(float)d8));
+            const uint32_t ui = (uint32_t)__builtin_ceilf(u * 1024.f);
+            acc += ui * ui;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (j == 0 && row < n_rows) {
+      const double xn = (double)rs * sqrt(vsq);  // ||x||
+      double res;
+      if (mulq > 0.f) {
+        const double delta = 1.0 - (double)mulq / ((double)rs * (double)sf);  // in [0, 2^-10]
+        res = sqrt((double)acc) / (1024.0 * (double)sf) + (delta > 0 ? delta : 0.0) * xn;
+      } else {
+        res = xn;  // row quantised to zeros
+      }
+      atomicMax((uint32_t*)meta, __float_as_uint((float)(res * 1.000001) * 1.000001f));
+      meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t + 2 + rr] = mulq;
+    }
+    if (j == 0 && row >= n_rows) meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t + 2 + rr] = 0.f;
+    if (tid == 0) {
+      meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t] = sf;
+      meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t + 1] = 1.0f / sf;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t rarc_quant_meta_floats_f8(int64_t n_rows) {
+  return (size_t)RARC_QMETA_HDR + (size_t)RARC_QMETA_F8_STRIDE * (size_t)((n_rows + 31) / 32);
+}
+
+extern "C" int rarc_quant_meta_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t n_rows, int d_pad,
+                                  int64_t first_row, float* d_qmeta, void* stream) {
+  RARC_REQUIRE(d_qmeta && ((d_corpus_f8 && d_row_scale) || n_rows == 0), RARC_E_INVALID,
+               "rarc_quant_meta_f8: null pointer");
+  RARC_REQUIRE(d_pad > 0 && d_pad % RARC_DIM_ALIGN_F8 == 0 && n_rows >= 0 && first_row >= 0 && first_row <= n_rows &&
+                   n_rows < (int64_t)0xffffffe0ll,
+               RARC_E_INVALID, "rarc_quant_meta_f8: bad arguments (n_rows=%lld first_row=%lld d_pad=%d)",
+               (long long)n_rows, (long long)first_row, d_pad);
+  const uint32_t t0 = (uint32_t)(first_row / 32), t1 = (uint32_t)((n_rows + 31) / 32);
+  if (t1 <= t0) return RARC_OK;
+  const uint32_t nt = t1 - t0;
+  const int grid = nt < 8192u ? (int)nt : 8192;
+  hipLaunchKernelGGL(rarc_quant_meta_f8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)d_corpus_f8, d_row_scale, d_pad, (uint32_t)n_rows, t0, nt, d_qmeta);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
 // ---- test hook: the dense int8 score matrix of a small shard -------------------------------------
 // approx[q][r] = <q8[q], d8[r]> * qinv[q] / s_tile(r), computed with the same rarc_quant8_chunk() as
 // the scan (one thread per (query, row); no MFMA).  tests/ compare it with canonical scores to check

@@ -241,6 +241,54 @@ __device__ __forceinline__ uint2 rarc_quant8_chunk(const uint4 v, const half_t s
   return o;
 }
 #endif
+// ---- fp8 (OCP e4m3fn) storage -------------------------------------------------------------------
+// value[m] = rowscale * decode(byte[m]); same integer algorithm as oracle/rarc_oracle.c (f8_encode /
+// f8_decode), so ingest is bit-identical to the oracle's.
+__host__ __device__ static inline uint8_t rarc_f8_encode(float x) {
+  union { float f; uint32_t u; } c; c.f = x;
+  uint32_t u = c.u;
+  const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+  u &= 0x7fffffffu;
+  c.u = u;
+  const float a = c.f;
+  if (!(a == a)) return sign;
+  if (a >= 448.0f) return sign | 0x7e;
+  if (a < 0.015625f) return sign | (uint8_t)(int)__builtin_rintf(a * 512.0f);
+  uint32_t r = u + 0x0007ffffu + ((u >> 20) & 1u);
+  r >>= 20;
+  uint32_t code = r - ((127u - 7u) << 3);
+  if (code > 0x7eu) code = 0x7eu;
+  return sign | (uint8_t)code;
+}
+#ifdef __HIPCC__
+typedef float float2_t __attribute__((ext_vector_type(2)));
+// 4 fp8 in a dword -> 4 fp32 (exact; v_cvt_pk_f32_fp8)
+__device__ __forceinline__ void rarc_f8x4_to_f32(uint32_t w, float (&o)[4]) {
+  const float2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+  o[0] = lo.x; o[1] = lo.y; o[2] = hi.x; o[3] = hi.y;
+}
+// One 16-byte chunk of an fp8 row (16 values) -> 16 int8 = RNE(value * mul): fp8 -> fp16 is exact
+// (v_cvt_scalef32_pk_f16_fp8 with scale 1), then the same fma(x, mul, 1536) low-byte trick as
+// rarc_quant8_chunk.  `mul` is the row's fp16 multiplier (row scale x tile scale, rounded down).
+__device__ __forceinline__ uint4 rarc_quant8_chunk_f8(const uint4 v, const half_t mul) {
+  const half2_t m2 = {mul, mul}, c2 = {(half_t)1536.f, (half_t)1536.f};
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const half2_t lo = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w[i], 1.0f, false);
+    const half2_t hi = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w[i], 1.0f, true);
+    const half2_t ylo = __builtin_elementwise_fma(lo, m2, c2), yhi = __builtin_elementwise_fma(hi, m2, c2);
+    o[i] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, yhi), __builtin_bit_cast(uint32_t, ylo), 0x06040200u);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+#endif
+constexpr int RARC_DIM_ALIGN_F8 = 256;  // fp8 rows: 16-byte chunks of 16 values, 512 threads per 32-row tile
+// fp8 quantisation metadata: [0] R, [1..3] reserved, then 34 floats per 32-row tile:
+//   [4 + 34t] s_t, [5 + 34t] 1/s_t, [6 + 34t + r] fp16-representable multiplier of row r of the tile
+constexpr int RARC_QMETA_F8_STRIDE = 34;
+
 // quantisation metadata (float array owned by the caller, see include/rarc.h):
 //   [0] max over rows of ||d - d8/s||_2 (as float bits, raised by atomicMax)   [1..3] reserved
 //   [4 + 2t], [5 + 2t] : scale s_t of 32-row tile t (an fp16-representable float) and 1/s_t

@@ -365,8 +365,11 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
 // k range (all fragment loads of a wave are issued at once: one memory round trip), partial
 // accumulators summed through LDS.  Rows come straight from global memory (6 MB, L2-shared by
 // the 8 query blocks).
-template <int D>
-__global__ __launch_bounds__(256) void rarc_seed_kernel(const half_t* __restrict__ corpus,
+// FMT 1: fp8 (e4m3fn) rows with per-row scales — bytes decode exactly to fp16, the score is multiplied
+// by the row's scale on the way out.
+template <int D, int FMT = 0>
+__global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__ corpus_v,
+                                                        const float* __restrict__ rowscale,
                                                         const half_t* __restrict__ q16, uint32_t n_rows,
                                                         uint32_t n_tiles, uint32_t seed_tiles,
                                                         float* __restrict__ seed) {
@@ -381,12 +384,26 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const half_t* __restrict
   uint32_t arow = tile * 32 + row;
   if (arow >= n_rows) arow = n_rows - 1;
   const half_t* qp = q16 + (size_t)qidx * D + 8 * h + 16 * KW * wave;
-  const half_t* ap = corpus + (size_t)arow * D + 8 * h + 16 * KW * wave;
   half8 af[KW], bf[KW];
+  if constexpr (FMT == 1) {
+    const uint8_t* ap = (const uint8_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
 #pragma unroll
-  for (int ks = 0; ks < KW; ++ks) {
-    af[ks] = *(const half8*)(ap + 16 * ks);
-    bf[ks] = *(const half8*)(qp + 16 * ks);
+    for (int ks = 0; ks < KW; ++ks) {
+      const uint2 v = *(const uint2*)(ap + 16 * ks);  // 8 fp8 values
+      const half2_t p0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.x, 1.0f, false);
+      const half2_t p1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.x, 1.0f, true);
+      const half2_t p2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, false);
+      const half2_t p3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, true);
+      af[ks] = (half8){p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+      bf[ks] = *(const half8*)(qp + 16 * ks);
+    }
+  } else {
+    const half_t* ap = (const half_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
+#pragma unroll
+    for (int ks = 0; ks < KW; ++ks) {
+      af[ks] = *(const half8*)(ap + 16 * ks);
+      bf[ks] = *(const half8*)(qp + 16 * ks);
+    }
   }
   f32x16 acc = {0};
 #pragma unroll
@@ -400,9 +417,11 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const half_t* __restrict
     float* out = seed + (size_t)qidx * (RARC_SEED_MAX_TILES * 32) + ti * 32;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float v = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
+      float v = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
       const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-      out[rr] = (tile * 32 + rr < n_rows) ? v : -INFINITY;
+      const bool live = tile * 32 + rr < n_rows;
+      if (FMT == 1 && live) v *= rowscale[tile * 32 + rr];
+      out[rr] = live ? v : -INFINITY;
     }
   }
 }
@@ -523,10 +542,11 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
   }
 }
 
-template <int D>
-static int launch_seed(const ScanParams& p, uint32_t seed_tiles, float* seed, hipStream_t s) {
-  hipLaunchKernelGGL(rarc_seed_kernel<D>, dim3(RARC_MAX_QUERIES / 32, seed_tiles), dim3(256), 0, s,
-                     p.corpus, p.q16, p.n_rows, p.n_tiles, seed_tiles, seed);
+template <int D, int FMT = 0>
+static int launch_seed(const ScanParams& p, uint32_t seed_tiles, float* seed, hipStream_t s,
+                       const float* rowscale = nullptr) {
+  hipLaunchKernelGGL((rarc_seed_kernel<D, FMT>), dim3(RARC_MAX_QUERIES / 32, seed_tiles), dim3(256), 0, s,
+                     (const void*)p.corpus, rowscale, p.q16, p.n_rows, p.n_tiles, seed_tiles, seed);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -552,9 +572,9 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
 }
 
 // Seed pass alone (used by the int8 scan, scan_q8.hip): thr[q] = sample statistic − sub_a[q] − sub_b[q].
-int rarc_seed_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq, int kprime,
-                     float bin_lo, float bin_hi, const float* sub_a, const float* sub_b, const RarcWs& ws,
-                     hipStream_t s) {
+int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
+                     const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
+                     const float* sub_b, const RarcWs& ws, hipStream_t s) {
   ScanParams p;
   p.corpus = (const half_t*)corpus;
   p.q16 = (const half_t*)q16;
@@ -571,6 +591,17 @@ int rarc_seed_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const ui
   if (seed_tiles > p.n_tiles) seed_tiles = p.n_tiles;
   int rc = RARC_OK;
   if (seed_tiles > 0) {
+    if (fmt == 1) {
+      switch (d_pad) {
+        case 256: rc = launch_seed<256, 1>(p, seed_tiles, ws.seed, s, rowscale); break;
+        case 512: rc = launch_seed<512, 1>(p, seed_tiles, ws.seed, s, rowscale); break;
+        case 768: rc = launch_seed<768, 1>(p, seed_tiles, ws.seed, s, rowscale); break;
+        case 1024: rc = launch_seed<1024, 1>(p, seed_tiles, ws.seed, s, rowscale); break;
+        default:
+          rarc_set_error("rarc_seed (fp8): padded dim %d unsupported (multiple of 256, <= 1024)", d_pad);
+          rc = RARC_E_UNSUPPORTED;
+      }
+    } else
     switch (d_pad) {
 #define SEED_CASE(DD) case DD: rc = launch_seed<DD>(p, seed_tiles, ws.seed, s); break;
       SEED_CASE(128) SEED_CASE(256) SEED_CASE(384) SEED_CASE(512) SEED_CASE(640) SEED_CASE(768) SEED_CASE(896)

@@ -32,8 +32,8 @@
 #include "rarc_common.h"
 
 struct ScanQ8Params {
-  const uint4* corpus;   // fp16 rows [ceil32(n_rows)][D], as 16-byte chunks
-  const float2* tmeta;   // per tile: (scale, 1/scale)
+  const uint4* corpus;   // fp16 (FMT 0) or fp8 (FMT 1) rows [ceil32(n_rows)][D], as 16-byte chunks
+  const float* tmeta;    // per tile: (scale, 1/scale) [+ 32 row multipliers for fp8]; qmeta + RARC_QMETA_HDR
   const int8_t* q8;      // [256][D]
   const float* qinv;     // [256]  1 / s_q
   const float* eps8;     // [256]
@@ -92,14 +92,17 @@ __device__ __forceinline__ void q8_lds_barrier() {
 // owner publishes a threshold only when it rose.  An extra store in the queue would not break
 // anything, but the counted wait behind it would sit until that store is acknowledged — microseconds
 // under a saturated HBM — which measured as +50 % kernel time when every survivor went out directly.
-template <int D, int ABL = 0>
+template <int D, int FMT = 0, int ABL = 0>
 __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Params p) {
   static_assert(D % 128 == 0 && D >= 128 && D <= 1024, "D must be a multiple of 128, <= 1024");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = ScanQ8Lds<D>;
   constexpr int KS = D / 32;          // MFMA k-steps
-  constexpr int CPR = D / 8;          // 16-byte fp16 chunks per row
-  constexpr int CPT = D / 128;        // chunks per thread per tile (32*CPR / 512)
+  static_assert(FMT == 0 || D % 256 == 0, "fp8 rows are padded to a multiple of 256");
+  constexpr int EPC = FMT ? 16 : 8;   // values per 16-byte chunk (fp8 : fp16)
+  constexpr int CPR = D / EPC;        // 16-byte chunks per row
+  constexpr int CPT = 32 * CPR / Q8_THREADS;  // chunks per thread per tile
+  constexpr int MSTRIDE = FMT ? RARC_QMETA_F8_STRIDE : 2;  // floats of metadata per tile
   constexpr int TCH = 32 * CPR;       // chunks per tile
 
   const int tid = threadIdx.x;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   constexpr bool WOFF_REGS = (D <= 768);
   auto woff_of = [&](int j) {
     const uint32_t c = j * Q8_THREADS + tid;
-    return (c / CPR) * L::RS + (c % CPR) * 8;
+    return (c / CPR) * L::RS + (c % CPR) * EPC;
   };
   uint32_t woff[WOFF_REGS ? CPT : 1];
   if constexpr (WOFF_REGS) {
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // group lands together (vector-memory returns are in order), two iterations after it was issued.
   struct Fetch {
     uint4 c[CPT];
+    float mul[FMT ? CPT : 1];  // fp8: the multiplier of each chunk's row (row scale x tile scale)
     float2 meta;
     uint32_t thr;
     uint32_t hw;
@@ -176,7 +180,12 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // while it is still in flight, the wait it needs then is for the OLDEST entries of the newest group,
   // i.e. no more than the wait for the group about to be consumed anyway)
   auto fetch = [&](Fetch& f, uint32_t tile) {
-    f.meta = p.tmeta[tile];
+    f.meta = *(const float2*)(p.tmeta + (size_t)tile * MSTRIDE);
+    if constexpr (FMT == 1) {
+#pragma unroll
+      for (int j = 0; j < CPT; ++j)
+        f.mul[j] = p.tmeta[(size_t)tile * MSTRIDE + 2 + (j * Q8_THREADS + tid) / CPR];
+    }
     f.thr = __hip_atomic_load(&p.thr[qidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     f.hw = __hip_atomic_load(hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_sched_barrier(0);
@@ -184,16 +193,23 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 #pragma unroll
     for (int j = 0; j < CPT; ++j) f.c[j] = src[j * Q8_THREADS];
   };
+  // chunk j of a fetch group -> int8 -> its place in the LDS tile `dst`
+  auto convert_chunk = [&](const Fetch& f, int j, half_t s, char* dst) {
+    char* at = dst + (WOFF_REGS ? woff[WOFF_REGS ? j : 0] : woff_of(j));
+    if constexpr (FMT == 1) {
+      *(uint4*)at = rarc_quant8_chunk_f8(f.c[j], (half_t)f.mul[j]);
+    } else {
+      uint2 o;
+      if (ABL & 16) { o.x = f.c[j].x ^ f.c[j].z; o.y = f.c[j].y ^ f.c[j].w; }
+      else o = rarc_quant8_chunk(f.c[j], s);
+      *(uint2*)at = o;
+    }
+  };
   auto convert_tile = [&](const Fetch& f, int buf) {
     const half_t s = (half_t)f.meta.x;
     char* dst = smem + buf * L::TILE;
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      uint2 o;
-      if (ABL & 16) { o.x = f.c[j].x ^ f.c[j].z; o.y = f.c[j].y ^ f.c[j].w; }
-      else o = rarc_quant8_chunk(f.c[j], s);
-      *(uint2*)(dst + (WOFF_REGS ? woff[WOFF_REGS ? j : 0] : woff_of(j))) = o;
-    }
+    for (int j = 0; j < CPT; ++j) convert_chunk(f, j, s, dst);
   };
 
   // 32 rows x 32 queries per wave: D/32 chained int8 MFMAs, A fragments read a few steps ahead —
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     char* dst = smem + (buf ^ 1) * L::TILE;
     const half_t s = (half_t)nx.meta.x;
     constexpr int PF = (D <= 768) ? 4 : 2;
-    constexpr int CSTEP = KS / CPT;  // one chunk converted every CSTEP MFMAs (KS = 4·CPT)
+    constexpr int CSTEP = KS / CPT;  // one chunk converted every CSTEP MFMAs (KS = 4·CPT for fp16, 8·CPT for fp8)
     i32x4 a[PF];
     if (!(ABL & 4)) {
 #pragma unroll
@@ -220,13 +236,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks % PF], qf[ks], c0, 0, 0, 0);
         if (ks + PF < KS) a[ks % PF] = *(const i32x4*)(a_base + 32 * (ks + PF));
       }
-      if (ks % CSTEP == CSTEP / 2) {
-        const int j = ks / CSTEP;
-        uint2 o;
-        if (ABL & 16) { o.x = nx.c[j].x ^ nx.c[j].z; o.y = nx.c[j].y ^ nx.c[j].w; }
-        else o = rarc_quant8_chunk(nx.c[j], s);
-        *(uint2*)(dst + (WOFF_REGS ? woff[WOFF_REGS ? j : 0] : woff_of(j))) = o;
-      }
+      if (ks % CSTEP == CSTEP / 2) convert_chunk(nx, ks / CSTEP, s, dst);
     }
     return c0;
   };
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 
   // fetch groups in flight: two up to D = 896; one beyond (a group is 36 registers at D = 1024 and a
   // spill would put scratch traffic into the very queue the counted waits rely on)
-  constexpr int NG = (D <= 896) ? 2 : 1;
+  constexpr int NG = (FMT == 1 || D <= 896) ? 2 : 1;
   // ---- prologue: tile t0 straight into LDS buffer 0; tiles t0+stride, t0+2·stride in flight ----
   // (the launch guarantees gridDim.x <= n_tiles, so tile t0 exists)
   Fetch f[NG];
@@ -411,36 +421,37 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 
 // ---- host side -----------------------------------------------------------------------------------
 bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop);  // rarc_api.hip
-int rarc_seed_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq, int kprime,
-                     float bin_lo, float bin_hi, const float* sub_a, const float* sub_b, const RarcWs& ws,
-                     hipStream_t s);  // scan_f16.hip
+int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
+                     const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
+                     const float* sub_b, const RarcWs& ws, hipStream_t s);  // scan_f16.hip
 
-template <int D>
+template <int D, int FMT>
 static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
   constexpr size_t lds = ScanQ8Lds<D>::TOTAL;
   static bool attr_done = false;
   if (!attr_done) {
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D>,
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, FMT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   hipEvent_t e0, e1;
   const bool prof = rarc_prof_next(&e0, &e1);
   if (prof) RARC_HIP_CHECK(hipEventRecord(e0, s));
-  hipLaunchKernelGGL(rarc_scan_q8_kernel<D>, dim3(grid), dim3(Q8_THREADS), lds, s, p);
+  hipLaunchKernelGGL((rarc_scan_q8_kernel<D, FMT>), dim3(grid), dim3(Q8_THREADS), lds, s, p);
   RARC_HIP_CHECK(hipGetLastError());
   if (prof) RARC_HIP_CHECK(hipEventRecord(e1, s));
   return RARC_OK;
 }
 
 // Host entry used by rarc_api.hip.  *grid_out = workgroups launched (owners of candidate segments).
-int rarc_scan_q8_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const float* qmeta,
-                        const uint16_t* q16, const int8_t* q8, const float* qinv, const float* eps16,
-                        const float* eps8, int nq, int kprime, float bin_lo, float bin_hi, const RarcWs& ws,
-                        int cap, int* grid_out, hipStream_t s) {
+// fmt 0: fp16 rows; fmt 1: fp8 (e4m3fn) rows with per-row scales `rowscale`.
+int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
+                        const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
+                        const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
+                        const RarcWs& ws, int cap, int* grid_out, hipStream_t s) {
   ScanQ8Params p;
   p.corpus = (const uint4*)corpus;
-  p.tmeta = (const float2*)(qmeta + RARC_QMETA_HDR);
+  p.tmeta = qmeta + RARC_QMETA_HDR;
   p.q8 = q8;
   p.qinv = qinv;
   p.eps8 = eps8;
@@ -461,7 +472,7 @@ int rarc_scan_q8_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const
   // seed pass (fp16 MFMA on a strided sample): t = k'-th best sample score, accurate to eps16, so
   // t − eps16 bounds the k-th best canonical score from below; rows whose int8 score is under
   // t − eps16 − eps8 are out
-  int rc = rarc_seed_launch(corpus, n_rows, d_pad, q16, nq, kprime, bin_lo, bin_hi, eps16, eps8, ws, s);
+  int rc = rarc_seed_launch(corpus, rowscale, fmt, n_rows, d_pad, q16, nq, kprime, bin_lo, bin_hi, eps16, eps8, ws, s);
   if (rc) return rc;
 
   int dev = 0, cus = 256;
@@ -471,15 +482,26 @@ int rarc_scan_q8_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const
   if ((uint32_t)grid > p.n_tiles) grid = (int)p.n_tiles;
   *grid_out = grid;
   if (p.n_tiles == 0) return RARC_OK;
+  if (fmt == 1) {
+    switch (d_pad) {
+      case 256: return launch_scan_q8<256, 1>(p, grid, s);
+      case 512: return launch_scan_q8<512, 1>(p, grid, s);
+      case 768: return launch_scan_q8<768, 1>(p, grid, s);
+      case 1024: return launch_scan_q8<1024, 1>(p, grid, s);
+      default:
+        rarc_set_error("rarc_scan_q8 (fp8): padded dim %d unsupported (multiple of 256, <= 1024)", d_pad);
+        return RARC_E_UNSUPPORTED;
+    }
+  }
   switch (d_pad) {
-    case 128: return launch_scan_q8<128>(p, grid, s);
-    case 256: return launch_scan_q8<256>(p, grid, s);
-    case 384: return launch_scan_q8<384>(p, grid, s);
-    case 512: return launch_scan_q8<512>(p, grid, s);
-    case 640: return launch_scan_q8<640>(p, grid, s);
-    case 768: return launch_scan_q8<768>(p, grid, s);
-    case 896: return launch_scan_q8<896>(p, grid, s);
-    case 1024: return launch_scan_q8<1024>(p, grid, s);
+    case 128: return launch_scan_q8<128, 0>(p, grid, s);
+    case 256: return launch_scan_q8<256, 0>(p, grid, s);
+    case 384: return launch_scan_q8<384, 0>(p, grid, s);
+    case 512: return launch_scan_q8<512, 0>(p, grid, s);
+    case 640: return launch_scan_q8<640, 0>(p, grid, s);
+    case 768: return launch_scan_q8<768, 0>(p, grid, s);
+    case 896: return launch_scan_q8<896, 0>(p, grid, s);
+    case 1024: return launch_scan_q8<1024, 0>(p, grid, s);
     default:
       rarc_set_error("rarc_scan_q8: padded dim %d unsupported (multiple of 128, <= 1024)", d_pad);
       return RARC_E_UNSUPPORTED;

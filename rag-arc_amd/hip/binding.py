@@ -46,6 +46,15 @@ SIGNATURES = {
                                 c_int, c_void_p]),
     "rarc_repair_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rarc_padded_dim_f8": (c_int, [c_int]),
+    "rarc_ingest_f8": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rarc_quant_meta_floats_f8": (c_size_t, [c_int64]),
+    "rarc_quant_meta_f8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),
+    "rarc_search_f8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                               c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                               c_int, c_void_p]),
+    "rarc_repair_f8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p,
+                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rarc_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rarc_rrf_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
@@ -91,5 +100,5 @@ def check(rc: int, what: str = "") -> None:
         raise RarcError(f"{what or 'librarc_hip'} failed ({rc}): {msg.decode() if msg else '?'}")
 
 
-def padded_dim(d: int) -> int:
-    return ((d + DIM_ALIGN - 1) // DIM_ALIGN) * DIM_ALIGN
+def padded_dim(d: int, align: int = DIM_ALIGN) -> int:
+    return ((d + align - 1) // align) * align

@@ -26,7 +26,8 @@ def _torch():
 
 
 class FlatIndexF16:
-    """Exact top-k inner-product search over fp16 rows resident in HBM.
+    """Exact top-k inner-product search over fp16 (or, with storage="f8", fp8 e4m3fn + per-row scale)
+    rows resident in HBM.
 
     metric "cosine": rows and queries are L2-normalised in fp32 before use (faiss.normalize_L2);
     metric "ip": raw inner product.  Returned scores are the canonical fp32 inner products of the
@@ -34,17 +35,22 @@ class FlatIndexF16:
     """
 
     def __init__(self, dim: int, metric: str = "cosine", device: int = 0, capacity: int = 0,
-                 id_base: int = 0, cand_cap: int = 131072, scan: str = "auto"):
+                 id_base: int = 0, cand_cap: int = 131072, scan: str = "auto", storage: str = "f16"):
         if metric not in ("cosine", "ip"):
             raise ValueError(f"unsupported metric: {metric}")
         if dim <= 0:
             raise ValueError("dim must be positive")
+        if storage not in ("f16", "f8"):
+            raise ValueError(f"unknown storage format: {storage}")
         self.torch = _torch()
         self.lib = B.load_library()
         self.dim = int(dim)
-        self.d_pad = B.padded_dim(self.dim)
+        self.storage = storage  # "f16": fp16 rows; "f8": e4m3fn bytes + one fp32 scale per row (BASELINE config 5)
+        self.d_pad = B.padded_dim(self.dim, 256 if storage == "f8" else B.DIM_ALIGN)
         if scan not in ("auto", "q8", "mfma16"):
             raise ValueError(f"unknown scan mode: {scan}")
+        if storage == "f8" and scan == "mfma16":
+            raise ValueError("fp8 rows are scanned by the int8-prefilter kernel only")
         limit = 768 if scan == "mfma16" else 1024
         if self.d_pad > limit:
             raise B.RarcError(f"dim {dim} pads to {self.d_pad} > {limit}: not supported by the {scan} scan kernel")
@@ -58,7 +64,8 @@ class FlatIndexF16:
         self.cand_cap = int(cand_cap)
         self.ntotal = 0
         self.max_norm = 0.0
-        self._rows = None  # torch.float16 [capacity][d_pad]
+        self._rows = None  # torch.float16 (or uint8 for fp8 storage) [capacity][d_pad]
+        self._rowscale = None  # fp8 storage: torch.float32 [capacity]
         self._qmeta = None  # torch.float32 [4 + 2*capacity/32]: quantisation metadata (include/rarc.h)
         self._lock = threading.Lock()  # callers may be pool threads (core/retrieval/base.py:92-96)
         self._ws = None
@@ -72,16 +79,25 @@ class FlatIndexF16:
         cap = ((int(n_rows) + _ROW_ALIGN - 1) // _ROW_ALIGN) * _ROW_ALIGN
         if self._rows is not None and self._rows.shape[0] >= cap:
             return
-        new = t.zeros((cap, self.d_pad), dtype=t.float16, device=self.device)
+        new = t.zeros((cap, self.d_pad), dtype=self._row_dtype(), device=self.device)
         if self._rows is not None and self.ntotal:
             new[: self.ntotal].copy_(self._rows[: self.ntotal])
         self._rows = new
+        if self.storage == "f8":
+            ns = t.ones(cap, dtype=t.float32, device=self.device)
+            if self._rowscale is not None and self.ntotal:
+                ns[: self.ntotal].copy_(self._rowscale[: self.ntotal])
+            self._rowscale = ns
         self._fit_qmeta()
+
+    def _row_dtype(self):
+        return self.torch.uint8 if self.storage == "f8" else self.torch.float16
 
     def _fit_qmeta(self) -> None:
         """Size the quantisation metadata for the current row buffer (keeps what is already there)."""
         t = self.torch
-        need = int(self.lib.rarc_quant_meta_floats(self._rows.shape[0]))
+        fn = self.lib.rarc_quant_meta_floats_f8 if self.storage == "f8" else self.lib.rarc_quant_meta_floats
+        need = int(fn(self._rows.shape[0]))
         if self._qmeta is None or self._qmeta.numel() < need:
             new = t.zeros(need, dtype=t.float32, device=self.device)
             if self._qmeta is not None:
@@ -91,6 +107,11 @@ class FlatIndexF16:
     def _requant(self, first_row: int) -> None:
         """(Re)compute tile scales + residual bound for the tiles touched by rows [first_row, ntotal)."""
         self._fit_qmeta()
+        if self.storage == "f8":
+            B.check(self.lib.rarc_quant_meta_f8(self._rows.data_ptr(), self._rowscale.data_ptr(), self.ntotal, self.d_pad,
+                                                int(first_row), self._qmeta.data_ptr(), self._stream()),
+                    "rarc_quant_meta_f8")
+            return
         B.check(self.lib.rarc_quant_meta_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, int(first_row),
                                              self._qmeta.data_ptr(), self._stream()), "rarc_quant_meta_f16")
 
@@ -113,6 +134,8 @@ class FlatIndexF16:
     AUTO_Q8_ROWS = 4_000_000
 
     def _use_q8(self) -> bool:
+        if self.storage == "f8":
+            return True
         if self.scan == "auto":
             return self.d_pad > 768 or self.ntotal >= self.AUTO_Q8_ROWS
         return self.scan == "q8"
@@ -127,8 +150,13 @@ class FlatIndexF16:
 
     @property
     def rows(self):
-        """The stored fp16 rows as a torch view [ntotal][d_pad]."""
+        """The stored rows as a torch view [ntotal][d_pad] (fp16, or e4m3fn bytes for fp8 storage)."""
         return None if self._rows is None else self._rows[: self.ntotal]
+
+    @property
+    def row_scales(self):
+        """fp8 storage: the per-row scales [ntotal] (value = scale * decode(byte))."""
+        return None if self._rowscale is None else self._rowscale[: self.ntotal]
 
     # ------------------------------------------------------------------ add
     def add(self, vectors) -> None:
@@ -145,10 +173,17 @@ class FlatIndexF16:
                 self.reserve(max(self.ntotal + n, 2 * self.ntotal))
             norm2 = t.empty(n, dtype=t.float32, device=self.device)
             dst = self._rows[self.ntotal: self.ntotal + n]
-            B.check(self.lib.rarc_ingest_f16(x.data_ptr(), x.shape[1], dst.data_ptr(), self.d_pad,
-                                             norm2.data_ptr(), n, self.dim,
-                                             1 if self.metric == "cosine" else 0, self._stream()),
-                    "rarc_ingest_f16")
+            if self.storage == "f8":
+                B.check(self.lib.rarc_ingest_f8(x.data_ptr(), x.shape[1], dst.data_ptr(), self.d_pad,
+                                                self._rowscale[self.ntotal: self.ntotal + n].data_ptr(),
+                                                norm2.data_ptr(), n, self.dim,
+                                                1 if self.metric == "cosine" else 0, self._stream()),
+                        "rarc_ingest_f8")
+            else:
+                B.check(self.lib.rarc_ingest_f16(x.data_ptr(), x.shape[1], dst.data_ptr(), self.d_pad,
+                                                 norm2.data_ptr(), n, self.dim,
+                                                 1 if self.metric == "cosine" else 0, self._stream()),
+                        "rarc_ingest_f16")
             self.max_norm = max(self.max_norm, float(norm2.max().sqrt().item()))
             old = self.ntotal
             self.ntotal += n
@@ -159,6 +194,8 @@ class FlatIndexF16:
         whose length is a multiple of 32 is adopted without a copy when the index is empty;
         `n_valid` (default: all) says how many of its rows are real."""
         t = self.torch
+        if self.storage != "f16":
+            raise B.RarcError("add_rows_f16 needs fp16 storage")
         with self._lock, t.cuda.device(self.device):
             if rows_f16.dtype != t.float16 or rows_f16.shape[1] != self.d_pad:
                 raise ValueError("rows must be float16 [n][d_pad]")
@@ -179,6 +216,8 @@ class FlatIndexF16:
     def load_rows(self, rows_f16_host, max_norm: float) -> None:
         """Upload rows already in storage format (host array [n][d_pad] float16, e.g. a memmap)."""
         t = self.torch
+        if self.storage != "f16":
+            raise B.RarcError("load_rows needs fp16 storage")
         with self._lock, t.cuda.device(self.device):
             n = rows_f16_host.shape[0]
             if rows_f16_host.shape[1] != self.d_pad:
@@ -257,11 +296,35 @@ class FlatIndexF16:
         stream = self._stream()
         self._prep(q)
         for qi in flagged:
+            self._call_repair(qi, k, out_ids, out_sc, ws, stream)
+            if int(b["found"].item()) & 0x80000000:
+                raise B.RarcError(f"repair of query {qi} overflowed its scratch list")
+
+    def _call_search(self, rows_ptr, qm, nq, k, kp, lo, hi, out_ids, out_sc, status, ws, stream) -> None:
+        b = self._qbuf
+        if self.storage == "f8":
+            sc_ptr = self._rowscale.data_ptr() if self._rowscale is not None else 0
+            B.check(self.lib.rarc_search_f8(rows_ptr, sc_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k,
+                                            kp, self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
+                                            status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+                    "rarc_search_f8")
+        else:
+            B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k, kp,
+                                             self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
+                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+                    "rarc_search_f16")
+
+    def _call_repair(self, qi, k, out_ids, out_sc, ws, stream) -> None:
+        b = self._qbuf
+        if self.storage == "f8":
+            B.check(self.lib.rarc_repair_f8(self._rows.data_ptr(), self._rowscale.data_ptr(), self.ntotal, self.d_pad,
+                                            b["qblock"].data_ptr(), qi, k, self.id_base, out_ids.data_ptr(),
+                                            out_sc.data_ptr(), b["found"].data_ptr(), ws.data_ptr(), ws.numel(), stream),
+                    "rarc_repair_f8")
+        else:
             B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["qblock"].data_ptr(), qi, k,
                                              self.id_base, out_ids.data_ptr(), out_sc.data_ptr(), b["found"].data_ptr(),
                                              ws.data_ptr(), ws.numel(), stream), "rarc_repair_f16")
-            if int(b["found"].item()) & 0x80000000:
-                raise B.RarcError(f"repair of query {qi} overflowed its scratch list")
 
     def _bins(self, q) -> Tuple[float, float]:
         if self.metric == "cosine":
@@ -283,10 +346,7 @@ class FlatIndexF16:
         kp = self.kprime_for(k)
         rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
         qm = self._qmeta.data_ptr() if (self._use_q8() and self._qmeta is not None and self.ntotal) else 0
-        B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k, kp,
-                                         self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
-                                         status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),
-                "rarc_search_f16")
+        self._call_search(rows_ptr, qm, nq, k, kp, lo, hi, out_ids, out_sc, status, ws, stream)
         self.last_status = status[:nq]
         if not repair or self.ntotal == 0:
             return
@@ -295,10 +355,7 @@ class FlatIndexF16:
         flagged = t.nonzero(status[:nq]).flatten().tolist() if any_flag else []
         self.last_repaired = flagged
         for qi in flagged:
-            B.check(self.lib.rarc_repair_f16(rows_ptr, self.ntotal, self.d_pad, b["qblock"].data_ptr(), qi, k,
-                                             self.id_base, out_ids.data_ptr(), out_sc.data_ptr(),
-                                             b["found"].data_ptr(), ws.data_ptr(), ws.numel(), stream),
-                    "rarc_repair_f16")
+            self._call_repair(qi, k, out_ids, out_sc, ws, stream)
             if int(b["found"].item()) & 0x80000000:
                 raise B.RarcError(f"repair of query {qi} overflowed its scratch list")
 
@@ -311,11 +368,7 @@ class FlatIndexF16:
             b = self._qbuf
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
             self._prep(q)
-            k = ids.shape[1]
-            B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["qblock"].data_ptr(),
-                                             qi, k, self.id_base, ids.data_ptr(), scores.data_ptr(),
-                                             b["found"].data_ptr(), ws.data_ptr(), ws.numel(), self._stream()),
-                    "rarc_repair_f16")
+            self._call_repair(qi, ids.shape[1], ids, scores, ws, self._stream())
             return int(b["found"].item())
 
 

@@ -39,6 +39,16 @@ def test_encoder_scan_rrf_1024d(oracle):
     idx.add_rows_f16(rows, 1.001)
     ids, sc = idx.search_device(q, K)
 
+    # the same corpus in config 5's storage format (fp8 e4m3fn + per-row scale), against its own oracle
+    idx8 = FlatIndexF16(H, storage="f8")
+    idx8.add(rows.float())
+    ids8, sc8 = idx8.search_device(q, K)
+    b8, s8, _ = oracle.ingest_f8(rows.float().cpu().numpy())
+    o8_ids, o8_sc, _ = oracle.flat_search_f8(b8, s8, oracle.normalize_L2(q.cpu().numpy()), K)
+    assert np.array_equal(ids8.cpu().numpy(), o8_ids)
+    assert np.array_equal(sc8.cpu().numpy().view(np.uint32), o8_sc.view(np.uint32))
+    assert (o8_ids[:, 0] == np.arange(NQ) * 7 + 11).all()
+
     q_h = q.cpu().numpy()
     rows_h = rows.cpu().numpy().view(np.uint16)
     o_ids, o_sc, _ = oracle.flat_search_f16(rows_h, oracle.normalize_L2(q_h), K)

@@ -20,13 +20,13 @@ static float run(const ScanQ8Params& p, int grid, int iters, const uint16_t* cor
                  int kprime, RarcWs ws) {
   constexpr int D = BD;
   constexpr size_t lds = ScanQ8Lds<D>::TOTAL;
-  hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, 0, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e30f;
   for (int it = 0; it < iters; ++it) {
-    rarc_seed_launch(corpus, N, D, qb.q16, 256, kprime, -1.f, 1.f, qb.eps16, qb.eps8, ws, 0);
+    rarc_seed_launch(corpus, nullptr, 0, N, D, qb.q16, 256, kprime, -1.f, 1.f, qb.eps16, qb.eps8, ws, 0);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((rarc_scan_q8_kernel<D, ABL>), dim3(grid), dim3(Q8_THREADS), lds, 0, p);
+    hipLaunchKernelGGL((rarc_scan_q8_kernel<D, 0, ABL>), dim3(grid), dim3(Q8_THREADS), lds, 0, p);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -56,7 +56,7 @@ int main(int argc, char** argv) {
   { float h[4]; hipMemcpy(h, qmeta, 16, hipMemcpyDeviceToHost); float e8[4], e16[4]; hipMemcpy(e8, qb.eps8, 16, hipMemcpyDeviceToHost); hipMemcpy(e16, qb.eps16, 16, hipMemcpyDeviceToHost);
     printf("R = %.5f  eps8[0..1] = %.5f %.5f  eps16[0] = %.6f\n", h[0], e8[0], e8[1], e16[0]); }
   RarcWs ws = rarc_ws_carve(wsb);
-  ScanQ8Params p; p.corpus = (const uint4*)corpus; p.tmeta = (const float2*)(qmeta + RARC_QMETA_HDR); p.q8 = qb.q8; p.qinv = qb.qinv; p.eps8 = qb.eps8;
+  ScanQ8Params p; p.corpus = (const uint4*)corpus; p.tmeta = qmeta + RARC_QMETA_HDR; p.q8 = qb.q8; p.qinv = qb.qinv; p.eps8 = qb.eps8;
   p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32);
   p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
   p.binlo = ws.binlo; p.binscale = ws.binscale; p.bininv = ws.bininv;
@@ -77,7 +77,7 @@ int main(int argc, char** argv) {
     hipEvent_t f0, f1; hipEventCreate(&f0); hipEventCreate(&f1);
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(f0, 0);
-      rarc_finalize_q8_launch(corpus, D, qb.q32, qb.eps8, 256, 100, 0, ws, CAP, grid, oi, os, st, 0);
+      rarc_finalize_q8_launch(corpus, nullptr, 0, D, qb.q32, qb.eps8, 256, 100, 0, ws, CAP, grid, oi, os, st, 0);
       hipEventRecord(f1, 0); hipEventSynchronize(f1); float ms; hipEventElapsedTime(&ms, f0, f1);
       unsigned long long h[10]; hipMemcpy(h, fd, 80, hipMemcpyDeviceToHost);
       printf("finalize: %.1f us; block0 phases (us): init %.1f collect1 %.1f rescore1 %.1f rankL %.1f collect2 %.1f rescore2 %.1f final %.1f; |G1|=%llu |G1+G2|=%llu\n", ms * 1000,
