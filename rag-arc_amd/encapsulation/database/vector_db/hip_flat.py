@@ -19,10 +19,10 @@ from ....core.utils.data_model import Document
 from .base import VectorStore
 
 
-def _default_engine(dim: int, metric: str, device: int):
+def _default_engine(dim: int, metric: str, device: int, storage: str = "f16"):
     from ....hip.engine import FlatIndexF16
 
-    return FlatIndexF16(dim, metric=metric, device=device)
+    return FlatIndexF16(dim, metric=metric, device=device, storage=storage)
 
 
 def _mmr_select(scored, embeddings, query_embedding, k, lambda_mult=0.5):
@@ -46,8 +46,11 @@ def _mmr_select(scored, embeddings, query_embedding, k, lambda_mult=0.5):
 
 class HipFlatVectorStore(VectorStore):
     def __init__(self, embedding, metric: str = "cosine", normalize_L2: bool = False, index_type: str = "flat",
-                 device: int = 0, engine_factory: Optional[Callable] = None, **kwargs: Any):
+                 device: int = 0, engine_factory: Optional[Callable] = None, storage: str = "f16", **kwargs: Any):
         super().__init__(**kwargs)
+        if storage not in ("f16", "f8"):
+            raise ValueError(f"unsupported row storage: {storage}")
+        self.storage = storage  # "f16", or "f8": e4m3fn bytes + one scale per row (half the HBM footprint)
         if index_type != "flat":
             raise ValueError(f"unsupported index type: {index_type} (exact flat scan only)")
         if metric not in ("cosine", "ip"):
@@ -85,7 +88,7 @@ class HipFlatVectorStore(VectorStore):
         elif len(metadatas) != len(texts):
             raise ValueError("number of metadatas must match number of texts")
         if self.index is None:
-            self.index = self._engine_factory(vectors.shape[1], self._engine_metric(), self.device)
+            self.index = self._make_engine(vectors.shape[1])
         start = self.index.ntotal
         self.index.add(vectors)
         for i, (text, meta, doc_id) in enumerate(zip(texts, metadatas, ids)):
@@ -176,22 +179,34 @@ class HipFlatVectorStore(VectorStore):
             return self._max_inner_product_relevance_score_fn
         raise ValueError(f"unsupported metric: {self.metric}")
 
+    def _make_engine(self, dim: int):
+        if self.storage == "f16":  # (custom factories keep their three-argument signature)
+            return self._engine_factory(dim, self._engine_metric(), self.device)
+        return self._engine_factory(dim, self._engine_metric(), self.device, self.storage)
+
     # ------------------------------------------------------------------ persistence
     def save_local(self, folder_path: str, index_name: str = "index") -> None:
-        """Flat shard file (fp16 rows, mmap-able) + pickled docstore; cf. VectorStore_Faiss.py:432-450."""
+        """Flat shard file (64-byte header, raw rows — mmap-able —, then the row scales for fp8 storage)
+        + pickled docstore; cf. VectorStore_Faiss.py:432-450."""
         os.makedirs(folder_path, exist_ok=True)
         if self.index is not None and self.index.ntotal:
             rows = self.index.rows
             rows = rows.cpu().numpy() if hasattr(rows, "cpu") else np.asarray(rows)
-            rows = np.ascontiguousarray(rows).view(np.float16)
-            header = np.array([0x43524152, 1, rows.shape[0], self.index.dim, rows.shape[1]], dtype=np.int64)
+            f8 = self.storage == "f8"
+            rows = np.ascontiguousarray(rows).view(np.uint8 if f8 else np.float16)
+            header = np.array([0x43524152, 2, rows.shape[0], self.index.dim, rows.shape[1], 1 if f8 else 0], dtype=np.int64)
             with open(os.path.join(folder_path, f"{index_name}.rarc"), "wb") as fh:
                 fh.write(header.tobytes())
                 fh.write(np.float32(self.index.max_norm).tobytes())
                 fh.write(b"\0" * (64 - header.nbytes - 4))
                 fh.write(rows.tobytes())
+                if f8:
+                    sc = self.index.row_scales
+                    sc = sc.cpu().numpy() if hasattr(sc, "cpu") else np.asarray(sc)
+                    fh.write(np.ascontiguousarray(sc, dtype=np.float32).tobytes())
         meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
-                "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2}
+                "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2,
+                "storage": self.storage}
         with open(os.path.join(folder_path, f"{index_name}.pkl"), "wb") as fh:
             pickle.dump(meta, fh)
 
@@ -199,19 +214,24 @@ class HipFlatVectorStore(VectorStore):
     def load_local(cls, folder_path: str, embeddings, index_name: str = "index", **kwargs: Any):
         with open(os.path.join(folder_path, f"{index_name}.pkl"), "rb") as fh:
             meta = pickle.load(fh)
+        kwargs.setdefault("storage", meta.get("storage", "f16"))
         store = cls(embedding=embeddings, index_type=meta["index_type"], metric=meta["metric"],
                     normalize_L2=meta["normalize_L2"], **kwargs)
         store.docstore, store.index_to_docstore_id = meta["docstore"], meta["index_to_docstore_id"]
         path = os.path.join(folder_path, f"{index_name}.rarc")
         if os.path.exists(path):
-            header = np.fromfile(path, dtype=np.int64, count=5)
-            if header[0] != 0x43524152 or header[1] != 1:
+            header = np.fromfile(path, dtype=np.int64, count=6)
+            if header[0] != 0x43524152 or header[1] not in (1, 2):
                 raise ValueError(f"{path}: not a rarc shard file")
             n, dim, d_pad = int(header[2]), int(header[3]), int(header[4])
-            max_norm = float(np.fromfile(path, dtype=np.float32, count=1, offset=40)[0])
-            rows = np.memmap(path, dtype=np.float16, mode="r", offset=64, shape=(n, d_pad))
-            store.index = store._engine_factory(dim, store._engine_metric(), store.device)
-            store.index.load_rows(rows, max_norm)
+            f8 = header[1] == 2 and int(header[5]) == 1
+            if f8 != (store.storage == "f8"):
+                raise ValueError(f"{path}: stored as {'fp8' if f8 else 'fp16'}, store configured for {store.storage}")
+            max_norm = float(np.fromfile(path, dtype=np.float32, count=1, offset=48 if header[1] == 2 else 40)[0])
+            rows = np.memmap(path, dtype=np.uint8 if f8 else np.float16, mode="r", offset=64, shape=(n, d_pad))
+            scales = np.fromfile(path, dtype=np.float32, count=n, offset=64 + n * d_pad) if f8 else None
+            store.index = store._make_engine(dim)
+            store.index.load_rows(rows, max_norm, row_scales=scales)
         return store
 
     @classmethod

@@ -213,20 +213,23 @@ class FlatIndexF16:
             self.max_norm = max(self.max_norm, float(max_norm))
             self._requant(old)
 
-    def load_rows(self, rows_f16_host, max_norm: float) -> None:
-        """Upload rows already in storage format (host array [n][d_pad] float16, e.g. a memmap)."""
+    def load_rows(self, rows_host, max_norm: float, row_scales=None) -> None:
+        """Upload rows already in storage format: host array [n][d_pad] float16 (e.g. a memmap), or for
+        fp8 storage uint8 bytes plus their fp32 `row_scales` [n]."""
         t = self.torch
-        if self.storage != "f16":
-            raise B.RarcError("load_rows needs fp16 storage")
+        if (self.storage == "f8") != (row_scales is not None):
+            raise ValueError("row_scales go with fp8 storage (and only with it)")
         with self._lock, t.cuda.device(self.device):
-            n = rows_f16_host.shape[0]
-            if rows_f16_host.shape[1] != self.d_pad:
+            n = rows_host.shape[0]
+            if rows_host.shape[1] != self.d_pad:
                 raise ValueError("rows must be [n][d_pad]")
             self.reserve(self.ntotal + n)
             step = 1 << 20
             for s in range(0, n, step):  # bounded pinned staging instead of one huge host tensor
-                chunk = t.from_numpy(np.ascontiguousarray(rows_f16_host[s:s + step]))
+                chunk = t.from_numpy(np.array(rows_host[s:s + step], copy=True))
                 self._rows[self.ntotal + s: self.ntotal + s + chunk.shape[0]].copy_(chunk)
+            if row_scales is not None:
+                self._rowscale[self.ntotal: self.ntotal + n].copy_(t.from_numpy(np.array(row_scales, dtype=np.float32, copy=True)))
             old = self.ntotal
             self.ntotal += n
             self.max_norm = max(self.max_norm, float(max_norm))

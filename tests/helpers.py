@@ -44,7 +44,7 @@ class OracleIndex:
         self.ntotal = self._rows.shape[0]
         self.max_norm = max(self.max_norm, float(np.sqrt(n2.max()))) if len(n2) else self.max_norm
 
-    def load_rows(self, rows, max_norm):
+    def load_rows(self, rows, max_norm, row_scales=None):
         self._rows = np.concatenate([self._rows, np.asarray(rows).view(np.uint16)])
         self.ntotal = self._rows.shape[0]
         self.max_norm = max(self.max_norm, max_norm)

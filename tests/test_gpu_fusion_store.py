@@ -136,6 +136,21 @@ def test_store_end_to_end_and_registry(tmp_path, oracle):
     assert [(d.id, s) for d, s in again.similarity_search_with_score("passage 77", k=10)] == \
            [(d.id, s) for d, s in hip.similarity_search_with_score("passage 77", k=10)]
 
+    # the same store over fp8 rows (half the HBM): answers equal the fp8 oracle's, and survive save / load
+    hip8 = HipFlatVectorStore.from_texts(texts, emb, ids=ids, storage="f8")
+    X = np.asarray(emb.embed_documents(texts), np.float32)
+    b8, s8, _ = oracle.ingest_f8(X)
+    for q in ("passage 77", "something else entirely"):
+        got = hip8.similarity_search_with_score(q, k=10)
+        oi, osc, _ = oracle.flat_search_f8(b8, s8, oracle.normalize_L2(np.asarray([emb.embed_query(q)], np.float32)), 10)
+        assert [d.id for d, _ in got] == [str(i) for i in oi[0]]
+        assert [s for _, s in got] == [float(v) for v in osc[0]]
+    hip8.save_local(str(tmp_path / "idx8"))
+    again8 = HipFlatVectorStore.load_local(str(tmp_path / "idx8"), emb)
+    assert again8.storage == "f8"
+    assert [(d.id, s) for d, s in again8.similarity_search_with_score("passage 77", k=10)] == \
+           [(d.id, s) for d, s in hip8.similarity_search_with_score("passage 77", k=10)]
+
     # JSON -> Register -> module graph -> invoke (the framework surface, with HIP fusion)
     qs = ["passage 1", "passage 2"]
     np.savez(tmp_path / "emb.npz", texts=np.array(texts + ["query a"]), vectors=np.array(emb.embed_documents(texts + ["query a"]), np.float32))
