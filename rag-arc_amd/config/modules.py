@@ -49,6 +49,7 @@ class HipFlatVectorStoreConfig(AbstractConfig):
     metric: Literal["cosine", "ip"] = "cosine"
     normalize_L2: bool = False
     device: int = 0
+    storage: Literal["f16", "f8"] = "f16"  # row storage in HBM: fp16, or fp8 e4m3fn + per-row scale
     corpus_path: Optional[str] = None  # .npz with `texts` (and optional `ids`) to ingest at build time
 
     def build(self) -> AbstractModule:
@@ -57,7 +58,7 @@ class HipFlatVectorStoreConfig(AbstractConfig):
         from ..encapsulation.database.vector_db.hip_flat import HipFlatVectorStore
 
         store = HipFlatVectorStore(self.embedding.build().impl, metric=self.metric, normalize_L2=self.normalize_L2,
-                                   device=self.device)
+                                   device=self.device, storage=self.storage)
         if self.corpus_path:
             data = np.load(self.corpus_path, allow_pickle=False)
             ids = [str(i) for i in data["ids"]] if "ids" in data else None
