@@ -240,6 +240,137 @@ __global__ __launch_bounds__(256) void rarc_attention_kernel(const half_t* qkv, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA attention: one wave per (sequence, head, block of 32 query rows); keys/values in tiles of 32.
+//   S^T = K · Q^T      v_mfma_f32_32x32x16_f16, A = K rows, B = Q rows (both 16-byte row loads from
+//                      the fused qkv matrix).  "Swapped": lane l then owns QUERY column l&31 and 16
+//                      of the tile's 32 keys, so the softmax statistics of a query live in one lane
+//                      pair (l, l^32) — max / sum are 15 in-lane ops and one cross-lane exchange.
+//   O^T += V^T · P^T   A = V^T fragments read from an LDS image the loader writes transposed
+//                      ([d][key], 80-byte rows), B = P^T assembled in registers: a lane keeps the
+//                      fp16 pairs of its own keys and swaps the other half with lane l^32.
+// Online softmax across key tiles (running max / sum per query, accumulator rescaled per lane).
+// Keys >= lens[seq] are masked; rows >= seq_len are neither loaded past the end nor stored.
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void rarc_attention_mfma_kernel(const half_t* __restrict__ qkv,
+                                                                  const int32_t* __restrict__ lens, int L, int H,
+                                                                  int n_heads, int q_blocks, int n_units,
+                                                                  half_t* __restrict__ ctx) {
+  constexpr int KS = DH / 16;  // k-steps of the QK^T product
+  constexpr int MB = DH / 32;  // 32-row blocks of O^T
+  constexpr int VROW = 40;     // halves per row of the transposed V image (32 keys + 8 padding)
+  __shared__ __attribute__((aligned(16))) half_t vt_all[4][DH * VROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= n_units) return;  // (no block-level barrier below: waves are independent)
+  half_t* vt = vt_all[wave];
+  const int qb = unit % q_blocks, bh = unit / q_blocks;
+  const int b = bh / n_heads, hd = bh % n_heads;
+  const int len = lens[b];
+  const int col = lane & 31, hh = lane >> 5;
+  const size_t rs = (size_t)3 * H;  // row stride of qkv in halves
+  const half_t* base = qkv + (size_t)b * L * rs + hd * DH;
+  const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;  // 1/sqrt(DH)
+  const int q0 = qb * 32;
+  const int qrow = (q0 + col < L) ? q0 + col : L - 1;
+
+  half8 qf[KS];  // B operand of S^T: this lane's query row, k = 16*ks + 8*hh ..
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(base + (size_t)qrow * rs + 16 * ks + 8 * hh);
+
+  f32x16 o[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    // ---- S^T tile: keys k0..k0+31 (rows) x this wave's 32 queries (columns) ----
+    const int krow = (k0 + col < L) ? k0 + col : L - 1;
+    f32x16 st = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8 kf = *(const half8*)(base + H + (size_t)krow * rs + 16 * ks + 8 * hh);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
+    }
+    // ---- V tile -> transposed LDS image vt[d][key] (each lane: 16-byte row pieces, written as halves) ----
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = lane; i < 32 * (DH / 8); i += 64) {
+      const int kr = i / (DH / 8), c8 = i % (DH / 8);
+      const int vrow = (k0 + kr < L) ? k0 + kr : L - 1;
+      const half8 v = *(const half8*)(base + 2 * H + (size_t)vrow * rs + 8 * c8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt[(8 * c8 + e) * VROW + kr] = v[e];
+    }
+    // ---- softmax statistics of this lane's query over its 16 keys, then with the partner lane ----
+    float s[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+      s[r] = key < len ? st[r] * scale : -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+    float psum = 0.f;
+    uint32_t pk[8];  // fp16 pairs: pk[2g], pk[2g+1] = keys 8g + 4hh + {0,1}, {2,3}
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - m_new);
+      const float p1 = (s[r + 1] == -INFINITY) ? 0.f : __expf(s[r + 1] - m_new);
+      psum += p0 + p1;
+      const half2_t h2 = {(half_t)p0, (half_t)p1};
+      pk[r >> 1] = __builtin_bit_cast(uint32_t, h2);
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+    __builtin_amdgcn_wave_barrier();
+    // ---- O^T += V^T · P^T over the tile's 32 keys (two k-steps of 16) ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // B fragment of lane (query, hh): keys 16ks + 8hh + 0..7 = group g = 2ks + hh: keys 8g+{0..3} sit in
+      // lane (query, 0) and 8g+{4..7} in lane (query, 1), both in that lane's pk[2g], pk[2g+1]
+      const int gm = 2 * ks + hh, go = 2 * ks + (1 - hh);  // my group; the group my partner needs from me
+      const uint32_t mine0 = hh ? (ks ? pk[6] : pk[2]) : (ks ? pk[4] : pk[0]);
+      const uint32_t mine1 = hh ? (ks ? pk[7] : pk[3]) : (ks ? pk[5] : pk[1]);
+      const uint32_t send0 = hh ? (ks ? pk[4] : pk[0]) : (ks ? pk[6] : pk[2]);
+      const uint32_t send1 = hh ? (ks ? pk[5] : pk[1]) : (ks ? pk[7] : pk[3]);
+      (void)gm; (void)go;
+      const uint32_t recv0 = (uint32_t)__shfl_xor((int)send0, 32, 64), recv1 = (uint32_t)__shfl_xor((int)send1, 32, 64);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 bw = hh ? (u32x4){recv0, recv1, mine0, mine1} : (u32x4){mine0, mine1, recv0, recv1};
+      const half8 pf = __builtin_bit_cast(half8, bw);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const half8 vf = *(const half8*)(vt + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
+        o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[mb], 0, 0, 0);
+      }
+    }
+  }
+  // ---- store: lane (query, hh) holds d = 32mb + 8(r>>2) + 4hh + (r&3) ----
+  if (q0 + col < L) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    half_t* out = ctx + ((size_t)b * L + q0 + col) * H + hd * DH;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const half4 w = {(half_t)(o[mb][4 * g] * inv), (half_t)(o[mb][4 * g + 1] * inv),
+                         (half_t)(o[mb][4 * g + 2] * inv), (half_t)(o[mb][4 * g + 3] * inv)};
+        *(half4*)(out + 32 * mb + 8 * g + 4 * hh) = w;
+      }
+  }
+}
+
 // CLS pooling (+ optional L2 normalisation with the canonical order of prep.hip)
 __global__ __launch_bounds__(64) void rarc_pool_kernel(const half_t* hidden, int L, int H, int normalize, float* out) {
   const int lane = threadIdx.x, j = lane & 7;
@@ -312,13 +443,14 @@ extern "C" int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, 
   RARC_REQUIRE(n_heads > 0 && (hidden == n_heads * 64 || hidden == n_heads * 32) && seq_len > 0 && seq_len <= 512 &&
                    n_seq > 0,
                RARC_E_UNSUPPORTED, "rarc_enc_attention: head_dim must be 32 or 64 and seq_len <= 512");
-  const int q_blocks = (seq_len + 63) / 64;
+  const int q_blocks = (seq_len + 31) / 32;
+  const int n_units = n_seq * n_heads * q_blocks;  // one wave each, four per workgroup
   if (hidden == n_heads * 64)
-    hipLaunchKernelGGL(rarc_attention_kernel<64>, dim3(n_seq * n_heads * q_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, (half_t*)d_ctx);
+    hipLaunchKernelGGL(rarc_attention_mfma_kernel<64>, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, n_units, (half_t*)d_ctx);
   else
-    hipLaunchKernelGGL(rarc_attention_kernel<32>, dim3(n_seq * n_heads * q_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, (half_t*)d_ctx);
+    hipLaunchKernelGGL(rarc_attention_mfma_kernel<32>, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, n_units, (half_t*)d_ctx);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

@@ -36,7 +36,9 @@ def _check(oracle, H, layers, heads, I, n_seq, L, seed):
     (128, 1, 2, 256, 3, 8),        # head_dim 64, tiny
     (128, 2, 4, 256, 5, 24),       # head_dim 32 (bge-small style heads)
     (384, 2, 12, 1536, 9, 32),     # bge-small shape, 2 layers
-    (256, 1, 4, 512, 2, 100),      # keys span two 64-key tiles
+    (256, 1, 4, 512, 2, 100),      # keys span four 32-key tiles, ragged last query block
+    (128, 1, 4, 256, 6, 200),      # head_dim 32, seven query blocks x seven key tiles, ragged lengths
+    (192, 1, 3, 384, 3, 65),       # head_dim 64, one key past a tile boundary
 ])
 def test_encoder_matches_oracle(oracle, H, layers, heads, I, n_seq, L):
     _check(oracle, H, layers, heads, I, n_seq, L, seed=H + L)
