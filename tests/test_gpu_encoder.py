@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _check(oracle, H, layers, heads, I, n_seq, L, seed):
     from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 
-    sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=800, max_pos=128, seed=seed)
+    sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=800, max_pos=256, seed=seed)
     enc = HipBertEncoder(sd, num_heads=heads)
     rng = np.random.default_rng(seed)
     ids = rng.integers(1, 800, (n_seq, L)).astype(np.int32)
@@ -38,7 +38,7 @@ def _check(oracle, H, layers, heads, I, n_seq, L, seed):
     (384, 2, 12, 1536, 9, 32),     # bge-small shape, 2 layers
     (256, 1, 4, 512, 2, 100),      # keys span four 32-key tiles, ragged last query block
     (128, 1, 4, 256, 6, 200),      # head_dim 32, seven query blocks x seven key tiles, ragged lengths
-    (192, 1, 3, 384, 3, 65),       # head_dim 64, one key past a tile boundary
+    (256, 1, 4, 512, 3, 65),       # head_dim 64, one key past a tile boundary
 ])
 def test_encoder_matches_oracle(oracle, H, layers, heads, I, n_seq, L):
     _check(oracle, H, layers, heads, I, n_seq, L, seed=H + L)
