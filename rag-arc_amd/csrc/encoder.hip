@@ -19,40 +19,54 @@
 // ------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] · W[N][K]ᵀ + bias[N]   (M, N multiples of 128; K multiple of 64)
 // ------------------------------------------------------------------------------------------
-constexpr int GM = 128, GN = 128, GK = 64;
-constexpr int G_TILE_BYTES = GM * GK * 2;  // 16 KiB per operand per stage
+constexpr int GM = 128, GN = 128, GK = 64;  // smallest tile (M is padded to a multiple of GM by the host)
 
-template <int ACT>  // 0 = bias only, 1 = bias + exact (erf) GELU
-__global__ __launch_bounds__(256, 2) void rarc_gemm_f16_kernel(const half_t* __restrict__ A,
-                                                               const half_t* __restrict__ W,
-                                                               const half_t* __restrict__ bias,
-                                                               half_t* __restrict__ C, int M, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | W 16K]
+// BM x 128 x 64 tiles, BM/32 x 2... waves laid out (BM/64) x 2, each computing a 64 x 64 block of C as 2 x 2
+// v_mfma_f32_32x32x16_f16.  Operand tiles stream HBM -> LDS by LDS-DMA (8 rows x 128 B per instruction,
+// XOR-swizzled on the source side: conflict-free ds_read_b128 fragments), STAGES deep:
+//   BM = 128: 4 waves, 2 stages of 32 KB, two workgroups per CU;
+//   BM = 256: 8 waves, 3 stages of 48 KB (two tiles in flight behind the one being multiplied), one
+//             workgroup per CU — the W tile feeds twice as many rows, and the prefetch is one tile deeper.
+template <int ACT, int BM, int STAGES>  // ACT 0 = bias only, 1 = bias + exact (erf) GELU
+__global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kernel(const half_t* __restrict__ A,
+                                                                                  const half_t* __restrict__ W,
+                                                                                  const half_t* __restrict__ bias,
+                                                                                  half_t* __restrict__ C, int M,
+                                                                                  int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [STAGES][A BM*128 B | W 16 KiB]
+  constexpr int NW = BM / 32;                   // waves
+  constexpr int A_BYTES = BM * GK * 2, W_BYTES = GN * GK * 2, ST_BYTES = A_BYTES + W_BYTES;
+  constexpr int A_DPW = (BM / 8) / NW, W_DPW = (GN / 8) / NW;  // 1-KiB DMA instructions per wave per tile
+  constexpr int DPW = A_DPW + W_DPW;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int row = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   // XCD-aware tile order: consecutive block ids (same XCD = id % 8) walk down a column of C tiles
-  const int tiles_m = M / GM;
+  const int tiles_m = M / BM;
   const int bid = blockIdx.x;
   const int tm = bid % tiles_m, tn = bid / tiles_m;
-  const half_t* Ab = A + (size_t)tm * GM * K;
+  const half_t* Ab = A + (size_t)tm * BM * K;
   const half_t* Wb = W + (size_t)tn * GN * K;
 
-  // DMA: per stage 16 instructions per operand (8 rows x 128 B each); wave issues 4 + 4
   const int drow = lane >> 3, dslot = lane & 7;
   auto issue = [&](int stage, int kt) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = wave * 4 + j;  // row-block of 8 rows: rows 8i .. 8i+7
+    for (int j = 0; j < A_DPW; ++j) {
+      const int i = wave * A_DPW + j;  // row-block of 8 rows: rows 8i .. 8i+7
       const int r = 8 * i + drow;
       const int c = dslot ^ ((r >> 1) & 7);
-      const half_t* ga = Ab + (size_t)r * K + kt * GK + c * 8;
-      const half_t* gw = Wb + (size_t)r * K + kt * GK + c * 8;
-      __builtin_amdgcn_global_load_lds(RARC_GPTR(ga), RARC_LPTR(smem + stage * 2 * G_TILE_BYTES + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(RARC_GPTR(gw),
-                                       RARC_LPTR(smem + stage * 2 * G_TILE_BYTES + G_TILE_BYTES + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(Ab + (size_t)r * K + kt * GK + c * 8),
+                                       RARC_LPTR(smem + stage * ST_BYTES + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < W_DPW; ++j) {
+      const int i = wave * W_DPW + j;
+      const int r = 8 * i + drow;
+      const int c = dslot ^ ((r >> 1) & 7);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(Wb + (size_t)r * K + kt * GK + c * 8),
+                                       RARC_LPTR(smem + stage * ST_BYTES + A_BYTES + i * 1024), 16, 0, 0);
     }
   };
   // fragment offsets inside a 32-row group (4 KiB): row*128 + ((chunk ^ sw) << 4)
@@ -68,42 +82,72 @@ __global__ __launch_bounds__(256, 2) void rarc_gemm_f16_kernel(const half_t* __r
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
 
   const int KT = K / GK;
-  issue(0, 0);
+#pragma unroll
+  for (int s0 = 0; s0 < STAGES - 1; ++s0)
+    if (s0 < KT) issue(s0, s0);
+  // fragments double-buffered in registers: the four ds_read_b128 of k-step kk+1 are in flight while the
+  // four MFMAs of k-step kk run (in-order LDS returns: "at most 4 outstanding" == step kk has landed)
+  half8 fa0[2], fa1[2], fb0[2], fb1[2];
+#define GEMM_LDFRAG(BUF, KK)                                                                          \
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"                          \
+               "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:4096"                               \
+               : "=&v"(fa0[BUF]), "=&v"(fa1[BUF]), "=&v"(fb0[BUF]), "=&v"(fb1[BUF])                   \
+               : "v"(abase + xk[KK]), "v"(wbase + xk[KK])                                             \
+               : "memory")
+#define GEMM_WAIT(BUF, N)                                                                             \
+  asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(fa0[BUF]), "+v"(fa1[BUF]), "+v"(fb0[BUF]), "+v"(fb1[BUF]))
+  int st = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    const int st = kt & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile kt has landed when at most the DMA of the (STAGES-2) newer tiles is outstanding
+    if (STAGES > 2 && kt + STAGES - 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * DPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (kt + 1 < KT) issue(st ^ 1, kt + 1);
-    const int abase = st * 2 * G_TILE_BYTES + (2 * wm) * 4096;
-    const int wbase = st * 2 * G_TILE_BYTES + G_TILE_BYTES + (2 * wn) * 4096;
+    {  // refill the stage consumed in the previous iteration
+      int ns = st + STAGES - 1;
+      if (ns >= STAGES) ns -= STAGES;
+      if (kt + STAGES - 1 < KT) issue(ns, kt + STAGES - 1);
+    }
+    const int abase = st * ST_BYTES + (2 * wm) * 4096;
+    const int wbase = st * ST_BYTES + A_BYTES + (2 * wn) * 4096;
+    GEMM_LDFRAG(0, 0);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      half8 a0, a1, b0, b1;
-      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:4096\n\t"
-                   "ds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:4096\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1)
-                   : "v"(abase + xk[kk]), "v"(wbase + xk[kk])
-                   : "memory");
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+      const int cur = kk & 1;
+      if (kk == 0) { GEMM_LDFRAG(1, 1); GEMM_WAIT(0, 4); }
+      else if (kk == 1) { GEMM_LDFRAG(0, 2); GEMM_WAIT(1, 4); }
+      else if (kk == 2) { GEMM_LDFRAG(1, 3); GEMM_WAIT(0, 4); }
+      else { GEMM_WAIT(1, 0); }
+      // swapped roles: the W fragment is the A operand, so a lane ends up with ONE row m of C and 16 of
+      // its columns n — four consecutive n per register quad: 8-byte stores instead of 2-byte ones
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb0[cur], fa0[cur], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb1[cur], fa0[cur], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb0[cur], fa1[cur], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb1[cur], fa1[cur], acc[1][1], 0, 0, 0);
     }
+    if (++st == STAGES) st = 0;
   }
-  // epilogue: lane holds column n = lane & 31, rows 8*(r>>2) + 4*h + (r&3) of each 32x32 block
+#undef GEMM_LDFRAG
+#undef GEMM_WAIT
+  // epilogue: lane holds row m = lane & 31 of each 32x32 block and columns n = 8*(r>>2) + 4*h + (r&3)
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    const int m = tm * BM + (2 * wm + i) * 32 + row;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int n = tn * GN + (2 * wn + j) * 32 + row;
-      const float b = (float)bias[n];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = tm * GM + (2 * wm + i) * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-        float v = acc[i][j][r] + b;
-        if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-        C[(size_t)m * N + n] = (half_t)v;
+      for (int g = 0; g < 4; ++g) {
+        const int n0 = tn * GN + (2 * wn + j) * 32 + 8 * g + 4 * h;
+        const half4 b4 = *(const half4*)(bias + n0);
+        half4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][4 * g + e] + (float)b4[e];
+          if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+          out[e] = (half_t)v;
+        }
+        *(half4*)(C + (size_t)m * N + n0) = out;
       }
     }
   }
@@ -393,20 +437,30 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   RARC_REQUIRE(d_a && d_w && d_bias && d_c, RARC_E_INVALID, "rarc_enc_gemm: null pointer");
   RARC_REQUIRE(m > 0 && n > 0 && k > 0 && m % GM == 0 && n % GN == 0 && k % GK == 0, RARC_E_UNSUPPORTED,
                "rarc_enc_gemm: need M,N multiples of 128 and K multiple of 64 (got %d,%d,%d)", m, n, k);
-  const size_t lds = 4 * G_TILE_BYTES;
+  hipStream_t s = (hipStream_t)stream;
+  const half_t *a = (const half_t*)d_a, *w = (const half_t*)d_w, *bs = (const half_t*)d_bias;
+  half_t* c = (half_t*)d_c;
+  // 256-row tiles (3-stage pipeline, one workgroup per CU) when M allows it and there are enough tiles to
+  // fill the chip; the 128-row kernel otherwise
+  const bool big = (m % 256 == 0) && ((m / 256) * (n / GN) >= 256);
+  constexpr size_t lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
   static bool attr = false;
   if (!attr) {
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
     attr = true;
   }
-  const int grid = (m / GM) * (n / GN);
-  if (act == 1)
-    hipLaunchKernelGGL(rarc_gemm_f16_kernel<1>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const half_t*)d_a,
-                       (const half_t*)d_w, (const half_t*)d_bias, (half_t*)d_c, m, n, k);
-  else
-    hipLaunchKernelGGL(rarc_gemm_f16_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const half_t*)d_a,
-                       (const half_t*)d_w, (const half_t*)d_bias, (half_t*)d_c, m, n, k);
+  if (big) {
+    const int grid = (m / 256) * (n / GN);
+    if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 256, 3>), dim3(grid), dim3(512), lds_big, s, a, w, bs, c, m, n, k);
+    else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 256, 3>), dim3(grid), dim3(512), lds_big, s, a, w, bs, c, m, n, k);
+  } else {
+    const int grid = (m / GM) * (n / GN);
+    if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 128, 2>), dim3(grid), dim3(256), lds_small, s, a, w, bs, c, m, n, k);
+    else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 128, 2>), dim3(grid), dim3(256), lds_small, s, a, w, bs, c, m, n, k);
+  }
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
