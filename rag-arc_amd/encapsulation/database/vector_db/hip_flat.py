@@ -138,15 +138,44 @@ class HipFlatVectorStore(VectorStore):
 
     def max_marginal_relevance_search_by_vector(self, embedding, k: int = 4, fetch_k: int = 20,
                                                 lambda_mult: float = 0.5, **kwargs: Any) -> List[Document]:
-        scored = self.similarity_search_by_vector_with_score(embedding, fetch_k, **kwargs)
+        """MMR as the reference does it (VectorStore_Faiss.py:276-372): fetch_k nearest, their texts
+        re-embedded, greedy selection.  `reembed=False` (extension) takes the
+        candidates' vectors from the HBM-resident rows instead of running the encoder on fetch_k texts
+        again: the stored rows are those very embeddings after normalisation, rounded to the storage
+        format (a relative 5e-4 for fp16), so the selection can differ from the reference's only where
+        two candidates' MMR values are within that rounding."""
+        reembed = kwargs.pop("reembed", True)
+        if self.ntotal == 0:
+            return []
+        qv32 = np.array([embedding]).astype(np.float32)
+        scores, rows = self.index.search(qv32, min(fetch_k, self.ntotal))
+        keep = [(float(sc), int(r)) for sc, r in zip(scores[0], rows[0]) if r != -1]
+        scored = [(self.docstore[self.index_to_docstore_id[r]], sc) for sc, r in keep]
         if not scored:
             return []
-        cand = np.array([self.embedding.embed_query(d.content) for d, _ in scored])  # re-embedded, as the reference
+        if reembed:
+            cand = np.array([self.embedding.embed_query(d.content) for d, _ in scored])  # re-embedded, as the reference
+        else:
+            cand = self._stored_vectors([r for _, r in keep])
         qv = np.array(embedding)
         if self.normalize_L2 or self.metric == "cosine":
             qv = qv / np.linalg.norm(qv)
             cand = cand / np.linalg.norm(cand, axis=1, keepdims=True)
         return _mmr_select(scored, cand.tolist(), qv.tolist(), k, lambda_mult)
+
+    def _stored_vectors(self, rows: List[int]) -> np.ndarray:
+        """Rows of the resident index as float64 [n][dim] (fp8 rows decoded and scaled)."""
+        import torch
+
+        idx = self.index
+        sel = torch.as_tensor(rows, dtype=torch.long, device=idx.rows.device) if hasattr(idx.rows, "device") else rows
+        r = idx.rows[sel]
+        if getattr(idx, "storage", "f16") == "f8":
+            vals = r.view(torch.float8_e4m3fn).to(torch.float32) * idx.row_scales[sel][:, None]
+        else:
+            vals = r.to(torch.float32) if hasattr(r, "to") else np.asarray(r).view(np.float16).astype(np.float32)
+        vals = vals.cpu().numpy() if hasattr(vals, "cpu") else np.asarray(vals)
+        return vals[:, : idx.dim].astype(np.float64)
 
     # ------------------------------------------------------------------ maintenance
     def delete(self, ids: Optional[List[str]] = None, **kwargs: Any) -> Optional[bool]:

@@ -136,6 +136,15 @@ def test_store_end_to_end_and_registry(tmp_path, oracle):
     assert [(d.id, s) for d, s in again.similarity_search_with_score("passage 77", k=10)] == \
            [(d.id, s) for d, s in hip.similarity_search_with_score("passage 77", k=10)]
 
+    # MMR from the resident rows (no re-embedding): same candidates, same first pick; later picks may
+    # differ from the re-embedding form only where MMR values tie within fp16 rounding (hash embeddings
+    # are mutually near-orthogonal, so ties are the rule here) — both are valid MMR orders of one pool
+    for q in ("passage 77", "passage 4242"):
+        a = hip.max_marginal_relevance_search(q, k=5, fetch_k=20)
+        b = hip.max_marginal_relevance_search(q, k=5, fetch_k=20, reembed=False)
+        pool = {d.id for d in hip.similarity_search(q, k=20)}
+        assert len(b) == 5 and a[0].id == b[0].id and {d.id for d in b} <= pool and len({d.id for d in b}) == 5
+
     # the same store over fp8 rows (half the HBM): answers equal the fp8 oracle's, and survive save / load
     hip8 = HipFlatVectorStore.from_texts(texts, emb, ids=ids, storage="f8")
     X = np.asarray(emb.embed_documents(texts), np.float32)
