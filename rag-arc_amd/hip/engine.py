@@ -362,6 +362,38 @@ class FlatIndexF16:
             if int(b["found"].item()) & 0x80000000:
                 raise B.RarcError(f"repair of query {qi} overflowed its scratch list")
 
+    def neighbors_above(self, queries, threshold: float, k_cap: int = 64):
+        """Range query by score: for every query, the stored rows whose canonical score is >= threshold
+        (the all-pairs-cosine-with-cut-off pattern of the reference's entity de-duplication,
+        encapsulation/database/graph_db/Base_Neo4j.py:542-583, threshold 0.95, and of SemanticChunker's
+        neighbour distances, core/file_management/chunker/spliter.py:354-371).  Runs as exact top-k_cap
+        searches, 256 queries per scan; a query whose k_cap-th hit still clears the threshold is searched
+        again with a larger k (up to the kernel limit) so that nothing is cut off silently.
+        Returns a list (one entry per query) of (ids int64 array, scores fp32 array), best first."""
+        t = self.torch
+        q = t.as_tensor(queries, dtype=t.float32).to(self.device)
+        if q.ndim == 1:
+            q = q[None, :]
+        out = [None] * q.shape[0]
+        todo = list(range(q.shape[0]))
+        k = max(1, min(int(k_cap), B.MAX_K - 28, max(self.ntotal, 1)))
+        while todo:
+            sub = q[t.as_tensor(todo, device=self.device)]
+            ids, sc = self.search_device(sub, k)
+            ids_h, sc_h = ids.cpu().numpy(), sc.cpu().numpy()
+            again = []
+            for j, qi in enumerate(todo):
+                full = k < min(self.ntotal, B.MAX_K - 28) and sc_h[j, k - 1] >= threshold and ids_h[j, k - 1] >= 0
+                if full:
+                    again.append(qi)
+                    continue
+                m = (sc_h[j] >= threshold) & (ids_h[j] >= 0)
+                out[qi] = (ids_h[j][m], sc_h[j][m])
+            todo = again
+            if todo:
+                k = min(4 * k, B.MAX_K - 28, self.ntotal)
+        return out
+
     def verify_query(self, queries, qi: int, ids, scores) -> int:
         """Run the exact repair scan on row `qi` of (ids, scores) [device tensors from search_device]
         and return how many rows beat the stored k-th entry (0 == the answer was already exact)."""

@@ -188,3 +188,22 @@ def test_l2norm_rows_kernel_matches_oracle(hip, oracle):
     assert np.array_equal(out.cpu().numpy()[:, :96].view(np.uint32),
                           oracle.normalize_L2(wide.cpu().numpy()[:, :96].copy()).view(np.uint32))
     assert not out.cpu().numpy()[:, 96:].any()
+
+
+def test_neighbors_above_threshold_matches_numpy(hip, oracle):
+    """All-pairs cosine with a cut-off (the reference's entity de-duplication pattern): every stored row
+    scoring >= threshold for each query, and nothing else — including a cluster larger than the first k."""
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((3000, 256)).astype(np.float32)
+    c = rng.standard_normal(256).astype(np.float32)
+    X[100:300] = c + 0.05 * rng.standard_normal((200, 256)).astype(np.float32)     # 200 near-duplicates
+    idx = hip.FlatIndexF16(256)
+    idx.add(X)
+    Q = np.stack([c, X[5], rng.standard_normal(256).astype(np.float32)])
+    got = idx.neighbors_above(Q, 0.95, k_cap=64)                                    # cluster (200) > k_cap (64)
+    rows, _ = oracle.ingest_f16(X)
+    ref_i, ref_s, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), 900)
+    for j in range(3):
+        m = ref_s[j] >= 0.95
+        assert np.array_equal(got[j][0], ref_i[j][m]) and np.array_equal(got[j][1].view(np.uint32), ref_s[j][m].view(np.uint32))
+    assert len(got[0][0]) == 200 and len(got[1][0]) == 1 and len(got[2][0]) == 0
