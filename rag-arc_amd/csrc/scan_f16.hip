@@ -580,14 +580,15 @@ int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t
   p.q16 = (const half_t*)q16;
   p.n_rows = (uint32_t)n_rows;
   p.n_tiles = (uint32_t)((n_rows + 31) / 32);
-  // sample size grows with the shard (1/128 of the tiles, at least 4096 and at most 16384 rows): the
-  // scan starts from the k'-th best of the sample, and with the int8 error margin taken off it a
-  // 4096-row sample lets several per cent of a large shard through before feedback takes over
-  // (42K candidates per query at 100M rows against 33K with 65536 sample rows — but those cost 0.5 ms
-  // per batch whatever the shard size, which an 8-way sharded scan of 3.7 ms cannot afford)
-  uint32_t seed_tiles = p.n_tiles / 128;
+  // sample size grows with the shard: 1/1024 of the tiles, at least 4096 and at most 65536 rows.  The
+  // scan starts from the k'-th best of the sample, and with the int8 error margin taken off it a small
+  // sample lets several per cent of a large shard through before feedback takes over (100M rows: 42K
+  // candidates per query and a 3 % longer scan with 4096 sample rows, 33K with 65536) — but the sample
+  // costs the same 8 µs per 1024 rows whatever the shard size, which a 3.7 ms scan of a 12.5M-row shard
+  // (100M rows over 8 GPUs) cannot afford: it gets 12K rows.
+  uint32_t seed_tiles = p.n_tiles / 1024;
   if (seed_tiles < (uint32_t)RARC_SEED_TILES) seed_tiles = (uint32_t)RARC_SEED_TILES;
-  if (seed_tiles > 512u) seed_tiles = 512u;
+  if (seed_tiles > (uint32_t)RARC_SEED_MAX_TILES) seed_tiles = (uint32_t)RARC_SEED_MAX_TILES;
   if (seed_tiles > p.n_tiles) seed_tiles = p.n_tiles;
   int rc = RARC_OK;
   if (seed_tiles > 0) {
