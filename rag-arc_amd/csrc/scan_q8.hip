@@ -81,7 +81,7 @@ __device__ __forceinline__ void q8_lds_barrier() {
 
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
 // 8 = no threshold refresh, 16 = no conversion, 32 = prune fast path only, 64 = never flush,
-// 1024 = s_memtime timeline of workgroup 0 into p.dbg
+// 256 = no ping-pong between the wave groups, 1024 = s_memtime timeline of workgroup 0 into p.dbg
 //
 // Vector-memory discipline.  The prefetched tile registers are consumed with counted waits
 // ("all but the newest N operations have returned"), which the compiler derives per program path and
@@ -331,10 +331,17 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // (scheduling fences: the groups must be ISSUED in this order, or the counted waits the compiler
   // derives for the first loop iteration assume the wrong group is the newest)
   __builtin_amdgcn_sched_barrier(0);
+  // ping-pong: waves w and w+4 share a SIMD.  Group A (waves 0-3) runs a tile's MFMAs first and prunes it
+  // afterwards; group B (waves 4-7) prunes the PREVIOUS tile first and runs the MFMAs second — so one
+  // wave's VALU / VMEM phase (prune, survivors, prefetch issue) overlaps its partner's matrix phase
+  // instead of both leaving the matrix pipe idle at the same time.
+  constexpr bool PP = (D <= 768) && !(ABL & 256);  // (where the second accumulator still fits in registers)
+  const bool grp_b = PP && wave >= Q8_WAVES / 2;
   if constexpr (NG == 2) {
     fetch(f[1], clamp_tile(t0 + stride));
     __builtin_amdgcn_sched_barrier(0);
-    fetch(f[0], clamp_tile(t0 + 2 * stride));
+    // (group B issues this one in its first iteration, by the same formula as in every later one)
+    if (!grp_b) fetch(f[0], clamp_tile(t0 + 2 * stride));
   } else {
     fetch(f[0], clamp_tile(t0 + stride));
   }
@@ -346,29 +353,47 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   q8_lds_barrier();
 
+  i32x16 acc_b = {0};      // group B: scores of the tile whose pruning is still to come
+  bool live_prev = false;  // group B: that tile exists
   uint32_t it = 0;
   // one iteration = one tile; PAR (its parity) names the LDS buffer read and the fetch group consumed
 #define Q8_STAMP(slot)                                                                                        \
   if ((ABL & 1024) && blockIdx.x == 0 && it >= 1000 && it < 1016 && lane == 0)                                 \
     p.dbg[8 + ((it - 1000) * Q8_WAVES + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
 #define Q8_G(PAR) (NG == 2 ? ((PAR) ^ 1) : 0)
-#define Q8_ITER(PAR)                                                                                          \
+#define Q8_ITER(PAR, GB)                                                                                      \
   {                                                                                                           \
     Q8_STAMP(0)                                                                                               \
-    const float tinv = mcur[PAR].y, tsc = mcur[PAR].x;                                                        \
-    i32x16 acc;                                                                                               \
-    acc = mfma_convert(PAR, f[Q8_G(PAR)]);                                                                    \
-    mcur[(PAR) ^ 1] = f[Q8_G(PAR)].meta;                                                                      \
-    Q8_STAMP(1)                                                                                               \
-    if (!(ABL & 8)) {                                                                                         \
-      thr = fmaxf(thr, __uint_as_float(f[Q8_G(PAR)].thr));                                                    \
-      if (lane < 32) s_hland[32 * wave + lane] = f[Q8_G(PAR)].hw;                                             \
+    if (!(GB)) { /* ---- group A: MFMA(cur) + convert(next), then prune(cur), then refill ---- */            \
+      const float tinv = mcur[PAR].y, tsc = mcur[PAR].x;                                                      \
+      i32x16 acc;                                                                                             \
+      acc = mfma_convert(PAR, f[Q8_G(PAR)]);                                                                  \
+      mcur[(PAR) ^ 1] = f[Q8_G(PAR)].meta;                                                                    \
+      Q8_STAMP(1)                                                                                             \
+      if (!(ABL & 8)) {                                                                                       \
+        thr = fmaxf(thr, __uint_as_float(f[Q8_G(PAR)].thr));                                                  \
+        if (lane < 32) s_hland[32 * wave + lane] = f[Q8_G(PAR)].hw;                                           \
+      }                                                                                                       \
+      if (!(ABL & 1) && live) prune(acc, cur, tinv, tsc);                                                     \
+      else if (acc[0] == 0x7fffffff) p.cnt2[0] = 1; /* keep the MFMAs alive */                                \
+      Q8_STAMP(2)                                                                                             \
+      /* refill that group with tile cur+3·stride */                                                          \
+      if (!(ABL & 2)) fetch(f[Q8_G(PAR)], clamp_tile(cur + (NG + 1) * stride));                               \
+    } else { /* ---- group B: prune(previous tile), refill the group consumed last iteration, then MFMA ---- */ \
+      if (!(ABL & 1) && live_prev) prune(acc_b, cur - stride, mcur[(PAR) ^ 1].y, mcur[(PAR) ^ 1].x);          \
+      live_prev = live;                                                                                       \
+      Q8_STAMP(1)                                                                                             \
+      if (!(ABL & 2)) fetch(f[PAR], clamp_tile(cur + 2 * stride));                                            \
+      __builtin_amdgcn_sched_barrier(0); /* the chunk loads must be ISSUED before the matrix phase */          \
+      Q8_STAMP(2)                                                                                             \
+      acc_b = mfma_convert(PAR, f[(PAR) ^ 1]);                                                                \
+      mcur[(PAR) ^ 1] = f[(PAR) ^ 1].meta;                                                                    \
+      if (!(ABL & 8)) {                                                                                       \
+        thr = fmaxf(thr, __uint_as_float(f[(PAR) ^ 1].thr));                                                  \
+        if (lane < 32) s_hland[32 * wave + lane] = f[(PAR) ^ 1].hw;                                           \
+      }                                                                                                       \
+      if ((ABL & 1) && acc_b[0] == 0x7fffffff) p.cnt2[0] = 1;                                                 \
     }                                                                                                         \
-    if (!(ABL & 1) && live) prune(acc, cur, tinv, tsc);                                                            \
-    else if (acc[0] == 0x7fffffff) p.cnt2[0] = 1; /* keep the MFMAs alive */                                  \
-    Q8_STAMP(2)                                                                                               \
-    /* refill that group with tile cur+3·stride */                                                            \
-    if (!(ABL & 2)) fetch(f[Q8_G(PAR)], clamp_tile(cur + (NG + 1) * stride));                                        \
     Q8_STAMP(3)                                                                                               \
     q8_lds_barrier();                                                                                         \
     Q8_STAMP(4)                                                                                               \
@@ -396,20 +421,31 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // the compiler's wait-counter merge treat the wrong fetch group as the newest one and drain the
   // queue every iteration).  When a workgroup's tile count is odd the last half-iteration runs on a
   // tile index past the end: its scores are ignored (`live`), its fetch is the usual tile-0 dummy.
-  for (uint32_t base = t0; base < p.n_tiles; base += 2 * stride) {
-    {
-      const uint32_t cur = base;
-      const bool live = true;
-      Q8_ITER(0)
-    }
-    {
-      const uint32_t cur = base + stride;
-      const bool live = cur < p.n_tiles;
-      Q8_ITER(1)
-    }
+  // (two copies of the loop, one per wave group: inside ONE loop the compiler would merge the wait counters
+  // of the two instruction orders and fall back to draining the queue)
+#define Q8_LOOP(GB)                                                                   \
+  for (uint32_t base = t0; base < p.n_tiles; base += 2 * stride) {                    \
+    {                                                                                 \
+      const uint32_t cur = base;                                                      \
+      const bool live = true;                                                         \
+      Q8_ITER(0, GB)                                                                  \
+    }                                                                                 \
+    {                                                                                 \
+      const uint32_t cur = base + stride;                                             \
+      const bool live = cur < p.n_tiles;                                              \
+      Q8_ITER(1, GB)                                                                  \
+    }                                                                                 \
   }
+  if (grp_b) {
+    Q8_LOOP(true)
+  } else {
+    Q8_LOOP(false)
+  }
+#undef Q8_LOOP
 #undef Q8_ITER
 #undef Q8_G
+  // group B still owes the pruning of its last tile (the second half of the last pair: LDS buffer 1)
+  if (grp_b && !(ABL & 1) && live_prev) prune(acc_b, t0 + (((p.n_tiles - 1 - t0) / stride) | 1u) * stride, mcur[1].y, mcur[1].x);
   flush();
   __syncthreads();
   if (tid < RARC_MAX_QUERIES) p.cnt2[(size_t)blockIdx.x * RARC_MAX_QUERIES + tid] = s_cnt[tid];

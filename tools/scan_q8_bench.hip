@@ -64,8 +64,8 @@ int main(int argc, char** argv) {
   int grid = 256;
   const double gb = (double)N * D * 2 / 1e9;
 #define RUN(A) { float us = run<A>(p, grid, 6, corpus, N, qb, KP, ws); printf("ABL=%2d  %8.1f us  %6.2f TB/s\n", A, us, gb / us * 1e3); }
-  RUN(0) RUN(0)
-  for (int v = 0; v < 0; ++v) { if (v == 0) run<1024>(p, grid, 1, corpus, N, qb, KP, ws); else run<1025>(p, grid, 1, corpus, N, qb, KP, ws);
+  RUN(0) RUN(0) RUN(256) RUN(1) RUN(257)
+  for (int v = 0; v < 1; ++v) { if (v == 0) run<1024>(p, grid, 1, corpus, N, qb, KP, ws); else run<1025>(p, grid, 1, corpus, N, qb, KP, ws);
     std::vector<unsigned long long> h(8192); hipMemcpy(h.data(), p.dbg, 65536, hipMemcpyDeviceToHost);
     printf("\ntimeline wg0 (%s), shader cycles relative to wave0 stamp0 of the iteration:  start  mfma+conv  pruned  fetched  barrier_out | next_start\n", v ? "no prune" : "full");
     for (int it = 4; it < 8; ++it) for (int w = 0; w < 8; ++w) { const unsigned long long* r = &h[8 + (it * 8 + w) * 8]; unsigned long long b0 = h[8 + (it * 8) * 8]; unsigned long long nb = h[8 + ((it + 1) * 8 + w) * 8];
