@@ -377,51 +377,54 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__
   __shared__ float part[3][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5;
-  const uint32_t ti = blockIdx.y;
   const uint32_t step = n_tiles / seed_tiles;  // >= 1 (seed_tiles <= n_tiles)
-  const uint32_t tile = ti * step;
   const uint32_t qidx = blockIdx.x * 32 + row;
-  uint32_t arow = tile * 32 + row;
-  if (arow >= n_rows) arow = n_rows - 1;
+  // the block's 32 queries stay in registers (this wave's quarter of K) while it walks its share of the
+  // sample tiles: re-reading them per tile was most of this kernel's L2 traffic
   const half_t* qp = q16 + (size_t)qidx * D + 8 * h + 16 * KW * wave;
-  half8 af[KW], bf[KW];
-  if constexpr (FMT == 1) {
-    const uint8_t* ap = (const uint8_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
+  half8 bf[KW];
 #pragma unroll
-    for (int ks = 0; ks < KW; ++ks) {
-      const uint2 v = *(const uint2*)(ap + 16 * ks);  // 8 fp8 values
-      const half2_t p0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.x, 1.0f, false);
-      const half2_t p1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.x, 1.0f, true);
-      const half2_t p2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, false);
-      const half2_t p3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, true);
-      af[ks] = (half8){p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
-      bf[ks] = *(const half8*)(qp + 16 * ks);
+  for (int ks = 0; ks < KW; ++ks) bf[ks] = *(const half8*)(qp + 16 * ks);
+  for (uint32_t ti = blockIdx.y; ti < seed_tiles; ti += gridDim.y) {
+    const uint32_t tile = ti * step;
+    uint32_t arow = tile * 32 + row;
+    if (arow >= n_rows) arow = n_rows - 1;
+    half8 af[KW];
+    if constexpr (FMT == 1) {
+      const uint8_t* ap = (const uint8_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
+#pragma unroll
+      for (int ks = 0; ks < KW; ++ks) {
+        const uint2 v = *(const uint2*)(ap + 16 * ks);  // 8 fp8 values
+        const half2_t p0 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.x, 1.0f, false);
+        const half2_t p1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.x, 1.0f, true);
+        const half2_t p2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, false);
+        const half2_t p3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, true);
+        af[ks] = (half8){p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+      }
+    } else {
+      const half_t* ap = (const half_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
+#pragma unroll
+      for (int ks = 0; ks < KW; ++ks) af[ks] = *(const half8*)(ap + 16 * ks);
     }
-  } else {
-    const half_t* ap = (const half_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
+    f32x16 acc = {0};
 #pragma unroll
-    for (int ks = 0; ks < KW; ++ks) {
-      af[ks] = *(const half8*)(ap + 16 * ks);
-      bf[ks] = *(const half8*)(qp + 16 * ks);
+    for (int ks = 0; ks < KW; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[ks], acc, 0, 0, 0);
+    __syncthreads();  // the previous tile's partial sums have been read
+    if (wave > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
     }
-  }
-  f32x16 acc = {0};
+    __syncthreads();
+    if (wave == 0) {
+      float* out = seed + (size_t)qidx * (RARC_SEED_MAX_TILES * 32) + ti * 32;
 #pragma unroll
-  for (int ks = 0; ks < KW; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[ks], acc, 0, 0, 0);
-  if (wave > 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[wave - 1][r][lane] = acc[r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* out = seed + (size_t)qidx * (RARC_SEED_MAX_TILES * 32) + ti * 32;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float v = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
-      const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
-      const bool live = tile * 32 + rr < n_rows;
-      if (FMT == 1 && live) v *= rowscale[tile * 32 + rr];
-      out[rr] = live ? v : -INFINITY;
+      for (int r = 0; r < 16; ++r) {
+        float v = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const bool live = tile * 32 + rr < n_rows;
+        if (FMT == 1 && live) v *= rowscale[tile * 32 + rr];
+        out[rr] = live ? v : -INFINITY;
+      }
     }
   }
 }
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__
 // 65536 floats, L2 resident): min/max, a 2048-bin histogram of the order-preserving keys over
 // [min, max], then the few keys of the bin holding the k'-th largest are ranked directly.  Also sets
 // the query's histogram window and clears its histogram.
-__global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, uint32_t seed_rows, uint32_t kprime,
+__global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, uint32_t seed_rows, uint32_t kprime,
                                                             uint32_t nq, float bin_lo_dflt, float bin_hi_dflt,
                                                             const float* sub_a, const float* sub_b,
                                                             uint32_t* thr, float* binlo, float* binscale,
@@ -451,12 +454,12 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
       if (!(v == v)) v = -INFINITY;  // NaN never becomes a threshold
       return rarc_ordkey(v);
     };
-    for (uint32_t i = tid; i < 2048; i += 256) s_hist[i] = 0;
+    for (uint32_t i = tid; i < 2048; i += blockDim.x) s_hist[i] = 0;
     if (tid == 0) { s_max = 0; s_min = 0xffffffffu; s_nlist = 0; s_key = 0; s_bin = 0; s_need = kprime; }
     __syncthreads();
     {  // block min / max of the keys: wave reduction first, one LDS atomic per wave
       uint32_t lmax = 0, lmin = 0xffffffffu;
-      for (uint32_t j = tid; j < seed_rows; j += 256) {
+      for (uint32_t j = tid; j < seed_rows; j += blockDim.x) {
         const uint32_t k = key_at(j);
         lmax = k > lmax ? k : lmax;
         lmin = (k > 0x007fffffu && k < lmin) ? k : lmin;  // skip -inf padding
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
       uint32_t b2 = k > kmin ? (uint32_t)((float)(k - kmin) * kscale) : 0u;  // monotone in key
       return b2 > 2047u ? 2047u : b2;
     };
-    for (uint32_t j = tid; j < seed_rows; j += 256) atomicAdd(&s_hist[bin_of_key(key_at(j))], 1u);
+    for (uint32_t j = tid; j < seed_rows; j += blockDim.x) atomicAdd(&s_hist[bin_of_key(key_at(j))], 1u);
     __syncthreads();
     if (tid < 64) {  // wave 0: bin holding the k'-th largest, count above it
       uint32_t above = 0;
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
     }
     __syncthreads();
     const uint32_t bin = s_bin, need = s_need;
-    for (uint32_t j = tid; j < seed_rows; j += 256) {
+    for (uint32_t j = tid; j < seed_rows; j += blockDim.x) {
       const uint32_t k = key_at(j);
       if (bin_of_key(k) == bin) {
         const uint32_t pos = atomicAdd(&s_nlist, 1u);
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
     __syncthreads();
     const uint32_t nl_all = s_nlist, nl = nl_all < (uint32_t)LIST ? nl_all : (uint32_t)LIST;
     if (nl_all <= (uint32_t)LIST) {
-      for (uint32_t i = tid; i < nl; i += 256) {  // the need-th largest of the bin (ties share a value)
+      for (uint32_t i = tid; i < nl; i += blockDim.x) {  // the need-th largest of the bin (ties share a value)
         const uint32_t mine = s_list[i];
         uint32_t gt = 0, ge = 0;
         for (uint32_t j = 0; j < nl; ++j) { gt += s_list[j] > mine; ge += s_list[j] >= mine; }
@@ -545,7 +548,10 @@ __global__ __launch_bounds__(256) void rarc_seed_thr_kernel(const float* seed, u
 template <int D, int FMT = 0>
 static int launch_seed(const ScanParams& p, uint32_t seed_tiles, float* seed, hipStream_t s,
                        const float* rowscale = nullptr) {
-  hipLaunchKernelGGL((rarc_seed_kernel<D, FMT>), dim3(RARC_MAX_QUERIES / 32, seed_tiles), dim3(256), 0, s,
+  // 8 query blocks x up to 128 tile walkers: 1024 workgroups of 4 waves fill the chip, and each walker
+  // amortises its query fragments over seed_tiles / 128 tiles
+  const uint32_t walkers = seed_tiles < 128u ? seed_tiles : 128u;
+  hipLaunchKernelGGL((rarc_seed_kernel<D, FMT>), dim3(RARC_MAX_QUERIES / 32, walkers), dim3(256), 0, s,
                      (const void*)p.corpus, rowscale, p.q16, p.n_rows, p.n_tiles, seed_tiles, seed);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
@@ -614,7 +620,7 @@ int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t
     }
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, s, ws.seed, seed_tiles * 32,
+  hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(1024), 0, s, ws.seed, seed_tiles * 32,
                      (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, sub_a, sub_b, (uint32_t*)ws.thr, ws.binlo,
                      ws.binscale, ws.bininv, ws.flags, ws.hist);
   RARC_HIP_CHECK(hipGetLastError());
@@ -661,7 +667,7 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
     RARC_DISPATCH_D(SEED_CALL)
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, s, ws.seed, seed_tiles * 32,
+  hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(1024), 0, s, ws.seed, seed_tiles * 32,
                      (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, (const float*)nullptr, (const float*)nullptr,
                      (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist);
   RARC_HIP_CHECK(hipGetLastError());

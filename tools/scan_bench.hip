@@ -17,8 +17,8 @@ static float run(const ScanParams& p, int grid, int iters, uint32_t nq, int kpri
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e30f;
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(rarc_seed_kernel<D>, dim3(8, seed_tiles), dim3(256), 0, 0, p.corpus, p.q16, p.n_rows, p.n_tiles, seed_tiles, ws.seed);
-    hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(256), dim3(256), 0, 0, ws.seed, seed_tiles * 32, (uint32_t)kprime, nq, -1.f, 1.f, (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist);
+    hipLaunchKernelGGL((rarc_seed_kernel<D, 0>), dim3(8, seed_tiles), dim3(256), 0, 0, (const void*)p.corpus, (const float*)nullptr, p.q16, p.n_rows, p.n_tiles, seed_tiles, ws.seed);
+    hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(256), dim3(1024), 0, 0, ws.seed, seed_tiles * 32, (uint32_t)kprime, nq, -1.f, 1.f, (const float*)nullptr, (const float*)nullptr, (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist);
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL((rarc_scan_f16_kernel<D, ABL>), dim3(grid), dim3(512), lds, 0, p);
     hipEventRecord(e1, 0);
@@ -37,8 +37,9 @@ int main(int argc, char** argv) {
   size_t wsbytes = RARC_WS_CAND + (size_t)256 * CAP * 8; hipMalloc(&wsb, wsbytes);
   rarc_synth_rows_f16((uint16_t*)corpus, D, D, 0, N, 1234, 0);
   { float* qf; hipMalloc(&qf, 256 * D * 4); rarc_synth_rows_f32(qf, D, D, 0, 256, 4321, 0);
-    float* q32; float* eps; hipMalloc(&q32, 256 * D * 4); hipMalloc(&eps, 1024);
-    rarc_prep_queries(qf, D, 256, D, D, 1, 1.001f, q32, (uint16_t*)q16, eps, 0); hipDeviceSynchronize(); }
+    void* qblock; hipMalloc(&qblock, rarc_qb_bytes(D));
+    rarc_prep_queries(qf, D, 256, D, D, 1, 1.001f, nullptr, qblock, 0); hipDeviceSynchronize();
+    hipMemcpy(q16, rarc_qb_carve(qblock, D).q16, 256 * D * 2, hipMemcpyDeviceToDevice); }
   RarcWs ws = rarc_ws_carve(wsb);
   ScanParams p; p.corpus = corpus; p.q16 = q16; p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32);
   p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
