@@ -35,12 +35,14 @@ def parse():
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--storage", choices=("f16", "f8"), default="f16",
                     help="row storage: fp16 (default) or fp8 e4m3fn + per-row scale (BASELINE config 5)")
+    ap.add_argument("--shadow", action="store_true",
+                    help="keep the int8 image of the fp16 rows (+50%% HBM): the prefilter scan reads it instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true")
     return ap.parse_args()
 
 
-def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="auto", storage="f16"):
+def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="auto", storage="f16", shadow=False):
     """HBM-resident shard holding global rows [lo, hi) of the synthetic corpus."""
     n = hi - lo
     if storage == "f8":  # synthetic fp32 rows -> ingest kernel (normalise, per-row scale, e4m3fn), in slabs
@@ -58,7 +60,7 @@ def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, 
     B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d_pad, dim, lo, n, seed, 0), "rarc_synth_rows_f16")
     if cap > n:
         rows[n:].zero_()
-    idx = FlatIndexF16(dim, metric="cosine", device=dev_index, id_base=lo, scan=scan)
+    idx = FlatIndexF16(dim, metric="cosine", device=dev_index, id_base=lo, scan=scan, shadow=shadow)
     idx.add_rows_f16(rows, 1.001, n_valid=n)  # adopts the buffer (no copy); unit rows rounded to fp16
     return idx
 
@@ -124,10 +126,10 @@ def main():
     if rows <= 0:  # auto: config 4's corpus if every rank's shard (+ slack) fits its HBM
         free = torch.cuda.mem_get_info(dev)[0]
         rows = 100_000_000
-        while rows > 1_000_000 and (rows / world) * d_pad * esize > 0.85 * free:
+        while rows > 1_000_000 and (rows / world) * d_pad * (esize + (1 if a.shadow else 0)) > 0.85 * free:
             rows //= 10
     lo, hi = shard_range(rows, rank, world)
-    idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi, storage=a.storage)
+    idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi, storage=a.storage, shadow=a.shadow)
     searcher = ShardedFlatSearch(idx, force_collective=use_dist)
     q = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev)
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), a.dim, a.dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
@@ -143,7 +145,8 @@ def main():
     tot_ms, n_l = ctypes.c_double(0), ctypes.c_int(0)
     B.check(lib.rarc_profile_end(ctypes.byref(tot_ms), ctypes.byref(n_l)), "rarc_profile_end")
     scan_ms = tot_ms.value / max(1, n_l.value)
-    shard_bytes = (hi - lo) * d_pad * esize  # algorithmic bytes of one scan launch on this rank
+    # algorithmic bytes of one scan launch on this rank (shadow mode: the scan reads the int8 image)
+    shard_bytes = (hi - lo) * d_pad * (1 if a.shadow else esize)
     flagged = len(getattr(idx, "last_repaired", []))
     # full-size exactness property on this rank's shard: the exact repair scan must find no row
     # beating the returned k-th entry (local results, before the cross-shard merge)
@@ -173,6 +176,7 @@ def main():
             "config": {"workload": f"{rows}x{a.dim} {'fp8 (e4m3fn + row scale)' if a.storage == 'f8' else 'fp16'} corpus resident in HBM, row-sharded over {world} GPU(s), "
                                    f"batch {a.batch} queries, cosine top-{a.k}, exact (canonical fp32 rescore)",
                        "n_corpus": rows, "d": a.dim, "batch": a.batch, "k": a.k, "rows_per_gpu": hi - lo,
+                       "int8_shadow_image": bool(a.shadow),
                        "repaired_queries_last_step": flagged,
                        "full_size_check": {"queries_verified_by_exact_rescan": 2, "rows_beating_kth": beat}},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -164,6 +164,23 @@ int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, con
                     uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Optional int8 "shadow" image of an fp16 corpus.  The int8-prefilter scan converts every fp16 row to
+ * int8 on each search; with d_pad a multiple of 256 the conversion can be done once, at ingest
+ * (rarc_quant_shadow_f16 = rarc_quant_meta_f16 + the image, int8 [ceil32(n_rows)][d_pad], caller-owned),
+ * and rarc_search_f16_shadow then scans the image instead: half the HBM traffic per search and no
+ * conversion arithmetic, for 50 % more HBM footprint.  Candidates are identical by construction (same
+ * bytes, same bound), the canonical rescore still reads the fp16 rows: results are bit-identical to
+ * rarc_search_f16.
+ */
+int rarc_quant_shadow_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, int64_t first_row,
+                          float* d_qmeta, int8_t* d_shadow8, void* stream);
+int rarc_search_f16_shadow(const uint16_t* d_corpus_f16, const int8_t* d_shadow8, int64_t n_rows, int d_pad,
+                           const float* d_qmeta, const void* d_qblock, int nq, int k, int kprime,
+                           int64_t id_base, float bin_lo, float bin_hi, int64_t* d_out_ids,
+                           float* d_out_scores, uint32_t* d_status, void* d_workspace, size_t workspace_bytes,
+                           int cand_cap, void* stream);
+
+/*
  * fp8 corpus (BASELINE.json config 5's storage): rows of OCP e4m3fn bytes, d_pad a multiple of 256
  * (rarc_padded_dim_f8), plus one fp32 scale per row: value[m] = d_row_scale[r] * decode(byte[m]).
  * Half the HBM footprint and scan traffic of fp16.  The calls mirror their fp16 counterparts:

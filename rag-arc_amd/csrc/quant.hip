@@ -24,7 +24,8 @@ __device__ __forceinline__ half_t half_round_down(float v) {
 // one workgroup (256 threads) per tile of 32 rows x d_pad fp16 (contiguous 64*d_pad bytes)
 __global__ __launch_bounds__(256) void rarc_quant_meta_kernel(const uint4* __restrict__ corpus, int d_pad,
                                                               uint32_t first_tile, uint32_t n_tiles,
-                                                              float* __restrict__ meta) {
+                                                              float* __restrict__ meta,
+                                                              uint2* __restrict__ shadow) {
   __shared__ uint32_t s_max;
   __shared__ uint32_t s_res[32];
   const int tid = threadIdx.x;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void rarc_quant_meta_kernel(const uint4* __res
     for (int c = tid; c < nchunk; c += 256) {
       const uint4 v = src[c];
       const uint2 q = rarc_quant8_chunk(v, s);
+      if (shadow) shadow[(size_t)t * nchunk + c] = q;  // the int8 image itself (row-major int8 [row][d_pad])
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
       const uint32_t qb[2] = {q.x, q.y};
       uint32_t acc = 0;
@@ -114,7 +116,26 @@ extern "C" int rarc_quant_meta_f16(const uint16_t* d_corpus_f16, int64_t n_rows,
   const uint32_t nt = t1 - t0;
   const int grid = nt < 8192u ? (int)nt : 8192;
   hipLaunchKernelGGL(rarc_quant_meta_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                     (const uint4*)d_corpus_f16, d_pad, t0, nt, d_qmeta);
+                     (const uint4*)d_corpus_f16, d_pad, t0, nt, d_qmeta, (uint2*)nullptr);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+// Same pass, also keeping the int8 image ("shadow") the prefilter scan would otherwise recompute from
+// the fp16 rows on every search: d_shadow8 is int8 [ceil32(n_rows)][d_pad], caller-owned.
+extern "C" int rarc_quant_shadow_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, int64_t first_row,
+                                     float* d_qmeta, int8_t* d_shadow8, void* stream) {
+  RARC_REQUIRE(d_qmeta && d_shadow8 && (d_corpus_f16 || n_rows == 0), RARC_E_INVALID,
+               "rarc_quant_shadow_f16: null pointer");
+  RARC_REQUIRE(d_pad > 0 && d_pad % 256 == 0 && n_rows >= 0 && first_row >= 0 && first_row <= n_rows &&
+                   n_rows < (int64_t)0xffffffe0ll,
+               RARC_E_INVALID, "rarc_quant_shadow_f16: bad arguments (d_pad must be a multiple of 256; got %d)", d_pad);
+  const uint32_t t0 = (uint32_t)(first_row / 32), t1 = (uint32_t)((n_rows + 31) / 32);
+  if (t1 <= t0) return RARC_OK;
+  const uint32_t nt = t1 - t0;
+  const int grid = nt < 8192u ? (int)nt : 8192;
+  hipLaunchKernelGGL(rarc_quant_meta_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)d_corpus_f16, d_pad, t0, nt, d_qmeta, (uint2*)d_shadow8);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

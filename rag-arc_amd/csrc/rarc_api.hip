@@ -12,7 +12,7 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
 int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                         const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
                         const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
-                        const RarcWs& ws, int cap, int* grid_out, hipStream_t s);
+                        const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8 = nullptr);
 int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
                             const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
                             int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s);
@@ -139,6 +139,37 @@ extern "C" int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
   return rarc_repair_launch(d_corpus_f16, nullptr, 0, n_rows, d_pad, qb.q32 + (size_t)q * d_pad, k, id_base,
                             d_out_ids + (size_t)q * k, d_out_scores + (size_t)q * k, d_found, ws, cap,
                             (hipStream_t)stream);
+}
+
+// ---- fp16 rows + int8 shadow image: the prefilter scan reads the image (half the bytes, no conversion) ----
+extern "C" int rarc_search_f16_shadow(const uint16_t* d_corpus_f16, const int8_t* d_shadow8, int64_t n_rows,
+                                      int d_pad, const float* d_qmeta, const void* d_qblock, int nq, int k,
+                                      int kprime, int64_t id_base, float bin_lo, float bin_hi, int64_t* d_out_ids,
+                                      float* d_out_scores, uint32_t* d_status, void* d_workspace,
+                                      size_t workspace_bytes, int cand_cap, void* stream) {
+  RARC_REQUIRE(d_qblock && d_qmeta && d_out_ids && d_out_scores && d_status, RARC_E_INVALID,
+               "rarc_search_f16_shadow: null pointer");
+  RARC_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll, RARC_E_INVALID,
+               "rarc_search_f16_shadow: n_rows=%lld outside [0, 2^32-32)", (long long)n_rows);
+  RARC_REQUIRE((d_corpus_f16 && d_shadow8) || n_rows == 0, RARC_E_INVALID, "rarc_search_f16_shadow: null corpus");
+  RARC_REQUIRE(d_pad > 0 && d_pad % 256 == 0, RARC_E_INVALID, "rarc_search_f16_shadow: d_pad=%d (multiple of 256)", d_pad);
+  RARC_REQUIRE(nq >= 0 && nq <= RARC_MAX_QUERIES, RARC_E_INVALID, "rarc_search_f16_shadow: nq=%d outside [0,%d]", nq,
+               RARC_MAX_QUERIES);
+  RARC_REQUIRE(k >= 1 && k <= kprime && kprime <= RARC_MAX_K, RARC_E_INVALID,
+               "rarc_search_f16_shadow: need 1 <= k (%d) <= kprime (%d) <= %d", k, kprime, RARC_MAX_K);
+  RARC_REQUIRE(bin_hi > bin_lo, RARC_E_INVALID, "rarc_search_f16_shadow: empty histogram range");
+  int rc = check_ws(d_workspace, workspace_bytes, cand_cap, "rarc_search_f16_shadow");
+  if (rc) return rc;
+  if (nq == 0) return RARC_OK;
+  const RarcWs ws = rarc_ws_carve(d_workspace);
+  const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
+  hipStream_t s = (hipStream_t)stream;
+  int n_wg = 0;
+  rc = rarc_scan_q8_launch(d_corpus_f16, nullptr, 2, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16, qb.eps8,
+                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, d_shadow8);
+  if (rc) return rc;
+  return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
+                                 n_wg, d_out_ids, d_out_scores, d_status, s);
 }
 
 // ---- fp8 (e4m3fn + per-row scale) corpus: BASELINE config 5's storage --------------------------------

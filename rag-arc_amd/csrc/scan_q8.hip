@@ -32,7 +32,7 @@
 #include "rarc_common.h"
 
 struct ScanQ8Params {
-  const uint4* corpus;   // fp16 (FMT 0) or fp8 (FMT 1) rows [ceil32(n_rows)][D], as 16-byte chunks
+  const uint4* corpus;   // fp16 (FMT 0), fp8 (FMT 1) or int8-shadow (FMT 2) rows [ceil32(n_rows)][D], 16-byte chunks
   const float* tmeta;    // per tile: (scale, 1/scale) [+ 32 row multipliers for fp8]; qmeta + RARC_QMETA_HDR
   const int8_t* q8;      // [256][D]
   const float* qinv;     // [256]  1 / s_q
@@ -99,10 +99,10 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   using L = ScanQ8Lds<D>;
   constexpr int KS = D / 32;          // MFMA k-steps
   static_assert(FMT == 0 || D % 256 == 0, "fp8 rows are padded to a multiple of 256");
-  constexpr int EPC = FMT ? 16 : 8;   // values per 16-byte chunk (fp8 : fp16)
+  constexpr int EPC = FMT ? 16 : 8;   // values per 16-byte chunk (fp8 / int8 : fp16)
   constexpr int CPR = D / EPC;        // 16-byte chunks per row
   constexpr int CPT = 32 * CPR / Q8_THREADS;  // chunks per thread per tile
-  constexpr int MSTRIDE = FMT ? RARC_QMETA_F8_STRIDE : 2;  // floats of metadata per tile
+  constexpr int MSTRIDE = FMT == 1 ? RARC_QMETA_F8_STRIDE : 2;  // floats of metadata per tile
   constexpr int TCH = 32 * CPR;       // chunks per tile
 
   const int tid = threadIdx.x;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // group lands together (vector-memory returns are in order), two iterations after it was issued.
   struct Fetch {
     uint4 c[CPT];
-    float mul[FMT ? CPT : 1];  // fp8: the multiplier of each chunk's row (row scale x tile scale)
+    float mul[FMT == 1 ? CPT : 1];  // fp8: the multiplier of each chunk's row (row scale x tile scale)
     float2 meta;
     uint32_t thr;
     uint32_t hw;
@@ -193,10 +193,19 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 #pragma unroll
     for (int j = 0; j < CPT; ++j) f.c[j] = src[j * Q8_THREADS];
   };
+  uint32_t opaque_zero = 0;
+  asm volatile("" : "+v"(opaque_zero));  // a zero the compiler cannot fold (FMT 2, see convert_chunk)
   // chunk j of a fetch group -> int8 -> its place in the LDS tile `dst`
   auto convert_chunk = [&](const Fetch& f, int j, half_t s, char* dst) {
     char* at = dst + (WOFF_REGS ? woff[WOFF_REGS ? j : 0] : woff_of(j));
-    if constexpr (FMT == 1) {
+    if constexpr (FMT == 2) {
+      // the shadow image already holds what the conversion would produce.  (The bytes pass through one
+      // VALU op on purpose: stored to LDS straight from the load's destination registers, the register
+      // allocator parks each load in a scratch tuple and copies it home right after issuing it — which
+      // means waiting for it on the spot.)
+      const uint4 v = f.c[j];
+      *(uint4*)at = make_uint4(v.x ^ opaque_zero, v.y ^ opaque_zero, v.z ^ opaque_zero, v.w ^ opaque_zero);
+    } else if constexpr (FMT == 1) {
       *(uint4*)at = rarc_quant8_chunk_f8(f.c[j], (half_t)f.mul[j]);
     } else {
       uint2 o;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 
   // fetch groups in flight: two up to D = 896; one beyond (a group is 36 registers at D = 1024 and a
   // spill would put scratch traffic into the very queue the counted waits rely on)
-  constexpr int NG = (FMT == 1 || D <= 896) ? 2 : 1;
+  constexpr int NG = (FMT != 0 || D <= 896) ? 2 : 1;
   // ---- prologue: tile t0 straight into LDS buffer 0; tiles t0+stride, t0+2·stride in flight ----
   // (the launch guarantees gridDim.x <= n_tiles, so tile t0 exists)
   Fetch f[NG];
@@ -481,12 +490,13 @@ static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
 
 // Host entry used by rarc_api.hip.  *grid_out = workgroups launched (owners of candidate segments).
 // fmt 0: fp16 rows; fmt 1: fp8 (e4m3fn) rows with per-row scales `rowscale`.
+// fmt 2: `shadow8` is the int8 image of the fp16 rows `corpus` (which the seed pass still reads).
 int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                         const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
                         const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
-                        const RarcWs& ws, int cap, int* grid_out, hipStream_t s) {
+                        const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8) {
   ScanQ8Params p;
-  p.corpus = (const uint4*)corpus;
+  p.corpus = fmt == 2 ? (const uint4*)shadow8 : (const uint4*)corpus;
   p.tmeta = qmeta + RARC_QMETA_HDR;
   p.q8 = q8;
   p.qinv = qinv;
@@ -508,7 +518,8 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   // seed pass (fp16 MFMA on a strided sample): t = k'-th best sample score, accurate to eps16, so
   // t − eps16 bounds the k-th best canonical score from below; rows whose int8 score is under
   // t − eps16 − eps8 are out
-  int rc = rarc_seed_launch(corpus, rowscale, fmt, n_rows, d_pad, q16, nq, kprime, bin_lo, bin_hi, eps16, eps8, ws, s);
+  int rc = rarc_seed_launch(corpus, rowscale, fmt == 2 ? 0 : fmt, n_rows, d_pad, q16, nq, kprime, bin_lo, bin_hi, eps16,
+                            eps8, ws, s);
   if (rc) return rc;
 
   int dev = 0, cus = 256;
@@ -518,6 +529,17 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   if ((uint32_t)grid > p.n_tiles) grid = (int)p.n_tiles;
   *grid_out = grid;
   if (p.n_tiles == 0) return RARC_OK;
+  if (fmt == 2) {
+    switch (d_pad) {
+      case 256: return launch_scan_q8<256, 2>(p, grid, s);
+      case 512: return launch_scan_q8<512, 2>(p, grid, s);
+      case 768: return launch_scan_q8<768, 2>(p, grid, s);
+      case 1024: return launch_scan_q8<1024, 2>(p, grid, s);
+      default:
+        rarc_set_error("rarc_scan_q8 (int8 shadow): padded dim %d unsupported (multiple of 256, <= 1024)", d_pad);
+        return RARC_E_UNSUPPORTED;
+    }
+  }
   if (fmt == 1) {
     switch (d_pad) {
       case 256: return launch_scan_q8<256, 1>(p, grid, s);

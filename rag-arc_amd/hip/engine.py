@@ -35,7 +35,8 @@ class FlatIndexF16:
     """
 
     def __init__(self, dim: int, metric: str = "cosine", device: int = 0, capacity: int = 0,
-                 id_base: int = 0, cand_cap: int = 131072, scan: str = "auto", storage: str = "f16"):
+                 id_base: int = 0, cand_cap: int = 131072, scan: str = "auto", storage: str = "f16",
+                 shadow: bool = False):
         if metric not in ("cosine", "ip"):
             raise ValueError(f"unsupported metric: {metric}")
         if dim <= 0:
@@ -64,6 +65,12 @@ class FlatIndexF16:
         self.cand_cap = int(cand_cap)
         self.ntotal = 0
         self.max_norm = 0.0
+        # shadow=True keeps the int8 image of the fp16 rows next to them (+50 % HBM): the int8-prefilter scan
+        # then reads the image (half the bytes per search, no conversion); results are unchanged
+        self.shadow = bool(shadow)
+        if self.shadow and (storage != "f16" or self.d_pad % 256 or scan == "mfma16"):
+            raise ValueError("shadow=True needs fp16 storage, a dimension that pads to a multiple of 256, and the q8 scan")
+        self._shadow = None  # torch.int8 [capacity][d_pad]
         self._rows = None  # torch.float16 (or uint8 for fp8 storage) [capacity][d_pad]
         self._rowscale = None  # fp8 storage: torch.float32 [capacity]
         self._qmeta = None  # torch.float32 [4 + 2*capacity/32]: quantisation metadata (include/rarc.h)
@@ -83,6 +90,11 @@ class FlatIndexF16:
         if self._rows is not None and self.ntotal:
             new[: self.ntotal].copy_(self._rows[: self.ntotal])
         self._rows = new
+        if self.shadow:
+            ns8 = t.zeros((cap, self.d_pad), dtype=t.int8, device=self.device)
+            if self._shadow is not None and self.ntotal:
+                ns8[: self.ntotal].copy_(self._shadow[: self.ntotal])
+            self._shadow = ns8
         if self.storage == "f8":
             ns = t.ones(cap, dtype=t.float32, device=self.device)
             if self._rowscale is not None and self.ntotal:
@@ -112,6 +124,15 @@ class FlatIndexF16:
                                                 int(first_row), self._qmeta.data_ptr(), self._stream()),
                     "rarc_quant_meta_f8")
             return
+        if self.shadow:
+            t = self.torch
+            if self._shadow is None or self._shadow.shape[0] != self._rows.shape[0]:
+                self._shadow = t.zeros((self._rows.shape[0], self.d_pad), dtype=t.int8, device=self.device)
+                first_row = 0  # a fresh image: every tile has to be written
+            B.check(self.lib.rarc_quant_shadow_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, int(first_row),
+                                                   self._qmeta.data_ptr(), self._shadow.data_ptr(), self._stream()),
+                    "rarc_quant_shadow_f16")
+            return
         B.check(self.lib.rarc_quant_meta_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, int(first_row),
                                              self._qmeta.data_ptr(), self._stream()), "rarc_quant_meta_f16")
 
@@ -134,7 +155,7 @@ class FlatIndexF16:
     AUTO_Q8_ROWS = 4_000_000
 
     def _use_q8(self) -> bool:
-        if self.storage == "f8":
+        if self.storage == "f8" or self.shadow:
             return True
         if self.scan == "auto":
             return self.d_pad > 768 or self.ntotal >= self.AUTO_Q8_ROWS
@@ -311,6 +332,12 @@ class FlatIndexF16:
                                             kp, self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),
                     "rarc_search_f8")
+        elif self.shadow and qm and self._shadow is not None:
+            B.check(self.lib.rarc_search_f16_shadow(rows_ptr, self._shadow.data_ptr(), self.ntotal, self.d_pad, qm,
+                                                    b["qblock"].data_ptr(), nq, k, kp, self.id_base, lo, hi,
+                                                    out_ids.data_ptr(), out_sc.data_ptr(), status.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+                    "rarc_search_f16_shadow")
         else:
             B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k, kp,
                                              self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),

@@ -207,3 +207,21 @@ def test_neighbors_above_threshold_matches_numpy(hip, oracle):
         m = ref_s[j] >= 0.95
         assert np.array_equal(got[j][0], ref_i[j][m]) and np.array_equal(got[j][1].view(np.uint32), ref_s[j][m].view(np.uint32))
     assert len(got[0][0]) == 200 and len(got[1][0]) == 1 and len(got[2][0]) == 0
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(33, 768, 5, 10), (5000, 768, 256, 100), (20000, 1024, 64, 100), (4097, 200, 64, 50)])
+def test_shadow_image_scan_matches_oracle(hip, oracle, n, d, nq, k):
+    """shadow=True: the prefilter reads the int8 image written at ingest instead of converting fp16 rows on
+    every search; answers are the same bits (appends in two steps exercise the image's growth)."""
+    X, Q = _data(n, d, nq, seed=n + 3 * d)
+    idx = hip.FlatIndexF16(d, shadow=True)
+    idx.add(X[: n // 3])
+    idx.add(X[n // 3:])
+    D, I = idx.search(Q, min(k, n))
+    rows, _ = oracle.ingest_f16(X, d_pad=idx.d_pad)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), min(k, n))
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    plain = hip.FlatIndexF16(d, scan="q8")
+    plain.add(X)
+    D2, I2 = plain.search(Q, min(k, n))
+    assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
