@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 200 /* 0.2.0: query block, int8 prefilter scan */
+#define RARC_VERSION 201 /* 0.2.0: query block, int8 prefilter scan */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
@@ -273,6 +273,28 @@ int rarc_enc_add_ln(const uint16_t* d_x, const uint16_t* d_resid, const uint16_t
                     const uint16_t* d_beta, float eps, int n_rows, int hidden, uint16_t* d_out, void* stream);
 int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, int hidden, int normalize,
                   float* d_out, void* stream);
+
+/*
+ * Whole encoder forward in one call: the launch loop over the layers runs on the host side of this
+ * library, not in the caller (at small batches the per-call overhead of a foreign-function binding is
+ * longer than the kernels).  `model` and `model->layers` are HOST structs of DEVICE pointers.
+ * n_seq*seq_len must be a multiple of 128 (pad with sequences of length 1).  d_ws: scratch of
+ * rarc_enc_workspace_bytes(hidden, inter, n_seq*seq_len) bytes.  d_out: fp32 [n_seq][hidden].
+ */
+typedef struct RarcEncLayer {
+  const uint16_t *qkv_w, *qkv_b; /* fused [3*hidden][hidden], [3*hidden] (query, key, value) */
+  const uint16_t *o_w, *o_b, *ln1_g, *ln1_b;
+  const uint16_t *f1_w, *f1_b, *f2_w, *f2_b, *ln2_g, *ln2_b;
+} RarcEncLayer;
+typedef struct RarcEncModel {
+  int hidden, heads, inter, n_layers;
+  float ln_eps;
+  const uint16_t *word, *pos, *type0, *emb_g, *emb_b;
+  const RarcEncLayer* layers; /* host array [n_layers] */
+} RarcEncModel;
+size_t rarc_enc_workspace_bytes(int hidden, int inter, int n_tokens);
+int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
+                     int seq_len, int normalize, void* d_ws, size_t ws_bytes, float* d_out, void* stream);
 
 /*
  * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan

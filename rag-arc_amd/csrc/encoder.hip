@@ -27,12 +27,15 @@ constexpr int GM = 128, GN = 128, GK = 64;  // smallest tile (M is padded to a m
 //   BM = 128: 4 waves, 2 stages of 32 KB, two workgroups per CU;
 //   BM = 256: 8 waves, 3 stages of 48 KB (two tiles in flight behind the one being multiplied), one
 //             workgroup per CU — the W tile feeds twice as many rows, and the prefetch is one tile deeper.
+//
+// ACT 2 = split-K: blockIdx.y owns the k range [y*K, (y+1)*K) of rows of length ldk and writes its fp32 partial
+// products (no bias) to ((float*)C)[y][M][N]; the LayerNorm kernel that follows sums the partials.
 template <int ACT, int BM, int STAGES>  // ACT 0 = bias only, 1 = bias + exact (erf) GELU
 __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kernel(const half_t* __restrict__ A,
                                                                                   const half_t* __restrict__ W,
                                                                                   const half_t* __restrict__ bias,
                                                                                   half_t* __restrict__ C, int M,
-                                                                                  int N, int K) {
+                                                                                  int N, int K, int ldk, int order) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [STAGES][A BM*128 B | W 16 KiB]
   constexpr int NW = BM / 32;                   // waves
   constexpr int A_BYTES = BM * GK * 2, W_BYTES = GN * GK * 2, ST_BYTES = A_BYTES + W_BYTES;
@@ -43,12 +46,15 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
   const int lane = tid & 63;
   const int row = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: consecutive block ids (same XCD = id % 8) walk down a column of C tiles
-  const int tiles_m = M / BM;
+  // XCD-aware tile order.  Workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the operand
+  // indexed by (id % tiles) is read once per XCD that needs it and the OTHER operand by all eight:
+  //   order 0: tm = id % tiles_m  -> an XCD keeps a few row-blocks of A, every W tile crosses the fabric 8 times
+  //   order 1: tn = id % tiles_n  -> an XCD keeps a few W tiles, A crosses 8 times   (M < N: small batches)
+  const int tiles_m = M / BM, tiles_n = N / GN;
   const int bid = blockIdx.x;
-  const int tm = bid % tiles_m, tn = bid / tiles_m;
-  const half_t* Ab = A + (size_t)tm * BM * K;
-  const half_t* Wb = W + (size_t)tn * GN * K;
+  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  const half_t* Ab = A + (size_t)tm * BM * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
+  const half_t* Wb = W + (size_t)tn * GN * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
 
   const int drow = lane >> 3, dslot = lane & 7;
   auto issue = [&](int stage, int kt) {
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
       const int i = wave * A_DPW + j;  // row-block of 8 rows: rows 8i .. 8i+7
       const int r = 8 * i + drow;
       const int c = dslot ^ ((r >> 1) & 7);
-      __builtin_amdgcn_global_load_lds(RARC_GPTR(Ab + (size_t)r * K + kt * GK + c * 8),
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(Ab + (size_t)r * ldk + kt * GK + c * 8),
                                        RARC_LPTR(smem + stage * ST_BYTES + i * 1024), 16, 0, 0);
     }
 #pragma unroll
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
       const int i = wave * W_DPW + j;
       const int r = 8 * i + drow;
       const int c = dslot ^ ((r >> 1) & 7);
-      __builtin_amdgcn_global_load_lds(RARC_GPTR(Wb + (size_t)r * K + kt * GK + c * 8),
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(Wb + (size_t)r * ldk + kt * GK + c * 8),
                                        RARC_LPTR(smem + stage * ST_BYTES + A_BYTES + i * 1024), 16, 0, 0);
     }
   };
@@ -139,6 +145,11 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n0 = tn * GN + (2 * wn + j) * 32 + 8 * g + 4 * h;
+        if (ACT == 2) {
+          float* P = (float*)C + ((size_t)blockIdx.y * M + m) * N + n0;
+          *(float4*)P = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+          continue;
+        }
         const half4 b4 = *(const half4*)(bias + n0);
         half4 out;
 #pragma unroll
@@ -162,18 +173,36 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int MAXPER>
-__device__ __forceinline__ void ln_row(float (&x)[MAXPER], int per, int H, const half_t* gamma, const half_t* beta,
-                                       float eps, half_t* out, int lane) {
+// A lane owns the 8-column chunks lane and lane + 64 of its row (H <= 1024): 16-byte accesses, all in registers.
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+struct LnRow { float x[2][8]; };
+
+__device__ __forceinline__ void ln_row(LnRow& r, int H, const half_t* gamma, const half_t* beta, float eps, half_t* out,
+                                       int lane) {
   float s = 0.f;
-  for (int i = 0; i < per; ++i) s += x[i];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += r.x[i][e];  // chunks past H hold zeros
   const float mean = wave_sum(s) / (float)H;
   float v = 0.f;
-  for (int i = 0; i < per; ++i) { const float d = x[i] - mean; v += d * d; }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    if ((lane + 64 * i) * 8 < H) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = r.x[i][e] - mean; v += d * d; }
+    }
   const float rstd = rsqrtf(wave_sum(v) / (float)H + eps);
-  for (int i = 0; i < per; ++i) {
-    const int c = lane + 64 * i;
-    out[c] = (half_t)((x[i] - mean) * rstd * (float)gamma[c] + (float)beta[c]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const half8v g = *(const half8v*)(gamma + c), b = *(const half8v*)(beta + c);
+      half8v o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)((r.x[i][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+      *(half8v*)(out + c) = o;
+    }
   }
 }
 
@@ -184,30 +213,63 @@ __global__ __launch_bounds__(256) void rarc_embed_ln_kernel(const int32_t* ids, 
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tokens) return;
-  const int per = H / 64;
-  float x[16];
   const half_t* w = word + (size_t)ids[t] * H;
   const half_t* p = pos + (size_t)(t % L) * H;
-  for (int i = 0; i < per; ++i) {
-    const int c = lane + 64 * i;
-    x[i] = (float)w[c] + (float)p[c] + (float)type0[c];
+  LnRow r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const half8v a = *(const half8v*)(w + c), b = *(const half8v*)(p + c), ty = *(const half8v*)(type0 + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.x[i][e] = (float)a[e] + (float)b[e] + (float)ty[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.x[i][e] = 0.f;
+    }
   }
-  ln_row<16>(x, per, H, gamma, beta, eps, out + (size_t)t * H, lane);
+  ln_row(r, H, gamma, beta, eps, out + (size_t)t * H, lane);
 }
 
-__global__ __launch_bounds__(256) void rarc_add_ln_kernel(const half_t* x_in, const half_t* resid, const half_t* gamma,
+// out = LayerNorm(x + resid); with n_parts > 0, x is instead fp16(bias + the sum of n_parts fp32 split-K partial
+// products parts[p][n_rows][H]), summed in the fixed order p = 0, 1, ...
+__global__ __launch_bounds__(256) void rarc_add_ln_kernel(const half_t* x_in, const float* parts, int n_parts,
+                                                          const half_t* bias, const half_t* resid, const half_t* gamma,
                                                           const half_t* beta, float eps, int n_rows, int H,
                                                           half_t* out) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_rows) return;
-  const int per = H / 64;
-  float x[16];
-  for (int i = 0; i < per; ++i) {
-    const int c = lane + 64 * i;
-    x[i] = (float)x_in[(size_t)t * H + c] + (float)resid[(size_t)t * H + c];
+  LnRow r;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = (lane + 64 * i) * 8;
+    if (c < H) {
+      const half8v b = *(const half8v*)(resid + (size_t)t * H + c);
+      if (n_parts > 0) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int p = 0; p < n_parts; ++p) {
+          const float4* src = (const float4*)(parts + ((size_t)p * n_rows + t) * H + c);
+          const float4 lo = src[0], hi = src[1];
+          acc[0] += lo.x; acc[1] += lo.y; acc[2] += lo.z; acc[3] += lo.w;
+          acc[4] += hi.x; acc[5] += hi.y; acc[6] += hi.z; acc[7] += hi.w;
+        }
+        const half8v bs = *(const half8v*)(bias + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.x[i][e] = (float)(half_t)(acc[e] + (float)bs[e]) + (float)b[e];
+      } else {
+        const half8v a = *(const half8v*)(x_in + (size_t)t * H + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.x[i][e] = (float)a[e] + (float)b[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.x[i][e] = 0.f;
+    }
   }
-  ln_row<16>(x, per, H, gamma, beta, eps, out + (size_t)t * H, lane);
+  ln_row(r, H, gamma, beta, eps, out + (size_t)t * H, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -432,6 +494,41 @@ __global__ __launch_bounds__(64) void rarc_pool_kernel(const half_t* hidden, int
 }
 
 // ------------------------------------------------------------------------------------------
+static int gemm_attrs() {
+  constexpr int lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
+  constexpr int lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
+  static bool attr = false;
+  if (attr) return RARC_OK;
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<2, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
+  attr = true;
+  return RARC_OK;
+}
+
+// Split-K factor for a GEMM that feeds a LayerNorm: with few output tiles (small batches) the k loop is cut into
+// S slices so that about one workgroup per CU is in flight; each slice keeps >= 8 k-tiles.
+static int enc_split(int m, int n, int k) {
+  const int tiles = (m / GM) * (n / GN);
+  int S = 1;
+  while (S < 4 && tiles * S * 2 <= 256 && k % (S * 2 * GK) == 0 && k / (S * 2) >= 8 * GK) S *= 2;
+  return S;
+}
+
+static int enc_gemm_splitk(const uint16_t* d_a, const uint16_t* d_w, float* d_parts, int m, int n, int k, int S,
+                           hipStream_t s) {
+  if (int rc = gemm_attrs()) return rc;
+  constexpr size_t lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
+  hipLaunchKernelGGL((rarc_gemm_f16_kernel<2, 128, 4>), dim3((m / GM) * (n / GN), S), dim3(256), lds_deep, s,
+                     (const half_t*)d_a, (const half_t*)d_w, (const half_t*)nullptr, (half_t*)d_parts, m, n, k / S, k, m < n ? 1 : 0);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
 extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
                              int n, int k, int act, void* stream) {
   RARC_REQUIRE(d_a && d_w && d_bias && d_c, RARC_E_INVALID, "rarc_enc_gemm: null pointer");
@@ -443,23 +540,25 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   // 256-row tiles (3-stage pipeline, one workgroup per CU) when M allows it and there are enough tiles to
   // fill the chip; the 128-row kernel otherwise
   const bool big = (m % 256 == 0) && ((m / 256) * (n / GN) >= 256);
+  const int order = m < n ? 1 : 0;  // the smaller operand is the one that crosses the fabric 8 times
+  // few tiles (small batches): at most one workgroup per CU, nothing else to hide the HBM/L2 latency of the
+  // k loop behind -> four stages (three tiles in flight) instead of two
+  const bool deep = !big && ((m / GM) * (n / GN) <= 256) && k >= 4 * GK;
   constexpr size_t lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
-  static bool attr = false;
-  if (!attr) {
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small));
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-    attr = true;
-  }
-  if (big) {
+  constexpr size_t lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
+  if (int rc = gemm_attrs()) return rc;
+  if (deep) {
+    const int grid = (m / GM) * (n / GN);
+    if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 128, 4>), dim3(grid), dim3(256), lds_deep, s, a, w, bs, c, m, n, k, k, order);
+    else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 128, 4>), dim3(grid), dim3(256), lds_deep, s, a, w, bs, c, m, n, k, k, order);
+  } else if (big) {
     const int grid = (m / 256) * (n / GN);
-    if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 256, 3>), dim3(grid), dim3(512), lds_big, s, a, w, bs, c, m, n, k);
-    else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 256, 3>), dim3(grid), dim3(512), lds_big, s, a, w, bs, c, m, n, k);
+    if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 256, 3>), dim3(grid), dim3(512), lds_big, s, a, w, bs, c, m, n, k, k, order);
+    else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 256, 3>), dim3(grid), dim3(512), lds_big, s, a, w, bs, c, m, n, k, k, order);
   } else {
     const int grid = (m / GM) * (n / GN);
-    if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 128, 2>), dim3(grid), dim3(256), lds_small, s, a, w, bs, c, m, n, k);
-    else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 128, 2>), dim3(grid), dim3(256), lds_small, s, a, w, bs, c, m, n, k);
+    if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 128, 2>), dim3(grid), dim3(256), lds_small, s, a, w, bs, c, m, n, k, k, order);
+    else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 128, 2>), dim3(grid), dim3(256), lds_small, s, a, w, bs, c, m, n, k, k, order);
   }
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
@@ -485,8 +584,8 @@ extern "C" int rarc_enc_add_ln(const uint16_t* d_x, const uint16_t* d_resid, con
   RARC_REQUIRE(hidden % 64 == 0 && hidden <= 1024 && n_rows > 0, RARC_E_UNSUPPORTED,
                "rarc_enc_add_ln: hidden must be a multiple of 64, <= 1024");
   hipLaunchKernelGGL(rarc_add_ln_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)d_x,
-                     (const half_t*)d_resid, (const half_t*)d_gamma, (const half_t*)d_beta, eps, n_rows, hidden,
-                     (half_t*)d_out);
+                     (const float*)nullptr, 0, (const half_t*)nullptr, (const half_t*)d_resid, (const half_t*)d_gamma,
+                     (const half_t*)d_beta, eps, n_rows, hidden, (half_t*)d_out);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -516,4 +615,70 @@ extern "C" int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, i
                      hidden, normalize, d_out);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Whole forward: the per-layer launch loop, issued from here so that a caller pays one foreign call
+// ------------------------------------------------------------------------------------------
+static inline size_t enc_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// split-K partials: S*M*N floats with (M/128)*(N/128)*S <= 256 workgroups (enc_split)
+static inline size_t enc_parts_bytes(int hidden, int n_tokens) {
+  const size_t mn = (size_t)n_tokens * hidden;
+  return enc_align((mn * 4 < (size_t)256 * GM * GN ? mn * 4 : (size_t)256 * GM * GN) * sizeof(float));
+}
+
+extern "C" size_t rarc_enc_workspace_bytes(int hidden, int inter, int n_tokens) {
+  if (hidden <= 0 || inter <= 0 || n_tokens <= 0) return 0;
+  const size_t mh = enc_align((size_t)n_tokens * hidden * 2);
+  return 3 * mh + enc_align((size_t)n_tokens * 3 * hidden * 2) + enc_align((size_t)n_tokens * inter * 2) +
+         enc_parts_bytes(hidden, n_tokens);
+}
+
+extern "C" int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
+                                int seq_len, int normalize, void* d_ws, size_t ws_bytes, float* d_out, void* stream) {
+  RARC_REQUIRE(model && model->layers && d_ids && d_lens && d_ws && d_out, RARC_E_INVALID, "rarc_enc_forward: null pointer");
+  const int H = model->hidden, I = model->inter;
+  RARC_REQUIRE(n_seq > 0 && seq_len > 0 && model->n_layers > 0, RARC_E_INVALID, "rarc_enc_forward: empty batch or model");
+  const long long m_ll = (long long)n_seq * seq_len;
+  RARC_REQUIRE(m_ll % GM == 0 && m_ll < (1ll << 31), RARC_E_UNSUPPORTED,
+               "rarc_enc_forward: n_seq*seq_len must be a multiple of 128 (got %lld)", m_ll);
+  const int M = (int)m_ll;
+  RARC_REQUIRE(ws_bytes >= rarc_enc_workspace_bytes(H, I, M), RARC_E_INVALID, "rarc_enc_forward: workspace too small");
+  char* w = (char*)d_ws;
+  const size_t mh = enc_align((size_t)M * H * 2);
+  uint16_t* x = (uint16_t*)w;
+  uint16_t* y = (uint16_t*)(w + mh);
+  uint16_t* ctx = (uint16_t*)(w + 2 * mh);
+  uint16_t* qkv = (uint16_t*)(w + 3 * mh);
+  uint16_t* mid = (uint16_t*)(w + 3 * mh + enc_align((size_t)M * 3 * H * 2));
+  float* parts = (float*)(w + 3 * mh + enc_align((size_t)M * 3 * H * 2) + enc_align((size_t)M * I * 2));
+  hipStream_t hs = (hipStream_t)stream;
+  const int s_o = enc_split(M, H, H), s_f2 = enc_split(M, H, I);
+  // y = x·Wᵀ + b then x = LayerNorm(y + x); with S > 1 the GEMM leaves S fp32 partials and the LayerNorm sums them
+  auto proj_ln = [&](const uint16_t* a, const uint16_t* wt, const uint16_t* b, int k, int S, const uint16_t* g,
+                     const uint16_t* be) -> int {
+    if (S == 1) {
+      if (int r = rarc_enc_gemm(a, wt, b, y, M, H, k, 0, stream)) return r;
+      return rarc_enc_add_ln(y, x, g, be, model->ln_eps, M, H, x, stream);
+    }
+    if (int r = enc_gemm_splitk(a, wt, parts, M, H, k, S, hs)) return r;
+    hipLaunchKernelGGL(rarc_add_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, hs, (const half_t*)nullptr, (const float*)parts,
+                       S, (const half_t*)b, (const half_t*)x, (const half_t*)g, (const half_t*)be, model->ln_eps, M, H,
+                       (half_t*)x);
+    RARC_HIP_CHECK(hipGetLastError());
+    return RARC_OK;
+  };
+  int rc = rarc_enc_embed_ln(d_ids, model->word, model->pos, model->type0, model->emb_g, model->emb_b, model->ln_eps, M,
+                             seq_len, H, x, stream);
+  for (int l = 0; l < model->n_layers && rc == RARC_OK; ++l) {
+    const RarcEncLayer& L = model->layers[l];
+    if ((rc = rarc_enc_gemm(x, L.qkv_w, L.qkv_b, qkv, M, 3 * H, H, 0, stream)) != RARC_OK) break;
+    if ((rc = rarc_enc_attention(qkv, d_lens, n_seq, seq_len, H, model->heads, ctx, stream)) != RARC_OK) break;
+    if ((rc = proj_ln(ctx, L.o_w, L.o_b, H, s_o, L.ln1_g, L.ln1_b)) != RARC_OK) break;
+    if ((rc = rarc_enc_gemm(x, L.f1_w, L.f1_b, mid, M, I, H, 1, stream)) != RARC_OK) break;
+    rc = proj_ln(mid, L.f2_w, L.f2_b, I, s_f2, L.ln2_g, L.ln2_b);
+  }
+  if (rc != RARC_OK) return rc;
+  return rarc_enc_pool(x, n_seq, seq_len, H, normalize, d_out, stream);
 }

@@ -9,6 +9,7 @@ callable `tokenize(text) -> list[int]` (WordPiece vocabularies do not ship offli
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -63,12 +64,13 @@ class HipBertEncoder:
         if self.inter % 128:
             raise B.RarcError("intermediate size must be a multiple of 128")
         self.max_pos = int(self.pos.shape[0])
-
-    def _gemm(self, a, w, bias, out, act, stream):
-        m, k = a.shape
-        n = w.shape[0]
-        B.check(self.lib.rarc_enc_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), out.data_ptr(), m, n, k, act, stream),
-                "rarc_enc_gemm")
+        # host-side table of device pointers handed to rarc_enc_forward (tensors above keep the memory alive)
+        self._layer_tab = (B.EncLayer * len(self.layers))(*[
+            B.EncLayer(**{k: v.data_ptr() for k, v in w.items()}) for w in self.layers])
+        self._model = B.EncModel(self.hidden, self.heads, self.inter, len(self.layers), self.eps, self.word.data_ptr(),
+                                 self.pos.data_ptr(), self.type0.data_ptr(), self.emb_g.data_ptr(),
+                                 self.emb_b.data_ptr(), self._layer_tab)
+        self._ws = None
 
     def forward(self, input_ids, lengths=None, normalize: bool = True):
         t = self.torch
@@ -89,28 +91,14 @@ class HipBertEncoder:
             st = t.cuda.current_stream(self.device).cuda_stream
             d_ids = t.from_numpy(np.ascontiguousarray(ids)).to(self.device)
             d_lens = t.from_numpy(np.ascontiguousarray(lens)).to(self.device)
-            x = t.empty((M, H), dtype=t.float16, device=self.device)
-            y = t.empty((M, H), dtype=t.float16, device=self.device)
-            ctx = t.empty((M, H), dtype=t.float16, device=self.device)
-            qkv = t.empty((M, 3 * H), dtype=t.float16, device=self.device)
-            mid = t.empty((M, I), dtype=t.float16, device=self.device)
+            need = int(self.lib.rarc_enc_workspace_bytes(H, I, M))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = t.empty(need, dtype=t.uint8, device=self.device)
             out = t.empty((n_pad, H), dtype=t.float32, device=self.device)
-            L_ = self.lib
-            B.check(L_.rarc_enc_embed_ln(d_ids.data_ptr(), self.word.data_ptr(), self.pos.data_ptr(), self.type0.data_ptr(),
-                                         self.emb_g.data_ptr(), self.emb_b.data_ptr(), self.eps, M, L, H, x.data_ptr(), st),
-                    "rarc_enc_embed_ln")
-            for w in self.layers:
-                self._gemm(x, w["qkv_w"], w["qkv_b"], qkv, 0, st)
-                B.check(L_.rarc_enc_attention(qkv.data_ptr(), d_lens.data_ptr(), n_pad, L, H, self.heads, ctx.data_ptr(), st),
-                        "rarc_enc_attention")
-                self._gemm(ctx, w["o_w"], w["o_b"], y, 0, st)
-                B.check(L_.rarc_enc_add_ln(y.data_ptr(), x.data_ptr(), w["ln1_g"].data_ptr(), w["ln1_b"].data_ptr(), self.eps,
-                                           M, H, x.data_ptr(), st), "rarc_enc_add_ln")
-                self._gemm(x, w["f1_w"], w["f1_b"], mid, 1, st)
-                self._gemm(mid, w["f2_w"], w["f2_b"], y, 0, st)
-                B.check(L_.rarc_enc_add_ln(y.data_ptr(), x.data_ptr(), w["ln2_g"].data_ptr(), w["ln2_b"].data_ptr(), self.eps,
-                                           M, H, x.data_ptr(), st), "rarc_enc_add_ln")
-            B.check(L_.rarc_enc_pool(x.data_ptr(), n_pad, L, H, 1 if normalize else 0, out.data_ptr(), st), "rarc_enc_pool")
+            # one foreign call per forward: the layer loop runs inside librarc_hip.so
+            B.check(self.lib.rarc_enc_forward(ctypes.addressof(self._model), d_ids.data_ptr(), d_lens.data_ptr(), n_pad, L,
+                                              1 if normalize else 0, self._ws.data_ptr(), self._ws.numel(),
+                                              out.data_ptr(), st), "rarc_enc_forward")
             return out[:n_seq]
 
 

@@ -24,6 +24,19 @@ class RarcError(RuntimeError):
     """Raised for every non-zero status returned by librarc_hip.so."""
 
 
+class EncLayer(ctypes.Structure):
+    """RarcEncLayer (include/rarc.h): device pointers of one transformer layer."""
+    _fields_ = [(n, c_void_p) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "f1_w", "f1_b", "f2_w",
+                                        "f2_b", "ln2_g", "ln2_b")]
+
+
+class EncModel(ctypes.Structure):
+    """RarcEncModel (include/rarc.h)."""
+    _fields_ = [("hidden", c_int), ("heads", c_int), ("inter", c_int), ("n_layers", c_int), ("ln_eps", c_float),
+                ("word", c_void_p), ("pos", c_void_p), ("type0", c_void_p), ("emb_g", c_void_p), ("emb_b", c_void_p),
+                ("layers", ctypes.POINTER(EncLayer))]
+
+
 _lock = threading.Lock()
 _lib = None
 
@@ -71,6 +84,9 @@ SIGNATURES = {
     "rarc_enc_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc_add_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rarc_enc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rarc_enc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                 c_void_p]),
     "rarc_profile_begin": (c_int, [c_int]),
     "rarc_profile_end": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = B.load_library()
     for name in _declared():
         assert hasattr(lib, name), f"{name} missing from librarc_hip.so"
-    assert lib.rarc_version() == 200
+    assert lib.rarc_version() == 201
     assert lib.rarc_padded_dim(1) == 128 and lib.rarc_padded_dim(768) == 768 and lib.rarc_padded_dim(769) == 896
     assert lib.rarc_search_workspace_bytes(16384) > 256 * 16384 * 8
 
@@ -52,3 +52,24 @@ def test_engine_refuses_to_run_without_a_gpu():
 
     with pytest.raises(B.RarcError):
         FlatIndexF16(384)
+
+
+def test_encoder_model_structs_match_the_header(tmp_path):
+    """binding.EncLayer / EncModel are laid out exactly like RarcEncLayer / RarcEncModel (gcc is the judge)."""
+    import ctypes
+    import subprocess
+
+    from rag_arc_amd.hip import binding as B
+
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rarc.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(RarcEncLayer), sizeof(RarcEncModel),'
+                   ' offsetof(RarcEncModel, ln_eps), offsetof(RarcEncModel, word), offsetof(RarcEncModel, layers),'
+                   ' offsetof(RarcEncLayer, ln2_b)); return 0;}\n')
+    exe = tmp_path / "layout"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(B.EncLayer), ctypes.sizeof(B.EncModel), B.EncModel.ln_eps.offset, B.EncModel.word.offset,
+            B.EncModel.layers.offset, B.EncLayer.ln2_b.offset]
+    assert got == want

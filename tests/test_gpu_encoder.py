@@ -39,6 +39,9 @@ def _check(oracle, H, layers, heads, I, n_seq, L, seed):
     (256, 1, 4, 512, 2, 100),      # keys span four 32-key tiles, ragged last query block
     (128, 1, 4, 256, 6, 200),      # head_dim 32, seven query blocks x seven key tiles, ragged lengths
     (256, 1, 4, 512, 3, 65),       # head_dim 64, one key past a tile boundary
+    (256, 1, 4, 2048, 4, 32),      # FFN2 runs split-K x4 (fp32 partials summed by the LayerNorm kernel)
+    (768, 1, 12, 3072, 4, 32),     # bge-base layer: LayerNorm rows span both 8-column chunks of a lane
+    (1024, 1, 16, 4096, 8, 16),    # bge-large layer: out-proj split x2, FFN2 split x4
 ])
 def test_encoder_matches_oracle(oracle, H, layers, heads, I, n_seq, L):
     _check(oracle, H, layers, heads, I, n_seq, L, seed=H + L)
