@@ -37,6 +37,8 @@ def parse():
                     help="row storage: fp16 (default) or fp8 e4m3fn + per-row scale (BASELINE config 5)")
     ap.add_argument("--shadow", action="store_true",
                     help="keep the int8 image of the fp16 rows (+50%% HBM): the prefilter scan reads it instead")
+    ap.add_argument("--scan", choices=("auto", "q8", "mfma16"), default="auto",
+                    help="scan kernel (auto: the engine's choice by shard size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true")
     return ap.parse_args()
@@ -129,7 +131,8 @@ def main():
         while rows > 1_000_000 and (rows / world) * d_pad * (esize + (1 if a.shadow else 0)) > 0.85 * free:
             rows //= 10
     lo, hi = shard_range(rows, rank, world)
-    idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi, storage=a.storage, shadow=a.shadow)
+    idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi, scan=a.scan, storage=a.storage,
+                      shadow=a.shadow)
     searcher = ShardedFlatSearch(idx, force_collective=use_dist)
     q = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev)
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), a.dim, a.dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")

@@ -8,6 +8,7 @@
 //
 // Also: rarc_repair (exact single-query rescan) and rarc_topk_merge (multi-shard merge).
 #include "rarc_common.h"
+#include <type_traits>
 
 constexpr int FIN_THREADS = 256;
 
@@ -324,27 +325,29 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   // contiguous bytes) and reads them back transposed, 2 bytes per lane per step; the loads of the
   // next 64 rows are in flight while the current ones are reduced.  (One row per THREAD, 16 bytes at
   // a time from 64 different rows per instruction, took 260 µs for 670 rows per query.)
-  auto rescore = [&](int from, int to) {
+  // NT = 16-byte loads per lane per row (8 lanes x 16 B = 128 B per step), a compile-time constant: with a
+  // run-time count the prefetch registers `pre` were demoted to scratch memory, every global load was waited
+  // for and copied there at once, and the prefetch hid nothing (17 us per round of 64 rows instead of 3)
+  auto rescore_n = [&](auto nt_c, int from, int to) __attribute__((always_inline)) {
+    constexpr int NT = decltype(nt_c)::value;
     const int lane = tid & 63, wv = tid >> 6, j = lane & 7, rr = lane >> 3;
-    const int rbytes = p.fmt ? p.d : p.d * 2;              // bytes of one stored row
-    const int rstride = rbytes + 16;                       // +16: the 8 rows of a wave start in 8 different bank groups
+    constexpr int rbytes = NT * 128;                       // bytes of one stored row
+    constexpr int rstride = rbytes + 16;                   // +16: the 8 rows of a wave start in 8 different bank groups
     char* stage = fsm + (size_t)wv * 8 * rstride;          // this wave's 8 rows
-    const int nt = rbytes / 128;                           // 16-byte loads per lane per row (8 lanes x 16 B = 128 B per step)
-    uint4 pre[FIN8_MAXD / 64];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // (HIP's uint4 struct in a conditionally written array stays in memory)
+    u32x4 pre[NT];
     auto issue = [&](int i) {                              // lane fetches chunks t*8 + j of row ex[i]
       if (i < to) {
-        const uint4* src = (const uint4*)((const char*)p.corpus + (size_t)rarc_candrow(ex[i]) * rbytes) + j;
+        const u32x4* src = (const u32x4*)((const char*)p.corpus + (size_t)rarc_candrow(ex[i]) * rbytes) + j;
 #pragma unroll
-        for (int t = 0; t < FIN8_MAXD / 64; ++t)
-          if (t < nt) pre[t] = src[t * 8];
+        for (int t = 0; t < NT; ++t) pre[t] = src[t * 8];
       }
     };
     int i = from + wv * 8 + rr;
     issue(i);
     for (; i - rr - wv * 8 < to; i += (blockDim.x >> 6) * 8) {  // wave-uniform trip count
 #pragma unroll
-      for (int t = 0; t < FIN8_MAXD / 64; ++t)
-        if (t < nt) *(uint4*)(stage + rr * rstride + (t * 8 + j) * 16) = pre[t];
+      for (int t = 0; t < NT; ++t) *(u32x4*)(stage + rr * rstride + (t * 8 + j) * 16) = pre[t];
       const int cur = i;
       issue(i + (blockDim.x >> 6) * 8);
       __builtin_amdgcn_wave_barrier();
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       if (cur < to) {
         if (p.fmt) {  // fp8: element 8m + j is byte 8m + j of the row
           const char* rowp = stage + rr * rstride + j;
-          for (int m0 = 0; m0 < p.d / 8; m0 += 16) {
+          for (int m0 = 0; m0 < NT * 16; m0 += 16) {  // d = rbytes
             float xs[16], qs[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
           }
         } else {
           const char* rowp = stage + rr * rstride + 2 * j;
-          for (int m0 = 0; m0 < p.d / 8; m0 += 16) {  // d is a multiple of 128: 16 chain steps per trip
+          for (int m0 = 0; m0 < NT * 8; m0 += 16) {  // d = rbytes / 2, a multiple of 128: 16 chain steps per trip
             float xs[16], qs[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {  // all 32 LDS reads of the trip issued before the first fma
@@ -386,6 +389,14 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
         ex[cur] = rarc_candkey(sc, row);
       }
       __builtin_amdgcn_wave_barrier();
+    }
+  };
+  auto rescore = [&](int from, int to) __attribute__((always_inline)) {
+    switch ((p.fmt ? p.d : p.d * 2) / 128) {  // block-uniform
+#define FIN8_NT(N) case N: rescore_n(std::integral_constant<int, N>{}, from, to); break;
+      FIN8_NT(2) FIN8_NT(4) FIN8_NT(6) FIN8_NT(8) FIN8_NT(10) FIN8_NT(12) FIN8_NT(14) FIN8_NT(16)
+#undef FIN8_NT
+      default: break;  // the launcher admits only d multiples of 128 (fp16) / 256 (fp8), <= 1024
     }
   };
 
@@ -441,6 +452,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   }
   FIN8_STAMP(7)
   if (p.dbg && q == 0 && tid == 0) { p.dbg[8] = ne1_all; p.dbg[9] = ne_all; }
+  if (p.dbg && tid == 0) { p.dbg[16 + 4 * q] = ne1_all; p.dbg[17 + 4 * q] = ne_all; p.dbg[18 + 4 * q] = __builtin_amdgcn_s_memrealtime(); }
   if (tid == 0) {
     uint32_t st = RARC_Q_OK;
     if (s_over || ne_all > (uint32_t)FIN8_RS) st |= RARC_Q_OVERFLOW;

@@ -38,7 +38,8 @@ static float run(const ScanQ8Params& p, int grid, int iters, const uint16_t* cor
 
 int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 1000000;
-  const int D = BD, NQ = 256, KP = 128, CAP = 65536;
+  const int K = argc > 2 ? atoi(argv[2]) : 10, KP = K + 28 > (K * 5 + 3) / 4 ? K + 28 : (K * 5 + 3) / 4;
+  const int D = BD, NQ = 256, CAP = 131072;
   uint16_t* corpus; void* wsb; void* qblock; float* qmeta;
   hipMalloc(&corpus, (size_t)(N + 32) * D * 2); hipMemset(corpus, 0, (size_t)(N + 32) * D * 2);
   size_t wsbytes = RARC_WS_CAND + (size_t)256 * CAP * 8; hipMalloc(&wsb, wsbytes);
@@ -72,14 +73,19 @@ int main(int argc, char** argv) {
       printf("%2d w%d: %6lld %6lld %6lld %6lld %6lld | %6lld\n", it, w, (long long)(r[0] - b0), (long long)(r[1] - b0), (long long)(r[2] - b0), (long long)(r[3] - b0), (long long)(r[4] - b0), (long long)(nb - b0)); } }
   run<0>(p, grid, 1, corpus, N, qb, KP, ws);
   { // finalize timing
-    int64_t* oi; float* os; uint32_t* st; hipMalloc(&oi, 256 * 100 * 8); hipMalloc(&os, 256 * 100 * 4); hipMalloc(&st, 257 * 4); hipMemset(st, 0, 257 * 4);
-    unsigned long long* fd; hipMalloc(&fd, 256); hipMemset(fd, 0, 256); g_fin8_dbg = fd;
+    int64_t* oi; float* os; uint32_t* st; hipMalloc(&oi, 256 * 1024 * 8); hipMalloc(&os, 256 * 1024 * 4); hipMalloc(&st, 257 * 4); hipMemset(st, 0, 257 * 4);
+    unsigned long long* fd; hipMalloc(&fd, 16384); hipMemset(fd, 0, 16384); g_fin8_dbg = fd;
     hipEvent_t f0, f1; hipEventCreate(&f0); hipEventCreate(&f1);
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 6; ++rep) {
+      if (rep >= 3) { run<0>(p, grid, 1, corpus, N, qb, KP, ws); printf("(after a scan) "); }
       hipEventRecord(f0, 0);
-      rarc_finalize_q8_launch(corpus, nullptr, 0, D, qb.q32, qb.eps8, 256, 100, 0, ws, CAP, grid, oi, os, st, 0);
+      rarc_finalize_q8_launch(corpus, nullptr, 0, D, qb.q32, qb.eps8, 256, K, 0, ws, CAP, grid, oi, os, st, 0);
       hipEventRecord(f1, 0); hipEventSynchronize(f1); float ms; hipEventElapsedTime(&ms, f0, f1);
-      unsigned long long h[10]; hipMemcpy(h, fd, 80, hipMemcpyDeviceToHost);
+      unsigned long long h[16 + 1024]; hipMemcpy(h, fd, sizeof(h), hipMemcpyDeviceToHost);
+      { double s1 = 0, s2 = 0; unsigned long long m1 = 0, m2 = 0, tmax = 0; int qmax = 0;
+        for (int q = 0; q < 256; ++q) { s1 += h[16 + 4 * q]; s2 += h[17 + 4 * q]; if (h[16 + 4 * q] > m1) m1 = h[16 + 4 * q]; if (h[17 + 4 * q] > m2) m2 = h[17 + 4 * q];
+          if (h[18 + 4 * q] > tmax) { tmax = h[18 + 4 * q]; qmax = q; } }
+        printf("  |G1| mean %.0f max %llu   |G1+G2| mean %.0f max %llu   last block q=%d ends %.1f us after block0 start (its |G1+G2| = %llu)\n", s1 / 256, m1, s2 / 256, m2, qmax, (tmax - h[0]) / 100.0, h[17 + 4 * qmax]); }
       printf("finalize: %.1f us; block0 phases (us): init %.1f collect1 %.1f rescore1 %.1f rankL %.1f collect2 %.1f rescore2 %.1f final %.1f; |G1|=%llu |G1+G2|=%llu\n", ms * 1000,
              (h[1]-h[0])/100.0, (h[2]-h[1])/100.0, (h[3]-h[2])/100.0, (h[4]-h[3])/100.0, (h[5]-h[4])/100.0, (h[6]-h[5])/100.0, (h[7]-h[6])/100.0, h[8], h[9]);
     }
