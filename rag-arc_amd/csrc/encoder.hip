@@ -135,22 +135,246 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
   }
 #undef GEMM_LDFRAG
 #undef GEMM_WAIT
-  // epilogue: lane holds row m = lane & 31 of each 32x32 block and columns n = 8*(r>>2) + 4*h + (r&3)
+  // epilogue: lane holds row m = lane & 31 of each 32x32 block and columns n = 8*(r>>2) + 4*h + (r&3) — its
+  // pieces lie in 32 different rows of C, so a direct store touches 32 cache lines per instruction with 16-32
+  // bytes each.  Each wave transposes its 64 x 64 block through LDS (the pipeline buffers are dead once every
+  // wave is past the barrier below) and writes whole rows: 128 B (fp16) or 256 B (fp32 split-K partials).
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (ACT == 2) {
+    constexpr int ST = 64 * 4 + 16;
+    char* ep = smem + wave * 64 * ST;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = tm * BM + (2 * wm + i) * 32 + row;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(ep + (i * 32 + row) * ST + (jj * 32 + 8 * g + 4 * h) * 4) =
+              make_float4(acc[i][jj][4 * g], acc[i][jj][4 * g + 1], acc[i][jj][4 * g + 2], acc[i][jj][4 * g + 3]);
+    __builtin_amdgcn_wave_barrier();
+    const int r4 = lane >> 4, c = lane & 15;
+    float* P = (float*)C + ((size_t)blockIdx.y * M + tm * BM + wm * 64) * N + tn * GN + wn * 64 + c * 4;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int r = t * 4 + r4;
+      *(float4*)(P + (size_t)r * N) = *(const float4*)(ep + r * ST + c * 16);
+    }
+  } else {
+    constexpr int ST = 64 * 2 + 16;
+    char* ep = smem + wave * 64 * ST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nl = jj * 32 + 8 * g + 4 * h;
+          const half4 b4 = *(const half4*)(bias + tn * GN + wn * 64 + nl);
+          half4 out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[i][jj][4 * g + e] + (float)b4[e];
+            if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            out[e] = (half_t)v;
+          }
+          *(half4*)(ep + (i * 32 + row) * ST + nl * 2) = out;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int r8 = lane >> 3, c = lane & 7;
+    half_t* Cw = C + (size_t)(tm * BM + wm * 64) * N + tn * GN + wn * 64 + c * 8;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = t * 8 + r8;
+      *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * ST + c * 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tiles for the large GEMMs (QKV, FFN1 at M >= 8192): half the L2 -> LDS bytes per flop of the
+// 256 x 128 kernel above, and an explicit ping-pong between the two waves of every SIMD.
+//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. x cols wc*64.. of the tile: acc[4][2] 32x32 blocks.
+//   LDS 128 KiB = 2 parities x {A0, A1, B0, B1} x 16 KiB.  A "half" h of an operand holds, for every wave, half of
+//   ITS rows: A_h = rows {wr*128 + h*64 + r}, B_h = cols {wc*64 + h*32 + r} — so a K tile is consumed as four
+//   output QUADRANTS (A0B0, A0B1, A1B1, A1B0: one phase each, 8 MFMAs over the whole k = 64), each half is first
+//   needed in a different phase, and the next tile's halves are restaged one per phase, three phases (>= 1500
+//   cycles) ahead of their first read, with 16 KiB x 3 in flight and counted vmcnt waits (never 0 in steady state).
+//   A phase = [L: ds_read the new fragments, issue 2 LDS-DMA, wait] barrier [M: 8 MFMAs] barrier.  Waves 4-7
+//   run one barrier behind waves 0-3: while one group of a SIMD's two waves multiplies, the other loads.
+//   Ordering (every wave passes every barrier):
+//     RAW  a half staged in phase p is read in phase p+3 or later; every wave waits for its own share of all
+//          stages <= p-2 at the end of L(p) (vmcnt(4): the two newest stages may be in flight), a barrier before
+//          anyone's L(p+1) follows.
+//     WAR  a buffer is restaged >= 2 phases after its last ds_read, and readers wait for lgkmcnt(0) inside the
+//          slot that issued the read.
+// ------------------------------------------------------------------------------------------
+constexpr int G256_EP_STRIDE = 144, G256_EP_BYTES = 128 * G256_EP_STRIDE;  // epilogue staging, per wave
+constexpr int G256_LDS = 8 * G256_EP_BYTES > 131072 ? 8 * G256_EP_BYTES : 131072;
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* __restrict__ A,
+                                                                  const half_t* __restrict__ W,
+                                                                  const half_t* __restrict__ bias,
+                                                                  half_t* __restrict__ C, int M, int N, int K,
+                                                                  int order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int row = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = M / 256, tiles_n = N / 256;
+  const int bid = blockIdx.x;
+  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  const half_t* Ab = A + (size_t)tm * 256 * K;
+  const half_t* Wb = W + (size_t)tn * 256 * K;
+  const int KT = K / GK;
+
+  // staging: half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k tile kt into parity par; this wave's two KiB of it
+  const int drow = lane >> 3, dslot = lane & 7;
+  auto stage = [&](int par, int which, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = wave * 2 + j;      // 8-row block of the 128-row half-tile
+      const int lr = 8 * i + drow;     // row inside the half-tile
+      const int c = dslot ^ ((lr >> 1) & 7);
+      const int h = which & 1;
+      const half_t* src = which < 2 ? Ab + (size_t)((lr >> 6) * 128 + h * 64 + (lr & 63)) * K
+                                    : Wb + (size_t)((lr >> 5) * 64 + h * 32 + (lr & 31)) * K;
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(src + kt * GK + c * 8),
+                                       RARC_LPTR(smem + par * 65536 + which * 16384 + i * 1024), 16, 0, 0);
+    }
+  };
+  const int sw = (row >> 1) & 7;
+  int xk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + hh) ^ sw) << 4);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+  half8 fa[4][2], fb0[4], fb1[4];  // [k step][block]: the A half in use (2 blocks of 32 rows); both B halves
+
+#define G256_LOAD_A(PAR, H)                                                                             \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    const int ad = xk[kk] + ((PAR) * 65536 + (H) * 16384 + wr * 8192);                                  \
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                               \
+                 : "=&v"(fa[kk][0]), "=&v"(fa[kk][1]) : "v"(ad) : "memory");                            \
+  }
+#define G256_LOAD_B(PAR, H, FB)                                                                         \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    const int ad = xk[kk] + ((PAR) * 65536 + 32768 + (H) * 16384 + wc * 4096);                          \
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(FB[kk]) : "v"(ad) : "memory");                           \
+  }
+  // end of a load slot: counted wait for the staged data the NEXT phase reads, then this slot's own ds_reads
+#define G256_WAIT(VM)                                                                                   \
+  asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)"                                       \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]),        \
+                 "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb0[0]), "+v"(fb0[1]),            \
+                 "+v"(fb0[2]), "+v"(fb0[3]), "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3])     \
+               :: "memory")
+#define G256_MMA(QM, QN, FB)                                                                            \
+  /* register-only MFMAs drift across s_barrier (they are pure to the optimiser): tie their inputs to */\
+  /* an asm after the slot's first barrier and their results to one before its second */               \
+  asm volatile("" : "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3]));                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    acc[2 * (QM)][QN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[kk], fa[kk][0], acc[2 * (QM)][QN], 0, 0, 0); \
+    acc[2 * (QM) + 1][QN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[kk], fa[kk][1], acc[2 * (QM) + 1][QN], 0, 0, 0); \
+  }                                                                                                     \
+  __builtin_amdgcn_s_setprio(0);                                                                        \
+  asm volatile("" : "+v"(acc[2 * (QM)][QN]), "+v"(acc[2 * (QM) + 1][QN]));                              \
+  __builtin_amdgcn_sched_barrier(0)
+#define G256_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+  // one k tile t (parity par) = four phases.  Reads: A0, B0 in phase 1, B1 in phase 2, A1 in phase 3 (B0 stays
+  // in registers for phase 4).  Restaging, one half per phase, each buffer one or two phases after its last read:
+  //   phase 1: A1 of tile t+1 (other parity; its buffer was read in phase 3 of tile t-1)
+  //   phase 2: A0 of tile t+2, phase 3: B0 of t+2, phase 4: B1 of t+2 (this parity)
+  // -> every half is staged >= 6 phases before its first read, 5-6 stages (80-96 KiB) are in flight, and the
+  // wait at the end of L(p) lets the five newest stages (10 DMA instructions of this wave) stay outstanding.
+#define G256_TILE(ST1, ST234, VM1, VM2, VM3, VM4)                                                       \
+  {                                                                                                     \
+    /* phase 1: quadrant A0 x B0 */                                                                     \
+    G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)                                                        \
+    if (ST1) stage(np, 1, kt + 1);                                                                      \
+    G256_WAIT(VM1);                                                                                     \
+    G256_BAR();                                                                                         \
+    G256_MMA(0, 0, fb0);                                                                                \
+    G256_BAR();                                                                                         \
+    /* phase 2: A0 x B1 */                                                                              \
+    G256_LOAD_B(par, 1, fb1)                                                                            \
+    if (ST234) stage(par, 0, kt + 2);                                                                   \
+    G256_WAIT(VM2);                                                                                     \
+    G256_BAR();                                                                                         \
+    G256_MMA(0, 1, fb1);                                                                                \
+    G256_BAR();                                                                                         \
+    /* phase 3: A1 x B1 */                                                                              \
+    G256_LOAD_A(par, 1)                                                                                 \
+    if (ST234) stage(par, 2, kt + 2);                                                                   \
+    G256_WAIT(VM3);                                                                                     \
+    G256_BAR();                                                                                         \
+    G256_MMA(1, 1, fb1);                                                                                \
+    G256_BAR();                                                                                         \
+    /* phase 4: A1 x B0 (no LDS reads) */                                                               \
+    if (ST234) stage(par, 3, kt + 2);                                                                   \
+    G256_WAIT(VM4);                                                                                     \
+    G256_BAR();                                                                                         \
+    G256_MMA(1, 0, fb0);                                                                                \
+    G256_BAR();                                                                                         \
+  }
+
+  // prologue: all of k tile 0, then A0, B0, B1 of tile 1 (its A1 follows in phase 1 of tile 0, as in steady state)
+  stage(0, 0, 0); stage(0, 2, 0); stage(0, 3, 0); stage(0, 1, 0);
+  if (KT >= 2) {
+    stage(1, 0, 1); stage(1, 2, 1); stage(1, 3, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  G256_BAR();
+  if (wr == 1) G256_BAR();  // waves 4-7 run one slot behind
+  int kt = 0;
+  for (; kt + 2 < KT; ++kt) {
+    const int par = kt & 1, np = par ^ 1;
+    G256_TILE(true, true, 10, 10, 10, 10)
+  }
+  if (kt + 1 < KT) {  // second-to-last tile: only the last tile's A1 is still to stage; the waits shrink with the queue
+    const int par = kt & 1, np = par ^ 1;
+    G256_TILE(true, false, 10, 8, 6, 4)
+    ++kt;
+  }
+  {  // last tile
+    const int par = kt & 1, np = par ^ 1;
+    (void)np;
+    G256_TILE(false, false, 2, 0, 0, 0)
+  }
+  if (wr == 0) G256_BAR();
+#undef G256_TILE
+#undef G256_LOAD_A
+#undef G256_LOAD_B
+#undef G256_WAIT
+#undef G256_MMA
+#undef G256_BAR
+  // epilogue: acc[i][j] is rows wr*128 + i*32 + row, cols wc*64 + j*32 + (8g + 4hh .. +3) of the tile.  A lane's
+  // 8-byte pieces lie in 32 different rows: stored directly, every instruction touches 32 cache lines with 16
+  // bytes each.  The pipeline buffers are dead now (every wave is past the last barrier), so each wave
+  // transposes its 128 x 64 block through its own 18 KiB of LDS (row stride 144 B) and writes whole 128-byte rows.
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  char* ep = smem + wave * G256_EP_BYTES;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n0 = tn * GN + (2 * wn + j) * 32 + 8 * g + 4 * h;
-        if (ACT == 2) {
-          float* P = (float*)C + ((size_t)blockIdx.y * M + m) * N + n0;
-          *(float4*)P = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-          continue;
-        }
-        const half4 b4 = *(const half4*)(bias + n0);
+        const int nl = j * 32 + 8 * g + 4 * hh;  // column inside the wave's block
+        const half4 b4 = *(const half4*)(bias + tn * 256 + wc * 64 + nl);
         half4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -158,8 +382,18 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
           if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
           out[e] = (half_t)v;
         }
-        *(half4*)(C + (size_t)m * N + n0) = out;
+        *(half4*)(ep + (i * 32 + row) * G256_EP_STRIDE + nl * 2) = out;
       }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int r8 = lane >> 3, c = lane & 7;
+    half_t* Cw = C + (size_t)(tm * 256 + wr * 128) * N + tn * 256 + wc * 64 + c * 8;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int r = t * 8 + r8;
+      *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16);
     }
   }
 }
@@ -506,6 +740,8 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<2, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   attr = true;
   return RARC_OK;
 }
@@ -547,6 +783,15 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   constexpr size_t lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
   constexpr size_t lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
   if (int rc = gemm_attrs()) return rc;
+  // 256 x 256 tiles when they fill the chip at least 1.5 times over (QKV / FFN1 at M >= 8192)
+  static const bool no256 = getenv("RARC_GEMM_256") && atoi(getenv("RARC_GEMM_256")) == 0;
+  if (!no256 && m % 256 == 0 && n % 256 == 0 && (m / 256) * (n / 256) >= 384) {
+    const int grid = (m / 256) * (n / 256), ord = m < n ? 1 : 0;
+    if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(grid), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, ord);
+    else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(grid), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, ord);
+    RARC_HIP_CHECK(hipGetLastError());
+    return RARC_OK;
+  }
   if (deep) {
     const int grid = (m / GM) * (n / GN);
     if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 128, 4>), dim3(grid), dim3(256), lds_deep, s, a, w, bs, c, m, n, k, k, order);
