@@ -16,6 +16,23 @@
 //   rarc_enc_pool       CLS row -> fp32 [, L2 normalise with the canonical sum order of prep.hip]
 #include "rarc_common.h"
 
+// exact-form GELU 0.5·v·(1 + erf(v/√2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// fp16 rounding of the result): 1 - erf(x) = (a1 t + ... + a5 t^5)·exp(-x²), t = 1/(1 + p·x), x >= 0.
+// About 16 instructions per element (two of them transcendental) against ~37 for the library erff — the GELU
+// epilogue was 28 % of the FFN1 GEMM.
+__device__ __forceinline__ float rarc_gelu_erf(float v) {
+  const float ax = __builtin_fabsf(v);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  float poly = 1.061405429f;
+  poly = __builtin_fmaf(poly, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(v * v * (-0.5f * 1.44269504088896340736f));  // exp(-v²/2)
+  const float hr = 0.5f * v * (poly * t * e);  // 0.5·v·(1 - erf(|v|/√2))
+  return v >= 0.f ? v - hr : hr;
+}
+
 // ------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] · W[N][K]ᵀ + bias[N]   (M, N multiples of 128; K multiple of 64)
 // ------------------------------------------------------------------------------------------
@@ -176,7 +193,7 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = acc[i][jj][4 * g + e] + (float)b4[e];
-            if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+            if (ACT == 1) v = rarc_gelu_erf(v);
             out[e] = (half_t)v;
           }
           *(half4*)(ep + (i * 32 + row) * ST + nl * 2) = out;
@@ -379,7 +396,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float v = acc[i][j][4 * g + e] + (float)b4[e];
-          if (ACT == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+          if (ACT == 1) v = rarc_gelu_erf(v);
           out[e] = (half_t)v;
         }
         *(half4*)(ep + (i * 32 + row) * G256_EP_STRIDE + nl * 2) = out;
@@ -394,6 +411,156 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     for (int t = 0; t < 16; ++t) {
       const int r = t * 8 + r8;
       *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The same ping-pong schedule on 256 x 128 tiles, for N = 1024 (attention output, FFN2: 256 tiles at M = 8192)
+// and for shapes whose 256 x 256 tile count would leave a ragged last round.
+//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. x cols wc*32..: acc[4] 32x32 blocks.
+//   LDS 144 KiB = a ring of 3 k tiles x {A0, A1, B} x 16 KiB (A_h as above; B = the 128 rows of W).
+//   Two phases per k tile (8 MFMAs each): A0 x B (reads A0, B), A1 x B (reads A1; B stays in registers).
+//   Restaging: phase 2 of tile t refills A0, B of its own slot with tile t+3; phase 1 of tile t with A1 of
+//   tile t+2 (slot of tile t-1) — 5 phases of lead, up to 80 KiB in flight; the wait at the end of L(p) lets
+//   the stages of the last four phases (12 DMA instructions per wave) stay outstanding.
+// ------------------------------------------------------------------------------------------
+constexpr int G128_EP_STRIDE = 80, G128_EP_BYTES = 128 * G128_EP_STRIDE;
+constexpr int G128_LDS = 3 * 49152;
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half_t* __restrict__ A,
+                                                                      const half_t* __restrict__ W,
+                                                                      const half_t* __restrict__ bias,
+                                                                      half_t* __restrict__ C, int M, int N, int K,
+                                                                      int order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int row = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = M / 256, tiles_n = N / 128;
+  const int bid = blockIdx.x;
+  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  const half_t* Ab = A + (size_t)tm * 256 * K;
+  const half_t* Wb = W + (size_t)tn * 128 * K;
+  const int KT = K / GK;  // >= 3 (launcher)
+
+  const int drow = lane >> 3, dslot = lane & 7;
+  auto stage = [&](int slot, int which, int kt) __attribute__((always_inline)) {  // which: 0 A0, 1 A1, 2 B
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = wave * 2 + j;
+      const int lr = 8 * i + drow;
+      const int c = dslot ^ ((lr >> 1) & 7);
+      const half_t* src = which < 2 ? Ab + (size_t)((lr >> 6) * 128 + which * 64 + (lr & 63)) * K : Wb + (size_t)lr * K;
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(src + kt * GK + c * 8),
+                                       RARC_LPTR(smem + slot * 49152 + which * 16384 + i * 1024), 16, 0, 0);
+    }
+  };
+  const int sw = (row >> 1) & 7;
+  int xk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + hh) ^ sw) << 4);
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x16){0};
+  half8 fa[4][2], fb[4];
+
+#define G128_LOAD_A(SLOT, H)                                                                            \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    const int ad = xk[kk] + ((SLOT) * 49152 + (H) * 16384 + wr * 8192);                                 \
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                               \
+                 : "=&v"(fa[kk][0]), "=&v"(fa[kk][1]) : "v"(ad) : "memory");                            \
+  }
+#define G128_LOAD_B(SLOT)                                                                               \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    const int ad = xk[kk] + ((SLOT) * 49152 + 32768 + wc * 4096);                                       \
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(fb[kk]) : "v"(ad) : "memory");                           \
+  }
+#define G128_WAIT(VM)                                                                                   \
+  asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)"                                       \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]),        \
+                 "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), \
+                 "+v"(fb[3])                                                                            \
+               :: "memory")
+#define G128_MMA(H)                                                                                     \
+  asm volatile("" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    acc[2 * (H)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk], fa[kk][0], acc[2 * (H)], 0, 0, 0);    \
+    acc[2 * (H) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk], fa[kk][1], acc[2 * (H) + 1], 0, 0, 0); \
+  }                                                                                                     \
+  __builtin_amdgcn_s_setprio(0);                                                                        \
+  asm volatile("" : "+v"(acc[2 * (H)]), "+v"(acc[2 * (H) + 1]));                                        \
+  __builtin_amdgcn_sched_barrier(0)
+#define G128_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define G128_TILE(ST_A1, ST_AB, VM1, VM2)                                                               \
+  {                                                                                                     \
+    G128_LOAD_A(sl, 0) G128_LOAD_B(sl)                                                                  \
+    if (ST_A1) stage(slp, 1, kt + 2);                                                                   \
+    G128_WAIT(VM1);                                                                                     \
+    G128_BAR();                                                                                         \
+    G128_MMA(0);                                                                                        \
+    G128_BAR();                                                                                         \
+    G128_LOAD_A(sl, 1)                                                                                  \
+    if (ST_AB) { stage(sl, 0, kt + 3); stage(sl, 2, kt + 3); }                                          \
+    G128_WAIT(VM2);                                                                                     \
+    G128_BAR();                                                                                         \
+    G128_MMA(1);                                                                                        \
+    G128_BAR();                                                                                         \
+    slp = sl; sl = sl == 2 ? 0 : sl + 1;                                                                \
+  }
+  // prologue in steady-state order: tiles 0, 1 whole, A0 and B of tile 2 (its A1 follows in phase 1 of tile 0)
+  stage(0, 0, 0); stage(0, 2, 0); stage(0, 1, 0);
+  stage(1, 0, 1); stage(1, 2, 1); stage(1, 1, 1);
+  stage(2, 0, 2); stage(2, 2, 2);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  G128_BAR();
+  if (wr == 1) G128_BAR();
+  int kt = 0, sl = 0, slp = 2;  // sl = kt % 3, slp = (kt + 2) % 3
+  for (; kt + 3 < KT; ++kt) G128_TILE(true, true, 12, 12)
+  G128_TILE(true, false, 12, 8)  // tile KT-3
+  ++kt;
+  G128_TILE(false, false, 6, 2)  // tile KT-2
+  ++kt;
+  G128_TILE(false, false, 0, 0)  // tile KT-1
+  if (wr == 0) G128_BAR();
+#undef G128_TILE
+#undef G128_LOAD_A
+#undef G128_LOAD_B
+#undef G128_WAIT
+#undef G128_MMA
+#undef G128_BAR
+  // epilogue: acc[i] is rows wr*128 + i*32 + row, cols wc*32 + (8g + 4hh .. +3); transposed through LDS like above
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  char* ep = smem + wave * G128_EP_BYTES;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nl = 8 * g + 4 * hh;
+      const half4 b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
+      half4 out;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[i][4 * g + e] + (float)b4[e];
+        if (ACT == 1) v = rarc_gelu_erf(v);
+        out[e] = (half_t)v;
+      }
+      *(half4*)(ep + (i * 32 + row) * G128_EP_STRIDE + nl * 2) = out;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  {
+    const int r16 = lane >> 2, c = lane & 3;
+    half_t* Cw = C + (size_t)(tm * 256 + wr * 128) * N + tn * 128 + wc * 32 + c * 8;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = t * 16 + r16;
+      *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16);
     }
   }
 }
@@ -742,6 +909,8 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<2, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   attr = true;
   return RARC_OK;
 }
@@ -783,14 +952,23 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   constexpr size_t lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
   constexpr size_t lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
   if (int rc = gemm_attrs()) return rc;
-  // 256 x 256 tiles when they fill the chip at least 1.5 times over (QKV / FFN1 at M >= 8192)
-  static const bool no256 = getenv("RARC_GEMM_256") && atoi(getenv("RARC_GEMM_256")) == 0;
-  if (!no256 && m % 256 == 0 && n % 256 == 0 && (m / 256) * (n / 256) >= 384) {
-    const int grid = (m / 256) * (n / 256), ord = m < n ? 1 : 0;
-    if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(grid), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, ord);
-    else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(grid), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, ord);
-    RARC_HIP_CHECK(hipGetLastError());
-    return RARC_OK;
+  // ping-pong kernels for the big shapes: 256 x 256 tiles when they come in whole rounds of the 256 CUs (or in
+  // many rounds), else 256 x 128 tiles; the older kernels below serve small batches and odd shapes
+  static const int force = getenv("RARC_GEMM_PP") ? atoi(getenv("RARC_GEMM_PP")) : -1;  // 0 off, 1 = 256x128 only
+  if (force != 0 && m % 256 == 0) {
+    const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
+    if (force != 1 && t256 >= 256 && (t256 % 256 == 0 || t256 >= 1024)) {
+      if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+      else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+      RARC_HIP_CHECK(hipGetLastError());
+      return RARC_OK;
+    }
+    if (t128 >= 256 && k >= 3 * GK) {
+      if (act == 1) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<1>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      else hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<0>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      RARC_HIP_CHECK(hipGetLastError());
+      return RARC_OK;
+    }
   }
   if (deep) {
     const int grid = (m / GM) * (n / GN);
