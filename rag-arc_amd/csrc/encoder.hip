@@ -7,9 +7,10 @@
 //
 // Kernels (fp16 storage, fp32 accumulate / statistics):
 //   rarc_enc_embed_ln   word + position + type embeddings -> LayerNorm            (HBM-bound)
-//   rarc_enc_gemm       C = A·Wᵀ + bias [, GELU]   A [M][K], W [N][K] (torch Linear layout)
-//                       128x128x64 tiles, 4 waves x (2x2) v_mfma_f32_32x32x16_f16, operands staged
-//                       HBM -> LDS by LDS-DMA with the same source-side XOR swizzle as the scan   (MFMA-bound)
+//   rarc_enc_gemm       C = A·Wᵀ + bias [, GELU]   A [M][K], W [N][K] (torch Linear layout); by shape:
+//                       256x256x64 / 256x128x64 ping-pong kernels (two wave groups alternate load and MFMA
+//                       slots, LDS-DMA staged 5-6 phases ahead with counted waits), or the 128/256x128 kernel
+//                       (2-4 stage pipeline, split-K option) for small batches              (MFMA-bound)
 //   rarc_enc_attention  softmax(Q·Kᵀ/sqrt(dh) + mask)·V per (sequence, head), keys streamed in
 //                       LDS tiles with an online softmax (sequence lengths <= 512)
 //   rarc_enc_add_ln     LayerNorm(x + residual)                                   (HBM-bound)

@@ -75,6 +75,38 @@ def test_gemm_kernel_alone(oracle):
     assert np.max(np.abs(dC.cpu().numpy().astype(np.float64) - ref)) < 2e-2 * max(1.0, np.abs(ref).max() / 8)
 
 
+@pytest.mark.parametrize("M,N,K,act", [
+    (8192, 4096, 64, 0),     # 256x256 ping-pong tiles, a single k tile (prologue + last-tile path only)
+    (8192, 4096, 192, 1),    # three k tiles: steady, second-to-last and last schedules, GELU epilogue
+    (8192, 4096, 448, 0),    # odd number of k tiles (buffer parity)
+    (8192, 1024, 192, 1),    # 256x128 ping-pong tiles (3-slot ring), the minimum of three k tiles
+    (8192, 1024, 448, 0),    # ring wraps twice, tail schedules
+    (4096, 2304, 320, 0),    # N not a multiple of 256 -> 256x128 tiles, ragged last round
+    (8192, 256, 256, 0),     # too few tiles for either: 256-row kernel of the older pipeline
+])
+def test_gemm_large_tile_kernels(oracle, M, N, K, act):
+    """Every large-shape GEMM path against a float64 product on a transposition-detecting operand pair
+    (random asymmetric A, W; position-dependent bias); fp16 output rounding is the only error allowed."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn((M, K), device="cuda", generator=g) * 0.5).half()
+    w = (torch.randn((N, K), device="cuda", generator=g) * 0.1).half()
+    bias = (torch.arange(N, device="cuda", dtype=torch.float32) / N - 0.5).half()
+    c = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+    B.check(lib.rarc_enc_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr(), M, N, K, act, 0))
+    ref = a.double() @ w.double().T + bias.double()
+    if act:
+        ref = 0.5 * ref * (1 + torch.erf(ref / np.sqrt(2)))
+    err = (c.double() - ref).abs()
+    assert not torch.isnan(c).any()
+    # half-ulp of fp16 at the value's magnitude, plus fp32 accumulation noise
+    assert bool((err <= ref.abs() * 2.0 ** -10 + 2e-3).all()), float(err.max())
+
+
 def test_embeddings_provider_contract(oracle):
     from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEmbeddings, HipBertEncoder
 
