@@ -373,7 +373,9 @@ class FlatIndexF16:
         stream = self._stream()
         self._prep(q)
         lo, hi = self._bins(q)
-        kp = self.kprime_for(k)
+        # the int8 path's threshold proof needs the k-th best approximate score, nothing beyond it (its 2·eps8
+        # margin is the slack); the fp16 path's certificate wants k' > k candidates
+        kp = k if self._use_q8() else self.kprime_for(k)
         rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
         qm = self._qmeta.data_ptr() if (self._use_q8() and self._qmeta is not None and self.ntotal) else 0
         self._call_search(rows_ptr, qm, nq, k, kp, lo, hi, out_ids, out_sc, status, ws, stream)
