@@ -567,6 +567,154 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
 }
 
 // ------------------------------------------------------------------------------------------
+// The ping-pong schedule for SMALL batches: 128 x 128 tiles, at most one workgroup per CU (<= 256 tiles), where the
+// one-barrier kernel leaves a CU's single wave per SIMD waiting on LDS and DMA latencies in turn.
+//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*64.. x cols wc*32..: acc[2] 32x32 blocks.
+//   LDS 128 KiB = a ring of 4 k tiles x {A, B} x 16 KiB.  One phase per k tile (8 MFMAs): L reads A (8) + B (4)
+//   fragments and restages the slot read in the PREVIOUS phase with the tile three ahead (4 DMA instructions per
+//   wave, 96 KiB in flight); the wait at the end of L(p) leaves the stages of L(p-1), L(p) outstanding (vmcnt 8).
+//   ACT 2 = split-K slice blockIdx.y -> fp32 partials (summed by the LayerNorm kernel), as in the first kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int G128S_LDS = 4 * 32768;
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t* __restrict__ A,
+                                                                    const half_t* __restrict__ W,
+                                                                    const half_t* __restrict__ bias,
+                                                                    half_t* __restrict__ C, int M, int N, int K, int ldk,
+                                                                    int order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int row = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = M / 128, tiles_n = N / 128;
+  const int bid = blockIdx.x;
+  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  const half_t* Ab = A + (size_t)tm * 128 * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
+  const half_t* Wb = W + (size_t)tn * 128 * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
+  const int KT = K / GK;  // >= 4 (launcher)
+
+  const int drow = lane >> 3, dslot = lane & 7;
+  auto stage = [&](int slot, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = wave * 2 + j;
+      const int lr = 8 * i + drow;
+      const int c = dslot ^ ((lr >> 1) & 7);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(Ab + (size_t)lr * ldk + kt * GK + c * 8),
+                                       RARC_LPTR(smem + slot * 32768 + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(Wb + (size_t)lr * ldk + kt * GK + c * 8),
+                                       RARC_LPTR(smem + slot * 32768 + 16384 + i * 1024), 16, 0, 0);
+    }
+  };
+  const int sw = (row >> 1) & 7;
+  int xk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + hh) ^ sw) << 4);
+
+  f32x16 acc[2];
+  acc[0] = (f32x16){0};
+  acc[1] = (f32x16){0};
+  half8 fa[4][2], fb[4];
+#define G128S_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define G128S_TILE(ST, VM)                                                                              \
+  {                                                                                                     \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+      const int ad = xk[kk] + (sl * 32768 + wr * 8192);                                                 \
+      asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                             \
+                   : "=&v"(fa[kk][0]), "=&v"(fa[kk][1]) : "v"(ad) : "memory");                          \
+    }                                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+      const int ad = xk[kk] + (sl * 32768 + 16384 + wc * 4096);                                         \
+      asm volatile("ds_read_b128 %0, %1" : "=&v"(fb[kk]) : "v"(ad) : "memory");                         \
+    }                                                                                                   \
+    if (ST) stage(slp, kt + 3);                                                                         \
+    asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)"                                     \
+                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]),      \
+                   "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb[0]), "+v"(fb[1]),            \
+                   "+v"(fb[2]), "+v"(fb[3])                                                             \
+                 :: "memory");                                                                          \
+    G128S_BAR();                                                                                        \
+    asm volatile("" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                      \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk], fa[kk][0], acc[0], 0, 0, 0);              \
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk], fa[kk][1], acc[1], 0, 0, 0);              \
+    }                                                                                                   \
+    __builtin_amdgcn_s_setprio(0);                                                                      \
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    G128S_BAR();                                                                                        \
+    slp = sl; sl = (sl + 1) & 3;                                                                        \
+  }
+  // prologue: tiles 0, 1, 2 (tile 3 follows in the first phase, into the slot nobody has read yet)
+  stage(0, 0); stage(1, 1); stage(2, 2);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  G128S_BAR();
+  if (wr == 1) G128S_BAR();  // waves 4-7 run one slot behind
+  int kt = 0, sl = 0, slp = 3;  // sl = kt & 3; slp = slot of tile kt-1 = slot of tile kt+3
+  for (; kt + 3 < KT; ++kt) G128S_TILE(true, 8)
+  G128S_TILE(false, 4)  // tile KT-3
+  ++kt;
+  G128S_TILE(false, 0)  // tile KT-2
+  ++kt;
+  G128S_TILE(false, 0)  // tile KT-1
+  if (wr == 0) G128S_BAR();
+#undef G128S_TILE
+#undef G128S_BAR
+  // epilogue: acc[i] is rows wr*64 + i*32 + row, cols wc*32 + (8g + 4hh .. +3); transposed through LDS into whole
+  // 64-byte (fp16) / 128-byte (fp32 partial) row segments
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  if (ACT == 2) {
+    constexpr int ST = 32 * 4 + 16;
+    char* ep = smem + wave * 64 * ST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(ep + (i * 32 + row) * ST + (8 * g + 4 * hh) * 4) =
+            make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+    __builtin_amdgcn_wave_barrier();
+    const int r8 = lane >> 3, c = lane & 7;
+    float* P = (float*)C + ((size_t)blockIdx.y * M + tm * 128 + wr * 64) * N + tn * 128 + wc * 32 + c * 4;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = t * 8 + r8;
+      *(float4*)(P + (size_t)r * N) = *(const float4*)(ep + r * ST + c * 16);
+    }
+  } else {
+    constexpr int ST = 32 * 2 + 16;
+    char* ep = smem + wave * 64 * ST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = 8 * g + 4 * hh;
+        const half4 b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
+        half4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][4 * g + e] + (float)b4[e];
+          if (ACT == 1) v = rarc_gelu_erf(v);
+          out[e] = (half_t)v;
+        }
+        *(half4*)(ep + (i * 32 + row) * ST + nl * 2) = out;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int r16 = lane >> 2, c = lane & 3;
+    half_t* Cw = C + (size_t)(tm * 128 + wr * 64) * N + tn * 128 + wc * 32 + c * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = t * 16 + r16;
+      *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * ST + c * 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm helpers: one wave per row, fp32 statistics, H <= 1024 (H multiple of 64)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -912,6 +1060,9 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   attr = true;
   return RARC_OK;
 }
@@ -929,6 +1080,12 @@ static int enc_gemm_splitk(const uint16_t* d_a, const uint16_t* d_w, float* d_pa
                            hipStream_t s) {
   if (int rc = gemm_attrs()) return rc;
   constexpr size_t lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
+  static const bool nopp = getenv("RARC_GEMM_PP") && atoi(getenv("RARC_GEMM_PP")) == 0;
+  if (!nopp && (k / S) >= 4 * GK)
+    hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<2>), dim3((m / GM) * (n / GN), S), dim3(512), G128S_LDS, s,
+                       (const half_t*)d_a, (const half_t*)d_w, (const half_t*)nullptr, (half_t*)d_parts, m, n, k / S, k,
+                       m < n ? 1 : 0);
+  else
   hipLaunchKernelGGL((rarc_gemm_f16_kernel<2, 128, 4>), dim3((m / GM) * (n / GN), S), dim3(256), lds_deep, s,
                      (const half_t*)d_a, (const half_t*)d_w, (const half_t*)nullptr, (half_t*)d_parts, m, n, k / S, k, m < n ? 1 : 0);
   RARC_HIP_CHECK(hipGetLastError());
@@ -971,7 +1128,11 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
       return RARC_OK;
     }
   }
-  if (deep) {
+  if (deep && force != 0 && k >= 4 * GK) {
+    const int grid = (m / GM) * (n / GN);
+    if (act == 1) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<1>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
+    else hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<0>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
+  } else if (deep) {
     const int grid = (m / GM) * (n / GN);
     if (act == 1) hipLaunchKernelGGL((rarc_gemm_f16_kernel<1, 128, 4>), dim3(grid), dim3(256), lds_deep, s, a, w, bs, c, m, n, k, k, order);
     else hipLaunchKernelGGL((rarc_gemm_f16_kernel<0, 128, 4>), dim3(grid), dim3(256), lds_deep, s, a, w, bs, c, m, n, k, k, order);

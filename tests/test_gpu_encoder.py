@@ -83,6 +83,10 @@ def test_gemm_kernel_alone(oracle):
     (8192, 1024, 448, 0),    # ring wraps twice, tail schedules
     (4096, 2304, 320, 0),    # N not a multiple of 256 -> 256x128 tiles, ragged last round
     (8192, 256, 256, 0),     # too few tiles for either: 256-row kernel of the older pipeline
+    (1024, 3072, 1024, 0),   # small batch: 128x128 ping-pong tiles (4-slot ring), 16 k tiles
+    (1024, 4096, 256, 1),    # ... the minimum of four k tiles, GELU
+    (512, 1024, 320, 0),     # ... five k tiles, a quarter of the CUs busy
+    (1024, 1024, 192, 0),    # K too short for the ring: one-barrier kernel
 ])
 def test_gemm_large_tile_kernels(oracle, M, N, K, act):
     """Every large-shape GEMM path against a float64 product on a transposition-detecting operand pair
