@@ -9,7 +9,7 @@ bad = 0
 noise = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
 side = torch.cuda.Stream()
 for (M, N, K, act) in [(8192, 4096, 1024, 1), (8192, 3072, 1024, 0), (8192, 1024, 4096, 0), (8192, 1024, 1024, 0), (16384, 4096, 320, 0),
-                       (4096, 2304, 768, 1)]:
+                       (4096, 2304, 768, 1), (1024, 3072, 1024, 0), (1024, 4096, 1024, 1), (512, 1024, 4096, 0)]:
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     a = (torch.randn((M, K), device="cuda", generator=g) * 0.5).half(); w = (torch.randn((N, K), device="cuda", generator=g) * 0.1).half()
     b = torch.randn(N, device="cuda", generator=g).half()
@@ -30,4 +30,20 @@ for (M, N, K, act) in [(8192, 4096, 1024, 1), (8192, 3072, 1024, 0), (8192, 1024
             print(f"MISMATCH M={M} N={N} K={K} it={it}: {(c != first).sum().item()} elements differ")
     torch.cuda.synchronize()
     print(f"M={M} N={N} K={K} act={act}: 200 launches identical" if not bad else "...")
+# whole forward at a small batch (split-K partial kernels + LayerNorm reduction) — bitwise repeatable
+import numpy as np
+from oracle import cpu_ref
+from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+enc = HipBertEncoder(cpu_ref.random_bert_state_dict(1024, 4, 16, 4096, vocab=2000, max_pos=64, seed=1), num_heads=16)
+ids = np.random.default_rng(0).integers(1, 2000, (32, 32)).astype(np.int32)
+e0 = enc.forward(ids).clone()
+for it in range(100):
+    if it % 2:
+        with torch.cuda.stream(side):
+            noise.add_(1)
+    if not torch.equal(enc.forward(ids), e0):
+        bad += 1
+        print("MISMATCH in forward", it)
+torch.cuda.synchronize()
+print("forward 32x32 (4 layers, split-K path): 100 runs identical" if not bad else "...")
 print("race screen:", "clean" if not bad else f"{bad} mismatching launches")
