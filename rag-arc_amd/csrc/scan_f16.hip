@@ -385,11 +385,11 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__
   half8 bf[KW];
 #pragma unroll
   for (int ks = 0; ks < KW; ++ks) bf[ks] = *(const half8*)(qp + 16 * ks);
-  for (uint32_t ti = blockIdx.y; ti < seed_tiles; ti += gridDim.y) {
-    const uint32_t tile = ti * step;
-    uint32_t arow = tile * 32 + row;
+  // the next tile's fragments are fetched before this tile's partial sums go through LDS (two barriers): the
+  // walk was one exposed memory round trip per tile
+  auto load_tile = [&](uint32_t ti, half8 (&dst)[KW]) __attribute__((always_inline)) {
+    uint32_t arow = ti * step * 32 + row;
     if (arow >= n_rows) arow = n_rows - 1;
-    half8 af[KW];
     if constexpr (FMT == 1) {
       const uint8_t* ap = (const uint8_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
 #pragma unroll
@@ -399,13 +399,20 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__
         const half2_t p1 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.x, 1.0f, true);
         const half2_t p2 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, false);
         const half2_t p3 = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v.y, 1.0f, true);
-        af[ks] = (half8){p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+        dst[ks] = (half8){p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
       }
     } else {
       const half_t* ap = (const half_t*)corpus_v + (size_t)arow * D + 8 * h + 16 * KW * wave;
 #pragma unroll
-      for (int ks = 0; ks < KW; ++ks) af[ks] = *(const half8*)(ap + 16 * ks);
+      for (int ks = 0; ks < KW; ++ks) dst[ks] = *(const half8*)(ap + 16 * ks);
     }
+  };
+  half8 af[KW], an[KW];
+  if (blockIdx.y < seed_tiles) load_tile(blockIdx.y, af);
+  for (uint32_t ti = blockIdx.y; ti < seed_tiles; ti += gridDim.y) {
+    const uint32_t tile = ti * step;
+    const uint32_t tn = ti + gridDim.y < seed_tiles ? ti + gridDim.y : ti;  // (the last trip re-reads its own tile)
+    load_tile(tn, an);
     f32x16 acc = {0};
 #pragma unroll
     for (int ks = 0; ks < KW; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks], bf[ks], acc, 0, 0, 0);
@@ -426,6 +433,8 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__
         out[rr] = live ? v : -INFINITY;
       }
     }
+#pragma unroll
+    for (int ks = 0; ks < KW; ++ks) af[ks] = an[ks];
   }
 }
 
