@@ -458,20 +458,25 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
   float t = -INFINITY, mx = -INFINITY;
   if (q < nq && seed_rows > 0) {  // block-uniform
     const float* sq = seed + (size_t)q * (RARC_SEED_MAX_TILES * 32);
-    auto key_at = [&](uint32_t j) {
-      float v = sq[j];
-      if (!(v == v)) v = -INFINITY;  // NaN never becomes a threshold
-      return rarc_ordkey(v);
+    auto keys4 = [&](uint32_t j4, uint32_t (&k4)[4]) {  // 16-byte loads: the sweeps were latency-bound at 4 bytes
+      const float4 v4 = ((const float4*)sq)[j4];
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) k4[e] = rarc_ordkey(v[e] == v[e] ? v[e] : -INFINITY);  // NaN never becomes a threshold
     };
     for (uint32_t i = tid; i < 2048; i += blockDim.x) s_hist[i] = 0;
     if (tid == 0) { s_max = 0; s_min = 0xffffffffu; s_nlist = 0; s_key = 0; s_bin = 0; s_need = kprime; }
     __syncthreads();
     {  // block min / max of the keys: wave reduction first, one LDS atomic per wave
       uint32_t lmax = 0, lmin = 0xffffffffu;
-      for (uint32_t j = tid; j < seed_rows; j += blockDim.x) {
-        const uint32_t k = key_at(j);
-        lmax = k > lmax ? k : lmax;
-        lmin = (k > 0x007fffffu && k < lmin) ? k : lmin;  // skip -inf padding
+      for (uint32_t j4 = tid; j4 < seed_rows / 4; j4 += blockDim.x) {  // (seed_rows is a multiple of 32)
+        uint32_t k4[4];
+        keys4(j4, k4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lmax = k4[e] > lmax ? k4[e] : lmax;
+          lmin = (k4[e] > 0x007fffffu && k4[e] < lmin) ? k4[e] : lmin;  // skip -inf padding
+        }
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -490,7 +495,12 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
       uint32_t b2 = k > kmin ? (uint32_t)((float)(k - kmin) * kscale) : 0u;  // monotone in key
       return b2 > 2047u ? 2047u : b2;
     };
-    for (uint32_t j = tid; j < seed_rows; j += blockDim.x) atomicAdd(&s_hist[bin_of_key(key_at(j))], 1u);
+    for (uint32_t j4 = tid; j4 < seed_rows / 4; j4 += blockDim.x) {
+      uint32_t k4[4];
+      keys4(j4, k4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&s_hist[bin_of_key(k4[e])], 1u);
+    }
     __syncthreads();
     if (tid < 64) {  // wave 0: bin holding the k'-th largest, count above it
       uint32_t above = 0;
@@ -499,12 +509,15 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
     }
     __syncthreads();
     const uint32_t bin = s_bin, need = s_need;
-    for (uint32_t j = tid; j < seed_rows; j += blockDim.x) {
-      const uint32_t k = key_at(j);
-      if (bin_of_key(k) == bin) {
-        const uint32_t pos = atomicAdd(&s_nlist, 1u);
-        if (pos < (uint32_t)LIST) s_list[pos] = k;
-      }
+    for (uint32_t j4 = tid; j4 < seed_rows / 4; j4 += blockDim.x) {
+      uint32_t k4[4];
+      keys4(j4, k4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (bin_of_key(k4[e]) == bin) {
+          const uint32_t pos = atomicAdd(&s_nlist, 1u);
+          if (pos < (uint32_t)LIST) s_list[pos] = k4[e];
+        }
     }
     __syncthreads();
     const uint32_t nl_all = s_nlist, nl = nl_all < (uint32_t)LIST ? nl_all : (uint32_t)LIST;
