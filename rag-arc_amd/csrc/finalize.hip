@@ -234,6 +234,9 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
 constexpr int FIN8_THREADS = 512;
 constexpr int FIN8_RS = 4096;     // rows rescored canonically per query (G1 ∪ G2)
 constexpr int FIN8_MAXD = 1024;
+#ifndef FIN8_COLLECT_U
+#define FIN8_COLLECT_U 8
+#endif
 
 struct Fin8Params {
   const void* corpus;      // fp16 rows (fmt 0) or fp8 rows (fmt 1)
@@ -292,25 +295,31 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   // time, 64 consecutive keys per load (coalesced); a wave issues the loads of four segments before it
   // looks at any of them, so a sweep over ~30K keys costs a handful of memory round trips.
   auto collect = [&](auto want) {
+    // segments in flight per wave: the sweep is a chain of dependent memory round trips, (256 / waves / U) x
+    // (longest segment / 64) of them — 4: 22 us per sweep of ~20 K keys; 8, 16: 17-18 us; 32: 20 us (41 MB of
+    // 512-byte pieces for the 256 queries together: the sweep is at what cold HBM gives such reads).
+    // (One flat index space over all segments with a per-key binary search of the prefix sums: 32 us.)
+    constexpr int U = FIN8_COLLECT_U;
     const int lane = tid & 63, wv = tid >> 6, nwv = blockDim.x >> 6;
-    for (uint32_t wg0 = wv * 4; wg0 < p.n_wg; wg0 += nwv * 4) {
-      uint32_t n[4];
+    for (uint32_t wg0 = wv * U; wg0 < p.n_wg; wg0 += nwv * U) {
+      uint32_t n[U];
+      uint32_t nmax = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const uint32_t wg = wg0 + u;
         const uint32_t c = wg < p.n_wg ? s_cnt[wg] : 0u;
         n[u] = c < p.seg ? c : p.seg;
+        nmax = n[u] > nmax ? n[u] : nmax;
       }
-      const uint32_t nmax = max(max(n[0], n[1]), max(n[2], n[3]));
       for (uint32_t base = 0; base < nmax; base += 64) {
-        uint64_t key[4];
+        uint64_t key[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const uint32_t i = base + lane;
           key[u] = i < n[u] ? p.cand[((size_t)q * RARC_MAX_WG + wg0 + u) * p.seg + i] : 0ull;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           if (base + lane < n[u] && want(rarc_candscore(key[u]))) {
             const uint32_t e = atomicAdd(&s_ne, 1u);
             if (e < FIN8_RS) ex[e] = key[u];
