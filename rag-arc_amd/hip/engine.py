@@ -152,7 +152,7 @@ class FlatIndexF16:
             )
         return self._ws
 
-    AUTO_Q8_ROWS = 3_000_000   # measured crossover ~2M rows (768 dims): 1M 0.51 vs 0.58 ms, 2M 0.88 vs 0.90, 4M 1.64 vs 1.50
+    AUTO_Q8_ROWS = 1_500_000   # measured (768 dims, ms/step q8 vs mfma16): 1M 0.57 vs 0.51, 2M 0.86 vs 0.90, 3M 1.16 vs 1.29
 
     def _use_q8(self) -> bool:
         if self.storage == "f8" or self.shadow:
