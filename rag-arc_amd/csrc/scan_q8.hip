@@ -81,7 +81,8 @@ __device__ __forceinline__ void q8_lds_barrier() {
 
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
 // 8 = no threshold refresh, 16 = no conversion, 32 = prune fast path only, 64 = never flush,
-// 256 = no ping-pong between the wave groups, 1024 = s_memtime timeline of workgroup 0 into p.dbg
+// 256 = no ping-pong between the wave groups, 1024 = s_memtime timeline of workgroup 0 into p.dbg,
+// 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
 //
 // Vector-memory discipline.  The prefetched tile registers are consumed with counted waits
 // ("all but the newest N operations have returned"), which the compiler derives per program path and
@@ -284,13 +285,23 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // case — each passing lane's best is its only survivor and is staged directly; otherwise all 16
   // positions are walked.
   auto prune = [&](const i32x16& acc, uint32_t tile, float tinv, float tsc) {
-    int pm = acc[0] << 4;
+    // fast path: the lane's best score only (v_max3: 8 instructions); WHERE it sits is worked out in the slow
+    // path, together with the count of scores above the integer threshold.  (Carrying the position along as
+    // (score << 4 | r) cost 16 more instructions on every tile for something 70 % of the tiles never use.)
+    int m, pm = 0;
+    if (ABL & 2048) {  // (A/B: the packed form)
+      pm = acc[0] << 4;
 #pragma unroll
-    for (int r = 1; r < 16; ++r) {
-      const int v = (acc[r] << 4) | r;  // |score| < 2^24: no overflow
-      pm = v > pm ? v : pm;
+      for (int r = 1; r < 16; ++r) {
+        const int v = (acc[r] << 4) | r;  // |score| < 2^24: no overflow
+        pm = v > pm ? v : pm;
+      }
+      m = pm >> 4;
+    } else {
+      m = acc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) m = acc[r] > m ? acc[r] : m;
     }
-    const int m = pm >> 4;
     const float sc = my_qinv * tinv;
     const bool pass = (float)m * sc >= thr;
     if (ABL & 32) {
@@ -303,10 +314,18 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       const float tq = fmaxf(thr * (my_sq8 * tsc), -2.0e9f);  // thr / sc up to rounding; -inf (no threshold yet) clamped
       const int ti = pass ? (int)__builtin_floorf(tq - 1.0f - __builtin_fabsf(tq) * 2e-6f) : 0x7fffffff;
       int c = 0;
+      uint32_t rs = (uint32_t)pm & 15u;
+      if (ABL & 2048) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) c += (acc[r] >= ti) ? 1 : 0;
+        for (int r = 0; r < 16; ++r) c += (acc[r] >= ti) ? 1 : 0;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          c += (acc[r] >= ti) ? 1 : 0;
+          rs = acc[r] == m ? (uint32_t)r : rs;  // (ties: the highest position, as the packed maximum picked)
+        }
+      }
       if (__builtin_amdgcn_ballot_w64(c > 1) == 0) {
-        const uint32_t rs = (uint32_t)pm & 15u;
         const uint32_t doc = row0 + (rs & 3) + 8 * (rs >> 2);
         stage_n(pass && doc < p.n_rows, (float)m * sc, doc);
       } else {

@@ -38,7 +38,7 @@ static float run(const ScanQ8Params& p, int grid, int iters, const uint16_t* cor
 
 int main(int argc, char** argv) {
   const int64_t N = argc > 1 ? atoll(argv[1]) : 1000000;
-  const int K = argc > 2 ? atoi(argv[2]) : 10, KP = K + 28 > (K * 5 + 3) / 4 ? K + 28 : (K * 5 + 3) / 4;
+  const int K = argc > 2 ? atoi(argv[2]) : 10, KP = K;  // (the engine passes k' = k on this path)
   const int D = BD, NQ = 256, CAP = 131072;
   uint16_t* corpus; void* wsb; void* qblock; float* qmeta;
   hipMalloc(&corpus, (size_t)(N + 32) * D * 2); hipMemset(corpus, 0, (size_t)(N + 32) * D * 2);
