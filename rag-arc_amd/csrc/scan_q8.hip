@@ -85,7 +85,7 @@ __device__ __forceinline__ void q8_lds_barrier() {
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
 // 8 = no threshold refresh, 16 = no conversion, 32 = prune fast path only, 64 = never flush,
 // 256 = no ping-pong between the wave groups, 1024 = s_memtime timeline of workgroup 0 into p.dbg,
-// 4096 = survivors walked per lane (no LDS transposition), 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
+// 4096 = survivors walked per lane (no LDS transposition), 8192 = parked scores walked at once (no batching), 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
 //
 // Vector-memory discipline.  The prefetched tile registers are consumed with counted waits
 // ("all but the newest N operations have returned"), which the compiler derives per program path and
@@ -283,6 +283,27 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   };
   auto stage_n = [&](bool want, float a, uint32_t doc) { stage_q(want, a, doc, qidx); };
   char* my_tb = smem + L::TB + wave * (Q8_TB_SLOTS * Q8_TB_STRIDE);
+  // Passing lanes park their 16 scores (+ threshold, scale, query, first row) in these slots; the wave walks the
+  // parked scores one per lane once four slots (64 scores: a full wave) have gathered, before a flush, and at
+  // the end.  LDS returns a wave's operations in order, so the reads see the writes.
+  uint32_t tb_n = 0;  // wave-uniform: slots in use
+  auto drain = [&]() {
+    if (tb_n == 0) return;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < (int)tb_n * 16; base += 64) {
+      const int item = base + lane;  // (slot, position) pair; slots past tb_n hold stale data and are masked out
+      const bool valid = item < (int)tb_n * 16;
+      const char* sp = my_tb + (item >> 4) * Q8_TB_STRIDE;
+      const int r = item & 15;
+      const int sv = *(const int*)(sp + 4 * r);
+      const i32x4 mt = *(const i32x4*)(sp + 64);
+      const float a = (float)sv * __uint_as_float((uint32_t)mt[1]);
+      const uint32_t doc = (uint32_t)mt[3] + (r & 3) + 8 * (r >> 2);
+      stage_q(valid && a >= __uint_as_float((uint32_t)mt[0]) && doc < p.n_rows, a, doc, (uint32_t)mt[2]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    tb_n = 0;
+  };
   // lane holds 16 integer scores of its query: rows 8*(r>>2) + 4*h + (r&3) of the tile.
   // Fast path (every tile): max of (score << 4 | r) — the best score and where it sits — and one
   // compare.  When some lane's best clears its threshold, the wave counts per lane how many of the 16
@@ -319,34 +340,21 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       const int np = __builtin_popcountll(pmask);
       if (np <= Q8_TB_SLOTS && !(ABL & 4096)) {
         // Usually one to three of the 64 lanes pass.  Instead of every lane walking its own 16 scores, the
-        // passing lanes lay theirs out in LDS (with their threshold, scale and query) and the wave walks the
-        // np x 16 scores one per lane: a quarter of the instructions of the per-lane walk (which cost 16 % of
-        // the scan on a 12.5M-row shard, where 85 % of the tiles have a passing lane).  Same acceptance test
-        // ((float)s * sc >= thr), hence the same candidates.  LDS returns a wave's operations in order, so
-        // the reads below see the writes above.
+        // passing lanes park theirs in LDS and the wave walks parked scores one per lane (drain): a quarter of
+        // the instructions of the per-lane walk at one slot per walk, less with four.  Same acceptance test
+        // ((float)s * sc >= thr, with the threshold of the moment the lane passed), hence the same candidates.
+        if (tb_n + (uint32_t)np > (uint32_t)Q8_TB_SLOTS) drain();
         if (pass) {
           const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
-          char* dst = my_tb + rank * Q8_TB_STRIDE;
+          char* dst = my_tb + (tb_n + rank) * Q8_TB_STRIDE;
           *(i32x4*)(dst) = (i32x4){acc[0], acc[1], acc[2], acc[3]};
           *(i32x4*)(dst + 16) = (i32x4){acc[4], acc[5], acc[6], acc[7]};
           *(i32x4*)(dst + 32) = (i32x4){acc[8], acc[9], acc[10], acc[11]};
           *(i32x4*)(dst + 48) = (i32x4){acc[12], acc[13], acc[14], acc[15]};
-          *(i32x4*)(dst + 64) = (i32x4){(int)__float_as_uint(thr), (int)__float_as_uint(sc), (int)(qidx | ((uint32_t)h << 16)), 0};
+          *(i32x4*)(dst + 64) = (i32x4){(int)__float_as_uint(thr), (int)__float_as_uint(sc), (int)qidx, (int)row0};
         }
-        __builtin_amdgcn_wave_barrier();
-        for (int base = 0; base < np * 16; base += 64) {
-          const int item = base + lane;  // (slot, position) pair; slots past np hold stale data and are masked out
-          const bool valid = item < np * 16;
-          const char* sp = my_tb + (item >> 4) * Q8_TB_STRIDE;
-          const int r = item & 15;
-          const int sv = *(const int*)(sp + 4 * r);
-          const i32x4 mt = *(const i32x4*)(sp + 64);
-          const float a = (float)sv * __uint_as_float((uint32_t)mt[1]);
-          const uint32_t qh = (uint32_t)mt[2];
-          const uint32_t doc = tile * 32 + 4 * (qh >> 16) + (r & 3) + 8 * (r >> 2);
-          stage_q(valid && a >= __uint_as_float((uint32_t)mt[0]) && doc < p.n_rows, a, doc, qh & 0xffffu);
-        }
-        __builtin_amdgcn_wave_barrier();
+        tb_n += (uint32_t)np;
+        if ((ABL & 8192) || tb_n >= 4) drain();
       } else {
       // every score s with (float)s*sc >= thr satisfies s >= ti (one unit + 1e-6 relative of slack)
       const float tq = fmaxf(thr * (my_sq8 * tsc), -2.0e9f);  // thr / sc up to rounding; -inf (no threshold yet) clamped
@@ -380,6 +388,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // all threads; staged entries -> private candidate segments + global histogram.  Each wave drains
   // its own region (it knows its count; nothing to exchange), so no barrier is needed around it.
   auto flush = [&]() {
+    drain();
     const uint32_t n = wcount < (uint32_t)Q8_WSTAGE ? wcount : (uint32_t)Q8_WSTAGE;
     for (uint32_t e = lane; e < n; e += 64) emit(my_sq[e], my_skey[e]);
     wcount = 0;
@@ -479,7 +488,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       }                                                                                                       \
     }                                                                                                         \
     /* flush the staged survivors: every tile while thresholds are still forming, then rarely */              \
-    if (!(ABL & 64) && wcount > 0 &&                                                                          \
+    if (!(ABL & 64) && (wcount | tb_n) != 0 &&                                                                 \
         (it <= 16 || (it & (it - 1)) == 0 || (it & 127) == 0 || wcount > (uint32_t)Q8_WSTAGE / 2))            \
       flush();                                                                                                \
   }
