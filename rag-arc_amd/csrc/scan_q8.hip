@@ -85,7 +85,7 @@ __device__ __forceinline__ void q8_lds_barrier() {
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
 // 8 = no threshold refresh, 16 = no conversion, 32 = prune fast path only, 64 = never flush,
 // 256 = no ping-pong between the wave groups, 1024 = s_memtime timeline of workgroup 0 into p.dbg,
-// 4096 = survivors walked per lane (no LDS transposition), 8192 = parked scores walked at once (no batching), 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
+// 16384 = every survivor updates the histogram, 4096 = survivors walked per lane (no LDS transposition), 8192 = parked scores walked at once (no batching), 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
 //
 // Vector-memory discipline.  The prefetched tile registers are consumed with counted waits
 // ("all but the newest N operations have returned"), which the compiler derives per program path and
@@ -255,10 +255,16 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   };
 
   // one survivor straight to global memory (flush, and the overflow path of the staging buffer)
-  auto emit = [&](uint32_t q, uint64_t key) {
+  // `hot`: the survivor also goes into the query's global histogram.  The histogram only serves to locate the
+  // k-th best approximate score A (the owner publishes thr = A - 2·eps8; the finalize starts from the bin of A),
+  // and A only rises: a survivor below thr + eps8 = A - eps8 can never take part in that, while such survivors
+  // are ~85 % of all (the margin region grows exponentially towards lower scores) — and every histogram update
+  // is a device-scope atomic.  Every row with a >= A(final) is counted whatever thresholds were current when it
+  // was flushed, because thr(at flush) + eps8 <= A(final) - eps8.
+  auto emit = [&](uint32_t q, uint64_t key, bool hot) {
     const uint32_t slot = atomicAdd(&s_cnt[q], 1u);
     if (slot < p.seg) p.cand[((size_t)q * RARC_MAX_WG + blockIdx.x) * p.seg + slot] = key;
-    atomicAdd(&p.hist[q * RARC_NB + rarc_bin_of(rarc_candscore(key), s_binlo[q], s_binscale[q])], 1u);
+    if (hot) atomicAdd(&p.hist[q * RARC_NB + rarc_bin_of(rarc_candscore(key), s_binlo[q], s_binscale[q])], 1u);
   };
   // Survivors go to an LDS staging area (no vector-memory traffic), one region per wave so that
   // slots are handed out with lane arithmetic (ballot + mbcnt) instead of an LDS atomic round trip;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         my_skey[pos] = key;
         my_sq[pos] = (uint8_t)qq;
       } else {
-        emit(qq, key);
+        emit(qq, key, true);
       }
     }
     wcount += (uint32_t)__builtin_popcountll(b);
@@ -390,7 +396,15 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   auto flush = [&]() {
     drain();
     const uint32_t n = wcount < (uint32_t)Q8_WSTAGE ? wcount : (uint32_t)Q8_WSTAGE;
-    for (uint32_t e = lane; e < n; e += 64) emit(my_sq[e], my_skey[e]);
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {  // wave-uniform trips: the threshold of an entry's query comes by shuffle
+      const uint32_t e = e0 + lane;
+      const bool v = e < n;
+      const uint32_t qq = v ? (uint32_t)my_sq[e] : qidx;
+      const uint64_t key = v ? my_skey[e] : 0ull;
+      const float tcur = __shfl(thr, (int)(qq & 31u), 64);  // this wave's lanes l and l+32 hold query 32·wave + l
+      const bool hot = (ABL & 16384) || rarc_candscore(key) >= tcur + s_eps8[qq];
+      if (v) emit(qq, key, hot);
+    }
     wcount = 0;
   };
 
