@@ -403,7 +403,9 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       const uint64_t key = v ? my_skey[e] : 0ull;
       const float tcur = __shfl(thr, (int)(qq & 31u), 64);  // this wave's lanes l and l+32 hold query 32·wave + l
       const bool hot = (ABL & 16384) || rarc_candscore(key) >= tcur + s_eps8[qq];
-      if (v) emit(qq, key, hot);
+      // (a survivor staged under an older, lower threshold that no longer clears the current one is dropped:
+      //  the final threshold is at least the current one)
+      if (v && rarc_candscore(key) >= tcur) emit(qq, key, hot);
     }
     wcount = 0;
   };
