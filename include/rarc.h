@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 201 /* 0.2.0: query block, int8 prefilter scan */
+#define RARC_VERSION 202 /* 0.2.0: query block, int8 prefilter scan */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
@@ -214,6 +214,13 @@ int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t
  */
 int rarc_topk_merge(const int64_t* d_ids, const float* d_scores, int n_lists, int nq, int k,
                     int64_t* d_out_ids, float* d_out_scores, void* stream);
+/*
+ * The same merge over lists in the form that crosses the all-gather as ONE tensor: int32 [n_lists][nq][k][3] =
+ * (id low word, id high word, fp32 score bits).  rarc_pack_results writes one rank's [nq][k][3] block.
+ */
+int rarc_pack_results(const int64_t* d_ids, const float* d_scores, int nq, int k, int32_t* d_packed, void* stream);
+int rarc_topk_merge_packed(const int32_t* d_packed, int n_lists, int nq, int k, int64_t* d_out_ids,
+                           float* d_out_scores, void* stream);
 
 /*
  * Reciprocal-rank fusion, bit-exact with RRFusion.fuse at core/utils/Fusion.py:45-76.

@@ -641,6 +641,9 @@ int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64
 // ============================================================================================
 // Multi-shard merge: [G][nq][k] sorted lists -> [nq][k]  (score desc, id asc)
 // ============================================================================================
+// PACKED: the lists arrive as int32 [G][nq][k][3] = (id low, id high, score bits) — the form that crosses the
+// all-gather as ONE tensor (rarc_pack_results writes it) — and `ids` points at them, `scores` is unused.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void rarc_merge_kernel(const int64_t* ids, const float* scores, int G,
                                                          int nq, int k, int64_t* out_ids,
                                                          float* out_scores) {
@@ -658,8 +661,16 @@ __global__ __launch_bounds__(256) void rarc_merge_kernel(const int64_t* ids, con
     if (i < n) {
       const int g = i / k, j = i % k;
       const size_t o = ((size_t)g * nq + q) * k + j;
-      id = ids[o];
-      if (id >= 0) key = rarc_ordkey(scores[o]);
+      float sc;
+      if (PACKED) {
+        const uint32_t* pk = (const uint32_t*)ids + o * 3;
+        id = (int64_t)((uint64_t)pk[0] | ((uint64_t)pk[1] << 32));
+        sc = __uint_as_float(pk[2]);
+      } else {
+        id = ids[o];
+        sc = scores[o];
+      }
+      if (id >= 0) key = rarc_ordkey(sc);
       else id = INT64_MAX;
     }
     sk[i] = key;
@@ -694,19 +705,38 @@ __global__ __launch_bounds__(256) void rarc_merge_kernel(const int64_t* ids, con
 }
 
 int rarc_merge_launch(const int64_t* ids, const float* scores, int G, int nq, int k, int64_t* out_ids,
-                      float* out_scores, hipStream_t s) {
+                      float* out_scores, hipStream_t s, bool packed) {
   int np2 = 2;
   while (np2 < G * k) np2 <<= 1;
   const size_t lds = (size_t)np2 * 12;
   RARC_REQUIRE(lds <= 160 * 1024, RARC_E_UNSUPPORTED, "rarc_topk_merge: %d lists x k=%d too large", G, k);
   static size_t lds_attr = 0;
   if (lds > lds_attr) {
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_merge_kernel,
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_merge_kernel<false>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_merge_kernel<true>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_attr = lds;
   }
-  hipLaunchKernelGGL(rarc_merge_kernel, dim3(nq), dim3(256), lds, s, ids, scores, G, nq, k, out_ids,
-                     out_scores);
+  if (packed)
+    hipLaunchKernelGGL(rarc_merge_kernel<true>, dim3(nq), dim3(256), lds, s, ids, scores, G, nq, k, out_ids, out_scores);
+  else
+    hipLaunchKernelGGL(rarc_merge_kernel<false>, dim3(nq), dim3(256), lds, s, ids, scores, G, nq, k, out_ids, out_scores);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+__global__ __launch_bounds__(256) void rarc_pack_kernel(const int64_t* ids, const float* scores, int n, uint32_t* out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t id = (uint64_t)ids[i];
+  out[3 * i] = (uint32_t)id;
+  out[3 * i + 1] = (uint32_t)(id >> 32);
+  out[3 * i + 2] = __float_as_uint(scores[i]);
+}
+
+int rarc_pack_launch(const int64_t* ids, const float* scores, int n, uint32_t* out, hipStream_t s) {
+  hipLaunchKernelGGL(rarc_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, s, ids, scores, n, out);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

@@ -20,7 +20,8 @@ int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64
                        const float* qv, int k, int64_t id_base, int64_t* ids, float* scores, uint32_t* found,
                        const RarcWs& ws, int cap, hipStream_t s);
 int rarc_merge_launch(const int64_t* ids, const float* scores, int G, int nq, int k, int64_t* out_ids,
-                      float* out_scores, hipStream_t s);
+                      float* out_scores, hipStream_t s, bool packed);
+int rarc_pack_launch(const int64_t* ids, const float* scores, int n, uint32_t* out, hipStream_t s);
 
 static thread_local char g_err[512] = "";
 
@@ -227,5 +228,19 @@ extern "C" int rarc_topk_merge(const int64_t* d_ids, const float* d_scores, int 
   RARC_REQUIRE(d_ids && d_scores && d_out_ids && d_out_scores, RARC_E_INVALID, "rarc_topk_merge: null pointer");
   RARC_REQUIRE(n_lists >= 1 && nq >= 0 && k >= 1, RARC_E_INVALID, "rarc_topk_merge: bad sizes");
   if (nq == 0) return RARC_OK;
-  return rarc_merge_launch(d_ids, d_scores, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream);
+  return rarc_merge_launch(d_ids, d_scores, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream, false);
+}
+
+extern "C" int rarc_pack_results(const int64_t* d_ids, const float* d_scores, int nq, int k, int32_t* d_packed, void* stream) {
+  RARC_REQUIRE(d_ids && d_scores && d_packed && nq >= 0 && k >= 1, RARC_E_INVALID, "rarc_pack_results: bad arguments");
+  if (nq == 0) return RARC_OK;
+  return rarc_pack_launch(d_ids, d_scores, nq * k, (uint32_t*)d_packed, (hipStream_t)stream);
+}
+
+extern "C" int rarc_topk_merge_packed(const int32_t* d_packed, int n_lists, int nq, int k, int64_t* d_out_ids,
+                                      float* d_out_scores, void* stream) {
+  RARC_REQUIRE(d_packed && d_out_ids && d_out_scores, RARC_E_INVALID, "rarc_topk_merge_packed: null pointer");
+  RARC_REQUIRE(n_lists >= 1 && nq >= 0 && k >= 1, RARC_E_INVALID, "rarc_topk_merge_packed: bad sizes");
+  if (nq == 0) return RARC_OK;
+  return rarc_merge_launch((const int64_t*)d_packed, nullptr, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream, true);
 }

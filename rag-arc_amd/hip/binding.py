@@ -73,6 +73,8 @@ SIGNATURES = {
     "rarc_repair_f8": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "rarc_topk_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_pack_results": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "rarc_topk_merge_packed": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rarc_rrf_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "rarc_rerank_order": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -83,6 +83,25 @@ class ShardedFlatSearch:
         t = self.torch
         if self.world == 1 and not self.force_collective:
             return ids, scores
+        if self.merge_fn == self._hip_merge and ids.is_cuda:
+            # device path: one pack kernel, ONE collective, one merge kernel that reads the packed lists
+            from . import binding as B
+
+            lib = B.load_library()
+            nq, kk = ids.shape
+            st = t.cuda.current_stream(ids.device).cuda_stream
+            gathered = t.empty((self.world, nq, kk, 3), dtype=t.int32, device=ids.device)
+            mine = t.empty((nq, kk, 3), dtype=t.int32, device=ids.device)
+            B.check(lib.rarc_pack_results(ids.contiguous().data_ptr(), scores.contiguous().data_ptr(), nq, kk,
+                                          mine.data_ptr(), st), "rarc_pack_results")
+            self.dist.all_gather_into_tensor(gathered.view(self.world * nq, kk, 3), mine, group=self.group)
+            if k != kk:
+                raise ValueError("merge width must equal the per-shard list width")
+            out_i = t.empty((nq, k), dtype=t.int64, device=ids.device)
+            out_s = t.empty((nq, k), dtype=t.float32, device=ids.device)
+            B.check(lib.rarc_topk_merge_packed(gathered.data_ptr(), self.world, nq, kk, out_i.data_ptr(),
+                                               out_s.data_ptr(), st), "rarc_topk_merge_packed")
+            return out_i, out_s
         mine = pack_results(t, ids, scores)
         # concatenated layout ([world*nq][k][3]) is the form both RCCL and gloo accept
         gathered = t.empty((self.world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype,

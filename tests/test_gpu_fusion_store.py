@@ -112,6 +112,18 @@ def test_topk_merge_kernel(oracle):
     mi, ms = s._hip_merge(torch.from_numpy(ids).cuda(), torch.from_numpy(sc).cuda(), k)
     wi, ws = oracle.topk_merge(ids, sc, k)
     assert np.array_equal(mi.cpu().numpy(), wi) and np.array_equal(ms.cpu().numpy().view(np.uint32), ws.view(np.uint32))
+    # the packed form that crosses the all-gather: pack each shard's block, merge the packed lists
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    d_ids, d_sc = torch.from_numpy(ids).cuda(), torch.from_numpy(sc).cuda()
+    packed = torch.empty((G, nq, k, 3), dtype=torch.int32, device="cuda")
+    for g in range(G):
+        B.check(lib.rarc_pack_results(d_ids[g].data_ptr(), d_sc[g].data_ptr(), nq, k, packed[g].data_ptr(), 0))
+    pi = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    ps = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    B.check(lib.rarc_topk_merge_packed(packed.data_ptr(), G, nq, k, pi.data_ptr(), ps.data_ptr(), 0))
+    assert np.array_equal(pi.cpu().numpy(), wi) and np.array_equal(ps.cpu().numpy().view(np.uint32), ws.view(np.uint32))
 
 
 def test_store_end_to_end_and_registry(tmp_path, oracle):
