@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__
                                                         float* __restrict__ seed) {
   constexpr int KS = D / 16, KW = KS / 4;  // k-steps per wave (D multiple of 128 -> KS multiple of 8)
   __shared__ float part[3][16][64];
+  __shared__ float tr[32 * 33];  // [32 queries][32 rows + 1]: output transposition
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5;
   const uint32_t step = n_tiles / seed_tiles;  // >= 1 (seed_tiles <= n_tiles)
@@ -423,15 +424,24 @@ __global__ __launch_bounds__(256) void rarc_seed_kernel(const void* __restrict__
     }
     __syncthreads();
     if (wave == 0) {
-      float* out = seed + (size_t)qidx * (RARC_SEED_MAX_TILES * 32) + ti * 32;
+      // a lane holds 16 scores of ONE query, four bytes each in 16 different cache lines of the seed buffer:
+      // transposed through LDS, a query's 32 scores of the tile leave as one 128-byte line
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = (acc[r] + part[0][r][lane]) + (part[1][r][lane] + part[2][r][lane]);
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * h;
         const bool live = tile * 32 + rr < n_rows;
         if (FMT == 1 && live) v *= rowscale[tile * 32 + rr];
-        out[rr] = live ? v : -INFINITY;
+        tr[row * 33 + rr] = live ? v : -INFINITY;
       }
+      __builtin_amdgcn_wave_barrier();
+      float* out = seed + (size_t)(blockIdx.x * 32) * (RARC_SEED_MAX_TILES * 32) + ti * 32;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {  // 2 queries x 32 rows per instruction
+        const int ql = 2 * t + (lane >> 5), rr = lane & 31;
+        out[(size_t)ql * (RARC_SEED_MAX_TILES * 32) + rr] = tr[ql * 33 + rr];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int ks = 0; ks < KW; ++ks) af[ks] = an[ks];
