@@ -217,7 +217,9 @@ def main():
             for qi in range(n1):
                 cpu_ref.flat_search_f16(rows_h, qn[qi:qi + 1], a.k)
             t_nq1 = (time.perf_counter() - t1) / n1
-            same_ids = bool(np.array_equal(ref_i, ids2.cpu().numpy()))
+            gpu_i = ids2.cpu().numpy()
+            recall = float(np.mean([len(np.intersect1d(ref_i[b], gpu_i[b])) / float(a.k) for b in range(a.batch)]))
+            same_ids = bool(np.array_equal(ref_i, gpu_i))
             same_sc = bool(np.array_equal(ref_s.view(np.uint32), sc2.cpu().numpy().view(np.uint32)))
             result["cpu_baseline"] = {
                 "value": round(a.batch / tcpu, 1), "unit": "queries/s", "cores": nthreads, "kind": "port",
@@ -225,7 +227,8 @@ def main():
                           f"full), {tcpu:.2f} s wall, {os.cpu_count()} host cpus",
                 "reference_style_nq1": {"value": round(1.0 / t_nq1, 1), "unit": "queries/s",
                                         "sample": f"{n1} queries, one per call as the reference issues them"},
-                "parity_vs_gpu": {"ids_bit_exact": same_ids, "scores_bit_exact": same_sc}}
+                "parity_vs_gpu": {"ids_bit_exact": same_ids, "scores_bit_exact": same_sc,
+                                  f"recall_at_{a.k}": round(recall, 6)}}
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
