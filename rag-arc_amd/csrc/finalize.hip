@@ -259,6 +259,7 @@ struct Fin8Params {
   float* out_scores;
   uint32_t* status;
   unsigned long long* dbg;  // tools: phase stamps of block 0 (100 MHz ticks), else null
+  uint32_t* tighten_thr;    // non-null: stop after step 1 and raise thr[q] to L - eps8 (split scan, scan_q8.hip)
 };
 
 __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fin8Params p) {
@@ -430,6 +431,15 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   __syncthreads();
   const float L = s_L;  // -inf when fewer than k candidates exist (then G1 already holds them all)
   FIN8_STAMP(4)
+  if (p.tighten_thr) {
+    // Mid-scan pass: L is the k-th best CANONICAL score among rows already scanned, so it bounds the final k-th
+    // best from below, and a row that good scores at least L - eps8 in int8: the rest of the shard runs under that.
+    if (tid == 0 && L > -INFINITY) {
+      const float t = L - (1.0002f * eps + 1e-7f);
+      if (t > __uint_as_float(p.tighten_thr[q])) p.tighten_thr[q] = __float_as_uint(t);
+    }
+    return;
+  }
 
   // ---- step 2: G2 = {a < T1, a + eps >= L}: canonical scores ----
   if (ne1_all <= (uint32_t)FIN8_RS && t1 > -INFINITY) collect([&](float a) { return a < t1 && a + eps * 1.0001f >= L; });
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
 unsigned long long* g_fin8_dbg = nullptr;  // set by tools only
 int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
                             const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
-                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s) {
+                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, bool tighten) {
   RARC_REQUIRE(d_pad <= FIN8_MAXD, RARC_E_UNSUPPORTED, "rarc_finalize_q8: d_pad %d > %d", d_pad, FIN8_MAXD);
   Fin8Params p;
   p.corpus = corpus;
@@ -498,7 +508,8 @@ int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, 
   p.out_ids = out_ids;
   p.out_scores = out_scores;
   p.status = status;
-  p.dbg = g_fin8_dbg;
+  p.dbg = tighten ? nullptr : g_fin8_dbg;
+  p.tighten_thr = tighten ? (uint32_t*)ws.thr : nullptr;
   // 8 waves stage 8 rows each up to d = 768 (97 KB); wider rows: 4 waves (66 KB at d = 1024)
   const int threads = (fmt || d_pad <= 768) ? FIN8_THREADS : FIN8_THREADS / 2;
   const size_t lds = (size_t)(threads / 64) * 8 * ((size_t)d_pad * (fmt ? 1 : 2) + 16);

@@ -12,10 +12,32 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
 int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                         const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
                         const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
-                        const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8 = nullptr);
+                        const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8,
+                        int (*tighten)(void* ctx, int n_wg), void* tighten_ctx);
 int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
                             const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
-                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s);
+                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, bool tighten);
+
+// int8-prefilter search = seed, scan (split in two launches around an exact mid-scan pass on large shards),
+// canonical finalize; shared by the fp16, fp8 and shadow-image entry points
+struct Q8Search {
+  const void* rows;       // what the finalize rescans: fp16 rows, or fp8 bytes
+  const float* rowscale;  // fp8 only
+  int fin_fmt;            // row format of `rows` for the finalize (0 fp16, 1 fp8)
+  int d_pad, nq, k, cap;
+  int64_t id_base;
+  const float *q32, *eps8;
+  const RarcWs* ws;
+  int64_t* out_ids;
+  float* out_scores;
+  uint32_t* status;
+  hipStream_t s;
+};
+static int q8_tighten(void* ctx, int n_wg) {
+  const Q8Search& a = *(const Q8Search*)ctx;
+  return rarc_finalize_q8_launch(a.rows, a.rowscale, a.fin_fmt, a.d_pad, a.q32, a.eps8, a.nq, a.k, a.id_base, *a.ws, a.cap,
+                                 n_wg, a.out_ids, a.out_scores, a.status, a.s, true);
+}
 int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                        const float* qv, int k, int64_t id_base, int64_t* ids, float* scores, uint32_t* found,
                        const RarcWs& ws, int cap, hipStream_t s);
@@ -111,11 +133,13 @@ extern "C" int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
   hipStream_t s = (hipStream_t)stream;
   int n_wg = 0;
   if (d_qmeta) {  // int8 prefilter scan + two-step canonical finalize (always exact unless a buffer overflows)
+    Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
+               d_status, s};
     rc = rarc_scan_q8_launch(d_corpus_f16, nullptr, 0, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16,
-                             qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s);
+                             qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a);
     if (rc) return rc;
     return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
-                                   n_wg, d_out_ids, d_out_scores, d_status, s);
+                                   n_wg, d_out_ids, d_out_scores, d_status, s, false);
   }
   // fp16 MFMA scan + k' selection + exactness certificate (kept for comparison)
   rc = rarc_scan_f16_launch(d_corpus_f16, n_rows, d_pad, qb.q16, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s);
@@ -166,11 +190,13 @@ extern "C" int rarc_search_f16_shadow(const uint16_t* d_corpus_f16, const int8_t
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipStream_t s = (hipStream_t)stream;
   int n_wg = 0;
+  Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
+             d_status, s};
   rc = rarc_scan_q8_launch(d_corpus_f16, nullptr, 2, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16, qb.eps8,
-                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, d_shadow8);
+                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, d_shadow8, q8_tighten, &a);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
-                                 n_wg, d_out_ids, d_out_scores, d_status, s);
+                                 n_wg, d_out_ids, d_out_scores, d_status, s, false);
 }
 
 // ---- fp8 (e4m3fn + per-row scale) corpus: BASELINE config 5's storage --------------------------------
@@ -197,11 +223,13 @@ extern "C" int rarc_search_f8(const uint8_t* d_corpus_f8, const float* d_row_sca
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipStream_t s = (hipStream_t)stream;
   int n_wg = 0;
+  Q8Search a{d_corpus_f8, d_row_scale, 1, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
+             d_status, s};
   rc = rarc_scan_q8_launch(d_corpus_f8, d_row_scale, 1, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16,
-                           qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s);
+                           qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f8, d_row_scale, 1, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
-                                 n_wg, d_out_ids, d_out_scores, d_status, s);
+                                 n_wg, d_out_ids, d_out_scores, d_status, s, false);
 }
 
 extern "C" int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t n_rows, int d_pad,

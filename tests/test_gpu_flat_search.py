@@ -107,6 +107,36 @@ def test_medium_c2_shape(hip, oracle):
     assert len(getattr(idx, "last_repaired", [])) <= 2
 
 
+def test_split_scan_large_shard(hip, oracle):
+    """2.2M rows (>= 65536 tiles): the int8 scan runs as two launches around the exact mid-scan pass that
+    tightens the thresholds (scan_q8.hip); ids and scores must still equal the oracle's, fp16 and fp8 rows."""
+    import torch
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    n, d, nq, k = 2_200_000, 128, 48, 50
+    rows_h = oracle.synth_rows_f16(n, d)                       # unit rows, storage format
+    q = oracle.synth_rows_f32(nq, d)
+    idx = hip.FlatIndexF16(d, scan="q8")
+    idx.load_rows(rows_h.view(np.float16), 1.001)
+    D, I = idx.search(q, k)
+    ref_I, ref_D, _ = oracle.flat_search_f16(rows_h, oracle.normalize_L2(q), k)
+    assert np.array_equal(I, ref_I) and np.array_equal(D.view(np.uint32), ref_D.view(np.uint32))
+    assert len(idx.last_repaired) == 0
+    # same data ordered by similarity to query 0, best rows LAST, then best rows FIRST (everything the mid-scan
+    # pass sees is below / above what follows)
+    sims = (rows_h.view(np.float16)[:, :d].astype(np.float32) @ oracle.normalize_L2(q)[0])
+    for order in (np.argsort(sims, kind="stable"), np.argsort(-sims, kind="stable")):
+        r2 = np.ascontiguousarray(rows_h[order])
+        idx2 = hip.FlatIndexF16(d, scan="q8")
+        idx2.load_rows(r2.view(np.float16), 1.001)
+        D2, I2 = idx2.search(q, k)
+        w_I, w_D, _ = oracle.flat_search_f16(r2, oracle.normalize_L2(q), k)
+        assert np.array_equal(I2, w_I) and np.array_equal(D2.view(np.uint32), w_D.view(np.uint32))
+        del idx2
+        torch.cuda.empty_cache()
+
+
 def test_incremental_add_and_growth(hip, oracle):
     X, Q = _data(3000, 768, 8, seed=9)
     idx = hip.FlatIndexF16(768)

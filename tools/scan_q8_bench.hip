@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
     printf("R = %.5f  eps8[0..1] = %.5f %.5f  eps16[0] = %.6f\n", h[0], e8[0], e8[1], e16[0]); }
   RarcWs ws = rarc_ws_carve(wsb);
   ScanQ8Params p; p.corpus = (const uint4*)corpus; p.tmeta = qmeta + RARC_QMETA_HDR; p.q8 = qb.q8; p.qinv = qb.qinv; p.eps8 = qb.eps8;
-  p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32);
+  p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32); p.t_begin = 0; p.resume = 0; p.hot_margin = 1.0f;
   p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
   p.binlo = ws.binlo; p.binscale = ws.binscale; p.bininv = ws.bininv;
   { unsigned long long* d; hipMalloc(&d, 65536); hipMemset(d, 0, 65536); p.dbg = d; }
@@ -79,7 +79,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 6; ++rep) {
       if (rep >= 3) { run<0>(p, grid, 1, corpus, N, qb, KP, ws); printf("(after a scan) "); }
       hipEventRecord(f0, 0);
-      rarc_finalize_q8_launch(corpus, nullptr, 0, D, qb.q32, qb.eps8, 256, K, 0, ws, CAP, grid, oi, os, st, 0);
+      rarc_finalize_q8_launch(corpus, nullptr, 0, D, qb.q32, qb.eps8, 256, K, 0, ws, CAP, grid, oi, os, st, 0, false);
       hipEventRecord(f1, 0); hipEventSynchronize(f1); float ms; hipEventElapsedTime(&ms, f0, f1);
       unsigned long long h[16 + 1024]; hipMemcpy(h, fd, sizeof(h), hipMemcpyDeviceToHost);
       { double s1 = 0, s2 = 0; unsigned long long m1 = 0, m2 = 0, tmax = 0; int qmax = 0;
