@@ -109,7 +109,7 @@ def test_medium_c2_shape(hip, oracle):
 
 def test_split_scan_large_shard(hip, oracle):
     """2.2M rows (>= 65536 tiles): the int8 scan runs as two launches around the exact mid-scan pass that
-    tightens the thresholds (scan_q8.hip); ids and scores must still equal the oracle's, fp16 and fp8 rows."""
+    tightens the thresholds (scan_q8.hip); ids and scores must still equal the oracle's (fp8 rows: test_gpu_fp8_corpus.py)."""
     import torch
     from rag_arc_amd.hip import binding as B
 

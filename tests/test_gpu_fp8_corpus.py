@@ -68,3 +68,21 @@ def test_fp8_repair_and_verify(oracle):
     assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
     ids, sc = idx.search_device(Q, 10)
     assert idx.verify_query(Q, 3, ids, sc) == 0
+
+
+def test_fp8_split_scan_large_shard(oracle):
+    """2.2M fp8 rows: the scan runs as two launches around the exact mid-scan pass (fp8 rescoring there too)."""
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    n, d, nq, k = 2_200_000, 200, 24, 40
+    rng = np.random.default_rng(77)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    idx = FlatIndexF16(d, metric="cosine", storage="f8")
+    for s in range(0, n, 550_000):
+        idx.add(X[s:s + 550_000])
+    ref_b, ref_s, _ = oracle.ingest_f8(X, normalize=True)
+    D, I = idx.search(Q, k)
+    rI, rD, _ = oracle.flat_search_f8(ref_b, ref_s, oracle.normalize_L2(Q), k)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    assert len(idx.last_repaired) == 0
