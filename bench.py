@@ -206,7 +206,8 @@ def main():
         B.check(lib.rarc_profile_begin(2 * steps2 + 8), "rarc_profile_begin")
         dt2, (ids2, sc2) = timed_steps(torch, dist, s2, q, a.k, steps2, max(a.warmup, 5), 1)
         B.check(lib.rarc_profile_end(ctypes.byref(tot_ms), ctypes.byref(n_l)), "rarc_profile_end")
-        scan2 = tot_ms.value / max(1, steps2)   # per scan pass (one or two launches)
+        # per scan pass (one or two launches; the warm-up passes of this leg are inside the profiling window too)
+        scan2 = tot_ms.value / max(1, steps2 + max(a.warmup, 5))
         result["c2"] = {"workload": f"{n2}x{a.dim} fp16, 1 GPU, batch {a.batch}, top-{a.k}",
                         "value": round(a.batch * steps2 / dt2, 1), "unit": "queries/s",
                         "ms_per_step": round(dt2 / steps2 * 1e3, 4), "scan_ms": round(scan2, 4),
