@@ -612,7 +612,7 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
 // Seed pass alone (used by the int8 scan, scan_q8.hip): thr[q] = sample statistic − sub_a[q] − sub_b[q].
 int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                      const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
-                     const float* sub_b, const RarcWs& ws, hipStream_t s) {
+                     const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered) {
   ScanParams p;
   p.corpus = (const half_t*)corpus;
   p.q16 = (const half_t*)q16;
@@ -624,7 +624,8 @@ int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t
   // candidates per query and a 3 % longer scan with 4096 sample rows, 33K with 65536) — but the sample
   // costs the same 8 µs per 1024 rows whatever the shard size, which a 3.7 ms scan of a 12.5M-row shard
   // (100M rows over 8 GPUs) cannot afford: it gets 12K rows.
-  uint32_t seed_tiles = p.n_tiles / 1024;
+  // (rows_covered: the part of the shard that will run under this threshold — the first launch of a split scan)
+  uint32_t seed_tiles = (uint32_t)(((rows_covered > 0 ? rows_covered : n_rows) + 31) / 32) / 1024;
   if (seed_tiles < (uint32_t)RARC_SEED_TILES) seed_tiles = (uint32_t)RARC_SEED_TILES;
   if (seed_tiles > (uint32_t)RARC_SEED_MAX_TILES) seed_tiles = (uint32_t)RARC_SEED_MAX_TILES;
   if (seed_tiles > p.n_tiles) seed_tiles = p.n_tiles;

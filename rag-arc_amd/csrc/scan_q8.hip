@@ -555,7 +555,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop);  // rarc_api.hip
 int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                      const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
-                     const float* sub_b, const RarcWs& ws, hipStream_t s);  // scan_f16.hip
+                     const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered = 0);  // scan_f16.hip
 
 template <int D, int FMT>
 static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
@@ -629,20 +629,12 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   p.nq = (uint32_t)nq;
   p.dbg = nullptr;
 
-  // seed pass (fp16 MFMA on a strided sample): t = k'-th best sample score, accurate to eps16, so
-  // t − eps16 bounds the k-th best canonical score from below; rows whose int8 score is under
-  // t − eps16 − eps8 are out
-  int rc = rarc_seed_launch(corpus, rowscale, fmt == 2 ? 0 : fmt, n_rows, d_pad, q16, nq, kprime, bin_lo, bin_hi, eps16,
-                            eps8, ws, s);
-  if (rc) return rc;
-
   int dev = 0, cus = 256;
   RARC_HIP_CHECK(hipGetDevice(&dev));
   RARC_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   int grid = cus < RARC_MAX_WG ? cus : RARC_MAX_WG;
   if ((uint32_t)grid > p.n_tiles) grid = (int)p.n_tiles;
   *grid_out = grid;
-  if (p.n_tiles == 0) return RARC_OK;
   auto launch = [&](const ScanQ8Params& pp) {
     return fmt == 2 ? dispatch_scan_q8<2>(pp, d_pad, grid, s)
                     : fmt == 1 ? dispatch_scan_q8<1>(pp, d_pad, grid, s) : dispatch_scan_q8<0>(pp, d_pad, grid, s);
@@ -654,9 +646,17 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   // shard runs under max(thr, L1 - eps8) from its first tile — a level the single launch only reaches at the
   // very end.  Measured: -2 % per step on a 12.5M-row shard, -2.5 % at 3M, -0.7 % at 100M, +1.6 % at 1M (not split).
   static const bool no_split = getenv("RARC_SCAN_SPLIT") && atoi(getenv("RARC_SCAN_SPLIT")) == 0;
-  const uint32_t pair = 2u * (uint32_t)grid;
+  const uint32_t pair = 2u * (uint32_t)(grid > 0 ? grid : 1);
   uint32_t t1 = (p.n_tiles / 8) / pair * pair;  // (1/4, 1/16, 1/32 measured: no better)
-  if (!tighten || no_split || t1 < 16 * pair) return launch(p);  // (below ~2M rows the second launch costs more than it saves)
+  const bool split = tighten && !no_split && t1 >= 16 * pair;  // (below ~2M rows the second launch costs more than it saves)
+  // seed pass (fp16 MFMA on a strided sample of the whole shard): t = k'-th best sample score, accurate to eps16,
+  // so t − eps16 bounds the k-th best canonical score from below; rows whose int8 score is under t − eps16 − eps8
+  // are out.  The sample is sized for the rows that run under it: the first launch only, when the scan is split.
+  int rc = rarc_seed_launch(corpus, rowscale, fmt == 2 ? 0 : fmt, n_rows, d_pad, q16, nq, kprime, bin_lo, bin_hi, eps16,
+                            eps8, ws, s, split ? (int64_t)t1 * 32 : 0);
+  if (rc) return rc;
+  if (p.n_tiles == 0) return RARC_OK;  // (the seed pass above still initialised thresholds, histograms and flags)
+  if (!split) return launch(p);
   ScanQ8Params p1 = p;
   p1.n_tiles = t1;
   if ((rc = launch(p1)) != RARC_OK) return rc;
