@@ -471,7 +471,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   }
   FIN8_STAMP(7)
   if (p.dbg && q == 0 && tid == 0) { p.dbg[8] = ne1_all; p.dbg[9] = ne_all; }
-  if (p.dbg && tid == 0) { p.dbg[16 + 4 * q] = ne1_all; p.dbg[17 + 4 * q] = ne_all; p.dbg[18 + 4 * q] = __builtin_amdgcn_s_memrealtime(); }
+  if (p.dbg && tid == 0) { p.dbg[16 + 4 * q] = ne1_all; p.dbg[17 + 4 * q] = ne_all; p.dbg[18 + 4 * q] = __builtin_amdgcn_s_memrealtime(); p.dbg[19 + 4 * q] = ((unsigned long long)__float_as_uint(t1) << 32) | __float_as_uint(L); }
   if (tid == 0) {
     uint32_t st = RARC_Q_OK;
     if (s_over || ne_all > (uint32_t)FIN8_RS) st |= RARC_Q_OVERFLOW;

@@ -563,6 +563,11 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
       if (sub_b) ts -= sub_b[q] * 1.0001f;
       if (mx > t) {
         float w = 4.f * (mx - t);
+        // (k = 1: the sample's k-th best IS its maximum and 4·(mx − t) collapses — every later, better row would
+        //  fall into the open top bin, the owner could never raise the threshold and the finalize would start
+        //  from thousands of rows; a quarter of the way to the score bound is what the rule gives at k = 100)
+        const float wfloor = 0.25f * (bin_hi_dflt - t);
+        if (w < wfloor) w = wfloor;
         const float wmin = 1e-3f * fabsf(t) + 1e-20f;  // keeps fp32 rounding of the bin map below one bin
         if (w < wmin) w = wmin;
         lo = ts;

@@ -85,6 +85,10 @@ int main(int argc, char** argv) {
       { double s1 = 0, s2 = 0; unsigned long long m1 = 0, m2 = 0, tmax = 0; int qmax = 0;
         for (int q = 0; q < 256; ++q) { s1 += h[16 + 4 * q]; s2 += h[17 + 4 * q]; if (h[16 + 4 * q] > m1) m1 = h[16 + 4 * q]; if (h[17 + 4 * q] > m2) m2 = h[17 + 4 * q];
           if (h[18 + 4 * q] > tmax) { tmax = h[18 + 4 * q]; qmax = q; } }
+        { int qb2 = 0; for (int q = 0; q < 256; ++q) if (h[16 + 4 * q] > h[16 + 4 * qb2]) qb2 = q;
+          unsigned long long v = h[19 + 4 * qb2]; unsigned int a = (unsigned int)(v >> 32), b = (unsigned int)v; float t1f, Lf; memcpy(&t1f, &a, 4); memcpy(&Lf, &b, 4);
+          float th[256]; hipMemcpy(th, ws.thr, 1024, hipMemcpyDeviceToHost); float lo[256]; hipMemcpy(lo, ws.binlo, 1024, hipMemcpyDeviceToHost); float bi[256]; hipMemcpy(bi, ws.bininv, 1024, hipMemcpyDeviceToHost);
+          printf("  worst query %d: |G1| %llu  T1 %.5f  L %.5f  thr %.5f  binlo %.5f  binwidth %.6f\n", qb2, h[16 + 4 * qb2], t1f, Lf, th[qb2], lo[qb2], bi[qb2]); }
         printf("  |G1| mean %.0f max %llu   |G1+G2| mean %.0f max %llu   last block q=%d ends %.1f us after block0 start (its |G1+G2| = %llu)\n", s1 / 256, m1, s2 / 256, m2, qmax, (tmax - h[0]) / 100.0, h[17 + 4 * qmax]); }
       printf("finalize: %.1f us; block0 phases (us): init %.1f collect1 %.1f rescore1 %.1f rankL %.1f collect2 %.1f rescore2 %.1f final %.1f; |G1|=%llu |G1+G2|=%llu\n", ms * 1000,
              (h[1]-h[0])/100.0, (h[2]-h[1])/100.0, (h[3]-h[2])/100.0, (h[4]-h[3])/100.0, (h[5]-h[4])/100.0, (h[6]-h[5])/100.0, (h[7]-h[6])/100.0, h[8], h[9]);
