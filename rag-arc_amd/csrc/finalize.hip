@@ -232,7 +232,7 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
 // RARC_Q_OVERFLOW and sends the query to rarc_repair_f16.
 // ============================================================================================
 constexpr int FIN8_THREADS = 512;
-constexpr int FIN8_RS = 4096;     // rows rescored canonically per query (G1 ∪ G2)
+constexpr int FIN8_RS = 6144;     // rows rescored canonically per query (G1 ∪ G2); 48 KiB of LDS beside the 97 KiB row staging
 constexpr int FIN8_MAXD = 1024;
 #ifndef FIN8_COLLECT_U
 #define FIN8_COLLECT_U 8

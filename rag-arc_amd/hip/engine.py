@@ -76,6 +76,7 @@ class FlatIndexF16:
         self._qmeta = None  # torch.float32 [4 + 2*capacity/32]: quantisation metadata (include/rarc.h)
         self._lock = threading.Lock()  # callers may be pool threads (core/retrieval/base.py:92-96)
         self._ws = None
+        self._cap_eff = 0          # candidate capacity the workspace was allocated for (grows with k)
         self._qbuf = None
         if capacity:
             self.reserve(capacity)
@@ -139,11 +140,16 @@ class FlatIndexF16:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def _workspace(self):
+    def _workspace(self, k: int = 0):
+        """Scratch for one search.  The candidate buffer grows with k (the int8 margin lets through a number of
+        candidates roughly proportional to k): `cand_cap` is per 128 results — k = 996 takes 8 x 268 MB."""
         t = self.torch
-        if self._ws is None:
-            nbytes = self.lib.rarc_search_workspace_bytes(self.cand_cap)
+        cap = self.cand_cap * max(1, -(-int(k) // 128))
+        if self._ws is None or cap > self._cap_eff:
+            self._cap_eff = max(cap, self._cap_eff)
+            nbytes = self.lib.rarc_search_workspace_bytes(self._cap_eff)
             self._ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+        if self._qbuf is None:
             mq = B.MAX_QUERIES
             self._qbuf = dict(
                 qblock=t.empty(int(self.lib.rarc_query_block_bytes(self.d_pad)), dtype=t.uint8, device=self.device),
@@ -316,7 +322,7 @@ class FlatIndexF16:
 
     def _repair_rows(self, q, k, out_ids, out_sc, flagged) -> None:
         """Re-prepare `q` (the shared query buffers may hold a later batch by now) and repair rows."""
-        ws, b = self._workspace(), self._qbuf
+        ws, b = self._workspace(k), self._qbuf
         stream = self._stream()
         self._prep(q)
         for qi in flagged:
@@ -330,18 +336,18 @@ class FlatIndexF16:
             sc_ptr = self._rowscale.data_ptr() if self._rowscale is not None else 0
             B.check(self.lib.rarc_search_f8(rows_ptr, sc_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k,
                                             kp, self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
-                                            status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+                                            status.data_ptr(), ws.data_ptr(), ws.numel(), self._cap_eff, stream),
                     "rarc_search_f8")
         elif self.shadow and qm and self._shadow is not None:
             B.check(self.lib.rarc_search_f16_shadow(rows_ptr, self._shadow.data_ptr(), self.ntotal, self.d_pad, qm,
                                                     b["qblock"].data_ptr(), nq, k, kp, self.id_base, lo, hi,
                                                     out_ids.data_ptr(), out_sc.data_ptr(), status.data_ptr(),
-                                                    ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+                                                    ws.data_ptr(), ws.numel(), self._cap_eff, stream),
                     "rarc_search_f16_shadow")
         else:
             B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k, kp,
                                              self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
-                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self.cand_cap, stream),
+                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self._cap_eff, stream),
                     "rarc_search_f16")
 
     def _call_repair(self, qi, k, out_ids, out_sc, ws, stream) -> None:
@@ -364,7 +370,7 @@ class FlatIndexF16:
 
     def _search_chunk(self, q, k, out_ids, out_sc, repair, status=None) -> None:
         t = self.torch
-        ws = self._workspace()
+        ws = self._workspace(k)
         b = self._qbuf
         if status is None:
             status = b["status"]

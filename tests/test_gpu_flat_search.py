@@ -68,7 +68,7 @@ def test_search_wide_rows_q8(hip, oracle, n, d, nq, k):
 def test_q8_overflow_is_flagged_and_repaired(hip, oracle):
     """A candidate buffer far too small for the batch: every query overflows, is flagged and repaired."""
     X, Q = _data(50_000, 768, 16, seed=77)
-    idx = hip.FlatIndexF16(768, cand_cap=4096, scan="q8")      # 16 slots per (workgroup, query)
+    idx = hip.FlatIndexF16(768, cand_cap=512, scan="q8")       # x8 for k = 900: 16 slots per (workgroup, query)
     idx.add(X)
     D, I = idx.search(Q, 900)
     assert len(idx.last_repaired) == 16

@@ -59,7 +59,7 @@ def test_fp8_repair_and_verify(oracle):
     from rag_arc_amd.hip.engine import FlatIndexF16
 
     X, Q = _data(50_000, 768, 16, seed=77)
-    idx = FlatIndexF16(768, cand_cap=4096, storage="f8")
+    idx = FlatIndexF16(768, cand_cap=512, storage="f8")      # x8 for k = 900: 16 slots per (workgroup, query)
     idx.add(X)
     D, I = idx.search(Q, 900)
     assert len(idx.last_repaired) == 16
