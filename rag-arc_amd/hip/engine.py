@@ -303,22 +303,27 @@ class FlatIndexF16:
 
     # ------------------------------------------------------------------ pipelined search
     def search_async(self, queries, k: int) -> "PendingSearch":
-        """Enqueue one batch (<= 256 queries) and return at once; `.result()` later performs the
-        status read-back (and the rare repair).  Lets a caller keep the GPU queue full: launch batch
-        i+1, then collect batch i.  Results are identical to search_device()."""
+        """Enqueue one batch and return at once; `.result()` later performs the status read-back (and the rare
+        repair).  Lets a caller keep the GPU queue full: launch batch i+1, then collect batch i.  Results are
+        identical to search_device().  More than 256 queries are enqueued as consecutive 256-query launches."""
         t = self.torch
         if not (1 <= k <= B.MAX_K):
             raise ValueError("k out of range")
         with self._lock, t.cuda.device(self.device):
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
-            if q.ndim != 2 or q.shape[1] != self.dim or q.shape[0] > B.MAX_QUERIES:
-                raise ValueError(f"expected [nq<=256][{self.dim}] queries, got {tuple(q.shape)}")
+            if q.ndim != 2 or q.shape[1] != self.dim or q.shape[0] < 1:
+                raise ValueError(f"expected [nq][{self.dim}] queries, got {tuple(q.shape)}")
             nq = q.shape[0]
             out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
             out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
-            status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this batch's own words
-            self._search_chunk(q, k, out_ids, out_sc, repair=False, status=status)
-            return PendingSearch(self, q, k, out_ids, out_sc, status[B.MAX_QUERIES:], status[:nq])
+            parts = []
+            for s0 in range(0, nq, B.MAX_QUERIES):
+                e0 = min(nq, s0 + B.MAX_QUERIES)
+                status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this launch's own words
+                self._search_chunk(q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], repair=False, status=status)
+                parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], status[B.MAX_QUERIES:],
+                                           status[:e0 - s0]))
+            return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc)
 
     def _repair_rows(self, q, k, out_ids, out_sc, flagged) -> None:
         """Re-prepare `q` (the shared query buffers may hold a later batch by now) and repair rows."""
@@ -437,8 +442,10 @@ class FlatIndexF16:
             ws = self._workspace()
             b = self._qbuf
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
-            self._prep(q)
-            self._call_repair(qi, ids.shape[1], ids, scores, ws, self._stream())
+            c0 = (qi // B.MAX_QUERIES) * B.MAX_QUERIES          # the 256-query launch row qi belongs to
+            c1 = min(q.shape[0], c0 + B.MAX_QUERIES)
+            self._prep(q[c0:c1])
+            self._call_repair(qi - c0, ids.shape[1], ids[c0:c1], scores[c0:c1], ws, self._stream())
             return int(b["found"].item())
 
 
@@ -459,4 +466,21 @@ class PendingSearch:
                 with self.index._lock, t.cuda.device(self.index.device):
                     self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired)
             self.index.last_repaired = self.repaired
+        return self.ids, self.scores
+
+
+class PendingBatches:
+    """search_async over more than 256 queries: one PendingSearch per 256-query launch, one result."""
+
+    def __init__(self, parts, ids, scores):
+        self.parts, self.ids, self.scores = parts, ids, scores
+        self.repaired = None
+
+    def result(self):
+        if self.repaired is None:
+            self.repaired = []
+            for i, p in enumerate(self.parts):
+                p.result()                                  # repairs write into the shared output views
+                self.repaired += [i * B.MAX_QUERIES + r for r in p.repaired]
+            self.parts[0].index.last_repaired = self.repaired
         return self.ids, self.scores

@@ -137,6 +137,23 @@ def test_split_scan_large_shard(hip, oracle):
         torch.cuda.empty_cache()
 
 
+def test_search_async_over_256_queries(hip, oracle):
+    """The pipelined form takes any batch: 600 queries go out as three 256-query launches, one result."""
+    import torch
+
+    X, Q = _data(6000, 384, 600, seed=5)
+    idx = hip.FlatIndexF16(384)
+    idx.add(X)
+    h = idx.search_async(torch.from_numpy(Q).cuda(), 10)
+    ai, asc = h.result()
+    si, ssc = idx.search_device(Q, 10)
+    assert torch.equal(ai, si) and torch.equal(asc.view(torch.int32), ssc.view(torch.int32))
+    rows, _ = oracle.ingest_f16(X)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), 10)
+    assert np.array_equal(ai.cpu().numpy(), rI) and np.array_equal(asc.cpu().numpy().view(np.uint32), rD.view(np.uint32))
+    assert idx.verify_query(Q, 599, ai, asc) == 0            # a row of the third launch
+
+
 def test_incremental_add_and_growth(hip, oracle):
     X, Q = _data(3000, 768, 8, seed=9)
     idx = hip.FlatIndexF16(768)
