@@ -290,7 +290,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
     if (tid == 0) s_t1 = rarc_bin_threshold(b, p.binlo[q], p.bininv[q]);
   }
   __syncthreads();
-  const float t1 = s_t1;  // -inf when fewer than k candidates exist: then G1 is everything
+  float t1 = s_t1;  // -inf when fewer than k candidates exist: then G1 is everything
 
   // walk the query's segments and append the keys `want` accepts to ex[].  One wave per segment at a
   // time, 64 consecutive keys per load (coalesced); a wave issues the loads of four segments before it
@@ -414,6 +414,32 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   FIN8_STAMP(1)
   collect([&](float a) { return a >= t1; });
   __syncthreads();
+  if (s_ne > (uint32_t)FIN8_RS && t1 > -INFINITY) {
+    // The histogram's bins were too coarse for this query (a window sized from a sample whose k-th best lies far
+    // below the final one): G1 does not fit.  Any cut with k <= |{a >= cut}| <= buffer will do: bisect for one
+    // between the histogram's edge and the top of its window, one sweep over the candidate keys per probe.
+    float a_lo = t1, a_hi = p.binlo[q] + (float)RARC_NB * p.bininv[q];
+    for (int probe = 0; probe < 24 && a_hi > a_lo; ++probe) {
+      const float mid = a_lo + 0.5f * (a_hi - a_lo);
+      if (!(mid > a_lo && mid < a_hi)) break;
+      __syncthreads();
+      if (tid == 0) s_ne = 0;
+      __syncthreads();
+      collect([&](float a) { return a >= mid; });
+      __syncthreads();
+      const uint32_t c = s_ne;
+      if (c > (uint32_t)FIN8_RS) a_lo = mid;
+      else if (c < (uint32_t)p.k) a_hi = mid;
+      else { t1 = mid; break; }
+    }
+    if (s_ne > (uint32_t)FIN8_RS || s_ne < (uint32_t)p.k) {  // no cut found (ties): leave the overflow for the flag
+      __syncthreads();
+      if (tid == 0) s_ne = 0;
+      __syncthreads();
+      collect([&](float a) { return a >= t1; });
+      __syncthreads();
+    }
+  }
   FIN8_STAMP(2)
   const uint32_t ne1_all = s_ne;
   const int ne1 = ne1_all < FIN8_RS ? (int)ne1_all : FIN8_RS;
@@ -445,10 +471,57 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   if (ne1_all <= (uint32_t)FIN8_RS && t1 > -INFINITY) collect([&](float a) { return a < t1 && a + eps * 1.0001f >= L; });
   __syncthreads();
   FIN8_STAMP(5)
-  const uint32_t ne_all = s_ne;
-  const int ne = ne_all < FIN8_RS ? (int)ne_all : FIN8_RS;
-  rescore(ne1, ne);
-  __syncthreads();
+  uint32_t ne_all = s_ne;
+  int ne = ne_all < FIN8_RS ? (int)ne_all : FIN8_RS;
+  bool band_fail = false;
+  if (ne_all > (uint32_t)FIN8_RS && ne1_all <= (uint32_t)FIN8_RS && ne1 >= p.k && L > -INFINITY) {
+    // G2 does not fit (large k on a large shard: k = 996 at 100M rows wants ~7000 rows).  Take it in bands of
+    // approximate score, best band first: keep the k best canonical keys so far in ex[0..k), collect the band's
+    // candidates behind them, rescore, keep the k best again.  The k-th best canonical score Lc only rises, so
+    // the floor Lc - eps below which nothing can matter rises with it; a band that does not fit is halved.
+    uint64_t* tmp = (uint64_t*)fsm;  // (the row staging area is idle while keys are ranked)
+    auto keep_top_k = [&](int n) {   // ex[0..n) -> its k best keys, in order, in ex[0..k); s_L = the k-th
+      for (int i = tid; i < n; i += blockDim.x) {
+        const uint64_t mine = ex[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (ex[j] > mine);
+        if (rank < p.k) tmp[rank] = mine;
+        if (rank == p.k - 1) s_L = rarc_candscore(mine);
+      }
+      __syncthreads();
+      for (int i = tid; i < p.k; i += blockDim.x) ex[i] = tmp[i];
+      __syncthreads();
+    };
+    keep_top_k(ne1);
+    float hi = t1, lo_try = -INFINITY;
+    for (int guard = 0; guard < 64; ++guard) {
+      const float floor_a = s_L - eps * 1.0001f;
+      if (!(hi > floor_a)) break;
+      const float lo = lo_try > floor_a ? lo_try : floor_a;
+      __syncthreads();
+      if (tid == 0) s_ne = (uint32_t)p.k;
+      __syncthreads();
+      collect([&](float a) { return a >= lo && a < hi; });
+      __syncthreads();
+      const uint32_t cnt = s_ne;
+      if (cnt > (uint32_t)FIN8_RS) {  // halve the band from below
+        const float mid = lo + 0.5f * (hi - lo);
+        if (!(mid > lo && mid < hi)) { band_fail = true; break; }
+        lo_try = mid;
+        continue;
+      }
+      rescore(p.k, (int)cnt);
+      __syncthreads();
+      keep_top_k((int)cnt);
+      hi = lo;
+      lo_try = -INFINITY;
+    }
+    ne = p.k;
+    ne_all = band_fail ? (uint32_t)FIN8_RS + 1u : (uint32_t)p.k;
+  } else {
+    rescore(ne1, ne);
+    __syncthreads();
+  }
   FIN8_STAMP(6)
 
   // ---- step 3: exact order (canonical score desc, id asc) by counting ----

@@ -82,3 +82,31 @@ def test_flags_are_raised_and_repair_fixes_them(oracle):
     rows, _ = oracle.ingest_f16(X)
     rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), 100)
     assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+
+
+def test_dense_score_band_large_k(oracle):
+    """20 000 rows whose scores to one query lie within two error bounds of each other, k = 996: the rows that
+    must be rescored (everything within eps8 of the k-th best) outnumber the finalize's 6144-row buffer, so it
+    takes them in bands of approximate score — and must still return the oracle's answer without a repair."""
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(31)
+    n, d, k = 300_000, 128, 996
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    q = np.zeros((3, d), np.float32)
+    q[0, 0] = 1.0
+    q[1:] = rng.standard_normal((2, d)).astype(np.float32)
+    c = rng.uniform(0.80, 0.83, 20_000).astype(np.float32)          # cosines to q[0], 0.03 wide
+    u = X[:20_000].copy()
+    u[:, 0] = 0.0
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    X[:20_000] = c[:, None] * q[0] + np.sqrt(1.0 - c * c)[:, None] * u
+    X = X[rng.permutation(n)]
+    idx = FlatIndexF16(d, scan="q8")
+    idx.add(X)
+    D, I = idx.search(q, k)
+    rows, _ = oracle.ingest_f16(X)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(q), k)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    assert len(idx.last_repaired) == 0
