@@ -572,6 +572,8 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
         if (w < wmin) w = wmin;
         lo = ts;
         hi = t + w;
+        // (no score exceeds the caller's bound: a window reaching past it only makes the bins coarser)
+        if (hi > bin_hi_dflt && bin_hi_dflt > t + wmin) hi = bin_hi_dflt;
       }
       t = ts;
     }
