@@ -166,7 +166,7 @@ def main():
         ach = shard_bytes / (scan_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        kname = "rarc_scan_q8_kernel" if idx._use_q8() else "rarc_scan_f16_kernel"
+        kname = "rarc_scan_q8_kernel" if idx._use_q8(a.k) else "rarc_scan_f16_kernel"
         if os.path.exists(tpath):
             try:
                 for ent in json.load(open(tpath)).get("entries", []):  # PMC passes recorded per shard size
@@ -190,7 +190,7 @@ def main():
                        "full_size_check": {"queries_verified_by_exact_rescan": 2, "rows_beating_kth": beat}},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "rarc_scan_q8_kernel" if idx._use_q8() else "rarc_scan_f16_kernel",
+                         "kernel": "rarc_scan_q8_kernel" if idx._use_q8(a.k) else "rarc_scan_f16_kernel",
                          "avg_launch_ms": round(scan_ms, 4),
                          "algorithmic_bytes_per_launch": int(shard_bytes), "launches_timed": n_l.value,
                          "launches_per_scan": launches_per_pass, "scan_ms_per_pass": round(scan_ms * launches_per_pass, 4)},

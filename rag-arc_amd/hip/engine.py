@@ -158,19 +158,25 @@ class FlatIndexF16:
             )
         return self._ws
 
-    AUTO_Q8_ROWS = 1_500_000   # measured (768 dims, ms/step q8 vs mfma16): 1M 0.57 vs 0.51, 2M 0.86 vs 0.90, 3M 1.16 vs 1.29
+    # "auto": measured crossover of the two scans (768 dims, ms per 256-query batch, int8 vs fp16 MFMA):
+    #   1M rows: k=10 0.44 / 0.50, k=50 0.51 / 0.52, k=100 0.56 / 0.53, k=400 0.82 / 0.66;  300K rows: k=10 0.24 / 0.25,
+    #   k=100 0.31 / 0.26;  2M rows, k=100: 0.86 / 0.90 — the int8 scan's candidate count grows with k, the fp16 scan's
+    #   cost does not, so the switch-over shard size does: 1.5M rows x (k/100)^0.7
+    AUTO_Q8_ROWS = 1_500_000
 
-    def _use_q8(self) -> bool:
+    def _use_q8(self, k: int = 100) -> bool:
         if self.storage == "f8" or self.shadow:
             return True
         if self.scan == "auto":
-            return self.d_pad > 768 or self.ntotal >= self.AUTO_Q8_ROWS
+            if self.d_pad > 768 or k > 900:   # the fp16 scan stops at 768 dims; its k' <= 1024 certificate gives out near k = 1000
+                return True
+            return self.ntotal >= self.AUTO_Q8_ROWS * (max(int(k), 1) / 100.0) ** 0.7
         return self.scan == "q8"
 
-    def _prep(self, q) -> None:
+    def _prep(self, q, k: int = 100) -> None:
         """rarc_prep_queries into the shared query block (caller holds the lock)."""
         norm = 1 if self.metric == "cosine" else 0
-        qm = self._qmeta.data_ptr() if (self._use_q8() and self._qmeta is not None) else 0
+        qm = self._qmeta.data_ptr() if (self._use_q8(k) and self._qmeta is not None) else 0
         B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
                                            max(self.max_norm, 1.0) if norm else self.max_norm, qm,
                                            self._qbuf["qblock"].data_ptr(), self._stream()), "rarc_prep_queries")
@@ -382,13 +388,13 @@ class FlatIndexF16:
             status.zero_()
         nq = q.shape[0]
         stream = self._stream()
-        self._prep(q)
+        self._prep(q, k)
         lo, hi = self._bins(q)
         # the int8 path's threshold proof needs the k-th best approximate score, nothing beyond it (its 2·eps8
         # margin is the slack); the fp16 path's certificate wants k' > k candidates
-        kp = k if self._use_q8() else self.kprime_for(k)
+        kp = k if self._use_q8(k) else self.kprime_for(k)
         rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
-        qm = self._qmeta.data_ptr() if (self._use_q8() and self._qmeta is not None and self.ntotal) else 0
+        qm = self._qmeta.data_ptr() if (self._use_q8(k) and self._qmeta is not None and self.ntotal) else 0
         self._call_search(rows_ptr, qm, nq, k, kp, lo, hi, out_ids, out_sc, status, ws, stream)
         self.last_status = status[:nq]
         if not repair or self.ntotal == 0:
