@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 202 /* 0.2.0: query block, int8 prefilter scan */
+#define RARC_VERSION 203 /* 0.2.1: N(0,1) generator, encoder table sizes in the ABI */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
@@ -246,7 +246,8 @@ int rarc_rerank_order(const uint16_t* d_z_no, const uint16_t* d_z_yes, int nq, i
 
 /*
  * Deterministic synthetic corpus / query generator (bench + full-size property
- * tests): counter-based integer hash -> Irwin-Hall(4) approx-normal -> exact
+ * tests): counter-based integer hash -> 52-bit uniform -> N(0,1) by the inverse normal CDF (Wichura AS 241,
+ * exactly rounded double operations only) -> integer on a 2^-20 grid -> exact
  * integer sum of squares -> fp64 scale -> fp16 (RNE).  Bit-identical to
  * oracle/rarc_oracle.c:synth_rows_f16.  Row r of the stream `seed` depends only
  * on (seed, first_row + r, d).
@@ -261,7 +262,9 @@ int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_r
  * sentence-transformers at core/file_management/embeddings/huggingface.py:122-126
  * ([external] BERT forward -> CLS pooling -> optional normalise).  Token ids in, embeddings out.
  * All tensors fp16 (uint16 bit patterns) unless noted; weights use torch.nn.Linear layout [out][in].
- *   rarc_enc_embed_ln : out[t] = LayerNorm(word[ids[t]] + pos[t % seq_len] + type0)
+ *   rarc_enc_embed_ln : out[t] = LayerNorm(word[ids[t]] + pos[t % seq_len] + type0); `vocab` = rows of d_word:
+ *                       an id outside [0, vocab) is clamped into the table (memory safety only — callers
+ *                       validate ids on the host, as the python binding does)
  *   rarc_enc_gemm     : C[M][N] = A[M][K] · W[N][K]^T + bias[N], act 0 = none, 1 = erf-GELU;
  *                       M, N multiples of 128, K multiple of 64 (MFMA 32x32x16 f16, fp32 accumulate)
  *   rarc_enc_attention: ctx = softmax(Q K^T / sqrt(dh) + key mask) V per (sequence, head) from the
@@ -271,7 +274,7 @@ int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_r
  */
 int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,
                       const uint16_t* d_type0, const uint16_t* d_gamma, const uint16_t* d_beta, float eps,
-                      int n_tokens, int seq_len, int hidden, uint16_t* d_out, void* stream);
+                      int n_tokens, int seq_len, int hidden, int vocab, uint16_t* d_out, void* stream);
 int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
                   int n, int k, int act, void* stream);
 int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
@@ -285,7 +288,8 @@ int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, int hidden, 
  * Whole encoder forward in one call: the launch loop over the layers runs on the host side of this
  * library, not in the caller (at small batches the per-call overhead of a foreign-function binding is
  * longer than the kernels).  `model` and `model->layers` are HOST structs of DEVICE pointers.
- * n_seq*seq_len must be a multiple of 128 (pad with sequences of length 1).  d_ws: scratch of
+ * n_seq*seq_len must be a multiple of 128 (pad seq_len to a multiple of 32 with masked tokens and n_seq to a
+ * multiple of 4 with sequences of length 1); d_lens[s] in [1, seq_len] (clamped into that range).  d_ws: scratch of
  * rarc_enc_workspace_bytes(hidden, inter, n_seq*seq_len) bytes.  d_out: fp32 [n_seq][hidden].
  */
 typedef struct RarcEncLayer {
@@ -298,6 +302,8 @@ typedef struct RarcEncModel {
   float ln_eps;
   const uint16_t *word, *pos, *type0, *emb_g, *emb_b;
   const RarcEncLayer* layers; /* host array [n_layers] */
+  int vocab;   /* rows of `word`  (REQUIRED > 0: token ids are clamped into [0, vocab)) */
+  int max_pos; /* rows of `pos`   (REQUIRED >= seq_len) */
 } RarcEncModel;
 size_t rarc_enc_workspace_bytes(int hidden, int inter, int n_tokens);
 int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
@@ -307,7 +313,8 @@ int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int3
  * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan
  * kernel with a pair of HIP events recorded on the search's own stream.  rarc_profile_end
  * synchronises, returns the summed scan time and the number of launches measured, and releases
- * the events.  Not thread safe; one profiling session at a time.
+ * the events.  One profiling session at a time per process (the event list is guarded by a mutex, so searches
+ * issued from other threads while a session is open are measured too, in launch order).
  */
 int rarc_profile_begin(int max_launches);
 int rarc_profile_end(double* total_scan_ms, int* n_launches);

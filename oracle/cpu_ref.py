@@ -49,6 +49,12 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError("oracle needs an x86-64 CPU with AVX2 + FMA + F16C")
         L.oracle_canon_dot_f16.restype = ctypes.c_float
         L.oracle_canon_dot_f16_scalar.restype = ctypes.c_float
+        L.oracle_synth_ppnd.restype = ctypes.c_double
+        L.oracle_synth_ppnd.argtypes = [ctypes.c_double]
+        L.oracle_synth_log.restype = ctypes.c_double
+        L.oracle_synth_log.argtypes = [ctypes.c_double]
+        L.oracle_synth_val.restype = ctypes.c_int32
+        L.oracle_synth_val.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32]
         _lib = L
     return _lib
 
@@ -202,6 +208,16 @@ def topk_merge(ids: np.ndarray, scores: np.ndarray, k: int) -> Tuple[np.ndarray,
 
 
 # ------------------------------------------------------------------------------------- synthetic
+def synth_ppnd(p: float) -> float:
+    """The generator's inverse normal CDF (Wichura AS 241 in exactly rounded double operations)."""
+    return float(lib().oracle_synth_ppnd(float(p)))
+
+
+def synth_val(seed: int, row: int, col: int) -> int:
+    """One N(0,1) draw of the counter-based generator as the integer rint(z * 2^20)."""
+    return int(lib().oracle_synth_val(seed, row, col))
+
+
 def synth_rows_f16(n: int, d: int, first_row: int = 0, seed: int = 1234, d_pad: int | None = None) -> np.ndarray:
     d_pad = d_pad or padded_dim(d)
     out = np.zeros((n, d_pad), dtype=np.uint16)

@@ -376,25 +376,99 @@ int oracle_flat_search_f8(const uint8_t* corpus, const float* scales, int64_t n,
   return nthreads;
 }
 
-/* ---- deterministic synthetic rows (mirrors rag-arc_amd/csrc/prep.hip: rarc_synth_kernel) ------ */
+/* ---- deterministic synthetic rows (mirrors rag-arc_amd/csrc/prep.hip: rarc_synth_kernel) ------
+ * v(seed,row,col) ~ N(0,1) ("D ~ N(0,1) ... or an identical counter-based generator"):
+ * counter hash -> 52-bit uniform p in (0,1) -> z = Phi^-1(p) by Wichura's AS 241 (PPND16, rel. error 1e-16)
+ * -> integer rint(z * 2^20).  Every step uses only exactly rounded double operations (+ - * / sqrt) in a fixed
+ * order — the one transcendental, log, is the explicit series below — so the GPU generator reproduces the
+ * integers bit for bit; rows are then normalised from the exact integer sum of squares.                      */
 static inline uint64_t synth_mix(uint64_t z) {
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
   return z ^ (z >> 31);
 }
+/* ln x for normal positive x: x = m * 2^e, m in (sqrt(1/2), sqrt 2], ln m = 2 atanh(s), s = (m-1)/(m+1) */
+static inline double synth_log(double x) {
+  uint64_t u;
+  memcpy(&u, &x, 8);
+  int e = (int)((u >> 52) & 0x7ff) - 1023;
+  u = (u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+  double m;
+  memcpy(&m, &u, 8);
+  if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }
+  const double s = (m - 1.0) / (m + 1.0), z = s * s;
+  double t = 1.0 / 27.0;
+  t = t * z + 1.0 / 25.0;
+  t = t * z + 1.0 / 23.0;
+  t = t * z + 1.0 / 21.0;
+  t = t * z + 1.0 / 19.0;
+  t = t * z + 1.0 / 17.0;
+  t = t * z + 1.0 / 15.0;
+  t = t * z + 1.0 / 13.0;
+  t = t * z + 1.0 / 11.0;
+  t = t * z + 1.0 / 9.0;
+  t = t * z + 1.0 / 7.0;
+  t = t * z + 1.0 / 5.0;
+  t = t * z + 1.0 / 3.0;
+  t = t * z + 1.0;
+  return (double)e * 0.6931471805599453 + (s + s) * t;
+}
+static inline double synth_ppnd(double p) {
+  const double q = p - 0.5;
+  if (q >= -0.425 && q <= 0.425) {
+    const double r = 0.180625 - q * q;
+    const double num = (((((((2.5090809287301226727e+3 * r + 3.3430575583588128105e+4) * r + 6.7265770927008700853e+4) * r +
+                            4.5921953931549871457e+4) * r + 1.3731693765509461125e+4) * r + 1.9715909503065514427e+3) * r +
+                         1.3314166789178437745e+2) * r + 3.3871328727963666080e0);
+    const double den = (((((((5.2264952788528545610e+3 * r + 2.8729085735721942674e+4) * r + 3.9307895800092710610e+4) * r +
+                            2.1213794301586595867e+4) * r + 5.3941960214247511077e+3) * r + 6.8718700749205790830e+2) * r +
+                         4.2313330701600911252e+1) * r + 1.0);
+    return q * num / den;
+  }
+  double r = q < 0.0 ? p : 1.0 - p;
+  r = sqrt(-synth_log(r));
+  double v;
+  if (r <= 5.0) {
+    r = r - 1.6;
+    const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r +
+                            1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r +
+                         4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+    const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r +
+                            1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r +
+                         2.05319162663775882187e0) * r + 1.0);
+    v = num / den;
+  } else {
+    r = r - 5.0;
+    const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r +
+                            2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r +
+                         5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+    const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r +
+                            7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r +
+                         5.99832206555887937690e-1) * r + 1.0);
+    v = num / den;
+  }
+  return q < 0.0 ? -v : v;
+}
 static inline int32_t synth_val(uint64_t seed, uint64_t row, uint32_t col) {
   const uint64_t h = synth_mix(synth_mix(seed ^ (row * 0xd1342543de82ef95ull)) + col);
-  return (int32_t)((h & 0xffff) + ((h >> 16) & 0xffff) + ((h >> 32) & 0xffff) + (h >> 48)) - 131070;
+  const double p = ((double)(h >> 12) + 0.5) * 2.220446049250313e-16; /* (i + 1/2) * 2^-52, exact */
+  return (int32_t)rint(synth_ppnd(p) * 1048576.0);
 }
+/* test hooks: the pieces of the generator, so the CPU suite can pin them against scipy */
+double oracle_synth_ppnd(double p) { return synth_ppnd(p); }
+double oracle_synth_log(double x) { return synth_log(x); }
+int32_t oracle_synth_val(uint64_t seed, uint64_t row, uint32_t col) { return synth_val(seed, row, col); }
 static void synth_row(float* tmp, int d, uint64_t seed, uint64_t row) {
   uint64_t ss = 0;
+  int32_t* iv = (int32_t*)tmp; /* same size as float: integers first, scaled in place afterwards */
   for (int c = 0; c < d; ++c) {
     const int64_t v = synth_val(seed, row, (uint32_t)c);
+    iv[c] = (int32_t)v;
     ss += (uint64_t)(v * v);
   }
   const double scale = ss > 0 ? 1.0 / sqrt((double)ss) : 0.0;
-  for (int c = 0; c < d; ++c) tmp[c] = (float)((double)synth_val(seed, row, (uint32_t)c) * scale);
+  for (int c = 0; c < d; ++c) tmp[c] = (float)((double)iv[c] * scale);
 }
 void oracle_synth_rows_f16(uint16_t* out, int d_pad, int d, int64_t first_row, int64_t n, uint64_t seed) {
 #pragma omp parallel

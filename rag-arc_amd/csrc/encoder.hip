@@ -759,11 +759,13 @@ __device__ __forceinline__ void ln_row(LnRow& r, int H, const half_t* gamma, con
 __global__ __launch_bounds__(256) void rarc_embed_ln_kernel(const int32_t* ids, const half_t* word, const half_t* pos,
                                                             const half_t* type0, const half_t* gamma,
                                                             const half_t* beta, float eps, int n_tokens, int L, int H,
-                                                            half_t* out) {
+                                                            int vocab, half_t* out) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= n_tokens) return;
-  const half_t* w = word + (size_t)ids[t] * H;
+  int id = ids[t];  // ids outside [0, vocab) never index outside the table (the host binding rejects them)
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const half_t* w = word + (size_t)id * H;
   const half_t* p = pos + (size_t)(t % L) * H;
   LnRow r;
 #pragma unroll
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(256) void rarc_attention_kernel(const half_t* qkv, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qb = blockIdx.x % q_blocks, bh = blockIdx.x / q_blocks;
   const int b = bh / n_heads, hd = bh % n_heads;
-  const int len = lens[b];
+  const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
   const size_t base = (size_t)b * L * 3 * H;
   const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;  // 1/sqrt(DH)
   const int q0 = qb * 64;
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(256) void rarc_attention_mfma_kernel(const half_t* 
   half_t* vt = vt_all[wave];
   const int qb = unit % q_blocks, bh = unit / q_blocks;
   const int b = bh / n_heads, hd = bh % n_heads;
-  const int len = lens[b];
+  const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);  // never an empty softmax, never past the sequence
   const int col = lane & 31, hh = lane >> 5;
   const size_t rs = (size_t)3 * H;  // row stride of qkv in halves
   const half_t* base = qkv + (size_t)b * L * rs + hd * DH;
@@ -1047,7 +1049,8 @@ __global__ __launch_bounds__(64) void rarc_pool_kernel(const half_t* hidden, int
 static int gemm_attrs() {
   constexpr int lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
   constexpr int lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
-  static bool attr = false;
+  static RarcPerDevice attr_dev;
+  size_t& attr = attr_dev.cur();
   if (attr) return RARC_OK;
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<0, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<1, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
@@ -1063,7 +1066,7 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
-  attr = true;
+  attr = 1;
   return RARC_OK;
 }
 
@@ -1151,13 +1154,14 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
 
 extern "C" int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,
                                  const uint16_t* d_type0, const uint16_t* d_gamma, const uint16_t* d_beta, float eps,
-                                 int n_tokens, int seq_len, int hidden, uint16_t* d_out, void* stream) {
+                                 int n_tokens, int seq_len, int hidden, int vocab, uint16_t* d_out, void* stream) {
   RARC_REQUIRE(d_ids && d_word && d_pos && d_type0 && d_gamma && d_beta && d_out, RARC_E_INVALID, "rarc_enc_embed_ln: null pointer");
   RARC_REQUIRE(hidden % 64 == 0 && hidden <= 1024 && n_tokens > 0 && seq_len > 0, RARC_E_UNSUPPORTED,
                "rarc_enc_embed_ln: hidden must be a multiple of 64, <= 1024");
+  RARC_REQUIRE(vocab > 0, RARC_E_INVALID, "rarc_enc_embed_ln: vocab (rows of the word table) must be given");
   hipLaunchKernelGGL(rarc_embed_ln_kernel, dim3((n_tokens + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_ids,
                      (const half_t*)d_word, (const half_t*)d_pos, (const half_t*)d_type0, (const half_t*)d_gamma,
-                     (const half_t*)d_beta, eps, n_tokens, seq_len, hidden, (half_t*)d_out);
+                     (const half_t*)d_beta, eps, n_tokens, seq_len, hidden, vocab, (half_t*)d_out);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -1225,6 +1229,9 @@ extern "C" int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids,
   RARC_REQUIRE(model && model->layers && d_ids && d_lens && d_ws && d_out, RARC_E_INVALID, "rarc_enc_forward: null pointer");
   const int H = model->hidden, I = model->inter;
   RARC_REQUIRE(n_seq > 0 && seq_len > 0 && model->n_layers > 0, RARC_E_INVALID, "rarc_enc_forward: empty batch or model");
+  RARC_REQUIRE(model->vocab > 0 && model->max_pos >= seq_len, RARC_E_INVALID,
+               "rarc_enc_forward: model->vocab (%d) must be set and model->max_pos (%d) must cover seq_len (%d)",
+               model->vocab, model->max_pos, seq_len);
   const long long m_ll = (long long)n_seq * seq_len;
   RARC_REQUIRE(m_ll % GM == 0 && m_ll < (1ll << 31), RARC_E_UNSUPPORTED,
                "rarc_enc_forward: n_seq*seq_len must be a multiple of 128 (got %lld)", m_ll);
@@ -1255,7 +1262,7 @@ extern "C" int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids,
     return RARC_OK;
   };
   int rc = rarc_enc_embed_ln(d_ids, model->word, model->pos, model->type0, model->emb_g, model->emb_b, model->ln_eps, M,
-                             seq_len, H, x, stream);
+                             seq_len, H, model->vocab, x, stream);
   for (int l = 0; l < model->n_layers && rc == RARC_OK; ++l) {
     const RarcEncLayer& L = model->layers[l];
     if ((rc = rarc_enc_gemm(x, L.qkv_w, L.qkv_b, qkv, M, 3 * H, H, 0, stream)) != RARC_OK) break;

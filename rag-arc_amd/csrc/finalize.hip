@@ -493,10 +493,14 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       __syncthreads();
     };
     keep_top_k(ne1);
+    // Only "the band's top reached the floor" ends the loop as a success: running out of iterations flags the
+    // query for repair.  A consumed band hands its width to the next one (dense G2: about one iteration per band
+    // instead of a fresh run of halvings from the whole remaining range).
     float hi = t1, lo_try = -INFINITY;
-    for (int guard = 0; guard < 64; ++guard) {
+    bool reached_floor = false;
+    for (int guard = 0; guard < 512; ++guard) {
       const float floor_a = s_L - eps * 1.0001f;
-      if (!(hi > floor_a)) break;
+      if (!(hi > floor_a)) { reached_floor = true; break; }
       const float lo = lo_try > floor_a ? lo_try : floor_a;
       __syncthreads();
       if (tid == 0) s_ne = (uint32_t)p.k;
@@ -513,9 +517,11 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       rescore(p.k, (int)cnt);
       __syncthreads();
       keep_top_k((int)cnt);
+      const float width = hi - lo;
       hi = lo;
-      lo_try = -INFINITY;
+      lo_try = (cnt > (uint32_t)(FIN8_RS / 2)) ? hi - width : hi - 2.0f * width;  // sparse band: try twice the width next
     }
+    if (!reached_floor) band_fail = true;
     ne = p.k;
     ne_all = band_fail ? (uint32_t)FIN8_RS + 1u : (uint32_t)p.k;
   } else {
@@ -586,7 +592,8 @@ int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, 
   // 8 waves stage 8 rows each up to d = 768 (97 KB); wider rows: 4 waves (66 KB at d = 1024)
   const int threads = (fmt || d_pad <= 768) ? FIN8_THREADS : FIN8_THREADS / 2;
   const size_t lds = (size_t)(threads / 64) * 8 * ((size_t)d_pad * (fmt ? 1 : 2) + 16);
-  static size_t lds_attr = 0;
+  static RarcPerDevice lds_attr_dev;
+  size_t& lds_attr = lds_attr_dev.cur();
   if (lds > lds_attr) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_finalize_q8_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -711,7 +718,8 @@ int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64
   int np2 = 2;
   while (np2 < (int)p.cap + 1) np2 <<= 1;
   const size_t lds = (size_t)np2 * 8;
-  static size_t lds_attr = 0;
+  static RarcPerDevice lds_attr_dev;
+  size_t& lds_attr = lds_attr_dev.cur();
   if (lds > lds_attr) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_repair_merge_kernel,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -794,7 +802,8 @@ int rarc_merge_launch(const int64_t* ids, const float* scores, int G, int nq, in
   while (np2 < G * k) np2 <<= 1;
   const size_t lds = (size_t)np2 * 12;
   RARC_REQUIRE(lds <= 160 * 1024, RARC_E_UNSUPPORTED, "rarc_topk_merge: %d lists x k=%d too large", G, k);
-  static size_t lds_attr = 0;
+  static RarcPerDevice lds_attr_dev;
+  size_t& lds_attr = lds_attr_dev.cur();
   if (lds > lds_attr) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_merge_kernel<false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

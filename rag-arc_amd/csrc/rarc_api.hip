@@ -48,11 +48,16 @@ int rarc_pack_launch(const int64_t* ids, const float* scores, int n, uint32_t* o
 static thread_local char g_err[512] = "";
 
 // ---- scan timing hooks -------------------------------------------------------------------------
+#include <atomic>
+#include <mutex>
 #include <vector>
+static std::mutex g_prof_mu;               // searches may come from pool threads (core/retrieval/base.py:92-96)
 static std::vector<hipEvent_t> g_prof_ev;  // pairs: [2i] start, [2i+1] stop
 static int g_prof_n = 0;
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_prof_on.load(std::memory_order_acquire)) return false;  // the common case takes no lock
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_on || (size_t)(2 * g_prof_n + 1) >= g_prof_ev.size()) return false;
   *start = g_prof_ev[2 * g_prof_n];
   *stop = g_prof_ev[2 * g_prof_n + 1];
@@ -60,6 +65,7 @@ bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop) {
   return true;
 }
 extern "C" int rarc_profile_begin(int max_launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   RARC_REQUIRE(max_launches > 0 && max_launches <= 65536 && !g_prof_on, RARC_E_INVALID, "rarc_profile_begin: bad state");
   g_prof_ev.resize((size_t)2 * max_launches);
   for (auto& e : g_prof_ev) RARC_HIP_CHECK(hipEventCreate(&e));
@@ -68,6 +74,7 @@ extern "C" int rarc_profile_begin(int max_launches) {
   return RARC_OK;
 }
 extern "C" int rarc_profile_end(double* total_scan_ms, int* n_launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   RARC_REQUIRE(g_prof_on && total_scan_ms && n_launches, RARC_E_INVALID, "rarc_profile_end: not profiling");
   double tot = 0;
   for (int i = 0; i < g_prof_n; ++i) {

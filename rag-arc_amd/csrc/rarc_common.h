@@ -305,6 +305,17 @@ void rarc_set_error(const char* fmt, ...);
       return RARC_E_HIP;                                                                  \
     }                                                                                     \
   } while (0)
+// hipFuncSetAttribute applies to the CURRENT device: a "done" flag is kept per (call site, device), so a process
+// that drives several GPUs sets the attribute once on each (racing threads at worst set it twice: harmless).
+struct RarcPerDevice {
+  size_t v[64] = {};
+  size_t& cur() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return v[(d < 0 ? 0 : d) & 63];
+  }
+};
+
 #define RARC_REQUIRE(cond, code, ...)  \
   do {                                 \
     if (!(cond)) {                     \

@@ -601,11 +601,11 @@ bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop);  // rarc_api.hip
 template <int D>
 static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
   constexpr size_t lds = ScanLds<D>::TOTAL;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static RarcPerDevice attr_done;
+  if (size_t& done = attr_done.cur(); !done) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_f16_kernel<D>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    done = 1;
   }
   hipEvent_t e0, e1;
   const bool prof = rarc_prof_next(&e0, &e1);

@@ -560,11 +560,11 @@ int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t
 template <int D, int FMT>
 static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
   constexpr size_t lds = ScanQ8Lds<D>::TOTAL;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static RarcPerDevice attr_done;
+  if (size_t& done = attr_done.cur(); !done) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, FMT>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done = true;
+    done = 1;
   }
   hipEvent_t e0, e1;
   const bool prof = rarc_prof_next(&e0, &e1);

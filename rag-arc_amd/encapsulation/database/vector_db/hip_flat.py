@@ -218,13 +218,15 @@ class HipFlatVectorStore(VectorStore):
         """Flat shard file (64-byte header, raw rows — mmap-able —, then the row scales for fp8 storage)
         + pickled docstore; cf. VectorStore_Faiss.py:432-450."""
         os.makedirs(folder_path, exist_ok=True)
+        shard = os.path.join(folder_path, f"{index_name}.rarc")
         if self.index is not None and self.index.ntotal:
             rows = self.index.rows
             rows = rows.cpu().numpy() if hasattr(rows, "cpu") else np.asarray(rows)
             f8 = self.storage == "f8"
             rows = np.ascontiguousarray(rows).view(np.uint8 if f8 else np.float16)
             header = np.array([0x43524152, 2, rows.shape[0], self.index.dim, rows.shape[1], 1 if f8 else 0], dtype=np.int64)
-            with open(os.path.join(folder_path, f"{index_name}.rarc"), "wb") as fh:
+            tmp = shard + ".tmp"          # written aside and renamed: a crash never leaves a header without its rows
+            with open(tmp, "wb") as fh:
                 fh.write(header.tobytes())
                 fh.write(np.float32(self.index.max_norm).tobytes())
                 fh.write(b"\0" * (64 - header.nbytes - 4))
@@ -233,6 +235,11 @@ class HipFlatVectorStore(VectorStore):
                     sc = self.index.row_scales
                     sc = sc.cpu().numpy() if hasattr(sc, "cpu") else np.asarray(sc)
                     fh.write(np.ascontiguousarray(sc, dtype=np.float32).tobytes())
+            os.replace(tmp, shard)
+        elif os.path.exists(shard):
+            # the reference always rewrites the index file (VectorStore_Faiss.py:438); an empty index must not
+            # leave the rows of an earlier save behind for load_local to pick up next to an empty docstore
+            os.unlink(shard)
         meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
                 "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2,
                 "storage": self.storage}

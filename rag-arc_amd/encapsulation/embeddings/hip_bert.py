@@ -34,7 +34,10 @@ class HipBertEncoder:
         sd = {k.replace("bert.", "", 1) if k.startswith("bert.") else k: v for k, v in state_dict.items()}
 
         def f16(name):
-            return torch.as_tensor(np.asarray(sd[name]), dtype=torch.float32).to(self.device).half().contiguous()
+            v = sd[name]
+            if isinstance(v, torch.Tensor):          # already a tensor (any device): no numpy round trip
+                return v.detach().to(self.device, torch.float32).half().contiguous()
+            return torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.device).half().contiguous()
 
         self.word = f16("embeddings.word_embeddings.weight")
         self.pos = f16("embeddings.position_embeddings.weight")
@@ -64,12 +67,13 @@ class HipBertEncoder:
         if self.inter % 128:
             raise B.RarcError("intermediate size must be a multiple of 128")
         self.max_pos = int(self.pos.shape[0])
+        self.vocab = int(self.word.shape[0])
         # host-side table of device pointers handed to rarc_enc_forward (tensors above keep the memory alive)
         self._layer_tab = (B.EncLayer * len(self.layers))(*[
             B.EncLayer(**{k: v.data_ptr() for k, v in w.items()}) for w in self.layers])
         self._model = B.EncModel(self.hidden, self.heads, self.inter, len(self.layers), self.eps, self.word.data_ptr(),
                                  self.pos.data_ptr(), self.type0.data_ptr(), self.emb_g.data_ptr(),
-                                 self.emb_b.data_ptr(), self._layer_tab)
+                                 self.emb_b.data_ptr(), self._layer_tab, self.vocab, self.max_pos)
         self._ws = None
 
     def forward(self, input_ids, lengths=None, normalize: bool = True):
@@ -81,7 +85,21 @@ class HipBertEncoder:
         if L > self.max_pos or L > 512:
             raise ValueError(f"sequence length {L} exceeds the model limit")
         lens = np.full(n_seq, L, np.int32) if lengths is None else np.asarray(lengths, np.int32)
-        step = 128 // math.gcd(L, 128)                      # GEMM rows (tokens) must be a multiple of 128
+        if n_seq == 0:
+            raise ValueError("empty batch")
+        if lens.shape != (n_seq,) or lens.min() < 1 or lens.max() > L:
+            raise ValueError(f"lengths must be [n_seq] values in [1, {L}]")
+        if ids.min() < 0 or ids.max() >= self.vocab:
+            raise ValueError(f"token ids must lie in [0, {self.vocab}) (got {int(ids.min())}..{int(ids.max())})")
+        # GEMM rows (tokens) must be a multiple of 128: pad the sequence length to a multiple of 32 with masked
+        # tokens (keys >= length are ignored, only position 0 is pooled) and the batch to a multiple of 4 — a
+        # single 7-token query runs 4 x 32 tokens, not 128 sequences.  (Position table too short for the padded
+        # length: pad the batch only.)
+        L32 = -(-L // 32) * 32
+        if L32 != L and L32 <= min(self.max_pos, 512):
+            ids = np.concatenate([ids, np.zeros((n_seq, L32 - L), np.int32)], axis=1)
+            L = L32
+        step = 128 // math.gcd(L, 128)
         n_pad = -(-n_seq // step) * step
         if n_pad != n_seq:
             ids = np.concatenate([ids, np.zeros((n_pad - n_seq, L), np.int32)])

@@ -34,7 +34,7 @@ class EncModel(ctypes.Structure):
     """RarcEncModel (include/rarc.h)."""
     _fields_ = [("hidden", c_int), ("heads", c_int), ("inter", c_int), ("n_layers", c_int), ("ln_eps", c_float),
                 ("word", c_void_p), ("pos", c_void_p), ("type0", c_void_p), ("emb_g", c_void_p), ("emb_b", c_void_p),
-                ("layers", ctypes.POINTER(EncLayer))]
+                ("layers", ctypes.POINTER(EncLayer)), ("vocab", c_int), ("max_pos", c_int)]
 
 
 _lock = threading.Lock()
@@ -81,7 +81,7 @@ SIGNATURES = {
     "rarc_synth_rows_f16": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_uint64, c_void_p]),
     "rarc_synth_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_uint64, c_void_p]),
     "rarc_enc_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,
-                                  c_int, c_void_p, c_void_p]),
+                                  c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rarc_enc_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc_add_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p]),

@@ -327,8 +327,14 @@ class FlatIndexF16:
                 e0 = min(nq, s0 + B.MAX_QUERIES)
                 status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this launch's own words
                 self._search_chunk(q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], repair=False, status=status)
-                parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], status[B.MAX_QUERIES:],
-                                           status[:e0 - s0]))
+                # the batch's one status word goes to pinned host memory behind the search, with an event of its
+                # own: result() waits for THIS batch only, not for whatever was enqueued after it
+                flag_h = t.empty(1, dtype=t.int32, pin_memory=True)
+                flag_h.copy_(status[B.MAX_QUERIES:], non_blocking=True)
+                done = t.cuda.Event()
+                done.record()
+                parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], flag_h,
+                                           status[:e0 - s0], done))
             return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc)
 
     def _repair_rows(self, q, k, out_ids, out_sc, flagged) -> None:
@@ -458,8 +464,9 @@ class FlatIndexF16:
 class PendingSearch:
     """Handle returned by FlatIndexF16.search_async."""
 
-    def __init__(self, index, q, k, ids, scores, flag, status):
+    def __init__(self, index, q, k, ids, scores, flag, status, done=None):
         self.index, self.q, self.k, self.ids, self.scores, self.flag, self.status = index, q, k, ids, scores, flag, status
+        self.done = done        # event recorded behind the copy of the status word into pinned memory (`flag`)
         self.repaired = None
 
     def result(self):
@@ -467,7 +474,9 @@ class PendingSearch:
         if self.repaired is None:
             t = self.index.torch
             self.repaired = []
-            if int(self.flag.item()):  # syncs on this batch only
+            if self.done is not None:
+                self.done.synchronize()   # this batch only: later batches keep running
+            if int(self.flag[0] if self.done is not None else self.flag.item()):
                 self.repaired = t.nonzero(self.status).flatten().tolist()
                 with self.index._lock, t.cuda.device(self.index.device):
                     self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired)

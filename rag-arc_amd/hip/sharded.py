@@ -22,6 +22,12 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(n_total, lo + per)
 
 
+def split_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Items [lo, hi) of a replicated batch that `rank` computes when the batch is split evenly (the online
+    query encoder of BASELINE config 5: each rank embeds its slice, one all-gather rebuilds the batch)."""
+    return shard_range(n_items, rank, world)
+
+
 def pack_results(torch, ids, scores):
     """(ids int64 [nq][k], scores fp32 [nq][k]) -> int32 [nq][k][3] (one collective instead of two)."""
     out = torch.empty(ids.shape + (3,), dtype=torch.int32, device=ids.device)
@@ -51,6 +57,18 @@ class ShardedFlatSearch:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.merge_fn = merge_fn or self._hip_merge
         self.force_collective = force_collective  # run gather + merge even with a single rank (testing)
+        self.exchange_events = None  # measure_exchange(True): [(start, stop)] event pairs around pack/gather/merge
+
+    def measure_exchange(self, on: bool = True) -> None:
+        """Bracket every exchange (pack kernel, all-gather, merge kernel) with a pair of events on the compute
+        stream; exchange_ms() returns the summed time.  Measurement hook for bench.py."""
+        self.exchange_events = [] if on else None
+
+    def exchange_ms(self) -> float:
+        ev = self.exchange_events or []
+        if ev:
+            ev[-1][1].synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in ev))
 
     def _hip_merge(self, ids, scores, k):
         """ids/scores: [G][nq][k] device tensors -> [nq][k] via rarc_topk_merge."""
@@ -87,6 +105,11 @@ class ShardedFlatSearch:
             # device path: one pack kernel, ONE collective, one merge kernel that reads the packed lists
             from . import binding as B
 
+            if self.exchange_events is not None:
+                ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
+                ev[0].record()
+                self.exchange_events.append(ev)
+
             lib = B.load_library()
             nq, kk = ids.shape
             st = t.cuda.current_stream(ids.device).cuda_stream
@@ -101,6 +124,8 @@ class ShardedFlatSearch:
             out_s = t.empty((nq, k), dtype=t.float32, device=ids.device)
             B.check(lib.rarc_topk_merge_packed(gathered.data_ptr(), self.world, nq, kk, out_i.data_ptr(),
                                                out_s.data_ptr(), st), "rarc_topk_merge_packed")
+            if self.exchange_events is not None:
+                self.exchange_events[-1][1].record()
             return out_i, out_s
         mine = pack_results(t, ids, scores)
         # concatenated layout ([world*nq][k][3]) is the form both RCCL and gloo accept

@@ -110,3 +110,32 @@ def test_dense_score_band_large_k(oracle):
     rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(q), k)
     assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
     assert len(idx.last_repaired) == 0
+
+
+def test_dense_score_band_100k_rows(oracle):
+    """90 000 rows whose cosines to one query lie within 0.008 of each other (less than one int8 error bound),
+    k = 100: every one of them has to be rescored canonically, fifteen buffers' worth.  The banded pass must get
+    through all of them (one iteration per band, the width handed on) and return the oracle's answer; if it ever
+    runs out of iterations the query is flagged and repaired — a wrong top-k is never returned silently."""
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(32)
+    n, d, k, m = 400_000, 128, 100, 90_000
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    q = np.zeros((2, d), np.float32)
+    q[0, 0] = 1.0
+    q[1] = rng.standard_normal(d).astype(np.float32)
+    c = rng.uniform(0.800, 0.808, m).astype(np.float32)
+    u = X[:m].copy()
+    u[:, 0] = 0.0
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    X[:m] = c[:, None] * q[0] + np.sqrt(1.0 - c * c)[:, None] * u
+    X = X[rng.permutation(n)]
+    idx = FlatIndexF16(d, scan="q8")
+    idx.add(X)
+    D, I = idx.search(q, k)
+    rows, _ = oracle.ingest_f16(X)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(q), k)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    print("repaired:", idx.last_repaired)

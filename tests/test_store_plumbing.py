@@ -64,6 +64,11 @@ def test_delete_rebuilds_and_persistence_round_trips(tmp_path):
     after = st2.similarity_search_with_score("t10", k=5)
     assert [(d.id, s) for d, s in before] == [(d.id, s) for d, s in after]
     assert st.delete() is True and st.ntotal == 0 and st.similarity_search("t1") == []
+    # an emptied store saved into the same folder must not leave the old shard file behind (the reference rewrites
+    # its index file on every save, VectorStore_Faiss.py:438): load_local then yields an empty, searchable store
+    st.save_local(str(tmp_path))
+    st3 = HipFlatVectorStore.load_local(str(tmp_path), emb, engine_factory=_engine)
+    assert st3.ntotal == 0 and st3.similarity_search("t10") == []
 
 
 def test_multipath_over_dense_and_lexical_lists(store):
