@@ -84,7 +84,9 @@ int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_corpus_f16, in
  * rarc_quant_meta_floats(n_rows) elements, ZEROED by the caller before the first call:
  *   [0]            R = max over stored rows of ||d - d8/s||_2 (the int8 image's residual norm);
  *                  only ever raised, so it stays valid when rows are appended
- *   [1..3]         reserved
+ *   [1]            rho: a bound of ||d - d_scanned|| over all rows when the scan reads a ROUNDED image of the
+ *                  stored rows (fp32 storage, rarc_search_f32: the caller sets it); 0 otherwise
+ *   [2..3]         reserved
  *   [4+2t], [5+2t] scale s_t of the 32-row tile t (127 / max|x| rounded down to fp16) and 1/s_t
  * The call (re)computes the entries of every tile that intersects rows [first_row, n_rows): after
  * appending rows, pass the old row count as first_row.  The corpus buffer must hold ceil32(n_rows)
@@ -206,6 +208,28 @@ int rarc_search_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t
 int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t n_rows, int d_pad,
                    const void* d_qblock, int q, int k, int64_t id_base, int64_t* d_out_ids, float* d_out_scores,
                    uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * fp32 corpus — the reference's own storage (np.float32 rows in IndexFlatIP, VectorStore_Faiss.py:170,199-202):
+ * returned scores are canonical fp32 dots of the fp32 query with the fp32 rows, no storage rounding at all
+ * (what SURVEY.md §8(b) lists as the fp32 variant of rarc_score_topk).  The scan kernels still stream a 2-byte
+ * image: the index holds fp32 rows [ceil32(n)][d_pad] for the rescore AND their fp16 image for the scan (6 bytes per
+ * element); candidates are discarded on the image's int8 scores under a bound that includes the image's rounding.
+ *   rarc_ingest_f32  normalise exactly as rarc_ingest_f16, store the fp32 row (zero padded) and its fp16 image
+ *   metadata         rarc_quant_meta_f16 on the IMAGE; then the caller writes d_qmeta[1] = rho >= max ||d32 - d16||
+ *                    (2^-11 * max||d|| + 2^-25 * sqrt(d_pad) covers normal and subnormal halves)
+ *   rarc_search_f32  int8-prefilter scan of the image + canonical finalize on the fp32 rows
+ *   rarc_repair_f32  exact single-query repair / verification on the fp32 rows
+ */
+int rarc_ingest_f32(const float* d_in, int64_t ld_in, float* d_corpus_f32, uint16_t* d_image_f16, int d_pad,
+                    float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream);
+int rarc_search_f32(const float* d_corpus_f32, const uint16_t* d_image_f16, int64_t n_rows, int d_pad,
+                    const float* d_qmeta, const void* d_qblock, int nq, int k, int kprime, int64_t id_base,
+                    float bin_lo, float bin_hi, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
+                    void* d_workspace, size_t workspace_bytes, int cand_cap, void* stream);
+int rarc_repair_f32(const float* d_corpus_f32, int64_t n_rows, int d_pad, const void* d_qblock, int q, int k,
+                    int64_t id_base, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_found, void* d_workspace,
+                    size_t workspace_bytes, void* stream);
 
 /*
  * Merge G sorted candidate lists per query into the global top-k

@@ -144,6 +144,33 @@ def flat_search_f8(corpus_u8: np.ndarray, scales: np.ndarray, q32: np.ndarray, k
     return ids, sc, int(nt)
 
 
+def ingest_f32(x: np.ndarray, normalize: bool = True, d_pad: int | None = None):
+    """add_texts side for fp32 storage — the reference's own (VectorStore_Faiss.py:170-202: astype(float32),
+    normalize_L2, index.add): returns (fp32 rows [n][d_pad], squared norms [n])."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n, d = x.shape
+    d_pad = d_pad or padded_dim(d)
+    out = np.zeros((n, d_pad), dtype=np.float32)
+    n2 = np.zeros(n, dtype=np.float32)
+    if n:
+        lib().oracle_ingest_f32(_p(x), ctypes.c_int64(d), _p(out), ctypes.c_int(d_pad), _p(n2), ctypes.c_int64(n),
+                                ctypes.c_int(d), ctypes.c_int(1 if normalize else 0))
+    return out, n2
+
+
+def flat_search_f32(corpus_f32: np.ndarray, q32: np.ndarray, k: int, id_base: int = 0):
+    """IndexFlatIP.search over fp32 rows (VectorStore_Faiss.py:262-263): canonical fp32 scores, (score desc, id asc)."""
+    corpus_f32 = np.ascontiguousarray(corpus_f32, dtype=np.float32)
+    n, d_pad = corpus_f32.shape
+    qp = pad_queries(q32, d_pad)
+    nq = qp.shape[0]
+    ids = np.full((nq, k), -1, dtype=np.int64)
+    sc = np.full((nq, k), -np.inf, dtype=np.float32)
+    nt = lib().oracle_flat_search_f32(_p(corpus_f32), ctypes.c_int64(n), ctypes.c_int(d_pad), _p(qp), ctypes.c_int(nq),
+                                      ctypes.c_int(k), ctypes.c_int64(id_base), _p(ids), _p(sc))
+    return ids, sc, int(nt)
+
+
 def pad_queries(q: np.ndarray, d_pad: int) -> np.ndarray:
     q = np.ascontiguousarray(q, dtype=np.float32)
     out = np.zeros((q.shape[0], d_pad), dtype=np.float32)

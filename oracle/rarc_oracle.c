@@ -237,6 +237,83 @@ int oracle_flat_search_f16(const uint16_t* corpus, int64_t n, int d_pad, const f
   return nthreads;
 }
 
+/* ---- fp32 storage: the reference's own (np.float32 rows in IndexFlatIP, VectorStore_Faiss.py:170,199-202) ----
+ * rows are the normalised fp32 vectors themselves (zero padded to d_pad); the canonical score is the same
+ * 8-chain fma order on fp32 x fp32.                                                                          */
+float oracle_canon_dot_f32(const float* q, const float* row, int d) {
+  __m256 acc = _mm256_setzero_ps();
+  for (int m = 0; m < d; m += 8) acc = _mm256_fmadd_ps(_mm256_loadu_ps(q + m), _mm256_loadu_ps(row + m), acc);
+  return tree8(acc);
+}
+void oracle_ingest_f32(const float* in, int64_t ld, float* out, int d_pad, float* norm2, int64_t n, int d, int normalize) {
+#pragma omp parallel for schedule(static)
+  for (int64_t r = 0; r < n; ++r) {
+    const float* v = in + r * ld;
+    float* o = out + r * (int64_t)d_pad;
+    float inv = 1.0f;
+    int scale = 0;
+    if (normalize) {
+      const float nr = canon_sumsq_f32(v, d);
+      if (nr > 0) { inv = (float)(1.0 / sqrtf(nr)); scale = 1; }
+    }
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < d_pad; ++m) {
+      const float f = m < d ? (scale ? v[m] * inv : v[m]) : 0.0f;
+      o[m] = f;
+      a[m & 7] = fmaf(f, f, a[m & 7]);
+    }
+    if (norm2) norm2[r] = ((a[0] + a[4]) + (a[2] + a[6])) + ((a[1] + a[5]) + (a[3] + a[7]));
+  }
+}
+int oracle_flat_search_f32(const float* corpus, int64_t n, int d_pad, const float* q, int nq, int k, int64_t id_base,
+                           int64_t* out_ids, float* out_scores) {
+  int nthreads = 1;
+#ifdef _OPENMP
+  nthreads = omp_get_max_threads();
+#endif
+  if (k < 1 || nq < 1) return nthreads;
+  uint64_t* heaps = (uint64_t*)malloc((size_t)nthreads * nq * k * sizeof(uint64_t));
+  int* hn = (int*)calloc((size_t)nthreads * nq, sizeof(int));
+#pragma omp parallel
+  {
+    int tid = 0;
+#ifdef _OPENMP
+    tid = omp_get_thread_num();
+#endif
+    uint64_t* H = heaps + (size_t)tid * nq * k;
+    int* N = hn + (size_t)tid * nq;
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t r = 0; r < n; ++r) {
+      const float* row = corpus + r * (int64_t)d_pad;
+      for (int qi = 0; qi < nq; ++qi)
+        heap_push(H + (size_t)qi * k, &N[qi], k, candkey(oracle_canon_dot_f32(q + (size_t)qi * d_pad, row, d_pad), (uint32_t)r));
+    }
+  }
+  uint64_t* all = (uint64_t*)malloc((size_t)nthreads * k * sizeof(uint64_t));
+  for (int qi = 0; qi < nq; ++qi) {
+    int c = 0;
+    for (int t = 0; t < nthreads; ++t) {
+      const int m = hn[(size_t)t * nq + qi];
+      memcpy(all + c, heaps + ((size_t)t * nq + qi) * k, (size_t)m * sizeof(uint64_t));
+      c += m;
+    }
+    qsort(all, (size_t)c, sizeof(uint64_t), cmp_desc_u64);
+    for (int i = 0; i < k; ++i) {
+      if (i < c) {
+        out_ids[(size_t)qi * k + i] = id_base + (int64_t)(uint32_t)(~(uint32_t)all[i]);
+        out_scores[(size_t)qi * k + i] = unordkey((uint32_t)(all[i] >> 32));
+      } else {
+        out_ids[(size_t)qi * k + i] = -1;
+        out_scores[(size_t)qi * k + i] = -INFINITY;
+      }
+    }
+  }
+  free(all);
+  free(heaps);
+  free(hn);
+  return nthreads;
+}
+
 /* canonical scores of selected rows (spot checks at sizes where a full search is too slow) */
 void oracle_score_rows_f16(const uint16_t* corpus, int d_pad, const float* qv, const int64_t* rows, int n,
                            float* out) {

@@ -49,7 +49,7 @@ class HipFlatVectorStoreConfig(AbstractConfig):
     metric: Literal["cosine", "ip"] = "cosine"
     normalize_L2: bool = False
     device: int = 0
-    storage: Literal["f16", "f8"] = "f16"  # row storage in HBM: fp16, or fp8 e4m3fn + per-row scale
+    storage: Literal["f16", "f8", "f32"] = "f16"  # rows in HBM: fp16, fp8 e4m3fn + per-row scale, or fp32 (the reference's)
     corpus_path: Optional[str] = None  # .npz with `texts` (and optional `ids`) to ingest at build time
 
     def build(self) -> AbstractModule:

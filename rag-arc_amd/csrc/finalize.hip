@@ -33,6 +33,25 @@ __device__ __forceinline__ float canon_dot_f16(const float* __restrict__ q,
   return rarc_canon_tree(a);
 }
 
+// canonical fp32 dot of a fp32 query with an fp32 row (d multiple of 8): the same 8 chains and tree
+__device__ __forceinline__ float canon_dot_f32(const float* __restrict__ q, const float* __restrict__ row, int d) {
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int m = 0; m < d; m += 8) {
+    const float4 x0 = *(const float4*)(row + m), x1 = *(const float4*)(row + m + 4);
+    const float4 q0 = *(const float4*)(q + m), q1 = *(const float4*)(q + m + 4);
+    a[0] = __builtin_fmaf(q0.x, x0.x, a[0]);
+    a[1] = __builtin_fmaf(q0.y, x0.y, a[1]);
+    a[2] = __builtin_fmaf(q0.z, x0.z, a[2]);
+    a[3] = __builtin_fmaf(q0.w, x0.w, a[3]);
+    a[4] = __builtin_fmaf(q1.x, x1.x, a[4]);
+    a[5] = __builtin_fmaf(q1.y, x1.y, a[5]);
+    a[6] = __builtin_fmaf(q1.z, x1.z, a[6]);
+    a[7] = __builtin_fmaf(q1.w, x1.w, a[7]);
+  }
+  return rarc_canon_tree(a);
+}
+
 // in-LDS bitonic sort, descending, n = power of two, all threads of the block participate
 __device__ __forceinline__ void bitonic_desc(uint64_t* a, int n) {
   for (int k = 2; k <= n; k <<= 1) {
@@ -239,7 +258,7 @@ constexpr int FIN8_MAXD = 1024;
 #endif
 
 struct Fin8Params {
-  const void* corpus;      // fp16 rows (fmt 0) or fp8 rows (fmt 1)
+  const void* corpus;      // the rows the canonical rescore reads: fp16 (fmt 0), fp8 (fmt 1) or fp32 (fmt 2)
   const float* rowscale;   // fmt 1: per-row scales
   int fmt;
   const float* q32;   // [256][d]
@@ -363,7 +382,19 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       __builtin_amdgcn_wave_barrier();
       float acc = 0.f;
       if (cur < to) {
-        if (p.fmt) {  // fp8: element 8m + j is byte 8m + j of the row
+        if (p.fmt == 2) {  // fp32 rows: element 8m + j is the float at byte 32m + 4j
+          const char* rowp = stage + rr * rstride + 4 * j;
+          for (int m0 = 0; m0 < NT * 4; m0 += 16) {  // d = rbytes / 4, a multiple of 128
+            float xs[16], qs[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+              xs[u] = *(const float*)(rowp + 32 * (m0 + u));
+              qs[u] = s_q[8 * (m0 + u) + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(qs[u], xs[u], acc);
+          }
+        } else if (p.fmt) {  // fp8: element 8m + j is byte 8m + j of the row
           const char* rowp = stage + rr * rstride + j;
           for (int m0 = 0; m0 < NT * 16; m0 += 16) {  // d = rbytes
             float xs[16], qs[16];
@@ -395,16 +426,17 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       if (cur < to && j == 0) {
         const uint32_t row = rarc_candrow(ex[cur]);
         float sc = rarc_canon_tree(a8);
-        if (p.fmt) sc = p.rowscale[row] * sc;
+        if (p.fmt == 1) sc = p.rowscale[row] * sc;
         ex[cur] = rarc_candkey(sc, row);
       }
       __builtin_amdgcn_wave_barrier();
     }
   };
   auto rescore = [&](int from, int to) __attribute__((always_inline)) {
-    switch ((p.fmt ? p.d : p.d * 2) / 128) {  // block-uniform
+    switch ((p.fmt == 2 ? p.d * 4 : (p.fmt ? p.d : p.d * 2)) / 128) {  // 128-byte steps per stored row; block-uniform
 #define FIN8_NT(N) case N: rescore_n(std::integral_constant<int, N>{}, from, to); break;
       FIN8_NT(2) FIN8_NT(4) FIN8_NT(6) FIN8_NT(8) FIN8_NT(10) FIN8_NT(12) FIN8_NT(14) FIN8_NT(16)
+      FIN8_NT(20) FIN8_NT(24) FIN8_NT(28) FIN8_NT(32)   // fp32 rows of 640 ... 1024 elements
 #undef FIN8_NT
       default: break;  // the launcher admits only d multiples of 128 (fp16) / 256 (fp8), <= 1024
     }
@@ -589,9 +621,10 @@ int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, 
   p.status = status;
   p.dbg = tighten ? nullptr : g_fin8_dbg;
   p.tighten_thr = tighten ? (uint32_t*)ws.thr : nullptr;
-  // 8 waves stage 8 rows each up to d = 768 (97 KB); wider rows: 4 waves (66 KB at d = 1024)
-  const int threads = (fmt || d_pad <= 768) ? FIN8_THREADS : FIN8_THREADS / 2;
-  const size_t lds = (size_t)(threads / 64) * 8 * ((size_t)d_pad * (fmt ? 1 : 2) + 16);
+  // 8 waves stage 8 rows each up to 1536 bytes per row (97 KB); up to 3072 bytes: 4 waves; fp32 rows of 1024: 2 waves
+  const size_t rbytes = (size_t)d_pad * (fmt == 2 ? 4 : (fmt ? 1 : 2));
+  const int threads = rbytes <= 1536 ? FIN8_THREADS : (rbytes <= 3072 ? FIN8_THREADS / 2 : FIN8_THREADS / 4);
+  const size_t lds = (size_t)(threads / 64) * 8 * (rbytes + 16);
   static RarcPerDevice lds_attr_dev;
   size_t& lds_attr = lds_attr_dev.cur();
   if (lds > lds_attr) {
@@ -631,6 +664,7 @@ __device__ __forceinline__ float canon_dot_f8(const float* __restrict__ q, const
 struct RepairParams {
   const half_t* corpus;
   const uint8_t* corpus8;   // fp8 rows (then corpus is null)
+  const float* corpus32;    // fp32 rows (then corpus and corpus8 are null)
   const float* rowscale;
   const float* qv;  // [d]
   uint32_t n_rows;
@@ -649,7 +683,8 @@ __global__ __launch_bounds__(256) void rarc_repair_scan_kernel(const RepairParam
   const float ks = p.scores[p.k - 1];
   const uint64_t kth = (kid < 0) ? 0ull : rarc_candkey(ks, (uint32_t)(kid - p.id_base));
   for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < p.n_rows; r += gridDim.x * blockDim.x) {
-    const float c = p.corpus8 ? canon_dot_f8(p.qv, p.corpus8 + (size_t)r * p.d, p.d, p.rowscale[r])
+    const float c = p.corpus32 ? canon_dot_f32(p.qv, p.corpus32 + (size_t)r * p.d, p.d)
+                  : p.corpus8 ? canon_dot_f8(p.qv, p.corpus8 + (size_t)r * p.d, p.d, p.rowscale[r])
                               : canon_dot_f16(p.qv, p.corpus + (size_t)r * p.d, p.d);
     const uint64_t key = rarc_candkey(c, r);
     if (key > kth) {
@@ -699,7 +734,8 @@ int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64
                        const RarcWs& ws, int cap, hipStream_t s) {
   RepairParams p;
   p.corpus = fmt ? nullptr : (const half_t*)corpus;
-  p.corpus8 = fmt ? (const uint8_t*)corpus : nullptr;
+  p.corpus8 = fmt == 1 ? (const uint8_t*)corpus : nullptr;
+  p.corpus32 = fmt == 2 ? (const float*)corpus : nullptr;
   p.rowscale = rowscale;
   p.qv = qv;
   p.n_rows = (uint32_t)n_rows;

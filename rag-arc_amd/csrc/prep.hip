@@ -84,6 +84,37 @@ __global__ __launch_bounds__(256) void rarc_ingest_kernel(const float* in, int64
   }
 }
 
+// fp32 storage (the reference's own: VectorStore_Faiss.py:170,199-202 keeps fp32): the normalised fp32 row is
+// stored as is (zero padded) and an fp16 image of it feeds the scan kernels; norm2 is that of the fp32 row.
+__global__ __launch_bounds__(256) void rarc_ingest_f32_kernel(const float* in, int64_t ld_in, float* out32, half_t* out16,
+                                                              int d_pad, float* row_norm2, int64_t n_rows, int d,
+                                                              int normalize) {
+  const int lane = threadIdx.x & 63, j = threadIdx.x & 7;
+  const int64_t rows_per_block = blockDim.x / 8;
+  for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < n_rows; r0 += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t r = r0 + threadIdx.x / 8;
+    const bool live = r < n_rows;
+    const float* x = in + (live ? r : 0) * ld_in;
+    float acc = 0.f;
+    if (live && normalize)
+      for (int m = j; m < d; m += 8) acc = __builtin_fmaf(x[m], x[m], acc);
+    const float nr = group8_tree_f32(acc, lane);
+    const float inv = (normalize && nr > 0.f) ? inv_norm(nr) : 1.f;
+    float acc2 = 0.f;
+    if (live) {
+      for (int m = j; m < d_pad; m += 8) {
+        float v = 0.f;
+        if (m < d) v = (normalize && nr > 0.f) ? x[m] * inv : x[m];
+        out32[r * d_pad + m] = v;
+        out16[r * d_pad + m] = (half_t)v;
+        acc2 = __builtin_fmaf(v, v, acc2);
+      }
+    }
+    const float n2 = group8_tree_f32(acc2, lane);
+    if (live && row_norm2 && j == 0) row_norm2[r] = n2;
+  }
+}
+
 // fp8 (e4m3fn + per-row scale) form of the ingest: same normalisation, then scale = max|x| / 448 and
 // byte = encode(x / scale).  8 lanes per row; bit-identical to oracle_ingest_f8.
 __device__ __forceinline__ float group8_max_f32(float v, int lane) {
@@ -217,14 +248,17 @@ __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in,
     hn = (s_red[0][3] + s_red[1][3]) + (s_red[2][3] + s_red[3][3]);
     // fp16 MFMA scores (seed pass): |approx - canonical| <= ||q32 - q16||·||d|| + fp32 accumulation
     const double acc_err = 8.0 * (double)d_pad * 5.9604644775390625e-08;  // 8·d·2^-24
-    const double e = (sqrt(dn) + acc_err * sqrt(qn)) * (double)corpus_max_norm * 1.01 + 1e-30;
+    // fp32 storage: the scans read an fp16 image of rows whose canonical score is taken on the fp32 originals;
+    // qmeta[1] = rho bounds ||d32 - d16|| over all rows, so either approximate scorer is off by ||q||·rho more
+    const double rho_err = (qmeta ? (double)qmeta[1] : 0.0) * sqrt(qn) * 1.0001;
+    const double e = (sqrt(dn) + acc_err * sqrt(qn)) * (double)corpus_max_norm * 1.01 + rho_err + 1e-30;
     eps[r] = live ? (float)e * 1.0001f : 0.f;
     // int8 prefilter (quant.hip): |<q,d> - approx| <= ||q^||·R + ||q - q^||·max||d||, plus the fp32
     // rounding of the canonical score and of the dequantisation
     if (eps8 && qinv) {
       const double R = qmeta ? (double)qmeta[0] : 0.0;
       const double e8 = (sqrt(hn) * R * 1.0001 + sqrt(rn) * (double)corpus_max_norm) * 1.0001 +
-                        (acc_err + 1e-6) * sqrt(qn) * (double)corpus_max_norm + 1e-30;
+                        (acc_err + 1e-6) * sqrt(qn) * (double)corpus_max_norm + rho_err + 1e-30;
       eps8[r] = live ? (float)e8 * 1.0001f : 0.f;
       qinv[r] = qi;
     }
@@ -356,6 +390,17 @@ extern "C" int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_cor
   if (n_rows == 0) return RARC_OK;
   hipLaunchKernelGGL(rarc_ingest_kernel, dim3(grid_for(n_rows, 32)), dim3(256), 0, (hipStream_t)stream, d_in,
                      ld_in, (half_t*)d_corpus_f16, d_pad, d_row_norm2, n_rows, d, normalize);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_ingest_f32(const float* d_in, int64_t ld_in, float* d_corpus_f32, uint16_t* d_image_f16, int d_pad,
+                               float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream) {
+  RARC_REQUIRE(d_in && d_corpus_f32 && d_image_f16 && d > 0 && d_pad >= d && d_pad % 8 == 0 && n_rows >= 0,
+               RARC_E_INVALID, "rarc_ingest_f32: bad arguments");
+  if (n_rows == 0) return RARC_OK;
+  hipLaunchKernelGGL(rarc_ingest_f32_kernel, dim3(grid_for(n_rows, 32)), dim3(256), 0, (hipStream_t)stream, d_in,
+                     ld_in, d_corpus_f32, (half_t*)d_image_f16, d_pad, d_row_norm2, n_rows, d, normalize);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

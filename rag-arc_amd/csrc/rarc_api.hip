@@ -23,7 +23,7 @@ int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, 
 struct Q8Search {
   const void* rows;       // what the finalize rescans: fp16 rows, or fp8 bytes
   const float* rowscale;  // fp8 only
-  int fin_fmt;            // row format of `rows` for the finalize (0 fp16, 1 fp8)
+  int fin_fmt;            // row format of `rows` for the finalize (0 fp16, 1 fp8, 2 fp32)
   int d_pad, nq, k, cap;
   int64_t id_base;
   const float *q32, *eps8;
@@ -204,6 +204,58 @@ extern "C" int rarc_search_f16_shadow(const uint16_t* d_corpus_f16, const int8_t
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
                                  n_wg, d_out_ids, d_out_scores, d_status, s, false);
+}
+
+// ---- fp32 rows (the reference's own storage) + their fp16 image: the scan reads the image, every returned score is
+// the canonical fp32 dot with the fp32 row; the image's rounding is part of the error bounds (qmeta[1], prep.hip)
+extern "C" int rarc_search_f32(const float* d_corpus_f32, const uint16_t* d_image_f16, int64_t n_rows, int d_pad,
+                               const float* d_qmeta, const void* d_qblock, int nq, int k, int kprime, int64_t id_base,
+                               float bin_lo, float bin_hi, int64_t* d_out_ids, float* d_out_scores,
+                               uint32_t* d_status, void* d_workspace, size_t workspace_bytes, int cand_cap,
+                               void* stream) {
+  RARC_REQUIRE(d_qblock && d_qmeta && d_out_ids && d_out_scores && d_status, RARC_E_INVALID,
+               "rarc_search_f32: null pointer");
+  RARC_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll, RARC_E_INVALID,
+               "rarc_search_f32: n_rows=%lld outside [0, 2^32-32)", (long long)n_rows);
+  RARC_REQUIRE((d_corpus_f32 && d_image_f16) || n_rows == 0, RARC_E_INVALID, "rarc_search_f32: null corpus");
+  RARC_REQUIRE(d_pad > 0 && d_pad % RARC_DIM_ALIGN == 0, RARC_E_INVALID, "rarc_search_f32: d_pad=%d", d_pad);
+  RARC_REQUIRE(nq >= 0 && nq <= RARC_MAX_QUERIES, RARC_E_INVALID, "rarc_search_f32: nq=%d outside [0,%d]", nq,
+               RARC_MAX_QUERIES);
+  RARC_REQUIRE(k >= 1 && k <= kprime && kprime <= RARC_MAX_K, RARC_E_INVALID,
+               "rarc_search_f32: need 1 <= k (%d) <= kprime (%d) <= %d", k, kprime, RARC_MAX_K);
+  RARC_REQUIRE(bin_hi > bin_lo, RARC_E_INVALID, "rarc_search_f32: empty histogram range");
+  int rc = check_ws(d_workspace, workspace_bytes, cand_cap, "rarc_search_f32");
+  if (rc) return rc;
+  if (nq == 0) return RARC_OK;
+  const RarcWs ws = rarc_ws_carve(d_workspace);
+  const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
+  hipStream_t s = (hipStream_t)stream;
+  int n_wg = 0;
+  Q8Search a{d_corpus_f32, nullptr, 2, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
+             d_status, s};
+  rc = rarc_scan_q8_launch(d_image_f16, nullptr, 0, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16, qb.eps8,
+                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a);
+  if (rc) return rc;
+  return rarc_finalize_q8_launch(d_corpus_f32, nullptr, 2, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap, n_wg,
+                                 d_out_ids, d_out_scores, d_status, s, false);
+}
+
+extern "C" int rarc_repair_f32(const float* d_corpus_f32, int64_t n_rows, int d_pad, const void* d_qblock, int q, int k,
+                               int64_t id_base, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_found,
+                               void* d_workspace, size_t workspace_bytes, void* stream) {
+  RARC_REQUIRE(d_corpus_f32 && d_qblock && d_out_ids && d_out_scores && d_found, RARC_E_INVALID,
+               "rarc_repair_f32: null pointer");
+  RARC_REQUIRE(q >= 0 && q < RARC_MAX_QUERIES && k >= 1 && k <= RARC_MAX_K && d_pad > 0 &&
+                   d_pad % RARC_DIM_ALIGN == 0 && n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll,
+               RARC_E_INVALID, "rarc_repair_f32: bad arguments (q=%d k=%d)", q, k);
+  int rc = check_ws(d_workspace, workspace_bytes, 4096, "rarc_repair_f32");
+  if (rc) return rc;
+  const int cap = (int)((workspace_bytes - RARC_WS_CAND) / 8);
+  const RarcWs ws = rarc_ws_carve(d_workspace);
+  const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
+  return rarc_repair_launch(d_corpus_f32, nullptr, 2, n_rows, d_pad, qb.q32 + (size_t)q * d_pad, k, id_base,
+                            d_out_ids + (size_t)q * k, d_out_scores + (size_t)q * k, d_found, ws, cap,
+                            (hipStream_t)stream);
 }
 
 // ---- fp8 (e4m3fn + per-row scale) corpus: BASELINE config 5's storage --------------------------------

@@ -48,9 +48,11 @@ class HipFlatVectorStore(VectorStore):
     def __init__(self, embedding, metric: str = "cosine", normalize_L2: bool = False, index_type: str = "flat",
                  device: int = 0, engine_factory: Optional[Callable] = None, storage: str = "f16", **kwargs: Any):
         super().__init__(**kwargs)
-        if storage not in ("f16", "f8"):
+        if storage not in ("f16", "f8", "f32"):
             raise ValueError(f"unsupported row storage: {storage}")
-        self.storage = storage  # "f16", or "f8": e4m3fn bytes + one scale per row (half the HBM footprint)
+        # "f16"; "f8": e4m3fn bytes + one scale per row (half the HBM footprint); "f32": the reference's own fp32
+        # rows (VectorStore_Faiss.py:170) — returned scores carry no storage rounding
+        self.storage = storage
         if index_type != "flat":
             raise ValueError(f"unsupported index type: {index_type} (exact flat scan only)")
         if metric not in ("cosine", "ip"):
@@ -223,8 +225,9 @@ class HipFlatVectorStore(VectorStore):
             rows = self.index.rows
             rows = rows.cpu().numpy() if hasattr(rows, "cpu") else np.asarray(rows)
             f8 = self.storage == "f8"
-            rows = np.ascontiguousarray(rows).view(np.uint8 if f8 else np.float16)
-            header = np.array([0x43524152, 2, rows.shape[0], self.index.dim, rows.shape[1], 1 if f8 else 0], dtype=np.int64)
+            code = {"f16": 0, "f8": 1, "f32": 2}[self.storage]
+            rows = np.ascontiguousarray(rows).view({0: np.float16, 1: np.uint8, 2: np.float32}[code])
+            header = np.array([0x43524152, 2, rows.shape[0], self.index.dim, rows.shape[1], code], dtype=np.int64)
             tmp = shard + ".tmp"          # written aside and renamed: a crash never leaves a header without its rows
             with open(tmp, "wb") as fh:
                 fh.write(header.tobytes())
@@ -260,11 +263,14 @@ class HipFlatVectorStore(VectorStore):
             if header[0] != 0x43524152 or header[1] not in (1, 2):
                 raise ValueError(f"{path}: not a rarc shard file")
             n, dim, d_pad = int(header[2]), int(header[3]), int(header[4])
-            f8 = header[1] == 2 and int(header[5]) == 1
-            if f8 != (store.storage == "f8"):
-                raise ValueError(f"{path}: stored as {'fp8' if f8 else 'fp16'}, store configured for {store.storage}")
+            code = int(header[5]) if header[1] == 2 else 0
+            f8 = code == 1
+            stored = {0: "f16", 1: "f8", 2: "f32"}.get(code)
+            if stored != store.storage:
+                raise ValueError(f"{path}: stored as {stored}, store configured for {store.storage}")
             max_norm = float(np.fromfile(path, dtype=np.float32, count=1, offset=48 if header[1] == 2 else 40)[0])
-            rows = np.memmap(path, dtype=np.uint8 if f8 else np.float16, mode="r", offset=64, shape=(n, d_pad))
+            rows = np.memmap(path, dtype={0: np.float16, 1: np.uint8, 2: np.float32}[code], mode="r", offset=64,
+                             shape=(n, d_pad))
             scales = np.fromfile(path, dtype=np.float32, count=n, offset=64 + n * d_pad) if f8 else None
             store.index = store._make_engine(dim)
             store.index.load_rows(rows, max_norm, row_scales=scales)

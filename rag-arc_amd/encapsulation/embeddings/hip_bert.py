@@ -120,6 +120,30 @@ class HipBertEncoder:
             return out[:n_seq]
 
 
+    def forward_device(self, d_ids, d_lens, normalize: bool = True):
+        """forward() for token ids that are already on the device: int32 tensors [n_seq][seq_len] and [n_seq]
+        with n_seq * seq_len a multiple of 128.  Nothing is copied or read back, so nothing is validated on the
+        host: ids and lengths are the caller's responsibility (the kernels clamp them into range)."""
+        t = self.torch
+        if d_ids.dtype != t.int32 or d_lens.dtype != t.int32 or d_ids.ndim != 2 or not d_ids.is_cuda:
+            raise ValueError("forward_device takes int32 device tensors [n_seq][seq_len], [n_seq]")
+        n_seq, L = d_ids.shape
+        M = n_seq * L
+        if M == 0 or M % 128 or L > min(self.max_pos, 512) or d_lens.shape != (n_seq,):
+            raise ValueError("n_seq * seq_len must be a positive multiple of 128 and seq_len within the position table")
+        with t.cuda.device(self.device):
+            st = t.cuda.current_stream(self.device).cuda_stream
+            need = int(self.lib.rarc_enc_workspace_bytes(self.hidden, self.inter, M))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = t.empty(need, dtype=t.uint8, device=self.device)
+            out = t.empty((n_seq, self.hidden), dtype=t.float32, device=self.device)
+            B.check(self.lib.rarc_enc_forward(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
+                                              d_lens.contiguous().data_ptr(), n_seq, L, 1 if normalize else 0,
+                                              self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), st),
+                    "rarc_enc_forward")
+            return out
+
+
 class HipBertEmbeddings(Embeddings):
     """Embeddings provider: tokenizer callable + HipBertEncoder."""
 

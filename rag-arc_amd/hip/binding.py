@@ -63,6 +63,12 @@ SIGNATURES = {
     "rarc_search_f16_shadow": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                        c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                        c_int, c_void_p]),
+    "rarc_ingest_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rarc_search_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_int, c_void_p]),
+    "rarc_repair_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "rarc_padded_dim_f8": (c_int, [c_int]),
     "rarc_ingest_f8": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rarc_quant_meta_floats_f8": (c_size_t, [c_int64]),

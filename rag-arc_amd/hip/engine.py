@@ -41,17 +41,20 @@ class FlatIndexF16:
             raise ValueError(f"unsupported metric: {metric}")
         if dim <= 0:
             raise ValueError("dim must be positive")
-        if storage not in ("f16", "f8"):
+        if storage not in ("f16", "f8", "f32"):
             raise ValueError(f"unknown storage format: {storage}")
         self.torch = _torch()
         self.lib = B.load_library()
         self.dim = int(dim)
-        self.storage = storage  # "f16": fp16 rows; "f8": e4m3fn bytes + one fp32 scale per row (BASELINE config 5)
+        # "f16": fp16 rows; "f8": e4m3fn bytes + one fp32 scale per row (BASELINE config 5); "f32": the reference's
+        # own storage (fp32 rows, VectorStore_Faiss.py:170) — scores carry no storage rounding; an fp16 image of
+        # the rows feeds the scan (6 bytes per element in HBM)
+        self.storage = storage
         self.d_pad = B.padded_dim(self.dim, 256 if storage == "f8" else B.DIM_ALIGN)
         if scan not in ("auto", "q8", "mfma16"):
             raise ValueError(f"unknown scan mode: {scan}")
-        if storage == "f8" and scan == "mfma16":
-            raise ValueError("fp8 rows are scanned by the int8-prefilter kernel only")
+        if storage in ("f8", "f32") and scan == "mfma16":
+            raise ValueError("fp8 / fp32 rows are scanned by the int8-prefilter kernel only")
         limit = 768 if scan == "mfma16" else 1024
         if self.d_pad > limit:
             raise B.RarcError(f"dim {dim} pads to {self.d_pad} > {limit}: not supported by the {scan} scan kernel")
@@ -73,6 +76,7 @@ class FlatIndexF16:
         self._shadow = None  # torch.int8 [capacity][d_pad]
         self._rows = None  # torch.float16 (or uint8 for fp8 storage) [capacity][d_pad]
         self._rowscale = None  # fp8 storage: torch.float32 [capacity]
+        self._image16 = None   # fp32 storage: torch.float16 [capacity][d_pad], what the scan kernels read
         self._qmeta = None  # torch.float32 [4 + 2*capacity/32]: quantisation metadata (include/rarc.h)
         self._lock = threading.Lock()  # callers may be pool threads (core/retrieval/base.py:92-96)
         self._ws = None
@@ -101,10 +105,16 @@ class FlatIndexF16:
             if self._rowscale is not None and self.ntotal:
                 ns[: self.ntotal].copy_(self._rowscale[: self.ntotal])
             self._rowscale = ns
+        if self.storage == "f32":
+            ni = t.zeros((cap, self.d_pad), dtype=t.float16, device=self.device)
+            if self._image16 is not None and self.ntotal:
+                ni[: self.ntotal].copy_(self._image16[: self.ntotal])
+            self._image16 = ni
         self._fit_qmeta()
 
     def _row_dtype(self):
-        return self.torch.uint8 if self.storage == "f8" else self.torch.float16
+        t = self.torch
+        return {"f8": t.uint8, "f16": t.float16, "f32": t.float32}[self.storage]
 
     def _fit_qmeta(self) -> None:
         """Size the quantisation metadata for the current row buffer (keeps what is already there)."""
@@ -124,6 +134,12 @@ class FlatIndexF16:
             B.check(self.lib.rarc_quant_meta_f8(self._rows.data_ptr(), self._rowscale.data_ptr(), self.ntotal, self.d_pad,
                                                 int(first_row), self._qmeta.data_ptr(), self._stream()),
                     "rarc_quant_meta_f8")
+            return
+        if self.storage == "f32":
+            B.check(self.lib.rarc_quant_meta_f16(self._image16.data_ptr(), self.ntotal, self.d_pad, int(first_row),
+                                                 self._qmeta.data_ptr(), self._stream()), "rarc_quant_meta_f16")
+            # qmeta[1] = rho >= max ||d32 - d16||: 2^-11 relative per normal half, 2^-25 absolute per subnormal one
+            self._qmeta[1] = float(self.max_norm) * 2.0 ** -11 * 1.001 + 2.0 ** -25 * float(self.d_pad) ** 0.5
             return
         if self.shadow:
             t = self.torch
@@ -165,7 +181,7 @@ class FlatIndexF16:
     AUTO_Q8_ROWS = 1_500_000
 
     def _use_q8(self, k: int = 100) -> bool:
-        if self.storage == "f8" or self.shadow:
+        if self.storage in ("f8", "f32") or self.shadow:
             return True
         if self.scan == "auto":
             if self.d_pad > 768 or k > 900:   # the fp16 scan stops at 768 dims; its k' <= 1024 certificate gives out near k = 1000
@@ -212,6 +228,12 @@ class FlatIndexF16:
                                                 norm2.data_ptr(), n, self.dim,
                                                 1 if self.metric == "cosine" else 0, self._stream()),
                         "rarc_ingest_f8")
+            elif self.storage == "f32":
+                B.check(self.lib.rarc_ingest_f32(x.data_ptr(), x.shape[1], dst.data_ptr(),
+                                                 self._image16[self.ntotal: self.ntotal + n].data_ptr(), self.d_pad,
+                                                 norm2.data_ptr(), n, self.dim,
+                                                 1 if self.metric == "cosine" else 0, self._stream()),
+                        "rarc_ingest_f32")
             else:
                 B.check(self.lib.rarc_ingest_f16(x.data_ptr(), x.shape[1], dst.data_ptr(), self.d_pad,
                                                  norm2.data_ptr(), n, self.dim,
@@ -263,6 +285,8 @@ class FlatIndexF16:
                 self._rows[self.ntotal + s: self.ntotal + s + chunk.shape[0]].copy_(chunk)
             if row_scales is not None:
                 self._rowscale[self.ntotal: self.ntotal + n].copy_(t.from_numpy(np.array(row_scales, dtype=np.float32, copy=True)))
+            if self.storage == "f32":   # the scan's image: the rows rounded to fp16 (round to nearest even)
+                self._image16[self.ntotal: self.ntotal + n].copy_(self._rows[self.ntotal: self.ntotal + n])
             old = self.ntotal
             self.ntotal += n
             self.max_norm = max(self.max_norm, float(max_norm))
@@ -355,6 +379,12 @@ class FlatIndexF16:
                                             kp, self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self._cap_eff, stream),
                     "rarc_search_f8")
+        elif self.storage == "f32":
+            img = self._image16.data_ptr() if self._image16 is not None else 0
+            B.check(self.lib.rarc_search_f32(rows_ptr, img, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k,
+                                             kp, self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
+                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self._cap_eff, stream),
+                    "rarc_search_f32")
         elif self.shadow and qm and self._shadow is not None:
             B.check(self.lib.rarc_search_f16_shadow(rows_ptr, self._shadow.data_ptr(), self.ntotal, self.d_pad, qm,
                                                     b["qblock"].data_ptr(), nq, k, kp, self.id_base, lo, hi,
@@ -374,6 +404,10 @@ class FlatIndexF16:
                                             b["qblock"].data_ptr(), qi, k, self.id_base, out_ids.data_ptr(),
                                             out_sc.data_ptr(), b["found"].data_ptr(), ws.data_ptr(), ws.numel(), stream),
                     "rarc_repair_f8")
+        elif self.storage == "f32":
+            B.check(self.lib.rarc_repair_f32(self._rows.data_ptr(), self.ntotal, self.d_pad, b["qblock"].data_ptr(), qi, k,
+                                             self.id_base, out_ids.data_ptr(), out_sc.data_ptr(), b["found"].data_ptr(),
+                                             ws.data_ptr(), ws.numel(), stream), "rarc_repair_f32")
         else:
             B.check(self.lib.rarc_repair_f16(self._rows.data_ptr(), self.ntotal, self.d_pad, b["qblock"].data_ptr(), qi, k,
                                              self.id_base, out_ids.data_ptr(), out_sc.data_ptr(), b["found"].data_ptr(),

@@ -13,6 +13,9 @@ Pinned here:
   relevance.json  VectorStore.similarity_search_with_relevance_scores + score fns
                                                               VectorStoreBase.py:263-273, :347-392
   cosine.json     spliter.cosine_similarity (numpy branch)    core/file_management/chunker/spliter.py:307-332
+  cosine_pin_d384.npz, cosine_pin_d768.npz
+                  the same function on 64 x 4096 fp16-representable vectors (inputs: tests/helpers.py:pin_inputs):
+                  the reference's float64 cosine matrix — the tight pin of the flat-search arithmetic
 """
 import asyncio
 import json
@@ -218,6 +221,18 @@ def main():
                "Y_f16_bits": Y.astype(np.float16).view(np.uint16).tolist(),
                "cos_hex": [[hexf(v) for v in row] for row in np.asarray(S, dtype=np.float64)]},
               open(os.path.join(OUT, "cosine.json"), "w"), indent=0)
+    # ------------------------------------------------------------------ flat-search pin (float64, 64 x 4096)
+    # fp16-representable inputs, so every storage format of the build holds them exactly (raw inner product) and
+    # the reference's float64 numbers are the one true answer for all of them.  Stored: the full cosine matrix
+    # as the reference returned it (float64), nothing derived.
+    sys.path.insert(0, os.path.dirname(OUT))                       # tests/  (helpers)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))      # repo root (helpers imports the oracle package)
+    from tests.helpers import PIN_SHAPES, pin_inputs
+    for d, nq, n, _seed in PIN_SHAPES:
+        Xp, Yp = pin_inputs(d)
+        Sp = np.asarray(spliter.cosine_similarity(Xp.astype(np.float64), Yp.astype(np.float64)), dtype=np.float64)
+        assert Sp.shape == (nq, n)
+        np.savez_compressed(os.path.join(OUT, f"cosine_pin_d{d}.npz"), cos=Sp)
     print("golden vectors written to", OUT)
 
 

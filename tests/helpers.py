@@ -17,6 +17,63 @@ from rag_arc_amd.encapsulation.embeddings.base import Embeddings
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def fp16_grid_matrix(n: int, d: int, seed: int) -> np.ndarray:
+    """Deterministic [n][d] float32 matrix whose every entry is exactly representable in fp16 (and so in fp32 and
+    float64): a bell-shaped sum of four hashed bytes on a grid of 1/128, |v| < 4.  Pure numpy integer arithmetic
+    (splitmix64), so the golden generator (tests/golden/make_golden.py, which feeds these very numbers to the
+    reference) and the tests build identical inputs without storing them."""
+    with np.errstate(over="ignore"):
+        base = np.array([seed], dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)   # wraps mod 2^64
+        z = np.arange(n * d, dtype=np.uint64) + base + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    v = ((z & np.uint64(0xFF)) + ((z >> np.uint64(8)) & np.uint64(0xFF)) + ((z >> np.uint64(16)) & np.uint64(0xFF))
+         + ((z >> np.uint64(24)) & np.uint64(0xFF))).astype(np.int64) - 510
+    out = (v.astype(np.float32) / np.float32(128.0)).reshape(n, d)
+    assert np.array_equal(out.astype(np.float16).astype(np.float32), out)
+    return out
+
+
+PIN_SHAPES = ((384, 64, 4096, 11), (768, 64, 4096, 12))   # (d, queries, rows, seed) of tests/golden/cosine_pin_d*.npz
+
+
+def pin_inputs(d: int):
+    """(X queries, Y rows) of the flat-search pin for dimension d."""
+    dd, nq, n, seed = next(sh for sh in PIN_SHAPES if sh[0] == d)
+    return fp16_grid_matrix(nq, dd, seed), fp16_grid_matrix(n, dd, seed + 100)
+
+
+def pin_reference(d: int):
+    """The reference's float64 cosine matrix for pin_inputs(d) plus what follows from it: float64 norms, the raw
+    inner products cos * |x| * |y|, and per query the ranking by either."""
+    X, Y = pin_inputs(d)
+    cos = np.load(os.path.join(GOLDEN, f"cosine_pin_d{d}.npz"))["cos"]
+    xn, yn = np.linalg.norm(X.astype(np.float64), axis=1), np.linalg.norm(Y.astype(np.float64), axis=1)
+    return X, Y, cos, xn, yn
+
+
+def check_against_pin(ref_scores: np.ndarray, got_ids: np.ndarray, got_scores: np.ndarray, tol: float = 1e-5):
+    """ref_scores: float64 [nq][n] (the reference's numbers); got: top-k of some implementation, scores already in
+    the same unit.  Every returned score within `tol` of the reference's number for that row; the returned SET
+    equals the reference's top-k wherever its k/k+1 gap exceeds `tol`; the ORDER too wherever all the gaps do.
+    Returns (max |delta|, queries set-checked, queries order-checked)."""
+    nq, k = got_ids.shape
+    worst, n_set, n_ord = 0.0, 0, 0
+    for b in range(nq):
+        order = np.lexsort((np.arange(ref_scores.shape[1]), -ref_scores[b]))
+        top = ref_scores[b][order[: k + 1]]
+        worst = max(worst, float(np.max(np.abs(ref_scores[b][got_ids[b]] - got_scores[b].astype(np.float64)))))
+        if k == ref_scores.shape[1] or top[k - 1] - top[k] > tol:
+            n_set += 1
+            assert set(got_ids[b].tolist()) == set(order[:k].tolist()), f"query {b}: top-{k} set differs"
+        if np.min(top[:-1] - top[1:]) > tol / 5:
+            n_ord += 1
+            assert got_ids[b].tolist() == order[:k].tolist(), f"query {b}: top-{k} order differs"
+    assert worst < tol, f"max |score - reference| = {worst}"
+    return worst, n_set, n_ord
+
+
 def golden(name):
     with open(os.path.join(GOLDEN, name)) as fh:
         return json.load(fh)

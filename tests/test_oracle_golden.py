@@ -127,3 +127,41 @@ def test_bert_oracle_matches_transformers(oracle):
         want = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(att)).last_hidden_state[:, 0].numpy()
     got = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=False)
     assert np.max(np.abs(got - want)) < 2e-5
+
+
+# ---- tight pin of the flat-search arithmetic: the reference's float64 numbers on 64 x 4096 vectors ---------------
+import pytest
+
+
+@pytest.mark.parametrize("d", [384, 768])
+def test_flat_search_pinned_to_reference_float64(oracle, d):
+    """spliter.cosine_similarity (the reference's own float64 numpy arithmetic, spliter.py:326-332) run on 64 x 4096
+    fp16-representable vectors (tests/golden/cosine_pin_d*.npz).  The inputs are exact in every storage format, so:
+    raw inner product over fp16 rows / float64 norms, and cosine over fp32 rows (normalise -> search, exactly the
+    reference's VectorStore_Faiss call sequence), must both land within 1e-5 of the reference's numbers, with the
+    reference's own top-100 wherever its gaps exceed the tolerance."""
+    from tests.helpers import check_against_pin, pin_reference
+
+    X, Y, cos, xn, yn = pin_reference(d)
+    # (a) metric "ip", fp16 storage: rows stored as they are (exact), canonical fp32 dot; reference ip = cos*|x|*|y|
+    rows16, _ = oracle.ingest_f16(Y, normalize=False)
+    assert np.array_equal(rows16[:, :d].view(np.float16).astype(np.float32), Y)
+    ids, sc, _ = oracle.flat_search_f16(rows16, X, 100)
+    ip_ref = cos * xn[:, None] * yn[None, :]
+    scale = float(np.max(xn)) * float(np.max(yn))            # compare in cosine units: divide by the norm product
+    for b in range(X.shape[0]):
+        got_cos = sc[b].astype(np.float64) / (xn[b] * yn[ids[b]])
+        assert np.max(np.abs(got_cos - cos[b][ids[b]])) < 1e-5
+    worst, n_set, n_ord = check_against_pin(ip_ref / scale, ids, sc / np.float32(scale), tol=1e-5)
+    assert n_set >= 50 and n_ord >= 10
+    # (b) metric "cosine", fp32 storage: normalise rows and queries in fp32 (faiss.normalize_L2), canonical dot
+    rows32, _ = oracle.ingest_f32(Y, normalize=True)
+    ids2, sc2, _ = oracle.flat_search_f32(rows32, oracle.normalize_L2(X), 100)
+    worst2, n_set2, n_ord2 = check_against_pin(cos, ids2, sc2, tol=1e-5)
+    assert worst2 < 2e-6 and n_set2 >= 50 and n_ord2 >= 10
+    # every pair, not just the top: all 4096 scores per query
+    idsA, scA, _ = oracle.flat_search_f32(rows32, oracle.normalize_L2(X), Y.shape[0])
+    full = np.zeros_like(cos)
+    for b in range(X.shape[0]):
+        full[b, idsA[b]] = scA[b]
+    assert np.max(np.abs(full - cos)) < 2e-6
