@@ -118,6 +118,17 @@ size_t rarc_query_block_bytes(int d_pad);
 int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad, int normalize,
                       float corpus_max_norm, const float* d_qmeta, void* d_qblock, void* stream);
 
+/*
+ * Re-running a search whose first attempt was flagged (RARC_Q_OVERFLOW / RARC_Q_UNCERTAIN): the k-th entry of the
+ * incomplete answer is the canonical score of a real row, hence a lower bound of the true k-th best score.  After
+ * rarc_prep_queries of the flagged queries, rarc_qblock_set_floor stores that bound per query (d_prev_ids /
+ * d_prev_scores: [nq][k], the rows of the first answer that belong to these queries; entries with id < 0 give no
+ * bound) and the next rarc_search_* starts from it instead of from a sample statistic: the candidate lists hold
+ * only rows within one error bound of the final threshold.  rarc_prep_queries resets the bounds to -inf.
+ */
+int rarc_qblock_set_floor(void* d_qblock, int d_pad, const int64_t* d_prev_ids, const float* d_prev_scores, int k,
+                          int nq, void* stream);
+
 /* Bytes of device scratch rarc_search_f16 / rarc_repair_f16 need (256-byte aligned base).
  * After a search, the uint32 at byte offset RARC_WS_ANYFLAG_OFFSET of the workspace is the OR of
  * all d_status words of that search (0 == nothing to repair). */

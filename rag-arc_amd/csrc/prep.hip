@@ -171,7 +171,8 @@ constexpr int PREP_MAX_D = 2048;
 __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in, int64_t ld_in, int nq, int d,
                                                                 int d_pad, int normalize, float corpus_max_norm,
                                                                 const float* qmeta, float* q32, half_t* q16,
-                                                                int8_t* q8, float* eps, float* eps8, float* qinv) {
+                                                                int8_t* q8, float* eps, float* eps8, float* qinv,
+                                                                float* hq, float* floor) {
   __shared__ float row[PREP_MAX_D];
   __shared__ float s_nr;
   __shared__ uint32_t s_amax;
@@ -261,6 +262,10 @@ __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in,
                         (acc_err + 1e-6) * sqrt(qn) * (double)corpus_max_norm + rho_err + 1e-30;
       eps8[r] = live ? (float)e8 * 1.0001f : 0.f;
       qinv[r] = qi;
+      // inside tile t the first term is ||q^||·R_t: the scan raises the query's threshold there by hq·(R − R_t),
+      // with hq rounded DOWN so that the reduced bound still dominates ||q^||·R_t·1.0001 + the rest
+      if (hq) hq[r] = live ? (float)(sqrt(hn) * 0.9999) : 0.f;
+      if (floor) floor[r] = -INFINITY;  // nothing known about the k-th best score yet
     }
   }
 }
@@ -431,7 +436,26 @@ extern "C" int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipLaunchKernelGGL(rarc_prep_queries_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, (hipStream_t)stream,
                      d_in, ld_in, nq, d, d_pad, normalize, corpus_max_norm, d_qmeta, qb.q32, (half_t*)qb.q16,
-                     qb.q8, qb.eps16, qb.eps8, qb.qinv);
+                     qb.q8, qb.eps16, qb.eps8, qb.qinv, qb.hq, qb.floor);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+// floor[q] = the k-th entry of a previous (possibly incomplete) answer for query q: canonical scores of real rows,
+// so the k-th best of them bounds the true k-th best from below (entries with id < 0 carry no information)
+__global__ void rarc_set_floor_kernel(const int64_t* ids, const float* scores, int k, int nq, float* floor) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) floor[q] = ids[(size_t)q * k + k - 1] >= 0 ? scores[(size_t)q * k + k - 1] : -INFINITY;
+}
+extern "C" int rarc_qblock_set_floor(void* d_qblock, int d_pad, const int64_t* d_prev_ids, const float* d_prev_scores,
+                                     int k, int nq, void* stream) {
+  RARC_REQUIRE(d_qblock && d_prev_ids && d_prev_scores && d_pad > 0 && d_pad % RARC_DIM_ALIGN == 0 && k >= 1 && nq >= 0 &&
+                   nq <= RARC_MAX_QUERIES,
+               RARC_E_INVALID, "rarc_qblock_set_floor: bad arguments");
+  if (nq == 0) return RARC_OK;
+  const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
+  hipLaunchKernelGGL(rarc_set_floor_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_prev_ids, d_prev_scores, k, nq,
+                     qb.floor);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

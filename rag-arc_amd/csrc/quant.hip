@@ -10,6 +10,15 @@
 // ingest (index.add, VectorStore_Faiss.py:199-202): one extra streaming pass over the new rows.
 #include "rarc_common.h"
 
+// smallest fp16 value >= v (v >= 0); +inf bits when v exceeds the fp16 range
+__device__ __forceinline__ uint16_t half_bits_round_up(float v) {
+  if (!(v < 65504.f)) return 0x7c00u;
+  half_t h = (half_t)v;  // RNE
+  uint16_t b = __builtin_bit_cast(uint16_t, h);
+  if ((float)h < v) b += 1;  // non-negative: next representable value up
+  return b;
+}
+
 // largest fp16 value <= v (v > 0, finite)
 __device__ __forceinline__ half_t half_round_down(float v) {
   half_t h = (half_t)v;  // RNE
@@ -87,21 +96,24 @@ __global__ __launch_bounds__(256) void rarc_quant_meta_kernel(const uint4* __res
       atomicAdd(&s_res[c / cpr], acc);
     }
     __syncthreads();
-    if (tid < 32) {
-      // ||d - d8/s|| <= sqrt(sum ui^2) / (1024 * s); rounded up
-      const float r = (float)(sqrt((double)s_res[tid]) / (1024.0 * (double)sf) * 1.000001);
-      atomicMax((uint32_t*)meta, __float_as_uint(r));  // non-negative floats order like their bits
-    }
-    if (tid == 0) {
-      meta[RARC_QMETA_HDR + 2 * (size_t)t] = sf;
-      meta[RARC_QMETA_HDR + 2 * (size_t)t + 1] = 1.0f / sf;
+    if (tid < 64) {
+      // ||d - d8/s|| <= sqrt(sum ui^2) / (1024 * s); rounded up.  R_t = the tile's largest (lanes 32-63 mirror 0-31)
+      float r = (float)(sqrt((double)s_res[tid & 31]) / (1024.0 * (double)sf) * 1.000001);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) r = fmaxf(r, __shfl_xor(r, o, 64));
+      if (tid == 0) {
+        atomicMax((uint32_t*)meta, __float_as_uint(r));  // non-negative floats order like their bits
+        float* mt = meta + RARC_QMETA_HDR + RARC_QMETA_STRIDE * (size_t)t;
+        mt[0] = rarc_tmeta_pack(__builtin_bit_cast(uint16_t, s), half_bits_round_up(r));
+        mt[1] = 1.0f / sf;
+      }
     }
     __syncthreads();
   }
 }
 
 extern "C" size_t rarc_quant_meta_floats(int64_t n_rows) {
-  return (size_t)RARC_QMETA_HDR + 2 * (size_t)((n_rows + 31) / 32);
+  return (size_t)RARC_QMETA_HDR + (size_t)RARC_QMETA_STRIDE * (size_t)((n_rows + 31) / 32);
 }
 
 extern "C" int rarc_quant_meta_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, int64_t first_row,
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(256) void rarc_quant_meta_f8_kernel(const uint4* __
                                                                  uint32_t n_rows, uint32_t first_tile,
                                                                  uint32_t n_tiles, float* __restrict__ meta) {
   __shared__ float s_rowmax[32];
+  __shared__ float s_rowres[32];
   __shared__ float s_tmax;
   const int tid = threadIdx.x, lane = tid & 63, j = tid & 7, rr = tid >> 3;  // 32 rows x 8 lanes
   const int cpr = d_pad / 16;  // 16-byte chunks per row
@@ -231,22 +244,30 @@ __global__ __launch_bounds__(256) void rarc_quant_meta_f8_kernel(const uint4* __
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    if (j == 0 && row < n_rows) {
-      const double xn = (double)rs * sqrt(vsq);  // ||x||
-      double res;
-      if (mulq > 0.f) {
-        const double delta = 1.0 - (double)mulq / ((double)rs * (double)sf);  // in [0, 2^-10]
-        res = sqrt((double)acc) / (1024.0 * (double)sf) + (delta > 0 ? delta : 0.0) * xn;
-      } else {
-        res = xn;  // row quantised to zeros
+    if (j == 0) {
+      float resf = 0.f;
+      if (row < n_rows) {
+        const double xn = (double)rs * sqrt(vsq);  // ||x||
+        double res;
+        if (mulq > 0.f) {
+          const double delta = 1.0 - (double)mulq / ((double)rs * (double)sf);  // in [0, 2^-10]
+          res = sqrt((double)acc) / (1024.0 * (double)sf) + (delta > 0 ? delta : 0.0) * xn;
+        } else {
+          res = xn;  // row quantised to zeros
+        }
+        resf = (float)(res * 1.000001) * 1.000001f;
       }
-      atomicMax((uint32_t*)meta, __float_as_uint((float)(res * 1.000001) * 1.000001f));
-      meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t + 2 + rr] = mulq;
+      s_rowres[rr] = resf;
+      meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t + 2 + rr] = row < n_rows ? mulq : 0.f;
     }
-    if (j == 0 && row >= n_rows) meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t + 2 + rr] = 0.f;
+    __syncthreads();
     if (tid == 0) {
-      meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t] = sf;
-      meta[RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t + 1] = 1.0f / sf;
+      float rt = 0.f;
+      for (int i = 0; i < 32; ++i) rt = fmaxf(rt, s_rowres[i]);
+      atomicMax((uint32_t*)meta, __float_as_uint(rt));
+      float* mt = meta + RARC_QMETA_HDR + RARC_QMETA_F8_STRIDE * (size_t)t;
+      mt[0] = rarc_tmeta_pack(__builtin_bit_cast(uint16_t, s), half_bits_round_up(rt));  // (s_t, R_t)
+      mt[1] = 1.0f / sf;
     }
     __syncthreads();
   }
@@ -287,8 +308,8 @@ __global__ __launch_bounds__(256) void rarc_q8_scores_kernel(const uint4* __rest
   const int q = blockIdx.y;
   if (r >= n_rows || q >= nq) return;
   const uint32_t t = r / 32;
-  const half_t s = (half_t)meta[RARC_QMETA_HDR + 2 * (size_t)t];
-  const float tinv = meta[RARC_QMETA_HDR + 2 * (size_t)t + 1];
+  const half_t s = __builtin_bit_cast(half_t, (uint16_t)__float_as_uint(meta[RARC_QMETA_HDR + RARC_QMETA_STRIDE * (size_t)t]));
+  const float tinv = meta[RARC_QMETA_HDR + RARC_QMETA_STRIDE * (size_t)t + 1];
   const uint4* row = corpus + (size_t)r * (d_pad / 8);
   const int8_t* qp = q8 + (size_t)q * d_pad;
   int acc = 0;

@@ -5,7 +5,7 @@
 
 int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq,
                          int kprime, float bin_lo, float bin_hi, const RarcWs& ws, int cap, int* grid_out,
-                         hipStream_t s);
+                         hipStream_t s, const float* floor, const float* floor_eps);
 int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, const float* eps, int nq,
                          int k, int kprime, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
                          int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s);
@@ -13,7 +13,7 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
                         const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
                         const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
                         const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8,
-                        int (*tighten)(void* ctx, int n_wg), void* tighten_ctx);
+                        int (*tighten)(void* ctx, int n_wg), void* tighten_ctx, const float* hq, const float* floor);
 int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
                             const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
                             int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, bool tighten);
@@ -143,13 +143,14 @@ extern "C" int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
     Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
                d_status, s};
     rc = rarc_scan_q8_launch(d_corpus_f16, nullptr, 0, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16,
-                             qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a);
+                             qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor);
     if (rc) return rc;
     return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
                                    n_wg, d_out_ids, d_out_scores, d_status, s, false);
   }
   // fp16 MFMA scan + k' selection + exactness certificate (kept for comparison)
-  rc = rarc_scan_f16_launch(d_corpus_f16, n_rows, d_pad, qb.q16, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s);
+  rc = rarc_scan_f16_launch(d_corpus_f16, n_rows, d_pad, qb.q16, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s,
+                            qb.floor, qb.eps16);
   if (rc) return rc;
   return rarc_finalize_launch(d_corpus_f16, d_pad, qb.q32, qb.eps16, nq, k, kprime, id_base, ws, cand_cap, n_wg,
                               d_out_ids, d_out_scores, d_status, s);
@@ -200,7 +201,7 @@ extern "C" int rarc_search_f16_shadow(const uint16_t* d_corpus_f16, const int8_t
   Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
              d_status, s};
   rc = rarc_scan_q8_launch(d_corpus_f16, nullptr, 2, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16, qb.eps8,
-                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, d_shadow8, q8_tighten, &a);
+                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, d_shadow8, q8_tighten, &a, qb.hq, qb.floor);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
                                  n_wg, d_out_ids, d_out_scores, d_status, s, false);
@@ -234,7 +235,7 @@ extern "C" int rarc_search_f32(const float* d_corpus_f32, const uint16_t* d_imag
   Q8Search a{d_corpus_f32, nullptr, 2, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
              d_status, s};
   rc = rarc_scan_q8_launch(d_image_f16, nullptr, 0, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16, qb.eps8,
-                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a);
+                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f32, nullptr, 2, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap, n_wg,
                                  d_out_ids, d_out_scores, d_status, s, false);
@@ -285,7 +286,7 @@ extern "C" int rarc_search_f8(const uint8_t* d_corpus_f8, const float* d_row_sca
   Q8Search a{d_corpus_f8, d_row_scale, 1, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, &ws, d_out_ids, d_out_scores,
              d_status, s};
   rc = rarc_scan_q8_launch(d_corpus_f8, d_row_scale, 1, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16,
-                           qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a);
+                           qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f8, d_row_scale, 1, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
                                  n_wg, d_out_ids, d_out_scores, d_status, s, false);

@@ -71,7 +71,10 @@ static inline RarcWs rarc_ws_carve(void* base) {
 
 // ---- query block (written by rarc_prep_queries, read by search / repair) ------------------------
 // q32 f32 [256][d_pad] | q16 f16 [256][d_pad] | q8 i8 [256][d_pad] | eps16 f32 [256] | eps8 f32 [256]
-// | qinv f32 [256].  d_pad is a multiple of 128, so every part starts 256-byte aligned.
+// | qinv f32 [256] | hq f32 [256] (||q8/s_q|| rounded down: eps8 shrinks by hq·(R − R_t) inside tile t)
+// | floor f32 [256] (a known lower bound of the query's k-th best canonical score, -inf when there is none:
+// rarc_prep_queries resets it, rarc_qblock_set_floor fills it before a search is re-run).
+// d_pad is a multiple of 128, so every part starts 256-byte aligned.
 struct RarcQb {
   float* q32;
   uint16_t* q16;
@@ -79,8 +82,10 @@ struct RarcQb {
   float* eps16;
   float* eps8;
   float* qinv;
+  float* hq;
+  float* floor;
 };
-static inline size_t rarc_qb_bytes(int d_pad) { return (size_t)RARC_MAX_QUERIES * (size_t)d_pad * 7 + 3 * 1024; }
+static inline size_t rarc_qb_bytes(int d_pad) { return (size_t)RARC_MAX_QUERIES * (size_t)d_pad * 7 + 5 * 1024; }
 static inline RarcQb rarc_qb_carve(const void* base, int d_pad) {
   char* b = (char*)base;
   const size_t n = (size_t)RARC_MAX_QUERIES * (size_t)d_pad;
@@ -91,6 +96,8 @@ static inline RarcQb rarc_qb_carve(const void* base, int d_pad) {
   q.eps16 = (float*)(b + n * 7);
   q.eps8 = (float*)(b + n * 7 + 1024);
   q.qinv = (float*)(b + n * 7 + 2048);
+  q.hq = (float*)(b + n * 7 + 3072);
+  q.floor = (float*)(b + n * 7 + 4096);
   return q;
 }
 
@@ -285,14 +292,21 @@ __device__ __forceinline__ uint4 rarc_quant8_chunk_f8(const uint4 v, const half_
 }
 #endif
 constexpr int RARC_DIM_ALIGN_F8 = 256;  // fp8 rows: 16-byte chunks of 16 values, 512 threads per 32-row tile
-// fp8 quantisation metadata: [0] R, [1..3] reserved, then 34 floats per 32-row tile:
-//   [4 + 34t] s_t, [5 + 34t] 1/s_t, [6 + 34t + r] fp16-representable multiplier of row r of the tile
+// fp8 quantisation metadata: [0] R, [1..3] as below, then 34 floats per 32-row tile:
+//   [4 + 34t] packed (s_t, R_t) word, [5 + 34t] 1/s_t, [6 + 34t + r] fp16-representable multiplier of row r of the tile
 constexpr int RARC_QMETA_F8_STRIDE = 34;
 
 // quantisation metadata (float array owned by the caller, see include/rarc.h):
 //   [0] max over rows of ||d - d8/s||_2 (as float bits, raised by atomicMax)   [1..3] reserved
-//   [4 + 2t], [5 + 2t] : scale s_t of 32-row tile t (an fp16-representable float) and 1/s_t
+//   [4 + 2t] : one 32-bit word: low half = the fp16 bits of the scale s_t of 32-row tile t, high half = the fp16 bits
+//              of R_t, the largest residual norm ||d - d8/s_t|| among the tile's rows, rounded UP (R = max R_t)
+//   [5 + 2t] : 1/s_t (float)
 constexpr int RARC_QMETA_HDR = 4;
+constexpr int RARC_QMETA_STRIDE = 2;
+static inline __host__ __device__ float rarc_tmeta_pack(uint16_t s_half_bits, uint16_t rt_half_bits) {
+  const uint32_t w = ((uint32_t)rt_half_bits << 16) | (uint32_t)s_half_bits;
+  return __builtin_bit_cast(float, w);
+}
 
 // ---- error plumbing (host) ------------------------------------------------------------------
 void rarc_set_error(const char* fmt, ...);

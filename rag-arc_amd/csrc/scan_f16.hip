@@ -457,7 +457,8 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
                                                             uint32_t nq, float bin_lo_dflt, float bin_hi_dflt,
                                                             const float* sub_a, const float* sub_b,
                                                             uint32_t* thr, float* binlo, float* binscale,
-                                                            float* bininv, uint32_t* flags, uint32_t* hist) {
+                                                            float* bininv, uint32_t* flags, uint32_t* hist,
+                                                            const float* floor, const float* floor_eps) {
   constexpr int LIST = 4096;
   __shared__ uint32_t s_hist[2048];
   __shared__ uint32_t s_list[LIST];
@@ -554,6 +555,13 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
   }
   if (tid == 0) {
     float lo = bin_lo_dflt, hi = bin_hi_dflt;
+    // a re-run search knows a lower bound of the k-th best canonical score from its first attempt (the k-th entry of
+    // the incomplete answer): far better than anything a sample can give
+    if (floor && q < nq) {
+      // (floor_eps: the scorer's own error bound when no sub_a / sub_b is taken off below — the fp16 scan)
+      const float f = floor[q] - (floor_eps ? floor_eps[q] * 1.0001f : 0.f);
+      if (f > t) t = f - (fabsf(f) * 1e-6f + 1e-30f);
+    }
     if (q >= nq) t = INFINITY;  // padding queries never pass
     else if (t > -INFINITY) {
       // int8 prefilter: the threshold lives in approx-score space, below the sample statistic by the
@@ -561,8 +569,8 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
       float ts = t;
       if (sub_a) ts -= sub_a[q] * 1.0001f;
       if (sub_b) ts -= sub_b[q] * 1.0001f;
-      if (mx > t) {
-        float w = 4.f * (mx - t);
+      {
+        float w = mx > t ? 4.f * (mx - t) : 0.f;  // (a floor above the sample's best: the width floor below sizes the window)
         // (k = 1: the sample's k-th best IS its maximum and 4·(mx − t) collapses — every later, better row would
         //  fall into the open top bin, the owner could never raise the threshold and the finalize would start
         //  from thousands of rows; a quarter of the way to the score bound is what the rule gives at k = 100)
@@ -619,7 +627,7 @@ static int launch_scan(const ScanParams& p, int grid, hipStream_t s) {
 // Seed pass alone (used by the int8 scan, scan_q8.hip): thr[q] = sample statistic − sub_a[q] − sub_b[q].
 int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                      const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
-                     const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered) {
+                     const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered, const float* floor) {
   ScanParams p;
   p.corpus = (const half_t*)corpus;
   p.q16 = (const half_t*)q16;
@@ -662,7 +670,7 @@ int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t
   }
   hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(1024), 0, s, ws.seed, seed_tiles * 32,
                      (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, sub_a, sub_b, (uint32_t*)ws.thr, ws.binlo,
-                     ws.binscale, ws.bininv, ws.flags, ws.hist);
+                     ws.binscale, ws.bininv, ws.flags, ws.hist, floor, (const float*)nullptr);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -670,7 +678,7 @@ int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t
 // Host entry used by rarc_api.hip.  *grid_out = workgroups launched (owners of candidate segments).
 int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, const uint16_t* q16, int nq,
                          int kprime, float bin_lo, float bin_hi, const RarcWs& ws, int cap, int* grid_out,
-                         hipStream_t s) {
+                         hipStream_t s, const float* floor, const float* floor_eps) {
   ScanParams p;
   p.corpus = (const half_t*)corpus;
   p.q16 = (const half_t*)q16;
@@ -709,7 +717,7 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
   }
   hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(RARC_MAX_QUERIES), dim3(1024), 0, s, ws.seed, seed_tiles * 32,
                      (uint32_t)kprime, (uint32_t)nq, bin_lo, bin_hi, (const float*)nullptr, (const float*)nullptr,
-                     (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist);
+                     (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist, floor, floor_eps);
   RARC_HIP_CHECK(hipGetLastError());
 
   int dev = 0, cus = 256;

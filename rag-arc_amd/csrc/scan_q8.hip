@@ -33,7 +33,8 @@
 
 struct ScanQ8Params {
   const uint4* corpus;   // fp16 (FMT 0), fp8 (FMT 1) or int8-shadow (FMT 2) rows [ceil32(n_rows)][D], 16-byte chunks
-  const float* tmeta;    // per tile: (scale, 1/scale) [+ 32 row multipliers for fp8]; qmeta + RARC_QMETA_HDR
+  const float* tmeta;    // per tile: (packed fp16 scale | fp16 R_t, 1/scale) [+ 32 row multipliers for fp8]; qmeta + RARC_QMETA_HDR
+  const float* hq;       // [256]  ||q8/s_q|| (rounded down): tile t's threshold is raised by hq·(R − R_t)
   const int8_t* q8;      // [256][D]
   const float* qinv;     // [256]  1 / s_q
   const float* eps8;     // [256]
@@ -79,6 +80,10 @@ struct ScanQ8Lds {
   static constexpr int TOTAL = TB + Q8_WAVES * Q8_TB_SLOTS * Q8_TB_STRIDE;
 };
 
+// the tile's metadata word: low half = fp16 scale, high half = fp16 R_t (rounded up; +inf when out of range)
+__device__ __forceinline__ half_t q8_tile_scale(float w) { return __builtin_bit_cast(half_t, (uint16_t)__float_as_uint(w)); }
+__device__ __forceinline__ float q8_tile_rt(float w) { return (float)__builtin_bit_cast(half_t, (uint16_t)(__float_as_uint(w) >> 16)); }
+
 // barrier that orders LDS traffic only: global loads stay in flight across it (a __syncthreads()
 // would drain vmcnt and with it the two-tile prefetch)
 __device__ __forceinline__ void q8_lds_barrier() {
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   constexpr int EPC = FMT ? 16 : 8;   // values per 16-byte chunk (fp8 / int8 : fp16)
   constexpr int CPR = D / EPC;        // 16-byte chunks per row
   constexpr int CPT = 32 * CPR / Q8_THREADS;  // chunks per thread per tile
-  constexpr int MSTRIDE = FMT == 1 ? RARC_QMETA_F8_STRIDE : 2;  // floats of metadata per tile
+  constexpr int MSTRIDE = FMT == 1 ? RARC_QMETA_F8_STRIDE : RARC_QMETA_STRIDE;  // floats of metadata per tile
   constexpr int TCH = 32 * CPR;       // chunks per tile
 
   const int tid = threadIdx.x;
@@ -145,7 +150,8 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const i32x4*)(qp + 32 * ks);
   }
   const float my_qinv = p.qinv[qidx];
-  const float my_sq8 = 1.0f / my_qinv;  // the query's int8 scale
+  const float my_hq = p.hq[qidx];
+  const float r_max = p.tmeta[0 - RARC_QMETA_HDR];  // R = max R_t (qmeta[0]), what eps8 was built on
   float thr = __uint_as_float(p.thr[qidx]);  // seed threshold; +inf for padding queries
   // everything fetched so far has landed before the first tile load is issued: the compiler's wait
   // counters then never tie a query fragment to the (deliberately long-lived) tile prefetches
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   struct Fetch {
     uint4 c[CPT];
     float mul[FMT == 1 ? CPT : 1];  // fp8: the multiplier of each chunk's row (row scale x tile scale)
-    float2 meta;
+    float2 meta;   // (fp16 scale | fp16 R_t in one word, 1/scale)
     uint32_t thr;
     uint32_t hw;
   };
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     }
   };
   auto convert_tile = [&](const Fetch& f, int buf) {
-    const half_t s = (half_t)f.meta.x;
+    const half_t s = q8_tile_scale(f.meta.x);
     char* dst = smem + buf * L::TILE;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) convert_chunk(f, j, s, dst);
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     i32x16 c0 = {0};
     const char* a_base = smem + buf * L::TILE + aoff;
     char* dst = smem + (buf ^ 1) * L::TILE;
-    const half_t s = (half_t)nx.meta.x;
+    const half_t s = q8_tile_scale(nx.meta.x);
     constexpr int PF = (D <= 768) ? 4 : 2;
     constexpr int CSTEP = KS / CPT;  // one chunk converted every CSTEP MFMAs (KS = 4·CPT for fp16, 8·CPT for fp8)
     i32x4 a[PF];
@@ -299,8 +305,13 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   auto drain = [&]() {
     if (tb_n == 0) return;
     __builtin_amdgcn_wave_barrier();
+    // (the lane index goes through an opaque copy: otherwise the slot address below is hoisted out of the scan loop
+    //  as a loop invariant, finds no free register there, and is SPILLED — and its reload here is a vector-memory
+    //  load whose wait, vmcnt(0), drains the whole two-tile prefetch queue on every drain)
+    int dl = lane;
+    asm volatile("" : "+v"(dl));
     for (int base = 0; base < (int)tb_n * 16; base += 64) {
-      const int item = base + lane;  // (slot, position) pair; slots past tb_n hold stale data and are masked out
+      const int item = base + dl;  // (slot, position) pair; slots past tb_n hold stale data and are masked out
       const bool valid = item < (int)tb_n * 16;
       const char* sp = my_tb + (item >> 4) * Q8_TB_STRIDE;
       const int r = item & 15;
@@ -319,7 +330,13 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // scores clear a (conservative) integer threshold: when no lane has more than one — by far the usual
   // case — each passing lane's best is its only survivor and is staged directly; otherwise all 16
   // positions are walked.
-  auto prune = [&](const i32x16& acc, uint32_t tile, float tinv, float tsc) {
+  // `thr_in` already carries the tile's bonus: every row of tile t is within eps8 − hq·(R − R_t) of its approximate
+  // score, so inside the tile the query's threshold may sit hq·(R − R_t) higher (an outlier tile anywhere in the
+  // shard sets R; the typical tile is 1.5 - 2x better)
+  auto prune = [&](const i32x16& acc, uint32_t tile, float tinv, float tmw) {
+    const float thr_g = thr;   // the query's threshold as published (flush compares against it)
+    const float tsc = (float)q8_tile_scale(tmw);
+    const float thr = __builtin_fmaf(my_hq, fmaxf(r_max - q8_tile_rt(tmw), 0.f), thr_g);
     // fast path: the lane's best score only (v_max3: 8 instructions); WHERE it sits is worked out in the slow
     // path, together with the count of scores above the integer threshold.  (Carrying the position along as
     // (score << 4 | r) cost 16 more instructions on every tile for something 70 % of the tiles never use.)
@@ -366,6 +383,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         if ((ABL & 8192) || tb_n >= 4) drain();
       } else {
       // every score s with (float)s*sc >= thr satisfies s >= ti (one unit + 1e-6 relative of slack)
+      const float my_sq8 = 1.0f / my_qinv;  // the query's int8 scale (recomputed here: this path is rare, registers are not)
       const float tq = fmaxf(thr * (my_sq8 * tsc), -2.0e9f);  // thr / sc up to rounding; -inf (no threshold yet) clamped
       const int ti = pass ? (int)__builtin_floorf(tq - 1.0f - __builtin_fabsf(tq) * 2e-6f) : 0x7fffffff;
       int c = 0;
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   Fetch f[NG];
   fetch(f[0], t0);
   convert_tile(f[0], 0);
-  float2 mcur[2];   // (scale, 1/scale) of the tile sitting in LDS buffer 0 / 1
+  float2 mcur[2];   // (scale | R_t word, 1/scale) of the tile sitting in LDS buffer 0 / 1
   mcur[0] = f[0].meta;
   // (scheduling fences: the groups must be ISSUED in this order, or the counted waits the compiler
   // derives for the first loop iteration assume the wrong group is the newest)
@@ -555,7 +573,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop);  // rarc_api.hip
 int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                      const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
-                     const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered = 0);  // scan_f16.hip
+                     const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered, const float* floor);  // scan_f16.hip
 
 template <int D, int FMT>
 static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
@@ -605,8 +623,9 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
                         const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
                         const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
                         const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8,
-                        int (*tighten)(void* ctx, int n_wg), void* tighten_ctx) {
+                        int (*tighten)(void* ctx, int n_wg), void* tighten_ctx, const float* hq, const float* floor) {
   ScanQ8Params p;
+  p.hq = hq;
   p.corpus = fmt == 2 ? (const uint4*)shadow8 : (const uint4*)corpus;
   p.tmeta = qmeta + RARC_QMETA_HDR;
   p.q8 = q8;
@@ -641,29 +660,45 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   };
   // Split scan.  While it follows the k-th best APPROXIMATE score the threshold sits two error bounds below it
   // (one because that score only bounds the true k-th best score L from below by eps8, one because a row as good
-  // as L may score eps8 lower).  After an eighth of the shard the caller's `tighten` pass rescores the best
-  // candidates so far exactly: their k-th best canonical score L1 needs no first margin, and the rest of the
-  // shard runs under max(thr, L1 - eps8) from its first tile — a level the single launch only reaches at the
-  // very end.  Measured: -2 % per step on a 12.5M-row shard, -2.5 % at 3M, -0.7 % at 100M, +1.6 % at 1M (not split).
-  static const bool no_split = getenv("RARC_SCAN_SPLIT") && atoi(getenv("RARC_SCAN_SPLIT")) == 0;
+  // as L may score eps8 lower).  At a few points of the scan — after 1/512, 1/64 and 1/8 of the shard, as far as
+  // each is large enough to be worth a launch — the caller's `tighten` pass rescores the best candidates so far
+  // exactly: their k-th best canonical score L1 needs no first margin, and the next stretch runs under
+  // max(thr, L1 - eps8) from its first tile.  The k-th best score of the first n rows grows like the (1 - k/n)
+  // quantile, so each stretch is 8x the previous one at a threshold roughly a third of a sigma higher; the lag of
+  // 2 eps8 behind that quantile is where most candidates came from (100M x 1024 fp8 rows on N(0,1) data: 97 K
+  // candidates per query with one pass at 1/8, mostly from the stretch [1M, 12.5M) rows).
+  // (RARC_SCAN_SPLIT=0: one launch; =1: the single pass at 1/8 of round 1.)
+  static const int split_mode = getenv("RARC_SCAN_SPLIT") ? atoi(getenv("RARC_SCAN_SPLIT")) : 3;
   const uint32_t pair = 2u * (uint32_t)(grid > 0 ? grid : 1);
-  uint32_t t1 = (p.n_tiles / 8) / pair * pair;  // (1/4, 1/16, 1/32 measured: no better)
-  const bool split = tighten && !no_split && t1 >= 16 * pair;  // (below ~2M rows the second launch costs more than it saves)
+  uint32_t cuts[3];
+  int n_cuts = 0;
+  if (tighten && split_mode > 0) {
+    const uint32_t div[3] = {512u, 64u, 8u};
+    for (int i = (split_mode >= 3 ? 0 : (split_mode == 2 ? 1 : 2)); i < 3; ++i) {
+      const uint32_t t = (p.n_tiles / div[i]) / pair * pair;
+      // (a stretch shorter than 8 pairs of tile rounds per workgroup costs more in launches than it saves; the
+      //  1/8 cut keeps its measured limit of 16: below ~2M rows the second launch does not pay)
+      if (t >= (div[i] == 8u ? 16u : 8u) * pair && (n_cuts == 0 || t > cuts[n_cuts - 1])) cuts[n_cuts++] = t;
+    }
+  }
   // seed pass (fp16 MFMA on a strided sample of the whole shard): t = k'-th best sample score, accurate to eps16,
   // so t − eps16 bounds the k-th best canonical score from below; rows whose int8 score is under t − eps16 − eps8
   // are out.  The sample is sized for the rows that run under it: the first launch only, when the scan is split.
   int rc = rarc_seed_launch(corpus, rowscale, fmt == 2 ? 0 : fmt, n_rows, d_pad, q16, nq, kprime, bin_lo, bin_hi, eps16,
-                            eps8, ws, s, split ? (int64_t)t1 * 32 : 0);
+                            eps8, ws, s, n_cuts ? (int64_t)cuts[0] * 32 : 0, floor);
   if (rc) return rc;
   if (p.n_tiles == 0) return RARC_OK;  // (the seed pass above still initialised thresholds, histograms and flags)
-  if (!split) return launch(p);
-  ScanQ8Params p1 = p;
-  p1.n_tiles = t1;
-  if ((rc = launch(p1)) != RARC_OK) return rc;
-  if ((rc = tighten(tighten_ctx, grid)) != RARC_OK) return rc;
-  ScanQ8Params p2 = p;
-  p2.t_begin = t1;
-  p2.resume = 1;
-  p2.hot_margin = 0.f;  // (the tightened threshold is no longer "k-th approximate score - 2 eps8": count everything)
-  return launch(p2);
+  uint32_t begin = 0;
+  for (int i = 0; i <= n_cuts; ++i) {
+    ScanQ8Params pi = p;
+    pi.t_begin = begin;
+    pi.n_tiles = i < n_cuts ? cuts[i] : p.n_tiles;
+    pi.resume = i > 0 ? 1u : 0u;
+    // (after a pass the tightened threshold is no longer "k-th approximate score - 2 eps8": count everything)
+    pi.hot_margin = i > 0 ? 0.f : 1.0f;
+    if ((rc = launch(pi)) != RARC_OK) return rc;
+    if (i < n_cuts && (rc = tighten(tighten_ctx, grid)) != RARC_OK) return rc;
+    begin = pi.n_tiles;
+  }
+  return RARC_OK;
 }

@@ -53,6 +53,7 @@ SIGNATURES = {
     "rarc_query_block_bytes": (c_size_t, [c_int]),
     "rarc_prep_queries": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                   c_void_p]),
+    "rarc_qblock_set_floor": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rarc_search_workspace_bytes": (c_size_t, [c_int]),
     "rarc_search_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                 c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

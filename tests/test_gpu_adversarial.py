@@ -139,3 +139,28 @@ def test_dense_score_band_100k_rows(oracle):
     rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(q), k)
     assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
     print("repaired:", idx.last_repaired)
+
+
+@pytest.mark.parametrize("storage", ["f16", "f8"])
+def test_overflowing_candidate_segments_are_rerun_from_a_score_floor(oracle, storage):
+    """A candidate capacity far too small for the shard: every query overflows its segments on the first attempt.
+    The flagged queries are searched again TOGETHER, starting from the k-th score the first attempt did establish
+    (rarc_qblock_set_floor), and come back exact — no per-query full scan."""
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(41)
+    n, d, nq, k = 400_000, 256, 48, 100
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    idx = FlatIndexF16(d, scan="q8" if storage == "f16" else "auto", storage=storage, cand_cap=4096)
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    if storage == "f16":
+        rows, _ = oracle.ingest_f16(X)
+        rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), k)
+    else:
+        b8, s8, _ = oracle.ingest_f8(X)
+        rI, rD, _ = oracle.flat_search_f8(b8, s8, oracle.normalize_L2(Q), k)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    assert len(idx.last_repaired) >= nq // 2, "the test is meant to overflow"
+    assert idx.last_rerun == len(idx.last_repaired), "the re-run should have settled every flagged query"

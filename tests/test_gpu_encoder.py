@@ -47,6 +47,66 @@ def test_encoder_matches_oracle(oracle, H, layers, heads, I, n_seq, L):
     _check(oracle, H, layers, heads, I, n_seq, L, seed=H + L)
 
 
+@pytest.mark.parametrize("name,H,layers,heads,I", [("bge-base", 768, 12, 12, 3072), ("bge-large", 1024, 24, 16, 4096)])
+def test_full_depth_encoder_and_induced_score_error(oracle, name, H, layers, heads, I):
+    """Full depth (12 / 24 layers of seeded weights) against the fp32 oracle: how far the fp16 forward drifts with
+    depth, and what that does to the cosine scores of a 100k-row scan.  |score(hip emb, d) - score(oracle emb, d)| <=
+    ||hip emb - oracle emb|| for unit rows, so the embedding distance IS the end-to-end score-error bound; the test
+    also measures the actual score differences over the top-100 of every query.  The figures are printed (and
+    quoted in DESIGN.md / INTEGRATION.md as the encoder's contract): the 1e-5 of the north star holds for the
+    search given the embeddings; the fp16 encoder itself is a 1e-3-class approximation of an fp32 one."""
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    n_seq, L = 16, 32
+    sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=800, max_pos=64, seed=layers)
+    enc = HipBertEncoder(sd, num_heads=heads)
+    rng = np.random.default_rng(layers)
+    ids = rng.integers(1, 800, (n_seq, L)).astype(np.int32)
+    lens = rng.integers(4, L + 1, n_seq).astype(np.int32)
+    for r, l in enumerate(lens):
+        ids[r, l:] = 0
+    got = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    sd16 = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    want = oracle.bert_forward_f32(sd16, ids, lens, heads, normalize=True)
+    max_abs = float(np.max(np.abs(got - want)))
+    dist = float(np.max(np.linalg.norm(got.astype(np.float64) - want.astype(np.float64), axis=1)))
+    cos = np.sum(got * want, axis=1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    # induced error on a scan: same 100k unit rows searched with both sets of embeddings
+    idx = FlatIndexF16(H, metric="cosine")
+    idx.add(oracle.synth_rows_f32(100_000, H, seed=1234))
+    Dg, Ig = idx.search(got, 100)
+    Dw, Iw = idx.search(want, 100)
+    recall = float(np.mean([len(np.intersect1d(Ig[b], Iw[b])) / 100.0 for b in range(n_seq)]))
+    sdiff = 0.0
+    for b in range(n_seq):
+        common, ig, iw = np.intersect1d(Ig[b], Iw[b], return_indices=True)
+        sdiff = max(sdiff, float(np.max(np.abs(Dg[b][ig] - Dw[b][iw]))))
+    print(f"ENCODER-DEPTH {name}: layers={layers} max|d_emb|={max_abs:.2e} max||d_emb||2={dist:.2e} "
+          f"min cos={cos.min():.6f} max|d_score| (top-100, 100k rows)={sdiff:.2e} recall@100 vs fp32 embeddings={recall:.4f}")
+    assert max_abs <= 4e-3 and cos.min() >= 0.9995
+    assert sdiff <= dist + 1e-6                      # Cauchy-Schwarz: the embedding distance bounds every score error
+    assert sdiff <= 4e-3
+
+
+def test_token_ids_and_lengths_are_validated(oracle):
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+
+    sd = oracle.random_bert_state_dict(128, 1, 2, 256, vocab=300, max_pos=64, seed=2)
+    enc = HipBertEncoder(sd, num_heads=2)
+    ok = np.ones((2, 8), np.int32)
+    for bad_ids, bad_lens in ((np.full((2, 8), 300, np.int32), None), (np.full((2, 8), -1, np.int32), None),
+                              (ok, [0, 8]), (ok, [9, 1]), (ok, [1])):
+        with pytest.raises(ValueError):
+            enc.forward(bad_ids, bad_lens)
+    # a single odd-length sequence runs as 4 x 32 tokens (length-masked padding), with the same result
+    one = np.array([[5, 6, 7, 8, 9, 10, 11]], np.int32)
+    a = enc.forward(one, [7]).cpu().numpy()
+    sd16 = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    want = oracle.bert_forward_f32(sd16, one, np.array([7]), 2, normalize=True)
+    assert np.max(np.abs(a - want)) <= 4e-3
+
+
 def test_gemm_kernel_alone(oracle):
     """A=I check with asymmetric W (catches transposes), then random data with bias + GELU."""
     import torch

@@ -107,6 +107,30 @@ def test_medium_c2_shape(hip, oracle):
     assert len(getattr(idx, "last_repaired", [])) <= 2
 
 
+def test_config2_full_size_auto_scan(hip, oracle):
+    """BASELINE config 2 at its real size: 1M x 768 fp16, 256 queries, k = 100, scan="auto" (which picks the fp16
+    MFMA scan at this shard size) — ids and scores bit-identical to the oracle (0.6 s of CPU on the GPU box)."""
+    import torch
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    n, d, nq, k = 1_000_000, 768, 256, 100
+    rows = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d, d, 0, n, 1234, 0))
+    q = torch.empty((nq, d), dtype=torch.float32, device="cuda")
+    B.check(lib.rarc_synth_rows_f32(q.data_ptr(), d, d, 0, nq, 4321, 0))
+    idx = hip.FlatIndexF16(d, scan="auto")
+    idx.add_rows_f16(rows, 1.001)
+    assert not idx._use_q8(k)
+    D, I = idx.search(q, k)
+    ref_I, ref_D, _ = oracle.flat_search_f16(rows.cpu().numpy().view(np.uint16), oracle.normalize_L2(q.cpu().numpy()), k)
+    assert np.array_equal(I, ref_I) and np.array_equal(D.view(np.uint32), ref_D.view(np.uint32))
+    assert len(idx.last_repaired) <= 2
+    idx.scan = "q8"                                      # and through the int8-prefilter scan at the same size
+    D8, I8 = idx.search(q, k)
+    assert np.array_equal(I8, ref_I) and np.array_equal(D8.view(np.uint32), ref_D.view(np.uint32))
+
+
 def test_split_scan_large_shard(hip, oracle):
     """2.2M rows (>= 65536 tiles): the int8 scan runs as two launches around the exact mid-scan pass that
     tightens the thresholds (scan_q8.hip); ids and scores must still equal the oracle's (fp8 rows: test_gpu_fp8_corpus.py)."""

@@ -33,7 +33,19 @@ def _worst_ratio(X, Q, metric):
         eps8 = qb[nqd * 7 + 1024: nqd * 7 + 2048].view(torch.float32)[: Q.shape[0]].double()
         rows = idx.rows.double()                                   # stored fp16 rows, exact in float64
         exact = q32 @ rows.T                                       # float64: within 1e-12 of the real dot product
-        err = (exact - out.double()).abs().max(dim=1).values
+        errs = (exact - out.double()).abs()
+        err = errs.max(dim=1).values
+        # per-tile form (what the scan applies): inside 32-row tile t the bound shrinks by hq[q]·(R − R_t), where
+        # the tile's R_t rides in the high half of its metadata word as an fp16 rounded up
+        hq = qb[nqd * 7 + 3072: nqd * 7 + 4096].view(torch.float32)[: Q.shape[0]].double()
+        nt = (n + 31) // 32
+        words = idx._qmeta[4: 4 + 2 * nt: 2].contiguous().view(torch.int32)
+        rt = ((words >> 16) & 0xffff).to(torch.int16).view(torch.float16).double()
+        R = idx._qmeta[0].double()
+        assert bool((rt <= R * (1 + 2.0 ** -10) + 1e-12).all()) and float(rt.max()) >= float(R) * 0.999
+        bonus = hq[:, None] * (R - rt).clamp(min=0.0)[None, :]                         # [nq][tiles]
+        eps_tile = (eps8[:, None] - bonus).repeat_interleave(32, dim=1)[:, :n]
+        assert bool((errs <= eps_tile).all()), "per-tile bound violated"
     assert bool((err <= eps8).all()), f"bound violated: worst err/eps8 = {(err / eps8).max().item():.3f}"
     return float((err / eps8).max().item())
 
