@@ -314,13 +314,14 @@ def main():
         lib, B, ctypes,
         lambda: timed_loop(torch, dist, lambda: searcher.search_async(q, a.k), lambda h: searcher.finish(h, a.k),
                            a.steps, 0, use_dist),
-        2 * a.steps * passes_per_step + 8)
+        8 * a.steps * passes_per_step + 16)
     exch_ms = searcher.exchange_ms() / max(1, a.steps)
     searcher.measure_exchange(False)
     scan_ms = tot_ms / max(1, n_l)
     # algorithmic bytes of one scan launch on this rank (shadow mode: the scan reads the int8 image).  A large
-    # shard is scanned in two launches of the same kernel (an eighth, an exact mid-scan pass, the rest): per-launch
-    # figures are averages over all launches, like the AverageNs of the kernel in the rocprofv3 CSV
+    # shard is scanned in up to four launches of the same kernel (stretches ending at 1/512, 1/64, 1/8 of the shard
+    # and at its end, an exact tightening pass between them): per-launch figures are averages over all launches,
+    # like the AverageNs of the kernel in the rocprofv3 CSV; scan_ms_per_pass is their sum for one whole scan
     passes = a.steps * passes_per_step
     launches_per_pass = max(1, round(n_l / max(1, passes)))
     shard_bytes = (hi - lo) * d_pad * (1 if a.shadow else esize) / launches_per_pass
@@ -387,7 +388,7 @@ def main():
         (dt2, (ids2, sc2)), tot2, nl2 = scan_profile(
             lib, B, ctypes,
             lambda: timed_loop(torch, dist, lambda: idx2.search_async(q, a.k), lambda h: h.result(), steps2, w2, False),
-            2 * (steps2 + w2) * passes_per_step + 8)
+            8 * (steps2 + w2) * passes_per_step + 16)
         scan2 = tot2 / max(1, steps2 + w2)   # per scan pass (the warm-up passes are inside the profiling window too)
         k2 = "rarc_scan_q8_kernel" if idx2._use_q8(a.k) else "rarc_scan_f16_kernel"
         bytes2 = n2 * B.padded_dim(a.dim) * 2
@@ -447,7 +448,7 @@ def leg_c3(torch, dist, lib, B, ctypes, idx2, q, dense_ids, n2, a, steps, warmup
 
     (dt, (fk, fs, fn)), tot, nl = scan_profile(
         lib, B, ctypes, lambda: timed_loop(torch, dist, lambda: idx2.search_async(q, K), end, steps, warmup, False),
-        2 * (steps + warmup) * passes_per_step + 8)
+        8 * (steps + warmup) * passes_per_step + 16)
     scan = tot / max(1, steps + warmup)
     return {"workload": f"config 3 end to end: {n2}x{a.dim} fp16 scan top-{K} -> rerank score->order (seeded fp16 logits) "
                         f"-> RRF with a supplied lexical list, batch {nq}, 1 GPU",
@@ -570,7 +571,7 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
     enc_ev.clear()
     searcher.measure_exchange(True)
     (dt, (fk, fs, fn)), tot, nl = scan_profile(lib, B, ctypes, lambda: timed_loop(torch, dist, begin, end, steps, 0, use_dist),
-                                               2 * steps + 8)
+                                               8 * steps + 16)
     exch = searcher.exchange_ms() / max(1, steps)
     torch.cuda.synchronize()
     enc_ms = sum(x.elapsed_time(y) for x, y in enc_ev) / max(1, len(enc_ev))

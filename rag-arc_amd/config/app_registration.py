@@ -1,7 +1,7 @@
 """Counterpart of the reference's config/app_registration.py:1-5: the registry singleton plus a
 helper that registers this backend's retriever stacks under the framework's own mechanism."""
 from ..framework.register import Register
-from .modules import MultiPathRetrieverConfig, VectorStoreRetrieverConfig
+from .modules import HipLogitRerankerConfig, MultiPathRetrieverConfig, VectorStoreRetrieverConfig
 
 registrator = Register()
 
@@ -12,3 +12,7 @@ def register_dense_retriever(config_path: str, app_name: str = "hip_dense_retrie
 
 def register_multipath_retriever(config_path: str, app_name: str = "hip_multipath_retriever") -> None:
     registrator.register(config_path, app_name, MultiPathRetrieverConfig)
+
+
+def register_reranker(config_path: str, app_name: str = "hip_reranker") -> None:
+    registrator.register(config_path, app_name, HipLogitRerankerConfig)

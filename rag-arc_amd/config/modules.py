@@ -40,12 +40,42 @@ class TableEmbeddingsConfig(AbstractConfig):
         return BuiltModule(config=self, impl=TableEmbeddings.from_npz(self.path))
 
 
-EmbeddingsConfig = Annotated[Union[TableEmbeddingsConfig], Field(discriminator="type")]
+class HipBertEmbeddingsConfig(AbstractConfig):
+    """The MI355X encoder as a registered embedding provider (the reference's HuggingFaceEmbeddings slot,
+    core/file_management/embeddings/huggingface.py:85-98,116-126: texts in, python float lists out).
+    `weights_path`: a BertModel state dict (HuggingFace tensor names) as .safetensors or .npz;
+    `vocab_path`: the checkpoint's vocab.txt (WordPiece)."""
+    type: Literal["hip_bert_embeddings"] = "hip_bert_embeddings"
+    weights_path: str
+    vocab_path: str
+    num_heads: int
+    normalize_embeddings: bool = True     # bge models: True (encode_kwargs={"normalize_embeddings": True})
+    do_lower_case: bool = True
+    max_length: int = 512
+    batch_size: int = 32
+    layer_norm_eps: float = 1e-12
+    device: int = 0
+
+    def build(self) -> AbstractModule:
+        from ..encapsulation.embeddings.hip_bert import HipBertEmbeddings, HipBertEncoder, load_state_dict
+        from ..encapsulation.embeddings.wordpiece import WordPieceTokenizer
+
+        enc = HipBertEncoder(load_state_dict(self.weights_path), num_heads=self.num_heads,
+                             layer_norm_eps=self.layer_norm_eps, device=self.device)
+        tok = WordPieceTokenizer.from_file(self.vocab_path, do_lower_case=self.do_lower_case,
+                                           max_length=min(self.max_length, enc.max_pos))
+        return BuiltModule(config=self, impl=HipBertEmbeddings(enc, tok, max_length=self.max_length,
+                                                               batch_size=self.batch_size,
+                                                               normalize_embeddings=self.normalize_embeddings,
+                                                               pad_id=tok.pad))
+
+
+EmbeddingsConfig = Annotated[Union[TableEmbeddingsConfig, HipBertEmbeddingsConfig], Field(discriminator="type")]
 
 
 class HipFlatVectorStoreConfig(AbstractConfig):
     type: Literal["hip_flat_vectorstore"] = "hip_flat_vectorstore"
-    embedding: TableEmbeddingsConfig
+    embedding: EmbeddingsConfig
     metric: Literal["cosine", "ip"] = "cosine"
     normalize_L2: bool = False
     device: int = 0
@@ -78,6 +108,26 @@ class VectorStoreRetrieverConfig(AbstractConfig):
         return BuiltModule(config=self, impl=VectorStoreRetriever(self.vectorstore.build().impl,
                                                                   search_type=self.search_type,
                                                                   search_kwargs=dict(self.search_kwargs)))
+
+
+class HipLogitRerankerConfig(AbstractConfig):
+    """The yes/no-logit reranker as a registered module (core/rerank/Reranker_Qwen3.py:6-75).  The score -> order
+    step runs in the rarc_rerank_order kernel; the (no, yes) logits come from `logits_path`, an .npz table of
+    logits computed offline for (query, document) pairs: `queries` [nq], `docs` [nd], `z_no` / `z_yes` [nq][nd]
+    fp16 — unknown pairs raise KeyError, like TableEmbeddings."""
+    type: Literal["hip_logit_reranker"] = "hip_logit_reranker"
+    logits_path: str
+    instruction: Optional[str] = None
+    device: int = 0
+
+    def build(self) -> AbstractModule:
+        from ..core.rerank.hip_reranker import HipLogitReranker, TableLogits
+
+        return BuiltModule(config=self, impl=HipLogitReranker(TableLogits.from_npz(self.logits_path),
+                                                              instruction=self.instruction, device=self.device))
+
+
+RerankerConfig = Annotated[Union[HipLogitRerankerConfig], Field(discriminator="type")]
 
 
 class RRFusionConfig(AbstractConfig):

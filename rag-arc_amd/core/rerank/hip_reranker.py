@@ -13,6 +13,31 @@ from ..utils.data_model import Document
 from .base import RerankerBase
 
 
+class TableLogits:
+    """`logit_fn` backed by a table of logits computed offline: (query, doc content) -> (z_no, z_yes)."""
+
+    def __init__(self, queries, docs, z_no, z_yes):
+        import numpy as np
+
+        self.qi = {str(q): i for i, q in enumerate(queries)}
+        self.di = {str(d): i for i, d in enumerate(docs)}
+        self.z_no, self.z_yes = np.asarray(z_no, dtype=np.float16), np.asarray(z_yes, dtype=np.float16)
+        if self.z_no.shape != (len(self.qi), len(self.di)) or self.z_yes.shape != self.z_no.shape:
+            raise ValueError("z_no / z_yes must be [n_queries][n_docs]")
+
+    @classmethod
+    def from_npz(cls, path: str) -> "TableLogits":
+        import numpy as np
+
+        with np.load(path, allow_pickle=False) as d:
+            return cls([str(x) for x in d["queries"]], [str(x) for x in d["docs"]], d["z_no"], d["z_yes"])
+
+    def __call__(self, query: str, contents: Sequence[str]):
+        q = self.qi[query]
+        cols = [self.di[c] for c in contents]
+        return self.z_no[q, cols], self.z_yes[q, cols]
+
+
 class HipLogitReranker(RerankerBase):
     def __init__(self, logit_fn: Callable[[str, Sequence[str]], Tuple], instruction: Optional[str] = None,
                  device: int = 0):

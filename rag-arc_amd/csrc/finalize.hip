@@ -277,6 +277,9 @@ struct Fin8Params {
   int64_t* out_ids;
   float* out_scores;
   uint32_t* status;
+  const float* tmeta;   // per-tile metadata of the scanned image (qmeta + RARC_QMETA_HDR): word 0 carries R_t
+  int mstride;          // floats per tile in tmeta (2, or 34 for fp8 rows)
+  const float* hq;      // [256] ||q8/s_q||: inside tile t the error bound is eps8 - hq·(R - R_t)  (scan_q8.hip)
   unsigned long long* dbg;  // tools: phase stamps of block 0 (100 MHz ticks), else null
   uint32_t* tighten_thr;    // non-null: stop after step 1 and raise thr[q] to L - eps8 (split scan, scan_q8.hip)
 };
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          if (base + lane < n[u] && want(rarc_candscore(key[u]))) {
+          if (base + lane < n[u] && want(rarc_candscore(key[u]), rarc_candrow(key[u]))) {
             const uint32_t e = atomicAdd(&s_ne, 1u);
             if (e < FIN8_RS) ex[e] = key[u];
           }
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
 
   // ---- step 1: G1 = {a >= T1}: canonical scores, L = k-th best of them ----
   FIN8_STAMP(1)
-  collect([&](float a) { return a >= t1; });
+  collect([&](float a, uint32_t) { return a >= t1; });
   __syncthreads();
   if (s_ne > (uint32_t)FIN8_RS && t1 > -INFINITY) {
     // The histogram's bins were too coarse for this query (a window sized from a sample whose k-th best lies far
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       __syncthreads();
       if (tid == 0) s_ne = 0;
       __syncthreads();
-      collect([&](float a) { return a >= mid; });
+      collect([&](float a, uint32_t) { return a >= mid; });
       __syncthreads();
       const uint32_t c = s_ne;
       if (c > (uint32_t)FIN8_RS) a_lo = mid;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       __syncthreads();
       if (tid == 0) s_ne = 0;
       __syncthreads();
-      collect([&](float a) { return a >= t1; });
+      collect([&](float a, uint32_t) { return a >= t1; });
       __syncthreads();
     }
   }
@@ -500,7 +503,19 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   }
 
   // ---- step 2: G2 = {a < T1, a + eps >= L}: canonical scores ----
-  if (ne1_all <= (uint32_t)FIN8_RS && t1 > -INFINITY) collect([&](float a) { return a < t1 && a + eps * 1.0001f >= L; });
+  // Could the row still reach `ref` canonically?  canonical <= a + eps8 for every row, and inside its own tile
+  // <= a + eps8 - hq·(R - R_t) (the bound the scan discarded with): the coarse test first, the tile's metadata word
+  // (a 4-byte gather) only for the few thousand rows that pass it — each row it then drops is a whole row not rescored
+  const float hqv = p.hq ? p.hq[q] : 0.f;
+  const float r_max = p.tmeta ? p.tmeta[0 - RARC_QMETA_HDR] : 0.f;
+  auto reaches = [&](float a, uint32_t row, float ref) {
+    if (!(a + eps * 1.0001f >= ref)) return false;
+    if (!p.tmeta) return true;
+    const uint32_t w = __float_as_uint(p.tmeta[(size_t)(row >> 5) * p.mstride]);
+    const float rt = (float)__builtin_bit_cast(half_t, (uint16_t)(w >> 16));
+    return a + (eps - hqv * fmaxf(r_max - rt, 0.f)) * 1.0001f >= ref;
+  };
+  if (ne1_all <= (uint32_t)FIN8_RS && t1 > -INFINITY) collect([&](float a, uint32_t row) { return a < t1 && reaches(a, row, L); });
   __syncthreads();
   FIN8_STAMP(5)
   uint32_t ne_all = s_ne;
@@ -537,7 +552,8 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       __syncthreads();
       if (tid == 0) s_ne = (uint32_t)p.k;
       __syncthreads();
-      collect([&](float a) { return a >= lo && a < hi; });
+      const float lc = s_L;
+      collect([&](float a, uint32_t row) { return a >= lo && a < hi && reaches(a, row, lc); });
       __syncthreads();
       const uint32_t cnt = s_ne;
       if (cnt > (uint32_t)FIN8_RS) {  // halve the band from below
@@ -597,7 +613,8 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
 unsigned long long* g_fin8_dbg = nullptr;  // set by tools only
 int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
                             const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
-                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, bool tighten) {
+                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, bool tighten,
+                            const float* qmeta, const float* hq) {
   RARC_REQUIRE(d_pad <= FIN8_MAXD, RARC_E_UNSUPPORTED, "rarc_finalize_q8: d_pad %d > %d", d_pad, FIN8_MAXD);
   Fin8Params p;
   p.corpus = corpus;
@@ -619,6 +636,9 @@ int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, 
   p.out_ids = out_ids;
   p.out_scores = out_scores;
   p.status = status;
+  p.tmeta = qmeta ? qmeta + RARC_QMETA_HDR : nullptr;
+  p.mstride = fmt == 1 ? RARC_QMETA_F8_STRIDE : RARC_QMETA_STRIDE;
+  p.hq = hq;
   p.dbg = tighten ? nullptr : g_fin8_dbg;
   p.tighten_thr = tighten ? (uint32_t*)ws.thr : nullptr;
   // 8 waves stage 8 rows each up to 1536 bytes per row (97 KB); up to 3072 bytes: 4 waves; fp32 rows of 1024: 2 waves

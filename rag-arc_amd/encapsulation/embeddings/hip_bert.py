@@ -5,7 +5,8 @@ optional normalisation, python float lists out).
 
 The forward pass runs in the rarc_enc_* HIP kernels (csrc/encoder.hip); weights are taken from a
 HuggingFace `BertModel` state dict (same tensor names), stored fp16 in HBM.  Tokenisation is a host
-callable `tokenize(text) -> list[int]` (WordPiece vocabularies do not ship offline).
+callable `tokenize(text) -> list[int]`; `wordpiece.WordPieceTokenizer` is the BERT tokeniser over a supplied
+vocab.txt (no vocabulary ships with this repo: there is no network here).
 """
 from __future__ import annotations
 
@@ -17,6 +18,19 @@ import numpy as np
 
 from ...hip import binding as B
 from .base import Embeddings
+
+
+def load_state_dict(path: str) -> Dict[str, "np.ndarray"]:
+    """A BertModel state dict (HuggingFace tensor names, with or without the "bert." prefix) from .safetensors
+    or .npz, as numpy arrays."""
+    if path.endswith(".safetensors"):
+        from safetensors.numpy import load_file
+
+        return dict(load_file(path))
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as data:
+            return {k: data[k] for k in data.files}
+    raise ValueError(f"unsupported weight file (want .safetensors or .npz): {path}")
 
 
 class HipBertEncoder:

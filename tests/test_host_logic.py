@@ -69,3 +69,43 @@ def test_multipath_management_helpers():
     f2 = OracleFusion(k=1.0)
     mp.set_fusion_method(f2)
     assert mp.fusion_method is f2 and mp.get_name() == "MultiPathRetriever"
+
+
+def test_encoder_and_reranker_configs_are_tagged_members_of_the_registry_unions():
+    """The HIP encoder and the reranker are selectable from JSON like any other backend: tagged configs in the
+    discriminated unions (pattern: framework/module_test.py:47-101 in the reference); wrong tags are rejected."""
+    import pydantic
+    import pytest
+
+    from rag_arc_amd.config.modules import (HipBertEmbeddingsConfig, HipFlatVectorStoreConfig, HipLogitRerankerConfig,
+                                            TableEmbeddingsConfig)
+
+    vs = HipFlatVectorStoreConfig(**{"type": "hip_flat_vectorstore", "storage": "f32",
+                                     "embedding": {"type": "hip_bert_embeddings", "weights_path": "w.safetensors",
+                                                   "vocab_path": "vocab.txt", "num_heads": 12}})
+    assert isinstance(vs.embedding, HipBertEmbeddingsConfig) and vs.embedding.normalize_embeddings is True
+    vs2 = HipFlatVectorStoreConfig(**{"type": "hip_flat_vectorstore", "embedding": {"type": "table_embeddings", "path": "e.npz"}})
+    assert isinstance(vs2.embedding, TableEmbeddingsConfig)
+    with pytest.raises(pydantic.ValidationError):
+        HipFlatVectorStoreConfig(**{"type": "hip_flat_vectorstore", "embedding": {"type": "no_such_provider", "path": "x"}})
+    with pytest.raises(pydantic.ValidationError):
+        HipBertEmbeddingsConfig(**{"type": "hip_bert_embeddings", "weights_path": "w.npz"})      # vocab_path, num_heads missing
+    rr = HipLogitRerankerConfig(**{"type": "hip_logit_reranker", "logits_path": "l.npz"})
+    assert rr.device == 0
+    with pytest.raises(pydantic.ValidationError):
+        HipLogitRerankerConfig(**{"type": "rrf", "logits_path": "l.npz"})
+
+
+def test_table_logits_lookup(tmp_path):
+    import numpy as np
+    import pytest
+
+    from rag_arc_amd.core.rerank.hip_reranker import TableLogits
+
+    np.savez(tmp_path / "l.npz", queries=np.array(["q1", "q2"]), docs=np.array(["a", "b", "c"]),
+             z_no=np.arange(6, dtype=np.float16).reshape(2, 3), z_yes=-np.arange(6, dtype=np.float16).reshape(2, 3))
+    t = TableLogits.from_npz(str(tmp_path / "l.npz"))
+    zn, zy = t("q2", ["c", "a"])
+    assert zn.tolist() == [5.0, 3.0] and zy.tolist() == [-5.0, -3.0]
+    with pytest.raises(KeyError):
+        t("q3", ["a"])
