@@ -345,6 +345,33 @@ int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int3
                      int seq_len, int normalize, void* d_ws, size_t ws_bytes, float* d_out, void* stream);
 
 /*
+ * Reranker LM forward — what Qwen3Reranker.compute_logits takes from the causal LM
+ * (core/rerank/Reranker_Qwen3.py:41-49: `self.lm(**inputs).logits[:, -1, :]` at the ids of "no" and "yes") for
+ * the LEFT-padded batches process_inputs builds (:29-39).  Qwen3-style decoder: RMSNorm, fused q|k|v projection
+ * with grouped K/V heads, per-head q/k RMSNorm, rotary embedding (rotate-half), causal attention, SwiGLU MLP, no
+ * biases; fp16 weights (torch.nn.Linear layout [out][in]) and activations, fp32 accumulation.
+ *   d_ids    int32 [n_seq][seq_len], left padded;  d_start int32 [n_seq]: index of each sequence's first real token
+ *            (positions run 0..seq_len-1 over the padded sequence, as in the reference's forward)
+ *   d_out    fp16 [n_seq][2]: (logit of no_id, logit of yes_id) at the last position — the input of rarc_rerank_order
+ * n_seq*seq_len a multiple of 128; head_dim 64 or 128; hidden, inter, (n_q+2*n_kv)*head_dim multiples of 128.
+ * `model`, `model->layers` are HOST structs of DEVICE pointers; zero_bias: max(hidden, 2*inter, qkv width) zeros.
+ */
+typedef struct RarcLmLayer {
+  const uint16_t *in_norm, *qkv_w, *q_norm, *k_norm, *o_w, *post_norm, *gate_up_w, *down_w;
+  /* qkv_w [(n_q+2*n_kv)*head_dim][hidden] = q_proj | k_proj | v_proj rows; gate_up_w [2*inter][hidden] = gate | up */
+} RarcLmLayer;
+typedef struct RarcLmModel {
+  int hidden, n_layers, n_q_heads, n_kv_heads, head_dim, inter, vocab;
+  float rms_eps, rope_theta;
+  const uint16_t *embed, *lm_head, *final_norm, *zero_bias;
+  const RarcLmLayer* layers; /* host array [n_layers] */
+} RarcLmModel;
+size_t rarc_lm_workspace_bytes(const RarcLmModel* model, int n_tokens);
+int rarc_lm_yes_no_logits(const RarcLmModel* model, const int32_t* d_ids, const int32_t* d_start, int n_seq,
+                          int seq_len, int no_id, int yes_id, void* d_ws, size_t ws_bytes, uint16_t* d_out_f16,
+                          void* stream);
+
+/*
  * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan
  * kernel with a pair of HIP events recorded on the search's own stream.  rarc_profile_end
  * synchronises, returns the summed scan time and the number of launches measured, and releases

@@ -380,3 +380,80 @@ def random_bert_state_dict(hidden, layers, heads, inter, vocab=1000, max_pos=128
         for nme in ("attention.output.LayerNorm", "output.LayerNorm"):
             sd[p + nme + ".weight"], sd[p + nme + ".bias"] = 1 + r(hidden), r(hidden)
     return sd
+
+
+# --------------------------------------------------------------------------------- reranker LM forward
+def qwen3_last_logits_f32(sd, cfg, input_ids, attention_mask, token_ids):
+    """Last-position logits of a Qwen3-style causal LM at `token_ids` (e.g. [no_id, yes_id]) in float32 numpy —
+    what Qwen3Reranker.compute_logits reads from `self.lm(**inputs).logits[:, -1, :]`
+    (core/rerank/Reranker_Qwen3.py:41-49) for a LEFT-padded batch (:29-39).  `sd`: HuggingFace Qwen3ForCausalLM
+    state dict (numpy); `cfg`: dict(num_attention_heads, num_key_value_heads, head_dim, rms_norm_eps, rope_theta).
+    Positions run 0..L-1 over the padded sequence (the reference's forward passes no position_ids).
+    Pinned against transformers.Qwen3ForCausalLM in tests/test_oracle_golden.py."""
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    ids = np.asarray(input_ids)
+    mask = np.asarray(attention_mask).astype(bool)
+    n, L = ids.shape
+    nq, nkv, dh = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
+    eps, theta = float(cfg.get("rms_norm_eps", 1e-6)), float(cfg.get("rope_theta", 1e6))
+
+    def rms(x, w):
+        return x / np.sqrt((x.astype(np.float32) ** 2).mean(-1, keepdims=True) + eps) * w
+
+    inv_freq = (1.0 / theta ** (np.arange(0, dh, 2, dtype=np.float32) / np.float32(dh))).astype(np.float32)
+    ang = np.arange(L, dtype=np.float32)[:, None] * inv_freq[None, :]
+    cos, sin = np.cos(np.concatenate([ang, ang], -1)), np.sin(np.concatenate([ang, ang], -1))     # [L][dh]
+
+    def rope(x):  # x [n][heads][L][dh]; rotate_half convention
+        x1, x2 = x[..., : dh // 2], x[..., dh // 2:]
+        return x * cos + np.concatenate([-x2, x1], -1) * sin
+
+    causal = np.tril(np.ones((L, L), dtype=bool))
+    allow = causal[None, :, :] & mask[:, None, :]                     # [n][query][key]
+    bias = np.where(allow, 0.0, -np.inf).astype(np.float32)
+    x = g("model.embed_tokens.weight")[ids]
+    i = 0
+    while f"model.layers.{i}.self_attn.q_proj.weight" in sd:
+        p = f"model.layers.{i}."
+        h = rms(x, g(p + "input_layernorm.weight"))
+        q = (h @ g(p + "self_attn.q_proj.weight").T).reshape(n, L, nq, dh)
+        k = (h @ g(p + "self_attn.k_proj.weight").T).reshape(n, L, nkv, dh)
+        v = (h @ g(p + "self_attn.v_proj.weight").T).reshape(n, L, nkv, dh)
+        q = rope(rms(q, g(p + "self_attn.q_norm.weight")).transpose(0, 2, 1, 3))
+        k = rope(rms(k, g(p + "self_attn.k_norm.weight")).transpose(0, 2, 1, 3))
+        v = v.transpose(0, 2, 1, 3)
+        rep = nq // nkv
+        k, v = np.repeat(k, rep, axis=1), np.repeat(v, rep, axis=1)
+        s = q @ k.transpose(0, 1, 3, 2) / np.sqrt(np.float32(dh)) + bias[:, None, :, :]
+        s = s - np.where(np.isfinite(s.max(-1, keepdims=True)), s.max(-1, keepdims=True), 0.0)
+        pr = np.exp(s)
+        den = pr.sum(-1, keepdims=True)
+        pr = np.where(den > 0, pr / np.where(den > 0, den, 1.0), 0.0)   # a padding query attends to nothing
+        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(n, L, nq * dh)
+        x = x + ctx @ g(p + "self_attn.o_proj.weight").T
+        h = rms(x, g(p + "post_attention_layernorm.weight"))
+        gate, up = h @ g(p + "mlp.gate_proj.weight").T, h @ g(p + "mlp.up_proj.weight").T
+        x = x + ((gate / (1.0 + np.exp(-gate))) * up) @ g(p + "mlp.down_proj.weight").T
+        i += 1
+    last = rms(x[:, -1, :], g("model.norm.weight"))
+    head = g("lm_head.weight") if "lm_head.weight" in sd else g("model.embed_tokens.weight")
+    return (last @ head[np.asarray(token_ids)].T).astype(np.float32)
+
+
+def random_qwen3_state_dict(hidden, layers, n_q, n_kv, head_dim, inter, vocab=1000, seed=0, scale=0.05, tie=True):
+    """Seeded synthetic Qwen3ForCausalLM weights (HuggingFace names); norm weights near 1."""
+    rng = np.random.default_rng(seed)
+    r = lambda *shape: (rng.standard_normal(shape) * scale).astype(np.float32)
+    sd = {"model.embed_tokens.weight": r(vocab, hidden) * 4, "model.norm.weight": 1 + r(hidden)}
+    for i in range(layers):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = r(n_q * head_dim, hidden)
+        sd[p + "self_attn.k_proj.weight"] = r(n_kv * head_dim, hidden)
+        sd[p + "self_attn.v_proj.weight"] = r(n_kv * head_dim, hidden)
+        sd[p + "self_attn.o_proj.weight"] = r(hidden, n_q * head_dim)
+        sd[p + "self_attn.q_norm.weight"], sd[p + "self_attn.k_norm.weight"] = 1 + r(head_dim), 1 + r(head_dim)
+        sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"] = r(inter, hidden), r(inter, hidden)
+        sd[p + "mlp.down_proj.weight"] = r(hidden, inter)
+        sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = 1 + r(hidden), 1 + r(hidden)
+    sd["lm_head.weight"] = sd["model.embed_tokens.weight"] if tie else r(vocab, hidden)
+    return sd

@@ -1,0 +1,154 @@
+"""Qwen3Reranker on the MI355X (reference: core/rerank/Reranker_Qwen3.py:6-75).
+
+Same steps as the reference: format_instruction (:23-27) -> process_inputs (:29-39: tokenise the pairs with
+truncation to max_length - |prefix| - |suffix|, wrap in the prefix / suffix token ids, LEFT pad) ->
+compute_logits (:41-49: LM forward, last-position logits of "no" and "yes", log_softmax over the two, exp) ->
+stable descending sort, optional top-k (:70-74).  The LM forward runs in rarc_lm_yes_no_logits
+(csrc/decoder.hip: RMSNorm, RoPE, grouped-query causal attention, SwiGLU, MFMA GEMMs), the score -> order step in
+rarc_rerank_order.  Weights are a HuggingFace Qwen3ForCausalLM state dict kept fp16 in HBM.
+
+The tokeniser is a callable `tokenize(text) -> list[int]` (Qwen's BPE vocabulary does not ship here — no network);
+`prefix_ids` / `suffix_ids` are the token ids of the chat-template prefix and suffix the reference encodes at
+construction (:14-17), `yes_id` / `no_id` those of "yes" / "no" (:18-19).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from ...hip import binding as B
+from ..utils.data_model import Document
+from .base import RerankerBase
+from .hip_reranker import HipLogitReranker
+
+
+class HipCausalLM:
+    """Qwen3-style decoder weights in HBM + the last-position (no, yes) logits of left-padded token batches."""
+
+    def __init__(self, state_dict: Dict[str, "np.ndarray"], num_attention_heads: int, num_key_value_heads: int,
+                 head_dim: int, rms_norm_eps: float = 1e-6, rope_theta: float = 1e6, device: int = 0):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise B.RarcError("no ROCm device visible: the HIP reranker has no CPU fallback")
+        self.torch, self.lib = torch, B.load_library()
+        self.device = torch.device("cuda", device)
+        sd = state_dict
+
+        def f16(v):
+            if isinstance(v, torch.Tensor):
+                return v.detach().to(self.device, torch.float32).half().contiguous()
+            return torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.device).half().contiguous()
+
+        self.embed = f16(sd["model.embed_tokens.weight"])
+        self.lm_head = f16(sd["lm_head.weight"]) if "lm_head.weight" in sd else self.embed   # tied embeddings
+        self.final_norm = f16(sd["model.norm.weight"])
+        self.vocab, self.hidden = int(self.embed.shape[0]), int(self.embed.shape[1])
+        self.n_q, self.n_kv, self.head_dim = int(num_attention_heads), int(num_key_value_heads), int(head_dim)
+        self.layers: List[dict] = []
+        i = 0
+        while f"model.layers.{i}.self_attn.q_proj.weight" in sd:
+            p = f"model.layers.{i}."
+            self.layers.append(dict(
+                in_norm=f16(sd[p + "input_layernorm.weight"]),
+                qkv_w=torch.cat([f16(sd[p + f"self_attn.{n}_proj.weight"]) for n in ("q", "k", "v")]).contiguous(),
+                q_norm=f16(sd[p + "self_attn.q_norm.weight"]), k_norm=f16(sd[p + "self_attn.k_norm.weight"]),
+                o_w=f16(sd[p + "self_attn.o_proj.weight"]),
+                post_norm=f16(sd[p + "post_attention_layernorm.weight"]),
+                gate_up_w=torch.cat([f16(sd[p + "mlp.gate_proj.weight"]), f16(sd[p + "mlp.up_proj.weight"])]).contiguous(),
+                down_w=f16(sd[p + "mlp.down_proj.weight"])))
+            i += 1
+        if not self.layers:
+            raise B.RarcError("state dict holds no model.layers.* tensors")
+        self.inter = int(self.layers[0]["down_w"].shape[1])
+        qkv_w = (self.n_q + 2 * self.n_kv) * self.head_dim
+        if tuple(self.layers[0]["qkv_w"].shape) != (qkv_w, self.hidden):
+            raise B.RarcError("q/k/v projection shapes do not match the head configuration")
+        if self.head_dim not in (64, 128) or self.hidden % 128 or self.inter % 128 or qkv_w % 128 or self.n_q % self.n_kv:
+            raise B.RarcError(f"unsupported decoder shape: hidden={self.hidden} inter={self.inter} heads={self.n_q}/{self.n_kv} "
+                              f"head_dim={self.head_dim}")
+        self._zero = torch.zeros(max(self.hidden, 2 * self.inter, qkv_w), dtype=torch.float16, device=self.device)
+        self._layer_tab = (B.LmLayer * len(self.layers))(*[
+            B.LmLayer(**{k: v.data_ptr() for k, v in w.items()}) for w in self.layers])
+        self._model = B.LmModel(self.hidden, len(self.layers), self.n_q, self.n_kv, self.head_dim, self.inter, self.vocab,
+                                float(rms_norm_eps), float(rope_theta), self.embed.data_ptr(), self.lm_head.data_ptr(),
+                                self.final_norm.data_ptr(), self._zero.data_ptr(), self._layer_tab)
+        self._ws = None
+
+    def yes_no_logits(self, input_ids, attention_mask, no_id: int, yes_id: int):
+        """input_ids / attention_mask: [n][L] LEFT padded (host arrays).  Returns fp16 device tensor [n][2] = (no, yes)."""
+        t = self.torch
+        ids = np.asarray(input_ids, dtype=np.int32)
+        mask = np.asarray(attention_mask).astype(bool)
+        if ids.ndim != 2 or mask.shape != ids.shape or ids.shape[0] == 0:
+            raise ValueError("input_ids and attention_mask must be [n][L]")
+        n, L = ids.shape
+        if not mask[:, -1].all() or (np.diff(mask.astype(np.int8), axis=1) < 0).any():
+            raise ValueError("batches must be LEFT padded (the reference's tokenizer uses padding_side='left')")
+        if ids[mask].min() < 0 or ids[mask].max() >= self.vocab or not (0 <= no_id < self.vocab and 0 <= yes_id < self.vocab):
+            raise ValueError(f"token ids must lie in [0, {self.vocab})")
+        start = (L - mask.sum(axis=1)).astype(np.int32)
+        # tokens (GEMM rows) must be a multiple of 128: pad the length on the LEFT to a multiple of 32 (masked
+        # positions; rotary embeddings are relative, so shifting every real token by the same amount changes nothing)
+        # and the batch to a multiple of 4 with one-token sequences
+        L32 = -(-L // 32) * 32
+        if L32 != L:
+            ids = np.concatenate([np.zeros((n, L32 - L), np.int32), ids], axis=1)
+            start = start + (L32 - L)
+            L = L32
+        n_pad = -(-n // 4) * 4
+        if n_pad != n:
+            ids = np.concatenate([ids, np.zeros((n_pad - n, L), np.int32)])
+            start = np.concatenate([start, np.full(n_pad - n, L - 1, np.int32)])
+        with t.cuda.device(self.device):
+            st = t.cuda.current_stream(self.device).cuda_stream
+            d_ids = t.from_numpy(np.ascontiguousarray(np.where(ids < 0, 0, ids))).to(self.device)
+            d_start = t.from_numpy(np.ascontiguousarray(start)).to(self.device)
+            need = int(self.lib.rarc_lm_workspace_bytes(ctypes.addressof(self._model), n_pad * L))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = t.empty(need, dtype=t.uint8, device=self.device)
+            out = t.empty((n_pad, 2), dtype=t.float16, device=self.device)
+            B.check(self.lib.rarc_lm_yes_no_logits(ctypes.addressof(self._model), d_ids.data_ptr(), d_start.data_ptr(), n_pad,
+                                                   L, int(no_id), int(yes_id), self._ws.data_ptr(), self._ws.numel(),
+                                                   out.data_ptr(), st), "rarc_lm_yes_no_logits")
+            return out[:n]
+
+
+class HipQwen3Reranker(HipLogitReranker):
+    """Drop-in for the reference's Qwen3Reranker: `rerank(query, documents, k=None, batch_size=8)`."""
+
+    def __init__(self, lm: HipCausalLM, tokenize: Callable[[str], Sequence[int]], yes_id: int, no_id: int,
+                 prefix_ids: Sequence[int] = (), suffix_ids: Sequence[int] = (), max_length: int = 4096,
+                 instruction: Optional[str] = None, pad_id: int = 0, device: Optional[int] = None):
+        super().__init__(self._logits, instruction=instruction,
+                         device=lm.device.index if device is None else device)
+        self.lm, self.tokenize = lm, tokenize
+        self.yes_id, self.no_id, self.pad_id = int(yes_id), int(no_id), int(pad_id)
+        self.prefix_ids, self.suffix_ids = list(prefix_ids), list(suffix_ids)
+        self.max_length = int(max_length)
+
+    def process_inputs(self, pairs: Sequence[str]):
+        """Reranker_Qwen3.py:29-39: truncate each pair's tokens, wrap in prefix / suffix, left pad."""
+        room = self.max_length - len(self.prefix_ids) - len(self.suffix_ids)
+        seqs = [self.prefix_ids + list(self.tokenize(p))[: max(room, 0)] + self.suffix_ids for p in pairs]
+        L = max(len(s) for s in seqs)
+        ids = np.full((len(seqs), L), self.pad_id, np.int32)
+        mask = np.zeros((len(seqs), L), np.int8)
+        for r, s in enumerate(seqs):
+            ids[r, L - len(s):] = s
+            mask[r, L - len(s):] = 1
+        return ids, mask
+
+    def _logits(self, query: str, contents: Sequence[str]):
+        pairs = [self.format_instruction(self.instruction, query, c) for c in contents]
+        ids, mask = self.process_inputs(pairs)
+        z = self.lm.yes_no_logits(ids, mask, self.no_id, self.yes_id).cpu().numpy()   # fp16 [n][2]: 4 bytes per pair
+        return z[:, 0], z[:, 1]
+
+    def compute_scores(self, query: str, contents: Sequence[str]) -> List[float]:
+        """The reference's compute_logits output for one batch: p_yes per pair (python floats of the fp16 values)."""
+        zn, zy = self._logits(query, contents)
+        scores, _ = self.score_order(zn, zy)
+        return [float(v) for v in scores[0].cpu().numpy()]

@@ -1,0 +1,352 @@
+// decoder.hip — the reranker's LM forward on the MI355X: last-position [no, yes] logits of a Qwen3-style
+// decoder (what Qwen3Reranker.compute_logits takes from `self.lm(**inputs).logits[:, -1, :]`,
+// core/rerank/Reranker_Qwen3.py:41-49, for the left-padded batches process_inputs builds, :29-39).
+//
+//   x = embed[ids]
+//   per layer:  h = RMSNorm(x)·w_in;  [q|k|v] = h·Wqkvᵀ  (GQA: n_q heads of q, n_kv heads of k and v)
+//               q, k <- RoPE(RMSNorm_head(q)·w_qn), RoPE(RMSNorm_head(k)·w_kn)       (Qwen3: per-head q/k norm)
+//               ctx = causal softmax(q·kᵀ/sqrt(dh)) v over the sequence's real tokens;  x += ctx·Woᵀ
+//               h = RMSNorm(x)·w_post;  [g|u] = h·Wguᵀ;  x += (silu(g)·u)·Wdownᵀ
+//   logits[s] = (RMSNorm(x[s, L-1])·w_final) · lm_head[{no, yes}]ᵀ
+//
+// The GEMMs are the encoder's MFMA ping-pong kernels (rarc_enc_gemm, encoder.hip: fp16 operands, fp32
+// accumulation); attention is the encoder's wave-per-32-queries MFMA kernel generalised to head_dim 128, grouped
+// K/V heads, a causal mask and left padding.  Activations and the residual stream are fp16, as in the reference's
+// `torch_dtype=torch.float16` model; norms, RoPE, softmax and the final dot products compute in fp32.
+#include "rarc_common.h"
+
+extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
+                             int n, int k, int act, void* stream);
+
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+// ---- embedding gather: x[t] = embed[ids[t]] (ids clamped into the table: memory safety, the host validates) ----
+__global__ __launch_bounds__(256) void rarc_lm_embed_kernel(const int32_t* ids, const half_t* embed, int n_tokens, int H,
+                                                            int vocab, half_t* x) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_tokens) return;
+  int id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const half8* src = (const half8*)(embed + (size_t)id * H);
+  half8* dst = (half8*)(x + (size_t)t * H);
+  for (int c = lane; c < H / 8; c += 64) dst[c] = src[c];
+}
+
+// ---- RMSNorm over the hidden dimension, optionally after a residual add --------------------------------------
+// delta != null:  x[t] += delta[t] (fp16 add, written back), then y[t] = x[t] · rsqrt(mean(x²) + eps) · w
+__global__ __launch_bounds__(256) void rarc_lm_rmsnorm_kernel(half_t* x, const half_t* delta, const half_t* w, float eps,
+                                                              int n_tokens, int H, half_t* y) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_tokens) return;
+  half_t* xr = x + (size_t)t * H;
+  float ss = 0.f;
+  for (int c = lane * 8; c < H; c += 512) {
+    half8 v = *(const half8*)(xr + c);
+    if (delta) {
+      const half8 dv = *(const half8*)(delta + (size_t)t * H + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] + (float)dv[e]);  // one rounding, like an fp16 tensor add
+      *(half8*)(xr + c) = v;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)v[e], (float)v[e], ss);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (!y) return;
+  const float inv = 1.0f / __builtin_sqrtf(ss / (float)H + eps);
+  for (int c = lane * 8; c < H; c += 512) {
+    const half8 v = *(const half8*)(xr + c), wv = *(const half8*)(w + c);
+    half8 o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o8[e] = (half_t)((float)wv[e] * (float)(half_t)((float)v[e] * inv));  // weight * x.to(fp16)
+    *(half8*)(y + (size_t)t * H + c) = o8;
+  }
+}
+
+// ---- per-head RMSNorm of q and k, then rotary embedding (HF rotate_half convention), in place on the fused qkv ----
+// one wave per (token, head) over the n_q + n_kv heads that carry positions; v heads are untouched
+template <int DH>
+__global__ __launch_bounds__(256) void rarc_lm_qknorm_rope_kernel(half_t* qkv, const half_t* qn_w, const half_t* kn_w,
+                                                                  float eps, float theta, int n_tokens, int L, int n_q,
+                                                                  int n_kv) {
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int heads = n_q + n_kv;
+  if (unit >= n_tokens * heads) return;
+  const int t = unit / heads, hd = unit % heads;
+  const int pos = t % L;  // positions run over the padded sequence, as in the reference's forward (no position_ids)
+  half_t* v = qkv + (size_t)t * (size_t)(n_q + 2 * n_kv) * DH + (size_t)hd * DH;
+  const half_t* w = hd < n_q ? qn_w : kn_w;
+  static_assert(DH == 64 || DH == 128, "head_dim 64 or 128");
+  // lane i owns the rotation pair (i, i + DH/2): DH = 128 -> one pair per lane; DH = 64 -> lanes 0..31
+  const int i = lane;
+  const bool on = i < DH / 2;
+  float a = on ? (float)v[i] : 0.f, b = on ? (float)v[i + DH / 2] : 0.f;
+  float ss = a * a + b * b;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
+  if (!on) return;
+  a = (float)w[i] * (float)(half_t)(a * inv);
+  b = (float)w[i + DH / 2] * (float)(half_t)(b * inv);
+  a = (float)(half_t)a;  // the normalised head is an fp16 tensor before the rotation
+  b = (float)(half_t)b;
+  // inv_freq_i = theta^(-2i/DH); angle = pos * inv_freq_i  (fp32, as the reference's rotary module computes them)
+  const float inv_freq = __builtin_exp2f(-(2.0f * (float)i / (float)DH) * __builtin_log2f(theta));
+  const float ang = (float)pos * inv_freq;
+  float sn, cs;
+  sincosf(ang, &sn, &cs);  // (the accurate one: angles reach thousands of radians at the low dimensions)
+  cs = (float)(half_t)cs;  // cos / sin are cast to the activations' dtype before use
+  sn = (float)(half_t)sn;
+  v[i] = (half_t)(a * cs - b * sn);
+  v[i + DH / 2] = (half_t)(b * cs + a * sn);
+}
+
+// ---- causal attention with grouped K/V heads and left padding ----------------------------------------------------
+// One wave per (sequence, q head, 32 queries); S^T = K·Q^T so a query's softmax statistics sit in one lane pair;
+// O^T += V^T·P^T with V transposed through LDS by the loader (the encoder's kernel, encoder.hip, with DH up to 128,
+// K/V taken from head hd / (n_q / n_kv), keys limited to [start[seq], query position]).
+template <int DH>
+__global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __restrict__ qkv,
+                                                                const int32_t* __restrict__ start, int L, int n_q, int n_kv,
+                                                                int q_blocks, int n_units, half_t* __restrict__ ctx) {
+  constexpr int KS = DH / 16;
+  constexpr int MB = DH / 32;
+  constexpr int VROW = 40;
+  __shared__ __attribute__((aligned(16))) half_t vt_all[4][DH * VROW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= n_units) return;
+  half_t* vt = vt_all[wave];
+  const int qb = unit % q_blocks, bh = unit / q_blocks;
+  const int b = bh / n_q, hd = bh % n_q;
+  const int kvh = hd / (n_q / n_kv);
+  int s0 = start[b];
+  s0 = s0 < 0 ? 0 : (s0 > L - 1 ? L - 1 : s0);
+  const int col = lane & 31, hh = lane >> 5;
+  const size_t rs = (size_t)(n_q + 2 * n_kv) * DH;  // row stride of the fused qkv in halves
+  const half_t* qbase = qkv + (size_t)b * L * rs + (size_t)hd * DH;
+  const half_t* kbase = qkv + (size_t)b * L * rs + (size_t)(n_q + kvh) * DH;
+  const half_t* vbase = qkv + (size_t)b * L * rs + (size_t)(n_q + n_kv + kvh) * DH;
+  const float scale = DH == 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(DH)
+  const int q0 = qb * 32;
+  const int qpos = (q0 + col < L) ? q0 + col : L - 1;
+
+  half8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qbase + (size_t)qpos * rs + 16 * ks + 8 * hh);
+  f32x16 o[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int k_end = (q0 + 32 < L) ? q0 + 32 : L;  // causal: no key beyond the block's last query
+
+  for (int k0 = (s0 / 32) * 32; k0 < k_end; k0 += 32) {
+    const int krow = (k0 + col < L) ? k0 + col : L - 1;
+    f32x16 st = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8 kf = *(const half8*)(kbase + (size_t)krow * rs + 16 * ks + 8 * hh);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = lane; i < 32 * (DH / 8); i += 64) {
+      const int kr = i / (DH / 8), c8 = i % (DH / 8);
+      const int vrow = (k0 + kr < L) ? k0 + kr : L - 1;
+      const half8 v = *(const half8*)(vbase + (size_t)vrow * rs + 8 * c8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vt[(8 * c8 + e) * VROW + kr] = v[e];
+    }
+    float s[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+      s[r] = (key >= s0 && key <= qpos) ? st[r] * scale : -INFINITY;
+      tmax = fmaxf(tmax, s[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+    float psum = 0.f;
+    uint32_t pk[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - m_new);
+      const float p1 = (s[r + 1] == -INFINITY) ? 0.f : __expf(s[r + 1] - m_new);
+      psum += p0 + p1;
+      const half2_t h2 = {(half_t)p0, (half_t)p1};
+      pk[r >> 1] = __builtin_bit_cast(uint32_t, h2);
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint32_t mine0 = hh ? (ks ? pk[6] : pk[2]) : (ks ? pk[4] : pk[0]);
+      const uint32_t mine1 = hh ? (ks ? pk[7] : pk[3]) : (ks ? pk[5] : pk[1]);
+      const uint32_t send0 = hh ? (ks ? pk[4] : pk[0]) : (ks ? pk[6] : pk[2]);
+      const uint32_t send1 = hh ? (ks ? pk[5] : pk[1]) : (ks ? pk[7] : pk[3]);
+      const uint32_t recv0 = (uint32_t)__shfl_xor((int)send0, 32, 64), recv1 = (uint32_t)__shfl_xor((int)send1, 32, 64);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 bw = hh ? (u32x4){recv0, recv1, mine0, mine1} : (u32x4){mine0, mine1, recv0, recv1};
+      const half8 pf = __builtin_bit_cast(half8, bw);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const half8 vf = *(const half8*)(vt + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
+        o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[mb], 0, 0, 0);
+      }
+    }
+  }
+  if (q0 + col < L) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;  // (a padding query attends to nothing: zeros)
+    half_t* out = ctx + ((size_t)b * L + q0 + col) * (size_t)n_q * DH + (size_t)hd * DH;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const half4v w = {(half_t)(o[mb][4 * g] * inv), (half_t)(o[mb][4 * g + 1] * inv),
+                          (half_t)(o[mb][4 * g + 2] * inv), (half_t)(o[mb][4 * g + 3] * inv)};
+        *(half4v*)(out + 32 * mb + 8 * g + 4 * hh) = w;
+      }
+  }
+}
+
+// ---- SwiGLU: h[t][j] = silu(g[t][j]) · u[t][j] from the fused [g | u] -----------------------------------------------
+__global__ __launch_bounds__(256) void rarc_lm_swiglu_kernel(const half_t* gu, int n_tokens, int I, half_t* h) {
+  const size_t n8 = (size_t)n_tokens * I / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t t = i / (I / 8), c = (i % (I / 8)) * 8;
+    const half8 g = *(const half8*)(gu + t * 2 * I + c), u = *(const half8*)(gu + t * 2 * I + I + c);
+    half8 o8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gf = (float)g[e];
+      const half_t act = (half_t)(gf / (1.0f + __expf(-gf)));  // silu, rounded to fp16 like the activation tensor
+      o8[e] = (half_t)((float)act * (float)u[e]);
+    }
+    *(half8*)(h + t * I + c) = o8;
+  }
+}
+
+// ---- last position: final RMSNorm, then the two logits (no, yes) = <normed, lm_head[id]> --------------------------
+__global__ __launch_bounds__(64) void rarc_lm_last_logits_kernel(const half_t* x, const half_t* w_final, const half_t* lm_head,
+                                                                 float eps, int L, int H, int no_id, int yes_id,
+                                                                 half_t* out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const half_t* xr = x + ((size_t)b * L + (L - 1)) * H;
+  float ss = 0.f;
+  for (int c = lane; c < H; c += 64) ss = __builtin_fmaf((float)xr[c], (float)xr[c], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float inv = 1.0f / __builtin_sqrtf(ss / (float)H + eps);
+  float a_no = 0.f, a_yes = 0.f;
+  for (int c = lane; c < H; c += 64) {
+    const float nv = (float)(half_t)((float)w_final[c] * (float)(half_t)((float)xr[c] * inv));
+    a_no = __builtin_fmaf(nv, (float)lm_head[(size_t)no_id * H + c], a_no);
+    a_yes = __builtin_fmaf(nv, (float)lm_head[(size_t)yes_id * H + c], a_yes);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a_no += __shfl_xor(a_no, o, 64);
+    a_yes += __shfl_xor(a_yes, o, 64);
+  }
+  if (lane == 0) {
+    out[2 * b] = (half_t)a_no;      // logits are an fp16 tensor in the reference's fp16 model
+    out[2 * b + 1] = (half_t)a_yes;
+  }
+}
+
+// ---- host ------------------------------------------------------------------------------------------------------
+static inline size_t lm_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t rarc_lm_workspace_bytes(const RarcLmModel* m, int n_tokens) {
+  if (!m || n_tokens <= 0) return 0;
+  const size_t T = (size_t)n_tokens, qkv = (size_t)(m->n_q_heads + 2 * m->n_kv_heads) * m->head_dim;
+  return 3 * lm_align(T * m->hidden * 2)                        // x, h (normed), delta (projection outputs)
+         + lm_align(T * qkv * 2)                                // fused q | k | v
+         + lm_align(T * (size_t)m->n_q_heads * m->head_dim * 2)  // attention context
+         + lm_align(T * 2 * (size_t)m->inter * 2)               // fused gate | up
+         + lm_align(T * (size_t)m->inter * 2);                  // silu(gate) * up
+}
+
+extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_seq,
+                                     int seq_len, int no_id, int yes_id, void* d_ws, size_t ws_bytes,
+                                     uint16_t* d_out_f16, void* stream) {
+  RARC_REQUIRE(m && m->layers && d_ids && d_start && d_ws && d_out_f16, RARC_E_INVALID, "rarc_lm_yes_no_logits: null pointer");
+  RARC_REQUIRE(m->embed && m->lm_head && m->final_norm && m->zero_bias, RARC_E_INVALID, "rarc_lm_yes_no_logits: incomplete model");
+  const int H = m->hidden, I = m->inter, DH = m->head_dim, NQ = m->n_q_heads, NKV = m->n_kv_heads;
+  RARC_REQUIRE(n_seq > 0 && seq_len > 0 && m->n_layers > 0, RARC_E_INVALID, "rarc_lm_yes_no_logits: empty batch or model");
+  RARC_REQUIRE((DH == 64 || DH == 128) && NQ > 0 && NKV > 0 && NQ % NKV == 0, RARC_E_UNSUPPORTED,
+               "rarc_lm_yes_no_logits: head_dim must be 64 or 128 and the q heads a multiple of the kv heads");
+  const int QKV = (NQ + 2 * NKV) * DH, QD = NQ * DH;
+  RARC_REQUIRE(H % 128 == 0 && I % 128 == 0 && QKV % 128 == 0 && QD % 64 == 0 && H <= 8192, RARC_E_UNSUPPORTED,
+               "rarc_lm_yes_no_logits: hidden, inter and the fused qkv width must be multiples of 128");
+  RARC_REQUIRE(m->vocab > 0 && no_id >= 0 && yes_id >= 0 && no_id < m->vocab && yes_id < m->vocab, RARC_E_INVALID,
+               "rarc_lm_yes_no_logits: token ids outside the vocabulary");
+  const long long t_ll = (long long)n_seq * seq_len;
+  RARC_REQUIRE(t_ll % 128 == 0 && t_ll < (1ll << 31), RARC_E_UNSUPPORTED,
+               "rarc_lm_yes_no_logits: n_seq*seq_len must be a multiple of 128 (got %lld)", t_ll);
+  const int T = (int)t_ll;
+  RARC_REQUIRE(ws_bytes >= rarc_lm_workspace_bytes(m, T), RARC_E_WORKSPACE, "rarc_lm_yes_no_logits: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)d_ws;
+  const size_t th = lm_align((size_t)T * H * 2);
+  half_t* x = (half_t*)w;
+  half_t* h = (half_t*)(w + th);
+  half_t* delta = (half_t*)(w + 2 * th);
+  half_t* qkv = (half_t*)(w + 3 * th);
+  half_t* ctx = (half_t*)((char*)qkv + lm_align((size_t)T * QKV * 2));
+  half_t* gu = (half_t*)((char*)ctx + lm_align((size_t)T * QD * 2));
+  half_t* act = (half_t*)((char*)gu + lm_align((size_t)T * 2 * I * 2));
+  const int tb = (T + 3) / 4;
+
+  hipLaunchKernelGGL(rarc_lm_embed_kernel, dim3(tb), dim3(256), 0, s, d_ids, (const half_t*)m->embed, T, H, m->vocab, x);
+  RARC_HIP_CHECK(hipGetLastError());
+  const int q_blocks = (seq_len + 31) / 32, n_units = n_seq * NQ * q_blocks;
+  for (int l = 0; l < m->n_layers; ++l) {
+    const RarcLmLayer& Ly = m->layers[l];
+    // (layer 0: plain norm; later layers: the previous layer's MLP output is added here, then normed)
+    hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, l ? (const half_t*)delta : (const half_t*)nullptr,
+                       (const half_t*)Ly.in_norm, m->rms_eps, T, H, h);
+    RARC_HIP_CHECK(hipGetLastError());
+    if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, T, QKV, H, 0, stream)) return rc;
+    const int rope_units = T * (NQ + NKV);
+    if (DH == 128)
+      hipLaunchKernelGGL(rarc_lm_qknorm_rope_kernel<128>, dim3((rope_units + 3) / 4), dim3(256), 0, s, qkv,
+                         (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps, m->rope_theta, T, seq_len, NQ, NKV);
+    else
+      hipLaunchKernelGGL(rarc_lm_qknorm_rope_kernel<64>, dim3((rope_units + 3) / 4), dim3(256), 0, s, qkv,
+                         (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps, m->rope_theta, T, seq_len, NQ, NKV);
+    RARC_HIP_CHECK(hipGetLastError());
+    if (DH == 128)
+      hipLaunchKernelGGL(rarc_lm_attention_kernel<128>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const half_t*)qkv, d_start,
+                         seq_len, NQ, NKV, q_blocks, n_units, ctx);
+    else
+      hipLaunchKernelGGL(rarc_lm_attention_kernel<64>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const half_t*)qkv, d_start,
+                         seq_len, NQ, NKV, q_blocks, n_units, ctx);
+    RARC_HIP_CHECK(hipGetLastError());
+    if (int rc = rarc_enc_gemm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, T, H, QD, 0, stream)) return rc;
+    hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)Ly.post_norm,
+                       m->rms_eps, T, H, h);
+    RARC_HIP_CHECK(hipGetLastError());
+    if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu, T, 2 * I, H, 0, stream)) return rc;
+    hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(2048), dim3(256), 0, s, (const half_t*)gu, T, I, act);
+    RARC_HIP_CHECK(hipGetLastError());
+    if (int rc = rarc_enc_gemm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)delta, T, H, I, 0, stream)) return rc;
+  }
+  // the last layer's MLP output joins the residual stream (no norm output wanted: y = null)
+  hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)nullptr, m->rms_eps,
+                     T, H, (half_t*)nullptr);
+  RARC_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(rarc_lm_last_logits_kernel, dim3(n_seq), dim3(64), 0, s, (const half_t*)x, (const half_t*)m->final_norm,
+                     (const half_t*)m->lm_head, m->rms_eps, seq_len, H, no_id, yes_id, (half_t*)d_out_f16);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

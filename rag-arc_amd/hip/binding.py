@@ -37,6 +37,18 @@ class EncModel(ctypes.Structure):
                 ("layers", ctypes.POINTER(EncLayer)), ("vocab", c_int), ("max_pos", c_int)]
 
 
+class LmLayer(ctypes.Structure):
+    """RarcLmLayer (include/rarc.h): device pointers of one decoder layer."""
+    _fields_ = [(n, c_void_p) for n in ("in_norm", "qkv_w", "q_norm", "k_norm", "o_w", "post_norm", "gate_up_w", "down_w")]
+
+
+class LmModel(ctypes.Structure):
+    """RarcLmModel (include/rarc.h)."""
+    _fields_ = [("hidden", c_int), ("n_layers", c_int), ("n_q_heads", c_int), ("n_kv_heads", c_int), ("head_dim", c_int),
+                ("inter", c_int), ("vocab", c_int), ("rms_eps", c_float), ("rope_theta", c_float), ("embed", c_void_p),
+                ("lm_head", c_void_p), ("final_norm", c_void_p), ("zero_bias", c_void_p), ("layers", ctypes.POINTER(LmLayer))]
+
+
 _lock = threading.Lock()
 _lib = None
 
@@ -96,6 +108,9 @@ SIGNATURES = {
     "rarc_enc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rarc_enc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                  c_void_p]),
+    "rarc_lm_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "rarc_lm_yes_no_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                      c_void_p]),
     "rarc_profile_begin": (c_int, [c_int]),
     "rarc_profile_end": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
 }

@@ -190,10 +190,10 @@ class FlatIndexF16:
             return self.ntotal >= self.AUTO_Q8_ROWS * (max(int(k), 1) / 100.0) ** 0.7
         return self.scan == "q8"
 
-    def _prep(self, q, k: int = 100) -> None:
+    def _prep(self, q, k: int = 100, force_q8: bool = False) -> None:
         """rarc_prep_queries into the shared query block (caller holds the lock)."""
         norm = 1 if self.metric == "cosine" else 0
-        qm = self._qmeta.data_ptr() if (self._use_q8(k) and self._qmeta is not None) else 0
+        qm = self._qmeta.data_ptr() if ((force_q8 or self._use_q8(k)) and self._qmeta is not None) else 0
         B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], q.shape[0], self.dim, self.d_pad, norm,
                                            max(self.max_norm, 1.0) if norm else self.max_norm, qm,
                                            self._qbuf["qblock"].data_ptr(), self._stream()), "rarc_prep_queries")
@@ -382,15 +382,18 @@ class FlatIndexF16:
             prev_i, prev_s = out_ids[sel].contiguous(), out_sc[sel].contiguous()
             ws = self._workspace(k, scale=4)
             b = self._qbuf
-            self._prep(sub_q, k)
+            # (queries the fp16 scan flagged UNCERTAIN — its certificate cannot separate rows closer than its own
+            #  error bound, as in tight clusters — go through the int8-prefilter path, which needs no certificate)
+            use_q8 = self._use_q8(k) or (self._qmeta is not None and self.storage == "f16")
+            self._prep(sub_q, k, force_q8=use_q8)
             B.check(self.lib.rarc_qblock_set_floor(b["qblock"].data_ptr(), self.d_pad, prev_i.data_ptr(), prev_s.data_ptr(),
                                                    k, len(left), stream), "rarc_qblock_set_floor")
             new_i, new_s = t.empty_like(prev_i), t.empty_like(prev_s)
             status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)
             lo, hi = self._bins(sub_q)
-            kp = k if self._use_q8(k) else self.kprime_for(k)
+            kp = k if use_q8 else self.kprime_for(k)
             rows_ptr = self._rows.data_ptr()
-            qm = self._qmeta.data_ptr() if (self._use_q8(k) and self._qmeta is not None) else 0
+            qm = self._qmeta.data_ptr() if (use_q8 and self._qmeta is not None) else 0
             self._call_search(rows_ptr, qm, len(left), k, kp, lo, hi, new_i, new_s, status, ws, stream)
             st = status[: len(left)].cpu()
             ok = (st == 0)

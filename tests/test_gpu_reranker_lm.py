@@ -1,0 +1,85 @@
+"""The reranker's LM forward on the GPU (csrc/decoder.hip through rarc_lm_yes_no_logits) against the float32 oracle
+(oracle.qwen3_last_logits_f32, itself pinned to transformers.Qwen3ForCausalLM): seeded weights at reduced configs,
+left-padded batches.  Tolerance (fp16 weights / activations / residual stream, fp32 accumulation, as the reference's
+torch.float16 model): |logit - oracle| <= 3e-2 on logits of magnitude ~1, and the reference's final score
+p_yes = sigmoid(z_yes - z_no) within 1e-2."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed):
+    from rag_arc_amd.core.rerank import HipCausalLM
+
+    sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=seed)
+    lm = HipCausalLM(sd, NQ, NKV, DH, rms_norm_eps=1e-6, rope_theta=1e6)
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(5, V, (n, L))
+    mask = np.ones((n, L), np.int64)
+    for r in range(n):
+        p = pads[r % len(pads)]
+        mask[r, :p] = 0
+        ids[r, :p] = 0
+    no_id, yes_id = 11, 42
+    got = lm.yes_no_logits(ids, mask, no_id, yes_id).float().cpu().numpy()
+    sd16 = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    want = oracle.qwen3_last_logits_f32(sd16, dict(num_attention_heads=NQ, num_key_value_heads=NKV, head_dim=DH,
+                                                   rms_norm_eps=1e-6, rope_theta=1e6), ids, mask, [no_id, yes_id])
+    err = np.max(np.abs(got - want))
+    p_got = 1.0 / (1.0 + np.exp(-(got[:, 1] - got[:, 0])))
+    p_want = 1.0 / (1.0 + np.exp(-(want[:, 1] - want[:, 0])))
+    print(f"LM-FWD H={H} layers={LAYERS} heads={NQ}/{NKV} dh={DH} L={L}: max|dlogit|={err:.2e} "
+          f"(|logit| up to {np.abs(want).max():.2f}) max|dp_yes|={np.max(np.abs(p_got - p_want)):.2e}")
+    assert err <= 3e-2 and np.max(np.abs(p_got - p_want)) <= 1e-2
+    return got
+
+
+@pytest.mark.parametrize("H,LAYERS,NQ,NKV,DH,I,n,L,pads", [
+    (256, 2, 4, 2, 64, 512, 5, 40, (0, 7, 33, 39, 16)),        # head_dim 64, grouped K/V, ragged left padding
+    (256, 1, 2, 2, 128, 256, 4, 32, (0, 31, 1, 12)),           # head_dim 128 (every Qwen3 reranker's), no grouping
+    (512, 3, 8, 2, 64, 1024, 3, 100, (0, 60, 99)),             # four q heads per kv head; keys span four tiles
+    (1024, 2, 16, 8, 128, 3072, 8, 64, (0, 5, 20, 63)),        # Qwen3-Reranker-0.6B's layer geometry, two layers
+])
+def test_yes_no_logits_match_oracle(oracle, H, LAYERS, NQ, NKV, DH, I, n, L, pads):
+    _run(oracle, H, LAYERS, NQ, NKV, DH, I, 1000, n, L, pads, seed=H + L)
+
+
+def test_reranker_end_to_end_matches_reference_steps(oracle):
+    """rerank(): prompt format, truncation, prefix / suffix ids, left padding, batches of 8, p_yes in fp16, stable
+    descending order — the steps of core/rerank/Reranker_Qwen3.py:23-75 with a toy tokenizer."""
+    from rag_arc_amd.core.rerank import HipCausalLM, HipQwen3Reranker
+    from rag_arc_amd.core.utils.data_model import Document
+
+    H, LAYERS, NQ, NKV, DH, I, V = 256, 2, 4, 2, 64, 512, 1000
+    sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=8)
+    lm = HipCausalLM(sd, NQ, NKV, DH)
+    tok = lambda text: [5 + (ord(c) * 31 + i) % 990 for i, c in enumerate(text)]
+    prefix, suffix = [1, 2, 3], [4, 9]
+    rr = HipQwen3Reranker(lm, tok, yes_id=42, no_id=11, prefix_ids=prefix, suffix_ids=suffix, max_length=96)
+    docs = [Document(content=f"passage {i} " + "x" * (i * 7 % 50), metadata={}, id=str(i)) for i in range(19)]
+    out = rr.rerank("what is a vector index?", docs, k=7)
+    # oracle: same token sequences through the fp32 forward, fp16 score arithmetic, stable sort
+    pairs = [rr.format_instruction(None, "what is a vector index?", d.content) for d in docs]
+    room = 96 - len(prefix) - len(suffix)
+    seqs = [prefix + tok(p)[:room] + suffix for p in pairs]
+    assert max(map(len, seqs)) == 96                                     # truncation is exercised
+    scores = []
+    for s0 in range(0, len(seqs), 8):
+        chunk = seqs[s0:s0 + 8]
+        L = max(map(len, chunk))
+        ids = np.zeros((len(chunk), L), np.int64)
+        mask = np.zeros((len(chunk), L), np.int64)
+        for r, s in enumerate(chunk):
+            ids[r, L - len(s):] = s
+            mask[r, L - len(s):] = 1
+        sd16 = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in sd.items()}
+        z = oracle.qwen3_last_logits_f32(sd16, dict(num_attention_heads=NQ, num_key_value_heads=NKV, head_dim=DH), ids, mask, [11, 42])
+        scores.extend(oracle.rerank_scores_f16(z[:, 0].astype(np.float16), z[:, 1].astype(np.float16)).tolist())
+    got_scores = []
+    for s0 in range(0, len(docs), 8):
+        got_scores.extend(rr.compute_scores("what is a vector index?", [d.content for d in docs[s0:s0 + 8]]))
+    assert np.max(np.abs(np.array(got_scores) - np.array(scores, dtype=np.float64))) < 1e-2
+    want_order = oracle.stable_desc_order(np.array(got_scores))          # the order of ITS scores, stable
+    assert [d.id for d in out] == [docs[i].id for i in want_order[:7]]
+    assert len(out) == 7 and all(isinstance(d, Document) for d in out)

@@ -165,3 +165,32 @@ def test_flat_search_pinned_to_reference_float64(oracle, d):
     for b in range(X.shape[0]):
         full[b, idsA[b]] = scA[b]
     assert np.max(np.abs(full - cos)) < 2e-6
+
+
+def test_qwen3_last_logits_oracle_matches_transformers(oracle):
+    """The reranker's LM forward, restated in numpy, against transformers.Qwen3ForCausalLM with the same seeded
+    weights at a reduced config, left-padded batch: last-position logits at two token ids (the reference reads
+    exactly these, core/rerank/Reranker_Qwen3.py:41-49)."""
+    torch = pytest.importorskip("torch")
+    transformers = pytest.importorskip("transformers")
+    if not hasattr(transformers, "Qwen3ForCausalLM"):
+        pytest.skip("this transformers has no Qwen3")
+    H, LAYERS, NQ, NKV, DH, I, V = 256, 2, 4, 2, 64, 512, 1000
+    sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=3)
+    cfg = transformers.Qwen3Config(vocab_size=V, hidden_size=H, intermediate_size=I, num_hidden_layers=LAYERS,
+                                   num_attention_heads=NQ, num_key_value_heads=NKV, head_dim=DH, rms_norm_eps=1e-6,
+                                   rope_theta=1e6, tie_word_embeddings=True, attention_bias=False, max_position_embeddings=512)
+    model = transformers.Qwen3ForCausalLM(cfg).eval()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    rng = np.random.default_rng(3)
+    n, L = 5, 40
+    ids = rng.integers(5, V, (n, L))
+    mask = np.ones((n, L), np.int64)
+    for r, pad in enumerate((0, 7, 33, 39, 16)):
+        mask[r, :pad] = 0
+        ids[r, :pad] = 0
+    with torch.no_grad():
+        want = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(mask)).logits[:, -1, :][:, [11, 42]].numpy()
+    got = oracle.qwen3_last_logits_f32(sd, dict(num_attention_heads=NQ, num_key_value_heads=NKV, head_dim=DH,
+                                                rms_norm_eps=1e-6, rope_theta=1e6), ids, mask, [11, 42])
+    assert np.max(np.abs(got - want)) < 2e-4, np.max(np.abs(got - want))
