@@ -225,7 +225,7 @@ def scan_profile(lib, B, ctypes, fn, max_launches):
     return out, tot_ms.value, n_l.value
 
 
-def recorded_traffic(kernel, rows_per_launch, dim):
+def recorded_traffic(kernel, rows_per_launch, dim, storage="f16"):
     """HBM bytes per scan from the committed PMC pass of the same shape (profiles/traffic_r02.json), or None."""
     for name in ("traffic_r02.json", "traffic_r01.json"):
         path = os.path.join(ROOT, "profiles", name)
@@ -234,6 +234,7 @@ def recorded_traffic(kernel, rows_per_launch, dim):
         try:
             for ent in json.load(open(path)).get("entries", []):
                 if (ent.get("rows_per_launch") == rows_per_launch and ent.get("dim") == dim
+                        and ent.get("storage", "f16") == storage
                         and ent.get("kernel", "rarc_scan_f16_kernel") == kernel):
                     return ent.get("hbm_bytes_per_launch"), f"recorded PMC pass (profiles/{name}), not measured in this run"
         except Exception:
@@ -267,6 +268,12 @@ def main():
         return dry_run(a)
 
     import ctypes
+
+    # stdout carries ONE line, the result.  Libraries print there too (RCCL writes a version banner to stdout when
+    # its communicator goes up or down): from here on file descriptor 1 is stderr, the result goes to the real one.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -353,7 +360,7 @@ def main():
     if rank == 0:
         qps = a.batch * a.steps / dt
         ach = shard_bytes / (scan_ms * 1e-3) / 1e9
-        traffic, tsrc = recorded_traffic(kname, hi - lo, a.dim)
+        traffic, tsrc = recorded_traffic(kname, hi - lo, a.dim, a.storage)
         if traffic:
             traffic = int(traffic / launches_per_pass)
         store_txt = "fp8 (e4m3fn + row scale)" if a.storage == "f8" else "fp16"
@@ -417,7 +424,7 @@ def main():
         if rank == 0:
             result["c5"] = c5
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

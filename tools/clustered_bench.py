@@ -46,6 +46,7 @@ for scan in ("q8", "mfma16") if D <= 768 else ("q8",):
     for _ in range(5):
         idx.search_device(q, K, repair=False)
     torch.cuda.synchronize(); t_scan = (time.time() - t0) / 5
+    idx.search_device(q, K)                            # (first exact call: allocates the re-run workspace once)
     torch.cuda.synchronize(); t0 = time.time()
     ids, sc = idx.search_device(q, K)                  # with the re-run / repair of flagged queries
     torch.cuda.synchronize(); t_full = time.time() - t0
