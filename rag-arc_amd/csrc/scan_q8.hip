@@ -245,6 +245,8 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     const char* a_base = smem + buf * L::TILE + aoff;
     char* dst = smem + (buf ^ 1) * L::TILE;
     const half_t s = q8_tile_scale(nx.meta.x);
+    // (D = 1024 fp8 with PF = 4 and/or one fetch group instead of two — 230-256 VGPRs, no spill — measured the same
+    //  15.7-15.9 ms per 50M rows as this: LDS prefetch depth is not what that kernel waits for)
     constexpr int PF = (D <= 768) ? 4 : 2;
     constexpr int CSTEP = KS / CPT;  // one chunk converted every CSTEP MFMAs (KS = 4·CPT for fp16, 8·CPT for fp8)
     i32x4 a[PF];
@@ -575,19 +577,29 @@ int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t
                      const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
                      const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered, const float* floor);  // scan_f16.hip
 
-template <int D, int FMT>
+template <int D, int FMT, int ABL = 0>
 static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
   constexpr size_t lds = ScanQ8Lds<D>::TOTAL;
   static RarcPerDevice attr_done;
   if (size_t& done = attr_done.cur(); !done) {
-    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, FMT>,
+    RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, FMT, ABL>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = 1;
   }
+#ifdef RARC_Q8_ABLATIONS
+  // (measurement builds only: RARC_Q8_ABL selects an ablated instantiation of the two headline shapes — results are wrong)
+  if constexpr (ABL == 0 && ((D == 1024 && FMT == 1) || (D == 768 && FMT == 0))) {
+    static const int abl = getenv("RARC_Q8_ABL") ? atoi(getenv("RARC_Q8_ABL")) : 0;
+    if (abl == 1) return launch_scan_q8<D, FMT, 1>(p, grid, s);
+    if (abl == 4) return launch_scan_q8<D, FMT, 4>(p, grid, s);
+    if (abl == 5) return launch_scan_q8<D, FMT, 5>(p, grid, s);
+    if (abl == 9) return launch_scan_q8<D, FMT, 9>(p, grid, s);
+  }
+#endif
   hipEvent_t e0, e1;
   const bool prof = rarc_prof_next(&e0, &e1);
   if (prof) RARC_HIP_CHECK(hipEventRecord(e0, s));
-  hipLaunchKernelGGL((rarc_scan_q8_kernel<D, FMT>), dim3(grid), dim3(Q8_THREADS), lds, s, p);
+  hipLaunchKernelGGL((rarc_scan_q8_kernel<D, FMT, ABL>), dim3(grid), dim3(Q8_THREADS), lds, s, p);
   RARC_HIP_CHECK(hipGetLastError());
   if (prof) RARC_HIP_CHECK(hipEventRecord(e1, s));
   return RARC_OK;
@@ -678,7 +690,9 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
       const uint32_t t = (p.n_tiles / div[i]) / pair * pair;
       // (a stretch shorter than 8 pairs of tile rounds per workgroup costs more in launches than it saves; the
       //  1/8 cut keeps its measured limit of 16: below ~2M rows the second launch does not pay)
-      if (t >= (div[i] == 8u ? 16u : 8u) * pair && (n_cuts == 0 || t > cuts[n_cuts - 1])) cuts[n_cuts++] = t;
+      static const int min_env = getenv("RARC_SPLIT_MIN") ? atoi(getenv("RARC_SPLIT_MIN")) : 0;  // (experiments)
+      const uint32_t min_pairs = min_env > 0 ? (uint32_t)min_env : (div[i] == 8u ? 16u : 8u);
+      if (t >= min_pairs * pair && (n_cuts == 0 || t > cuts[n_cuts - 1])) cuts[n_cuts++] = t;
     }
   }
   // seed pass (fp16 MFMA on a strided sample of the whole shard): t = k'-th best sample score, accurate to eps16,

@@ -10,7 +10,8 @@ import threading
 from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB = os.path.join(_PKG, "lib", "librarc_hip.so")
+# (RARC_LIBRARY: load another build of the same ABI, e.g. a measurement build; default = the in-tree library)
+_LIB = os.environ.get("RARC_LIBRARY") or os.path.join(_PKG, "lib", "librarc_hip.so")
 
 MAX_QUERIES = 256
 MAX_K = 1024
