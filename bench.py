@@ -55,6 +55,8 @@ def parse(argv=None):
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-lm", action="store_true", help="skip the reranker LM-forward sample inside the c3 leg")
+    ap.add_argument("--lm-queries", type=int, default=8, help="queries whose top-k are reranked by the LM forward (c3.reranker_lm)")
     ap.add_argument("--c5-rows", type=int, default=0, help="rows of the config-5 corpus (0 = auto: 100M if it fits)")
     ap.add_argument("--c5-layers", type=int, default=24, help="encoder depth of the config-5 leg (bge-large: 24)")
     ap.add_argument("--verify-queries", type=int, default=32,
@@ -410,6 +412,8 @@ def main():
                                          "mfma_TFLOPs": round(2.0 * a.batch * n2 * a.dim / (scan2 * 1e-3) / 1e12, 1)}}
         if not a.no_c3:
             result["c3"] = leg_c3(torch, dist, lib, B, ctypes, idx2, q, ids2, n2, a, steps2, w2, passes_per_step, bytes2, k2)
+            if not a.no_lm:
+                result["c3"]["reranker_lm"] = leg_reranker_lm(torch, np, a, dev, local_rank)
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(np, idx2, q, ids2, sc2, n2, a)
         if idx2 is not idx:
@@ -464,6 +468,63 @@ def leg_c3(torch, dist, lib, B, ctypes, idx2, q, dense_ids, n2, a, steps, warmup
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(scan_bytes / (scan * 1e-3) / 1e9, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_bytes / (scan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "end_to_end_frac": round(scan_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
+def leg_reranker_lm(torch, np, a, dev, local_rank):
+    """The reranker's LM forward (core/rerank/Reranker_Qwen3.py:29-49) on a bounded sample: Qwen3-Reranker-0.6B's
+    geometry (28 layers, hidden 1024, 16 query / 8 key-value heads of 128, ffn 3072, vocabulary 151 669; seeded fp16
+    weights), `--lm-queries` queries x top-k (query, document) pairs of 64 tokens, left padded — the (no, yes) logits
+    of every pair in ONE rarc_lm_yes_no_logits call per query batch, then rarc_rerank_order.  Reported beside config 3's
+    seeded-logit leg, not inside its rate: a full batch of 256 queries x 100 pairs is 1.4 PFLOP of LM forward."""
+    from rag_arc_amd.core.rerank import HipCausalLM, HipLogitReranker
+
+    H, LAYERS, NQ, NKV, DH, I, V, L = 1024, 28, 16, 8, 128, 3072, 151_669, 64
+    g = torch.Generator(device=dev)
+    g.manual_seed(28)
+    rnd = lambda *shape: torch.randn(shape, generator=g, device=dev) * 0.03
+    sd = {"model.embed_tokens.weight": rnd(V, H), "model.norm.weight": 1.0 + rnd(H)}
+    for i in range(LAYERS):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"] = rnd(NQ * DH, H), rnd(NKV * DH, H)
+        sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.o_proj.weight"] = rnd(NKV * DH, H), rnd(H, NQ * DH)
+        sd[p + "self_attn.q_norm.weight"], sd[p + "self_attn.k_norm.weight"] = 1.0 + rnd(DH), 1.0 + rnd(DH)
+        sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"] = rnd(I, H), rnd(I, H), rnd(H, I)
+        sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = 1.0 + rnd(H), 1.0 + rnd(H)
+    lm = HipCausalLM(sd, NQ, NKV, DH, device=local_rank)
+    del sd
+    nqr, K = max(1, a.lm_queries), a.k
+    n_pairs = nqr * K
+    n_pairs -= n_pairs % 4
+    rng = np.random.default_rng(28)
+    ids = rng.integers(10, V, (n_pairs, L)).astype(np.int32)
+    mask = np.ones((n_pairs, L), np.int8)
+    for r in range(n_pairs):                      # ragged prompts, left padded
+        pad = int(rng.integers(0, L // 2))
+        mask[r, :pad] = 0
+        ids[r, :pad] = 0
+    rr = HipLogitReranker(lambda *_: None, device=local_rank)
+
+    def once():
+        z = lm.yes_no_logits(ids, mask, 1, 2)
+        return rr.score_order(z[:, 0].reshape(-1, K)[: n_pairs // K], z[:, 1].reshape(-1, K)[: n_pairs // K])
+
+    once()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        scores, perm = once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    tokens = n_pairs * L
+    per_tok = LAYERS * (2.0 * (H * (NQ + 2 * NKV) * DH + NQ * DH * H + H * 2 * I + I * H) + 4.0 * L * NQ * DH)
+    return {"workload": f"Qwen3-Reranker-0.6B geometry ({LAYERS} layers, seeded fp16 weights): {n_pairs} (query, document) pairs x {L} "
+                        f"tokens, left padded -> (no, yes) logits -> p_yes -> stable order; {nqr} queries x top-{K}",
+            "ms_per_call": round(dt * 1e3, 3), "pairs_per_s": round(n_pairs / dt, 1), "queries_reranked_per_s": round(n_pairs / K / dt, 2),
+            "roofline": {"bound": "mfma", "achieved": round(per_tok * tokens / dt / 1e12, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": round(per_tok * tokens / dt / 1e12 / MFMA_F16_PEAK_TF, 4), "flops_per_call": per_tok * tokens,
+                         "includes": "host-side padding + H2D of the token ids, all layers, last-position logits, rerank order"},
+            "finite": bool(torch.isfinite(scores.float()).all().item())}
 
 
 def cpu_baseline(np, idx2, q, ids2, sc2, n2, a):

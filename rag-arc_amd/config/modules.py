@@ -55,6 +55,12 @@ class HipBertEmbeddingsConfig(AbstractConfig):
     batch_size: int = 32
     layer_norm_eps: float = 1e-12
     device: int = 0
+    # sentence-transformers prompts (huggingface.py:26-37): model_kwargs 'prompts' / 'default_prompt_name',
+    # encode_kwargs 'prompt_name' / 'prompt'
+    prompts: Dict[str, str] = Field(default_factory=dict)
+    default_prompt_name: Optional[str] = None
+    prompt_name: Optional[str] = None
+    prompt: Optional[str] = None
 
     def build(self) -> AbstractModule:
         from ..encapsulation.embeddings.hip_bert import HipBertEmbeddings, HipBertEncoder, load_state_dict
@@ -67,7 +73,9 @@ class HipBertEmbeddingsConfig(AbstractConfig):
         return BuiltModule(config=self, impl=HipBertEmbeddings(enc, tok, max_length=self.max_length,
                                                                batch_size=self.batch_size,
                                                                normalize_embeddings=self.normalize_embeddings,
-                                                               pad_id=tok.pad))
+                                                               pad_id=tok.pad, prompts=self.prompts,
+                                                               default_prompt_name=self.default_prompt_name,
+                                                               prompt_name=self.prompt_name, prompt=self.prompt))
 
 
 EmbeddingsConfig = Annotated[Union[TableEmbeddingsConfig, HipBertEmbeddingsConfig], Field(discriminator="type")]

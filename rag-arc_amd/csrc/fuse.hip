@@ -44,24 +44,39 @@ __global__ __launch_bounds__(256) void rarc_rrf_kernel(const int64_t* keys, cons
     }
   }
   __syncthreads();
-  // first occurrence of every key in (list, position) order
+  // The three all-pairs sweeps below are branch-free on purpose: with early exits and conditional divisions every
+  // LDS read waited for the previous one (57 us per 256 x 200 items); as straight unrolled loops the reads pipeline.
+  // first occurrence of every key in (list, position) order; each item's own term 1.0 / (k + rank), once
   for (int t = threadIdx.x; t < n; t += blockDim.x) {
     const int64_t k = s_key[t];
     int f = t;
-    for (int u = 0; u < t; ++u)
-      if (s_key[u] == k) { f = u; break; }
+#pragma unroll 8
+    for (int u = 0; u < t; ++u) f = (s_key[u] == k && u < f) ? u : f;
     s_first[t] = f;
+    s_score[t] = 1.0 / (rrf_k + (double)s_rank[t]);   // (becomes the key's sum below, for first occurrences)
   }
   __syncthreads();
-  // score of each distinct key: sequential fp64 sum over its occurrences, in order
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    if (s_first[t] != t) continue;
-    const int64_t k = s_key[t];
-    double s = 0.0;
-    for (int u = t; u < n; ++u)
-      if (s_key[u] == k) s += 1.0 / (rrf_k + (double)s_rank[u]);
-    s_score[t] = s;
-    atomicAdd(&s_nuniq, 1);
+  // score of each distinct key: sequential fp64 sum over its occurrences, in order (adding 0.0 for the others
+  // leaves every partial sum bit for bit what the reference's `+=` over the occurrences alone produces)
+  double my_sum[(RRF_MAX_ITEMS + 255) / 256];
+  {
+    int j = 0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x, ++j) {
+      const int64_t k = s_key[t];
+      double s = 0.0;
+#pragma unroll 8
+      for (int u = 0; u < n; ++u) s += (u >= t && s_key[u] == k) ? s_score[u] : 0.0;
+      my_sum[j] = s;
+    }
+  }
+  __syncthreads();  // every term has been read before any is overwritten by a sum
+  {
+    int j = 0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x, ++j) {
+      if (s_first[t] != t) continue;
+      s_score[t] = my_sum[j];
+      atomicAdd(&s_nuniq, 1);
+    }
   }
   __syncthreads();
   // stable descending order by counting: position = #{distinct u better than t}
@@ -69,10 +84,10 @@ __global__ __launch_bounds__(256) void rarc_rrf_kernel(const int64_t* keys, cons
     if (s_first[t] != t) continue;
     const double s = s_score[t];
     int pos = 0;
+#pragma unroll 8
     for (int u = 0; u < n; ++u) {
-      if (s_first[u] != u || u == t) continue;
       const double su = s_score[u];
-      pos += (su > s) || (su == s && u < t);
+      pos += (s_first[u] == u && u != t && ((su > s) || (su == s && u < t))) ? 1 : 0;
     }
     if (pos < top_k) {
       out_keys[(size_t)b * top_k + pos] = s_key[t];

@@ -162,11 +162,22 @@ class HipBertEmbeddings(Embeddings):
     """Embeddings provider: tokenizer callable + HipBertEncoder."""
 
     def __init__(self, encoder: HipBertEncoder, tokenize: Callable[[str], Sequence[int]], max_length: int = 512,
-                 batch_size: int = 32, normalize_embeddings: bool = True, pad_id: int = 0, **kwargs):
+                 batch_size: int = 32, normalize_embeddings: bool = True, pad_id: int = 0,
+                 prompts: Optional[Dict[str, str]] = None, default_prompt_name: Optional[str] = None,
+                 prompt_name: Optional[str] = None, prompt: Optional[str] = None, **kwargs):
         super().__init__(**kwargs)
         self.encoder, self.tokenize = encoder, tokenize
         self.max_length, self.batch_size = min(max_length, encoder.max_pos), batch_size
         self.normalize, self.pad_id = normalize_embeddings, pad_id
+        # sentence-transformers prompts, as the reference passes them (huggingface.py:26-37: model_kwargs
+        # 'prompts' / 'default_prompt_name', encode_kwargs 'prompt_name' / 'prompt'): a string put in front of
+        # every text before tokenisation; `prompt` wins over `prompt_name`, which wins over the default
+        self.prompts = dict(prompts or {})
+        for name in (default_prompt_name, prompt_name):
+            if name is not None and name not in self.prompts:
+                raise ValueError(f"prompt name {name!r} not found in the configured prompts {sorted(self.prompts)}")
+        self.prompt = prompt if prompt is not None else self.prompts.get(prompt_name if prompt_name is not None
+                                                                          else default_prompt_name, None)
 
     def embed_documents_device(self, texts: List[str]):
         """Same embeddings as embed_documents, left on the device as one fp32 tensor [n][hidden]
@@ -174,6 +185,8 @@ class HipBertEmbeddings(Embeddings):
         VectorStore_Faiss.py:169-170)."""
         t = self.encoder.torch
         texts = [x.replace("\n", " ") for x in texts]
+        if self.prompt:
+            texts = [self.prompt + x for x in texts]
         out = t.empty((len(texts), self.encoder.hidden), dtype=t.float32, device=self.encoder.device)
         order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))   # longest first, like sentence-transformers
         for s in range(0, len(order), self.batch_size):

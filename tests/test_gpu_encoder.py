@@ -184,6 +184,15 @@ def test_embeddings_provider_contract(oracle):
     q = emb.embed_query("gamma delta")
     assert np.allclose(q, vecs[3], atol=2e-3)                      # batch composition does not matter
     assert np.allclose(emb.embed_query("x\ny"), emb.embed_query("x y"), atol=1e-6)   # newline -> space
+    # sentence-transformers prompts (huggingface.py:26-37): the prompt string goes in front of the text
+    enc = emb.encoder
+    pq = HipBertEmbeddings(enc, tok, batch_size=4, prompts={"query": "ask: ", "passage": "doc: "}, default_prompt_name="query")
+    assert np.allclose(pq.embed_query("gamma"), emb.embed_query("ask: gamma"), atol=1e-6)
+    pp = HipBertEmbeddings(enc, tok, batch_size=4, prompts={"query": "ask: ", "passage": "doc: "}, default_prompt_name="query",
+                           prompt_name="passage")
+    assert np.allclose(pp.embed_query("gamma"), emb.embed_query("doc: gamma"), atol=1e-6)
+    with pytest.raises(ValueError):
+        HipBertEmbeddings(enc, tok, prompts={"query": "q"}, prompt_name="nope")
 
 
 def test_store_ingests_device_embeddings_without_round_trip(oracle):
