@@ -305,7 +305,8 @@ int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_r
  *   rarc_enc_attention: ctx = softmax(Q K^T / sqrt(dh) + key mask) V per (sequence, head) from the
  *                       fused qkv [n_seq*seq_len][3*hidden]; keys >= d_lens[seq] are masked; dh 32 or 64
  *   rarc_enc_add_ln   : out = LayerNorm(x + resid)
- *   rarc_enc_pool     : out[b] = hidden[b*seq_len + 0] as fp32 (optionally L2-normalised)
+ *   rarc_enc_pool     : out[b] = hidden[b*seq_len + 0] as fp32 (optionally L2-normalised)          [CLS pooling]
+ *   rarc_enc_pool_mean: out[b] = mean over the d_lens[b] real tokens of hidden[b*seq_len + t], fp32  [mean pooling]
  */
 int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,
                       const uint16_t* d_type0, const uint16_t* d_gamma, const uint16_t* d_beta, float eps,
@@ -318,11 +319,14 @@ int rarc_enc_add_ln(const uint16_t* d_x, const uint16_t* d_resid, const uint16_t
                     const uint16_t* d_beta, float eps, int n_rows, int hidden, uint16_t* d_out, void* stream);
 int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, int hidden, int normalize,
                   float* d_out, void* stream);
+int rarc_enc_pool_mean(const uint16_t* d_hidden, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
+                       int normalize, float* d_out, void* stream);
 
 /*
  * Whole encoder forward in one call: the launch loop over the layers runs on the host side of this
  * library, not in the caller (at small batches the per-call overhead of a foreign-function binding is
  * longer than the kernels).  `model` and `model->layers` are HOST structs of DEVICE pointers.
+ * `normalize`: bit 0 = L2-normalise the pooled vector, bit 1 = mean pooling over the real tokens instead of CLS.
  * n_seq*seq_len must be a multiple of 128 (pad seq_len to a multiple of 32 with masked tokens and n_seq to a
  * multiple of 4 with sequences of length 1); d_lens[s] in [1, seq_len] (clamped into that range).  d_ws: scratch of
  * rarc_enc_workspace_bytes(hidden, inter, n_seq*seq_len) bytes.  d_out: fp32 [n_seq][hidden].

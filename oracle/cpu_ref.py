@@ -315,7 +315,7 @@ def stable_desc_order(scores: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------- encoder
-def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=True):
+def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=True, pooling="cls"):
     """BERT encoder forward in float32 numpy, CLS pooling (what SentenceTransformer.encode computes
     for bge-style models reached from huggingface.py:122-126).  `sd` = HuggingFace BertModel state
     dict (numpy arrays).  Pinned against transformers.BertModel in tests/test_oracle_golden.py."""
@@ -360,7 +360,11 @@ def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=Tru
         h = 0.5 * h * (1.0 + erf(h / np.sqrt(2.0)))
         x = ln(lin(h.astype(np.float32), "output.dense") + x, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))
         i += 1
-    cls = x[:, 0, :].astype(np.float32)
+    if pooling == "mean":   # sentence-transformers Pooling(mode_mean_tokens): mean over the attention-masked tokens
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)[:, :, None]
+        cls = ((x * m).sum(1) / m.sum(1)).astype(np.float32)
+    else:
+        cls = x[:, 0, :].astype(np.float32)
     return normalize_L2(cls) if normalize else cls
 
 

@@ -50,6 +50,7 @@ class HipBertEmbeddingsConfig(AbstractConfig):
     vocab_path: str
     num_heads: int
     normalize_embeddings: bool = True     # bge models: True (encode_kwargs={"normalize_embeddings": True})
+    pooling: Literal["cls", "mean"] = "cls"   # the checkpoint's sentence-transformers pooling module: bge = cls
     do_lower_case: bool = True
     max_length: int = 512
     batch_size: int = 32
@@ -67,7 +68,7 @@ class HipBertEmbeddingsConfig(AbstractConfig):
         from ..encapsulation.embeddings.wordpiece import WordPieceTokenizer
 
         enc = HipBertEncoder(load_state_dict(self.weights_path), num_heads=self.num_heads,
-                             layer_norm_eps=self.layer_norm_eps, device=self.device)
+                             layer_norm_eps=self.layer_norm_eps, device=self.device, pooling=self.pooling)
         tok = WordPieceTokenizer.from_file(self.vocab_path, do_lower_case=self.do_lower_case,
                                            max_length=min(self.max_length, enc.max_pos))
         return BuiltModule(config=self, impl=HipBertEmbeddings(enc, tok, max_length=self.max_length,

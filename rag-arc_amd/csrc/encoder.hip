@@ -1045,6 +1045,37 @@ __global__ __launch_bounds__(64) void rarc_pool_kernel(const half_t* hidden, int
   for (int c = lane; c < H; c += 64) out[(size_t)b * H + c] = (float)x[c] * inv;
 }
 
+// Mean pooling over the sequence's real tokens (sentence-transformers' default for all-MiniLM / gte style models):
+// out[b] = sum_{t < len} hidden[b, t] / len in fp32, then the optional L2 normalisation (canonical order: the sum of
+// squares of the pooled fp32 vector runs through the same 8 chains).  One workgroup per sequence.
+__global__ __launch_bounds__(256) void rarc_pool_mean_kernel(const half_t* hidden, const int32_t* lens, int L, int H,
+                                                             int normalize, float* out) {
+  __shared__ float s_vec[1024];
+  __shared__ float s_nr;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
+  const half_t* x = hidden + (size_t)b * L * H;
+  for (int c = tid; c < H; c += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < len; ++t) acc += (float)x[(size_t)t * H + c];   // token order: fixed, sequential
+    s_vec[c] = acc / (float)len;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float acc = 0.f;
+    if (tid < 8)
+      for (int m2 = tid; m2 < H; m2 += 8) acc = __builtin_fmaf(s_vec[m2], s_vec[m2], acc);
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = __shfl(acc, i, 64);
+    if (tid == 0) s_nr = rarc_canon_tree(a);
+  }
+  __syncthreads();
+  const float nr = s_nr;
+  const float inv = (normalize && nr > 0.f) ? (float)(1.0 / (double)(float)sqrt((double)nr)) : 1.f;
+  for (int c = tid; c < H; c += 256) out[(size_t)b * H + c] = s_vec[c] * inv;
+}
+
 // ------------------------------------------------------------------------------------------
 static int gemm_attrs() {
   constexpr int lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
@@ -1206,6 +1237,16 @@ extern "C" int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, i
   return RARC_OK;
 }
 
+extern "C" int rarc_enc_pool_mean(const uint16_t* d_hidden, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
+                                  int normalize, float* d_out, void* stream) {
+  RARC_REQUIRE(d_hidden && d_lens && d_out && n_seq > 0 && seq_len > 0 && hidden % 8 == 0 && hidden <= 1024, RARC_E_INVALID,
+               "rarc_enc_pool_mean: bad arguments");
+  hipLaunchKernelGGL(rarc_pool_mean_kernel, dim3(n_seq), dim3(256), 0, (hipStream_t)stream, (const half_t*)d_hidden, d_lens,
+                     seq_len, hidden, normalize, d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Whole forward: the per-layer launch loop, issued from here so that a caller pays one foreign call
 // ------------------------------------------------------------------------------------------
@@ -1272,5 +1313,6 @@ extern "C" int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids,
     rc = proj_ln(mid, L.f2_w, L.f2_b, I, s_f2, L.ln2_g, L.ln2_b);
   }
   if (rc != RARC_OK) return rc;
-  return rarc_enc_pool(x, n_seq, seq_len, H, normalize, d_out, stream);
+  if (normalize & 2) return rarc_enc_pool_mean(x, d_lens, n_seq, seq_len, H, normalize & 1, d_out, stream);
+  return rarc_enc_pool(x, n_seq, seq_len, H, normalize & 1, d_out, stream);
 }

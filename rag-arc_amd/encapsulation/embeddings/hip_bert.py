@@ -37,7 +37,7 @@ class HipBertEncoder:
     """token ids [n_seq][seq_len] (+ lengths) -> fp32 embeddings [n_seq][hidden] on the device."""
 
     def __init__(self, state_dict: Dict[str, "np.ndarray"], num_heads: int, layer_norm_eps: float = 1e-12,
-                 device: int = 0):
+                 device: int = 0, pooling: str = "cls"):
         import torch
 
         if not torch.cuda.is_available():
@@ -45,6 +45,9 @@ class HipBertEncoder:
         self.torch, self.lib = torch, B.load_library()
         self.device = torch.device("cuda", device)
         self.eps = float(layer_norm_eps)
+        if pooling not in ("cls", "mean"):
+            raise ValueError("pooling must be 'cls' (bge) or 'mean' (all-MiniLM / gte style)")
+        self._pool_bit = 2 if pooling == "mean" else 0
         sd = {k.replace("bert.", "", 1) if k.startswith("bert.") else k: v for k, v in state_dict.items()}
 
         def f16(name):
@@ -129,7 +132,7 @@ class HipBertEncoder:
             out = t.empty((n_pad, H), dtype=t.float32, device=self.device)
             # one foreign call per forward: the layer loop runs inside librarc_hip.so
             B.check(self.lib.rarc_enc_forward(ctypes.addressof(self._model), d_ids.data_ptr(), d_lens.data_ptr(), n_pad, L,
-                                              1 if normalize else 0, self._ws.data_ptr(), self._ws.numel(),
+                                              (1 if normalize else 0) | self._pool_bit, self._ws.data_ptr(), self._ws.numel(),
                                               out.data_ptr(), st), "rarc_enc_forward")
             return out[:n_seq]
 
@@ -152,7 +155,7 @@ class HipBertEncoder:
                 self._ws = t.empty(need, dtype=t.uint8, device=self.device)
             out = t.empty((n_seq, self.hidden), dtype=t.float32, device=self.device)
             B.check(self.lib.rarc_enc_forward(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
-                                              d_lens.contiguous().data_ptr(), n_seq, L, 1 if normalize else 0,
+                                              d_lens.contiguous().data_ptr(), n_seq, L, (1 if normalize else 0) | self._pool_bit,
                                               self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), st),
                     "rarc_enc_forward")
             return out

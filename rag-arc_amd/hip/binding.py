@@ -106,6 +106,7 @@ SIGNATURES = {
     "rarc_enc_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc_add_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc_pool": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "rarc_enc_pool_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rarc_enc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                  c_void_p]),

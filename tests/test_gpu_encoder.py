@@ -107,6 +107,25 @@ def test_token_ids_and_lengths_are_validated(oracle):
     assert np.max(np.abs(a - want)) <= 4e-3
 
 
+def test_mean_pooling_matches_oracle(oracle):
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+
+    sd = oracle.random_bert_state_dict(384, 2, 12, 1536, vocab=500, max_pos=64, seed=21)
+    enc = HipBertEncoder(sd, num_heads=12, pooling="mean")
+    rng = np.random.default_rng(21)
+    ids = rng.integers(1, 500, (7, 24)).astype(np.int32)
+    lens = np.array([24, 1, 5, 17, 24, 9, 2], np.int32)
+    for r, l in enumerate(lens):
+        ids[r, l:] = 0
+    sd16 = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    for norm in (True, False):
+        got = enc.forward(ids, lens, normalize=norm).cpu().numpy()
+        want = oracle.bert_forward_f32(sd16, ids, lens, 12, normalize=norm, pooling="mean")
+        assert np.max(np.abs(got - want)) <= (4e-3 if norm else 2e-2)
+        cos = np.sum(got * want, axis=1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+        assert cos.min() >= 0.9995
+
+
 def test_gemm_kernel_alone(oracle):
     """A=I check with asymmetric W (catches transposes), then random data with bias + GELU."""
     import torch

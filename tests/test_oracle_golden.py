@@ -124,9 +124,15 @@ def test_bert_oracle_matches_transformers(oracle):
         ids[r, l:] = 0
     att = (np.arange(24)[None, :] < lens[:, None]).astype(np.int64)
     with torch.no_grad():
-        want = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(att)).last_hidden_state[:, 0].numpy()
+        hs = model(input_ids=torch.from_numpy(ids), attention_mask=torch.from_numpy(att)).last_hidden_state
+    want = hs[:, 0].numpy()
     got = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=False)
     assert np.max(np.abs(got - want)) < 2e-5
+    # mean pooling as sentence-transformers' Pooling(mode_mean_tokens): masked sum / token count
+    m = torch.from_numpy(att).float()[:, :, None]
+    want_mean = ((hs * m).sum(1) / m.sum(1)).numpy()
+    got_mean = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=False, pooling="mean")
+    assert np.max(np.abs(got_mean - want_mean)) < 2e-5
 
 
 # ---- tight pin of the flat-search arithmetic: the reference's float64 numbers on 64 x 4096 vectors ---------------
