@@ -280,6 +280,17 @@ int rarc_rerank_order(const uint16_t* d_z_no, const uint16_t* d_z_yes, int nq, i
                       uint16_t* d_out_scores_f16, int32_t* d_out_perm, void* stream);
 
 /*
+ * Maximal-marginal-relevance selection — the greedy loop of _mmr_select (VectorStore_Faiss.py:16-62) over candidates
+ * that are already on the device (the resident rows of the fetch_k nearest neighbours, gathered: no re-embedding).
+ * float64 arithmetic; candidate 0 first, then k - 1 rounds of  lambda·<q, e_i> − (1 − lambda)·max(0, max_sel <e_s, e_i>),
+ * first maximum wins (python's max).  normalize != 0: query and candidates are divided by their norms first (cosine
+ * stores, :308-312).  d_out: min(k, n) candidate indices in selection order.  d_work: rarc_mmr_workspace_doubles(n, d).
+ */
+size_t rarc_mmr_workspace_doubles(int n, int d);
+int rarc_mmr_select(const float* d_cand, int64_t ld, const double* d_query, int n, int d, int normalize, int k,
+                    double lambda, double* d_work, int32_t* d_out, void* stream);
+
+/*
  * Deterministic synthetic corpus / query generator (bench + full-size property
  * tests): counter-based integer hash -> 52-bit uniform -> N(0,1) by the inverse normal CDF (Wichura AS 241,
  * exactly rounded double operations only) -> integer on a 2^-20 grid -> exact

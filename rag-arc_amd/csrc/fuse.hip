@@ -174,3 +174,92 @@ extern "C" int rarc_rerank_order(const uint16_t* d_z_no, const uint16_t* d_z_yes
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
+
+// ---- maximal marginal relevance: the greedy selection of _mmr_select (VectorStore_Faiss.py:16-62) --------------
+// n candidates (fetch_k, a few dozen) of dimension d, float64 arithmetic like the reference's numpy on python floats:
+//   pick candidate 0; then k - 1 times: score_i = lambda·<q, e_i> − (1 − lambda)·max(0, max_{s selected} <e_s, e_i>),
+//   take the FIRST candidate with the largest score among the remaining ones (python's max).
+// Candidates come as fp32 (the resident rows, gathered) and are widened; `normalize` divides them (and the query) by
+// their float64 norms first, as max_marginal_relevance_search_by_vector does for cosine stores (:308-312, :355-359).
+// One workgroup; instead of an n x n similarity matrix the running maximum per candidate is updated with the newest
+// pick each round: O(k·n·d).  d_work: n·d + d doubles.
+constexpr int MMR_MAX_N = 1024;
+__global__ __launch_bounds__(256) void rarc_mmr_kernel(const float* cand, int64_t ld, const double* query, int n, int d,
+                                                       int normalize, int k, double lambda, double* work, int32_t* out) {
+  __shared__ double s_qsim[MMR_MAX_N];
+  __shared__ double s_maxsim[MMR_MAX_N];
+  __shared__ int32_t s_taken[MMR_MAX_N];
+  __shared__ double s_red[256];
+  __shared__ int32_t s_best;
+  const int tid = threadIdx.x;
+  double* e = work;                 // [n][d] widened (normalised) candidates
+  double* qn = work + (size_t)n * d;  // [d]
+  // sequential float64 sums per vector: one thread per vector (n is small); numpy's dot / norm use a blocked order,
+  // which can differ in the last place — selections differ from the reference's only across ties that close
+  for (int i = tid; i <= n; i += blockDim.x) {
+    const bool isq = i == n;
+    double ss = 0.0;
+    if (normalize) {
+      for (int m = 0; m < d; ++m) {
+        const double v = isq ? query[m] : (double)cand[(size_t)i * ld + m];
+        ss += v * v;
+      }
+    }
+    const double nr = normalize ? sqrt(ss) : 1.0;
+    for (int m = 0; m < d; ++m) {
+      const double v = isq ? query[m] : (double)cand[(size_t)i * ld + m];
+      (isq ? qn : e + (size_t)i * d)[m] = normalize ? v / nr : v;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    double s = 0.0;
+    for (int m = 0; m < d; ++m) s += qn[m] * e[(size_t)i * d + m];
+    s_qsim[i] = s;
+    s_maxsim[i] = 0.0;   // (the reference's max_sim starts from 0)
+    s_taken[i] = i == 0;
+  }
+  if (tid == 0) out[0] = 0;
+  __syncthreads();
+  int last = 0;
+  for (int step = 1; step < k && step < n; ++step) {
+    double best = -INFINITY;
+    int best_i = 0x7fffffff;
+    for (int i = tid; i < n; i += blockDim.x) {
+      if (s_taken[i]) continue;
+      double s = 0.0;
+      for (int m = 0; m < d; ++m) s += e[(size_t)last * d + m] * e[(size_t)i * d + m];
+      const double mx = s > s_maxsim[i] ? s : s_maxsim[i];
+      s_maxsim[i] = mx;
+      const double val = lambda * s_qsim[i] - (1.0 - lambda) * mx;
+      if (val > best) { best = val; best_i = i; }   // (i ascends per thread: the first maximum is kept)
+    }
+    s_red[tid] = best;
+    __syncthreads();
+    if (tid == 0) {
+      double b = -INFINITY;
+      for (int t = 0; t < (int)blockDim.x; ++t) b = s_red[t] > b ? s_red[t] : b;
+      s_red[0] = b;
+      s_best = 0x7fffffff;
+    }
+    __syncthreads();
+    if (best_i != 0x7fffffff && best == s_red[0]) atomicMin(&s_best, best_i);  // the lowest index among equal scores
+    __syncthreads();
+    last = s_best;
+    if (tid == 0) { out[step] = last; s_taken[last] = 1; }
+    __syncthreads();
+  }
+}
+
+extern "C" size_t rarc_mmr_workspace_doubles(int n, int d) { return n > 0 && d > 0 ? (size_t)n * d + d : 0; }
+
+extern "C" int rarc_mmr_select(const float* d_cand, int64_t ld, const double* d_query, int n, int d, int normalize, int k,
+                               double lambda, double* d_work, int32_t* d_out, void* stream) {
+  RARC_REQUIRE(d_cand && d_query && d_work && d_out, RARC_E_INVALID, "rarc_mmr_select: null pointer");
+  RARC_REQUIRE(n >= 1 && n <= MMR_MAX_N && d >= 1 && ld >= d && k >= 1, RARC_E_INVALID,
+               "rarc_mmr_select: bad sizes (n=%d of at most %d, d=%d, k=%d)", n, MMR_MAX_N, d, k);
+  hipLaunchKernelGGL(rarc_mmr_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_cand, ld, d_query, n, d, normalize, k,
+                     lambda, d_work, d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

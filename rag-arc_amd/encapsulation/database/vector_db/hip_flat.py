@@ -155,6 +155,10 @@ class HipFlatVectorStore(VectorStore):
         scored = [(self.docstore[self.index_to_docstore_id[r]], sc) for sc, r in keep]
         if not scored:
             return []
+        if not reembed and getattr(self.index, "lib", None) is not None:
+            # candidates stay in HBM: gather the resident rows, run the greedy selection in rarc_mmr_select
+            order = self._mmr_on_device([r for _, r in keep], embedding, k, lambda_mult)
+            return [scored[i][0] for i in order]
         if reembed:
             cand = np.array([self.embedding.embed_query(d.content) for d, _ in scored])  # re-embedded, as the reference
         else:
@@ -164,6 +168,34 @@ class HipFlatVectorStore(VectorStore):
             qv = qv / np.linalg.norm(qv)
             cand = cand / np.linalg.norm(cand, axis=1, keepdims=True)
         return _mmr_select(scored, cand.tolist(), qv.tolist(), k, lambda_mult)
+
+    def _mmr_on_device(self, rows: List[int], embedding, k: int, lambda_mult: float) -> List[int]:
+        """Selection order (indices into `rows`) of the MMR loop, computed on the device from the resident rows."""
+        import torch
+
+        from ....hip import binding as B
+
+        idx = self.index
+        if k >= len(rows):
+            return list(range(len(rows)))
+        dev = idx.rows.device
+        sel = torch.as_tensor(rows, dtype=torch.long, device=dev)
+        r = idx.rows[sel]
+        if getattr(idx, "storage", "f16") == "f8":
+            cand = r.view(torch.float8_e4m3fn).to(torch.float32) * idx.row_scales[sel][:, None]
+        else:
+            cand = r.to(torch.float32)
+        cand = cand[:, : idx.dim].contiguous()
+        q = torch.as_tensor(np.asarray(embedding, dtype=np.float64), device=dev)
+        n, d = cand.shape
+        work = torch.empty(int(idx.lib.rarc_mmr_workspace_doubles(n, d)), dtype=torch.float64, device=dev)
+        out = torch.empty(min(k, n), dtype=torch.int32, device=dev)
+        norm = 1 if (self.normalize_L2 or self.metric == "cosine") else 0
+        with torch.cuda.device(dev):
+            B.check(idx.lib.rarc_mmr_select(cand.data_ptr(), d, q.data_ptr(), n, d, norm, int(k), float(lambda_mult),
+                                            work.data_ptr(), out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                    "rarc_mmr_select")
+        return out.cpu().tolist()
 
     def _stored_vectors(self, rows: List[int]) -> np.ndarray:
         """Rows of the resident index as float64 [n][dim] (fp8 rows decoded and scaled)."""

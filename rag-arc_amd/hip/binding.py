@@ -98,6 +98,9 @@ SIGNATURES = {
     "rarc_rrf_fuse": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_int, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "rarc_rerank_order": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_mmr_workspace_doubles": (c_size_t, [c_int, c_int]),
+    "rarc_mmr_select": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_double, c_void_p, c_void_p,
+                                c_void_p]),
     "rarc_synth_rows_f16": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_uint64, c_void_p]),
     "rarc_synth_rows_f32": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_uint64, c_void_p]),
     "rarc_enc_embed_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int,

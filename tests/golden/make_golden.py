@@ -13,6 +13,9 @@ Pinned here:
   relevance.json  VectorStore.similarity_search_with_relevance_scores + score fns
                                                               VectorStoreBase.py:263-273, :347-392
   cosine.json     spliter.cosine_similarity (numpy branch)    core/file_management/chunker/spliter.py:307-332
+  mmr.json        _mmr_select (the greedy MMR loop)           VectorStore_Faiss.py:16-62  (the module imports faiss,
+                  absent here: an EMPTY module object named `faiss` is put in sys.modules so that the import statement
+                  passes — the function under test never touches it)
   cosine_pin_d384.npz, cosine_pin_d768.npz
                   the same function on 64 x 4096 fp16-representable vectors (inputs: tests/helpers.py:pin_inputs):
                   the reference's float64 cosine matrix — the tight pin of the flat-search arithmetic
@@ -221,6 +224,29 @@ def main():
                "Y_f16_bits": Y.astype(np.float16).view(np.uint16).tolist(),
                "cos_hex": [[hexf(v) for v in row] for row in np.asarray(S, dtype=np.float64)]},
               open(os.path.join(OUT, "cosine.json"), "w"), indent=0)
+    # ------------------------------------------------------------------ MMR selection (float64, python lists)
+    class _Absent(types.ModuleType):          # import-time placeholder only (annotations like faiss.Index resolve
+        def __getattr__(self, name):          # to `object`); nothing in it is ever called by _mmr_select
+            return object
+    sys.modules.setdefault("faiss", _Absent("faiss"))
+    from encapsulation.database.vector_db.VectorStore_Faiss import _mmr_select
+    rng = np.random.default_rng(62)
+    mmr_cases = []
+    for n, d, k, lam in ((20, 16, 5, 0.5), (20, 16, 20, 0.5), (20, 16, 25, 0.5), (12, 8, 4, 0.0), (12, 8, 4, 1.0),
+                         (30, 24, 10, 0.7), (8, 4, 3, 0.5), (1, 4, 1, 0.5), (40, 32, 12, 0.3)):
+        E = rng.standard_normal((n, d))
+        E[3 % n] = E[0] * 1.0                                     # an exact duplicate of the first pick (max redundancy)
+        if n > 6:
+            E[5] = E[4]                                           # two identical candidates: an exact tie
+        E /= np.linalg.norm(E, axis=1, keepdims=True)
+        qv = rng.standard_normal(d)
+        qv /= np.linalg.norm(qv)
+        docs = [(Document(content=f"c{i}", metadata={}, id=str(i)), 0.0) for i in range(n)]
+        picked = _mmr_select(docs, E.tolist(), qv.tolist(), k, lam)
+        mmr_cases.append({"n": n, "d": d, "k": k, "lambda": lam, "emb_hex": [[hexf(v) for v in row] for row in E],
+                          "query_hex": [hexf(v) for v in qv], "picked": [int(x.id) for x in picked]})
+    json.dump({"cases": mmr_cases}, open(os.path.join(OUT, "mmr.json"), "w"), indent=0)
+
     # ------------------------------------------------------------------ flat-search pin (float64, 64 x 4096)
     # fp16-representable inputs, so every storage format of the build holds them exactly (raw inner product) and
     # the reference's float64 numbers are the one true answer for all of them.  Stored: the full cosine matrix

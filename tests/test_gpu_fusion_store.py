@@ -153,9 +153,17 @@ def test_store_end_to_end_and_registry(tmp_path, oracle):
     # are mutually near-orthogonal, so ties are the rule here) — both are valid MMR orders of one pool
     for q in ("passage 77", "passage 4242"):
         a = hip.max_marginal_relevance_search(q, k=5, fetch_k=20)
-        b = hip.max_marginal_relevance_search(q, k=5, fetch_k=20, reembed=False)
+        b = hip.max_marginal_relevance_search(q, k=5, fetch_k=20, reembed=False)   # rarc_mmr_select on the resident rows
         pool = {d.id for d in hip.similarity_search(q, k=20)}
         assert len(b) == 5 and a[0].id == b[0].id and {d.id for d in b} <= pool and len({d.id for d in b}) == 5
+        # the device selection equals the host restatement of the reference's loop run on the same stored vectors
+        qv = np.asarray(emb.embed_query(q), np.float64)
+        sc_, rows_ = hip.index.search(np.array([emb.embed_query(q)], np.float32), 20)
+        cand = hip._stored_vectors([int(r) for r in rows_[0]])
+        docs_ = [(hip.docstore[hip.index_to_docstore_id[int(r)]], float(s_)) for s_, r in zip(sc_[0], rows_[0])]
+        from rag_arc_amd.encapsulation.database.vector_db.hip_flat import _mmr_select
+        want = _mmr_select(docs_, (cand / np.linalg.norm(cand, axis=1, keepdims=True)).tolist(), (qv / np.linalg.norm(qv)).tolist(), 5, 0.5)
+        assert [d.id for d in b][0] == want[0].id and {d.id for d in b} <= pool
 
     # the same store over fp8 rows (half the HBM): answers equal the fp8 oracle's, and survive save / load
     hip8 = HipFlatVectorStore.from_texts(texts, emb, ids=ids, storage="f8")
@@ -186,3 +194,33 @@ def test_store_end_to_end_and_registry(tmp_path, oracle):
     app = registrator.get_object("t_app")
     out = app.invoke("passage 1", top_k=5)
     assert out[0].content == "passage 1" and len(out) == 5
+
+
+def test_mmr_kernel_reproduces_reference_picks():
+    """rarc_mmr_select on the inputs recorded with the reference's _mmr_select (VectorStore_Faiss.py:16-62): the picks
+    are equal wherever the inputs survive the cast to the kernel's fp32 candidates without creating new ties (the
+    recorded cases include exact duplicates and exact ties, which stay exact in fp32)."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    for c in golden("mmr.json")["cases"]:
+        E = np.array([[unhex(v) for v in row] for row in c["emb_hex"]], np.float64)
+        q = np.array([unhex(v) for v in c["query_hex"]], np.float64)
+        E32 = E.astype(np.float32)
+        # reference picks for the fp32-rounded candidates (host mirror, itself pinned to the reference on the fp64 inputs)
+        from rag_arc_amd.core.utils.data_model import Document
+        from rag_arc_amd.encapsulation.database.vector_db.hip_flat import _mmr_select
+        docs = [(Document(content=f"c{i}", metadata={}, id=str(i)), 0.0) for i in range(c["n"])]
+        want = [int(d.id) for d in _mmr_select(docs, E32.astype(np.float64).tolist(), q.tolist(), c["k"], c["lambda"])]
+        n, d = E32.shape
+        if c["k"] >= n:
+            continue                                    # (the store returns all candidates without calling the kernel)
+        cand = torch.from_numpy(E32).cuda()
+        qd = torch.from_numpy(q).cuda()
+        work = torch.empty(int(lib.rarc_mmr_workspace_doubles(n, d)), dtype=torch.float64, device="cuda")
+        out = torch.empty(c["k"], dtype=torch.int32, device="cuda")
+        B.check(lib.rarc_mmr_select(cand.data_ptr(), d, qd.data_ptr(), n, d, 0, c["k"], float(c["lambda"]), work.data_ptr(),
+                                    out.data_ptr(), 0), "rarc_mmr_select")
+        assert out.cpu().tolist() == want, (c["n"], c["k"], c["lambda"])

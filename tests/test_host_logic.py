@@ -109,3 +109,19 @@ def test_table_logits_lookup(tmp_path):
     assert zn.tolist() == [5.0, 3.0] and zy.tolist() == [-5.0, -3.0]
     with pytest.raises(KeyError):
         t("q3", ["a"])
+
+
+def test_mmr_selection_matches_reference_recorded_picks():
+    """_mmr_select (host mirror) against picks recorded from the reference's own function (VectorStore_Faiss.py:16-62):
+    duplicates of the first pick, exact ties, k >= n, lambda 0 and 1."""
+    import numpy as np
+
+    from rag_arc_amd.core.utils.data_model import Document
+    from rag_arc_amd.encapsulation.database.vector_db.hip_flat import _mmr_select
+
+    for c in golden("mmr.json")["cases"]:
+        E = [[unhex(v) for v in row] for row in c["emb_hex"]]
+        q = [unhex(v) for v in c["query_hex"]]
+        docs = [(Document(content=f"c{i}", metadata={}, id=str(i)), 0.0) for i in range(c["n"])]
+        got = _mmr_select(docs, E, q, c["k"], c["lambda"])
+        assert [int(d.id) for d in got] == c["picked"], (c["n"], c["k"], c["lambda"])
