@@ -595,9 +595,14 @@ __global__ __launch_bounds__(1024) void rarc_seed_thr_kernel(const float* seed, 
 template <int D, int FMT = 0>
 static int launch_seed(const ScanParams& p, uint32_t seed_tiles, float* seed, hipStream_t s,
                        const float* rowscale = nullptr) {
-  // 8 query blocks x up to 128 tile walkers: 1024 workgroups of 4 waves fill the chip, and each walker
-  // amortises its query fragments over seed_tiles / 128 tiles
-  const uint32_t walkers = seed_tiles < 128u ? seed_tiles : 128u;
+  // 8 query blocks x up to 128 tile walkers (1024 workgroups of 4 waves fill the chip); a walker takes at least
+  // four tiles, so that its 48 KB of query fragments are fetched once per four tiles and the next tile's loads run
+  // behind the current tile's MFMAs (128-tile sample of a small shard: 128 walkers 23.4 us, 64: 15.1, 32: 13.5, 16: 20.8)
+  static const uint32_t walk_env = getenv("RARC_SEED_WALKERS") ? (uint32_t)atoi(getenv("RARC_SEED_WALKERS")) : 0u;  // (experiments)
+  uint32_t walkers = walk_env ? walk_env : (seed_tiles + 3u) / 4u;
+  if (walkers > 128u) walkers = 128u;
+  if (walkers > seed_tiles) walkers = seed_tiles;
+  if (walkers < 1u) walkers = 1u;
   hipLaunchKernelGGL((rarc_seed_kernel<D, FMT>), dim3(RARC_MAX_QUERIES / 32, walkers), dim3(256), 0, s,
                      (const void*)p.corpus, rowscale, p.q16, p.n_rows, p.n_tiles, seed_tiles, seed);
   RARC_HIP_CHECK(hipGetLastError());
