@@ -61,6 +61,11 @@ def parse(argv=None):
     ap.add_argument("--c5-layers", type=int, default=24, help="encoder depth of the config-5 leg (bge-large: 24)")
     ap.add_argument("--verify-queries", type=int, default=32,
                     help="queries whose answer is re-checked by an exact canonical re-scan of the whole shard")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend of the ranks: nccl (= RCCL, the measured configuration) or gloo (rehearsals)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks "
+                         "on one device).  The N-rank code path runs for real, on real kernels; the timings mean nothing")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (gloo): shard ranges, the (id, score) all-gather, the "
                          "merge and the max-over-ranks timing, with a stand-in local search; no GPU, no kernel")
@@ -77,7 +82,10 @@ def _free_port() -> int:
 def launch_ranks(a, argv) -> int:
     """Start a.gpus ranks of this script under torch.distributed.run and relay rank 0's JSON line.
     Runs before anything in this process has initialised the GPU (device_count() does not)."""
-    if not a.dry_run:
+    if a.one_device and a.backend != "gloo":
+        print("bench.py: --one-device needs --backend gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
+        return 2
+    if not a.dry_run and not a.one_device:
         import torch
 
         n_dev = torch.cuda.device_count()
@@ -283,12 +291,15 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("RARC_FORCE_DIST") == "1"   # the env var exercises RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     if a.gpus != world and rank == 0:
         print(f"# note: --gpus {a.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -371,7 +382,9 @@ def main():
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": a.storage, "data": "synthetic",
-            "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "rccl_ranks": dist.get_world_size() if (use_dist and a.backend == "nccl") else 0,
+            **({"rehearsal": f"{world} ranks over {a.backend}" + (" sharing cuda:0: timings are not a measurement" if a.one_device else "")}
+               if (use_dist and (a.backend != "nccl" or a.one_device)) else {}),
             "config": {"workload": f"{rows}x{a.dim} {store_txt} corpus of N(0,1) directions resident in HBM, row-sharded "
                                    f"over {world} GPU(s), batch {a.batch} queries, cosine top-{a.k}, exact (canonical fp32 rescore)",
                        "n_corpus": rows, "d": a.dim, "batch": a.batch, "k": a.k, "rows_per_gpu": hi - lo,

@@ -1,0 +1,36 @@
+"""`bench.py --gpus N` end to end with N real ranks on real kernels, on a one-GPU box: --backend gloo --one-device puts
+every rank on cuda:0 (RCCL refuses that; gloo moves the same tensors).  Exercises what the driver's scaling run
+exercises — launcher, shard ranges, per-rank index build, pipelined steps, packed exchange + merge, the full-size
+check reduced over ranks, and the config-5 leg with the encoder split over the ranks — minus RCCL itself.  Timings
+of ranks that share a GPU mean nothing and are not looked at."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_runs_with_n_ranks_on_one_device(world):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--one-device",
+                        "--rows", "4000000", "--c5-rows", "2000000", "--c5-layers", "2", "--steps", "3", "--warmup", "1",
+                        "--verify-queries", "4"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["config"]["rows_per_gpu"] == 4_000_000 // world
+    chk = out["config"]["full_size_check"]
+    assert chk["rows_beating_kth"] == 0 and chk.get("queries_differing", 0) == 0 and chk["ranks_checked"] == world
+    assert out["config"]["repaired_queries_last_step"] == 0 and out["config"]["exchange_ms_per_step"] > 0
+    c5 = out["c5"]
+    assert c5["n_gpus"] == world and c5["queries_embedded_per_gpu"] == 256 // world and c5["fused_entries_per_query"] == 100
+    assert c5["full_size_check"]["rows_beating_kth"] == 0
