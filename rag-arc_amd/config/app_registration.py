@@ -1,7 +1,8 @@
 """Counterpart of the reference's config/app_registration.py:1-5: the registry singleton plus a
 helper that registers this backend's retriever stacks under the framework's own mechanism."""
 from ..framework.register import Register
-from .modules import HipLogitRerankerConfig, MultiPathRetrieverConfig, VectorStoreRetrieverConfig
+from .modules import (HipLogitRerankerConfig, HipQwen3RerankerConfig, MultiPathRetrieverConfig,
+                      VectorStoreRetrieverConfig)
 
 registrator = Register()
 
@@ -16,3 +17,7 @@ def register_multipath_retriever(config_path: str, app_name: str = "hip_multipat
 
 def register_reranker(config_path: str, app_name: str = "hip_reranker") -> None:
     registrator.register(config_path, app_name, HipLogitRerankerConfig)
+
+
+def register_qwen3_reranker(config_path: str, app_name: str = "hip_qwen3_reranker") -> None:
+    registrator.register(config_path, app_name, HipQwen3RerankerConfig)

@@ -136,7 +136,42 @@ class HipLogitRerankerConfig(AbstractConfig):
                                                               instruction=self.instruction, device=self.device))
 
 
-RerankerConfig = Annotated[Union[HipLogitRerankerConfig], Field(discriminator="type")]
+class HipQwen3RerankerConfig(AbstractConfig):
+    """The reference's Qwen3Reranker (core/rerank/Reranker_Qwen3.py:6-75) with the LM forward on the MI355X
+    (rarc_lm_yes_no_logits).  `weights_path`: a Qwen3ForCausalLM state dict (.safetensors / .npz, HuggingFace names);
+    `tokenizer_path`: the checkpoint's tokenizer.json (loaded with the `tokenizers` library, as AutoTokenizer does);
+    the head geometry comes from the checkpoint's config.json (Qwen3-Reranker-0.6B: 16 / 8 heads of 128)."""
+    type: Literal["hip_qwen3_reranker"] = "hip_qwen3_reranker"
+    weights_path: str
+    tokenizer_path: str
+    num_attention_heads: int
+    num_key_value_heads: int
+    head_dim: int = 128
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    max_length: int = 4096
+    instruction: Optional[str] = None
+    device: int = 0
+
+    def build(self) -> AbstractModule:
+        from tokenizers import Tokenizer
+
+        from ..core.rerank.hip_qwen3 import HipCausalLM, HipQwen3Reranker
+        from ..encapsulation.embeddings.hip_bert import load_state_dict
+
+        tok = Tokenizer.from_file(self.tokenizer_path)
+        yes_id, no_id = tok.token_to_id("yes"), tok.token_to_id("no")
+        if yes_id is None or no_id is None:
+            raise ValueError("the tokenizer has no 'yes' / 'no' tokens")
+        lm = HipCausalLM(load_state_dict(self.weights_path), self.num_attention_heads, self.num_key_value_heads,
+                         self.head_dim, rms_norm_eps=self.rms_norm_eps, rope_theta=self.rope_theta, device=self.device)
+        pad = tok.token_to_id("<|endoftext|>")
+        rr = HipQwen3Reranker(lm, lambda text: tok.encode(text, add_special_tokens=False).ids, yes_id=yes_id, no_id=no_id,
+                              max_length=self.max_length, instruction=self.instruction, pad_id=pad if pad is not None else 0)
+        return BuiltModule(config=self, impl=rr)
+
+
+RerankerConfig = Annotated[Union[HipLogitRerankerConfig, HipQwen3RerankerConfig], Field(discriminator="type")]
 
 
 class RRFusionConfig(AbstractConfig):

@@ -119,18 +119,28 @@ class HipCausalLM:
 class HipQwen3Reranker(HipLogitReranker):
     """Drop-in for the reference's Qwen3Reranker: `rerank(query, documents, k=None, batch_size=8)`."""
 
+    # the chat-template wrapper the reference encodes once at construction (Reranker_Qwen3.py:16-17)
+    PREFIX = ("<|im_start|>system\nJudge whether the Document meets the requirements based on the Query and the Instruct "
+              "provided. Note that the answer can only be \"yes\" or \"no\".<|im_end|>\n<|im_start|>user\n")
+    SUFFIX = "<|im_end|>\n<|im_start|>assistant\n<think>\n\n</think>\n\n"
+
     def __init__(self, lm: HipCausalLM, tokenize: Callable[[str], Sequence[int]], yes_id: int, no_id: int,
-                 prefix_ids: Sequence[int] = (), suffix_ids: Sequence[int] = (), max_length: int = 4096,
-                 instruction: Optional[str] = None, pad_id: int = 0, device: Optional[int] = None):
+                 prefix_ids: Optional[Sequence[int]] = None, suffix_ids: Optional[Sequence[int]] = None,
+                 max_length: int = 4096, instruction: Optional[str] = None, pad_id: int = 0,
+                 device: Optional[int] = None):
         super().__init__(self._logits, instruction=instruction,
                          device=lm.device.index if device is None else device)
         self.lm, self.tokenize = lm, tokenize
-        self.yes_id, self.no_id, self.pad_id = int(yes_id), int(no_id), int(pad_id)
-        self.prefix_ids, self.suffix_ids = list(prefix_ids), list(suffix_ids)
+        self.yes_id, self.no_id, self.pad_id = int(yes_id), int(no_id), int(pad_id)   # token_true_id / token_false_id (:14-15)
+        self.prefix, self.suffix = self.PREFIX, self.SUFFIX
+        # prefix_tokens / suffix_tokens: given, or encoded with the same tokenizer as the reference does
+        self.prefix_ids = list(tokenize(self.PREFIX)) if prefix_ids is None else list(prefix_ids)
+        self.suffix_ids = list(tokenize(self.SUFFIX)) if suffix_ids is None else list(suffix_ids)
         self.max_length = int(max_length)
 
     def process_inputs(self, pairs: Sequence[str]):
-        """Reranker_Qwen3.py:29-39: truncate each pair's tokens, wrap in prefix / suffix, left pad."""
+        """Reranker_Qwen3.py:29-39: truncate each pair's tokens, wrap in prefix / suffix, left pad.  Returns
+        (input_ids, attention_mask) as host arrays [n][L]."""
         room = self.max_length - len(self.prefix_ids) - len(self.suffix_ids)
         seqs = [self.prefix_ids + list(self.tokenize(p))[: max(room, 0)] + self.suffix_ids for p in pairs]
         L = max(len(s) for s in seqs)
@@ -147,8 +157,15 @@ class HipQwen3Reranker(HipLogitReranker):
         z = self.lm.yes_no_logits(ids, mask, self.no_id, self.yes_id).cpu().numpy()   # fp16 [n][2]: 4 bytes per pair
         return z[:, 0], z[:, 1]
 
-    def compute_scores(self, query: str, contents: Sequence[str]) -> List[float]:
-        """The reference's compute_logits output for one batch: p_yes per pair (python floats of the fp16 values)."""
-        zn, zy = self._logits(query, contents)
-        scores, _ = self.score_order(zn, zy)
+    def compute_logits(self, inputs) -> List[float]:
+        """Reranker_Qwen3.py:41-49 for one left-padded batch `inputs = (input_ids, attention_mask)`: last-position logits
+        of "no" / "yes" -> log_softmax over the two -> exp, as python floats of the fp16 values."""
+        ids, mask = inputs
+        z = self.lm.yes_no_logits(ids, mask, self.no_id, self.yes_id).cpu().numpy()
+        scores, _ = self.score_order(z[:, 0], z[:, 1])
         return [float(v) for v in scores[0].cpu().numpy()]
+
+    def compute_scores(self, pairs, instruction=None, **kwargs) -> List[float]:
+        """Reranker_Qwen3.py:51-55: `pairs` = [(query, document text), ...] -> p_yes per pair."""
+        texts = [self.format_instruction(instruction, q, d) for q, d in pairs]
+        return self.compute_logits(self.process_inputs(texts))

@@ -78,8 +78,47 @@ def test_reranker_end_to_end_matches_reference_steps(oracle):
         scores.extend(oracle.rerank_scores_f16(z[:, 0].astype(np.float16), z[:, 1].astype(np.float16)).tolist())
     got_scores = []
     for s0 in range(0, len(docs), 8):
-        got_scores.extend(rr.compute_scores("what is a vector index?", [d.content for d in docs[s0:s0 + 8]]))
+        got_scores.extend(rr.compute_scores([("what is a vector index?", d.content) for d in docs[s0:s0 + 8]]))
     assert np.max(np.abs(np.array(got_scores) - np.array(scores, dtype=np.float64))) < 1e-2
     want_order = oracle.stable_desc_order(np.array(got_scores))          # the order of ITS scores, stable
     assert [d.id for d in out] == [docs[i].id for i in want_order[:7]]
     assert len(out) == 7 and all(isinstance(d, Document) for d in out)
+
+
+def test_qwen3_reranker_from_json_registry(oracle, tmp_path):
+    """JSON -> Register.register -> HipQwen3Reranker: weights from .safetensors, tokenizer from a tokenizer.json (the
+    `tokenizers` library), rerank() through the registered module equals the directly constructed one."""
+    import json
+
+    from safetensors.numpy import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers
+
+    from rag_arc_amd.config.app_registration import register_qwen3_reranker, registrator
+    from rag_arc_amd.core.rerank import HipCausalLM, HipQwen3Reranker
+    from rag_arc_amd.core.utils.data_model import Document
+
+    words = ["<|endoftext|>", "[UNK]", "yes", "no", "<|im_start|>", "<|im_end|>", "system", "user", "assistant", "<think>", "</think>",
+             "judge", "whether", "the", "document", "meets", "requirements", "query", "instruct", "passage", "about", "vector",
+             "index", "search", "rank", "<", ">", ":", ".", ",", "\"", "a", "is", "what", "?"] + [f"w{i}" for i in range(200)]
+    tok = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    tok.pre_tokenizer = pre_tokenizers.Whitespace()
+    tok.save(str(tmp_path / "tokenizer.json"))
+    H, LAYERS, NQ, NKV, DH, I, V = 256, 2, 4, 2, 64, 512, len(words)
+    V = (V + 7) // 8 * 8
+    sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=12)
+    sd = {k: np.ascontiguousarray(v) for k, v in sd.items() if k != "lm_head.weight"}      # tied embeddings: no lm_head tensor
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    (tmp_path / "rr.json").write_text(json.dumps({"type": "hip_qwen3_reranker", "weights_path": str(tmp_path / "model.safetensors"),
+                                                 "tokenizer_path": str(tmp_path / "tokenizer.json"), "num_attention_heads": NQ,
+                                                 "num_key_value_heads": NKV, "head_dim": DH, "max_length": 128}))
+    register_qwen3_reranker(str(tmp_path / "rr.json"), "q3")
+    rr = registrator.get_object("q3")
+    docs = [Document(content=f"passage about w{i} vector index w{i + 1} .", metadata={}, id=str(i)) for i in range(11)]
+    got = rr.rerank("what is a vector index ?", docs, k=5)
+    direct = HipQwen3Reranker(HipCausalLM(sd, NQ, NKV, DH), lambda t: tok.encode(t, add_special_tokens=False).ids,
+                              yes_id=tok.token_to_id("yes"), no_id=tok.token_to_id("no"), max_length=128,
+                              pad_id=tok.token_to_id("<|endoftext|>"))
+    want = direct.rerank("what is a vector index ?", docs, k=5)
+    assert [d.id for d in got] == [d.id for d in want] and len(got) == 5
+    scores = direct.compute_scores([("what is a vector index ?", d.content) for d in docs[:8]])
+    assert len(scores) == 8 and all(0.0 <= s <= 1.0 for s in scores)
