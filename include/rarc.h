@@ -177,6 +177,18 @@ int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, con
                     uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Batched exact verification: for queries q_first .. q_first + nq - 1 (nq <= 8) of the prepared query block, count the
+ * rows of the shard whose canonical key (score desc, id asc) beats the k-th entry of the query's answer in
+ * d_ids / d_scores ([256][k] rows of the batch).  d_counts[i] includes the k - 1 better entries of the answer itself
+ * when they are real rows, so an exact answer gives d_counts[i] == (number of valid entries among its first k - 1).
+ * A row is read once for all nq queries: the whole batch of 256 is checked against an exact scan in 32 passes.
+ * row_format: 0 fp16 rows, 1 fp8 rows + d_row_scale, 2 fp32 rows.
+ */
+int rarc_verify_batch(const void* d_rows, const float* d_row_scale, int row_format, int64_t n_rows, int d_pad,
+                      const void* d_qblock, int q_first, int nq, int k, int64_t id_base, const int64_t* d_ids,
+                      const float* d_scores, uint32_t* d_counts, void* stream);
+
+/*
  * Optional int8 "shadow" image of an fp16 corpus.  The int8-prefilter scan converts every fp16 row to
  * int8 on each search; with d_pad a multiple of 256 the conversion can be done once, at ingest
  * (rarc_quant_shadow_f16 = rarc_quant_meta_f16 + the image, int8 [ceil32(n_rows)][d_pad], caller-owned),

@@ -43,6 +43,9 @@ static int q8_tighten(void* ctx, int n_wg) {
 int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                        const float* qv, int k, int64_t id_base, int64_t* ids, float* scores, uint32_t* found,
                        const RarcWs& ws, int cap, hipStream_t s);
+int rarc_verify_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad, const float* q32,
+                       int q_first, int nq, int k, int64_t id_base, const int64_t* ids, const float* scores,
+                       uint32_t* counts, hipStream_t s);
 int rarc_merge_launch(const int64_t* ids, const float* scores, int G, int nq, int k, int64_t* out_ids,
                       float* out_scores, hipStream_t s, bool packed);
 int rarc_pack_launch(const int64_t* ids, const float* scores, int n, uint32_t* out, hipStream_t s);
@@ -311,6 +314,21 @@ extern "C" int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_sca
   return rarc_repair_launch(d_corpus_f8, d_row_scale, 1, n_rows, d_pad, qb.q32 + (size_t)q * d_pad, k, id_base,
                             d_out_ids + (size_t)q * k, d_out_scores + (size_t)q * k, d_found, ws, cap,
                             (hipStream_t)stream);
+}
+
+// exact batched verification of up to 8 answers against a canonical scan of the shard (finalize.hip)
+extern "C" int rarc_verify_batch(const void* d_rows, const float* d_row_scale, int row_format, int64_t n_rows, int d_pad,
+                                 const void* d_qblock, int q_first, int nq, int k, int64_t id_base, const int64_t* d_ids,
+                                 const float* d_scores, uint32_t* d_counts, void* stream) {
+  RARC_REQUIRE(d_rows && d_qblock && d_ids && d_scores && d_counts, RARC_E_INVALID, "rarc_verify_batch: null pointer");
+  RARC_REQUIRE(row_format >= 0 && row_format <= 2 && (row_format != 1 || d_row_scale), RARC_E_INVALID,
+               "rarc_verify_batch: row_format %d (0 fp16, 1 fp8 + scales, 2 fp32)", row_format);
+  RARC_REQUIRE(nq >= 1 && nq <= 8 && q_first >= 0 && q_first + nq <= RARC_MAX_QUERIES && k >= 1 && k <= RARC_MAX_K &&
+                   d_pad > 0 && d_pad % RARC_DIM_ALIGN == 0 && d_pad <= 1024 && n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll,
+               RARC_E_INVALID, "rarc_verify_batch: bad arguments (q_first=%d nq=%d k=%d d_pad=%d)", q_first, nq, k, d_pad);
+  const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
+  return rarc_verify_launch(d_rows, d_row_scale, row_format, n_rows, d_pad, qb.q32, q_first, nq, k, id_base, d_ids,
+                            d_scores, d_counts, (hipStream_t)stream);
 }
 
 extern "C" int rarc_topk_merge(const int64_t* d_ids, const float* d_scores, int n_lists, int nq, int k,

@@ -73,6 +73,8 @@ SIGNATURES = {
                                 c_int, c_void_p]),
     "rarc_repair_f16": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "rarc_verify_batch": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
     "rarc_quant_shadow_f16": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p, c_void_p]),
     "rarc_search_f16_shadow": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                        c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,

@@ -534,6 +534,46 @@ class FlatIndexF16:
             return int(b["found"].item())
 
 
+    def verify_batch(self, queries, ids, scores, which=None) -> int:
+        """Exact check of whole answers: for the queries `which` (default: all) count the rows of the shard that beat
+        the stored k-th entry, by a canonical scan that reads every row once per EIGHT queries (rarc_verify_batch).
+        Returns the total over the queries (0 == every checked answer is exact)."""
+        t = self.torch
+        fmt = {"f16": 0, "f8": 1, "f32": 2}[self.storage]
+        nq, k = ids.shape
+        which = list(range(nq)) if which is None else sorted(set(int(w) for w in which))
+        total = 0
+        with self._lock, t.cuda.device(self.device):
+            self._workspace()
+            b = self._qbuf
+            q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
+            counts = t.zeros(8, dtype=t.int32, device=self.device)
+            sc_ptr = self._rowscale.data_ptr() if self._rowscale is not None else 0
+            for c0 in range(0, nq, B.MAX_QUERIES):
+                c1 = min(nq, c0 + B.MAX_QUERIES)
+                todo = [w - c0 for w in which if c0 <= w < c1]
+                if not todo:
+                    continue
+                self._prep(q[c0:c1])
+                ids_c, sc_c = ids[c0:c1].contiguous(), scores[c0:c1].contiguous()
+                # groups of up to 8 CONSECUTIVE queries (the kernel takes a range)
+                i = 0
+                while i < len(todo):
+                    j = i
+                    while j + 1 < len(todo) and todo[j + 1] == todo[j] + 1 and j + 1 - i < 8:
+                        j += 1
+                    first, n = todo[i], j - i + 1
+                    B.check(self.lib.rarc_verify_batch(self._rows.data_ptr(), sc_ptr, fmt, self.ntotal, self.d_pad,
+                                                       b["qblock"].data_ptr(), first, n, k, self.id_base, ids_c.data_ptr(),
+                                                       sc_c.data_ptr(), counts.data_ptr(), self._stream()),
+                            "rarc_verify_batch")
+                    got = counts[:n].cpu().numpy().astype(np.int64)
+                    valid = (ids_c[first:first + n, : k - 1] >= 0).sum(dim=1).cpu().numpy().astype(np.int64)
+                    total += int(np.maximum(got - valid, 0).sum())
+                    i = j + 1
+        return total
+
+
 class PendingSearch:
     """Handle returned by FlatIndexF16.search_async."""
 

@@ -296,3 +296,29 @@ def test_shadow_image_scan_matches_oracle(hip, oracle, n, d, nq, k):
     plain.add(X)
     D2, I2 = plain.search(Q, min(k, n))
     assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
+
+
+@pytest.mark.parametrize("storage", ["f16", "f8", "f32"])
+def test_batched_exact_verification(hip, oracle, storage):
+    """rarc_verify_batch: an exact answer has no row beating its k-th entry, for every query of the batch at once; a
+    corrupted answer (k-th entry swapped for the worst row of the shard) is caught, with the count an exhaustive
+    scan would find."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 120_000, 384, 21, 30
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    idx = hip.FlatIndexF16(d, storage=storage)
+    idx.add(X)
+    ids, sc = idx.search_device(torch.from_numpy(Q).cuda(), k)
+    assert idx.verify_batch(Q, ids, sc) == 0
+    assert idx.verify_batch(Q, ids, sc, which=[0, 1, 2, 9, 20]) == 0
+    bad_i, bad_s = ids.clone(), sc.clone()
+    worst_i, worst_s = idx.search_device(torch.from_numpy(-Q).cuda(), 1)      # the row most OPPOSITE to each query
+    for qi in (3, 4, 17):
+        bad_i[qi, k - 1] = worst_i[qi, 0]
+        bad_s[qi, k - 1] = -worst_s[qi, 0]
+    # the planted entry is the query's WORST row: every other row beats it, k - 1 of them already listed in the answer
+    assert idx.verify_batch(Q, bad_i, bad_s) == 3 * (n - k)
+    assert idx.verify_batch(Q, bad_i, bad_s, which=[4]) == n - k and idx.verify_batch(Q, bad_i, bad_s, which=[5, 6]) == 0

@@ -42,6 +42,7 @@ def test_five_million_rows(oracle):
     # exactness: nothing in 5M rows beats the k-th entry
     for b in (0, 17, 100, 255):
         assert idx.verify_query(q, b, ids, sc) == 0
+    assert idx.verify_batch(q, ids, sc) == 0                          # ... for all 256 queries in one pass
     # sharding invariance: 3 shards with id_base + HIP merge == single shard
     parts_i, parts_s = [], []
     for g in range(3):
@@ -107,6 +108,7 @@ def test_full_size_properties_other_storage_formats(oracle, storage, N, D):
             assert np.array_equal(o_s[0].view(np.uint32), S[b].view(np.uint32))
     for b in (0, 77, 255):
         assert idx.verify_query(q, b, ids, sc) == 0
+    assert idx.verify_batch(q, ids, sc) == 0
     del idx
     torch.cuda.empty_cache()
     parts_i, parts_s = [], []
