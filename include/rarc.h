@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 203 /* 0.2.1: N(0,1) generator, encoder table sizes in the ABI */
+#define RARC_VERSION 204 /* 0.2.4: + batched verification, float64 cosine matrix / adjacent distances */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
@@ -66,6 +66,20 @@ int rarc_padded_dim(int d);
  */
 int rarc_l2norm_rows_f32(const float* d_in, int64_t ld_in, float* d_out, int64_t ld_out,
                          int64_t n_rows, int d, void* stream);
+
+/*
+ * Cosine similarities in float64, as the chunker computes them (numpy branch of
+ *   core/file_management/chunker/spliter.py:307-332  cosine_similarity(X, Y)
+ * = np.dot(X, Y.T) / np.outer(|X|, |Y|), entries that come out NaN/inf (a zero row) set to 0), and the distances of
+ * consecutive rows  1 - cosine(x_i, x_{i+1})  of
+ *   core/file_management/chunker/spliter.py:354-371  calculate_cosine_distances.
+ * Inputs are fp32 rows on the device (what an Embeddings provider returns), sums run in fp64: products of fp32
+ * values are exact there, so only the order of the additions differs from numpy (|delta| ~ 1e-16 relative).
+ * d_out: [nx][ny] doubles / [n_rows - 1] doubles.
+ */
+int rarc_cosine_matrix_f32(const float* d_x, int64_t ld_x, int nx, const float* d_y, int64_t ld_y, int ny, int d,
+                           double* d_out, void* stream);
+int rarc_adjacent_cosine_distance_f32(const float* d_x, int64_t ld_x, int n_rows, int d, double* d_out, void* stream);
 
 /*
  * Ingest: fp32 rows -> (optionally L2-normalised) -> fp16 corpus rows of length

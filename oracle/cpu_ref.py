@@ -262,6 +262,47 @@ def synth_rows_f32(n: int, d: int, first_row: int = 0, seed: int = 4321) -> np.n
     return out
 
 
+# ---- the chunker's float64 cosines (core/file_management/chunker/spliter.py:307-371) ----
+def _lane_sums(prod: np.ndarray) -> np.ndarray:
+    """Sum the last axis in the order of rarc_cosine_pairs_kernel: 64 lanes, lane l adds elements l, l+64, ... in
+    ascending order, then a butterfly over lane distances 32, 16, ..., 1 (lane 0's value)."""
+    d = prod.shape[-1]
+    pad = (-d) % 64
+    if pad:
+        prod = np.concatenate([prod, np.zeros(prod.shape[:-1] + (pad,), np.float64)], axis=-1)
+    steps = prod.reshape(prod.shape[:-1] + (-1, 64))
+    lanes = np.zeros(prod.shape[:-1] + (64,), np.float64)
+    for m in range(steps.shape[-2]):
+        lanes = lanes + steps[..., m, :]
+    idx = np.arange(64)
+    for off in (32, 16, 8, 4, 2, 1):
+        lanes = lanes + lanes[..., idx ^ off]
+    return lanes[..., 0]
+
+
+def cosine_matrix_f64(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """spliter.cosine_similarity's numpy branch (:326-332) on fp32 rows: dot / (|x| |y|) in float64, NaN/inf -> 0."""
+    x64, y64 = np.asarray(x, np.float32).astype(np.float64), np.asarray(y, np.float32).astype(np.float64)
+    dot = _lane_sums(x64[:, None, :] * y64[None, :, :])
+    nx, ny = _lane_sums(x64 * x64), _lane_sums(y64 * y64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sim = dot / (np.sqrt(nx)[:, None] * np.sqrt(ny)[None, :])
+    sim[~np.isfinite(sim)] = 0.0
+    return sim
+
+
+def adjacent_cosine_distances(x: np.ndarray) -> np.ndarray:
+    """calculate_cosine_distances (:354-371): 1 - cosine(x[i], x[i+1])."""
+    x64 = np.asarray(x, np.float32).astype(np.float64)
+    if x64.shape[0] < 2:
+        return np.zeros(0, np.float64)
+    a, b = x64[:-1], x64[1:]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        sim = _lane_sums(a * b) / (np.sqrt(_lane_sums(a * a)) * np.sqrt(_lane_sums(b * b)))
+    sim[~np.isfinite(sim)] = 0.0
+    return 1.0 - sim
+
+
 # ------------------------------------------------------------------------------------------- RRF
 def rrf_fuse(lists: Sequence[Sequence[Hashable]], rrf_k: float = 60.0, top_k: int = 10) -> List[Tuple[Hashable, float]]:
     """RRFusion.fuse (core/utils/Fusion.py:45-76) on bare keys (the reference keys on

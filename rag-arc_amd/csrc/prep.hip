@@ -2,6 +2,7 @@
 //   rarc_l2norm_rows_f32   faiss.normalize_L2            (VectorStore_Faiss.py:150-154)
 //   rarc_ingest_f16        normalise + index.add as fp16 (VectorStore_Faiss.py:178, :199-202)
 //   rarc_prep_queries      np.array([q]).astype(f32) + normalise (VectorStore_Faiss.py:258-259)
+//   rarc_cosine_matrix_f32 / rarc_adjacent_cosine_distance_f32   the chunker's float64 cosines (spliter.py:307-371)
 //   rarc_synth_rows_*      deterministic synthetic data (bench / property tests)
 //
 // All reductions use the canonical 8-lane order: lane j of an 8-lane group owns elements
@@ -50,6 +51,39 @@ __global__ __launch_bounds__(256) void rarc_l2norm_kernel(const float* in, int64
       } else if (y != x) {
         for (int m = j; m < d; m += 8) y[m] = x[m];
       }
+    }
+  }
+}
+
+// Cosine similarity of row pairs in float64 (the chunker's distances, core/file_management/chunker/spliter.py:307-371:
+// np.dot(X, Y.T) / np.outer(|X|, |Y|) on float64 arrays, non-finite quotients -> 0).  One wave per (i, j) pair: lane l
+// owns elements l, l+64, ... (products of fp32 values are exact in fp64, one rounding per add), then a butterfly
+// over lane distances 32, 16, ..., 1.  `adjacent`: pairs (i, i+1) of X only and the value written is 1 - similarity.
+__global__ __launch_bounds__(256) void rarc_cosine_pairs_kernel(const float* x, int64_t ldx, int nx, const float* y,
+                                                                int64_t ldy, int ny, int d, int adjacent, double* out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n_pairs = adjacent ? (int64_t)nx - 1 : (int64_t)nx * ny;
+  for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < n_pairs; p += (int64_t)gridDim.x * 4) {
+    const int64_t i = adjacent ? p : p / ny, j = adjacent ? p + 1 : p % ny;
+    const float* a = x + i * ldx;
+    const float* b = adjacent ? x + j * ldx : y + j * ldy;
+    double dot = 0.0, na = 0.0, nb = 0.0;
+    for (int m = lane; m < d; m += 64) {
+      const double av = (double)a[m], bv = (double)b[m];
+      dot = __builtin_fma(av, bv, dot);
+      na = __builtin_fma(av, av, na);
+      nb = __builtin_fma(bv, bv, nb);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      dot += __shfl_xor(dot, off, 64);
+      na += __shfl_xor(na, off, 64);
+      nb += __shfl_xor(nb, off, 64);
+    }
+    if (lane == 0) {
+      double sim = dot / (sqrt(na) * sqrt(nb));
+      if (!(sim - sim == 0.0)) sim = 0.0;  // NaN or +-inf (a zero row): the reference zeroes those entries
+      out[p] = adjacent ? 1.0 - sim : sim;
     }
   }
 }
@@ -384,6 +418,28 @@ extern "C" int rarc_l2norm_rows_f32(const float* d_in, int64_t ld_in, float* d_o
   if (n_rows == 0) return RARC_OK;
   hipLaunchKernelGGL(rarc_l2norm_kernel, dim3(grid_for(n_rows, 32)), dim3(256), 0, (hipStream_t)stream,
                      d_in, ld_in, d_out, ld_out, n_rows, d);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_cosine_matrix_f32(const float* d_x, int64_t ld_x, int nx, const float* d_y, int64_t ld_y, int ny,
+                                      int d, double* d_out, void* stream) {
+  RARC_REQUIRE(d_x && d_y && d_out && d > 0 && nx >= 0 && ny >= 0 && ld_x >= d && ld_y >= d, RARC_E_INVALID,
+               "rarc_cosine_matrix_f32: bad arguments");
+  if (nx == 0 || ny == 0) return RARC_OK;
+  hipLaunchKernelGGL(rarc_cosine_pairs_kernel, dim3(grid_for((int64_t)nx * ny, 4)), dim3(256), 0, (hipStream_t)stream,
+                     d_x, ld_x, nx, d_y, ld_y, ny, d, 0, d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_adjacent_cosine_distance_f32(const float* d_x, int64_t ld_x, int n_rows, int d, double* d_out,
+                                                 void* stream) {
+  RARC_REQUIRE(d_x && d_out && d > 0 && n_rows >= 0 && ld_x >= d, RARC_E_INVALID,
+               "rarc_adjacent_cosine_distance_f32: bad arguments");
+  if (n_rows < 2) return RARC_OK;
+  hipLaunchKernelGGL(rarc_cosine_pairs_kernel, dim3(grid_for(n_rows - 1, 4)), dim3(256), 0, (hipStream_t)stream, d_x,
+                     ld_x, n_rows, d_x, ld_x, n_rows, d, 1, d_out);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

@@ -59,6 +59,8 @@ SIGNATURES = {
     "rarc_last_error": (ctypes.c_char_p, []),
     "rarc_padded_dim": (c_int, [c_int]),
     "rarc_l2norm_rows_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "rarc_cosine_matrix_f32": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "rarc_adjacent_cosine_distance_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "rarc_ingest_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rarc_quant_meta_floats": (c_size_t, [c_int64]),
     "rarc_quant_meta_f16": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p]),

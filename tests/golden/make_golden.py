@@ -16,6 +16,8 @@ Pinned here:
   mmr.json        _mmr_select (the greedy MMR loop)           VectorStore_Faiss.py:16-62  (the module imports faiss,
                   absent here: an EMPTY module object named `faiss` is put in sys.modules so that the import statement
                   passes — the function under test never touches it)
+  chunker.json    SemanticChunker.split_text / calculate_cosine_distances / cosine_similarity with a zero row
+                                                              core/file_management/chunker/spliter.py:307-534
   cosine_pin_d384.npz, cosine_pin_d768.npz
                   the same function on 64 x 4096 fp16-representable vectors (inputs: tests/helpers.py:pin_inputs):
                   the reference's float64 cosine matrix — the tight pin of the flat-search arithmetic
@@ -259,6 +261,23 @@ def main():
         Sp = np.asarray(spliter.cosine_similarity(Xp.astype(np.float64), Yp.astype(np.float64)), dtype=np.float64)
         assert Sp.shape == (nq, n)
         np.savez_compressed(os.path.join(OUT, f"cosine_pin_d{d}.npz"), cos=Sp)
+    # ------------------------------------------------------------------ semantic chunker
+    # the reference's SemanticChunker over a deterministic fake provider (tests/helpers.py): distances as float64
+    # bit patterns + the chunks, per parameter set; short texts exercise the early returns
+    from tests.helpers import CHUNKER_CASES, CHUNKER_SHORT_TEXTS, CHUNKER_TEXT, ChunkerFakeEmbeddings
+    ch_cases = []
+    for params in CHUNKER_CASES:
+        ch = spliter.SemanticChunker(ChunkerFakeEmbeddings(), **params)
+        pieces = __import__("re").split(ch.sentence_split_regex, CHUNKER_TEXT)
+        dist, _ = ch._calculate_sentence_distances(pieces)
+        ch_cases.append({"params": params, "distances_hex": [hexf(v) for v in dist], "chunks": ch.split_text(CHUNKER_TEXT)})
+    short = [{"text": t, "chunks": spliter.SemanticChunker(ChunkerFakeEmbeddings()).split_text(t),
+              "chunks_gradient": spliter.SemanticChunker(ChunkerFakeEmbeddings(), breakpoint_threshold_type="gradient").split_text(t)}
+             for t in CHUNKER_SHORT_TEXTS]
+    zero = ChunkerFakeEmbeddings().embed_documents(["Rivers run.", "Bread bakes."])
+    zmat = spliter.cosine_similarity([zero[0], [0.0] * len(zero[0])], [zero[1], [0.0] * len(zero[0]), zero[0]])
+    json.dump({"cases": ch_cases, "short": short, "zero_row_matrix_hex": [[hexf(v) for v in row] for row in zmat]},
+              open(os.path.join(OUT, "chunker.json"), "w"), indent=0)
     print("golden vectors written to", OUT)
 
 

@@ -193,3 +193,49 @@ class ScriptedStore(VectorStore):
 def scripted_scored():
     return [(Document(content=f"doc{i}", metadata={}, id=str(i)), s)
             for i, s in enumerate([0.9, 0.75, 0.5, 0.25, 0.1, 0.05, -0.2, 0.0])]
+
+
+# ---- semantic chunker fixture (tests/golden/chunker.json): inputs shared by the golden generator and the tests ----
+class ChunkerFakeEmbeddings:
+    """Deterministic stand-in for an embedding provider: a topic vector chosen by the sentence window's LAST topic word
+    plus hashed per-text noise, all on the fp16 grid (exact in fp32) — so the reference (float64 on these floats) and
+    the device kernels (fp32 rows, float64 sums) see identical numbers."""
+
+    def __init__(self, d: int = 96):
+        self.d = d
+
+    def embed_documents(self, texts):
+        import zlib
+
+        out = []
+        for t in texts:
+            words = [w.strip(".?!,").lower() for w in t.split()]
+            topic = next((w for w in reversed(words) if w in CHUNKER_TOPICS), "none")
+            base = fp16_grid_matrix(1, self.d, 1000 + sorted(CHUNKER_TOPICS + ("none",)).index(topic))[0]
+            noise = fp16_grid_matrix(1, self.d, zlib.crc32(t.encode()) & 0xFFFF)[0]
+            out.append((base * np.float32(2.0) + noise * np.float32(0.25)).astype(np.float32).tolist())
+        return out
+
+    def embed_query(self, text):
+        return self.embed_documents([text])[0]
+
+
+CHUNKER_TOPICS = ("rivers", "engines", "bread", "stars")
+CHUNKER_TEXT = (
+    "Rivers carry silt to the sea. Many rivers flood in spring! Do rivers freeze in the north? Old rivers meander widely. "
+    "Engines burn fuel to turn shafts. Small engines idle roughly. Are engines quieter now? Diesel engines last long. "
+    "Modern engines use sensors. Bread needs flour and water. Good bread takes time! Why does bread rise? "
+    "Stale bread makes fine crumbs. Stars fuse hydrogen for ages. Some stars collapse. Can stars be counted? "
+    "Bright stars guide sailors. Distant stars look red.")
+CHUNKER_CASES = (
+    {"breakpoint_threshold_type": "percentile"},
+    {"breakpoint_threshold_type": "percentile", "breakpoint_threshold_amount": 70, "buffer_size": 0},
+    {"breakpoint_threshold_type": "standard_deviation", "breakpoint_threshold_amount": 1.0},
+    {"breakpoint_threshold_type": "interquartile", "breakpoint_threshold_amount": 0.5, "buffer_size": 2},
+    {"breakpoint_threshold_type": "gradient", "breakpoint_threshold_amount": 80},
+    {"number_of_chunks": 4},
+    {"number_of_chunks": 40},
+    {"number_of_chunks": 1},
+    {"breakpoint_threshold_type": "percentile", "breakpoint_threshold_amount": 50, "min_chunk_size": 120},
+)
+CHUNKER_SHORT_TEXTS = ("One sentence only.", "Two sentences here. That is all.", "")
