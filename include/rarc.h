@@ -337,7 +337,8 @@ int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int64_t first_r
  *   rarc_enc_embed_ln : out[t] = LayerNorm(word[ids[t]] + pos[t % seq_len] + type0); `vocab` = rows of d_word:
  *                       an id outside [0, vocab) is clamped into the table (memory safety only — callers
  *                       validate ids on the host, as the python binding does)
- *   rarc_enc_gemm     : C[M][N] = A[M][K] · W[N][K]^T + bias[N], act 0 = none, 1 = erf-GELU;
+ *   rarc_enc_gemm     : C[M][N] = A[M][K] · W[N][K]^T + bias[N], act 0 = none, 1 = erf-GELU, 3 = SwiGLU over gate/up
+ *                       columns interleaved in groups of 8 (C is then [M][N/2]; large shapes only, see RarcLmLayer);
  *                       M, N multiples of 128, K multiple of 64 (MFMA 32x32x16 f16, fp32 accumulate)
  *   rarc_enc_attention: ctx = softmax(Q K^T / sqrt(dh) + key mask) V per (sequence, head) from the
  *                       fused qkv [n_seq*seq_len][3*hidden]; keys >= d_lens[seq] are masked; dh 32 or 64
@@ -399,7 +400,10 @@ int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int3
  */
 typedef struct RarcLmLayer {
   const uint16_t *in_norm, *qkv_w, *q_norm, *k_norm, *o_w, *post_norm, *gate_up_w, *down_w;
-  /* qkv_w [(n_q+2*n_kv)*head_dim][hidden] = q_proj | k_proj | v_proj rows; gate_up_w [2*inter][hidden] = gate | up */
+  /* qkv_w [(n_q+2*n_kv)*head_dim][hidden] = q_proj | k_proj | v_proj rows;
+   * gate_up_w [2*inter][hidden] = gate_proj and up_proj rows INTERLEAVED in groups of 8: rows 16b .. 16b+7 are
+   * gate_proj rows 8b .. 8b+7, rows 16b+8 .. 16b+15 the up_proj rows of the same features (so that one lane of the
+   * GEMM's 32 x 32 MFMA blocks holds gate and up of a feature and the SwiGLU is its epilogue; inter % 8 == 0) */
 } RarcLmLayer;
 typedef struct RarcLmModel {
   int hidden, n_layers, n_q_heads, n_kv_heads, head_dim, inter, vocab;

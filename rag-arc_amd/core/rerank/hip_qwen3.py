@@ -57,7 +57,7 @@ class HipCausalLM:
                 q_norm=f16(sd[p + "self_attn.q_norm.weight"]), k_norm=f16(sd[p + "self_attn.k_norm.weight"]),
                 o_w=f16(sd[p + "self_attn.o_proj.weight"]),
                 post_norm=f16(sd[p + "post_attention_layernorm.weight"]),
-                gate_up_w=torch.cat([f16(sd[p + "mlp.gate_proj.weight"]), f16(sd[p + "mlp.up_proj.weight"])]).contiguous(),
+                gate_up_w=self._interleave8(f16(sd[p + "mlp.gate_proj.weight"]), f16(sd[p + "mlp.up_proj.weight"])),
                 down_w=f16(sd[p + "mlp.down_proj.weight"])))
             i += 1
         if not self.layers:
@@ -76,6 +76,15 @@ class HipCausalLM:
                                 float(rms_norm_eps), float(rope_theta), self.embed.data_ptr(), self.lm_head.data_ptr(),
                                 self.final_norm.data_ptr(), self._zero.data_ptr(), self._layer_tab)
         self._ws = None
+
+    def _interleave8(self, gate, up):
+        """[2*inter][hidden]: 8 gate_proj rows, then the 8 up_proj rows of the same features, and so on — the layout
+        RarcLmLayer.gate_up_w asks for (include/rarc.h): SwiGLU becomes the epilogue of the gate/up GEMM."""
+        inter, hidden = gate.shape
+        if inter % 8 or tuple(up.shape) != (inter, hidden):
+            raise B.RarcError(f"gate_proj / up_proj shapes {tuple(gate.shape)} / {tuple(up.shape)}: need equal shapes, rows % 8 == 0")
+        return self.torch.stack([gate.view(inter // 8, 8, hidden), up.view(inter // 8, 8, hidden)], dim=1).reshape(
+            2 * inter, hidden).contiguous()
 
     def yes_no_logits(self, input_ids, attention_mask, no_id: int, yes_id: int):
         """input_ids / attention_mask: [n][L] LEFT padded (host arrays).  Returns fp16 device tensor [n][2] = (no, yes)."""

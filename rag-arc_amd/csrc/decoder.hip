@@ -4,7 +4,8 @@
 //
 //   x = embed[ids]
 //   per layer:  h = RMSNorm(x)·w_in;  [q|k|v] = h·Wqkvᵀ  (GQA: n_q heads of q, n_kv heads of k and v)
-//               q, k <- RoPE(RMSNorm_head(q)·w_qn), RoPE(RMSNorm_head(k)·w_kn)       (Qwen3: per-head q/k norm)
+//               q, k <- RoPE(RMSNorm_head(q)·w_qn), RoPE(RMSNorm_head(k)·w_kn)       (Qwen3: per-head q/k norm;
+//                       applied inside the attention kernel, on its operand fragments)
 //               ctx = causal softmax(q·kᵀ/sqrt(dh)) v over the sequence's real tokens;  x += ctx·Woᵀ
 //               h = RMSNorm(x)·w_post;  [g|u] = h·Wguᵀ;  x += (silu(g)·u)·Wdownᵀ
 //   logits[s] = (RMSNorm(x[s, L-1])·w_final) · lm_head[{no, yes}]ᵀ
@@ -17,6 +18,8 @@
 
 extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
                              int n, int k, int act, void* stream);
+
+bool rarc_gemm_swiglu_fused(int m, int n, int k);  // encoder.hip: act = 3 available for this shape
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
@@ -64,42 +67,50 @@ __global__ __launch_bounds__(256) void rarc_lm_rmsnorm_kernel(half_t* x, const h
   }
 }
 
-// ---- per-head RMSNorm of q and k, then rotary embedding (HF rotate_half convention), in place on the fused qkv ----
-// one wave per TOKEN: lane i owns the rotation pair (i, i + DH/2) of every head that carries positions (the n_q + n_kv
-// q and k heads; v heads are untouched), so cos / sin of (position, i) are computed once and reused for all of them
-// (one wave per (token, head) spent most of its time in sincosf: 374 us per layer at 51 200 tokens)
-template <int DH>
-__global__ __launch_bounds__(256) void rarc_lm_qknorm_rope_kernel(half_t* qkv, const half_t* qn_w, const half_t* kn_w,
-                                                                  float eps, float theta, int n_tokens, int L, int n_q,
-                                                                  int n_kv) {
-  static_assert(DH == 64 || DH == 128, "head_dim 64 or 128");
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (t >= n_tokens) return;
-  const int pos = t % L;  // positions run over the padded sequence, as in the reference's forward (no position_ids)
-  const int i = lane;
-  const bool on = i < DH / 2;  // DH = 128: one pair per lane; DH = 64: lanes 0..31
-  // inv_freq_i = theta^(-2i/DH); angle = pos * inv_freq_i  (fp32, as the reference's rotary module computes them)
+// ---- rotary table: (cos, sin) of (position, pair i) as fp16 pairs, [L][DH/2] ------------------------------------------
+// inv_freq_i = theta^(-2i/DH); angle = pos * inv_freq_i in fp32, as the reference's rotary module computes them, then cast
+// to the activations' dtype before use.  Positions run over the PADDED sequence (the reference passes no position_ids).
+// Computed once per forward and read from cache by the attention kernel (computing sincosf where it is used cost
+// 374 us per layer at 51 200 tokens: the angles reach thousands of radians and need the accurate routine).
+__global__ __launch_bounds__(256) void rarc_lm_rope_table_kernel(int L, int DH, float theta, half2_t* table) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L * (DH / 2)) return;
+  const int pos = idx / (DH / 2), i = idx % (DH / 2);
   const float inv_freq = __builtin_exp2f(-(2.0f * (float)i / (float)DH) * __builtin_log2f(theta));
   float sn, cs;
-  sincosf((float)pos * inv_freq, &sn, &cs);  // (the accurate one: angles reach thousands of radians at the low dimensions)
-  cs = (float)(half_t)cs;  // cos / sin are cast to the activations' dtype before use
-  sn = (float)(half_t)sn;
-  const float wq0 = on ? (float)qn_w[i] : 0.f, wq1 = on ? (float)qn_w[i + DH / 2] : 0.f;
-  const float wk0 = on ? (float)kn_w[i] : 0.f, wk1 = on ? (float)kn_w[i + DH / 2] : 0.f;
-  half_t* row = qkv + (size_t)t * (size_t)(n_q + 2 * n_kv) * DH;
-  for (int hd = 0; hd < n_q + n_kv; ++hd) {
-    half_t* v = row + (size_t)hd * DH;
-    float a = on ? (float)v[i] : 0.f, b = on ? (float)v[i + DH / 2] : 0.f;
-    float ss = a * a + b * b;
+  sincosf((float)pos * inv_freq, &sn, &cs);
+  table[idx] = (half2_t){(half_t)cs, (half_t)sn};
+}
+
+// ---- per-head RMSNorm, then rotary embedding (HF rotate_half convention), on MFMA operand fragments ---------------
+// f[ks][e] is element 16 ks + 8 hh + e of one head row (the lane pair (l, l ^ 32) holds the whole row), so the rotation
+// partner i + DH/2 of an element sits in the same lane (fragment ks + KS/2) and the row's sum of squares needs one
+// exchange.  Roundings follow the reference's fp16 tensors: x·inv -> fp16, ·weight -> fp16, rotation -> fp16.
+template <int DH>
+__device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* __restrict__ w, float eps,
+                                             const half2_t* __restrict__ cs_row, int hh) {
+  constexpr int KS = DH / 16;
+  float ss = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
-    const float w0 = hd < n_q ? wq0 : wk0, w1 = hd < n_q ? wq1 : wk1;
-    a = (float)(half_t)(w0 * (float)(half_t)(a * inv));  // weight * x.to(fp16): the normalised head is an fp16 tensor
-    b = (float)(half_t)(w1 * (float)(half_t)(b * inv));
-    if (on) {
-      v[i] = (half_t)(a * cs - b * sn);
-      v[i + DH / 2] = (half_t)(b * cs + a * sn);
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)f[ks][e], (float)f[ks][e], ss);
+  ss += __shfl_xor(ss, 32, 64);
+  const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
+#pragma unroll
+  for (int ks = 0; ks < KS / 2; ++ks) {
+    const int i0 = 16 * ks + 8 * hh;
+    const half8 w0 = *(const half8*)(w + i0), w1 = *(const half8*)(w + i0 + DH / 2);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 c0 = *(const u32x4*)(cs_row + i0), c1 = *(const u32x4*)(cs_row + i0 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? c0[e] : c1[e - 4]);
+      const float cs = (float)cs2[0], sn = (float)cs2[1];
+      const float a = (float)(half_t)((float)w0[e] * (float)(half_t)((float)f[ks][e] * inv));
+      const float b = (float)(half_t)((float)w1[e] * (float)(half_t)((float)f[ks + KS / 2][e] * inv));
+      f[ks][e] = (half_t)(a * cs - b * sn);
+      f[ks + KS / 2][e] = (half_t)(b * cs + a * sn);
     }
   }
 }
@@ -107,11 +118,15 @@ __global__ __launch_bounds__(256) void rarc_lm_qknorm_rope_kernel(half_t* qkv, c
 // ---- causal attention with grouped K/V heads and left padding ----------------------------------------------------
 // One wave per (sequence, q head, 32 queries); S^T = K·Q^T so a query's softmax statistics sit in one lane pair;
 // O^T += V^T·P^T with V transposed through LDS by the loader (the encoder's kernel, encoder.hip, with DH up to 128,
-// K/V taken from head hd / (n_q / n_kv), keys limited to [start[seq], query position]).
+// K/V taken from head hd / (n_q / n_kv), keys limited to [start[seq], query position]).  q and k come RAW from the
+// qkv GEMM: their per-head RMSNorm and rotary embedding are applied to the operand fragments as they are loaded
+// (lm_norm_rope) — a separate in-place pass over the qkv tensor cost 198 us per layer at 51 200 tokens.
 template <int DH>
 __global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __restrict__ qkv,
                                                                 const int32_t* __restrict__ start, int L, int n_q, int n_kv,
-                                                                int q_blocks, int n_units, half_t* __restrict__ ctx) {
+                                                                int q_blocks, int n_units, const half_t* __restrict__ qn_w,
+                                                                const half_t* __restrict__ kn_w, float eps,
+                                                                const half2_t* __restrict__ rope, half_t* __restrict__ ctx) {
   constexpr int KS = DH / 16;
   constexpr int MB = DH / 32;
   constexpr int VROW = 40;
@@ -137,6 +152,7 @@ __global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __
   half8 qf[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qbase + (size_t)qpos * rs + 16 * ks + 8 * hh);
+  lm_norm_rope<DH>(qf, qn_w, eps, rope + (size_t)qpos * (DH / 2), hh);
   f32x16 o[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
@@ -146,19 +162,27 @@ __global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __
   for (int k0 = (s0 / 32) * 32; k0 < k_end; k0 += 32) {
     const int krow = (k0 + col < L) ? k0 + col : L - 1;
     f32x16 st = {0};
+    half8 kf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const half8 kf = *(const half8*)(kbase + (size_t)krow * rs + 16 * ks + 8 * hh);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
-    }
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const half8*)(kbase + (size_t)krow * rs + 16 * ks + 8 * hh);
+    lm_norm_rope<DH>(kf, kn_w, eps, rope + (size_t)krow * (DH / 2), hh);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], st, 0, 0, 0);
     __builtin_amdgcn_wave_barrier();
+    // V^T image [d][key]: a lane takes four consecutive keys of one 8-column chunk and writes the four values of each
+    // column as one 8-byte piece (one 2-byte write per value made 64 LDS writes per lane per tile)
 #pragma unroll
-    for (int i = lane; i < 32 * (DH / 8); i += 64) {
-      const int kr = i / (DH / 8), c8 = i % (DH / 8);
-      const int vrow = (k0 + kr < L) ? k0 + kr : L - 1;
-      const half8 v = *(const half8*)(vbase + (size_t)vrow * rs + 8 * c8);
+    for (int i = lane; i < 8 * (DH / 8); i += 64) {
+      const int q4 = i & 7, c8 = i >> 3;
+      half8 v4[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) vt[(8 * c8 + e) * VROW + kr] = v[e];
+      for (int r = 0; r < 4; ++r) {
+        const int vrow = (k0 + 4 * q4 + r < L) ? k0 + 4 * q4 + r : L - 1;
+        v4[r] = *(const half8*)(vbase + (size_t)vrow * rs + 8 * c8);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        *(half4v*)(vt + (8 * c8 + e) * VROW + 4 * q4) = (half4v){v4[0][e], v4[1][e], v4[2][e], v4[3][e]};
     }
     float s[16];
     float tmax = -INFINITY;
@@ -220,12 +244,14 @@ __global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __
   }
 }
 
-// ---- SwiGLU: h[t][j] = silu(g[t][j]) · u[t][j] from the fused [g | u] -----------------------------------------------
+// ---- SwiGLU: h[t][j] = silu(g[t][j]) · u[t][j] from the fused gate/up GEMM output, whose columns come in groups of 16:
+// 8 gates, then the 8 ups of the same features (RarcLmLayer.gate_up_w, rarc.h).  Only for shapes the GEMM's own
+// SwiGLU epilogue (encoder.hip, act = 3) does not take: small batches.
 __global__ __launch_bounds__(256) void rarc_lm_swiglu_kernel(const half_t* gu, int n_tokens, int I, half_t* h) {
   const size_t n8 = (size_t)n_tokens * I / 8;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
     const size_t t = i / (I / 8), c = (i % (I / 8)) * 8;
-    const half8 g = *(const half8*)(gu + t * 2 * I + c), u = *(const half8*)(gu + t * 2 * I + I + c);
+    const half8 g = *(const half8*)(gu + t * 2 * I + 2 * c), u = *(const half8*)(gu + t * 2 * I + 2 * c + 8);
     half8 o8;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -275,7 +301,8 @@ extern "C" size_t rarc_lm_workspace_bytes(const RarcLmModel* m, int n_tokens) {
          + lm_align(T * qkv * 2)                                // fused q | k | v
          + lm_align(T * (size_t)m->n_q_heads * m->head_dim * 2)  // attention context
          + lm_align(T * 2 * (size_t)m->inter * 2)               // fused gate | up
-         + lm_align(T * (size_t)m->inter * 2);                  // silu(gate) * up
+         + lm_align(T * (size_t)m->inter * 2)                   // silu(gate) * up
+         + lm_align(T * (size_t)(m->head_dim / 2) * 4);         // rotary (cos, sin) table, at most one row per token
 }
 
 extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_seq,
@@ -307,7 +334,12 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
   half_t* ctx = (half_t*)((char*)qkv + lm_align((size_t)T * QKV * 2));
   half_t* gu = (half_t*)((char*)ctx + lm_align((size_t)T * QD * 2));
   half_t* act = (half_t*)((char*)gu + lm_align((size_t)T * 2 * I * 2));
+  half2_t* rope = (half2_t*)((char*)act + lm_align((size_t)T * I * 2));
   const int tb = (T + 3) / 4;
+
+  hipLaunchKernelGGL(rarc_lm_rope_table_kernel, dim3((seq_len * (DH / 2) + 255) / 256), dim3(256), 0, s, seq_len, DH,
+                     m->rope_theta, rope);
+  RARC_HIP_CHECK(hipGetLastError());
 
   hipLaunchKernelGGL(rarc_lm_embed_kernel, dim3(tb), dim3(256), 0, s, d_ids, (const half_t*)m->embed, T, H, m->vocab, x);
   RARC_HIP_CHECK(hipGetLastError());
@@ -320,26 +352,25 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
     RARC_HIP_CHECK(hipGetLastError());
     if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, T, QKV, H, 0, stream)) return rc;
     if (DH == 128)
-      hipLaunchKernelGGL(rarc_lm_qknorm_rope_kernel<128>, dim3(tb), dim3(256), 0, s, qkv,
-                         (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps, m->rope_theta, T, seq_len, NQ, NKV);
-    else
-      hipLaunchKernelGGL(rarc_lm_qknorm_rope_kernel<64>, dim3(tb), dim3(256), 0, s, qkv,
-                         (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps, m->rope_theta, T, seq_len, NQ, NKV);
-    RARC_HIP_CHECK(hipGetLastError());
-    if (DH == 128)
       hipLaunchKernelGGL(rarc_lm_attention_kernel<128>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const half_t*)qkv, d_start,
-                         seq_len, NQ, NKV, q_blocks, n_units, ctx);
+                         seq_len, NQ, NKV, q_blocks, n_units, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
+                         (const half2_t*)rope, ctx);
     else
       hipLaunchKernelGGL(rarc_lm_attention_kernel<64>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const half_t*)qkv, d_start,
-                         seq_len, NQ, NKV, q_blocks, n_units, ctx);
+                         seq_len, NQ, NKV, q_blocks, n_units, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
+                         (const half2_t*)rope, ctx);
     RARC_HIP_CHECK(hipGetLastError());
     if (int rc = rarc_enc_gemm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, T, H, QD, 0, stream)) return rc;
     hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)Ly.post_norm,
                        m->rms_eps, T, H, h);
     RARC_HIP_CHECK(hipGetLastError());
-    if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu, T, 2 * I, H, 0, stream)) return rc;
-    hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(2048), dim3(256), 0, s, (const half_t*)gu, T, I, act);
-    RARC_HIP_CHECK(hipGetLastError());
+    if (rarc_gemm_swiglu_fused(T, 2 * I, H)) {  // silu(gate)·up in the GEMM's epilogue: the [T][2I] tensor never exists
+      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)act, T, 2 * I, H, 3, stream)) return rc;
+    } else {
+      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu, T, 2 * I, H, 0, stream)) return rc;
+      hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(2048), dim3(256), 0, s, (const half_t*)gu, T, I, act);
+      RARC_HIP_CHECK(hipGetLastError());
+    }
     if (int rc = rarc_enc_gemm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)delta, T, H, I, 0, stream)) return rc;
   }
   // the last layer's MLP output joins the residual stream (no norm output wanted: y = null)

@@ -34,6 +34,16 @@ __device__ __forceinline__ float rarc_gelu_erf(float v) {
   return v >= 0.f ? v - hr : hr;
 }
 
+// SwiGLU epilogue (ACT 3; the reranker LM's gate|up GEMM, decoder.hip): the W rows are interleaved in groups of 8 —
+// 8 gate rows, then the 8 up rows of the same features — so in every 32 x 32 MFMA block a lane's column groups g = 0, 2
+// are gates and g = 1, 3 the matching ups, and the epilogue writes silu(gate)·up straight away: C is [M][N/2].
+// Roundings as in the unfused path (GEMM output fp16, silu fp16, product fp16), so both give the same bits.
+__device__ __forceinline__ half_t rarc_swiglu_f16(float gate_acc, float up_acc) {
+  const float gf = (float)(half_t)gate_acc, uf = (float)(half_t)up_acc;
+  const half_t act = (half_t)(gf / (1.0f + __expf(-gf)));
+  return (half_t)((float)act * uf);
+}
+
 // ------------------------------------------------------------------------------------------
 // GEMM  C[M][N] = A[M][K] · W[N][K]ᵀ + bias[N]   (M, N multiples of 128; K multiple of 64)
 // ------------------------------------------------------------------------------------------
@@ -385,6 +395,34 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   // transposes its 128 x 64 block through its own 18 KiB of LDS (row stride 144 B) and writes whole 128-byte rows.
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
   char* ep = smem + wave * G256_EP_BYTES;
+  if constexpr (ACT == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const int nl = j * 32 + 8 * g + 4 * hh;
+          const half4 bg = *(const half4*)(bias + tn * 256 + wc * 64 + nl), bu = *(const half4*)(bias + tn * 256 + wc * 64 + nl + 8);
+          half4 out;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            out[e] = rarc_swiglu_f16(acc[i][j][4 * g + e] + (float)bg[e], acc[i][j][4 * g + 4 + e] + (float)bu[e]);
+          *(half4*)(ep + (i * 32 + row) * G256_EP_STRIDE + (j * 16 + 4 * g + 4 * hh) * 2) = out;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int r16 = lane >> 2, c = lane & 3;
+    const int NO = N / 2;
+    half_t* Cw = C + (size_t)(tm * 256 + wr * 128) * NO + tn * 128 + wc * 32 + c * 8;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = t * 16 + r16;
+      *(uint4*)(Cw + (size_t)r * NO) = *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -538,6 +576,30 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
   // epilogue: acc[i] is rows wr*128 + i*32 + row, cols wc*32 + (8g + 4hh .. +3); transposed through LDS like above
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
   char* ep = smem + wave * G128_EP_BYTES;
+  if constexpr (ACT == 3) {  // silu(gate)·up (see rarc_swiglu_f16): the wave's 32 columns are 16 features -> 32-byte rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        const int nl = 8 * g + 4 * hh;
+        const half4 bg = *(const half4*)(bias + tn * 128 + wc * 32 + nl), bu = *(const half4*)(bias + tn * 128 + wc * 32 + nl + 8);
+        half4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = rarc_swiglu_f16(acc[i][4 * g + e] + (float)bg[e], acc[i][4 * g + 4 + e] + (float)bu[e]);
+        *(half4*)(ep + (i * 32 + row) * G128_EP_STRIDE + (4 * g + 4 * hh) * 2) = out;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int r32 = lane >> 1, c = lane & 1;
+    const int NO = N / 2;
+    half_t* Cw = C + (size_t)(tm * 256 + wr * 128) * NO + tn * 64 + wc * 16 + c * 8;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = t * 32 + r32;
+      *(uint4*)(Cw + (size_t)r * NO) = *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -1126,6 +1188,16 @@ static int enc_gemm_splitk(const uint16_t* d_a, const uint16_t* d_w, float* d_pa
   return RARC_OK;
 }
 
+// true when rarc_enc_gemm(m, n, k) runs one of the 256-row ping-pong kernels, i.e. when act = 3 (fused SwiGLU) is available
+bool rarc_gemm_swiglu_fused(int m, int n, int k) {
+  static const int force = getenv("RARC_GEMM_PP") ? atoi(getenv("RARC_GEMM_PP")) : -1;
+  if (force == 0 || m <= 0 || m % 256 || n % GN || k % GK) return false;
+  const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
+  static const int t256_min = getenv("RARC_GEMM_T256_MIN") ? atoi(getenv("RARC_GEMM_T256_MIN")) : 384;
+  if (force != 1 && t256 >= 256 && (t256 % 256 == 0 || t256 >= t256_min)) return true;
+  return t128 >= 256 && k >= 3 * GK;
+}
+
 extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
                              int n, int k, int act, void* stream) {
   RARC_REQUIRE(d_a && d_w && d_bias && d_c, RARC_E_INVALID, "rarc_enc_gemm: null pointer");
@@ -1144,24 +1216,31 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   constexpr size_t lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
   constexpr size_t lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
   if (int rc = gemm_attrs()) return rc;
-  // ping-pong kernels for the big shapes: 256 x 256 tiles when they come in whole rounds of the 256 CUs (or in
-  // many rounds), else 256 x 128 tiles; the older kernels below serve small batches and odd shapes
+  // ping-pong kernels for the big shapes: 256 x 256 tiles when they come in whole rounds of the 256 CUs or in at
+  // least 384 tiles (a 256 x 256 tile costs 1.4x a 256 x 128 one for twice the area, which outweighs a ragged last
+  // round from there on: 51 200 x 1024 x 3072 went from 415 to 339 us), else 256 x 128 tiles; the older kernels
+  // below serve small batches and odd shapes
   static const int force = getenv("RARC_GEMM_PP") ? atoi(getenv("RARC_GEMM_PP")) : -1;  // 0 off, 1 = 256x128 only
   if (force != 0 && m % 256 == 0) {
     const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
-    if (force != 1 && t256 >= 256 && (t256 % 256 == 0 || t256 >= 1024)) {
-      if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+    static const int t256_min = getenv("RARC_GEMM_T256_MIN") ? atoi(getenv("RARC_GEMM_T256_MIN")) : 384;  // (experiments)
+    if (force != 1 && t256 >= 256 && (t256 % 256 == 0 || t256 >= t256_min)) {
+      if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
       else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
     }
     if (t128 >= 256 && k >= 3 * GK) {
-      if (act == 1) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<1>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      if (act == 3) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<3>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 1) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<1>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<0>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
     }
   }
+  RARC_REQUIRE(act != 3, RARC_E_UNSUPPORTED, "rarc_enc_gemm: the fused SwiGLU epilogue needs a shape the 256-row kernels take "
+               "(ask rarc_gemm_swiglu_fused first)");
   if (deep && force != 0 && k >= 4 * GK) {
     const int grid = (m / GM) * (n / GN);
     if (act == 1) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<1>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);

@@ -40,6 +40,7 @@ def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed):
     (256, 1, 2, 2, 128, 256, 4, 32, (0, 31, 1, 12)),           # head_dim 128 (every Qwen3 reranker's), no grouping
     (512, 3, 8, 2, 64, 1024, 3, 100, (0, 60, 99)),             # four q heads per kv head; keys span four tiles
     (1024, 2, 16, 8, 128, 3072, 8, 64, (0, 5, 20, 63)),        # Qwen3-Reranker-0.6B's layer geometry, two layers
+    (256, 2, 4, 2, 64, 2048, 32, 64, (0, 9, 40, 63)),          # 2048 tokens: SwiGLU runs as the gate/up GEMM's epilogue
 ])
 def test_yes_no_logits_match_oracle(oracle, H, LAYERS, NQ, NKV, DH, I, n, L, pads):
     _run(oracle, H, LAYERS, NQ, NKV, DH, I, 1000, n, L, pads, seed=H + L)
@@ -122,3 +123,36 @@ def test_qwen3_reranker_from_json_registry(oracle, tmp_path):
     assert [d.id for d in got] == [d.id for d in want] and len(got) == 5
     scores = direct.compute_scores([("what is a vector index ?", d.content) for d in docs[:8]])
     assert len(scores) == 8 and all(0.0 <= s <= 1.0 for s in scores)
+
+
+@pytest.mark.parametrize("m,n,k", [(2048, 4096, 256), (4096, 4096, 128), (8192, 6144, 192), (256, 32768, 64 * 3)])
+def test_swiglu_epilogue_equals_gemm_then_swiglu(m, n, k):
+    """rarc_enc_gemm act = 3 (gate / up columns interleaved in groups of 8 -> silu(gate)·up, [m][n/2]) against the
+    plain GEMM's own output put through the same roundings on the host side: fp16 GEMM output, fp16 silu, fp16 product.
+    Both the 256 x 256 and the 256 x 128 tile kernels are taken by these shapes."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(m + n + k)
+    a = (torch.randn((m, k), generator=g, device="cuda") * 0.5).half()
+    w = (torch.randn((n, k), generator=g, device="cuda") * 0.2).half()
+    bias = (torch.randn((n,), generator=g, device="cuda") * 0.3).half()
+    plain = torch.empty((m, n), dtype=torch.float16, device="cuda")
+    fused = torch.full((m, n // 2), float("nan"), dtype=torch.float16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    B.check(lib.rarc_enc_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), plain.data_ptr(), m, n, k, 0, st))
+    B.check(lib.rarc_enc_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), fused.data_ptr(), m, n, k, 3, st))
+    gu = plain.view(m, n // 16, 2, 8).float()
+    gate, up = gu[:, :, 0].reshape(m, n // 2), gu[:, :, 1].reshape(m, n // 2)
+    want = ((gate / (1.0 + torch.exp(-gate))).half().float() * up).half()
+    assert bool(torch.isfinite(fused).all())
+    diff = (fused.float() - want.float()).abs()
+    ulp = torch.clamp(want.float().abs(), min=6e-5) * 2.0 ** -10            # device __expf vs torch.exp: a last-bit matter
+    assert bool((diff <= 2.0 * ulp).all()) and float((diff == 0).float().mean()) > 0.98
+    # a shape the 256-row kernels do not take: refused loudly, not computed some other way
+    small = torch.empty((128, 64), dtype=torch.float16, device="cuda")
+    rc = lib.rarc_enc_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), small.data_ptr(), 128, 128, k, 3, st)
+    assert rc != 0
