@@ -10,7 +10,7 @@ JSON -> <Config>(**data).build() -> module graph, e.g.
                                      "corpus_path": "corpus.npz"}}]}
 """
 from dataclasses import dataclass, field
-from typing import Annotated, Any, Dict, List, Literal, Optional, Union
+from typing import ClassVar, Annotated, Any, Dict, List, Literal, Optional, Union
 
 from pydantic import Field
 
@@ -139,11 +139,14 @@ class HipLogitRerankerConfig(AbstractConfig):
 class HipQwen3RerankerConfig(AbstractConfig):
     """The reference's Qwen3Reranker (core/rerank/Reranker_Qwen3.py:6-75) with the LM forward on the MI355X
     (rarc_lm_yes_no_logits).  `weights_path`: a Qwen3ForCausalLM state dict (.safetensors / .npz, HuggingFace names);
-    `tokenizer_path`: the checkpoint's tokenizer.json (loaded with the `tokenizers` library, as AutoTokenizer does);
-    the head geometry comes from the checkpoint's config.json (Qwen3-Reranker-0.6B: 16 / 8 heads of 128)."""
+    `tokenizer_path`: the checkpoint's tokenizer.json, or `vocab_path` + `merges_path`: its vocab.json and merges.txt
+    (byte-level BPE, rag_arc_amd.core.rerank.bpe); the head geometry comes from the checkpoint's config.json
+    (Qwen3-Reranker-0.6B: 16 / 8 heads of 128)."""
     type: Literal["hip_qwen3_reranker"] = "hip_qwen3_reranker"
     weights_path: str
-    tokenizer_path: str
+    tokenizer_path: Optional[str] = None
+    vocab_path: Optional[str] = None
+    merges_path: Optional[str] = None
     num_attention_heads: int
     num_key_value_heads: int
     head_dim: int = 128
@@ -154,21 +157,46 @@ class HipQwen3RerankerConfig(AbstractConfig):
     device: int = 0
 
     def build(self) -> AbstractModule:
-        from tokenizers import Tokenizer
-
+        from ..core.rerank.bpe import ByteLevelBPETokenizer
         from ..core.rerank.hip_qwen3 import HipCausalLM, HipQwen3Reranker
         from ..encapsulation.embeddings.hip_bert import load_state_dict
 
-        tok = Tokenizer.from_file(self.tokenizer_path)
-        yes_id, no_id = tok.token_to_id("yes"), tok.token_to_id("no")
-        if yes_id is None or no_id is None:
-            raise ValueError("the tokenizer has no 'yes' / 'no' tokens")
+        if self.tokenizer_path:
+            import json
+
+            with open(self.tokenizer_path, encoding="utf-8") as fh:
+                kind = json.load(fh).get("model", {}).get("type")
+            if kind == "BPE":
+                tok = ByteLevelBPETokenizer.from_tokenizer_json(self.tokenizer_path)
+            else:                                   # another tokenizer model: the library AutoTokenizer itself loads it with
+                from tokenizers import Tokenizer
+
+                lib_tok = Tokenizer.from_file(self.tokenizer_path)
+
+                class _LibraryTokenizer:
+                    encode = staticmethod(lambda text: lib_tok.encode(text, add_special_tokens=False).ids)
+                    convert_tokens_to_ids = staticmethod(lib_tok.token_to_id)
+
+                tok = _LibraryTokenizer
+        elif self.vocab_path and self.merges_path:
+            special = {t: i for i, t in enumerate(self.SPECIAL_TOKENS, start=self.FIRST_SPECIAL_ID)}
+            tok = ByteLevelBPETokenizer.from_files(self.vocab_path, self.merges_path, special)
+        else:
+            raise ValueError("hip_qwen3_reranker: give tokenizer_path, or vocab_path and merges_path")
         lm = HipCausalLM(load_state_dict(self.weights_path), self.num_attention_heads, self.num_key_value_heads,
                          self.head_dim, rms_norm_eps=self.rms_norm_eps, rope_theta=self.rope_theta, device=self.device)
-        pad = tok.token_to_id("<|endoftext|>")
-        rr = HipQwen3Reranker(lm, lambda text: tok.encode(text, add_special_tokens=False).ids, yes_id=yes_id, no_id=no_id,
-                              max_length=self.max_length, instruction=self.instruction, pad_id=pad if pad is not None else 0)
+        rr = HipQwen3Reranker.from_tokenizer(lm, tok, max_length=self.max_length, instruction=self.instruction)
         return BuiltModule(config=self, impl=rr)
+
+    # vocab.json carries no added tokens; Qwen2 / Qwen3 checkpoints list these, in this order, from id 151643 on
+    # (tokenizer_config.json: added_tokens_decoder) — tokenizer.json has them inside and needs none of this
+    FIRST_SPECIAL_ID: ClassVar[int] = 151643
+    SPECIAL_TOKENS: ClassVar[tuple] = (
+        "<|endoftext|>", "<|im_start|>", "<|im_end|>", "<|object_ref_start|>", "<|object_ref_end|>", "<|box_start|>",
+        "<|box_end|>", "<|quad_start|>", "<|quad_end|>", "<|vision_start|>", "<|vision_end|>", "<|vision_pad|>",
+        "<|image_pad|>", "<|video_pad|>", "<tool_call>", "</tool_call>", "<|fim_prefix|>", "<|fim_middle|>",
+        "<|fim_suffix|>", "<|fim_pad|>", "<|repo_name|>", "<|file_sep|>", "<tool_response>", "</tool_response>",
+        "<think>", "</think>")
 
 
 RerankerConfig = Annotated[Union[HipLogitRerankerConfig, HipQwen3RerankerConfig], Field(discriminator="type")]

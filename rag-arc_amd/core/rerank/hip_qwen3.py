@@ -7,9 +7,10 @@ stable descending sort, optional top-k (:70-74).  The LM forward runs in rarc_lm
 (csrc/decoder.hip: RMSNorm, RoPE, grouped-query causal attention, SwiGLU, MFMA GEMMs), the score -> order step in
 rarc_rerank_order.  Weights are a HuggingFace Qwen3ForCausalLM state dict kept fp16 in HBM.
 
-The tokeniser is a callable `tokenize(text) -> list[int]` (Qwen's BPE vocabulary does not ship here — no network);
-`prefix_ids` / `suffix_ids` are the token ids of the chat-template prefix and suffix the reference encodes at
-construction (:14-17), `yes_id` / `no_id` those of "yes" / "no" (:18-19).
+The tokeniser is a callable `tokenize(text) -> list[int]`; `from_tokenizer` takes the byte-level BPE tokeniser of
+rag_arc_amd.core.rerank.bpe (over the checkpoint's vocab.json + merges.txt or tokenizer.json — Qwen's vocabulary does
+not ship here, no network) and derives what the reference's constructor does: `prefix_ids` / `suffix_ids`, the token
+ids of the chat-template prefix and suffix (:14-17), and `yes_id` / `no_id`, those of "yes" / "no" (:18-19).
 """
 from __future__ import annotations
 
@@ -146,6 +147,19 @@ class HipQwen3Reranker(HipLogitReranker):
         self.prefix_ids = list(tokenize(self.PREFIX)) if prefix_ids is None else list(prefix_ids)
         self.suffix_ids = list(tokenize(self.SUFFIX)) if suffix_ids is None else list(suffix_ids)
         self.max_length = int(max_length)
+
+    @classmethod
+    def from_tokenizer(cls, lm: HipCausalLM, tokenizer, max_length: int = 4096, instruction: Optional[str] = None,
+                       pad_token: str = "<|endoftext|>", device: Optional[int] = None):
+        """What the reference's constructor derives from its tokenizer (Reranker_Qwen3.py:14-19): the ids of "yes" / "no",
+        the encoded prefix and suffix; `tokenizer` has encode(text) -> ids and convert_tokens_to_ids(token)
+        (rag_arc_amd.core.rerank.bpe.ByteLevelBPETokenizer over the checkpoint's vocab.json + merges.txt or tokenizer.json)."""
+        yes_id, no_id = tokenizer.convert_tokens_to_ids("yes"), tokenizer.convert_tokens_to_ids("no")
+        if yes_id is None or no_id is None:
+            raise ValueError("the tokenizer has no 'yes' / 'no' tokens")
+        pad = tokenizer.convert_tokens_to_ids(pad_token)
+        return cls(lm, tokenizer.encode, yes_id=yes_id, no_id=no_id, max_length=max_length, instruction=instruction,
+                   pad_id=0 if pad is None else pad, device=device)
 
     def process_inputs(self, pairs: Sequence[str]):
         """Reranker_Qwen3.py:29-39: truncate each pair's tokens, wrap in prefix / suffix, left pad.  Returns

@@ -1188,13 +1188,22 @@ static int enc_gemm_splitk(const uint16_t* d_a, const uint16_t* d_w, float* d_pa
   return RARC_OK;
 }
 
+// 256 x 256 or 256 x 128 tiles?  One workgroup per CU either way, so the time is rounds x time per round, and a
+// 256 x 256 tile takes about 1.5x a 256 x 128 one for twice the area (measured 1.44x at K = 3072): the larger tile
+// wins whenever its ragged last round costs less than that (51 200 x 1024 x 3072: 800 tiles in 4 rounds, 339 us,
+// against 1600 tiles in 7 rounds, 415 us; 8192 x 3072 x 1024: 384 tiles in 2 rounds ties with 768 in 3 and stays).
+static bool gemm_prefers_256x256(int t256, int t128) {
+  constexpr int CUS = 256;
+  if (t256 < CUS) return false;
+  return 3 * ((t256 + CUS - 1) / CUS) < 2 * ((t128 + CUS - 1) / CUS);
+}
+
 // true when rarc_enc_gemm(m, n, k) runs one of the 256-row ping-pong kernels, i.e. when act = 3 (fused SwiGLU) is available
 bool rarc_gemm_swiglu_fused(int m, int n, int k) {
   static const int force = getenv("RARC_GEMM_PP") ? atoi(getenv("RARC_GEMM_PP")) : -1;
   if (force == 0 || m <= 0 || m % 256 || n % GN || k % GK) return false;
   const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
-  static const int t256_min = getenv("RARC_GEMM_T256_MIN") ? atoi(getenv("RARC_GEMM_T256_MIN")) : 384;
-  if (force != 1 && t256 >= 256 && (t256 % 256 == 0 || t256 >= t256_min)) return true;
+  if (force != 1 && gemm_prefers_256x256(t256, t128)) return true;
   return t128 >= 256 && k >= 3 * GK;
 }
 
@@ -1216,15 +1225,12 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   constexpr size_t lds_small = 2 * (128 * GK * 2 + GN * GK * 2), lds_big = 3 * (256 * GK * 2 + GN * GK * 2);
   constexpr size_t lds_deep = 4 * (128 * GK * 2 + GN * GK * 2);
   if (int rc = gemm_attrs()) return rc;
-  // ping-pong kernels for the big shapes: 256 x 256 tiles when they come in whole rounds of the 256 CUs or in at
-  // least 384 tiles (a 256 x 256 tile costs 1.4x a 256 x 128 one for twice the area, which outweighs a ragged last
-  // round from there on: 51 200 x 1024 x 3072 went from 415 to 339 us), else 256 x 128 tiles; the older kernels
+  // ping-pong kernels for the big shapes, 256 x 256 or 256 x 128 tiles by gemm_prefers_256x256; the older kernels
   // below serve small batches and odd shapes
   static const int force = getenv("RARC_GEMM_PP") ? atoi(getenv("RARC_GEMM_PP")) : -1;  // 0 off, 1 = 256x128 only
   if (force != 0 && m % 256 == 0) {
     const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
-    static const int t256_min = getenv("RARC_GEMM_T256_MIN") ? atoi(getenv("RARC_GEMM_T256_MIN")) : 384;  // (experiments)
-    if (force != 1 && t256 >= 256 && (t256 % 256 == 0 || t256 >= t256_min)) {
+    if (force != 1 && gemm_prefers_256x256(t256, t128)) {
       if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
       else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);

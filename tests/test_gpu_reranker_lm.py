@@ -125,6 +125,66 @@ def test_qwen3_reranker_from_json_registry(oracle, tmp_path):
     assert len(scores) == 8 and all(0.0 <= s <= 1.0 for s in scores)
 
 
+def test_qwen3_reranker_registry_with_byte_level_bpe_files(oracle, tmp_path):
+    """The same through a byte-level BPE vocabulary (trained offline here; Qwen's is not on disk): tokenizer.json and the
+    vocab.json + merges.txt pair both register, tokenise like the `tokenizers` library and give the same ranking."""
+    import json
+
+    from safetensors.numpy import save_file
+    from tokenizers import AddedToken, Regex, Tokenizer, models, normalizers, pre_tokenizers, trainers
+
+    from rag_arc_amd.config.app_registration import register_qwen3_reranker, registrator
+    from rag_arc_amd.config.modules import HipQwen3RerankerConfig
+    from rag_arc_amd.core.rerank import HipCausalLM, HipQwen3Reranker
+    from rag_arc_amd.core.rerank.bpe import QWEN_PATTERN
+    from rag_arc_amd.core.utils.data_model import Document
+
+    docs = [Document(content=f"passage {i}: a vector index ranks {i * 37 % 11} rows; naïve café 北京!", metadata={}, id=str(i)) for i in range(9)]
+    corpus = [HipQwen3Reranker.PREFIX, HipQwen3Reranker.SUFFIX, "yes no yes no", "<Instruct>: <Query>: <Document>:"] + [d.content for d in docs]
+    tok = Tokenizer(models.BPE())
+    tok.normalizer = normalizers.NFC()
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split(Regex(QWEN_PATTERN), behavior="isolated", invert=False),
+                                                 pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    tok.train_from_iterator(corpus * 4, trainers.BpeTrainer(vocab_size=420, initial_alphabet=pre_tokenizers.ByteLevel.alphabet(),
+                                                            special_tokens=[], show_progress=False))
+    first = tok.get_vocab_size()
+    tok.add_special_tokens([AddedToken(t, special=True, normalized=False) for t in HipQwen3RerankerConfig.SPECIAL_TOKENS])
+    assert tok.token_to_id("<|endoftext|>") == first and tok.token_to_id("yes") is not None and tok.token_to_id("no") is not None
+    tok.save(str(tmp_path / "tokenizer.json"))
+    spec = json.loads(tok.to_str())
+    (tmp_path / "vocab.json").write_text(json.dumps(spec["model"]["vocab"]), encoding="utf-8")
+    (tmp_path / "merges.txt").write_text("#version: 0.2\n" + "\n".join(" ".join(m) for m in spec["model"]["merges"]) + "\n", encoding="utf-8")
+    H, LAYERS, NQ, NKV, DH, I = 256, 2, 4, 2, 64, 512
+    V = (tok.get_vocab_size() + 7) // 8 * 8
+    sd = {k: np.ascontiguousarray(v) for k, v in oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=13).items()
+          if k != "lm_head.weight"}
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    common = {"type": "hip_qwen3_reranker", "weights_path": str(tmp_path / "model.safetensors"), "num_attention_heads": NQ,
+              "num_key_value_heads": NKV, "head_dim": DH, "max_length": 160}
+    (tmp_path / "a.json").write_text(json.dumps({**common, "tokenizer_path": str(tmp_path / "tokenizer.json")}))
+    (tmp_path / "b.json").write_text(json.dumps({**common, "vocab_path": str(tmp_path / "vocab.json"), "merges_path": str(tmp_path / "merges.txt")}))
+    register_qwen3_reranker(str(tmp_path / "a.json"), "q3_json")
+    a = registrator.get_object("q3_json")
+    direct = HipQwen3Reranker(HipCausalLM(sd, NQ, NKV, DH), lambda t: tok.encode(t, add_special_tokens=False).ids,
+                              yes_id=tok.token_to_id("yes"), no_id=tok.token_to_id("no"), max_length=160,
+                              pad_id=tok.token_to_id("<|endoftext|>"))
+    assert a.impl.prefix_ids == direct.prefix_ids and a.impl.suffix_ids == direct.suffix_ids
+    assert (a.impl.yes_id, a.impl.no_id, a.impl.pad_id) == (direct.yes_id, direct.no_id, direct.pad_id)
+    q = "what's a vector index?"
+    want = [d.id for d in direct.rerank(q, docs, k=6)]
+    assert [d.id for d in a.rerank(q, docs, k=6)] == want
+    # vocab.json + merges.txt: the special tokens take Qwen's fixed ids (151643 ...), which this toy embedding table does not
+    # hold — the tokenisation of plain text and the yes / no ids are what the pair of files determines
+    cfg_b = HipQwen3RerankerConfig(**json.loads((tmp_path / "b.json").read_text()))
+    from rag_arc_amd.core.rerank.bpe import ByteLevelBPETokenizer
+
+    tb = ByteLevelBPETokenizer.from_files(cfg_b.vocab_path, cfg_b.merges_path,
+                                          {t: i for i, t in enumerate(cfg_b.SPECIAL_TOKENS, start=cfg_b.FIRST_SPECIAL_ID)})
+    assert tb.encode(docs[3].content) == tok.encode(docs[3].content, add_special_tokens=False).ids
+    assert tb.encode("<|im_end|>\n") == [cfg_b.FIRST_SPECIAL_ID + 2] + tok.encode("\n", add_special_tokens=False).ids
+    assert tb.convert_tokens_to_ids("yes") == tok.token_to_id("yes")
+
+
 @pytest.mark.parametrize("m,n,k", [(2048, 4096, 256), (4096, 4096, 128), (8192, 6144, 192), (256, 32768, 64 * 3)])
 def test_swiglu_epilogue_equals_gemm_then_swiglu(m, n, k):
     """rarc_enc_gemm act = 3 (gate / up columns interleaved in groups of 8 -> silu(gate)·up, [m][n/2]) against the
