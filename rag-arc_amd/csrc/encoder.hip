@@ -49,6 +49,28 @@ __device__ __forceinline__ half_t rarc_swiglu_f16(float gate_acc, float up_acc) 
 // ------------------------------------------------------------------------------------------
 constexpr int GM = 128, GN = 128, GK = 64;  // smallest tile (M is padded to a multiple of GM by the host)
 
+// blockIdx -> output tile.  Workgroups go to the 8 XCDs round-robin by id, every XCD has its own 4 MB L2, and the
+// 32 workgroups resident on an XCD run their k loops roughly in step.  order 0 / 1 (the plain row- or column-major
+// walks) hand an XCD 32 tiles that share ONE operand tile between them: the other operand is fetched 32 times over
+// from the fabric, and the GEMMs sat at the ~6.4 TB/s the CUs can pull past their L2s (11 bytes per cycle per CU,
+// MFMA pipe busy 38 %).  order 2: XCD x owns a contiguous range of a "grouped" tile order — 8 row-tiles deep, then
+// the next column-tile — so its 32 resident tiles form an 8 x 4 block: 12 operand tiles serve 32 output tiles.
+__device__ __forceinline__ void gemm_tile_of(int bid, int grid, int tiles_m, int tiles_n, int order, int& tm, int& tn) {
+  if (order != 2) {
+    tm = order ? bid / tiles_n : bid % tiles_m;
+    tn = order ? bid % tiles_n : bid / tiles_m;
+    return;
+  }
+  const int x = bid & 7, q = grid >> 3, rem = grid & 7;
+  const int id = x * q + (x < rem ? x : rem) + (bid >> 3);  // XCD x: ids [x*q + min(x, rem), ... + q + (x < rem))
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * tiles_n, g = id / per_group, first_m = g * GROUP_M;
+  const int rows = tiles_m - first_m < GROUP_M ? tiles_m - first_m : GROUP_M;
+  const int in_group = id - g * per_group;
+  tm = first_m + in_group % rows;
+  tn = in_group / rows;
+}
+
 // BM x 128 x 64 tiles, BM/32 x 2... waves laid out (BM/64) x 2, each computing a 64 x 64 block of C as 2 x 2
 // v_mfma_f32_32x32x16_f16.  Operand tiles stream HBM -> LDS by LDS-DMA (8 rows x 128 B per instruction,
 // XOR-swizzled on the source side: conflict-free ds_read_b128 fragments), STAGES deep:
@@ -80,7 +102,8 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
   //   order 1: tn = id % tiles_n  -> an XCD keeps a few W tiles, A crosses 8 times   (M < N: small batches)
   const int tiles_m = M / BM, tiles_n = N / GN;
   const int bid = blockIdx.x;
-  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  int tm, tn;
+  gemm_tile_of(bid, (int)gridDim.x, tiles_m, tiles_n, order, tm, tn);
   const half_t* Ab = A + (size_t)tm * BM * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
   const half_t* Wb = W + (size_t)tn * GN * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
 
@@ -254,25 +277,38 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   const int lane = tid & 63;
   const int row = lane & 31, hh = lane >> 5;
   const int wr = wave >> 2, wc = wave & 3;
-  const int tiles_m = M / 256, tiles_n = N / 256;
-  const int bid = blockIdx.x;
-  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+  // persistent: a workgroup walks tiles blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of 8, so all of them sit
+  // on its own XCD's share of the tile order).  The stores of one tile's epilogue drain while the next tile's
+  // first operand tiles are fetched, instead of holding the CU until they are acknowledged.
+  const int drow = lane >> 3, dslot = lane & 7;
+  uint32_t soff[4][2];
+#pragma unroll
+  for (int which = 0; which < 4; ++which)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int lr = 8 * (wave * 2 + j) + drow;  // row inside the 128-row half-tile
+      const int c = dslot ^ ((lr >> 1) & 7);     // XOR swizzle on the source side
+      const int h = which & 1;
+      const int trow = which < 2 ? (lr >> 6) * 128 + h * 64 + (lr & 63) : (lr >> 5) * 64 + h * 32 + (lr & 31);
+      soff[which][j] = ((uint32_t)trow * (uint32_t)K + (uint32_t)c * 8u) * 2u;
+    }
+  for (int bid = blockIdx.x; bid < n_tiles; bid += gridDim.x) {
+  int tm, tn;
+  gemm_tile_of(bid, n_tiles, tiles_m, tiles_n, order, tm, tn);
   const half_t* Ab = A + (size_t)tm * 256 * K;
   const half_t* Wb = W + (size_t)tn * 256 * K;
   const int KT = K / GK;
 
-  // staging: half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k tile kt into parity par; this wave's two KiB of it
-  const int drow = lane >> 3, dslot = lane & 7;
+  // staging: half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k tile kt into parity par; this wave's two KiB of it.
+  // The lane's source offsets inside a tile fit 32 bits (256 rows x K halves) and do not depend on the tile: eight
+  // registers for the whole kernel, added to the uniform tile base (64-bit pairs here spilled once the tile loop came).
   auto stage = [&](int par, int which, int kt) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int i = wave * 2 + j;      // 8-row block of the 128-row half-tile
-      const int lr = 8 * i + drow;     // row inside the half-tile
-      const int c = dslot ^ ((lr >> 1) & 7);
-      const int h = which & 1;
-      const half_t* src = which < 2 ? Ab + (size_t)((lr >> 6) * 128 + h * 64 + (lr & 63)) * K
-                                    : Wb + (size_t)((lr >> 5) * 64 + h * 32 + (lr & 31)) * K;
-      __builtin_amdgcn_global_load_lds(RARC_GPTR(src + kt * GK + c * 8),
+      const char* base = (const char*)(which < 2 ? Ab : Wb) + (size_t)kt * (GK * 2);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(base + soff[which][j]),
                                        RARC_LPTR(smem + par * 65536 + which * 16384 + i * 1024), 16, 0, 0);
     }
   };
@@ -394,6 +430,11 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   // bytes each.  The pipeline buffers are dead now (every wave is past the last barrier), so each wave
   // transposes its 128 x 64 block through its own 18 KiB of LDS (row stride 144 B) and writes whole 128-byte rows.
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  // (the lane index goes through an opaque copy: everything the epilogue derives from it would otherwise be hoisted
+  //  out of the tile loop and kept in registers through the main loop, which has none to spare)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int row_e = lane_e & 31, hh_e = lane_e >> 5;
   char* ep = smem + wave * G256_EP_BYTES;
   if constexpr (ACT == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
 #pragma unroll
@@ -402,18 +443,18 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
       for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
-          const int nl = j * 32 + 8 * g + 4 * hh;
+          const int nl = j * 32 + 8 * g + 4 * hh_e;
           const half4 bg = *(const half4*)(bias + tn * 256 + wc * 64 + nl), bu = *(const half4*)(bias + tn * 256 + wc * 64 + nl + 8);
           half4 out;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             out[e] = rarc_swiglu_f16(acc[i][j][4 * g + e] + (float)bg[e], acc[i][j][4 * g + 4 + e] + (float)bu[e]);
-          *(half4*)(ep + (i * 32 + row) * G256_EP_STRIDE + (j * 16 + 4 * g + 4 * hh) * 2) = out;
+          *(half4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + (j * 16 + 4 * g + 4 * hh_e) * 2) = out;
         }
       }
     }
     __builtin_amdgcn_wave_barrier();
-    const int r16 = lane >> 2, c = lane & 3;
+    const int r16 = lane_e >> 2, c = lane_e & 3;
     const int NO = N / 2;
     half_t* Cw = C + (size_t)(tm * 256 + wr * 128) * NO + tn * 128 + wc * 32 + c * 8;
 #pragma unroll
@@ -421,15 +462,14 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
       const int r = t * 16 + r16;
       *(uint4*)(Cw + (size_t)r * NO) = *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16);
     }
-    return;
-  }
+  } else {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * hh;  // column inside the wave's block
+        const int nl = j * 32 + 8 * g + 4 * hh_e;  // column inside the wave's block
         const half4 b4 = *(const half4*)(bias + tn * 256 + wc * 64 + nl);
         half4 out;
 #pragma unroll
@@ -438,19 +478,24 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
           if (ACT == 1) v = rarc_gelu_erf(v);
           out[e] = (half_t)v;
         }
-        *(half4*)(ep + (i * 32 + row) * G256_EP_STRIDE + nl * 2) = out;
+        *(half4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + nl * 2) = out;
       }
     }
   }
   __builtin_amdgcn_wave_barrier();
   {
-    const int r8 = lane >> 3, c = lane & 7;
+    const int r8 = lane_e >> 3, c = lane_e & 7;
     half_t* Cw = C + (size_t)(tm * 256 + wr * 128) * N + tn * 256 + wc * 64 + c * 8;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int r = t * 8 + r8;
       *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16);
     }
+  }
+  }
+  // every wave is done reading its staging block before the next tile's operand DMA lands in the same LDS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
   }
 }
 
@@ -480,7 +525,8 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_m = M / 256, tiles_n = N / 128;
   const int bid = blockIdx.x;
-  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  int tm, tn;
+  gemm_tile_of(bid, (int)gridDim.x, tiles_m, tiles_n, order, tm, tn);
   const half_t* Ab = A + (size_t)tm * 256 * K;
   const half_t* Wb = W + (size_t)tn * 128 * K;
   const int KT = K / GK;  // >= 3 (launcher)
@@ -652,7 +698,8 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
   const int wr = wave >> 2, wc = wave & 3;
   const int tiles_m = M / 128, tiles_n = N / 128;
   const int bid = blockIdx.x;
-  const int tm = order ? bid / tiles_n : bid % tiles_m, tn = order ? bid % tiles_n : bid / tiles_m;
+  int tm, tn;
+  gemm_tile_of(bid, (int)gridDim.x, tiles_m, tiles_n, order, tm, tn);
   const half_t* Ab = A + (size_t)tm * 128 * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
   const half_t* Wb = W + (size_t)tn * 128 * ldk + (ACT == 2 ? (size_t)blockIdx.y * K : 0);
   const int KT = K / GK;  // >= 4 (launcher)
@@ -1154,6 +1201,8 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm_f16_kernel<2, 128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_deep));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
@@ -1218,7 +1267,9 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   // 256-row tiles (3-stage pipeline, one workgroup per CU) when M allows it and there are enough tiles to
   // fill the chip; the 128-row kernel otherwise
   const bool big = (m % 256 == 0) && ((m / 256) * (n / GN) >= 256);
-  const int order = m < n ? 1 : 0;  // the smaller operand is the one that crosses the fabric 8 times
+  // XCD-aware grouped tile order (gemm_tile_of); RARC_GEMM_SWZ=0: the plain walk, the smaller operand crossing the fabric 8 times
+  static const bool swz = !(getenv("RARC_GEMM_SWZ") && atoi(getenv("RARC_GEMM_SWZ")) == 0);
+  const int order = swz ? 2 : (m < n ? 1 : 0);
   // few tiles (small batches): at most one workgroup per CU, nothing else to hide the HBM/L2 latency of the
   // k loop behind -> four stages (three tiles in flight) instead of two
   const bool deep = !big && ((m / GM) * (n / GN) <= 256) && k >= 4 * GK;
@@ -1231,9 +1282,11 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   if (force != 0 && m % 256 == 0) {
     const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
     if (force != 1 && gemm_prefers_256x256(t256, t128)) {
-      if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
-      else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
-      else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(t256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+      static const bool persist = !(getenv("RARC_GEMM_PERSIST") && atoi(getenv("RARC_GEMM_PERSIST")) == 0);
+      const int g256 = persist && t256 > 256 ? 256 : t256;
+      if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+      else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
     }
