@@ -116,32 +116,44 @@ __device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* 
 }
 
 // ---- causal attention with grouped K/V heads and left padding ----------------------------------------------------
-// One wave per (sequence, q head, 32 queries); S^T = K·Q^T so a query's softmax statistics sit in one lane pair;
-// O^T += V^T·P^T with V transposed through LDS by the loader (the encoder's kernel, encoder.hip, with DH up to 128,
-// K/V taken from head hd / (n_q / n_kv), keys limited to [start[seq], query position]).  q and k come RAW from the
-// qkv GEMM: their per-head RMSNorm and rotary embedding are applied to the operand fragments as they are loaded
-// (lm_norm_rope) — a separate in-place pass over the qkv tensor cost 198 us per layer at 51 200 tokens.
+// One WORKGROUP (4 waves) per (sequence, K/V head, group of four (q head, 32-query block) units); one wave per unit.
+// Units of a (sequence, K/V head) are ordered query-block major, so the four waves of a workgroup want (nearly) the same
+// keys: every 32-key tile is fetched ONCE per workgroup with coalesced 256-byte row loads, k gets its per-head RMSNorm
+// and rotary embedding there (a row lives in 16 lanes: the rotation partner i + DH/2 is eight lanes away, the sum of
+// squares four exchanges), and lands in LDS as the MFMA operand image — K row-major with a 16-byte pad per row
+// (conflict-free ds_read_b128 fragments), V transposed [d][key] with key pairs packed into 4-byte writes.
+//   S^T = K · Q^T       v_mfma_f32_32x32x16_f16, A = K fragments from LDS, B = the wave's Q rows (registers; RMSNorm +
+//                       rotary applied to the fragments as they are loaded, lm_norm_rope): lane l owns query l & 31, the
+//                       softmax statistics of a query sit in the lane pair (l, l ^ 32)
+//   O^T += V^T · P^T    A = V^T fragments from LDS, B = P^T assembled in registers
+// Keys limited to [start[seq], query position].  The wave-per-unit kernel this replaces loaded K and V per wave with
+// 16-byte pieces of 32 different rows, redid k's norm + rotary per wave and needed 366 VGPRs: 357 us per layer at
+// 51 200 tokens (265 us before norm + rotary moved in, plus 198 us for their own pass over the qkv tensor).
 template <int DH>
-__global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __restrict__ qkv,
-                                                                const int32_t* __restrict__ start, int L, int n_q, int n_kv,
-                                                                int q_blocks, int n_units, const half_t* __restrict__ qn_w,
-                                                                const half_t* __restrict__ kn_w, float eps,
-                                                                const half2_t* __restrict__ rope, half_t* __restrict__ ctx) {
+__global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t* __restrict__ qkv,
+                                                                   const int32_t* __restrict__ start, int L, int n_q, int n_kv,
+                                                                   int q_blocks, int wg_per_kv, const half_t* __restrict__ qn_w,
+                                                                   const half_t* __restrict__ kn_w, float eps,
+                                                                   const half2_t* __restrict__ rope, half_t* __restrict__ ctx) {
   constexpr int KS = DH / 16;
   constexpr int MB = DH / 32;
-  constexpr int VROW = 40;
-  __shared__ __attribute__((aligned(16))) half_t vt_all[4][DH * VROW];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wave;
-  if (unit >= n_units) return;
-  half_t* vt = vt_all[wave];
-  const int qb = unit % q_blocks, bh = unit / q_blocks;
-  const int b = bh / n_q, hd = bh % n_q;
-  const int kvh = hd / (n_q / n_kv);
+  constexpr int VROW = 40;              // halves per V^T row: 32 keys + pad (16-byte aligned rows)
+  constexpr int KROW = DH + 8;          // halves per K row: DH + 16 bytes
+  constexpr int CH = DH / 8;            // 16-byte chunks per row
+  constexpr int RPP = 64 / CH;          // K rows per wave pass (4 at DH = 128, 8 at DH = 64)
+  __shared__ __attribute__((aligned(16))) half_t kimg[32 * KROW];
+  __shared__ __attribute__((aligned(16))) half_t vt[DH * VROW];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = n_q / n_kv, units = G * q_blocks;           // units of one (sequence, K/V head)
+  const int wg = blockIdx.x % wg_per_kv, bk = blockIdx.x / wg_per_kv;
+  const int b = bk / n_kv, kvh = bk % n_kv;
+  const int u = wg * 4 + wave;                              // this wave's unit (may be past the end: it only helps staging)
+  const bool live = u < units;
+  const int qb = live ? u / G : 0, hd = kvh * G + (live ? u % G : 0);
   int s0 = start[b];
   s0 = s0 < 0 ? 0 : (s0 > L - 1 ? L - 1 : s0);
   const int col = lane & 31, hh = lane >> 5;
-  const size_t rs = (size_t)(n_q + 2 * n_kv) * DH;  // row stride of the fused qkv in halves
+  const size_t rs = (size_t)(n_q + 2 * n_kv) * DH;          // row stride of the fused qkv in halves
   const half_t* qbase = qkv + (size_t)b * L * rs + (size_t)hd * DH;
   const half_t* kbase = qkv + (size_t)b * L * rs + (size_t)(n_q + kvh) * DH;
   const half_t* vbase = qkv + (size_t)b * L * rs + (size_t)(n_q + n_kv + kvh) * DH;
@@ -157,32 +169,68 @@ __global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
   float m_run = -INFINITY, l_run = 0.f;
-  const int k_end = (q0 + 32 < L) ? q0 + 32 : L;  // causal: no key beyond the block's last query
+  const int k_end = live ? ((q0 + 32 < L) ? q0 + 32 : L) : 0;  // causal: no key beyond the block's last query
+  // the workgroup's last unit has the largest query block: its key range is the workgroup's
+  const int last_u = (wg * 4 + 3 < units ? wg * 4 + 3 : units - 1), last_q0 = (last_u / G) * 32;
+  const int wg_k_end = (last_q0 + 32 < L) ? last_q0 + 32 : L;
 
-  for (int k0 = (s0 / 32) * 32; k0 < k_end; k0 += 32) {
-    const int krow = (k0 + col < L) ? k0 + col : L - 1;
-    f32x16 st = {0};
-    half8 kf[KS];
+  // staging roles: K row = 8*wave + pass*RPP + lane / CH, chunk c = lane % CH; the k-norm weights and this lane's
+  // rotary sign are fixed for the whole kernel
+  const int kc = lane % CH, kr_in = lane / CH;
+  const half8 kw = *(const half8*)(kn_w + 8 * kc);
+  const bool upper = kc >= CH / 2;                           // this chunk holds elements i + DH/2 of the rotation pairs
+
+  for (int k0 = (s0 / 32) * 32; k0 < wg_k_end; k0 += 32) {
+    __syncthreads();                                         // the previous tile's fragments have been read
+    // ---- K rows 8*wave .. +7: load, RMSNorm, rotary, store as the A-operand image ----
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const half8*)(kbase + (size_t)krow * rs + 16 * ks + 8 * hh);
-    lm_norm_rope<DH>(kf, kn_w, eps, rope + (size_t)krow * (DH / 2), hh);
+    for (int pass = 0; pass < 8 / RPP; ++pass) {
+      const int r = 8 * wave + pass * RPP + kr_in;
+      const int krow = (k0 + r < L) ? k0 + r : L - 1;
+      const half8 x = *(const half8*)(kbase + (size_t)krow * rs + 8 * kc);
+      float ss = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], st, 0, 0, 0);
-    __builtin_amdgcn_wave_barrier();
-    // V^T image [d][key]: a lane takes four consecutive keys of one 8-column chunk and writes the four values of each
-    // column as one 8-byte piece (one 2-byte write per value made 64 LDS writes per lane per tile)
+      for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)x[e], (float)x[e], ss);
 #pragma unroll
-    for (int i = lane; i < 8 * (DH / 8); i += 64) {
-      const int q4 = i & 7, c8 = i >> 3;
-      half8 v4[4];
+      for (int o2 = 1; o2 < CH; o2 <<= 1) ss += __shfl_xor(ss, o2, 64);
+      const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const half2_t* cs_row = rope + (size_t)krow * (DH / 2) + 8 * (kc % (CH / 2));
+      const u32x4 c0 = *(const u32x4*)cs_row, c1 = *(const u32x4*)(cs_row + 4);
+      half8 xn;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int vrow = (k0 + 4 * q4 + r < L) ? k0 + 4 * q4 + r : L - 1;
-        v4[r] = *(const half8*)(vbase + (size_t)vrow * rs + 8 * c8);
+      for (int e = 0; e < 8; ++e) xn[e] = (half_t)((float)kw[e] * (float)(half_t)((float)x[e] * inv));
+      u32x4 mine = __builtin_bit_cast(u32x4, xn), other;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) other[w4] = (uint32_t)__shfl_xor((int)mine[w4], CH / 2, 64);
+      const half8 pn = __builtin_bit_cast(half8, other);
+      half8 out;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? c0[e] : c1[e - 4]);
+        const float cs = (float)cs2[0], sn = (float)cs2[1];
+        // lower half: a cos - b sin with a = own, b = partner; upper half: b cos + a sin with b = own, a = partner
+        out[e] = upper ? (half_t)((float)xn[e] * cs + (float)pn[e] * sn) : (half_t)((float)xn[e] * cs - (float)pn[e] * sn);
       }
+      *(half8*)(kimg + r * KROW + 8 * kc) = out;
+    }
+    // ---- V^T: this wave's d-chunks CH/4*wave .., all 32 keys; a lane packs one key pair of one chunk ----
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        *(half4v*)(vt + (8 * c8 + e) * VROW + 4 * q4) = (half4v){v4[0][e], v4[1][e], v4[2][e], v4[3][e]};
+    for (int i = lane; i < 16 * (CH / 4); i += 64) {
+      const int p = i & 15, c8 = (CH / 4) * wave + (i >> 4);
+      const int r0 = (k0 + 2 * p < L) ? k0 + 2 * p : L - 1, r1 = (k0 + 2 * p + 1 < L) ? k0 + 2 * p + 1 : L - 1;
+      const half8 v0 = *(const half8*)(vbase + (size_t)r0 * rs + 8 * c8), v1 = *(const half8*)(vbase + (size_t)r1 * rs + 8 * c8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *(half2_t*)(vt + (8 * c8 + e) * VROW + 2 * p) = (half2_t){v0[e], v1[e]};
+    }
+    __syncthreads();
+    if (k0 >= k_end) continue;                               // beyond this wave's causal range: it only staged
+
+    f32x16 st = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8 kf = *(const half8*)(kimg + col * KROW + 16 * ks + 8 * hh);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
     }
     float s[16];
     float tmax = -INFINITY;
@@ -212,7 +260,6 @@ __global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint32_t mine0 = hh ? (ks ? pk[6] : pk[2]) : (ks ? pk[4] : pk[0]);
@@ -230,7 +277,7 @@ __global__ __launch_bounds__(256) void rarc_lm_attention_kernel(const half_t* __
       }
     }
   }
-  if (q0 + col < L) {
+  if (live && q0 + col < L) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;  // (a padding query attends to nothing: zeros)
     half_t* out = ctx + ((size_t)b * L + q0 + col) * (size_t)n_q * DH + (size_t)hd * DH;
 #pragma unroll
@@ -343,7 +390,7 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
 
   hipLaunchKernelGGL(rarc_lm_embed_kernel, dim3(tb), dim3(256), 0, s, d_ids, (const half_t*)m->embed, T, H, m->vocab, x);
   RARC_HIP_CHECK(hipGetLastError());
-  const int q_blocks = (seq_len + 31) / 32, n_units = n_seq * NQ * q_blocks;
+  const int q_blocks = (seq_len + 31) / 32, wg_per_kv = ((NQ / NKV) * q_blocks + 3) / 4;  // attention workgroups per (sequence, K/V head)
   for (int l = 0; l < m->n_layers; ++l) {
     const RarcLmLayer& Ly = m->layers[l];
     // (layer 0: plain norm; later layers: the previous layer's MLP output is added here, then normed)
@@ -352,12 +399,12 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
     RARC_HIP_CHECK(hipGetLastError());
     if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, T, QKV, H, 0, stream)) return rc;
     if (DH == 128)
-      hipLaunchKernelGGL(rarc_lm_attention_kernel<128>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const half_t*)qkv, d_start,
-                         seq_len, NQ, NKV, q_blocks, n_units, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
+      hipLaunchKernelGGL(rarc_lm_attention_kernel<128>, dim3(n_seq * NKV * wg_per_kv), dim3(256), 0, s, (const half_t*)qkv, d_start,
+                         seq_len, NQ, NKV, q_blocks, wg_per_kv, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
                          (const half2_t*)rope, ctx);
     else
-      hipLaunchKernelGGL(rarc_lm_attention_kernel<64>, dim3((n_units + 3) / 4), dim3(256), 0, s, (const half_t*)qkv, d_start,
-                         seq_len, NQ, NKV, q_blocks, n_units, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
+      hipLaunchKernelGGL(rarc_lm_attention_kernel<64>, dim3(n_seq * NKV * wg_per_kv), dim3(256), 0, s, (const half_t*)qkv, d_start,
+                         seq_len, NQ, NKV, q_blocks, wg_per_kv, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
                          (const half2_t*)rope, ctx);
     RARC_HIP_CHECK(hipGetLastError());
     if (int rc = rarc_enc_gemm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, T, H, QD, 0, stream)) return rc;
