@@ -30,5 +30,16 @@ export PROBE_SCRIPT=tools/enc_only.py
 pmc sq_encoder SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_encoder -- python3 tools/enc_only.py > $O/kt_encoder.log 2>&1
 f=$(ls -t $O/kt_encoder/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/encoder_kernel_stats.csv
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_lm -- python3 tools/lm_only.py > $O/kt_lm.log 2>&1
+f=$(ls -t $O/kt_lm/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/lm_kernel_stats.csv
+export PROBE_SEQS=32
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_enc32 -- python3 tools/enc_only.py > $O/kt_enc32.log 2>&1
+f=$(ls -t $O/kt_enc32/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/encoder_32seq_kernel_stats.csv
+unset PROBE_SEQS
+export PROBE_SCRIPT=tools/gpu_scan_only.py PROBE_ROWS=1000000 PROBE_DIM=768 PROBE_STORAGE=f16 PROBE_ITERS=20
+pmc sq_c2_1m SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+python3 tools/enc_batch_sweep.py 2>/dev/null | grep ENC > $O/encoder_batch_sweep.txt
+python3 tools/gemm_k_sweep.py 2>/dev/null | grep "^M=" > $O/gemm_k_sweep.txt
+python3 tools/gemm_lm_bench.py 2>/dev/null | grep "^M=" > $O/gemm_lm_shapes.txt
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +4M -delete
 ls $O; for f in $O/*_bench.json; do echo "== $f"; cut -c1-400 $f; done; cat $O/pmc_*.txt | grep -v "^$" | head -120
