@@ -531,7 +531,11 @@ def leg_reranker_lm(torch, np, a, dev, local_rank):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     tokens = n_pairs * L
-    per_tok = LAYERS * (2.0 * (H * (NQ + 2 * NKV) * DH + NQ * DH * H + H * 2 * I + I * H) + 4.0 * L * NQ * DH)
+    # flops actually needed: every layer's q|k|v projection and attention on all tokens; output projection + MLP on all
+    # tokens in all layers but the last, where only the last position of each pair goes on (rarc_lm_yes_no_logits does that)
+    mix = 2.0 * H * (NQ + 2 * NKV) * DH + 4.0 * L * NQ * DH
+    rest = 2.0 * (NQ * DH * H + H * 2 * I + I * H)
+    per_tok = LAYERS * mix + (LAYERS - 1) * rest + rest / L
     return {"workload": f"Qwen3-Reranker-0.6B geometry ({LAYERS} layers, seeded fp16 weights): {n_pairs} (query, document) pairs x {L} "
                         f"tokens, left padded -> (no, yes) logits -> p_yes -> stable order; {nqr} queries x top-{K}",
             "ms_per_call": round(dt * 1e3, 3), "pairs_per_s": round(n_pairs / dt, 1), "queries_reranked_per_s": round(n_pairs / K / dt, 2),

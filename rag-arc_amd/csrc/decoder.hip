@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void rarc_lm_swiglu_kernel(const half_t* gu, i
 
 // ---- last position: final RMSNorm, then the two logits (no, yes) = <normed, lm_head[id]> --------------------------
 __global__ __launch_bounds__(64) void rarc_lm_last_logits_kernel(const half_t* x, const half_t* w_final, const half_t* lm_head,
-                                                                 float eps, int L, int H, int no_id, int yes_id,
-                                                                 half_t* out) {
+                                                                 float eps, int row_stride, int row_off, int H, int no_id,
+                                                                 int yes_id, half_t* out) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  const half_t* xr = x + ((size_t)b * L + (L - 1)) * H;
+  const half_t* xr = x + ((size_t)b * row_stride + row_off) * H;  // [T][H] rows: stride L, offset L-1; compact rows: 1, 0
   float ss = 0.f;
   for (int c = lane; c < H; c += 64) ss = __builtin_fmaf((float)xr[c], (float)xr[c], ss);
 #pragma unroll
@@ -336,6 +336,15 @@ __global__ __launch_bounds__(64) void rarc_lm_last_logits_kernel(const half_t* x
     out[2 * b] = (half_t)a_no;      // logits are an fp16 tensor in the reference's fp16 model
     out[2 * b + 1] = (half_t)a_yes;
   }
+}
+
+// ---- last positions: dst[s] = src[s*L + L-1] for s < n_seq, zero rows up to n_rows (a multiple of 128 for the GEMMs) ----
+__global__ __launch_bounds__(256) void rarc_lm_gather_last_kernel(const half_t* src, int L, int W, int n_seq, int n_rows, half_t* dst) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n_rows) return;
+  const half8* from = (const half8*)(src + ((size_t)r * L + (L - 1)) * W);
+  half8* to = (half8*)(dst + (size_t)r * W);
+  for (int c = lane; c < W / 8; c += 64) to[c] = r < n_seq ? from[c] : (half8){0};
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------
@@ -390,6 +399,9 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
 
   hipLaunchKernelGGL(rarc_lm_embed_kernel, dim3(tb), dim3(256), 0, s, d_ids, (const half_t*)m->embed, T, H, m->vocab, x);
   RARC_HIP_CHECK(hipGetLastError());
+  // last layer on the last positions only, when its compact buffers fit into the (then idle) gate|up buffer
+  const int Mp = (n_seq + 127) / 128 * 128;
+  const bool last_only = 6 * 256 + (size_t)Mp * ((size_t)QD + 3 * (size_t)H + 3 * (size_t)I) * 2 <= (size_t)T * 2 * I * 2;
   const int q_blocks = (seq_len + 31) / 32, wg_per_kv = ((NQ / NKV) * q_blocks + 3) / 4;  // attention workgroups per (sequence, K/V head)
   for (int l = 0; l < m->n_layers; ++l) {
     const RarcLmLayer& Ly = m->layers[l];
@@ -407,6 +419,41 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
                          seq_len, NQ, NKV, q_blocks, wg_per_kv, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
                          (const half2_t*)rope, ctx);
     RARC_HIP_CHECK(hipGetLastError());
+    if (l == m->n_layers - 1 && last_only) {
+      // Only the last position's logits are wanted, and after the last layer's attention nothing mixes positions any
+      // more: its output projection, MLP and residual adds run on the n_seq last rows alone (gathered, padded to a
+      // multiple of 128 rows) instead of on all T tokens.
+      char* cw = (char*)gu;  // the full-size gate|up buffer is idle in this layer: the compact buffers live there
+      half_t* ctx_l = (half_t*)cw;                 cw += lm_align((size_t)Mp * QD * 2);
+      half_t* x_l = (half_t*)cw;                   cw += lm_align((size_t)Mp * H * 2);
+      half_t* h_l = (half_t*)cw;                   cw += lm_align((size_t)Mp * H * 2);
+      half_t* d_l = (half_t*)cw;                   cw += lm_align((size_t)Mp * H * 2);
+      half_t* act_l = (half_t*)cw;                 cw += lm_align((size_t)Mp * I * 2);
+      half_t* gu_l = (half_t*)cw;
+      const int gb = (Mp + 3) / 4;
+      hipLaunchKernelGGL(rarc_lm_gather_last_kernel, dim3(gb), dim3(256), 0, s, (const half_t*)ctx, seq_len, QD, n_seq, Mp, ctx_l);
+      hipLaunchKernelGGL(rarc_lm_gather_last_kernel, dim3(gb), dim3(256), 0, s, (const half_t*)x, seq_len, H, n_seq, Mp, x_l);
+      RARC_HIP_CHECK(hipGetLastError());
+      if (int rc = rarc_enc_gemm((const uint16_t*)ctx_l, Ly.o_w, m->zero_bias, (uint16_t*)d_l, Mp, H, QD, 0, stream)) return rc;
+      hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(gb), dim3(256), 0, s, x_l, (const half_t*)d_l, (const half_t*)Ly.post_norm,
+                         m->rms_eps, Mp, H, h_l);
+      RARC_HIP_CHECK(hipGetLastError());
+      if (rarc_gemm_swiglu_fused(Mp, 2 * I, H)) {
+        if (int rc = rarc_enc_gemm((const uint16_t*)h_l, Ly.gate_up_w, m->zero_bias, (uint16_t*)act_l, Mp, 2 * I, H, 3, stream)) return rc;
+      } else {
+        if (int rc = rarc_enc_gemm((const uint16_t*)h_l, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu_l, Mp, 2 * I, H, 0, stream)) return rc;
+        hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(512), dim3(256), 0, s, (const half_t*)gu_l, Mp, I, act_l);
+        RARC_HIP_CHECK(hipGetLastError());
+      }
+      if (int rc = rarc_enc_gemm((const uint16_t*)act_l, Ly.down_w, m->zero_bias, (uint16_t*)d_l, Mp, H, I, 0, stream)) return rc;
+      hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(gb), dim3(256), 0, s, x_l, (const half_t*)d_l, (const half_t*)nullptr,
+                         m->rms_eps, Mp, H, (half_t*)nullptr);
+      RARC_HIP_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(rarc_lm_last_logits_kernel, dim3(n_seq), dim3(64), 0, s, (const half_t*)x_l, (const half_t*)m->final_norm,
+                         (const half_t*)m->lm_head, m->rms_eps, 1, 0, H, no_id, yes_id, (half_t*)d_out_f16);
+      RARC_HIP_CHECK(hipGetLastError());
+      return RARC_OK;
+    }
     if (int rc = rarc_enc_gemm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, T, H, QD, 0, stream)) return rc;
     hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)Ly.post_norm,
                        m->rms_eps, T, H, h);
@@ -425,7 +472,7 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
                      T, H, (half_t*)nullptr);
   RARC_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(rarc_lm_last_logits_kernel, dim3(n_seq), dim3(64), 0, s, (const half_t*)x, (const half_t*)m->final_norm,
-                     (const half_t*)m->lm_head, m->rms_eps, seq_len, H, no_id, yes_id, (half_t*)d_out_f16);
+                     (const half_t*)m->lm_head, m->rms_eps, seq_len, seq_len - 1, H, no_id, yes_id, (half_t*)d_out_f16);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
