@@ -41,6 +41,9 @@ def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed):
     (512, 3, 8, 2, 64, 1024, 3, 100, (0, 60, 99)),             # four q heads per kv head; keys span four tiles
     (1024, 2, 16, 8, 128, 3072, 8, 64, (0, 5, 20, 63)),        # Qwen3-Reranker-0.6B's layer geometry, two layers
     (256, 2, 4, 2, 64, 2048, 32, 64, (0, 9, 40, 63)),          # 2048 tokens: SwiGLU runs as the gate/up GEMM's epilogue
+    (384, 2, 6, 2, 64, 512, 4, 96, (0, 33, 64, 95)),           # three q heads per kv head x three query blocks: 9 units
+                                                               # per (sequence, kv head), attention workgroups of 4 + 4 + 1
+    (256, 1, 2, 1, 128, 256, 4, 160, (0, 1, 100, 159)),        # head_dim 128, 2 x 5 units: workgroups of 4 + 4 + 2, five key tiles
 ])
 def test_yes_no_logits_match_oracle(oracle, H, LAYERS, NQ, NKV, DH, I, n, L, pads):
     _run(oracle, H, LAYERS, NQ, NKV, DH, I, 1000, n, L, pads, seed=H + L)
