@@ -166,6 +166,10 @@ def test_gemm_kernel_alone(oracle):
     (1024, 4096, 256, 1),    # ... the minimum of four k tiles, GELU
     (512, 1024, 320, 0),     # ... five k tiles, a quarter of the CUs busy
     (1024, 1024, 192, 0),    # K too short for the ring: one-barrier kernel
+    (256 * 37, 256 * 7, 192, 0),   # 259 tiles of 256x256 on 256 persistent workgroups: three of them take a second tile
+    (256 * 19, 256 * 27, 128, 1),  # 513 tiles: two full rounds + one, XCD shares of 65 / 64 tiles, GELU
+    (256 * 50, 256 * 16, 64, 0),   # 800 tiles (the reranker LM's down projection count), single k tile per tile
+    (256 * 3, 256 * 100, 256, 0),  # N >> M: 300 tiles, 8-deep row groups of a 3-row tile grid (partial group only)
 ])
 def test_gemm_large_tile_kernels(oracle, M, N, K, act):
     """Every large-shape GEMM path against a float64 product on a transposition-detecting operand pair
