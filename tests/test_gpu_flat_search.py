@@ -322,3 +322,37 @@ def test_batched_exact_verification(hip, oracle, storage):
     # the planted entry is the query's WORST row: every other row beats it, k - 1 of them already listed in the answer
     assert idx.verify_batch(Q, bad_i, bad_s) == 3 * (n - k)
     assert idx.verify_batch(Q, bad_i, bad_s, which=[4]) == n - k and idx.verify_batch(Q, bad_i, bad_s, which=[5, 6]) == 0
+
+
+def test_twin_search_context_two_streams(oracle):
+    """twin(): a second search context over the same rows (own query block, workspace, side stream).  Alternating
+    batches between index and twin gives the answers of the index alone; the twin is read-only and goes stale when
+    the parent changes."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(5)
+    n, d, k = 70_000, 384, 20
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    idx = FlatIndexF16(d)
+    idx.add(X)
+    tw = idx.twin()
+    batches = [torch.from_numpy(rng.standard_normal((64 + 16 * i, d)).astype(np.float32)).cuda() for i in range(6)]
+    want = [idx.search_device(q, k) for q in batches]
+    pend = [(idx if i % 2 == 0 else tw).search_async(q, k) for i, q in enumerate(batches)]      # all six in flight
+    for (wi, ws), h in zip(want, pend):
+        gi, gs = h.result()
+        assert torch.equal(gi, wi) and torch.equal(gs.view(torch.int32), ws.view(torch.int32))
+    rows, _ = oracle.ingest_f16(X, normalize=True)
+    oi, osc, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(batches[1].cpu().numpy()), k)
+    gi, gs = tw.search_device(batches[1], k)
+    assert np.array_equal(gi.cpu().numpy(), oi) and np.array_equal(gs.cpu().numpy().view(np.uint32), osc.view(np.uint32))
+    with pytest.raises(B.RarcError):
+        tw.add(X[:8])
+    idx.add(X[:40])
+    with pytest.raises(B.RarcError):
+        tw.search_async(batches[0], k)
+    tw2 = idx.twin()
+    assert tw2.ntotal == n + 40 and torch.equal(tw2.search_device(batches[0], k)[0], idx.search_device(batches[0], k)[0])
