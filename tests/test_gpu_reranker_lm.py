@@ -44,6 +44,7 @@ def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed):
     (384, 2, 6, 2, 64, 512, 4, 96, (0, 33, 64, 95)),           # three q heads per kv head x three query blocks: 9 units
                                                                # per (sequence, kv head), attention workgroups of 4 + 4 + 1
     (256, 1, 2, 1, 128, 256, 4, 160, (0, 1, 100, 159)),        # head_dim 128, 2 x 5 units: workgroups of 4 + 4 + 2, five key tiles
+    (256, 2, 4, 2, 64, 512, 2, 1024, (0, 700)),                # long prompts: 32 query blocks x up to 32 key tiles
 ])
 def test_yes_no_logits_match_oracle(oracle, H, LAYERS, NQ, NKV, DH, I, n, L, pads):
     _run(oracle, H, LAYERS, NQ, NKV, DH, I, 1000, n, L, pads, seed=H + L)
