@@ -1283,11 +1283,29 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
     const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
     if (force != 1 && gemm_prefers_256x256(t256, t128)) {
       static const bool persist = !(getenv("RARC_GEMM_PERSIST") && atoi(getenv("RARC_GEMM_PERSIST")) == 0);
-      const int g256 = persist && t256 > 256 ? 256 : t256;
-      if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
-      else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
-      else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m, n, k, order);
+      // A short last round is given away: when the tiles beyond the last whole round of 256 are at most a quarter
+      // round (51 200 x 1024: 800 tiles = 3 rounds + 32), the whole rounds run here on the leading rows and the
+      // trailing rows go through the dispatcher again as a problem of their own — 128 x 128 tiles on half the CUs
+      // finish those 32 tiles' worth in 0.4 of a tile time instead of holding 224 CUs idle for a whole one.
+      // (The cut is by rows, so the whole rounds must cover whole tile rows: a multiple of lcm(256, tiles_n) tiles.)
+      static const bool cut_tail = !(getenv("RARC_GEMM_TAIL") && atoi(getenv("RARC_GEMM_TAIL")) == 0);
+      const int tiles_n = n / 256;
+      int lcm = tiles_n;
+      while (lcm % 256) lcm += tiles_n;
+      const int full = t256 / lcm * lcm, rem = t256 - full;
+      int m_main = m;
+      if (cut_tail && persist && full > 0 && rem > 0 && 4 * rem <= 256 &&
+          (act != 3 || rarc_gemm_swiglu_fused(m - full / tiles_n * 256, n, k)))
+        m_main = full / tiles_n * 256;
+      const int t_main = (m_main / 256) * tiles_n;
+      const int g256 = persist && t_main > 256 ? 256 : t_main;
+      if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
+      if (m_main < m)
+        return rarc_enc_gemm(d_a + (size_t)m_main * k, d_w, d_bias, d_c + (size_t)m_main * (act == 3 ? n / 2 : n), m - m_main, n, k,
+                             act, stream);
       return RARC_OK;
     }
     if (t128 >= 256 && k >= 3 * GK) {

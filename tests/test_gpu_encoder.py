@@ -170,6 +170,8 @@ def test_gemm_kernel_alone(oracle):
     (256 * 19, 256 * 27, 128, 1),  # 513 tiles: two full rounds + one, XCD shares of 65 / 64 tiles, GELU
     (256 * 50, 256 * 16, 64, 0),   # 800 tiles (the reranker LM's down projection count), single k tile per tile
     (256 * 3, 256 * 100, 256, 0),  # N >> M: 300 tiles, 8-deep row groups of a 3-row tile grid (partial group only)
+    (256 * 70, 256 * 4, 320, 1),   # 280 tiles = one round + 24: the short tail (6 tile rows) is cut off and runs as its own GEMM
+    (256 * 200, 256 * 4, 128, 0),  # the reranker LM's projection shape: 800 tiles = 3 rounds + 32
 ])
 def test_gemm_large_tile_kernels(oracle, M, N, K, act):
     """Every large-shape GEMM path against a float64 product on a transposition-detecting operand pair
