@@ -392,7 +392,7 @@ def main():
                        "generator": "counter hash -> 52-bit uniform -> inverse normal CDF (AS 241), rows L2-normalised",
                        "int8_shadow_image": bool(a.shadow),
                        "exchange_ms_per_step": round(exch_ms, 4) if use_dist else 0.0,
-                       "exchange": "pack + one RCCL all-gather of (id, score) + merge" if use_dist else "none (one shard)",
+                       "exchange": (f"pack + one {'RCCL' if a.backend == 'nccl' else a.backend} all-gather of (id, score) + merge") if use_dist else "none (one shard)",
                        "repaired_queries_last_step": flagged,
                        "full_size_check": check},
             "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
