@@ -364,6 +364,7 @@ extern "C" size_t rarc_lm_workspace_bytes(const RarcLmModel* m, int n_tokens) {
 extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_seq,
                                      int seq_len, int no_id, int yes_id, void* d_ws, size_t ws_bytes,
                                      uint16_t* d_out_f16, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(m && m->layers && d_ids && d_start && d_ws && d_out_f16, RARC_E_INVALID, "rarc_lm_yes_no_logits: null pointer");
   RARC_REQUIRE(m->embed && m->lm_head && m->final_norm && m->zero_bias, RARC_E_INVALID, "rarc_lm_yes_no_logits: incomplete model");
   const int H = m->hidden, I = m->inter, DH = m->head_dim, NQ = m->n_q_heads, NKV = m->n_kv_heads;

@@ -1423,6 +1423,7 @@ extern "C" size_t rarc_enc_workspace_bytes(int hidden, int inter, int n_tokens) 
 
 extern "C" int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
                                 int seq_len, int normalize, void* d_ws, size_t ws_bytes, float* d_out, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(model && model->layers && d_ids && d_lens && d_ws && d_out, RARC_E_INVALID, "rarc_enc_forward: null pointer");
   const int H = model->hidden, I = model->inter;
   RARC_REQUIRE(n_seq > 0 && seq_len > 0 && model->n_layers > 0, RARC_E_INVALID, "rarc_enc_forward: empty batch or model");

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(RRF_THREADS) void rarc_rrf_kernel(const int64_t* ke
 extern "C" int rarc_rrf_fuse(const int64_t* d_keys, const int32_t* d_len, int nq, int n_lists, int max_len,
                              double rrf_k, int top_k, int64_t* d_out_keys, double* d_out_scores,
                              int32_t* d_out_n, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_keys && d_len && d_out_keys && d_out_scores && d_out_n, RARC_E_INVALID, "rarc_rrf_fuse: null pointer");
   RARC_REQUIRE(nq >= 0 && n_lists >= 1 && n_lists <= 64 && max_len >= 0 && top_k >= 0, RARC_E_INVALID,
                "rarc_rrf_fuse: bad sizes (nq=%d lists=%d max_len=%d top_k=%d)", nq, n_lists, max_len, top_k);
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(256) void rarc_rerank_kernel(const half_t* z_no, co
 
 extern "C" int rarc_rerank_order(const uint16_t* d_z_no, const uint16_t* d_z_yes, int nq, int n,
                                  uint16_t* d_out_scores_f16, int32_t* d_out_perm, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_z_no && d_z_yes && d_out_scores_f16 && d_out_perm, RARC_E_INVALID, "rarc_rerank_order: null pointer");
   RARC_REQUIRE(nq >= 0 && n >= 0 && n <= RERANK_MAX, RARC_E_UNSUPPORTED, "rarc_rerank_order: n=%d exceeds %d", n,
                RERANK_MAX);
@@ -255,6 +257,7 @@ extern "C" size_t rarc_mmr_workspace_doubles(int n, int d) { return n > 0 && d >
 
 extern "C" int rarc_mmr_select(const float* d_cand, int64_t ld, const double* d_query, int n, int d, int normalize, int k,
                                double lambda, double* d_work, int32_t* d_out, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_cand && d_query && d_work && d_out, RARC_E_INVALID, "rarc_mmr_select: null pointer");
   RARC_REQUIRE(n >= 1 && n <= MMR_MAX_N && d >= 1 && ld >= d && k >= 1, RARC_E_INVALID,
                "rarc_mmr_select: bad sizes (n=%d of at most %d, d=%d, k=%d)", n, MMR_MAX_N, d, k);

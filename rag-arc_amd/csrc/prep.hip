@@ -446,6 +446,7 @@ extern "C" int rarc_adjacent_cosine_distance_f32(const float* d_x, int64_t ld_x,
 
 extern "C" int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_corpus_f16, int d_pad,
                                float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_in && d_corpus_f16 && d > 0 && d_pad >= d && d_pad % 8 == 0 && n_rows >= 0, RARC_E_INVALID,
                "rarc_ingest_f16: bad arguments");
   if (n_rows == 0) return RARC_OK;
@@ -457,6 +458,7 @@ extern "C" int rarc_ingest_f16(const float* d_in, int64_t ld_in, uint16_t* d_cor
 
 extern "C" int rarc_ingest_f32(const float* d_in, int64_t ld_in, float* d_corpus_f32, uint16_t* d_image_f16, int d_pad,
                                float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_in && d_corpus_f32 && d_image_f16 && d > 0 && d_pad >= d && d_pad % 8 == 0 && n_rows >= 0,
                RARC_E_INVALID, "rarc_ingest_f32: bad arguments");
   if (n_rows == 0) return RARC_OK;
@@ -472,6 +474,7 @@ extern "C" int rarc_padded_dim_f8(int d) {
 
 extern "C" int rarc_ingest_f8(const float* d_in, int64_t ld_in, uint8_t* d_corpus_f8, int d_pad, float* d_row_scale,
                               float* d_row_norm2, int64_t n_rows, int d, int normalize, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_in && d_corpus_f8 && d_row_scale && d > 0 && d_pad >= d && d_pad % RARC_DIM_ALIGN_F8 == 0 &&
                    n_rows >= 0,
                RARC_E_INVALID, "rarc_ingest_f8: bad arguments");
@@ -486,6 +489,7 @@ extern "C" size_t rarc_query_block_bytes(int d_pad) { return d_pad > 0 ? rarc_qb
 
 extern "C" int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d, int d_pad, int normalize,
                                  float corpus_max_norm, const float* d_qmeta, void* d_qblock, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_in && d_qblock && ((uintptr_t)d_qblock % 256) == 0 && d > 0 && d_pad >= d &&
                    d_pad % RARC_DIM_ALIGN == 0 && d_pad <= PREP_MAX_D && nq >= 0 && nq <= RARC_MAX_QUERIES,
                RARC_E_INVALID, "rarc_prep_queries: bad arguments (nq=%d d=%d d_pad=%d)", nq, d, d_pad);

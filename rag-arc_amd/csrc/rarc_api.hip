@@ -103,6 +103,26 @@ void rarc_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- roctx (see rarc_common.h) ----
+#include <dlfcn.h>
+static int (*g_roctx_push)(const char*) = nullptr;
+static int (*g_roctx_pop)() = nullptr;
+static bool roctx_ready() {
+  static const bool ok = [] {
+    const char* e = getenv("RARC_ROCTX");
+    if (!e || atoi(e) == 0) return false;
+    void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+    g_roctx_push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    g_roctx_pop = (int (*)())dlsym(h, "roctxRangePop");
+    return g_roctx_push && g_roctx_pop;
+  }();
+  return ok;
+}
+void rarc_roctx_push(const char* name) { if (roctx_ready()) g_roctx_push(name); }
+void rarc_roctx_pop() { if (roctx_ready()) g_roctx_pop(); }
+
 extern "C" int rarc_version(void) { return RARC_VERSION; }
 extern "C" const char* rarc_last_error(void) { return g_err; }
 extern "C" int rarc_padded_dim(int d) {
@@ -127,6 +147,7 @@ extern "C" int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
                                const void* d_qblock, int nq, int k, int kprime, int64_t id_base, float bin_lo,
                                float bin_hi, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                                void* d_workspace, size_t workspace_bytes, int cand_cap, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_qblock && d_out_ids && d_out_scores && d_status, RARC_E_INVALID, "rarc_search_f16: null pointer");
   RARC_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll, RARC_E_INVALID,
                "rarc_search_f16: n_rows=%lld outside [0, 2^32-32)", (long long)n_rows);
@@ -164,6 +185,7 @@ extern "C" int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
 extern "C" int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, const void* d_qblock,
                                int q, int k, int64_t id_base, int64_t* d_out_ids, float* d_out_scores,
                                uint32_t* d_found, void* d_workspace, size_t workspace_bytes, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_corpus_f16 && d_qblock && d_out_ids && d_out_scores && d_found, RARC_E_INVALID,
                "rarc_repair_f16: null pointer");
   RARC_REQUIRE(q >= 0 && q < RARC_MAX_QUERIES && k >= 1 && k <= RARC_MAX_K && d_pad > 0 &&
@@ -185,6 +207,7 @@ extern "C" int rarc_search_f16_shadow(const uint16_t* d_corpus_f16, const int8_t
                                       int kprime, int64_t id_base, float bin_lo, float bin_hi, int64_t* d_out_ids,
                                       float* d_out_scores, uint32_t* d_status, void* d_workspace,
                                       size_t workspace_bytes, int cand_cap, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_qblock && d_qmeta && d_out_ids && d_out_scores && d_status, RARC_E_INVALID,
                "rarc_search_f16_shadow: null pointer");
   RARC_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll, RARC_E_INVALID,
@@ -219,6 +242,7 @@ extern "C" int rarc_search_f32(const float* d_corpus_f32, const uint16_t* d_imag
                                float bin_lo, float bin_hi, int64_t* d_out_ids, float* d_out_scores,
                                uint32_t* d_status, void* d_workspace, size_t workspace_bytes, int cand_cap,
                                void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_qblock && d_qmeta && d_out_ids && d_out_scores && d_status, RARC_E_INVALID,
                "rarc_search_f32: null pointer");
   RARC_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll, RARC_E_INVALID,
@@ -249,6 +273,7 @@ extern "C" int rarc_search_f32(const float* d_corpus_f32, const uint16_t* d_imag
 extern "C" int rarc_repair_f32(const float* d_corpus_f32, int64_t n_rows, int d_pad, const void* d_qblock, int q, int k,
                                int64_t id_base, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_found,
                                void* d_workspace, size_t workspace_bytes, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_corpus_f32 && d_qblock && d_out_ids && d_out_scores && d_found, RARC_E_INVALID,
                "rarc_repair_f32: null pointer");
   RARC_REQUIRE(q >= 0 && q < RARC_MAX_QUERIES && k >= 1 && k <= RARC_MAX_K && d_pad > 0 &&
@@ -270,6 +295,7 @@ extern "C" int rarc_search_f8(const uint8_t* d_corpus_f8, const float* d_row_sca
                               int64_t id_base, float bin_lo, float bin_hi, int64_t* d_out_ids,
                               float* d_out_scores, uint32_t* d_status, void* d_workspace, size_t workspace_bytes,
                               int cand_cap, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_qblock && d_qmeta && d_out_ids && d_out_scores && d_status, RARC_E_INVALID,
                "rarc_search_f8: null pointer");
   RARC_REQUIRE(n_rows >= 0 && n_rows < (int64_t)0xffffffe0ll, RARC_E_INVALID,
@@ -301,6 +327,7 @@ extern "C" int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_sca
                               const void* d_qblock, int q, int k, int64_t id_base, int64_t* d_out_ids,
                               float* d_out_scores, uint32_t* d_found, void* d_workspace, size_t workspace_bytes,
                               void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_corpus_f8 && d_row_scale && d_qblock && d_out_ids && d_out_scores && d_found, RARC_E_INVALID,
                "rarc_repair_f8: null pointer");
   RARC_REQUIRE(q >= 0 && q < RARC_MAX_QUERIES && k >= 1 && k <= RARC_MAX_K && d_pad > 0 &&
@@ -320,6 +347,7 @@ extern "C" int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_sca
 extern "C" int rarc_verify_batch(const void* d_rows, const float* d_row_scale, int row_format, int64_t n_rows, int d_pad,
                                  const void* d_qblock, int q_first, int nq, int k, int64_t id_base, const int64_t* d_ids,
                                  const float* d_scores, uint32_t* d_counts, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_rows && d_qblock && d_ids && d_scores && d_counts, RARC_E_INVALID, "rarc_verify_batch: null pointer");
   RARC_REQUIRE(row_format >= 0 && row_format <= 2 && (row_format != 1 || d_row_scale), RARC_E_INVALID,
                "rarc_verify_batch: row_format %d (0 fp16, 1 fp8 + scales, 2 fp32)", row_format);
@@ -333,6 +361,7 @@ extern "C" int rarc_verify_batch(const void* d_rows, const float* d_row_scale, i
 
 extern "C" int rarc_topk_merge(const int64_t* d_ids, const float* d_scores, int n_lists, int nq, int k,
                                int64_t* d_out_ids, float* d_out_scores, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_ids && d_scores && d_out_ids && d_out_scores, RARC_E_INVALID, "rarc_topk_merge: null pointer");
   RARC_REQUIRE(n_lists >= 1 && nq >= 0 && k >= 1, RARC_E_INVALID, "rarc_topk_merge: bad sizes");
   if (nq == 0) return RARC_OK;
@@ -347,6 +376,7 @@ extern "C" int rarc_pack_results(const int64_t* d_ids, const float* d_scores, in
 
 extern "C" int rarc_topk_merge_packed(const int32_t* d_packed, int n_lists, int nq, int k, int64_t* d_out_ids,
                                       float* d_out_scores, void* stream) {
+  RARC_RANGE();
   RARC_REQUIRE(d_packed && d_out_ids && d_out_scores, RARC_E_INVALID, "rarc_topk_merge_packed: null pointer");
   RARC_REQUIRE(n_lists >= 1 && nq >= 0 && k >= 1, RARC_E_INVALID, "rarc_topk_merge_packed: bad sizes");
   if (nq == 0) return RARC_OK;

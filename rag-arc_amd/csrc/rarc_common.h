@@ -337,3 +337,16 @@ struct RarcPerDevice {
       return (code);                   \
     }                                  \
   } while (0)
+
+// ---- optional roctx ranges around the C-ABI entry points (rocprofv3 --marker-trace) -------------------------------
+// RARC_ROCTX=1 resolves roctxRangePushA / roctxRangePop from the profiler SDK's library at first use (dlopen: no link
+// dependency, nothing happens without the variable).  One range per entry point, named after it.
+void rarc_roctx_push(const char* name);
+void rarc_roctx_pop();
+struct RarcRange {
+  explicit RarcRange(const char* name) { rarc_roctx_push(name); }
+  ~RarcRange() { rarc_roctx_pop(); }
+  RarcRange(const RarcRange&) = delete;
+  RarcRange& operator=(const RarcRange&) = delete;
+};
+#define RARC_RANGE() RarcRange rarc_range_guard_(__func__)
