@@ -7,6 +7,8 @@
 #include "../rag-arc_amd/csrc/scan_f16.hip"
 #include "../rag-arc_amd/csrc/prep.hip"
 void rarc_set_error(const char* fmt, ...) { (void)fmt; }
+void rarc_roctx_push(const char*) {}
+void rarc_roctx_pop() {}
 bool rarc_prof_next(hipEvent_t*, hipEvent_t*) { return false; }
 
 template <int ABL>
@@ -18,7 +20,7 @@ static float run(const ScanParams& p, int grid, int iters, uint32_t nq, int kpri
   float best = 1e30f;
   for (int it = 0; it < iters; ++it) {
     hipLaunchKernelGGL((rarc_seed_kernel<D, 0>), dim3(8, seed_tiles), dim3(256), 0, 0, (const void*)p.corpus, (const float*)nullptr, p.q16, p.n_rows, p.n_tiles, seed_tiles, ws.seed);
-    hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(256), dim3(1024), 0, 0, ws.seed, seed_tiles * 32, (uint32_t)kprime, nq, -1.f, 1.f, (const float*)nullptr, (const float*)nullptr, (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist);
+    hipLaunchKernelGGL(rarc_seed_thr_kernel, dim3(256), dim3(1024), 0, 0, ws.seed, seed_tiles * 32, (uint32_t)kprime, nq, -1.f, 1.f, (const float*)nullptr, (const float*)nullptr, (uint32_t*)ws.thr, ws.binlo, ws.binscale, ws.bininv, ws.flags, ws.hist, (const float*)nullptr, (const float*)nullptr);
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL((rarc_scan_f16_kernel<D, ABL>), dim3(grid), dim3(512), lds, 0, p);
     hipEventRecord(e1, 0);

@@ -10,6 +10,8 @@
 #include "../rag-arc_amd/csrc/prep.hip"
 #include "../rag-arc_amd/csrc/finalize.hip"
 void rarc_set_error(const char* fmt, ...) { (void)fmt; }
+void rarc_roctx_push(const char*) {}
+void rarc_roctx_pop() {}
 bool rarc_prof_next(hipEvent_t*, hipEvent_t*) { return false; }
 
 #ifndef BD
@@ -24,7 +26,7 @@ static float run(const ScanQ8Params& p, int grid, int iters, const uint16_t* cor
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e30f;
   for (int it = 0; it < iters; ++it) {
-    rarc_seed_launch(corpus, nullptr, 0, N, D, qb.q16, 256, kprime, -1.f, 1.f, qb.eps16, qb.eps8, ws, 0);
+    rarc_seed_launch(corpus, nullptr, 0, N, D, qb.q16, 256, kprime, -1.f, 1.f, qb.eps16, qb.eps8, ws, 0, 0, nullptr);
     hipEventRecord(e0, 0);
     hipLaunchKernelGGL((rarc_scan_q8_kernel<D, 0, ABL>), dim3(grid), dim3(Q8_THREADS), lds, 0, p);
     hipEventRecord(e1, 0);
@@ -57,7 +59,7 @@ int main(int argc, char** argv) {
   { float h[4]; hipMemcpy(h, qmeta, 16, hipMemcpyDeviceToHost); float e8[4], e16[4]; hipMemcpy(e8, qb.eps8, 16, hipMemcpyDeviceToHost); hipMemcpy(e16, qb.eps16, 16, hipMemcpyDeviceToHost);
     printf("R = %.5f  eps8[0..1] = %.5f %.5f  eps16[0] = %.6f\n", h[0], e8[0], e8[1], e16[0]); }
   RarcWs ws = rarc_ws_carve(wsb);
-  ScanQ8Params p; p.corpus = (const uint4*)corpus; p.tmeta = qmeta + RARC_QMETA_HDR; p.q8 = qb.q8; p.qinv = qb.qinv; p.eps8 = qb.eps8;
+  ScanQ8Params p; p.corpus = (const uint4*)corpus; p.tmeta = qmeta + RARC_QMETA_HDR; p.q8 = qb.q8; p.qinv = qb.qinv; p.eps8 = qb.eps8; p.hq = qb.hq;
   p.n_rows = (uint32_t)N; p.n_tiles = (uint32_t)((N + 31) / 32); p.t_begin = 0; p.resume = 0; p.hot_margin = 1.0f;
   p.thr = (uint32_t*)ws.thr; p.hist = ws.hist; p.cnt2 = ws.cnt2; p.cand = ws.cand; p.seg = CAP / 256; p.kprime = KP; p.nq = NQ;
   p.binlo = ws.binlo; p.binscale = ws.binscale; p.bininv = ws.bininv;
@@ -79,7 +81,7 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 6; ++rep) {
       if (rep >= 3) { run<0>(p, grid, 1, corpus, N, qb, KP, ws); printf("(after a scan) "); }
       hipEventRecord(f0, 0);
-      rarc_finalize_q8_launch(corpus, nullptr, 0, D, qb.q32, qb.eps8, 256, K, 0, ws, CAP, grid, oi, os, st, 0, false);
+      rarc_finalize_q8_launch(corpus, nullptr, 0, D, qb.q32, qb.eps8, 256, K, 0, ws, CAP, grid, oi, os, st, 0, false, qmeta, qb.hq);
       hipEventRecord(f1, 0); hipEventSynchronize(f1); float ms; hipEventElapsedTime(&ms, f0, f1);
       unsigned long long h[16 + 1024]; hipMemcpy(h, fd, sizeof(h), hipMemcpyDeviceToHost);
       { double s1 = 0, s2 = 0; unsigned long long m1 = 0, m2 = 0, tmax = 0; int qmax = 0;
