@@ -64,6 +64,8 @@ constexpr int Q8_STAGE = 8 * Q8_WSTAGE;   // ... per workgroup
 constexpr int Q8_TB_SLOTS = 16;           // passing lanes per wave and tile handled by the transposed survivor walk
 constexpr int Q8_TB_STRIDE = 80;          // 16 int32 scores | threshold | scale | query + row-half
 
+constexpr int Q8_DEEP_D = 384;  // rows up to this many dimensions run with four fetch groups in flight (see NG)
+
 template <int D>
 struct ScanQ8Lds {
   static constexpr int RS = D + 16;         // row stride of the int8 tile (bytes)
@@ -434,8 +436,10 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   };
 
   // fetch groups in flight: two up to D = 896; one beyond (a group is 36 registers at D = 1024 and a
-  // spill would put scratch traffic into the very queue the counted waits rely on)
-  constexpr int NG = (FMT != 0 || D <= 896) ? 2 : 1;
+  // spill would put scratch traffic into the very queue the counted waits rely on); FOUR for narrow rows, where two
+  // tiles are too few bytes in flight to cover the HBM latency (48 KB per CU at D = 384 against ~45 KB needed:
+  // cycles per tile were 1170 + 2.4 D, the constant being exposed latency — DESIGN.md, narrow rows)
+  constexpr int NG = D <= Q8_DEEP_D ? 4 : ((FMT != 0 || D <= 896) ? 2 : 1);
   // ---- prologue: tile t0 straight into LDS buffer 0; tiles t0+stride, t0+2·stride in flight ----
   // (the launch guarantees gridDim.x <= n_tiles, so tile t0 exists)
   Fetch f[NG];
@@ -452,7 +456,15 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // instead of both leaving the matrix pipe idle at the same time.
   constexpr bool PP = (D <= 768) && !(ABL & 256);  // (where the second accumulator still fits in registers)
   const bool grp_b = PP && wave >= Q8_WAVES / 2;
-  if constexpr (NG == 2) {
+  if constexpr (NG == 4) {
+    fetch(f[1], clamp_tile(t0 + stride));
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(f[2], clamp_tile(t0 + 2 * stride));
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(f[3], clamp_tile(t0 + 3 * stride));
+    __builtin_amdgcn_sched_barrier(0);
+    if (!grp_b) fetch(f[0], clamp_tile(t0 + 4 * stride));  // (group B: in its first iteration, as below)
+  } else if constexpr (NG == 2) {
     fetch(f[1], clamp_tile(t0 + stride));
     __builtin_amdgcn_sched_barrier(0);
     // (group B issues this one in its first iteration, by the same formula as in every later one)
@@ -476,37 +488,37 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 #define Q8_STAMP(slot)                                                                                        \
   if ((ABL & 1024) && blockIdx.x == 0 && it >= 1000 && it < 1016 && lane == 0)                                 \
     p.dbg[8 + ((it - 1000) * Q8_WAVES + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
-#define Q8_G(PAR) (NG == 2 ? ((PAR) ^ 1) : 0)
-#define Q8_ITER(PAR, GB)                                                                                      \
+// G = the fetch group this iteration converts (tile cur + stride), GP = the one the previous iteration converted
+#define Q8_ITER(PAR, GB, G, GP)                                                                               \
   {                                                                                                           \
     Q8_STAMP(0)                                                                                               \
     if (!(GB)) { /* ---- group A: MFMA(cur) + convert(next), then prune(cur), then refill ---- */            \
       const float tinv = mcur[PAR].y, tsc = mcur[PAR].x;                                                      \
       i32x16 acc;                                                                                             \
-      acc = mfma_convert(PAR, f[Q8_G(PAR)]);                                                                  \
-      mcur[(PAR) ^ 1] = f[Q8_G(PAR)].meta;                                                                    \
+      acc = mfma_convert(PAR, f[G]);                                                                  \
+      mcur[(PAR) ^ 1] = f[G].meta;                                                                    \
       Q8_STAMP(1)                                                                                             \
       if (!(ABL & 8)) {                                                                                       \
-        thr = fmaxf(thr, __uint_as_float(f[Q8_G(PAR)].thr));                                                  \
-        if (lane < 32) s_hland[32 * wave + lane] = f[Q8_G(PAR)].hw;                                           \
+        thr = fmaxf(thr, __uint_as_float(f[G].thr));                                                  \
+        if (lane < 32) s_hland[32 * wave + lane] = f[G].hw;                                           \
       }                                                                                                       \
       if (!(ABL & 1) && live) prune(acc, cur, tinv, tsc);                                                     \
       else if (acc[0] == 0x7fffffff) p.cnt2[0] = 1; /* keep the MFMAs alive */                                \
       Q8_STAMP(2)                                                                                             \
       /* refill that group with tile cur+3·stride */                                                          \
-      if (!(ABL & 2)) fetch(f[Q8_G(PAR)], clamp_tile(cur + (NG + 1) * stride));                               \
+      if (!(ABL & 2)) fetch(f[G], clamp_tile(cur + (NG + 1) * stride));                               \
     } else { /* ---- group B: prune(previous tile), refill the group consumed last iteration, then MFMA ---- */ \
       if (!(ABL & 1) && live_prev) prune(acc_b, cur - stride, mcur[(PAR) ^ 1].y, mcur[(PAR) ^ 1].x);          \
       live_prev = live;                                                                                       \
       Q8_STAMP(1)                                                                                             \
-      if (!(ABL & 2)) fetch(f[PAR], clamp_tile(cur + 2 * stride));                                            \
+      if (!(ABL & 2)) fetch(f[GP], clamp_tile(cur + NG * stride));                                            \
       __builtin_amdgcn_sched_barrier(0); /* the chunk loads must be ISSUED before the matrix phase */          \
       Q8_STAMP(2)                                                                                             \
-      acc_b = mfma_convert(PAR, f[(PAR) ^ 1]);                                                                \
-      mcur[(PAR) ^ 1] = f[(PAR) ^ 1].meta;                                                                    \
+      acc_b = mfma_convert(PAR, f[G]);                                                                        \
+      mcur[(PAR) ^ 1] = f[G].meta;                                                                            \
       if (!(ABL & 8)) {                                                                                       \
-        thr = fmaxf(thr, __uint_as_float(f[(PAR) ^ 1].thr));                                                  \
-        if (lane < 32) s_hland[32 * wave + lane] = f[(PAR) ^ 1].hw;                                           \
+        thr = fmaxf(thr, __uint_as_float(f[G].thr));                                                          \
+        if (lane < 32) s_hland[32 * wave + lane] = f[G].hw;                                                   \
       }                                                                                                       \
       if ((ABL & 1) && acc_b[0] == 0x7fffffff) p.cnt2[0] = 1;                                                 \
     }                                                                                                         \
@@ -539,17 +551,20 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // tile index past the end: its scores are ignored (`live`), its fetch is the usual tile-0 dummy.
   // (two copies of the loop, one per wave group: inside ONE loop the compiler would merge the wait counters
   // of the two instruction orders and fall back to draining the queue)
+#define Q8_STEP(OFF, PAR, GB, G, GP)                                                  \
+    {                                                                                 \
+      const uint32_t cur = base + (OFF) * stride;                                     \
+      const bool live = (OFF) == 0 || cur < p.n_tiles;                                \
+      Q8_ITER(PAR, GB, G, GP)                                                         \
+    }
 #define Q8_LOOP(GB)                                                                   \
-  for (uint32_t base = t0; base < p.n_tiles; base += 2 * stride) {                    \
-    {                                                                                 \
-      const uint32_t cur = base;                                                      \
-      const bool live = true;                                                         \
-      Q8_ITER(0, GB)                                                                  \
+  if constexpr (NG == 4) {                                                            \
+    for (uint32_t base = t0; base < p.n_tiles; base += 4 * stride) {                  \
+      Q8_STEP(0, 0, GB, 1, 0) Q8_STEP(1, 1, GB, 2, 1) Q8_STEP(2, 0, GB, 3, 2) Q8_STEP(3, 1, GB, 0, 3) \
     }                                                                                 \
-    {                                                                                 \
-      const uint32_t cur = base + stride;                                             \
-      const bool live = cur < p.n_tiles;                                              \
-      Q8_ITER(1, GB)                                                                  \
+  } else {                                                                            \
+    for (uint32_t base = t0; base < p.n_tiles; base += 2 * stride) {                  \
+      Q8_STEP(0, 0, GB, NG == 2 ? 1 : 0, 0) Q8_STEP(1, 1, GB, 0, NG == 2 ? 1 : 0)     \
     }                                                                                 \
   }
   if (grp_b) {
@@ -557,11 +572,12 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   } else {
     Q8_LOOP(false)
   }
+#undef Q8_STEP
 #undef Q8_LOOP
 #undef Q8_ITER
-#undef Q8_G
   // group B still owes the pruning of its last tile (the second half of the last pair: LDS buffer 1)
-  if (grp_b && !(ABL & 1) && live_prev) prune(acc_b, t0 + (((p.n_tiles - 1 - t0) / stride) | 1u) * stride, mcur[1].y, mcur[1].x);
+  if (grp_b && !(ABL & 1) && live_prev)
+    prune(acc_b, t0 + (((p.n_tiles - 1 - t0) / stride) | (NG == 4 ? 3u : 1u)) * stride, mcur[1].y, mcur[1].x);
   flush();
   __syncthreads();
   if (tid < RARC_MAX_QUERIES) p.cnt2[(size_t)blockIdx.x * RARC_MAX_QUERIES + tid] = s_cnt[tid];
