@@ -64,6 +64,8 @@ constexpr int Q8_STAGE = 8 * Q8_WSTAGE;   // ... per workgroup
 constexpr int Q8_TB_SLOTS = 16;           // passing lanes per wave and tile handled by the transposed survivor walk
 constexpr int Q8_TB_STRIDE = 80;          // 16 int32 scores | threshold | scale | query + row-half
 
+template <bool B>
+struct Q8Flag { static constexpr bool value = B; };
 constexpr int Q8_DEEP_D = 384;  // rows up to this many dimensions run with four fetch groups in flight (see NG)
 
 template <int D>
@@ -194,15 +196,20 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // (small items first: if the register allocator decides to move one of these long-lived values
   // while it is still in flight, the wait it needs then is for the OLDEST entries of the newest group,
   // i.e. no more than the wait for the group about to be consumed anyway)
-  auto fetch = [&](Fetch& f, uint32_t tile) {
+  // `refresh`: also re-read the lane's published threshold and the owner's histogram word.  With four fetch groups
+  // (narrow rows) only one group in four does: at D = 384 the three small loads were half of a tile's vector-memory
+  // instructions, and a CU issues one wave-instruction per ~45 cycles whatever its size (48 per tile = the tile period).
+  auto fetch = [&](Fetch& f, uint32_t tile, auto refresh) {
     f.meta = *(const float2*)(p.tmeta + (size_t)tile * MSTRIDE);
     if constexpr (FMT == 1) {
 #pragma unroll
       for (int j = 0; j < CPT; ++j)
         f.mul[j] = p.tmeta[(size_t)tile * MSTRIDE + 2 + (j * Q8_THREADS + tid) / CPR];
     }
-    f.thr = __hip_atomic_load(&p.thr[qidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    f.hw = __hip_atomic_load(hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (decltype(refresh)::value) {
+      f.thr = __hip_atomic_load(&p.thr[qidx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f.hw = __hip_atomic_load(hword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const uint4* src = p.corpus + (size_t)tile * TCH + tid;
 #pragma unroll
@@ -443,7 +450,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // ---- prologue: tile t0 straight into LDS buffer 0; tiles t0+stride, t0+2·stride in flight ----
   // (the launch guarantees gridDim.x <= n_tiles, so tile t0 exists)
   Fetch f[NG];
-  fetch(f[0], t0);
+  fetch(f[0], t0, Q8Flag<true>{});
   convert_tile(f[0], 0);
   float2 mcur[2];   // (scale | R_t word, 1/scale) of the tile sitting in LDS buffer 0 / 1
   mcur[0] = f[0].meta;
@@ -457,20 +464,20 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   constexpr bool PP = (D <= 768) && !(ABL & 256);  // (where the second accumulator still fits in registers)
   const bool grp_b = PP && wave >= Q8_WAVES / 2;
   if constexpr (NG == 4) {
-    fetch(f[1], clamp_tile(t0 + stride));
+    fetch(f[1], clamp_tile(t0 + stride), Q8Flag<true>{});
     __builtin_amdgcn_sched_barrier(0);
-    fetch(f[2], clamp_tile(t0 + 2 * stride));
+    fetch(f[2], clamp_tile(t0 + 2 * stride), Q8Flag<true>{});
     __builtin_amdgcn_sched_barrier(0);
-    fetch(f[3], clamp_tile(t0 + 3 * stride));
+    fetch(f[3], clamp_tile(t0 + 3 * stride), Q8Flag<true>{});
     __builtin_amdgcn_sched_barrier(0);
-    if (!grp_b) fetch(f[0], clamp_tile(t0 + 4 * stride));  // (group B: in its first iteration, as below)
+    if (!grp_b) fetch(f[0], clamp_tile(t0 + 4 * stride), Q8Flag<true>{});  // (group B: in its first iteration, as below)
   } else if constexpr (NG == 2) {
-    fetch(f[1], clamp_tile(t0 + stride));
+    fetch(f[1], clamp_tile(t0 + stride), Q8Flag<true>{});
     __builtin_amdgcn_sched_barrier(0);
     // (group B issues this one in its first iteration, by the same formula as in every later one)
-    if (!grp_b) fetch(f[0], clamp_tile(t0 + 2 * stride));
+    if (!grp_b) fetch(f[0], clamp_tile(t0 + 2 * stride), Q8Flag<true>{});
   } else {
-    fetch(f[0], clamp_tile(t0 + stride));
+    fetch(f[0], clamp_tile(t0 + stride), Q8Flag<true>{});
   }
   __builtin_amdgcn_sched_barrier(0);
   // owner lane: last threshold it published (starts from what the seed pass / the tightening pass left there)
@@ -489,6 +496,8 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   if ((ABL & 1024) && blockIdx.x == 0 && it >= 1000 && it < 1016 && lane == 0)                                 \
     p.dbg[8 + ((it - 1000) * Q8_WAVES + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
 // G = the fetch group this iteration converts (tile cur + stride), GP = the one the previous iteration converted
+// RF(g): does fetch group g carry the threshold / histogram refresh (all of them unless NG == 4: then group 1 only)
+#define Q8_RF(g) (NG != 4 || (g) == 1)
 #define Q8_ITER(PAR, GB, G, GP)                                                                               \
   {                                                                                                           \
     Q8_STAMP(0)                                                                                               \
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       acc = mfma_convert(PAR, f[G]);                                                                  \
       mcur[(PAR) ^ 1] = f[G].meta;                                                                    \
       Q8_STAMP(1)                                                                                             \
-      if (!(ABL & 8)) {                                                                                       \
+      if (!(ABL & 8) && Q8_RF(G)) {                                                                           \
         thr = fmaxf(thr, __uint_as_float(f[G].thr));                                                  \
         if (lane < 32) s_hland[32 * wave + lane] = f[G].hw;                                           \
       }                                                                                                       \
@@ -506,17 +515,17 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       else if (acc[0] == 0x7fffffff) p.cnt2[0] = 1; /* keep the MFMAs alive */                                \
       Q8_STAMP(2)                                                                                             \
       /* refill that group with tile cur+3·stride */                                                          \
-      if (!(ABL & 2)) fetch(f[G], clamp_tile(cur + (NG + 1) * stride));                               \
+      if (!(ABL & 2)) fetch(f[G], clamp_tile(cur + (NG + 1) * stride), Q8Flag<Q8_RF(G)>{});           \
     } else { /* ---- group B: prune(previous tile), refill the group consumed last iteration, then MFMA ---- */ \
       if (!(ABL & 1) && live_prev) prune(acc_b, cur - stride, mcur[(PAR) ^ 1].y, mcur[(PAR) ^ 1].x);          \
       live_prev = live;                                                                                       \
       Q8_STAMP(1)                                                                                             \
-      if (!(ABL & 2)) fetch(f[GP], clamp_tile(cur + NG * stride));                                            \
+      if (!(ABL & 2)) fetch(f[GP], clamp_tile(cur + NG * stride), Q8Flag<Q8_RF(GP)>{});                       \
       __builtin_amdgcn_sched_barrier(0); /* the chunk loads must be ISSUED before the matrix phase */          \
       Q8_STAMP(2)                                                                                             \
       acc_b = mfma_convert(PAR, f[G]);                                                                        \
       mcur[(PAR) ^ 1] = f[G].meta;                                                                            \
-      if (!(ABL & 8)) {                                                                                       \
+      if (!(ABL & 8) && Q8_RF(G)) {                                                                           \
         thr = fmaxf(thr, __uint_as_float(f[G].thr));                                                          \
         if (lane < 32) s_hland[32 * wave + lane] = f[G].hw;                                                   \
       }                                                                                                       \
@@ -575,6 +584,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 #undef Q8_STEP
 #undef Q8_LOOP
 #undef Q8_ITER
+#undef Q8_RF
   // group B still owes the pruning of its last tile (the second half of the last pair: LDS buffer 1)
   if (grp_b && !(ABL & 1) && live_prev)
     prune(acc_b, t0 + (((p.n_tiles - 1 - t0) / stride) | (NG == 4 ? 3u : 1u)) * stride, mcur[1].y, mcur[1].x);
