@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 204 /* 0.2.4: + batched verification, float64 cosine matrix / adjacent distances */
+#define RARC_VERSION 205 /* 0.2.5: gate_up_w rows interleaved in groups of 8 (SwiGLU epilogue, act = 3), LM workspace + rotary table */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
