@@ -49,6 +49,12 @@ constexpr int SCAN_WAVES = 8;
 // refill the slot with fragment S+R.  Every asm statement names the registers it touches, so the
 // order between steps is fixed by data flow; immediates come from template parameters.
 constexpr int SCAN_RING = 6;
+#ifndef SCAN_DMA_B_INLOOP
+#define SCAN_DMA_B_INLOOP 0  // group B's pieces: 0 = all right after the barrier, 1 = spread through its MFMA chain too
+#endif
+#ifndef SCAN_DMA_EVERY
+#define SCAN_DMA_EVERY 8  // MFMA steps between two LDS-DMA issues of a wave (1 = all in the first steps)
+#endif
 
 template <int S, int KS, int R>
 struct ScanSteps {
@@ -59,7 +65,7 @@ struct ScanSteps {
   static __device__ __forceinline__ void run(f32x16& acc, half8 (&rg)[R], const half8 (&qf)[KS], int a0, int a1,
                                              int a2, int a3, Dma& dma) {
     constexpr int slot = S % R;
-    if constexpr (S >= 1 && S <= KS / 8) dma(S - 1);
+    if constexpr (S % SCAN_DMA_EVERY == 1 && S / SCAN_DMA_EVERY < KS / 8) dma(S / SCAN_DMA_EVERY);
     if constexpr (S + R < KS) {
       constexpr int S2 = S + R;  // fragment that refills this slot
       const int addr = (S2 & 3) == 0 ? a0 : (S2 & 3) == 1 ? a1 : (S2 & 3) == 2 ? a2 : a3;
@@ -271,13 +277,13 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     // the DMA of tile cur+2 is issued piecewise from inside the MFMA loop (see ScanSteps)
     const uint32_t dma_tile = cur + 2 * stride;
     auto dma = [&](int j) {
-      if (issued && !grp_b) {  // group B issued all its pieces right after the barrier
+      if (issued && (SCAN_DMA_B_INLOOP || !grp_b)) {  // (else group B issued all its pieces right after the barrier)
         asm volatile("" ::: "memory");
         issue_piece(nb, dma_tile, j);
         asm volatile("" ::: "memory");
       }
     };
-    if (issued && (grp_b || (ABL & 4))) issue(nb, dma_tile);  // group B (it prunes first anyway)
+    if (issued && ((grp_b && !SCAN_DMA_B_INLOOP) || (ABL & 4))) issue(nb, dma_tile);  // group B (it prunes first anyway)
     RARC_STAMP(1)
     // group B prunes the PREVIOUS tile now, while group A (same SIMDs) already streams MFMAs
     if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
