@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 205 /* 0.2.5: gate_up_w rows interleaved in groups of 8 (SwiGLU epilogue, act = 3), LM workspace + rotary table */
+#define RARC_VERSION 300 /* 0.3.0: fp32-class encoder forward (rarc_enc32_*: split-operand fp16 MFMA, fp32 everywhere else) */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
@@ -385,6 +385,40 @@ typedef struct RarcEncModel {
 size_t rarc_enc_workspace_bytes(int hidden, int inter, int n_tokens);
 int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
                      int seq_len, int normalize, void* d_ws, size_t ws_bytes, float* d_out, void* stream);
+
+/*
+ * The same forward at the REFERENCE's precision (fp32-class; `precision = "fp32"` of the embedding provider).
+ * `SentenceTransformer(model_name, **model_kwargs)` (huggingface.py:96-98) loads fp32 weights and `.encode` (:122-126)
+ * runs an fp32 forward; rarc_enc_forward above is an fp16 approximation of it (1e-3 class), this one agrees with an
+ * fp32 forward to fp32 rounding noise.  The GEMMs run on the fp16 MFMA over SPLIT operands: x*s = hi + lo (two fp16
+ * numbers, s a power of two per row, together 22 bits of x), C = [A_lo|A_hi|A_hi] * [W_hi|W_lo|W_hi]^T / (s_a s_w): one
+ * fp16 GEMM over K' = 3K with fp32 accumulation.  Residual stream, LayerNorm, GELU (libm erff), softmax (libm expf),
+ * attention products and pooling are fp32.
+ *   rarc_enc32_split_weight : W fp32 [n][k] (torch Linear layout) -> d_w3 fp16 [n][3k] = [hi | lo | hi], d_rw fp32 [n] = 1/s_w
+ *   rarc_enc32_split_rows   : X fp32 [m][k] -> d_a3 fp16 [m][3k] = [lo | hi | hi], d_ra fp32 [m] = 1/s_a   (k % 4 == 0, k <= 4096)
+ *   rarc_enc32_gemm         : C fp32 [m][n] = X W^T + bias from the two split images (m, n multiples of 128, k of 64)
+ *   rarc_enc32_forward      : token ids -> fp32 embeddings; arguments as rarc_enc_forward; hidden <= 1024, inter <= 4096
+ */
+typedef struct RarcEnc32Layer {
+  const uint16_t* qkv_w3; const float *qkv_rw, *qkv_b;           /* fused [3*hidden][3*hidden] split rows, [3*hidden], [3*hidden] */
+  const uint16_t* o_w3;   const float *o_rw, *o_b, *ln1_g, *ln1_b;
+  const uint16_t* f1_w3;  const float *f1_rw, *f1_b;
+  const uint16_t* f2_w3;  const float *f2_rw, *f2_b, *ln2_g, *ln2_b;
+} RarcEnc32Layer;
+typedef struct RarcEnc32Model {
+  int hidden, heads, inter, n_layers;
+  float ln_eps;
+  const float *word, *pos, *type0, *emb_g, *emb_b; /* fp32 tables and LayerNorm parameters */
+  const RarcEnc32Layer* layers;                    /* host array [n_layers] */
+  int vocab, max_pos;                              /* REQUIRED, as in RarcEncModel */
+} RarcEnc32Model;
+int rarc_enc32_split_weight(const float* d_w, int n, int k, uint16_t* d_w3, float* d_rw, void* stream);
+int rarc_enc32_split_rows(const float* d_x, int m, int k, uint16_t* d_a3, float* d_ra, void* stream);
+int rarc_enc32_gemm(const uint16_t* d_a3, const float* d_ra, const uint16_t* d_w3, const float* d_rw,
+                    const float* d_bias, float* d_c, int m, int n, int k, void* stream);
+size_t rarc_enc32_workspace_bytes(int hidden, int inter, int n_tokens);
+int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
+                       int seq_len, int normalize, void* d_ws, size_t ws_bytes, float* d_out, void* stream);
 
 /*
  * Reranker LM forward — what Qwen3Reranker.compute_logits takes from the causal LM

@@ -356,10 +356,12 @@ def stable_desc_order(scores: np.ndarray) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------- encoder
-def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=True, pooling="cls"):
+def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=True, pooling="cls", dtype=np.float32):
     """BERT encoder forward in float32 numpy, CLS pooling (what SentenceTransformer.encode computes
     for bge-style models reached from huggingface.py:122-126).  `sd` = HuggingFace BertModel state
-    dict (numpy arrays).  Pinned against transformers.BertModel in tests/test_oracle_golden.py."""
+    dict (numpy arrays).  Pinned against transformers.BertModel in tests/test_oracle_golden.py.
+    dtype=np.float64 runs the same graph in float64 on the same (fp32) weights: the yardstick two fp32-class
+    forwards are measured against (tests of the fp32 encoder mode)."""
     from math import sqrt
 
     try:
@@ -367,7 +369,7 @@ def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=Tru
     except Exception:  # pragma: no cover
         import math
         erf = np.vectorize(math.erf)
-    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    g = lambda k: np.asarray(sd[k], dtype=np.float32).astype(dtype)
     ids = np.asarray(input_ids)
     n, L = ids.shape
     lens = np.asarray(lengths)
@@ -382,7 +384,7 @@ def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=Tru
     x = ln(x, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"))
     H = x.shape[-1]
     dh = H // num_heads
-    mask = np.where(np.arange(L)[None, :] < lens[:, None], 0.0, -np.inf).astype(np.float32)   # [n][L] keys
+    mask = np.where(np.arange(L)[None, :] < lens[:, None], 0.0, -np.inf).astype(dtype)   # [n][L] keys
     i = 0
     while f"encoder.layer.{i}.attention.self.query.weight" in sd:
         p = f"encoder.layer.{i}."
@@ -399,13 +401,15 @@ def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=Tru
                g(p + "attention.output.LayerNorm.bias"))
         h = lin(x, "intermediate.dense")
         h = 0.5 * h * (1.0 + erf(h / np.sqrt(2.0)))
-        x = ln(lin(h.astype(np.float32), "output.dense") + x, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))
+        x = ln(lin(h.astype(dtype), "output.dense") + x, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))
         i += 1
     if pooling == "mean":   # sentence-transformers Pooling(mode_mean_tokens): mean over the attention-masked tokens
-        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.float32)[:, :, None]
-        cls = ((x * m).sum(1) / m.sum(1)).astype(np.float32)
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(dtype)[:, :, None]
+        cls = ((x * m).sum(1) / m.sum(1)).astype(dtype)
     else:
-        cls = x[:, 0, :].astype(np.float32)
+        cls = x[:, 0, :].astype(dtype)
+    if dtype != np.float32:
+        return cls / np.linalg.norm(cls, axis=1, keepdims=True) if normalize else cls
     return normalize_L2(cls) if normalize else cls
 
 
@@ -435,7 +439,7 @@ def qwen3_last_logits_f32(sd, cfg, input_ids, attention_mask, token_ids):
     state dict (numpy); `cfg`: dict(num_attention_heads, num_key_value_heads, head_dim, rms_norm_eps, rope_theta).
     Positions run 0..L-1 over the padded sequence (the reference's forward passes no position_ids).
     Pinned against transformers.Qwen3ForCausalLM in tests/test_oracle_golden.py."""
-    g = lambda k: np.asarray(sd[k], dtype=np.float32)
+    g = lambda k: np.asarray(sd[k], dtype=np.float32).astype(dtype)
     ids = np.asarray(input_ids)
     mask = np.asarray(attention_mask).astype(bool)
     n, L = ids.shape

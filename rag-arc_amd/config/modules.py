@@ -56,6 +56,9 @@ class HipBertEmbeddingsConfig(AbstractConfig):
     batch_size: int = 32
     layer_norm_eps: float = 1e-12
     device: int = 0
+    # "fp32": the reference's arithmetic (SentenceTransformer loads fp32, huggingface.py:96-98) — split-operand MFMA GEMMs,
+    # fp32 everywhere else; "fp16": the faster 1e-3-class forward (what model_kwargs={"torch_dtype": float16} would ask for)
+    precision: Literal["fp32", "fp16"] = "fp32"
     # sentence-transformers prompts (huggingface.py:26-37): model_kwargs 'prompts' / 'default_prompt_name',
     # encode_kwargs 'prompt_name' / 'prompt'
     prompts: Dict[str, str] = Field(default_factory=dict)
@@ -68,7 +71,8 @@ class HipBertEmbeddingsConfig(AbstractConfig):
         from ..encapsulation.embeddings.wordpiece import WordPieceTokenizer
 
         enc = HipBertEncoder(load_state_dict(self.weights_path), num_heads=self.num_heads,
-                             layer_norm_eps=self.layer_norm_eps, device=self.device, pooling=self.pooling)
+                             layer_norm_eps=self.layer_norm_eps, device=self.device, pooling=self.pooling,
+                             precision=self.precision)
         tok = WordPieceTokenizer.from_file(self.vocab_path, do_lower_case=self.do_lower_case,
                                            max_length=min(self.max_length, enc.max_pos))
         return BuiltModule(config=self, impl=HipBertEmbeddings(enc, tok, max_length=self.max_length,

@@ -1237,6 +1237,12 @@ static int enc_gemm_splitk(const uint16_t* d_a, const uint16_t* d_w, float* d_pa
   return RARC_OK;
 }
 
+// fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward
+// (encoder_f32.hip: split operands, K = 3x the model's k).  The split-K kernels with one slice.
+int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s) {
+  return enc_gemm_splitk(a, w, c, m, n, k, 1, s);
+}
+
 // 256 x 256 or 256 x 128 tiles?  One workgroup per CU either way, so the time is rounds x time per round, and a
 // 256 x 256 tile takes about 1.5x a 256 x 128 one for twice the area (measured 1.44x at K = 3072): the larger tile
 // wins whenever its ragged last round costs less than that (51 200 x 1024 x 3072: 800 tiles in 4 rounds, 339 us,

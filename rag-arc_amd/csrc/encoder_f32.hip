@@ -1,0 +1,445 @@
+// encoder_f32.hip — the encoder forward at the REFERENCE's precision (fp32-class), precision = "fp32" of the provider.
+//
+// HuggingFaceEmbeddings builds `SentenceTransformer(model_name, **model_kwargs)` with no dtype
+// (core/file_management/embeddings/huggingface.py:96-98) and calls `.encode` (:122-126): an fp32 forward.  The fp16
+// forward of encoder.hip is a 1e-3-class approximation of it; this file is the mode whose embeddings agree with an
+// fp32 forward to fp32 rounding noise, so that ids and scores downstream are the reference's.
+//
+// The dense contractions still run on the fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate) — as SPLIT operands:
+//   x·s = hi + lo,  hi = fp16(x·s),  lo = fp16(x·s − hi)        (s a power of two per row: both roundings lose < 2^-22 |x|)
+//   C = A·Wᵀ = [A_lo | A_hi | A_hi] · [W_hi | W_lo | W_hi]ᵀ / (s_a[m]·s_w[n])          (the lo·lo term, 2^-22 relative, is dropped)
+// i.e. ONE fp16 GEMM over K' = 3K with the small cross terms accumulated first; fp16 products are exact in fp32, the
+// accumulator is fp32, the row scales are powers of two (exact).  Per-row scales put the row maximum in [2^13, 2^14):
+// lo is a normal fp16 number for every element within 2^-17 of the row maximum, and an element below that is
+// represented to 2^-39 of the maximum even if subnormal halves were flushed.
+// Everything between the GEMMs is fp32: residual stream, LayerNorm (two-pass statistics), exact erf GELU (libm erff),
+// softmax (libm expf), pooling and the canonical L2 normalisation.  Attention (QKᵀ, PV) is fp32 FMA.
+#include "rarc_common.h"
+
+int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s);  // encoder.hip
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+// power-of-two scale that puts `mx` into [2^13, 2^14) (1 for a zero / non-finite maximum); inv = 1/s, both exact
+__device__ __forceinline__ void e32_scale_of(float mx, float& s, float& inv) {
+  s = 1.f; inv = 1.f;
+  if (mx > 0.f && mx < __builtin_inff()) {
+    int e;
+    (void)frexpf(mx, &e);            // mx = m·2^e, m in [0.5, 1)
+    int ex = 14 - e;
+    ex = ex > 100 ? 100 : (ex < -100 ? -100 : ex);
+    s = ldexpf(1.f, ex);
+    inv = ldexpf(1.f, -ex);
+  }
+}
+
+__device__ __forceinline__ void e32_split4(const float4 v, float s, half4_t& hi, half4_t& lo) {
+  const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi[e] = (half_t)x[e];
+    lo[e] = (half_t)(x[e] - (float)hi[e]);   // the difference is exact in fp32
+  }
+}
+
+__device__ __forceinline__ float e32_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float e32_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// 256-thread block reductions (fixed order: wave tree, then waves 0..3); `slot` = 4 floats of LDS per call site
+__device__ __forceinline__ float e32_block_sum(float v, float* slot) {
+  v = e32_wave_sum(v);
+  if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return ((slot[0] + slot[1]) + (slot[2] + slot[3]));
+}
+__device__ __forceinline__ float e32_block_max(float v, float* slot) {
+  v = e32_wave_max(v);
+  if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(slot[0], slot[1]), fmaxf(slot[2], slot[3]));
+}
+
+// One workgroup (256 threads) per row of n <= 1024·NV elements; thread t owns the float4 chunks t + 256·i.
+template <int NV>
+struct E32Row {
+  float4 v[NV];
+};
+
+// row -> split image [lo | hi | hi] (3n halves) + the row's inverse scale
+template <int NV>
+__device__ __forceinline__ void e32_store_split(const E32Row<NV>& r, int n, half_t* out3, float* ra_out, float* slot) {
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((threadIdx.x + 256 * i) * 4 < n)
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(r.v[i].x), fabsf(r.v[i].y))), fmaxf(fabsf(r.v[i].z), fabsf(r.v[i].w)));
+  mx = e32_block_max(mx, slot);
+  float s, inv;
+  e32_scale_of(mx, s, inv);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (threadIdx.x + 256 * i) * 4;
+    if (c < n) {
+      half4_t hi, lo;
+      e32_split4(r.v[i], s, hi, lo);
+      *(half4_t*)(out3 + c) = lo;
+      *(half4_t*)(out3 + n + c) = hi;
+      *(half4_t*)(out3 + 2 * n + c) = hi;
+    }
+  }
+  if (threadIdx.x == 0) *ra_out = inv;
+}
+
+// LayerNorm of the row in place (two-pass fp32 statistics, population variance, 1/sqrt exact-rounded)
+template <int NV>
+__device__ __forceinline__ void e32_layernorm(E32Row<NV>& r, int n, const float* gamma, const float* beta, float eps,
+                                              float* slot) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((threadIdx.x + 256 * i) * 4 < n) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+  const float mean = e32_block_sum(s, slot) / (float)n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((threadIdx.x + 256 * i) * 4 < n) {
+      const float a = r.v[i].x - mean, b = r.v[i].y - mean, c = r.v[i].z - mean, d = r.v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  const float var = e32_block_sum(q, slot + 4) / (float)n;
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (threadIdx.x + 256 * i) * 4;
+    if (c < n) {
+      const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+      r.v[i].x = (r.v[i].x - mean) * rstd * g.x + b.x;
+      r.v[i].y = (r.v[i].y - mean) * rstd * g.y + b.y;
+      r.v[i].z = (r.v[i].z - mean) * rstd * g.z + b.z;
+      r.v[i].w = (r.v[i].w - mean) * rstd * g.w + b.w;
+    }
+  }
+}
+
+__device__ __forceinline__ float e32_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// Row epilogue of a split GEMM.  MODE:
+//   0  v = P·ra·rw + bias                      -> out32
+//   1  v = gelu(P·ra·rw + bias)                -> split image
+//   2  v = LayerNorm(P·ra·rw + bias + resid)   -> out32 (may alias resid) and split image
+//   3  v = P (plain fp32 rows, no scales)      -> split image
+template <int NV, int MODE>
+__global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* __restrict__ P, const float* __restrict__ ra,
+                                                           const float* __restrict__ rw, const float* __restrict__ bias,
+                                                           const float* resid, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, int n,
+                                                           float* out32, half_t* __restrict__ out3,
+                                                           float* __restrict__ ra_out) {
+  __shared__ float slot[12];
+  const size_t m = blockIdx.x;
+  E32Row<NV> r;
+  const float ram = MODE == 3 ? 1.f : ra[m];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (threadIdx.x + 256 * i) * 4;
+    if (c < n) {
+      float4 p = *(const float4*)(P + m * n + c);
+      if (MODE != 3) {
+        const float4 w = *(const float4*)(rw + c), b = *(const float4*)(bias + c);
+        // ra, rw are powers of two: the two scalings are exact, the bias add rounds once (as in x·Wᵀ + b)
+        p.x = p.x * ram * w.x + b.x; p.y = p.y * ram * w.y + b.y; p.z = p.z * ram * w.z + b.z; p.w = p.w * ram * w.w + b.w;
+      }
+      if (MODE == 1) { p.x = e32_gelu(p.x); p.y = e32_gelu(p.y); p.z = e32_gelu(p.z); p.w = e32_gelu(p.w); }
+      if (MODE == 2) {
+        const float4 x = *(const float4*)(resid + m * n + c);
+        p.x += x.x; p.y += x.y; p.z += x.z; p.w += x.w;
+      }
+      r.v[i] = p;
+    } else {
+      r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (MODE == 2) e32_layernorm<NV>(r, n, gamma, beta, eps, slot);
+  if (MODE == 0 || MODE == 2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (threadIdx.x + 256 * i) * 4;
+      if (c < n) *(float4*)(out32 + m * n + c) = r.v[i];
+    }
+  }
+  if (MODE != 0) e32_store_split<NV>(r, n, out3 + m * 3 * n, ra_out + m, slot + 8);
+}
+
+// x = LayerNorm(word[id] + pos[t % L] + type0) -> fp32 rows + split image
+__global__ __launch_bounds__(256) void rarc_e32_embed_kernel(const int32_t* __restrict__ ids, const float* __restrict__ word,
+                                                             const float* __restrict__ pos, const float* __restrict__ type0,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, int L, int H, int vocab, float* __restrict__ out32,
+                                                             half_t* __restrict__ out3, float* __restrict__ ra_out) {
+  __shared__ float slot[12];
+  const size_t t = blockIdx.x;
+  int id = ids[t];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  E32Row<1> r;
+  const int c = threadIdx.x * 4;
+  if (c < H) {
+    const float4 a = *(const float4*)(word + (size_t)id * H + c), b = *(const float4*)(pos + (size_t)(t % L) * H + c),
+                 ty = *(const float4*)(type0 + c);
+    // (word + type) + pos: the order BertEmbeddings adds them in (inputs_embeds + token_type_embeddings, then + position)
+    r.v[0] = make_float4((a.x + ty.x) + b.x, (a.y + ty.y) + b.y, (a.z + ty.z) + b.z, (a.w + ty.w) + b.w);
+  } else {
+    r.v[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  e32_layernorm<1>(r, H, gamma, beta, eps, slot);
+  if (c < H) *(float4*)(out32 + t * H + c) = r.v[0];
+  e32_store_split<1>(r, H, out3 + t * 3 * H, ra_out + t, slot + 8);
+}
+
+// weight rows at load time: W fp32 [N][K] -> [W_hi | W_lo | W_hi] (3K halves per row) + inverse row scale
+__global__ __launch_bounds__(256) void rarc_e32_split_weight_kernel(const float* __restrict__ W, int K, half_t* __restrict__ w3,
+                                                                    float* __restrict__ rw) {
+  __shared__ float slot[4];
+  const size_t nrow = blockIdx.x;
+  const float* w = W + nrow * K;
+  float mx = 0.f;
+  for (int c = threadIdx.x; c < K; c += 256) mx = fmaxf(mx, fabsf(w[c]));
+  mx = e32_block_max(mx, slot);
+  float s, inv;
+  e32_scale_of(mx, s, inv);
+  half_t* o = w3 + nrow * 3 * K;
+  for (int c = threadIdx.x; c < K; c += 256) {
+    const float x = w[c] * s;
+    const half_t hi = (half_t)x, lo = (half_t)(x - (float)hi);
+    o[c] = hi;
+    o[K + c] = lo;
+    o[2 * K + c] = hi;
+  }
+  if (threadIdx.x == 0) rw[nrow] = inv;
+}
+
+// ------------------------------------------------------------------------------------------
+// Attention in fp32: P [M][3H] is the raw split product of the fused q|k|v projection; its scales and bias are applied
+// as the values are staged in LDS (no separate pass).  One workgroup per (sequence, head, block of 64 query rows);
+// wave w owns rows w, w+4, ...; keys/values stream through LDS in 64-key tiles; scores with lane <-> key, outputs with
+// lane <-> dimension; online softmax (libm expf); keys >= lens[seq] masked.
+// ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __restrict__ P, const float* __restrict__ ra,
+                                                                 const float* __restrict__ rw, const float* __restrict__ bias,
+                                                                 const int32_t* __restrict__ lens, int L, int H, int n_heads,
+                                                                 int q_blocks, float* __restrict__ ctx) {
+  constexpr int KT = 64, RPW = 16;
+  __shared__ float ks[KT][DH + 1];
+  __shared__ float vs[KT][DH + 1];
+  __shared__ float qs[64][DH + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qb = blockIdx.x % q_blocks, bh = blockIdx.x / q_blocks;
+  const int b = bh / n_heads, hd = bh % n_heads;
+  const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
+  const size_t row0 = (size_t)b * L;
+  const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;  // 1/sqrt(DH)
+  const int q0 = qb * 64;
+  auto val = [&](size_t tok, int col) -> float { return P[tok * 3 * H + col] * ra[tok] * rw[col] + bias[col]; };
+  for (int i = threadIdx.x; i < 64 * DH; i += 256) {
+    const int r = i / DH, c = i % DH;
+    qs[r][c] = (q0 + r < L) ? val(row0 + q0 + r, hd * DH + c) : 0.f;
+  }
+  float m[RPW], l[RPW], o[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) { m[r] = -INFINITY; l[r] = 0.f; o[r] = 0.f; }
+  for (int k0 = 0; k0 < len; k0 += KT) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < KT * DH; i += 256) {
+      const int kr = i / DH, kc = i % DH;
+      const int kj = k0 + kr;
+      float kv = 0.f, vv = 0.f;
+      if (kj < len) {
+        kv = val(row0 + kj, H + hd * DH + kc);
+        vv = val(row0 + kj, 2 * H + hd * DH + kc);
+      }
+      ks[kr][kc] = kv;
+      vs[kr][kc] = vv;
+    }
+    __syncthreads();
+    const bool klive = k0 + lane < len;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int qr = 4 * r + wave;
+      if (q0 + qr >= L) continue;  // wave-uniform
+      float s = -INFINITY;
+      if (klive) {
+        float a = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qs[qr][d], ks[lane][d], a);
+        s = a * scale;
+      }
+      const float tmax = e32_wave_max(s);
+      const float mnew = fmaxf(m[r], tmax);
+      const float p = (s == -INFINITY) ? 0.f : expf(s - mnew);
+      const float corr = (m[r] == -INFINITY) ? 0.f : expf(m[r] - mnew);
+      l[r] = l[r] * corr + e32_wave_sum(p);
+      float acc = o[r] * corr;
+      for (int j = 0; j < KT; ++j) acc = __builtin_fmaf(__shfl(p, j, 64), vs[j][lane & (DH - 1)], acc);
+      o[r] = acc;
+      m[r] = mnew;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int qi = q0 + 4 * r + wave;
+    if (qi < L && lane < DH) ctx[(row0 + qi) * H + hd * DH + lane] = l[r] > 0.f ? o[r] / l[r] : 0.f;
+  }
+}
+
+// pooling over fp32 hidden states: CLS row or the mean of the real tokens; optional canonical L2 normalisation
+__global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restrict__ hidden, const int32_t* __restrict__ lens,
+                                                            int L, int H, int mean, int normalize, float* __restrict__ out) {
+  __shared__ float s_vec[1024];
+  __shared__ float s_nr;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* x = hidden + (size_t)b * L * H;
+  if (mean) {
+    const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
+    for (int c = tid; c < H; c += 256) {
+      float acc = 0.f;
+      for (int t = 0; t < len; ++t) acc += x[(size_t)t * H + c];
+      s_vec[c] = acc / (float)len;
+    }
+  } else {
+    for (int c = tid; c < H; c += 256) s_vec[c] = x[c];
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float acc = 0.f;
+    if (tid < 8)
+      for (int m2 = tid; m2 < H; m2 += 8) acc = __builtin_fmaf(s_vec[m2], s_vec[m2], acc);
+    float a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = __shfl(acc, i, 64);
+    if (tid == 0) s_nr = rarc_canon_tree(a);
+  }
+  __syncthreads();
+  const float nr = s_nr;
+  const float inv = (normalize && nr > 0.f) ? (float)(1.0 / (double)(float)sqrt((double)nr)) : 1.f;
+  for (int c = tid; c < H; c += 256) out[(size_t)b * H + c] = s_vec[c] * inv;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+static int e32_epi(const float* P, const float* ra, const float* rw, const float* bias, const float* resid, const float* gamma,
+                   const float* beta, float eps, int m, int n, float* out32, uint16_t* out3, float* ra_out, hipStream_t s) {
+  RARC_REQUIRE(n % 4 == 0 && n <= 4096, RARC_E_UNSUPPORTED, "fp32-class encoder: row length %d (need a multiple of 4, <= 4096)", n);
+  if (n <= 1024)
+    hipLaunchKernelGGL((rarc_e32_epi_kernel<1, MODE>), dim3(m), dim3(256), 0, s, P, ra, rw, bias, resid, gamma, beta, eps, n,
+                       out32, (half_t*)out3, ra_out);
+  else
+    hipLaunchKernelGGL((rarc_e32_epi_kernel<4, MODE>), dim3(m), dim3(256), 0, s, P, ra, rw, bias, resid, gamma, beta, eps, n,
+                       out32, (half_t*)out3, ra_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_enc32_split_weight(const float* d_w, int n, int k, uint16_t* d_w3, float* d_rw, void* stream) {
+  RARC_REQUIRE(d_w && d_w3 && d_rw && n > 0 && k > 0, RARC_E_INVALID, "rarc_enc32_split_weight: bad arguments");
+  hipLaunchKernelGGL(rarc_e32_split_weight_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, d_w, k, (half_t*)d_w3, d_rw);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+extern "C" int rarc_enc32_split_rows(const float* d_x, int m, int k, uint16_t* d_a3, float* d_ra, void* stream) {
+  RARC_REQUIRE(d_x && d_a3 && d_ra && m > 0 && k > 0, RARC_E_INVALID, "rarc_enc32_split_rows: bad arguments");
+  return e32_epi<3>(d_x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, m, k, nullptr, d_a3, d_ra, (hipStream_t)stream);
+}
+
+extern "C" int rarc_enc32_gemm(const uint16_t* d_a3, const float* d_ra, const uint16_t* d_w3, const float* d_rw,
+                               const float* d_bias, float* d_c, int m, int n, int k, void* stream) {
+  RARC_REQUIRE(d_a3 && d_ra && d_w3 && d_rw && d_bias && d_c, RARC_E_INVALID, "rarc_enc32_gemm: null pointer");
+  RARC_REQUIRE(m > 0 && n > 0 && k > 0 && m % 128 == 0 && n % 128 == 0 && k % 64 == 0, RARC_E_UNSUPPORTED,
+               "rarc_enc32_gemm: need M, N multiples of 128 and K a multiple of 64 (got %d, %d, %d)", m, n, k);
+  if (int rc = rarc_gemm_f16_f32out(d_a3, d_w3, d_c, m, n, 3 * k, (hipStream_t)stream)) return rc;
+  return e32_epi<0>(d_c, d_ra, d_rw, d_bias, nullptr, nullptr, nullptr, 0.f, m, n, d_c, nullptr, nullptr, (hipStream_t)stream);
+}
+
+static inline size_t e32_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" size_t rarc_enc32_workspace_bytes(int hidden, int inter, int n_tokens) {
+  if (hidden <= 0 || inter <= 0 || n_tokens <= 0) return 0;
+  const size_t M = (size_t)n_tokens, H = (size_t)hidden, I = (size_t)inter;
+  const size_t wide = 3 * H > I ? 3 * H : I;
+  return 2 * e32_align(M * H * 4)      // x (residual stream), ctx
+         + e32_align(M * 3 * H * 2)    // split image of x / ctx
+         + e32_align(M * 3 * I * 2)    // split image of the GELU output
+         + e32_align(M * wide * 4)     // raw GEMM products
+         + 2 * e32_align(M * 4);       // row scales
+}
+
+extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
+                                  int seq_len, int normalize, void* d_ws, size_t ws_bytes, float* d_out, void* stream) {
+  RARC_RANGE();
+  RARC_REQUIRE(model && model->layers && d_ids && d_lens && d_ws && d_out, RARC_E_INVALID, "rarc_enc32_forward: null pointer");
+  const int H = model->hidden, I = model->inter;
+  RARC_REQUIRE(n_seq > 0 && seq_len > 0 && model->n_layers > 0, RARC_E_INVALID, "rarc_enc32_forward: empty batch or model");
+  RARC_REQUIRE(model->vocab > 0 && model->max_pos >= seq_len, RARC_E_INVALID,
+               "rarc_enc32_forward: model->vocab (%d) must be set and model->max_pos (%d) must cover seq_len (%d)",
+               model->vocab, model->max_pos, seq_len);
+  RARC_REQUIRE(H % 128 == 0 && H <= 1024 && I % 128 == 0 && I <= 4096 && model->heads > 0 &&
+                   (H == model->heads * 64 || H == model->heads * 32) && seq_len <= 512,
+               RARC_E_UNSUPPORTED, "rarc_enc32_forward: hidden %d / inter %d / heads %d / seq_len %d not supported", H, I,
+               model->heads, seq_len);
+  const long long m_ll = (long long)n_seq * seq_len;
+  RARC_REQUIRE(m_ll % 128 == 0 && m_ll < (1ll << 31), RARC_E_UNSUPPORTED,
+               "rarc_enc32_forward: n_seq*seq_len must be a multiple of 128 (got %lld)", m_ll);
+  const int M = (int)m_ll;
+  RARC_REQUIRE(ws_bytes >= rarc_enc32_workspace_bytes(H, I, M), RARC_E_INVALID, "rarc_enc32_forward: workspace too small");
+  hipStream_t hs = (hipStream_t)stream;
+  char* w = (char*)d_ws;
+  const size_t wide = (size_t)(3 * H > I ? 3 * H : I);
+  float* x = (float*)w;                 w += e32_align((size_t)M * H * 4);
+  float* ctx = (float*)w;               w += e32_align((size_t)M * H * 4);
+  uint16_t* xs = (uint16_t*)w;          w += e32_align((size_t)M * 3 * H * 2);
+  uint16_t* mids = (uint16_t*)w;        w += e32_align((size_t)M * 3 * I * 2);
+  float* P = (float*)w;                 w += e32_align((size_t)M * wide * 4);
+  float* ra_a = (float*)w;              w += e32_align((size_t)M * 4);
+  float* ra_b = (float*)w;
+  const float eps = model->ln_eps;
+
+  hipLaunchKernelGGL(rarc_e32_embed_kernel, dim3(M), dim3(256), 0, hs, d_ids, model->word, model->pos, model->type0,
+                     model->emb_g, model->emb_b, eps, seq_len, H, model->vocab, x, (half_t*)xs, ra_a);
+  RARC_HIP_CHECK(hipGetLastError());
+  const int q_blocks = (seq_len + 63) / 64;
+  int rc = RARC_OK;
+  for (int l = 0; l < model->n_layers; ++l) {
+    const RarcEnc32Layer& Ly = model->layers[l];
+    // fused q|k|v projection; its scales and bias are applied by the attention kernel's loads
+    if ((rc = rarc_gemm_f16_f32out(xs, Ly.qkv_w3, P, M, 3 * H, 3 * H, hs)) != RARC_OK) return rc;
+    if (H == model->heads * 64)
+      hipLaunchKernelGGL(rarc_e32_attention_kernel<64>, dim3(n_seq * model->heads * q_blocks), dim3(256), 0, hs, P, ra_a,
+                         Ly.qkv_rw, Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, ctx);
+    else
+      hipLaunchKernelGGL(rarc_e32_attention_kernel<32>, dim3(n_seq * model->heads * q_blocks), dim3(256), 0, hs, P, ra_a,
+                         Ly.qkv_rw, Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, ctx);
+    RARC_HIP_CHECK(hipGetLastError());
+    if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs))) return rc;
+    // attention output projection -> x = LayerNorm(proj + x)
+    if ((rc = rarc_gemm_f16_f32out(xs, Ly.o_w3, P, M, H, 3 * H, hs)) != RARC_OK) return rc;
+    if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs))) return rc;
+    // FFN
+    if ((rc = rarc_gemm_f16_f32out(xs, Ly.f1_w3, P, M, I, 3 * H, hs)) != RARC_OK) return rc;
+    if ((rc = e32_epi<1>(P, ra_a, Ly.f1_rw, Ly.f1_b, nullptr, nullptr, nullptr, 0.f, M, I, nullptr, mids, ra_b, hs))) return rc;
+    if ((rc = rarc_gemm_f16_f32out(mids, Ly.f2_w3, P, M, H, 3 * I, hs)) != RARC_OK) return rc;
+    if ((rc = e32_epi<2>(P, ra_b, Ly.f2_rw, Ly.f2_b, x, Ly.ln2_g, Ly.ln2_b, eps, M, H, x, xs, ra_a, hs))) return rc;
+  }
+  hipLaunchKernelGGL(rarc_e32_pool_kernel, dim3(n_seq), dim3(256), 0, hs, x, d_lens, seq_len, H, (normalize & 2) ? 1 : 0,
+                     normalize & 1, d_out);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}

@@ -34,10 +34,17 @@ def load_state_dict(path: str) -> Dict[str, "np.ndarray"]:
 
 
 class HipBertEncoder:
-    """token ids [n_seq][seq_len] (+ lengths) -> fp32 embeddings [n_seq][hidden] on the device."""
+    """token ids [n_seq][seq_len] (+ lengths) -> fp32 embeddings [n_seq][hidden] on the device.
+
+    precision = "fp32" (default): the reference's arithmetic class — `SentenceTransformer(...)` at
+    huggingface.py:96-98 loads fp32 weights and `.encode` runs an fp32 forward.  Weights are kept as split fp16
+    pairs (22 bits) + fp32 everything else, the GEMMs run as split-operand fp16 MFMA with fp32 accumulation
+    (csrc/encoder_f32.hip); embeddings agree with an fp32 forward to fp32 rounding noise.
+    precision = "fp16": the fast forward of csrc/encoder.hip (fp16 weights / activations, fp32 accumulation),
+    a 1e-3-class approximation — for callers who would pass `model_kwargs={"torch_dtype": float16}`."""
 
     def __init__(self, state_dict: Dict[str, "np.ndarray"], num_heads: int, layer_norm_eps: float = 1e-12,
-                 device: int = 0, pooling: str = "cls"):
+                 device: int = 0, pooling: str = "cls", precision: str = "fp32"):
         import torch
 
         if not torch.cuda.is_available():
@@ -47,19 +54,24 @@ class HipBertEncoder:
         self.eps = float(layer_norm_eps)
         if pooling not in ("cls", "mean"):
             raise ValueError("pooling must be 'cls' (bge) or 'mean' (all-MiniLM / gte style)")
+        if precision not in ("fp32", "fp16"):
+            raise ValueError("precision must be 'fp32' (the reference's) or 'fp16'")
+        self.precision = precision
         self._pool_bit = 2 if pooling == "mean" else 0
         sd = {k.replace("bert.", "", 1) if k.startswith("bert.") else k: v for k, v in state_dict.items()}
 
-        def f16(name):
+        def f32(name):
             v = sd[name]
             if isinstance(v, torch.Tensor):          # already a tensor (any device): no numpy round trip
-                return v.detach().to(self.device, torch.float32).half().contiguous()
-            return torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.device).half().contiguous()
+                return v.detach().to(self.device, torch.float32).contiguous()
+            return torch.as_tensor(np.asarray(v), dtype=torch.float32).to(self.device).contiguous()
 
-        self.word = f16("embeddings.word_embeddings.weight")
-        self.pos = f16("embeddings.position_embeddings.weight")
-        self.type0 = f16("embeddings.token_type_embeddings.weight")[0].contiguous()
-        self.emb_g, self.emb_b = f16("embeddings.LayerNorm.weight"), f16("embeddings.LayerNorm.bias")
+        f16 = lambda name: f32(name).half().contiguous()
+        ld = f32 if precision == "fp32" else f16
+        self.word = ld("embeddings.word_embeddings.weight")
+        self.pos = ld("embeddings.position_embeddings.weight")
+        self.type0 = ld("embeddings.token_type_embeddings.weight")[0].contiguous()
+        self.emb_g, self.emb_b = ld("embeddings.LayerNorm.weight"), ld("embeddings.LayerNorm.bias")
         self.hidden = int(self.word.shape[1])
         self.heads = int(num_heads)
         if self.hidden % 128 or self.hidden // self.heads not in (32, 64) or self.hidden > 1024:
@@ -68,30 +80,48 @@ class HipBertEncoder:
         i = 0
         while f"encoder.layer.{i}.attention.self.query.weight" in sd:
             p = f"encoder.layer.{i}."
-            qkv_w = torch.cat([f16(p + f"attention.self.{n}.weight") for n in ("query", "key", "value")]).contiguous()
-            qkv_b = torch.cat([f16(p + f"attention.self.{n}.bias") for n in ("query", "key", "value")]).contiguous()
-            self.layers.append(dict(
-                qkv_w=qkv_w, qkv_b=qkv_b,
-                o_w=f16(p + "attention.output.dense.weight"), o_b=f16(p + "attention.output.dense.bias"),
-                ln1_g=f16(p + "attention.output.LayerNorm.weight"), ln1_b=f16(p + "attention.output.LayerNorm.bias"),
-                f1_w=f16(p + "intermediate.dense.weight"), f1_b=f16(p + "intermediate.dense.bias"),
-                f2_w=f16(p + "output.dense.weight"), f2_b=f16(p + "output.dense.bias"),
-                ln2_g=f16(p + "output.LayerNorm.weight"), ln2_b=f16(p + "output.LayerNorm.bias")))
+            cat = lambda kind: torch.cat([ld(p + f"attention.self.{n}.{kind}") for n in ("query", "key", "value")]).contiguous()
+            lay = dict(
+                qkv_w=cat("weight"), qkv_b=cat("bias"),
+                o_w=ld(p + "attention.output.dense.weight"), o_b=ld(p + "attention.output.dense.bias"),
+                ln1_g=ld(p + "attention.output.LayerNorm.weight"), ln1_b=ld(p + "attention.output.LayerNorm.bias"),
+                f1_w=ld(p + "intermediate.dense.weight"), f1_b=ld(p + "intermediate.dense.bias"),
+                f2_w=ld(p + "output.dense.weight"), f2_b=ld(p + "output.dense.bias"),
+                ln2_g=ld(p + "output.LayerNorm.weight"), ln2_b=ld(p + "output.LayerNorm.bias"))
+            if precision == "fp32":
+                for nm in ("qkv", "o", "f1", "f2"):     # fp32 [n][k] -> split image fp16 [n][3k] + inverse row scales
+                    lay[nm + "_w3"], lay[nm + "_rw"] = self._split_weight(lay.pop(nm + "_w"))
+            self.layers.append(lay)
             i += 1
         if not self.layers:
             raise B.RarcError("state dict holds no encoder.layer.* tensors")
-        self.inter = int(self.layers[0]["f1_w"].shape[0])
-        if self.inter % 128:
-            raise B.RarcError("intermediate size must be a multiple of 128")
+        w1 = self.layers[0]["f1_w3" if precision == "fp32" else "f1_w"]
+        self.inter = int(w1.shape[0])
+        if self.inter % 128 or (precision == "fp32" and self.inter > 4096):
+            raise B.RarcError("intermediate size must be a multiple of 128 (fp32 mode: at most 4096)")
         self.max_pos = int(self.pos.shape[0])
         self.vocab = int(self.word.shape[0])
         # host-side table of device pointers handed to rarc_enc_forward (tensors above keep the memory alive)
-        self._layer_tab = (B.EncLayer * len(self.layers))(*[
-            B.EncLayer(**{k: v.data_ptr() for k, v in w.items()}) for w in self.layers])
-        self._model = B.EncModel(self.hidden, self.heads, self.inter, len(self.layers), self.eps, self.word.data_ptr(),
-                                 self.pos.data_ptr(), self.type0.data_ptr(), self.emb_g.data_ptr(),
-                                 self.emb_b.data_ptr(), self._layer_tab, self.vocab, self.max_pos)
+        LayerT, ModelT = (B.Enc32Layer, B.Enc32Model) if precision == "fp32" else (B.EncLayer, B.EncModel)
+        self._layer_tab = (LayerT * len(self.layers))(*[
+            LayerT(**{k: v.data_ptr() for k, v in w.items()}) for w in self.layers])
+        self._model = ModelT(self.hidden, self.heads, self.inter, len(self.layers), self.eps, self.word.data_ptr(),
+                             self.pos.data_ptr(), self.type0.data_ptr(), self.emb_g.data_ptr(),
+                             self.emb_b.data_ptr(), self._layer_tab, self.vocab, self.max_pos)
+        self._fwd = self.lib.rarc_enc32_forward if precision == "fp32" else self.lib.rarc_enc_forward
+        self._ws_bytes = self.lib.rarc_enc32_workspace_bytes if precision == "fp32" else self.lib.rarc_enc_workspace_bytes
         self._ws = None
+
+    def _split_weight(self, w32):
+        t = self.torch
+        n, k = int(w32.shape[0]), int(w32.shape[1])
+        with t.cuda.device(self.device):
+            w3 = t.empty((n, 3 * k), dtype=t.float16, device=self.device)
+            rw = t.empty(n, dtype=t.float32, device=self.device)
+            B.check(self.lib.rarc_enc32_split_weight(w32.data_ptr(), n, k, w3.data_ptr(), rw.data_ptr(),
+                                                     t.cuda.current_stream(self.device).cuda_stream), "rarc_enc32_split_weight")
+            t.cuda.current_stream(self.device).synchronize()     # w32 is released when this returns
+        return w3, rw
 
     def forward(self, input_ids, lengths=None, normalize: bool = True):
         t = self.torch
@@ -126,12 +156,12 @@ class HipBertEncoder:
             st = t.cuda.current_stream(self.device).cuda_stream
             d_ids = t.from_numpy(np.ascontiguousarray(ids)).to(self.device)
             d_lens = t.from_numpy(np.ascontiguousarray(lens)).to(self.device)
-            need = int(self.lib.rarc_enc_workspace_bytes(H, I, M))
+            need = int(self._ws_bytes(H, I, M))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = t.empty(need, dtype=t.uint8, device=self.device)
             out = t.empty((n_pad, H), dtype=t.float32, device=self.device)
             # one foreign call per forward: the layer loop runs inside librarc_hip.so
-            B.check(self.lib.rarc_enc_forward(ctypes.addressof(self._model), d_ids.data_ptr(), d_lens.data_ptr(), n_pad, L,
+            B.check(self._fwd(ctypes.addressof(self._model), d_ids.data_ptr(), d_lens.data_ptr(), n_pad, L,
                                               (1 if normalize else 0) | self._pool_bit, self._ws.data_ptr(), self._ws.numel(),
                                               out.data_ptr(), st), "rarc_enc_forward")
             return out[:n_seq]
@@ -150,11 +180,11 @@ class HipBertEncoder:
             raise ValueError("n_seq * seq_len must be a positive multiple of 128 and seq_len within the position table")
         with t.cuda.device(self.device):
             st = t.cuda.current_stream(self.device).cuda_stream
-            need = int(self.lib.rarc_enc_workspace_bytes(self.hidden, self.inter, M))
+            need = int(self._ws_bytes(self.hidden, self.inter, M))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = t.empty(need, dtype=t.uint8, device=self.device)
             out = t.empty((n_seq, self.hidden), dtype=t.float32, device=self.device)
-            B.check(self.lib.rarc_enc_forward(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
+            B.check(self._fwd(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
                                               d_lens.contiguous().data_ptr(), n_seq, L, (1 if normalize else 0) | self._pool_bit,
                                               self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), st),
                     "rarc_enc_forward")

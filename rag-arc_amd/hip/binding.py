@@ -38,6 +38,19 @@ class EncModel(ctypes.Structure):
                 ("layers", ctypes.POINTER(EncLayer)), ("vocab", c_int), ("max_pos", c_int)]
 
 
+class Enc32Layer(ctypes.Structure):
+    """RarcEnc32Layer (include/rarc.h): split fp16 weight images + fp32 scales / biases / LayerNorm of one layer."""
+    _fields_ = [(n, c_void_p) for n in ("qkv_w3", "qkv_rw", "qkv_b", "o_w3", "o_rw", "o_b", "ln1_g", "ln1_b", "f1_w3", "f1_rw",
+                                        "f1_b", "f2_w3", "f2_rw", "f2_b", "ln2_g", "ln2_b")]
+
+
+class Enc32Model(ctypes.Structure):
+    """RarcEnc32Model (include/rarc.h)."""
+    _fields_ = [("hidden", c_int), ("heads", c_int), ("inter", c_int), ("n_layers", c_int), ("ln_eps", c_float),
+                ("word", c_void_p), ("pos", c_void_p), ("type0", c_void_p), ("emb_g", c_void_p), ("emb_b", c_void_p),
+                ("layers", ctypes.POINTER(Enc32Layer)), ("vocab", c_int), ("max_pos", c_int)]
+
+
 class LmLayer(ctypes.Structure):
     """RarcLmLayer (include/rarc.h): device pointers of one decoder layer."""
     _fields_ = [(n, c_void_p) for n in ("in_norm", "qkv_w", "q_norm", "k_norm", "o_w", "post_norm", "gate_up_w", "down_w")]
@@ -117,6 +130,12 @@ SIGNATURES = {
     "rarc_enc_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "rarc_enc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                  c_void_p]),
+    "rarc_enc32_split_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_enc32_split_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_enc32_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rarc_enc32_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "rarc_enc32_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
+                                   c_void_p]),
     "rarc_lm_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "rarc_lm_yes_no_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                       c_void_p]),

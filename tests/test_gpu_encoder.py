@@ -15,7 +15,7 @@ def _check(oracle, H, layers, heads, I, n_seq, L, seed):
     from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 
     sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=800, max_pos=256, seed=seed)
-    enc = HipBertEncoder(sd, num_heads=heads)
+    enc = HipBertEncoder(sd, num_heads=heads, precision="fp16")
     rng = np.random.default_rng(seed)
     ids = rng.integers(1, 800, (n_seq, L)).astype(np.int32)
     lens = rng.integers(1, L + 1, n_seq).astype(np.int32)
@@ -60,7 +60,7 @@ def test_full_depth_encoder_and_induced_score_error(oracle, name, H, layers, hea
 
     n_seq, L = 16, 32
     sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=800, max_pos=64, seed=layers)
-    enc = HipBertEncoder(sd, num_heads=heads)
+    enc = HipBertEncoder(sd, num_heads=heads, precision="fp16")
     rng = np.random.default_rng(layers)
     ids = rng.integers(1, 800, (n_seq, L)).astype(np.int32)
     lens = rng.integers(4, L + 1, n_seq).astype(np.int32)
@@ -93,7 +93,7 @@ def test_token_ids_and_lengths_are_validated(oracle):
     from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 
     sd = oracle.random_bert_state_dict(128, 1, 2, 256, vocab=300, max_pos=64, seed=2)
-    enc = HipBertEncoder(sd, num_heads=2)
+    enc = HipBertEncoder(sd, num_heads=2, precision="fp16")
     ok = np.ones((2, 8), np.int32)
     for bad_ids, bad_lens in ((np.full((2, 8), 300, np.int32), None), (np.full((2, 8), -1, np.int32), None),
                               (ok, [0, 8]), (ok, [9, 1]), (ok, [1])):
@@ -111,7 +111,7 @@ def test_mean_pooling_matches_oracle(oracle):
     from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 
     sd = oracle.random_bert_state_dict(384, 2, 12, 1536, vocab=500, max_pos=64, seed=21)
-    enc = HipBertEncoder(sd, num_heads=12, pooling="mean")
+    enc = HipBertEncoder(sd, num_heads=12, pooling="mean", precision="fp16")
     rng = np.random.default_rng(21)
     ids = rng.integers(1, 500, (7, 24)).astype(np.int32)
     lens = np.array([24, 1, 5, 17, 24, 9, 2], np.int32)
@@ -201,7 +201,7 @@ def test_embeddings_provider_contract(oracle):
 
     sd = oracle.random_bert_state_dict(128, 1, 2, 256, vocab=300, max_pos=64, seed=2)
     tok = lambda text: [1 + (ord(c) % 250) for c in text][:40]
-    emb = HipBertEmbeddings(HipBertEncoder(sd, num_heads=2), tok, batch_size=4)
+    emb = HipBertEmbeddings(HipBertEncoder(sd, num_heads=2, precision="fp16"), tok, batch_size=4)
     texts = ["alpha", "a much longer piece of text\nwith a newline", "b", "gamma delta", "e"]
     vecs = emb.embed_documents(texts)
     assert len(vecs) == 5 and all(len(v) == 128 and isinstance(v[0], float) for v in vecs)
@@ -228,7 +228,7 @@ def test_store_ingests_device_embeddings_without_round_trip(oracle):
 
     sd = oracle.random_bert_state_dict(128, 1, 2, 256, vocab=300, max_pos=64, seed=4)
     tok = lambda text: [1 + (ord(c) * 7 + i) % 250 for i, c in enumerate(text)][:48]
-    emb = HipBertEmbeddings(HipBertEncoder(sd, num_heads=2), tok, batch_size=64)
+    emb = HipBertEmbeddings(HipBertEncoder(sd, num_heads=2, precision="fp16"), tok, batch_size=64)
     texts = [f"chunk {i} about topic {i % 17}" for i in range(500)]
     fast = HipFlatVectorStore.from_texts(texts, emb, ids=[str(i) for i in range(500)])
 

@@ -31,7 +31,7 @@ def test_random_encoder_geometry(oracle, seed):
     lens[0] = L
     for r, l in enumerate(lens):
         ids[r, l:] = 0
-    enc = HipBertEncoder(sd, num_heads=heads, pooling=pooling)
+    enc = HipBertEncoder(sd, num_heads=heads, pooling=pooling, precision="fp16")
     got = enc.forward(ids, lens, normalize=True).cpu().numpy()
     sd16 = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}      # the storage format's rounding
     want = oracle.bert_forward_f32(sd16, ids, lens, heads, normalize=True, pooling=pooling)
