@@ -13,7 +13,7 @@
 // lo is a normal fp16 number for every element within 2^-17 of the row maximum, and an element below that is
 // represented to 2^-39 of the maximum even if subnormal halves were flushed.
 // Everything between the GEMMs is fp32: residual stream, LayerNorm (two-pass statistics), exact erf GELU (libm erff),
-// softmax (libm expf), pooling and the canonical L2 normalisation.  Attention (QKᵀ, PV) is fp32 FMA.
+// softmax (libm expf), pooling and the canonical L2 normalisation.  Attention (QKᵀ, PV) runs on the fp32 MFMA (exact fp32).
 #include "rarc_common.h"
 
 int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s);  // encoder.hip
@@ -136,7 +136,7 @@ __device__ __forceinline__ float e32_gelu(float v) { return 0.5f * v * (1.0f + e
 //   2  v = LayerNorm(P·ra·rw + bias + resid)   -> out32 (may alias resid) and split image
 //   3  v = P (plain fp32 rows, no scales)      -> split image
 template <int NV, int MODE>
-__global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* __restrict__ P, const float* __restrict__ ra,
+__global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const float* __restrict__ ra,
                                                            const float* __restrict__ rw, const float* __restrict__ bias,
                                                            const float* resid, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int n,
@@ -225,76 +225,135 @@ __global__ __launch_bounds__(256) void rarc_e32_split_weight_kernel(const float*
 }
 
 // ------------------------------------------------------------------------------------------
-// Attention in fp32: P [M][3H] is the raw split product of the fused q|k|v projection; its scales and bias are applied
-// as the values are staged in LDS (no separate pass).  One workgroup per (sequence, head, block of 64 query rows);
-// wave w owns rows w, w+4, ...; keys/values stream through LDS in 64-key tiles; scores with lane <-> key, outputs with
-// lane <-> dimension; online softmax (libm expf); keys >= lens[seq] masked.
+// Attention in fp32 on the fp32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate — an fmaf chain).
+// P [M][3H] is the raw split product of the fused q|k|v projection; its scales and bias are applied as the values are
+// loaded (no separate pass): value = P·ra[token]·rw[column] + bias[column].
+// One wave per (sequence, head, block of 32 query rows); keys / values in tiles of 32; four waves per workgroup.
+//   S^T = K · Q^T    A = K rows, B = Q rows.  The instruction contracts two k indices per step, one per lane half:
+//                    half hh takes d = hh·DH/2 + s at step s, so a lane's operand stream is a CONTIGUOUS half row
+//                    (DH/2 floats: float4 loads).  Lane (l&31 = query, hh) ends with 16 of the tile's 32 keys:
+//                    key(r, hh) = 8(r>>2) + 4hh + (r&3); a query's softmax statistics live in the lane pair (l, l^32).
+//   O^T += V^T · P^T step s contracts keys key(s, 0) and key(s, 1): the B operand is the lane's own probability
+//                    register s (no cross-lane traffic), the A operand V[key(s, hh)][32mb + (l&31)] comes from the
+//                    wave's LDS copy of the V tile (row stride DH + 8 floats: the two halves hit disjoint banks).
+// Online softmax over key tiles with libm expf; keys >= lens[seq] masked; rows >= seq_len neither loaded past the
+// end nor stored.
 // ------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __restrict__ P, const float* __restrict__ ra,
                                                                  const float* __restrict__ rw, const float* __restrict__ bias,
                                                                  const int32_t* __restrict__ lens, int L, int H, int n_heads,
-                                                                 int q_blocks, float* __restrict__ ctx) {
-  constexpr int KT = 64, RPW = 16;
-  __shared__ float ks[KT][DH + 1];
-  __shared__ float vs[KT][DH + 1];
-  __shared__ float qs[64][DH + 1];
+                                                                 int q_blocks, int n_units, float* __restrict__ ctx) {
+  constexpr int HD = DH / 2;     // floats of a q / k row one lane half contracts
+  constexpr int MB = DH / 32;    // 32-row blocks of O^T
+  constexpr int VS = DH + 8;     // row stride of the V tile in LDS (floats)
+  __shared__ __attribute__((aligned(16))) float vs_all[4][32 * VS];
+  __shared__ __attribute__((aligned(16))) float sb_all[4][6 * DH];   // rw | bias of this head's q, k, v columns
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qb = blockIdx.x % q_blocks, bh = blockIdx.x / q_blocks;
+  const int unit = blockIdx.x * 4 + wave;
+  if (unit >= n_units) return;  // (no block-level barrier below: waves are independent)
+  float* vs = vs_all[wave];
+  float* sb = sb_all[wave];
+  const int qb = unit % q_blocks, bh = unit / q_blocks;
   const int b = bh / n_heads, hd = bh % n_heads;
   const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
-  const size_t row0 = (size_t)b * L;
+  const int col = lane & 31, hh = lane >> 5;
+  const size_t rs = (size_t)3 * H;
+  const size_t tok0 = (size_t)b * L;
   const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;  // 1/sqrt(DH)
-  const int q0 = qb * 64;
-  auto val = [&](size_t tok, int col) -> float { return P[tok * 3 * H + col] * ra[tok] * rw[col] + bias[col]; };
-  for (int i = threadIdx.x; i < 64 * DH; i += 256) {
-    const int r = i / DH, c = i % DH;
-    qs[r][c] = (q0 + r < L) ? val(row0 + q0 + r, hd * DH + c) : 0.f;
+  for (int i = lane; i < 3 * DH; i += 64) {
+    const int part = i / DH, c = i % DH;   // 0 q, 1 k, 2 v
+    sb[part * 2 * DH + c] = rw[part * H + hd * DH + c];
+    sb[part * 2 * DH + DH + c] = bias[part * H + hd * DH + c];
   }
-  float m[RPW], l[RPW], o[RPW];
+  __builtin_amdgcn_wave_barrier();
+  const int q0 = qb * 32;
+  const int qrow = (q0 + col < L) ? q0 + col : L - 1;
+  // a lane's half row of q or k: P·ra·rw + bias over d = hh*HD .. hh*HD + HD - 1
+  auto load_half = [&](size_t tok, int part, float (&dst)[HD]) {
+    const float r = ra[tok];
+    const float* src = P + tok * rs + part * H + hd * DH + hh * HD;
+    const float* w = sb + part * 2 * DH + hh * HD;
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) { m[r] = -INFINITY; l[r] = 0.f; o[r] = 0.f; }
-  for (int k0 = 0; k0 < len; k0 += KT) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < KT * DH; i += 256) {
-      const int kr = i / DH, kc = i % DH;
-      const int kj = k0 + kr;
-      float kv = 0.f, vv = 0.f;
-      if (kj < len) {
-        kv = val(row0 + kj, H + hd * DH + kc);
-        vv = val(row0 + kj, 2 * H + hd * DH + kc);
-      }
-      ks[kr][kc] = kv;
-      vs[kr][kc] = vv;
+    for (int c = 0; c < HD; c += 4) {
+      const float4 p = *(const float4*)(src + c), s4 = *(const float4*)(w + c), b4 = *(const float4*)(w + DH + c);
+      dst[c] = p.x * r * s4.x + b4.x; dst[c + 1] = p.y * r * s4.y + b4.y;
+      dst[c + 2] = p.z * r * s4.z + b4.z; dst[c + 3] = p.w * r * s4.w + b4.w;
     }
-    __syncthreads();
-    const bool klive = k0 + lane < len;
+  };
+  float qf[HD];
+  load_half(tok0 + qrow, 0, qf);
+
+  f32x16 o[MB];
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const int qr = 4 * r + wave;
-      if (q0 + qr >= L) continue;  // wave-uniform
-      float s = -INFINITY;
-      if (klive) {
-        float a = 0.f;
-#pragma unroll 16
-        for (int d = 0; d < DH; ++d) a = __builtin_fmaf(qs[qr][d], ks[lane][d], a);
-        s = a * scale;
-      }
-      const float tmax = e32_wave_max(s);
-      const float mnew = fmaxf(m[r], tmax);
-      const float p = (s == -INFINITY) ? 0.f : expf(s - mnew);
-      const float corr = (m[r] == -INFINITY) ? 0.f : expf(m[r] - mnew);
-      l[r] = l[r] * corr + e32_wave_sum(p);
-      float acc = o[r] * corr;
-      for (int j = 0; j < KT; ++j) acc = __builtin_fmaf(__shfl(p, j, 64), vs[j][lane & (DH - 1)], acc);
-      o[r] = acc;
-      m[r] = mnew;
+  for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    // ---- S^T tile: keys k0..k0+31 (rows) x this wave's 32 queries (columns) ----
+    const int krow = (k0 + col < L) ? k0 + col : L - 1;
+    float kf[HD];
+    load_half(tok0 + krow, 1, kf);
+    f32x16 st = {0};
+#pragma unroll
+    for (int s = 0; s < HD; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], st, 0, 0, 0);
+    // ---- V tile -> LDS [key][d] (scaled + biased), 16-byte pieces, coalesced rows ----
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = lane; i < 32 * (DH / 4); i += 64) {
+      const int kr = i / (DH / 4), c4 = i % (DH / 4);
+      const int vrow = (k0 + kr < L) ? k0 + kr : L - 1;
+      const float r = ra[tok0 + vrow];
+      const float4 p = *(const float4*)(P + (tok0 + vrow) * rs + 2 * H + hd * DH + 4 * c4);
+      const float4 s4 = *(const float4*)(sb + 4 * DH + 4 * c4), b4 = *(const float4*)(sb + 5 * DH + 4 * c4);
+      *(float4*)(vs + kr * VS + 4 * c4) =
+          make_float4(p.x * r * s4.x + b4.x, p.y * r * s4.y + b4.y, p.z * r * s4.z + b4.z, p.w * r * s4.w + b4.w);
+    }
+    // ---- softmax statistics of this lane's query over its 16 keys, then with the partner lane ----
+    float pr[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+      pr[r] = key < len ? st[r] * scale : -INFINITY;
+      tmax = fmaxf(tmax, pr[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      pr[r] = (pr[r] == -INFINITY) ? 0.f : expf(pr[r] - m_new);
+      psum += pr[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+    __builtin_amdgcn_wave_barrier();
+    // ---- O^T += V^T · P^T: step s contracts keys key(s, 0), key(s, 1) ----
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int key = 8 * (s >> 2) + 4 * hh + (s & 3);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+        o[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key * VS + 32 * mb + col], pr[s], o[mb], 0, 0, 0);
     }
   }
+  // ---- store: lane (query, hh) holds d = 32mb + 8(r>>2) + 4hh + (r&3) ----
+  if (q0 + col < L) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* out = ctx + (tok0 + q0 + col) * H + hd * DH;
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const int qi = q0 + 4 * r + wave;
-    if (qi < L && lane < DH) ctx[(row0 + qi) * H + hd * DH + lane] = l[r] > 0.f ? o[r] / l[r] : 0.f;
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(out + 32 * mb + 8 * g + 4 * hh) =
+            make_float4(o[mb][4 * g] * inv, o[mb][4 * g + 1] * inv, o[mb][4 * g + 2] * inv, o[mb][4 * g + 3] * inv);
   }
 }
 
@@ -415,18 +474,19 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   hipLaunchKernelGGL(rarc_e32_embed_kernel, dim3(M), dim3(256), 0, hs, d_ids, model->word, model->pos, model->type0,
                      model->emb_g, model->emb_b, eps, seq_len, H, model->vocab, x, (half_t*)xs, ra_a);
   RARC_HIP_CHECK(hipGetLastError());
-  const int q_blocks = (seq_len + 63) / 64;
+  const int q_blocks = (seq_len + 31) / 32;
+  const int n_units = n_seq * model->heads * q_blocks;  // one wave each, four per workgroup
   int rc = RARC_OK;
   for (int l = 0; l < model->n_layers; ++l) {
     const RarcEnc32Layer& Ly = model->layers[l];
     // fused q|k|v projection; its scales and bias are applied by the attention kernel's loads
     if ((rc = rarc_gemm_f16_f32out(xs, Ly.qkv_w3, P, M, 3 * H, 3 * H, hs)) != RARC_OK) return rc;
     if (H == model->heads * 64)
-      hipLaunchKernelGGL(rarc_e32_attention_kernel<64>, dim3(n_seq * model->heads * q_blocks), dim3(256), 0, hs, P, ra_a,
-                         Ly.qkv_rw, Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, ctx);
+      hipLaunchKernelGGL(rarc_e32_attention_kernel<64>, dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw,
+                         Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx);
     else
-      hipLaunchKernelGGL(rarc_e32_attention_kernel<32>, dim3(n_seq * model->heads * q_blocks), dim3(256), 0, hs, P, ra_a,
-                         Ly.qkv_rw, Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, ctx);
+      hipLaunchKernelGGL(rarc_e32_attention_kernel<32>, dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw,
+                         Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx);
     RARC_HIP_CHECK(hipGetLastError());
     if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs))) return rc;
     // attention output projection -> x = LayerNorm(proj + x)

@@ -15,7 +15,7 @@ for i in range(LAYERS):
         sd[p + nm + ".weight"], sd[p + nm + ".bias"] = rnd(o, c), rnd(o)
     for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
         sd[p + nm + ".weight"], sd[p + nm + ".bias"] = 1.0 + rnd(H), rnd(H)
-enc = HipBertEncoder(sd, num_heads=HEADS)
+enc = HipBertEncoder(sd, num_heads=HEADS, precision=os.environ.get("RARC_ENC_PRECISION", "fp16"))
 tok = torch.randint(1, VOCAB, (NQ, L), generator=g, device=dev).int()
 lens = torch.full((NQ,), L, dtype=torch.int32, device=dev)
 for _ in range(6):

@@ -9,7 +9,7 @@ import numpy as np, torch
 from oracle import cpu_ref
 from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 sd = cpu_ref.random_bert_state_dict(1024, 24, 16, 4096, vocab=2000, max_pos=512, seed=1)
-enc = HipBertEncoder(sd, num_heads=16)
+enc = HipBertEncoder(sd, num_heads=16, precision="fp16")
 ids = np.random.default_rng(0).integers(1, 2000, (256, 32)).astype(np.int32)
 for _ in range(6): enc.forward(ids)
 torch.cuda.synchronize()
