@@ -59,6 +59,13 @@ def parse(argv=None):
     ap.add_argument("--lm-queries", type=int, default=8, help="queries whose top-k are reranked by the LM forward (c3.reranker_lm)")
     ap.add_argument("--c5-rows", type=int, default=0, help="rows of the config-5 corpus (0 = auto: 100M if it fits)")
     ap.add_argument("--c5-layers", type=int, default=24, help="encoder depth of the config-5 leg (bge-large: 24)")
+    ap.add_argument("--encoder-precision", choices=("fp32", "fp16"), default="fp32",
+                    help="config-5 encoder arithmetic: fp32 = the reference's (SentenceTransformer default; split-operand MFMA "
+                         "GEMMs, ids equal to an fp32 forward's), fp16 = the 1e-3-class fast forward")
+    ap.add_argument("--encoder-overlap", action="store_true",
+                    help="config 5: embed batch i+1 on a side stream under the scan of batch i (measured: no gain on one GPU — "
+                         "the persistent scan kernel holds every CU's whole register file, so the forward's kernels wait for it)")
+    ap.add_argument("--no-c5-alt", action="store_true", help="config 5: skip the second timed loop in the other encoder precision")
     ap.add_argument("--verify-queries", type=int, default=256,
                     help="queries whose answer is re-checked by an exact canonical re-scan of the whole shard (eight queries "
                          "per pass over the rows: the default checks the whole batch, ~2 s at 100M rows)")
@@ -599,7 +606,9 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
             sd[p + nm + ".weight"], sd[p + nm + ".bias"] = rnd(o, c), rnd(o)
         for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
             sd[p + nm + ".weight"], sd[p + nm + ".bias"] = 1.0 + rnd(H), rnd(H)
-    enc = HipBertEncoder(sd, num_heads=HEADS, device=local_rank)
+    enc = HipBertEncoder(sd, num_heads=HEADS, device=local_rank, precision=a.encoder_precision)
+    other = "fp16" if a.encoder_precision == "fp32" else "fp32"
+    enc_other = HipBertEncoder(sd, num_heads=HEADS, device=local_rank, precision=other)   # timed alone, beside the leg
     sd_host = None
     if rank == 0 and not a.no_cpu_baseline and world == 1:
         sd_host = {k: v.cpu().numpy() for k, v in sd.items()}
@@ -624,23 +633,49 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
     split = use_dist and nq % world == 0
     if not split:
         q_lo, q_hi = 0, nq
-    full = torch.empty((nq, H), dtype=torch.float32, device=dev)
-    enc_ev = []
+    # The encoder of batch i+1 runs on a SIDE stream under the scan of batch i (the scan leaves the matrix pipe about half
+    # idle and the encoder barely touches HBM); the scan's stream waits on the event that closes the forward.  Two result
+    # buffers alternate: a search copies its queries into the index's query block first thing, so a buffer is free again
+    # long before its next use with at most two batches in flight.
+    overlap = a.encoder_overlap
+    main_stream = torch.cuda.current_stream(dev)
+    enc_stream = torch.cuda.Stream(device=dev) if overlap else main_stream
+    mine_buf = [torch.empty((q_hi - q_lo, H), dtype=torch.float32, device=dev) for _ in range(2)]
+    full_buf = [torch.empty((nq, H), dtype=torch.float32, device=dev) for _ in range(2)]
+    enc_ev, n_emb, active = [], [0], [a.encoder_precision]
 
     def embed():
+        slot = n_emb[0] & 1
+        n_emb[0] += 1
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        mine = enc.forward_device(tok[q_lo:q_hi], lens[q_lo:q_hi], normalize=True)   # token ids already in HBM
-        if split:
-            dist.all_gather_into_tensor(full, mine.contiguous())
-            out = full
-        else:
-            out = mine
-        e1.record()
+        with torch.cuda.stream(enc_stream):
+            e0.record()
+            mine = encoders[active[0]].forward_device(tok[q_lo:q_hi], lens[q_lo:q_hi], normalize=True, out=mine_buf[slot])   # token ids already in HBM
+            if split:
+                dist.all_gather_into_tensor(full_buf[slot], mine)
+                out = full_buf[slot]
+            else:
+                out = mine
+            e1.record()
+        if overlap:
+            main_stream.wait_event(e1)
         enc_ev.append((e0, e1))
         return out
 
-    emb0 = embed()
+    def time_alone(e, reps=5):   # forward of this rank's share, nothing else on the GPU
+        for _ in range(2):
+            e.forward_device(tok[q_lo:q_hi], lens[q_lo:q_hi], normalize=True, out=mine_buf[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e.forward_device(tok[q_lo:q_hi], lens[q_lo:q_hi], normalize=True, out=mine_buf[0])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    enc_alone_ms, enc_other_ms = time_alone(enc), time_alone(enc_other)
+    encoders = {a.encoder_precision: enc, other: enc_other}
+
+    emb0 = embed().clone()
     ids0, _ = searcher.search_device(emb0, K)
     lex = lexical_lists(torch, ids0, rows, K)
     lens2 = torch.full((nq, 2), K, dtype=torch.int32, device=dev)
@@ -662,6 +697,18 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
     torch.cuda.synchronize()
     enc_ms = sum(x.elapsed_time(y) for x, y in enc_ev) / max(1, len(enc_ev))
     scan_ms = tot / max(1, steps)
+    alt = None
+    if not a.no_c5_alt:   # the same loop with the other encoder arithmetic, for the record (not the leg's value)
+        active[0] = other
+        timed_loop(torch, dist, begin, end, 0, 2, use_dist)
+        enc_ev.clear()
+        dt_alt, _ = timed_loop(torch, dist, begin, end, steps, 0, use_dist)
+        torch.cuda.synchronize()
+        alt = {"encoder_precision": other, "value": round(nq * steps / dt_alt, 1), "unit": "queries/s",
+               "ms_per_step": round(dt_alt / steps * 1e3, 4),
+               "encoder_ms": round(sum(x.elapsed_time(y) for x, y in enc_ev) / max(1, len(enc_ev)), 4),
+               "note": "same loop, other encoder arithmetic" + ("; ids are NOT the fp32 reference's (1e-3-class embeddings)" if other == "fp16" else "")}
+        active[0] = a.encoder_precision
     # full-size property of the fp8 shard: exact re-scan of a few queries
     l_ids, l_sc = idx.search_device(emb0, K)
     vq = list(range(min(nq, max(0, a.verify_queries))))
@@ -669,11 +716,18 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
     if rank != 0:
         return None
     n_tok = (q_hi - q_lo) * L
-    flops = LAYERS * n_tok * (2.0 * (3 * H * H + H * H + 2 * H * FFN) + 4.0 * L * H)
+    gemm_flops = LAYERS * n_tok * 2.0 * (3 * H * H + H * H + 2 * H * FFN)
+    flops = gemm_flops + LAYERS * n_tok * 4.0 * L * H
+    mfma_flops = flops + (2.0 * gemm_flops if a.encoder_precision == "fp32" else 0.0)
     scan_bytes = (hi - lo) * (H + 4)
+    prec_txt = ("fp32-class forward (the reference's precision: split-operand fp16 MFMA GEMMs, fp32 elsewhere)"
+                if a.encoder_precision == "fp32" else "fp16 forward (1e-3 class)")
     out = {"workload": f"config 5 end to end: {nq} queries x {L} tokens -> bge-large geometry encoder ({LAYERS} layers, seeded "
-                       f"fp16 weights) -> {rows}x{H} fp8 (e4m3fn + row scale) corpus over {world} GPU(s), top-{K} -> RRF "
+                       f"weights, {prec_txt}) -> {rows}x{H} fp8 (e4m3fn + row scale) corpus over {world} GPU(s), top-{K} -> RRF "
                        f"with a supplied lexical list",
+           "encoder_precision": a.encoder_precision,
+           "encoder_overlap": "side stream under the previous batch's scan" if overlap else "none (same stream)",
+           "encoder_alone_ms": round(enc_alone_ms, 4), f"encoder_alone_ms_{other}": round(enc_other_ms, 4),
            "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
            "n_gpus": world, "rows_per_gpu": hi - lo, "queries_embedded_per_gpu": q_hi - q_lo,
            "encoder_ms": round(enc_ms, 4), "scan_ms": round(scan_ms, 4), "exchange_ms_per_step": round(exch, 4),
@@ -684,13 +738,19 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
                         "frac": round(scan_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "algorithmic_bytes_per_scan": int(scan_bytes),
                         "int8_TOPs": round(2.0 * nq * (hi - lo) * H / (scan_ms * 1e-3) / 1e12, 1)},
-           "encoder_roofline": {"bound": "mfma", "achieved": round(flops / (enc_ms * 1e-3) / 1e12, 1),
+           "encoder_roofline": {"bound": "mfma", "achieved": round(mfma_flops / (enc_alone_ms * 1e-3) / 1e12, 1),
                                 "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                                "frac": round(flops / (enc_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),
-                                "flops_per_forward": flops, "tokens_per_forward": n_tok,
+                                "frac": round(mfma_flops / (enc_alone_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),
+                                "flops_per_forward": flops, "mfma_flops_per_forward": mfma_flops, "tokens_per_forward": n_tok,
+                                "timed": "the forward alone (encoder_alone_ms); encoder_ms is its duration inside the step, under the scan",
+                                "note": "fp32 mode issues 3 fp16 MFMA products per model flop (split operands): achieved counts the MFMA flops issued"
+                                        if a.encoder_precision == "fp32" else "fp16 MFMA flops = model flops",
                                 "includes": "embedding + all layers + pooling" + (" + all-gather of the embeddings" if split else "")}}
+    if alt is not None:
+        out["other_encoder_precision"] = alt
     if sd_host is not None:
         out["cpu_baseline"] = cpu_baseline_c5(np, sd_host, tok_h, lens_h, HEADS, idx, emb0, K, fuse, lex)
+        out["encoder_vs_host_fp32_forward"] = out["cpu_baseline"].pop("encoder_check")
     return out
 
 
@@ -701,8 +761,9 @@ def cpu_baseline_c5(np, sd_host, tok_h, lens_h, heads, idx, emb, K, fuse, lex):
 
     ns = min(16, tok_h.shape[0])
     t0 = time.perf_counter()
-    cpu_ref.bert_forward_f32(sd_host, tok_h[:ns], lens_h[:ns], heads)
+    o_emb = cpu_ref.bert_forward_f32(sd_host, tok_h[:ns], lens_h[:ns], heads)
     t_enc = (time.perf_counter() - t0) / ns
+    dist_l2 = np.linalg.norm(emb[:ns].cpu().numpy().astype(np.float64) - o_emb.astype(np.float64), axis=1)
     n_s = min(1_000_000, idx.ntotal)
     rows_h = idx.rows[:n_s].cpu().numpy()
     sc_h = idx.row_scales[:n_s].cpu().numpy()
@@ -719,7 +780,9 @@ def cpu_baseline_c5(np, sd_host, tok_h, lens_h, heads, idx, emb, K, fuse, lex):
     return {"value": round(1.0 / per_q_1m, 2), "unit": "queries/s", "cores": nthreads, "kind": "port",
             "sample": f"numpy fp32 encoder forward on {ns} queries ({t_enc * 1e3:.1f} ms each) + oracle fp8 flat search of "
                       f"{qn.shape[0]} queries over a {n_s}-row slice ({t_scan:.2f} s) + python RRF ({t_rrf * 1e6:.0f} us each); "
-                      f"the rate is for the {n_s}-row slice, not extrapolated to the full corpus"}
+                      f"the rate is for the {n_s}-row slice, not extrapolated to the full corpus",
+            "encoder_check": {"queries": ns, "max_l2_distance_to_numpy_fp32_forward": float(dist_l2.max()),
+                              "note": "device embeddings vs the host's fp32 forward from the same token ids (bounds every cosine-score difference)"}}
 
 
 if __name__ == "__main__":

@@ -436,7 +436,27 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   asm volatile("" : "+v"(lane_e));
   const int row_e = lane_e & 31, hh_e = lane_e >> 5;
   char* ep = smem + wave * G256_EP_BYTES;
-  if constexpr (ACT == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
+  if constexpr (ACT == 4) {  // raw fp32 products, no bias (the split-operand GEMMs of encoder_f32.hip): C is float [M][N]
+    // the wave's 128 x 64 block goes through its 18 KiB of staging in two 32-column halves of 128-byte rows
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(float4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + (8 * g + 4 * hh_e) * 4) =
+              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+      __builtin_amdgcn_wave_barrier();
+      const int r8 = lane_e >> 3, c = lane_e & 7;
+      float* Cw = (float*)C + (size_t)(tm * 256 + wr * 128) * N + tn * 256 + wc * 64 + j * 32 + c * 4;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int r = t * 8 + r8;
+        *(float4*)(Cw + (size_t)r * N) = *(const float4*)(ep + r * G256_EP_STRIDE + c * 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if constexpr (ACT == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -511,6 +531,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 // ------------------------------------------------------------------------------------------
 constexpr int G128_EP_STRIDE = 80, G128_EP_BYTES = 128 * G128_EP_STRIDE;
 constexpr int G128_LDS = 3 * 49152;
+static_assert(8 * 128 * 144 <= G128_LDS, "fp32 epilogue staging of the 256 x 128 kernel");
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half_t* __restrict__ A,
                                                                       const half_t* __restrict__ W,
@@ -622,6 +643,24 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
   // epilogue: acc[i] is rows wr*128 + i*32 + row, cols wc*32 + (8g + 4hh .. +3); transposed through LDS like above
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
   char* ep = smem + wave * G128_EP_BYTES;
+  if constexpr (ACT == 4) {  // raw fp32 products, no bias: the wave's 128 x 32 block as 128-byte rows (144-byte staging rows)
+    char* ep4 = smem + wave * (128 * 144);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(ep4 + (i * 32 + row) * 144 + (8 * g + 4 * hh) * 4) =
+            make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+    __builtin_amdgcn_wave_barrier();
+    const int r8 = lane >> 3, c = lane & 7;
+    float* Cw = (float*)C + (size_t)(tm * 256 + wr * 128) * N + tn * 128 + wc * 32 + c * 4;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int r = t * 8 + r8;
+      *(float4*)(Cw + (size_t)r * N) = *(const float4*)(ep4 + r * 144 + c * 16);
+    }
+    return;
+  }
   if constexpr (ACT == 3) {  // silu(gate)·up (see rarc_swiglu_f16): the wave's 32 columns are 16 features -> 32-byte rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1202,6 +1241,8 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
@@ -1237,12 +1278,6 @@ static int enc_gemm_splitk(const uint16_t* d_a, const uint16_t* d_w, float* d_pa
   return RARC_OK;
 }
 
-// fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward
-// (encoder_f32.hip: split operands, K = 3x the model's k).  The split-K kernels with one slice.
-int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s) {
-  return enc_gemm_splitk(a, w, c, m, n, k, 1, s);
-}
-
 // 256 x 256 or 256 x 128 tiles?  One workgroup per CU either way, so the time is rounds x time per round, and a
 // 256 x 256 tile takes about 1.5x a 256 x 128 one for twice the area (measured 1.44x at K = 3072): the larger tile
 // wins whenever its ragged last round costs less than that (51 200 x 1024 x 3072: 800 tiles in 4 rounds, 339 us,
@@ -1262,11 +1297,9 @@ bool rarc_gemm_swiglu_fused(int m, int n, int k) {
   return t128 >= 256 && k >= 3 * GK;
 }
 
-extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
-                             int n, int k, int act, void* stream) {
-  RARC_REQUIRE(d_a && d_w && d_bias && d_c, RARC_E_INVALID, "rarc_enc_gemm: null pointer");
-  RARC_REQUIRE(m > 0 && n > 0 && k > 0 && m % GM == 0 && n % GN == 0 && k % GK == 0, RARC_E_UNSUPPORTED,
-               "rarc_enc_gemm: need M,N multiples of 128 and K multiple of 64 (got %d,%d,%d)", m, n, k);
+// act 0 / 1 / 3 as rarc_enc_gemm; act 4: raw fp32 products, no bias, d_c is float [M][N] (encoder_f32.hip)
+static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m, int n, int k,
+                         int act, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const half_t *a = (const half_t*)d_a, *w = (const half_t*)d_w, *bs = (const half_t*)d_bias;
   half_t* c = (half_t*)d_c;
@@ -1305,17 +1338,19 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
         m_main = full / tiles_n * 256;
       const int t_main = (m_main / 256) * tiles_n;
       const int g256 = persist && t_main > 256 ? 256 : t_main;
-      if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      if (act == 4) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<4>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      else if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
-      if (m_main < m)
-        return rarc_enc_gemm(d_a + (size_t)m_main * k, d_w, d_bias, d_c + (size_t)m_main * (act == 3 ? n / 2 : n), m - m_main, n, k,
-                             act, stream);
+      if (m_main < m)   // (d_c counts 2-byte elements: an fp32 row is 2n of them)
+        return enc_gemm_impl(d_a + (size_t)m_main * k, d_w, d_bias, d_c + (size_t)m_main * (act == 3 ? n / 2 : (act == 4 ? 2 * n : n)),
+                             m - m_main, n, k, act, stream);
       return RARC_OK;
     }
     if (t128 >= 256 && k >= 3 * GK) {
-      if (act == 3) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<3>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      if (act == 4) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<4>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 3) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<3>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 1) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<1>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<0>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
@@ -1324,6 +1359,7 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   }
   RARC_REQUIRE(act != 3, RARC_E_UNSUPPORTED, "rarc_enc_gemm: the fused SwiGLU epilogue needs a shape the 256-row kernels take "
                "(ask rarc_gemm_swiglu_fused first)");
+  if (act == 4) return enc_gemm_splitk(d_a, d_w, (float*)d_c, m, n, k, 1, s);   // small / odd shapes: the split-K kernels, one slice
   if (deep && force != 0 && k >= 4 * GK) {
     const int grid = (m / GM) * (n / GN);
     if (act == 1) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<1>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
@@ -1343,6 +1379,23 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
   }
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
+}
+
+extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
+                             int n, int k, int act, void* stream) {
+  RARC_REQUIRE(d_a && d_w && d_bias && d_c, RARC_E_INVALID, "rarc_enc_gemm: null pointer");
+  RARC_REQUIRE(m > 0 && n > 0 && k > 0 && m % GM == 0 && n % GN == 0 && k % GK == 0, RARC_E_UNSUPPORTED,
+               "rarc_enc_gemm: need M,N multiples of 128 and K multiple of 64 (got %d,%d,%d)", m, n, k);
+  RARC_REQUIRE(act == 0 || act == 1 || act == 3, RARC_E_INVALID, "rarc_enc_gemm: act must be 0, 1 or 3");
+  return enc_gemm_impl(d_a, d_w, d_bias, d_c, m, n, k, act, stream);
+}
+
+// fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward
+// (encoder_f32.hip: split operands, K = 3x the model's k), on the same tile kernels with an fp32 epilogue.
+int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s) {
+  static const bool small_only = getenv("RARC_GEMM32_BIG") && atoi(getenv("RARC_GEMM32_BIG")) == 0;
+  if (small_only) return enc_gemm_splitk(a, w, c, m, n, k, 1, s);
+  return enc_gemm_impl(a, w, nullptr, (uint16_t*)c, m, n, k, 4, (void*)s);
 }
 
 extern "C" int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,

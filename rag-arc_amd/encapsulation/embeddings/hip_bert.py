@@ -163,14 +163,17 @@ class HipBertEncoder:
             # one foreign call per forward: the layer loop runs inside librarc_hip.so
             B.check(self._fwd(ctypes.addressof(self._model), d_ids.data_ptr(), d_lens.data_ptr(), n_pad, L,
                                               (1 if normalize else 0) | self._pool_bit, self._ws.data_ptr(), self._ws.numel(),
-                                              out.data_ptr(), st), "rarc_enc_forward")
+                                              out.data_ptr(), st),
+                    "rarc_enc32_forward" if self.precision == "fp32" else "rarc_enc_forward")
             return out[:n_seq]
 
 
-    def forward_device(self, d_ids, d_lens, normalize: bool = True):
+    def forward_device(self, d_ids, d_lens, normalize: bool = True, out=None):
         """forward() for token ids that are already on the device: int32 tensors [n_seq][seq_len] and [n_seq]
         with n_seq * seq_len a multiple of 128.  Nothing is copied or read back, so nothing is validated on the
-        host: ids and lengths are the caller's responsibility (the kernels clamp them into range)."""
+        host: ids and lengths are the caller's responsibility (the kernels clamp them into range).  Runs on the
+        CURRENT stream; `out` (fp32 [n_seq][hidden], optional) lets a caller that pipelines forwards on a side stream
+        own the result buffers instead of taking a fresh allocation per call."""
         t = self.torch
         if d_ids.dtype != t.int32 or d_lens.dtype != t.int32 or d_ids.ndim != 2 or not d_ids.is_cuda:
             raise ValueError("forward_device takes int32 device tensors [n_seq][seq_len], [n_seq]")
@@ -183,11 +186,14 @@ class HipBertEncoder:
             need = int(self._ws_bytes(self.hidden, self.inter, M))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = t.empty(need, dtype=t.uint8, device=self.device)
-            out = t.empty((n_seq, self.hidden), dtype=t.float32, device=self.device)
+            if out is None:
+                out = t.empty((n_seq, self.hidden), dtype=t.float32, device=self.device)
+            elif out.shape != (n_seq, self.hidden) or out.dtype != t.float32 or not out.is_contiguous() or out.device != self.device:
+                raise ValueError("out must be a contiguous fp32 [n_seq][hidden] tensor on the encoder's device")
             B.check(self._fwd(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
-                                              d_lens.contiguous().data_ptr(), n_seq, L, (1 if normalize else 0) | self._pool_bit,
-                                              self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), st),
-                    "rarc_enc_forward")
+                              d_lens.contiguous().data_ptr(), n_seq, L, (1 if normalize else 0) | self._pool_bit,
+                              self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), st),
+                    "rarc_enc32_forward" if self.precision == "fp32" else "rarc_enc_forward")
             return out
 
 

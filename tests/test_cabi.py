@@ -54,22 +54,29 @@ def test_engine_refuses_to_run_without_a_gpu():
         FlatIndexF16(384)
 
 
-def test_encoder_model_structs_match_the_header(tmp_path):
-    """binding.EncLayer / EncModel are laid out exactly like RarcEncLayer / RarcEncModel (gcc is the judge)."""
+def test_model_structs_match_the_header(tmp_path):
+    """Every ctypes mirror of a header struct — encoder (fp16 and fp32-class) and reranker LM, layer and model — has the
+    header's size and the header's offset for EVERY field (gcc is the judge)."""
     import ctypes
     import subprocess
 
     from rag_arc_amd.hip import binding as B
 
+    pairs = [("RarcEncLayer", B.EncLayer), ("RarcEncModel", B.EncModel), ("RarcEnc32Layer", B.Enc32Layer),
+             ("RarcEnc32Model", B.Enc32Model), ("RarcLmLayer", B.LmLayer), ("RarcLmModel", B.LmModel)]
+    lines = []
+    for cname, cls in pairs:
+        lines.append(f'printf("%zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("%zu\\n", offsetof({cname}, {fname}));')
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rarc.h"\n'
-                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(RarcEncLayer), sizeof(RarcEncModel),'
-                   ' offsetof(RarcEncModel, ln_eps), offsetof(RarcEncModel, word), offsetof(RarcEncModel, layers),'
-                   ' offsetof(RarcEncLayer, ln2_b)); return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "rarc.h"\nint main(void){' + "".join(lines) + "return 0;}\n")
     exe = tmp_path / "layout"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    want = [ctypes.sizeof(B.EncLayer), ctypes.sizeof(B.EncModel), B.EncModel.ln_eps.offset, B.EncModel.word.offset,
-            B.EncModel.layers.offset, B.EncLayer.ln2_b.offset]
+    want = []
+    for _, cls in pairs:
+        want.append(ctypes.sizeof(cls))
+        want += [getattr(cls, fname).offset for fname, _ in cls._fields_]
     assert got == want

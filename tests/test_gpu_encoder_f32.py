@@ -26,7 +26,14 @@ def _tokens(rng, n_seq, L, vocab):
     return ids, lens
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 384, 128), (1024, 3072, 1024), (512, 1024, 4096), (8192, 1024, 1024)])
+@pytest.mark.parametrize("M,N,K", [
+    (256, 384, 128),        # one-barrier / small ping-pong kernels (split-K kernels with one slice)
+    (1024, 3072, 1024),     # 128 x 128 ping-pong tiles
+    (512, 1024, 4096),      # long K' = 12288
+    (8192, 1024, 1024),     # 256 x 128 ping-pong tiles, fp32 epilogue
+    (8192, 4096, 256),      # 256 x 256 persistent tiles, fp32 epilogue in two 32-column halves
+    (256 * 70, 1024, 128),  # 280 tiles of 256 x 256: one round + a cut-off tail that runs as its own GEMM (fp32 row offset)
+])
 def test_split_gemm_is_fp32_class(M, N, K):
     import torch
 
