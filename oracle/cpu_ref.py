@@ -439,7 +439,7 @@ def qwen3_last_logits_f32(sd, cfg, input_ids, attention_mask, token_ids):
     state dict (numpy); `cfg`: dict(num_attention_heads, num_key_value_heads, head_dim, rms_norm_eps, rope_theta).
     Positions run 0..L-1 over the padded sequence (the reference's forward passes no position_ids).
     Pinned against transformers.Qwen3ForCausalLM in tests/test_oracle_golden.py."""
-    g = lambda k: np.asarray(sd[k], dtype=np.float32).astype(dtype)
+    g = lambda k: np.asarray(sd[k], dtype=np.float32)
     ids = np.asarray(input_ids)
     mask = np.asarray(attention_mask).astype(bool)
     n, L = ids.shape

@@ -89,6 +89,27 @@ def test_full_depth_encoder_and_induced_score_error(oracle, name, H, layers, hea
     assert sdiff <= 4e-3
 
 
+def test_fp16_encoder_long_sequences_512(oracle):
+    """seq_len 512 — the attention kernel's limit (encoder.hip: seq_len <= 512) and bge's max_position_embeddings:
+    sixteen 32-key tiles x sixteen query blocks, ragged lengths."""
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+
+    H, heads, I, n_seq, L = 256, 4, 1024, 3, 512
+    sd = oracle.random_bert_state_dict(H, 2, heads, I, vocab=800, max_pos=512, seed=512)
+    enc = HipBertEncoder(sd, num_heads=heads, precision="fp16")
+    rng = np.random.default_rng(512)
+    ids = rng.integers(1, 800, (n_seq, L)).astype(np.int32)
+    lens = np.array([512, 481, 7], np.int32)
+    for r, l in enumerate(lens):
+        ids[r, l:] = 0
+    got = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    sd16 = {k: v.astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    want = oracle.bert_forward_f32(sd16, ids, lens, heads, normalize=True)
+    assert np.max(np.abs(got - want)) <= 4e-3
+    cos = np.sum(got * want, axis=1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    assert cos.min() >= 0.9995
+
+
 def test_token_ids_and_lengths_are_validated(oracle):
     from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 

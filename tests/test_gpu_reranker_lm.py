@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed):
+def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed, tol_logit=3e-2, tol_p=1e-2):
     from rag_arc_amd.core.rerank import HipCausalLM
 
     sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=seed)
@@ -31,7 +31,7 @@ def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed):
     p_want = 1.0 / (1.0 + np.exp(-(want[:, 1] - want[:, 0])))
     print(f"LM-FWD H={H} layers={LAYERS} heads={NQ}/{NKV} dh={DH} L={L}: max|dlogit|={err:.2e} "
           f"(|logit| up to {np.abs(want).max():.2f}) max|dp_yes|={np.max(np.abs(p_got - p_want)):.2e}")
-    assert err <= 3e-2 and np.max(np.abs(p_got - p_want)) <= 1e-2
+    assert err <= tol_logit and np.max(np.abs(p_got - p_want)) <= tol_p
     return got
 
 
@@ -48,6 +48,21 @@ def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed):
 ])
 def test_yes_no_logits_match_oracle(oracle, H, LAYERS, NQ, NKV, DH, I, n, L, pads):
     _run(oracle, H, LAYERS, NQ, NKV, DH, I, 1000, n, L, pads, seed=H + L)
+
+
+def test_bench_geometry_full_depth_and_vocabulary(oracle):
+    """The geometry bench.py's reranker leg runs (Qwen3-Reranker-0.6B: 28 layers, hidden 1024, 16 query / 8 key-value
+    heads of 128, ffn 3072, vocabulary 151 669 with tied embeddings), eight left-padded pairs of 64 tokens, against the
+    fp32 oracle (0.45 TFLOP on the host).  Tolerance at this depth (fp16 residual stream, error grows ~ sqrt(depth)):
+    |logit - oracle| <= 1e-1 on logits of magnitude ~10, p_yes within 3e-2."""
+    _run(oracle, 1024, 28, 16, 8, 128, 3072, 151_669, 8, 64, (0, 5, 20, 63, 1, 33, 48, 11), seed=28, tol_logit=1e-1, tol_p=3e-2)
+
+
+def test_max_length_4096_tokens(oracle):
+    """One pair at the reference's max_length (Reranker_Qwen3.py:7: 4096 tokens), 0.6B layer geometry, four layers:
+    128 query blocks x up to 128 key tiles per head, rotary angles up to 4095 rad."""
+    _run(oracle, 1024, 4, 16, 8, 128, 3072, 2000, 1, 4096, (0,), seed=4096, tol_logit=5e-2, tol_p=2e-2)
+    _run(oracle, 1024, 2, 16, 8, 128, 3072, 2000, 1, 4096, (1500,), seed=4097, tol_logit=5e-2, tol_p=2e-2)   # left padded
 
 
 def test_reranker_end_to_end_matches_reference_steps(oracle):
