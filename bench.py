@@ -15,7 +15,7 @@ scaling): `--rows` rows of dimension `--dim`, N(0,1) directions, row-sharded ove
 workload = BASELINE.json config 4's corpus (100M x 768 fp16) when it fits the ranks' HBM, otherwise the
 largest power-of-ten row count that does.  The same line also carries, as objects of their own:
   c2  config 2 (1M x 768, one GPU)                                   [N = 1]
-  c3  config 3 end to end: c2 + reranker score->order + RRF          [N = 1]
+  c3  config 3 end to end: c2 + the cross-encoder's LM forward on 256 x 100 prompts + score->order + RRF   [N = 1]
   c5  config 5 end to end: bge-large encoder forward (24 layers, seeded weights) -> fp8 100M x 1024
       sharded scan -> RRF with the supplied lexical list             [every N]
   cpu_baseline  the CPU oracle timed on the host cores               [N = 1]
@@ -55,8 +55,9 @@ def parse(argv=None):
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
-    ap.add_argument("--no-lm", action="store_true", help="skip the reranker LM-forward sample inside the c3 leg")
-    ap.add_argument("--lm-queries", type=int, default=8, help="queries whose top-k are reranked by the LM forward (c3.reranker_lm)")
+    ap.add_argument("--no-lm", action="store_true", help="config 3 without its cross-encoder's LM forward (seeded logits instead)")
+    ap.add_argument("--c3-steps", type=int, default=2, help="timed steps of the config-3 leg (one step = 256 x 100 LM prompts, seconds)")
+    ap.add_argument("--c3-chunk", type=int, default=640, help="(query, document) prompts per LM call in the config-3 leg")
     ap.add_argument("--c5-rows", type=int, default=0, help="rows of the config-5 corpus (0 = auto: 100M if it fits)")
     ap.add_argument("--c5-layers", type=int, default=24, help="encoder depth of the config-5 leg (bge-large: 24)")
     ap.add_argument("--encoder-precision", choices=("fp32", "fp16"), default="fp32",
@@ -432,9 +433,9 @@ def main():
                                          "frac": round(bytes2 / (scan2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                          "mfma_TFLOPs": round(2.0 * a.batch * n2 * a.dim / (scan2 * 1e-3) / 1e12, 1)}}
         if not a.no_c3:
-            result["c3"] = leg_c3(torch, dist, lib, B, ctypes, idx2, q, ids2, n2, a, steps2, w2, passes_per_step, bytes2, k2)
-            if not a.no_lm:
-                result["c3"]["reranker_lm"] = leg_reranker_lm(torch, np, a, dev, local_rank)
+            result["c3"] = leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, ids2, n2, a, steps2, w2, passes_per_step, bytes2, k2,
+                                  dev, local_rank)
+            torch.cuda.empty_cache()
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(np, idx2, q, ids2, sc2, n2, a)
         if idx2 is not idx:
@@ -455,51 +456,61 @@ def main():
         dist.destroy_process_group()
 
 
-def leg_c3(torch, dist, lib, B, ctypes, idx2, q, dense_ids, n2, a, steps, warmup, passes_per_step, scan_bytes, kname):
-    """BASELINE config 3 end to end on one GPU (reference path: core/retrieval/mutipath.py:37-93 ->
-    VectorStore_Faiss.py:240,258-263 -> Reranker_Qwen3.py:41-49,70-74 -> core/utils/Fusion.py:45-76): dense
-    top-k over 1M x 768 -> reranker score->order on seeded fp16 (no, yes) logit pairs -> RRF with the supplied
-    lexical list.  (The reranker's LM forward is not part of this leg: seeded logits)"""
-    from rag_arc_amd.core.rerank import HipLogitReranker
-    from rag_arc_amd.core.utils import HipRRFusion
-
-    dev, K, nq = q.device, a.k, a.batch
-    g = torch.Generator(device=dev)
-    g.manual_seed(99)
-    zn = (torch.randn((nq, K), generator=g, device=dev) * 3).half()
-    zy = (torch.randn((nq, K), generator=g, device=dev) * 3).half()
-    lex = lexical_lists(torch, dense_ids, n2, K)
-    lens = torch.full((nq, 2), K, dtype=torch.int32, device=dev)
-    rr, fuse = HipLogitReranker(lambda *_: None, device=dev.index or 0), HipRRFusion(device=dev.index or 0)
-
-    def end(h):
-        ids, _ = h.result()
-        _, perm = rr.score_order(zn, zy)
-        keys = torch.stack([torch.gather(ids, 1, perm.long()), lex], dim=1)
-        return fuse.fuse_ids(keys, lens, K)
-
-    (dt, (fk, fs, fn)), tot, nl = scan_profile(
-        lib, B, ctypes, lambda: timed_loop(torch, dist, lambda: idx2.search_async(q, K), end, steps, warmup, False),
-        8 * (steps + warmup) * passes_per_step + 16)
-    scan = tot / max(1, steps + warmup)
-    return {"workload": f"config 3 end to end: {n2}x{a.dim} fp16 scan top-{K} -> rerank score->order (seeded fp16 logits) "
-                        f"-> RRF with a supplied lexical list, batch {nq}, 1 GPU",
-            "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
-            "scan_ms": round(scan, 4), "fused_entries_per_query": int(fn.min().item()),
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(scan_bytes / (scan * 1e-3) / 1e9, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_bytes / (scan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "end_to_end_frac": round(scan_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+# Token counts of the reference's prompt around a (query, document) pair (core/rerank/Reranker_Qwen3.py:16-17,23-27), counted by
+# words and punctuation marks: Qwen's vocabulary does not ship here (no network), so these are estimates of what its BPE yields.
+C3_TPL = {"prefix": 39,      # <|im_start|>system\nJudge whether the Document meets ... "yes" or "no".<|im_end|>\n<|im_start|>user\n
+          "instruct": 19,    # "<Instruct>: Given a web search query, retrieve relevant passages that answer the query\n"
+          "query_hdr": 4,    # "<Query>: "
+          "query": 12,       # a short web-search query
+          "doc_hdr": 5,      # "\n<Document>: "
+          "suffix": 9}       # <|im_end|>\n<|im_start|>assistant\n<think>\n\n</think>\n\n
+C3_DOC_MIN, C3_DOC_SPAN = 64, 129      # document chunk length in tokens: 64 + hash(doc id) % 129  ->  64 .. 192
 
 
-def leg_reranker_lm(torch, np, a, dev, local_rank):
-    """The reranker's LM forward (core/rerank/Reranker_Qwen3.py:29-49) on a bounded sample: Qwen3-Reranker-0.6B's
-    geometry (28 layers, hidden 1024, 16 query / 8 key-value heads of 128, ffn 3072, vocabulary 151 669; seeded fp16
-    weights), `--lm-queries` queries x top-k (query, document) pairs of 64 tokens, left padded — the (no, yes) logits
-    of every pair in ONE rarc_lm_yes_no_logits call per query batch, then rarc_rerank_order.  Reported beside config 3's
-    seeded-logit leg, not inside its rate: a full batch of 256 queries x 100 pairs is 1.4 PFLOP of LM forward."""
-    from rag_arc_amd.core.rerank import HipCausalLM, HipLogitReranker
+def _mix64(torch, key, pos):
+    """Counter hash on int64 tensors (wrapping arithmetic): the synthetic token at position `pos` of the text `key`."""
+    x = key * 6364136223846793005 + pos * 1442695040888963407 + 0x632BE59BD9B4E019
+    x = x ^ (x >> 29)
+    x = x * (-4658895280553007687)
+    x = x ^ (x >> 32)
+    return (x >> 17) & 0x7FFFFFFF
 
-    H, LAYERS, NQ, NKV, DH, I, V, L = 1024, 28, 16, 8, 128, 3072, 151_669, 64
+
+def c3_pair_tokens(torch, qidx, doc, Lc, vocab):
+    """LEFT-padded token ids [n][Lc] (int32) + first-real-token index [n] (int32) of the prompts for pairs (query qidx[i],
+    document doc[i]): template tokens depend on the position only (the same ids in every pair, like a real template), query
+    tokens on (query, position), document tokens on (document id, position); lengths per C3_TPL / C3_DOC_*."""
+    t = C3_TPL
+    dl = C3_DOC_MIN + _mix64(torch, doc, torch.zeros_like(doc) - 1) % C3_DOC_SPAN
+    fixed = t["prefix"] + t["instruct"] + t["query_hdr"] + t["query"] + t["doc_hdr"] + t["suffix"]
+    ell = fixed + dl
+    pos = torch.arange(Lc, device=doc.device)[None, :] - (Lc - ell)[:, None]            # < 0: padding
+    q0 = t["prefix"] + t["instruct"] + t["query_hdr"]
+    d0 = q0 + t["query"] + t["doc_hdr"]
+    in_q = (pos >= q0) & (pos < q0 + t["query"])
+    in_d = (pos >= d0) & (pos < d0 + dl[:, None])
+    key = torch.where(in_q, (qidx[:, None] + 1) * 1_000_003, torch.where(in_d, doc[:, None] + (1 << 40), torch.zeros_like(pos)))
+    # (suffix positions are counted from the end so that the suffix ids do not depend on the document length)
+    ppos = torch.where(pos >= d0 + dl[:, None], pos - ell[:, None] + (1 << 20), pos)
+    tok = 10 + _mix64(torch, key, ppos) % (vocab - 10)
+    ids = torch.where(pos >= 0, tok, torch.zeros_like(tok)).int().contiguous()
+    return ids, (Lc - ell).int().contiguous(), ell
+
+
+def c3_pair_lengths(torch, doc):
+    t = C3_TPL
+    return (t["prefix"] + t["instruct"] + t["query_hdr"] + t["query"] + t["doc_hdr"] + t["suffix"] + C3_DOC_MIN
+            + _mix64(torch, doc, torch.zeros_like(doc) - 1) % C3_DOC_SPAN)
+
+
+LM_GEOM = dict(H=1024, LAYERS=28, NQ=16, NKV=8, DH=128, I=3072, V=151_669)   # Qwen3-Reranker-0.6B
+
+
+def build_reranker_lm(torch, dev, local_rank, want_host):
+    from rag_arc_amd.core.rerank import HipCausalLM
+
+    G = LM_GEOM
+    H, LAYERS, NQ, NKV, DH, I, V = (G[k] for k in ("H", "LAYERS", "NQ", "NKV", "DH", "I", "V"))
     g = torch.Generator(device=dev)
     g.manual_seed(28)
     rnd = lambda *shape: torch.randn(shape, generator=g, device=dev) * 0.03
@@ -512,44 +523,160 @@ def leg_reranker_lm(torch, np, a, dev, local_rank):
         sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"], sd[p + "mlp.down_proj.weight"] = rnd(I, H), rnd(I, H), rnd(H, I)
         sd[p + "input_layernorm.weight"], sd[p + "post_attention_layernorm.weight"] = 1.0 + rnd(H), 1.0 + rnd(H)
     lm = HipCausalLM(sd, NQ, NKV, DH, device=local_rank)
-    del sd
-    nqr, K = max(1, a.lm_queries), a.k
-    n_pairs = nqr * K
-    n_pairs -= n_pairs % 4
-    rng = np.random.default_rng(28)
-    ids = rng.integers(10, V, (n_pairs, L)).astype(np.int32)
-    mask = np.ones((n_pairs, L), np.int8)
-    for r in range(n_pairs):                      # ragged prompts, left padded
-        pad = int(rng.integers(0, L // 2))
-        mask[r, :pad] = 0
-        ids[r, :pad] = 0
-    rr = HipLogitReranker(lambda *_: None, device=local_rank)
+    # the oracle sees the weights the device holds (fp16 storage, as the reference's torch_dtype=float16), computes in fp32
+    sd_host = {k: v.half().float().cpu().numpy() for k, v in sd.items()} if want_host else None
+    return lm, sd_host
 
-    def once():
-        z = lm.yes_no_logits(ids, mask, 1, 2)
-        return rr.score_order(z[:, 0].reshape(-1, K)[: n_pairs // K], z[:, 1].reshape(-1, K)[: n_pairs // K])
 
-    once()
+def leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, dense_ids, n2, a, steps, warmup, passes_per_step, scan_bytes, kname,
+           dev, local_rank):
+    """BASELINE config 3 end to end on one GPU, AS CONFIGURED (reference path: core/retrieval/mutipath.py:37-93 ->
+    VectorStore_Faiss.py:240,258-263 -> Reranker_Qwen3.py:23-49,57-74 -> core/utils/Fusion.py:45-76): per step, batch-256
+    dense top-100 over 1M x 768 -> the cross-encoder's LM forward on all 256 x 100 (query, document) prompts (templated,
+    left padded, Qwen3-Reranker-0.6B geometry with seeded fp16 weights) -> p_yes -> stable order -> RRF with the supplied
+    lexical list.  Token ids are synthesised on the device from (query, document id) (no vocabulary ships offline): the
+    LM's work depends on the lengths only.  The pairs of a step are sorted by length and run in chunks of `--c3-chunk`
+    pairs, each chunk left padded to its own longest prompt.
+    Sub-field `without_lm_forward`: the same loop with seeded logits in place of the LM (round 2's c3 figure)."""
+    from rag_arc_amd.core.rerank import HipLogitReranker
+    from rag_arc_amd.core.utils import HipRRFusion
+
+    K, nq = a.k, a.batch
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    zn = (torch.randn((nq, K), generator=g, device=dev) * 3).half()
+    zy = (torch.randn((nq, K), generator=g, device=dev) * 3).half()
+    lex = lexical_lists(torch, dense_ids, n2, K)
+    lens = torch.full((nq, 2), K, dtype=torch.int32, device=dev)
+    rr, fuse = HipLogitReranker(lambda *_: None, device=local_rank), HipRRFusion(device=local_rank)
+
+    def end_seeded(h):
+        ids, _ = h.result()
+        _, perm = rr.score_order(zn, zy)
+        keys = torch.stack([torch.gather(ids, 1, perm.long()), lex], dim=1)
+        return fuse.fuse_ids(keys, lens, K)
+
+    (dt0, (fk, fs, fn)), tot, nl = scan_profile(
+        lib, B, ctypes, lambda: timed_loop(torch, dist, lambda: idx2.search_async(q, K), end_seeded, steps, warmup, False),
+        8 * (steps + warmup) * passes_per_step + 16)
+    scan = tot / max(1, steps + warmup)
+    scan_roof = {"bound": "hbm", "kernel": kname, "achieved": round(scan_bytes / (scan * 1e-3) / 1e9, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_bytes / (scan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    no_lm = {"workload": "the same loop with seeded fp16 (no, yes) logits in place of the LM forward: scan -> rerank score->order -> RRF",
+             "value": round(nq * steps / dt0, 1), "unit": "queries/s", "ms_per_step": round(dt0 / steps * 1e3, 4),
+             "scan_ms": round(scan, 4), "roofline": scan_roof}
+    if a.no_lm:
+        return {"workload": f"config 3 WITHOUT its cross-encoder (--no-lm): {n2}x{a.dim} fp16 scan top-{K} -> rerank score->order "
+                            f"(seeded logits) -> RRF, batch {nq}, 1 GPU", **{k: v for k, v in no_lm.items() if k != "workload"},
+                "fused_entries_per_query": int(fn.min().item())}
+
+    G = LM_GEOM
+    H, LAYERS, NQ, NKV, DH, I, V = (G[k] for k in ("H", "LAYERS", "NQ", "NKV", "DH", "I", "V"))
+    lm, sd_host = build_reranker_lm(torch, dev, local_rank, want_host=not a.no_cpu_baseline)
+    NO_ID, YES_ID = 1, 2
+    n_pairs, CH = nq * K, max(4, a.c3_chunk - a.c3_chunk % 4)
+    qidx_all = torch.arange(nq, device=dev).repeat_interleave(K)
+    z_all = torch.empty((n_pairs, 2), dtype=torch.float16, device=dev)
+    lm_ev, stats = [], {}
+
+    def rerank_fuse(ids):
+        """the cross-encoder over every (query, top-k document) pair of the batch, then order and fuse"""
+        doc = ids.reshape(-1)
+        ell = c3_pair_lengths(torch, doc)
+        order = torch.argsort(ell, stable=True)
+        ell_s = ell[order]
+        starts = list(range(0, n_pairs, CH))
+        cmax = [int(v) for v in torch.stack([ell_s[min(s0 + CH, n_pairs) - 1] for s0 in starts]).cpu().tolist()]   # one read-back
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tokens = 0
+        for s0, mx in zip(starts, cmax):
+            sel = order[s0:s0 + CH]
+            if sel.numel() % 4:      # (n_pairs is a multiple of 4 whenever k is: not hit at the defaults)
+                sel = torch.cat([sel, sel[-1:].expand(4 - sel.numel() % 4)])
+            Lc = -(-mx // 32) * 32
+            t_ids, t_start, _ = c3_pair_tokens(torch, qidx_all[sel], doc[sel], Lc, V)
+            z_all[sel] = lm.yes_no_logits_device(t_ids, t_start, NO_ID, YES_ID)
+            tokens += int(sel.numel()) * Lc
+        e1.record()
+        lm_ev.append((e0, e1))
+        stats.update(padded_tokens=tokens, real_tokens=None, ell=ell)
+        z = z_all.view(nq, K, 2)
+        _, perm = rr.score_order(z[:, :, 0].contiguous(), z[:, :, 1].contiguous())
+        keys = torch.stack([torch.gather(ids, 1, perm.long()), lex], dim=1)
+        return fuse.fuse_ids(keys, lens, K)
+
+    def end(h):
+        ids, _ = h.result()
+        return rerank_fuse(ids)
+
+    st3, w3 = max(1, a.c3_steps), 1
+    timed_loop(torch, dist, lambda: idx2.search_async(q, K), end, 0, w3, False)
+    lm_ev.clear()
+    dt, (fk, fs, fn) = timed_loop(torch, dist, lambda: idx2.search_async(q, K), end, st3, 0, False)
     torch.cuda.synchronize()
-    reps = 3
+    lm_ms = sum(x.elapsed_time(y) for x, y in lm_ev) / max(1, len(lm_ev))
+    ell = stats["ell"].double()
+    real_tokens = float(ell.sum().item())
+    g_mix = 2.0 * H * (NQ + 2 * NKV) * DH
+    g_rest = 2.0 * (NQ * DH * H + H * 2 * I + I * H)
+    # algorithmic flops of one step's LM work: projections on the REAL tokens (the last layer's output projection and MLP on
+    # the last position only, as rarc_lm_yes_no_logits computes them), causal attention over real keys
+    flops = (LAYERS * (real_tokens * g_mix + 2.0 * NQ * DH * float((ell * (ell + 1)).sum().item()))
+             + (LAYERS - 1) * real_tokens * g_rest + n_pairs * g_rest)
+    out = {"workload": f"config 3 end to end, cross-encoder included: {n2}x{a.dim} fp16 scan top-{K} -> LM forward on {nq} x {K} = "
+                       f"{n_pairs} templated (query, document) prompts of {int(ell.min().item())}-{int(ell.max().item())} tokens "
+                       f"(Qwen3-Reranker-0.6B geometry: {LAYERS} layers, hidden {H}, {NQ}/{NKV} heads of {DH}, ffn {I}, vocabulary {V}; "
+                       f"seeded fp16 weights) -> p_yes -> stable order -> RRF with a supplied lexical list, batch {nq}, 1 GPU",
+           "value": round(nq * st3 / dt, 2), "unit": "queries/s", "ms_per_step": round(dt / st3 * 1e3, 3), "steps": st3, "warmup": w3,
+           "pairs_per_s": round(n_pairs * st3 / dt, 1), "lm_ms_per_step": round(lm_ms, 3),
+           "prompt_tokens": {"template": C3_TPL, "document": f"{C3_DOC_MIN}..{C3_DOC_MIN + C3_DOC_SPAN - 1} by a hash of the document id",
+                             "real_tokens_per_step": int(real_tokens), "padded_tokens_per_step": int(stats["padded_tokens"]),
+                             "chunk_pairs": CH, "note": "template token counts are word-count estimates (Qwen's vocabulary does not ship offline)"},
+           "fused_entries_per_query": int(fn.min().item()),
+           "roofline": {"bound": "mfma", "kernel": "rarc_gemm256_f16_kernel / rarc_gemm256x128_f16_kernel (LM projections), rarc_lm_attention_kernel<128>",
+                        "achieved": round(flops / (lm_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(flops / (lm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4), "flops_per_step": flops,
+                        "timed": "HIP events around the LM calls of a step (token synthesis, chunk gather and scatter included)",
+                        "end_to_end_frac": round(flops / (dt / st3) / 1e12 / MFMA_F16_PEAK_TF, 4)},
+           "without_lm_forward": no_lm}
+    if sd_host is not None:
+        out["cpu_baseline"], out["lm_parity_vs_oracle"] = cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, NO_ID, YES_ID, K)
+    return out
+
+
+def cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, no_id, yes_id, K):
+    """The reranker's LM forward on the host (numpy fp32 oracle, pinned to transformers.Qwen3ForCausalLM) on four of the
+    step's prompts, timed — and the device logits of the same four prompts checked against it."""
+    from oracle import cpu_ref
+
+    G = LM_GEOM
+    doc = dense_ids.reshape(-1)
+    ell = c3_pair_lengths(torch, doc)
+    order = torch.argsort(ell, stable=True)
+    pick = order[torch.tensor([0, len(order) // 3, 2 * len(order) // 3, len(order) - 1], device=order.device)]
+    Lc = -(-int(ell[pick].max().item()) // 32) * 32
+    t_ids, t_start, _ = c3_pair_tokens(torch, qidx_all[pick], doc[pick], Lc, V)
+    got = lm.yes_no_logits_device(t_ids, t_start, no_id, yes_id).float().cpu().numpy()
+    ids_h, start_h = t_ids.cpu().numpy(), t_start.cpu().numpy()
+    mask = (np.arange(Lc)[None, :] >= start_h[:, None]).astype(np.int64)
     t0 = time.perf_counter()
-    for _ in range(reps):
-        scores, perm = once()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    tokens = n_pairs * L
-    # flops actually needed: every layer's q|k|v projection and attention on all tokens; output projection + MLP on all
-    # tokens in all layers but the last, where only the last position of each pair goes on (rarc_lm_yes_no_logits does that)
-    mix = 2.0 * H * (NQ + 2 * NKV) * DH + 4.0 * L * NQ * DH
-    rest = 2.0 * (NQ * DH * H + H * 2 * I + I * H)
-    per_tok = LAYERS * mix + (LAYERS - 1) * rest + rest / L
-    return {"workload": f"Qwen3-Reranker-0.6B geometry ({LAYERS} layers, seeded fp16 weights): {n_pairs} (query, document) pairs x {L} "
-                        f"tokens, left padded -> (no, yes) logits -> p_yes -> stable order; {nqr} queries x top-{K}",
-            "ms_per_call": round(dt * 1e3, 3), "pairs_per_s": round(n_pairs / dt, 1), "queries_reranked_per_s": round(n_pairs / K / dt, 2),
-            "roofline": {"bound": "mfma", "achieved": round(per_tok * tokens / dt / 1e12, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": round(per_tok * tokens / dt / 1e12 / MFMA_F16_PEAK_TF, 4), "flops_per_call": per_tok * tokens,
-                         "includes": "host-side padding + H2D of the token ids, all layers, last-position logits, rerank order"},
-            "finite": bool(torch.isfinite(scores.float()).all().item())}
+    want = cpu_ref.qwen3_last_logits_f32(sd_host, dict(num_attention_heads=G["NQ"], num_key_value_heads=G["NKV"], head_dim=G["DH"],
+                                                       rms_norm_eps=1e-6, rope_theta=1e6), ids_h, mask, [no_id, yes_id])
+    t_cpu = time.perf_counter() - t0
+    p_got = 1.0 / (1.0 + np.exp(-(got[:, 1] - got[:, 0]).astype(np.float64)))
+    p_want = 1.0 / (1.0 + np.exp(-(want[:, 1] - want[:, 0]).astype(np.float64)))
+    n = len(pick)
+    base = {"value": round(n / t_cpu / K, 4), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy fp32 LM forward (oracle/cpu_ref.qwen3_last_logits_f32) of {n} prompts of up to {Lc} tokens in {t_cpu:.2f} s "
+                      f"= {n / t_cpu:.2f} pairs/s; a query is {K} pairs; the scan and the fusion are not in this figure (they are "
+                      f"three orders of magnitude cheaper)"}
+    parity = {"prompts_checked": n, "max_abs_dlogit": float(np.max(np.abs(got - want))), "max_abs_logit": float(np.max(np.abs(want))),
+              "max_abs_dp_yes": float(np.max(np.abs(p_got - p_want))),
+              "tolerance": "fp16 model as the reference's torch_dtype=float16: |dlogit| <= 1e-1 at 28 layers, |dp_yes| <= 3e-2 "
+                           "(tests/test_gpu_reranker_lm.py::test_bench_geometry_full_depth_and_vocabulary)",
+              "within_tolerance": bool(np.max(np.abs(got - want)) <= 1e-1 and np.max(np.abs(p_got - p_want)) <= 3e-2)}
+    return base, parity
 
 
 def cpu_baseline(np, idx2, q, ids2, sc2, n2, a):

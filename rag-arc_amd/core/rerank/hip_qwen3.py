@@ -126,6 +126,29 @@ class HipCausalLM:
             return out[:n]
 
 
+    def yes_no_logits_device(self, d_ids, d_start, no_id: int, yes_id: int, out=None):
+        """yes_no_logits() for batches that are already on the device: int32 tensors [n][L] (LEFT padded) and [n]
+        (index of each sequence's first real token), n * L a multiple of 128.  Nothing is copied, read back or
+        validated on the host (the kernels clamp token ids into the table).  Returns fp16 [n][2] = (no, yes)."""
+        t = self.torch
+        if d_ids.dtype != t.int32 or d_start.dtype != t.int32 or d_ids.ndim != 2 or not d_ids.is_cuda:
+            raise ValueError("yes_no_logits_device takes int32 device tensors [n][L], [n]")
+        n, L = d_ids.shape
+        if n * L == 0 or (n * L) % 128 or d_start.shape != (n,):
+            raise ValueError("n * L must be a positive multiple of 128")
+        with t.cuda.device(self.device):
+            need = int(self.lib.rarc_lm_workspace_bytes(ctypes.addressof(self._model), n * L))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = t.empty(need, dtype=t.uint8, device=self.device)
+            if out is None:
+                out = t.empty((n, 2), dtype=t.float16, device=self.device)
+            B.check(self.lib.rarc_lm_yes_no_logits(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
+                                                   d_start.contiguous().data_ptr(), n, L, int(no_id), int(yes_id),
+                                                   self._ws.data_ptr(), self._ws.numel(), out.data_ptr(),
+                                                   t.cuda.current_stream(self.device).cuda_stream), "rarc_lm_yes_no_logits")
+            return out
+
+
 class HipQwen3Reranker(HipLogitReranker):
     """Drop-in for the reference's Qwen3Reranker: `rerank(query, documents, k=None, batch_size=8)`."""
 
