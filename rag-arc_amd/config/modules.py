@@ -109,9 +109,57 @@ class HipFlatVectorStoreConfig(AbstractConfig):
         return BuiltModule(config=self, impl=store)
 
 
+class HipShardedFlatVectorStoreConfig(AbstractConfig):
+    """HipFlatVectorStore row-sharded over the GPUs of a node (BASELINE configs 4 / 5): build it under
+    `torchrun --nproc-per-node N` and every rank holds rows [r*ceil(n/N), (r+1)*ceil(n/N)) of the corpus in its GPU's HBM,
+    answers a query with its local exact top-k, and ONE RCCL all-gather + merge gives every rank the global answer
+    (rag_arc_amd/encapsulation/database/vector_db/hip_sharded.py).  Without WORLD_SIZE (or with WORLD_SIZE = 1) it is a
+    one-shard store.  The reference's slot is the same (`framework/register.py:15-21`: any config with a `type` tag and
+    build()); it has no distributed code of its own."""
+    type: Literal["hip_sharded_flat_vectorstore"] = "hip_sharded_flat_vectorstore"
+    embedding: EmbeddingsConfig
+    metric: Literal["cosine", "ip"] = "cosine"
+    normalize_L2: bool = False
+    storage: Literal["f16", "f8", "f32"] = "f16"
+    corpus_path: Optional[str] = None     # .npz with `texts` (and optional `ids`): EVERY rank reads it, each keeps its slice
+    backend: Literal["nccl", "gloo"] = "nccl"   # nccl = RCCL over xGMI (the product); gloo: rehearsals on one device / CPU
+    one_device: bool = False              # rehearsal: every rank on cuda:0 (needs backend gloo; RCCL refuses it)
+
+    def build(self) -> AbstractModule:
+        import os
+
+        import numpy as np
+        import torch
+        import torch.distributed as dist
+
+        from ..encapsulation.database.vector_db.hip_sharded import HipShardedFlatVectorStore
+
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = 0 if self.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+        if world > 1 and not dist.is_initialized():
+            if self.one_device and self.backend != "gloo":
+                raise ValueError("one_device needs backend gloo (RCCL refuses two ranks on one device)")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            rank = int(os.environ.get("RANK", "0"))
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
+        store = HipShardedFlatVectorStore(self.embedding.build().impl, metric=self.metric, normalize_L2=self.normalize_L2,
+                                          device=local_rank, storage=self.storage)
+        if self.corpus_path:
+            data = np.load(self.corpus_path, allow_pickle=False)
+            ids = [str(i) for i in data["ids"]] if "ids" in data else None
+            store.add_texts([str(t) for t in data["texts"]], ids=ids)
+        return BuiltModule(config=self, impl=store)
+
+
 class VectorStoreRetrieverConfig(AbstractConfig):
     type: Literal["vectorstore_retriever"] = "vectorstore_retriever"
-    vectorstore: HipFlatVectorStoreConfig
+    vectorstore: Annotated[Union[HipFlatVectorStoreConfig, HipShardedFlatVectorStoreConfig], Field(discriminator="type")]
     search_type: str = "similarity"
     search_kwargs: Dict[str, Any] = Field(default_factory=dict)
 

@@ -27,6 +27,11 @@ class BaseRetriever(ABC):
     async def ainvoke(self, input: str, **kwargs: Any) -> List[Document]:
         return await self._aget_relevant_documents(input, **kwargs)
 
+    def batch_invoke(self, inputs: List[str], **kwargs: Any) -> List[List[Document]]:
+        """Extension over the reference (which has no batch entry point): element i equals invoke(inputs[i], **kwargs).
+        Retrievers over a batched backend override this to answer the whole list in one pass."""
+        return [self.invoke(q, **kwargs) for q in inputs]
+
     # -- to implement ------------------------------------------------------------------------
     @abstractmethod
     def _get_relevant_documents(self, query: str, **kwargs: Any) -> List[Document]:

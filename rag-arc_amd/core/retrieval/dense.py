@@ -53,6 +53,22 @@ class VectorStoreRetriever(BaseRetriever):
             logger.error("retrieval failed: %s", exc)
             raise
 
+    def batch_invoke(self, inputs: List[str], **kwargs: Any) -> List[List[Document]]:
+        """invoke() for a list of queries in ONE pass of the store (one encoder call, one scan per 256 queries) when the
+        store can batch (`batch_similarity_search`: HipFlatVectorStore and its sharded form) and the search type is
+        "similarity"; otherwise query by query.  Element i equals invoke(inputs[i], **kwargs)."""
+        params: Dict[str, Any] = {**self.search_kwargs, **kwargs}
+        k = params.get("k", getattr(self, "k", 5))
+        params["k"] = k
+        batched = getattr(self.vectorstore, "batch_similarity_search", None)
+        if self.search_type != "similarity" or batched is None:
+            return [self.invoke(q, **kwargs) for q in inputs]
+        try:
+            return [docs[:k] for docs in batched(list(inputs), **params)]
+        except Exception as exc:
+            logger.error("batched retrieval failed: %s", exc)
+            raise
+
     # ------------------------------------------------------------------ async
     async def _aget_relevant_documents(self, query: str, **kwargs: Any) -> List[Document]:
         params: Dict[str, Any] = {**self.search_kwargs, **kwargs}

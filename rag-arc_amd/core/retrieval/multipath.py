@@ -38,6 +38,33 @@ class MultiPathRetriever(BaseRetriever):
             return []
         return [r.document for r in self.fusion_method.fuse(gathered, top_k)]
 
+    def batch_invoke(self, inputs: List[str], **kwargs: Any) -> List[List[Document]]:
+        """invoke() for a list of queries: every retriever answers the whole list (in one pass where it can batch), then
+        ALL queries are fused in one kernel launch (`fuse_many`) when the fusion method has one.  Element i equals
+        invoke(inputs[i], **kwargs) — same kwargs hand-down, same swallow-and-report of a failing retriever."""
+        inputs = list(inputs)
+        top_k = kwargs.get("top_k", 10)
+        per_retriever: List[List[List[RetrievalResult]]] = []
+        for retriever in self.retrievers:
+            try:
+                lists = retriever.batch_invoke(inputs, **{**kwargs, "k": self.top_k_per_retriever})
+                per_retriever.append([[RetrievalResult(document=d, score=getattr(d, "score", 1.0), rank=i + 1)
+                                       for i, d in enumerate(docs)] for docs in lists])
+            except Exception as exc:  # noqa: BLE001
+                print(f"retriever {type(retriever).__name__} failed: {exc}")
+                per_retriever.append([[] for _ in inputs])
+        gathered = [[lists[qi] for lists in per_retriever] for qi in range(len(inputs))]
+        live = [qi for qi, g in enumerate(gathered) if g and not all(len(one) == 0 for one in g)]
+        out: List[List[Document]] = [[] for _ in inputs]
+        fuse_many = getattr(self.fusion_method, "fuse_many", None)
+        if fuse_many is not None and live:
+            for qi, fused in zip(live, fuse_many([gathered[qi] for qi in live], top_k)):
+                out[qi] = [r.document for r in fused]
+        else:
+            for qi in live:
+                out[qi] = [r.document for r in self.fusion_method.fuse(gathered[qi], top_k)]
+        return out
+
     def add_retriever(self, retriever: BaseRetriever) -> None:
         self.retrievers.append(retriever)
 

@@ -83,5 +83,37 @@ class HipRRFusion(FusionMethod):
                 for i, (key, score) in enumerate(zip(fk, fs))]
 
 
+    def fuse_many(self, batch: List[List[List[RetrievalResult]]], top_k: int) -> List[List[RetrievalResult]]:
+        """fuse() for many queries in ONE kernel launch: batch[q] is the list of per-retriever result lists of query q.
+        Element q equals fuse(batch[q], top_k) (same side effects on the input ranks)."""
+        import torch
+
+        if not batch:
+            return []
+        n_lists = max(len(one) for one in batch)
+        max_len = max((len(lst) for one in batch for lst in one), default=0)
+        if max_len == 0 or top_k <= 0 or n_lists == 0:
+            return [[] for _ in batch]
+        table = [[[0] * max_len for _ in range(n_lists)] for _ in batch]
+        lens = [[0] * n_lists for _ in batch]
+        docs: List[dict] = []
+        for qi, results in enumerate(batch):
+            key_of, doc_of = {}, {}
+            for li, one in enumerate(results):
+                lens[qi][li] = len(one)
+                for pi, item in enumerate(one):
+                    item.rank = pi + 1
+                    key = key_of.setdefault(item.document.content, len(key_of))
+                    doc_of[key] = item.document  # last occurrence wins
+                    table[qi][li][pi] = key
+            docs.append(doc_of)
+        dev = torch.device("cuda", self.device)
+        fk, fs, fn = self.fuse_ids(torch.tensor(table, dtype=torch.int64, device=dev),
+                                   torch.tensor(lens, dtype=torch.int32, device=dev), min(top_k, n_lists * max_len))
+        fk, fs, fn = fk.cpu().tolist(), fs.cpu().tolist(), fn.cpu().tolist()
+        return [[RetrievalResult(document=docs[qi][key], score=score, rank=i + 1)
+                 for i, (key, score) in enumerate(zip(fk[qi][: fn[qi]], fs[qi][: fn[qi]]))] for qi in range(len(batch))]
+
+
 # the name the reference exports
 RRFusion = HipRRFusion

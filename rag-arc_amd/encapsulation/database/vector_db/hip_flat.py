@@ -10,8 +10,9 @@ products defined in DESIGN.md, ties ordered by insertion index.  IVF / HNSW / L2
 """
 import os
 import pickle
+import threading
 import uuid
-from typing import Any, Callable, List, Optional, Tuple
+from typing import Any, Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -44,10 +45,78 @@ def _mmr_select(scored, embeddings, query_embedding, k, lambda_mult=0.5):
     return [scored[i][0] for i in chosen]
 
 
+class _QueryCoalescer:
+    """Gathers the queries of CONCURRENT callers into one scan.
+
+    The reference issues one query per `index.search` (VectorStore_Faiss.py:258-263) and its `ainvoke` runs every call on
+    a thread of its own (core/retrieval/base.py:82-96), so a busy service holds many one-query searches at once — each a
+    full pass over the corpus.  Here a caller that finds the index idle launches at once (no added latency, alone if
+    nobody else is waiting); callers that arrive WHILE a scan is running queue up, and whoever is woken first takes the
+    whole queue — up to 256 queries — through ONE scan.  256 threads calling together cost two or three scans instead
+    of 256.  `window_s` > 0 additionally lets an idle-index leader wait that long for company.
+
+    An exact top-k under a total order (score desc, id asc) is a prefix of the top-k' for k' > k, so one launch with the
+    largest k of the batch serves every caller."""
+
+    def __init__(self, run_batch: Callable, max_batch: int = 256, window_s: float = 0.0):
+        self.run_batch, self.max_batch, self.window_s = run_batch, int(max_batch), float(window_s)
+        self.cv = threading.Condition()
+        self.queue: list = []
+        self.busy = False
+        self.launches = 0        # scans issued
+        self.served = 0          # queries answered
+
+    class _Item:
+        __slots__ = ("payload", "k", "result", "error", "done")
+
+        def __init__(self, payload, k):
+            self.payload, self.k, self.result, self.error, self.done = payload, k, None, None, False
+
+    def submit(self, payload, k: int):
+        """payload: a query text or a query vector; returns (scores fp32 [k], rows int64 [k]) of that query."""
+        item = self._Item(payload, int(k))
+        while True:
+            with self.cv:
+                if item not in self.queue and not item.done:
+                    self.queue.append(item)
+                while not item.done and self.busy:
+                    self.cv.wait()
+                if item.done:
+                    break
+                self.busy = True                       # this caller leads the next launch
+                if self.window_s > 0 and len(self.queue) < self.max_batch:
+                    self.cv.wait(timeout=self.window_s)
+                batch = self.queue[: self.max_batch]   # FIFO (the leader's own item is among them unless > max_batch queued)
+                del self.queue[: self.max_batch]
+            try:
+                results = self.run_batch([it.payload for it in batch], max(it.k for it in batch))
+                for it, (sc, rows) in zip(batch, results):
+                    it.result = (sc[: it.k], rows[: it.k])
+            except BaseException as exc:  # noqa: BLE001 - every waiter of the batch must learn of it
+                for it in batch:
+                    it.error = exc
+            finally:
+                with self.cv:
+                    self.launches += 1
+                    self.served += len(batch)
+                    for it in batch:
+                        it.done = True
+                    self.busy = False
+                    self.cv.notify_all()
+            if item.done:
+                break
+        if item.error is not None:
+            raise item.error
+        return item.result
+
+
 class HipFlatVectorStore(VectorStore):
     def __init__(self, embedding, metric: str = "cosine", normalize_L2: bool = False, index_type: str = "flat",
-                 device: int = 0, engine_factory: Optional[Callable] = None, storage: str = "f16", **kwargs: Any):
+                 device: int = 0, engine_factory: Optional[Callable] = None, storage: str = "f16",
+                 coalesce: bool = True, coalesce_window_us: float = 0.0, **kwargs: Any):
         super().__init__(**kwargs)
+        # concurrent one-query callers (the reference's only calling pattern) share scans: see _QueryCoalescer
+        self._coalescer = (_QueryCoalescer(self._run_query_batch, 256, coalesce_window_us * 1e-6) if coalesce else None)
         if storage not in ("f16", "f8", "f32"):
             raise ValueError(f"unsupported row storage: {storage}")
         # "f16"; "f8": e4m3fn bytes + one scale per row (half the HBM footprint); "f32": the reference's own fp32
@@ -105,6 +174,9 @@ class HipFlatVectorStore(VectorStore):
     def similarity_search_with_score(self, query: str, k: int = 4, **kwargs: Any) -> List[Tuple[Document, float]]:
         if self.ntotal == 0:
             return []
+        if self._coalescer is not None and self._batch_embedder() is not None:
+            # text goes into the queue: the leader embeds the whole batch in one encoder call, then scans once
+            return self._to_documents(*self._coalescer.submit(query, min(k, self.ntotal)))
         return self.similarity_search_by_vector_with_score(self.embedding.embed_query(query), k, **kwargs)
 
     def similarity_search_by_vector(self, embedding: List[float], k: int = 4, **kwargs: Any) -> List[Document]:
@@ -113,23 +185,76 @@ class HipFlatVectorStore(VectorStore):
     def similarity_search_by_vector_with_score(self, embedding, k: int = 4, **kwargs: Any):
         if self.ntotal == 0:
             return []
-        qv = np.array([embedding]).astype(np.float32)
         k = min(k, self.ntotal)
-        scores, rows = self.index.search(qv, k)
+        if self._coalescer is not None:
+            scores, rows = self._coalescer.submit(np.asarray(embedding, dtype=np.float32), k)
+        else:
+            qv = np.array([embedding]).astype(np.float32)
+            scores, rows = self.index.search(qv, k)
+            scores, rows = scores[0], rows[0]
+        return self._to_documents(scores, rows)
+
+    def _to_documents(self, scores, rows) -> List[Tuple[Document, float]]:
         out = []
-        for score, row in zip(scores[0], rows[0]):
+        for score, row in zip(scores, rows):
             if row == -1:
                 continue
             out.append((self.docstore[self.index_to_docstore_id[int(row)]], float(score)))
         return out
 
+    # -- batches: many queries, one scan (extension over the reference, which only has nq = 1) ----------------------
+    def _batch_embedder(self) -> Optional[Callable]:
+        """A function texts -> vectors that is the provider's embed_query applied to each text, if the provider has one
+        (`embed_queries`); None otherwise (each caller then embeds its own query before queueing)."""
+        return getattr(self.embedding, "embed_queries_device", None) or getattr(self.embedding, "embed_queries", None)
+
+    def _run_query_batch(self, payloads: Sequence, k: int):
+        """One scan for a batch of queries given as texts and / or vectors; returns [(scores [k], rows [k])] per query."""
+        texts = [i for i, p in enumerate(payloads) if isinstance(p, str)]
+        if texts and len(texts) == len(payloads) and hasattr(self.embedding, "embed_queries_device"):
+            q = self.embedding.embed_queries_device([payloads[i] for i in texts])        # stays in HBM
+        else:
+            vecs: list = list(payloads)
+            if texts:
+                emb = self._batch_embedder()([payloads[i] for i in texts])
+                emb = emb.cpu().numpy() if hasattr(emb, "cpu") else emb
+                for i, v in zip(texts, emb):
+                    vecs[i] = np.asarray(v, dtype=np.float32)
+            q = np.stack([np.asarray(v, dtype=np.float32) for v in vecs])
+        scores, rows = self.index.search(q, min(k, self.ntotal))
+        return list(zip(scores, rows))
+
     def batch_search_by_vector(self, embeddings, k: int = 4):
-        """Extension over the reference (which only has nq = 1): many queries in one scan.
-        Returns (scores fp32 [nq][k], row indices int64 [nq][k])."""
+        """Many query vectors in one scan.  Returns (scores fp32 [nq][k], row indices int64 [nq][k])."""
         if self.ntotal == 0:
             nq = len(embeddings)
             return np.zeros((nq, 0), np.float32), np.zeros((nq, 0), np.int64)
-        return self.index.search(np.asarray(embeddings, dtype=np.float32), min(k, self.ntotal))
+        q = embeddings if hasattr(embeddings, "is_cuda") else np.asarray(embeddings, dtype=np.float32)
+        return self.index.search(q, min(k, self.ntotal))
+
+    def batch_similarity_search_with_score(self, queries: Sequence[str], k: int = 4, **kwargs: Any):
+        """similarity_search_with_score for a list of queries: one encoder call (when the provider can batch), one scan per
+        256 queries.  Element i equals similarity_search_with_score(queries[i], k)."""
+        queries = list(queries)
+        if self.ntotal == 0 or not queries:
+            return [[] for _ in queries]
+        if hasattr(self.embedding, "embed_queries_device"):
+            q = self.embedding.embed_queries_device(queries)
+        elif hasattr(self.embedding, "embed_queries"):
+            q = np.asarray(self.embedding.embed_queries(queries), dtype=np.float32)
+        else:
+            q = np.asarray([self.embedding.embed_query(t) for t in queries], dtype=np.float32)
+        scores, rows = self.batch_search_by_vector(q, k)
+        return [self._to_documents(s, r) for s, r in zip(scores, rows)]
+
+    def batch_similarity_search(self, queries: Sequence[str], k: int = 4, **kwargs: Any) -> List[List[Document]]:
+        return [[d for d, _ in one] for one in self.batch_similarity_search_with_score(queries, k, **kwargs)]
+
+    @property
+    def coalesced_launches(self) -> Tuple[int, int]:
+        """(scans issued, queries answered) by the coalescing front so far."""
+        c = self._coalescer
+        return (0, 0) if c is None else (c.launches, c.served)
 
     def max_marginal_relevance_search(self, query: str, k: int = 4, fetch_k: int = 20, lambda_mult: float = 0.5,
                                       **kwargs: Any) -> List[Document]:

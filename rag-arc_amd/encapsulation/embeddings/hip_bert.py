@@ -244,3 +244,11 @@ class HipBertEmbeddings(Embeddings):
 
     def embed_query(self, text: str) -> List[float]:
         return self.embed_documents([text])[0]
+
+    # embed_query IS embed_documents([text])[0] here, as in the reference (huggingface.py:145): a batch of queries is
+    # therefore one encoder call.  (The vector store's batched search and its coalescing front look for these.)
+    def embed_queries(self, texts: List[str]) -> List[List[float]]:
+        return self.embed_documents(list(texts))
+
+    def embed_queries_device(self, texts: List[str]):
+        return self.embed_documents_device(list(texts))

@@ -162,7 +162,7 @@ class FlatIndexF16:
     def _workspace(self, k: int = 0, scale: int = 1):
         """Scratch for one search.  The candidate buffer grows with k (the int8 margin lets through a number of
         candidates roughly proportional to k): `cand_cap` is per 128 results — k = 996 takes 8 x 268 MB.
-        `scale` multiplies it for the re-run of flagged queries (it never shrinks again)."""
+        (The re-run of flagged queries takes a larger workspace of its own, see _repair_rows.)"""
         t = self.torch
         cap = self.cand_cap * max(1, -(-int(k) // 128)) * max(1, int(scale))
         if self._ws is None or cap > self._cap_eff:
@@ -330,6 +330,10 @@ class FlatIndexF16:
                 other._own_stream = t.cuda.Stream()
         return other
 
+    def _rows_version(self) -> int:
+        """Version of the rows a search reads (a twin reads its parent's)."""
+        return self._parent._version if self._parent is not None else self._version
+
     def _not_a_twin(self) -> None:
         if self._parent is not None:
             raise B.RarcError("a twin() search context is read-only: change the index it was taken from")
@@ -404,7 +408,8 @@ class FlatIndexF16:
                 done = t.cuda.Event()
                 done.record()
                 parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], flag_h,
-                                           status[:e0 - s0], done))
+                                           status[:e0 - s0], done, stream=t.cuda.current_stream(self.device),
+                                           version=self._rows_version()))
             return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc)
 
     def _repair_rows(self, q, k, out_ids, out_sc, flagged) -> None:
@@ -421,11 +426,23 @@ class FlatIndexF16:
         t = self.torch
         stream = self._stream()
         left = list(flagged)
+        big = None
         if left and self.ntotal:
+            # the re-run gets a workspace of ITS OWN with four times the candidate capacity, released afterwards: the
+            # steady-state workspace (and the cand_cap every later search is launched with) stays what it was.  If HBM
+            # cannot spare it the re-run is skipped — the exact per-query scan below needs no extra memory.
+            cap_big = 4 * self.cand_cap * max(1, -(-int(k) // 128))
+            try:
+                big = t.empty(int(self.lib.rarc_search_workspace_bytes(cap_big)), dtype=t.uint8, device=self.device)
+            except (t.cuda.OutOfMemoryError, RuntimeError) as exc:
+                if "out of memory" not in str(exc).lower():
+                    raise
+                big = None
+        if big is not None:
             sel = t.as_tensor(left, dtype=t.long, device=self.device)
             sub_q = q[sel].contiguous()
             prev_i, prev_s = out_ids[sel].contiguous(), out_sc[sel].contiguous()
-            ws = self._workspace(k, scale=4)
+            self._workspace(k)
             b = self._qbuf
             # (queries the fp16 scan flagged UNCERTAIN — its certificate cannot separate rows closer than its own
             #  error bound, as in tight clusters — go through the int8-prefilter path, which needs no certificate)
@@ -439,7 +456,7 @@ class FlatIndexF16:
             kp = k if use_q8 else self.kprime_for(k)
             rows_ptr = self._rows.data_ptr()
             qm = self._qmeta.data_ptr() if (use_q8 and self._qmeta is not None) else 0
-            self._call_search(rows_ptr, qm, len(left), k, kp, lo, hi, new_i, new_s, status, ws, stream)
+            self._call_search(rows_ptr, qm, len(left), k, kp, lo, hi, new_i, new_s, status, big, stream, cap=cap_big)
             st = status[: len(left)].cpu()
             ok = (st == 0)
             if bool(ok.any()):
@@ -448,6 +465,8 @@ class FlatIndexF16:
                 out_sc[good] = new_s[ok.to(self.device)]
             left = [qi for qi, fine in zip(left, ok.tolist()) if not fine]
             self.last_rerun = len(flagged) - len(left)
+            t.cuda.current_stream(self.device).synchronize()   # the re-run has finished with `big` before it is released
+            del big
         if not left:
             return
         ws, b = self._workspace(k), self._qbuf
@@ -457,30 +476,31 @@ class FlatIndexF16:
             if int(b["found"].item()) & 0x80000000:
                 raise B.RarcError(f"repair of query {qi} overflowed its scratch list")
 
-    def _call_search(self, rows_ptr, qm, nq, k, kp, lo, hi, out_ids, out_sc, status, ws, stream) -> None:
+    def _call_search(self, rows_ptr, qm, nq, k, kp, lo, hi, out_ids, out_sc, status, ws, stream, cap=None) -> None:
         b = self._qbuf
+        cap = self._cap_eff if cap is None else int(cap)
         if self.storage == "f8":
             sc_ptr = self._rowscale.data_ptr() if self._rowscale is not None else 0
             B.check(self.lib.rarc_search_f8(rows_ptr, sc_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k,
                                             kp, self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
-                                            status.data_ptr(), ws.data_ptr(), ws.numel(), self._cap_eff, stream),
+                                            status.data_ptr(), ws.data_ptr(), ws.numel(), cap, stream),
                     "rarc_search_f8")
         elif self.storage == "f32":
             img = self._image16.data_ptr() if self._image16 is not None else 0
             B.check(self.lib.rarc_search_f32(rows_ptr, img, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k,
                                              kp, self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
-                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self._cap_eff, stream),
+                                             status.data_ptr(), ws.data_ptr(), ws.numel(), cap, stream),
                     "rarc_search_f32")
         elif self.shadow and qm and self._shadow is not None:
             B.check(self.lib.rarc_search_f16_shadow(rows_ptr, self._shadow.data_ptr(), self.ntotal, self.d_pad, qm,
                                                     b["qblock"].data_ptr(), nq, k, kp, self.id_base, lo, hi,
                                                     out_ids.data_ptr(), out_sc.data_ptr(), status.data_ptr(),
-                                                    ws.data_ptr(), ws.numel(), self._cap_eff, stream),
+                                                    ws.data_ptr(), ws.numel(), cap, stream),
                     "rarc_search_f16_shadow")
         else:
             B.check(self.lib.rarc_search_f16(rows_ptr, self.ntotal, self.d_pad, qm, b["qblock"].data_ptr(), nq, k, kp,
                                              self.id_base, lo, hi, out_ids.data_ptr(), out_sc.data_ptr(),
-                                             status.data_ptr(), ws.data_ptr(), ws.numel(), self._cap_eff, stream),
+                                             status.data_ptr(), ws.data_ptr(), ws.numel(), cap, stream),
                     "rarc_search_f16")
 
     def _call_repair(self, qi, k, out_ids, out_sc, ws, stream) -> None:
@@ -579,20 +599,22 @@ class FlatIndexF16:
             return int(b["found"].item())
 
 
-    def verify_batch(self, queries, ids, scores, which=None) -> int:
-        """Exact check of whole answers: for the queries `which` (default: all) count the rows of the shard that beat
-        the stored k-th entry, by a canonical scan that reads every row once per EIGHT queries (rarc_verify_batch).
-        Returns the total over the queries (0 == every checked answer is exact)."""
+    def verify_batch(self, queries, ids, scores, which=None, detail: bool = False):
+        """Exact check of whole answers: for the queries `which` (default: all), by a canonical scan that reads every row
+        once per EIGHT queries (rarc_verify_batch), (a) count the rows of the shard that beat the stored k-th entry and
+        (b) look every row at or above the k-th entry up in the answer, (id, canonical score) compared bit for bit.
+        Returns the number of rows beating a k-th entry PLUS the number of answer entries that are not such an exact
+        pair (0 == every checked answer is exact, entry by entry); detail=True returns the two figures separately."""
         t = self.torch
         fmt = {"f16": 0, "f8": 1, "f32": 2}[self.storage]
         nq, k = ids.shape
         which = list(range(nq)) if which is None else sorted(set(int(w) for w in which))
-        total = 0
+        beating = wrong = 0
         with self._lock, t.cuda.device(self.device):
             self._workspace()
             b = self._qbuf
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
-            counts = t.zeros(8, dtype=t.int32, device=self.device)
+            counts = t.zeros(16, dtype=t.int32, device=self.device)
             sc_ptr = self._rowscale.data_ptr() if self._rowscale is not None else 0
             for c0 in range(0, nq, B.MAX_QUERIES):
                 c1 = min(nq, c0 + B.MAX_QUERIES)
@@ -612,23 +634,35 @@ class FlatIndexF16:
                                                        b["qblock"].data_ptr(), first, n, k, self.id_base, ids_c.data_ptr(),
                                                        sc_c.data_ptr(), counts.data_ptr(), self._stream()),
                             "rarc_verify_batch")
-                    got = counts[:n].cpu().numpy().astype(np.int64)
+                    c_h = counts.cpu().numpy().astype(np.int64)
+                    got, pairs = c_h[:n], c_h[8:8 + n]
+                    valid_all = (ids_c[first:first + n] >= 0).sum(dim=1).cpu().numpy().astype(np.int64)
                     valid = (ids_c[first:first + n, : k - 1] >= 0).sum(dim=1).cpu().numpy().astype(np.int64)
-                    total += int(np.maximum(got - valid, 0).sum())
+                    full = (ids_c[first:first + n, k - 1] >= 0).cpu().numpy()      # (short answers are not pair-checked)
+                    beating += int(np.maximum(got - valid, 0).sum())
+                    wrong += int(np.where(full, np.maximum(valid_all - pairs, 0), 0).sum())
                     i = j + 1
-        return total
+        return (beating, wrong) if detail else beating + wrong
 
 
 class PendingSearch:
     """Handle returned by FlatIndexF16.search_async."""
 
-    def __init__(self, index, q, k, ids, scores, flag, status, done=None):
+    def __init__(self, index, q, k, ids, scores, flag, status, done=None, stream=None, version=None):
         self.index, self.q, self.k, self.ids, self.scores, self.flag, self.status = index, q, k, ids, scores, flag, status
         self.done = done        # event recorded behind the copy of the status word into pinned memory (`flag`)
+        self.stream = stream    # the stream the search was enqueued on (a twin's side stream, else the caller's)
+        self.version = version  # version of the rows when it was enqueued
         self.repaired = None
 
     def result(self):
-        """(ids int64 [nq][k], scores fp32 [nq][k]) device tensors, exact."""
+        """(ids int64 [nq][k], scores fp32 [nq][k]) device tensors, exact.
+
+        A flagged query is repaired HERE, and the repair reuses the index's query block and workspace — which later
+        batches of the same index (the other 256-query chunks of a PendingBatches, a twin's next batch) may still be
+        reading.  So the repair is enqueued on the stream the search itself ran on: behind everything already queued
+        there, ahead of everything queued later, whatever stream the collecting thread happens to be on; and that
+        stream is drained before the answer is handed out, so it is safe to use on any stream."""
         if self.repaired is None:
             t = self.index.torch
             self.repaired = []
@@ -636,8 +670,13 @@ class PendingSearch:
                 self.done.synchronize()   # this batch only: later batches keep running
             if int(self.flag[0] if self.done is not None else self.flag.item()):
                 self.repaired = t.nonzero(self.status).flatten().tolist()
-                with self.index._lock, t.cuda.device(self.index.device):
+                if self.version is not None and self.version != self.index._rows_version():
+                    raise B.RarcError("the index rows changed while a search was in flight: its flagged queries cannot be "
+                                      "repaired against the rows it scanned (collect results before add() / reset())")
+                stream = self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)
+                with self.index._lock, t.cuda.device(self.index.device), t.cuda.stream(stream):
                     self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired)
+                    stream.synchronize()
             self.index.last_repaired = self.repaired
         return self.ids, self.scores
 

@@ -320,8 +320,24 @@ def test_batched_exact_verification(hip, oracle, storage):
         bad_i[qi, k - 1] = worst_i[qi, 0]
         bad_s[qi, k - 1] = -worst_s[qi, 0]
     # the planted entry is the query's WORST row: every other row beats it, k - 1 of them already listed in the answer
-    assert idx.verify_batch(Q, bad_i, bad_s) == 3 * (n - k)
-    assert idx.verify_batch(Q, bad_i, bad_s, which=[4]) == n - k and idx.verify_batch(Q, bad_i, bad_s, which=[5, 6]) == 0
+    assert idx.verify_batch(Q, bad_i, bad_s, detail=True)[0] == 3 * (n - k)
+    assert idx.verify_batch(Q, bad_i, bad_s, which=[4], detail=True)[0] == n - k and idx.verify_batch(Q, bad_i, bad_s, which=[5, 6]) == 0
+    # every returned (id, score) pair is checked, not only the k-th: a score one ulp off, an id swapped for a
+    # row that does not belong, and two entries exchanged (ids and scores no longer paired) are each reported
+    for corrupt in ("score", "id", "swap"):
+        c_i, c_s = ids.clone(), sc.clone()
+        if corrupt == "score":
+            c_s[2, 5] = torch.nextafter(c_s[2, 5], c_s[2, 5] + 1)
+            c_s[7, 0] = torch.nextafter(c_s[7, 0], c_s[7, 0] - 1)
+        elif corrupt == "id":
+            c_i[2, 5] = worst_i[2, 0]
+            c_i[7, 0] = worst_i[7, 0]
+        else:
+            c_i[2, 5], c_i[2, 6] = ids[2, 6], ids[2, 5]
+            c_i[7, 0], c_i[7, 1] = ids[7, 1], ids[7, 0]
+        beating, wrong = idx.verify_batch(Q, c_i, c_s, detail=True)
+        assert wrong == (4 if corrupt == "swap" else 2), (corrupt, beating, wrong)
+        assert idx.verify_batch(Q, c_i, c_s, which=[0, 1, 3]) == 0
 
 
 def test_twin_search_context_two_streams(oracle):
