@@ -88,17 +88,37 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def count_gpus_sysfs():
+    """GPUs of this node per the amdkfd topology (nodes with simd_count > 0), honouring HIP/ROCR_VISIBLE_DEVICES as a count;
+    None when the topology is not readable."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(a, argv) -> int:
     """Start a.gpus ranks of this script under torch.distributed.run and relay rank 0's JSON line.
-    Runs before anything in this process has initialised the GPU (device_count() does not)."""
+    The parent never touches the GPU runtime: the devices are counted from the kernel driver's topology in sysfs
+    (/sys/class/kfd: one node per agent, GPUs are those with SIMDs), not through torch / HIP — a device count through the
+    runtime can bring the runtime up in this process.  When sysfs cannot tell, the ranks themselves report a
+    missing device."""
     if a.one_device and a.backend != "gloo":
         print("bench.py: --one-device needs --backend gloo (RCCL refuses two ranks on one device)", file=sys.stderr)
         return 2
     if not a.dry_run and not a.one_device:
-        import torch
-
-        n_dev = torch.cuda.device_count()
-        if n_dev < a.gpus:
+        n_dev = count_gpus_sysfs()
+        if n_dev is not None and n_dev < a.gpus:
             print(f"bench.py: --gpus {a.gpus} but only {n_dev} GPU(s) visible on this node", file=sys.stderr)
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
@@ -302,6 +322,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if a.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or os.environ.get("RARC_FORCE_DIST") == "1"   # the env var exercises RCCL with one rank
+    if torch.cuda.device_count() <= local_rank:    # (a rank is its own process: counting devices here is this rank's business)
+        print(f"bench.py: --gpus {a.gpus} but only {torch.cuda.device_count()} GPU(s) visible on this node", file=sys.stderr)
+        sys.exit(2)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -7,10 +7,14 @@ What is restated here, and how it is pinned:
 
 * flat inner-product search / L2 normalisation (faiss arithmetic reached from
   encapsulation/database/vector_db/VectorStore_Faiss.py:150-154, :170-202, :258-272):
-  thin ctypes wrappers over oracle/rarc_oracle.c.  faiss is not vendored in /root/reference, no
-  version is pinned there and the reference holds no golden vector for it -> "parity unpinned"
-  (see the header of rarc_oracle.c and DESIGN.md).  A float64 numpy cross-check
-  (`flat_search_f64`) bounds the canonical fp32 scores to the 1e-5 the north star asks for.
+  thin ctypes wrappers over oracle/rarc_oracle.c.  faiss is not vendored in /root/reference and not
+  installed here; PINNED instead to the reference's own float64 cosine (spliter.py:326-332) run on
+  64 x 4096 fp16-representable vectors at d = 384 / 768 (tests/golden/cosine_pin_d*.npz, 1e-5; see
+  the header of rarc_oracle.c and DESIGN.md §2).  A float64 numpy cross-check (`flat_search_f64`)
+  bounds the canonical fp32 scores to the 1e-5 the north star asks for on any input.
+* BERT forward (`bert_forward_f32`, float32 or float64) and the reranker's LM forward
+  (`qwen3_last_logits_f32`): numpy graphs PINNED against transformers.BertModel /
+  transformers.Qwen3ForCausalLM with seeded weights (tests/test_oracle_golden.py).
 * reciprocal-rank fusion (core/utils/Fusion.py:45-76), the relevance-score quirk
   (encapsulation/database/vector_db/VectorStoreBase.py:263-266) and the reranker's
   score->order step (core/rerank/Reranker_Qwen3.py:41-49, :70-74): pure python / numpy below,

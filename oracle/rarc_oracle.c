@@ -4,13 +4,17 @@
  * A restatement of the arithmetic of RAG-ARC's dense-retrieval hot path, used only by tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker / timed CPU baseline.
  *
- * PARITY STATUS: the reference reaches this arithmetic through faiss, which is NOT vendored in
- * /root/reference (requirements.txt is empty, no version pinned) and is not installed here, and
- * the reference holds no test, fixture or golden vector for it.  The flat
- * search / normalise parts of this oracle are therefore "parity unpinned": they restate faiss's
- * published contract — normalize_L2 = x * (1/sqrt(sum x^2)) in fp32 with zero rows untouched
- * (fvec_renorm_L2), IndexFlatIP.search = exact fp32 inner products sorted by score descending,
- * int64 labels, -1 padding — at the reference's call sites:
+ * PARITY STATUS: PINNED (round 2) to numbers the reference itself produced.  The reference reaches this arithmetic
+ * through faiss, which is NOT vendored in /root/reference (requirements.txt is empty, no version pinned) and is not
+ * installed here, so faiss's own outputs cannot be recorded; what IS importable from the reference and computes the same
+ * quantity is its float64 cosine (core/file_management/chunker/spliter.py:326-332, `cosine_similarity`).
+ * tests/golden/make_golden.py ran it on 64 queries x 4096 rows of fp16-representable vectors at d = 384 and 768
+ * (tests/golden/cosine_pin_d*.npz); tests/test_oracle_golden.py::test_flat_search_pinned_to_reference_float64 holds this
+ * oracle (fp16 and fp32 rows) to those numbers within 1e-5 (measured < 2e-6) on all 262 144 pairs, with the reference's
+ * top-100 set / order wherever its gaps exceed the tolerance; tests/test_gpu_reference_pin.py holds the HIP index to the
+ * same check.  Beyond that pin the flat search / normalise parts restate faiss's published contract — normalize_L2 =
+ * x * (1/sqrt(sum x^2)) in fp32 with zero rows untouched (fvec_renorm_L2), IndexFlatIP.search = exact fp32 inner
+ * products sorted by score descending, int64 labels, -1 padding — at the reference's call sites:
  *   encapsulation/database/vector_db/VectorStore_Faiss.py:150-154  (_normalize_vectors)
  *   encapsulation/database/vector_db/VectorStore_Faiss.py:170-202  (add_texts: astype(f32), normalise, add)
  *   encapsulation/database/vector_db/VectorStore_Faiss.py:258-272  (query: astype(f32), normalise, k=min(k,ntotal), search)

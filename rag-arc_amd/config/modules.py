@@ -231,7 +231,28 @@ class HipQwen3RerankerConfig(AbstractConfig):
 
                 tok = _LibraryTokenizer
         elif self.vocab_path and self.merges_path:
-            special = {t: i for i, t in enumerate(self.SPECIAL_TOKENS, start=self.FIRST_SPECIAL_ID)}
+            import json
+            import os
+
+            # the added tokens: the checkpoint's own list (tokenizer_config.json: added_tokens_decoder) when it lies next to
+            # vocab.json; otherwise Qwen2 / Qwen3's, but only if they fit THIS vocabulary — the first special id must follow
+            # the last vocab.json id and none of the tokens may already be an ordinary token; anything else fails loudly
+            special = None
+            cfg_path = os.path.join(os.path.dirname(os.path.abspath(self.vocab_path)), "tokenizer_config.json")
+            if os.path.exists(cfg_path):
+                with open(cfg_path, encoding="utf-8") as fh:
+                    dec = json.load(fh).get("added_tokens_decoder") or {}
+                special = {v["content"]: int(i) for i, v in dec.items()} or None
+            if special is None:
+                with open(self.vocab_path, encoding="utf-8") as fh:
+                    vocab = json.load(fh)
+                clash = [t for t in self.SPECIAL_TOKENS if t in vocab]
+                if max(vocab.values()) + 1 != self.FIRST_SPECIAL_ID or clash:
+                    raise ValueError(f"hip_qwen3_reranker: {self.vocab_path} is not Qwen2/Qwen3's vocabulary (last id "
+                                     f"{max(vocab.values())}, expected {self.FIRST_SPECIAL_ID - 1}; special tokens already "
+                                     f"present: {clash[:3]}): give tokenizer_path (tokenizer.json) or put the checkpoint's "
+                                     f"tokenizer_config.json next to vocab.json")
+                special = {t: i for i, t in enumerate(self.SPECIAL_TOKENS, start=self.FIRST_SPECIAL_ID)}
             tok = ByteLevelBPETokenizer.from_files(self.vocab_path, self.merges_path, special)
         else:
             raise ValueError("hip_qwen3_reranker: give tokenizer_path, or vocab_path and merges_path")

@@ -46,10 +46,10 @@ class ByteLevelBPETokenizer:
         self.vocab = dict(vocab)
         self.ranks: Dict[Tuple[str, str], int] = {}
         for line in merges:
+            if isinstance(line, str) and (not line.strip() or line.startswith("#version")):
+                continue                                       # header ("#version: 0.2" splits into two fields!) / blank line
             pair = tuple(line.split(" ")) if isinstance(line, str) else tuple(line)
             if len(pair) != 2:
-                if isinstance(line, str) and (not line.strip() or line.startswith("#version")):
-                    continue                                   # header / blank line of a merges.txt
                 raise ValueError(f"merge rule {line!r} is not a pair")
             self.ranks.setdefault(pair, len(self.ranks))
         self.special = dict(special_tokens or {})
