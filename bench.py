@@ -58,6 +58,8 @@ def parse(argv=None):
     ap.add_argument("--no-lm", action="store_true", help="config 3 without its cross-encoder's LM forward (seeded logits instead)")
     ap.add_argument("--c3-steps", type=int, default=2, help="timed steps of the config-3 leg (one step = 256 x 100 LM prompts, seconds)")
     ap.add_argument("--c3-chunk", type=int, default=640, help="(query, document) prompts per LM call in the config-3 leg")
+    ap.add_argument("--c3-no-prefix-sharing", action="store_true",
+                    help="config 3: run every (query, document) prompt whole (the reference's way) instead of the shared part once per query")
     ap.add_argument("--c5-rows", type=int, default=0, help="rows of the config-5 corpus (0 = auto: 100M if it fits)")
     ap.add_argument("--c5-layers", type=int, default=24, help="encoder depth of the config-5 leg (bge-large: 24)")
     ap.add_argument("--encoder-precision", choices=("fp32", "fp16"), default="fp32",
@@ -499,31 +501,49 @@ def _mix64(torch, key, pos):
     return (x >> 17) & 0x7FFFFFFF
 
 
-def c3_pair_tokens(torch, qidx, doc, Lc, vocab):
-    """LEFT-padded token ids [n][Lc] (int32) + first-real-token index [n] (int32) of the prompts for pairs (query qidx[i],
-    document doc[i]): template tokens depend on the position only (the same ids in every pair, like a real template), query
-    tokens on (query, position), document tokens on (document id, position); lengths per C3_TPL / C3_DOC_*."""
+def _c3_fixed():
     t = C3_TPL
+    q0 = t["prefix"] + t["instruct"] + t["query_hdr"]            # first query token
+    d0 = q0 + t["query"] + t["doc_hdr"]                          # first document token = length of the part shared by a query's prompts
+    return q0, d0, d0 + t["suffix"]
+
+
+def c3_pair_lengths(torch, doc):
+    """prompt length of each (query, document) pair"""
+    return _c3_fixed()[2] + C3_DOC_MIN + _mix64(torch, doc, torch.zeros_like(doc) - 1) % C3_DOC_SPAN
+
+
+def c3_pair_tokens(torch, qidx, doc, Lc, vocab, p_lo=0):
+    """LEFT-padded token ids [n][Lc] (int32) + first-real-token index [n] (int32) of prompt positions [p_lo, length) of the
+    pairs (query qidx[i], document doc[i]) — p_lo = 0: the whole prompts; p_lo = the shared length: what follows the part all
+    prompts of a query have in common.  Template tokens depend on the position only (the same ids in every pair, like a real
+    template), query tokens on (query, position), document tokens on (document id, position); lengths per C3_TPL / C3_DOC_*."""
+    t = C3_TPL
+    q0, d0, fixed = _c3_fixed()
     dl = C3_DOC_MIN + _mix64(torch, doc, torch.zeros_like(doc) - 1) % C3_DOC_SPAN
-    fixed = t["prefix"] + t["instruct"] + t["query_hdr"] + t["query"] + t["doc_hdr"] + t["suffix"]
     ell = fixed + dl
-    pos = torch.arange(Lc, device=doc.device)[None, :] - (Lc - ell)[:, None]            # < 0: padding
-    q0 = t["prefix"] + t["instruct"] + t["query_hdr"]
-    d0 = q0 + t["query"] + t["doc_hdr"]
+    pos = torch.arange(Lc, device=doc.device)[None, :] - (Lc - (ell - p_lo))[:, None] + p_lo      # < p_lo: padding
     in_q = (pos >= q0) & (pos < q0 + t["query"])
     in_d = (pos >= d0) & (pos < d0 + dl[:, None])
     key = torch.where(in_q, (qidx[:, None] + 1) * 1_000_003, torch.where(in_d, doc[:, None] + (1 << 40), torch.zeros_like(pos)))
     # (suffix positions are counted from the end so that the suffix ids do not depend on the document length)
     ppos = torch.where(pos >= d0 + dl[:, None], pos - ell[:, None] + (1 << 20), pos)
     tok = 10 + _mix64(torch, key, ppos) % (vocab - 10)
-    ids = torch.where(pos >= 0, tok, torch.zeros_like(tok)).int().contiguous()
-    return ids, (Lc - ell).int().contiguous(), ell
+    ids = torch.where(pos >= p_lo, tok, torch.zeros_like(tok)).int().contiguous()
+    return ids, (Lc - (ell - p_lo)).int().contiguous(), ell
 
 
-def c3_pair_lengths(torch, doc):
+def c3_shared_tokens(torch, nq, P, vocab, dev):
+    """The part every prompt of a query shares (chat prefix, instruction, query, "<Document>: "): [nq][P] LEFT padded + starts."""
+    q0, d0, _ = _c3_fixed()
     t = C3_TPL
-    return (t["prefix"] + t["instruct"] + t["query_hdr"] + t["query"] + t["doc_hdr"] + t["suffix"] + C3_DOC_MIN
-            + _mix64(torch, doc, torch.zeros_like(doc) - 1) % C3_DOC_SPAN)
+    pos = (torch.arange(P, device=dev)[None, :] - (P - d0)).expand(nq, P)
+    qidx = torch.arange(nq, device=dev)
+    in_q = (pos >= q0) & (pos < q0 + t["query"])
+    key = torch.where(in_q, ((qidx[:, None] + 1) * 1_000_003).expand(nq, P), torch.zeros_like(pos))
+    tok = 10 + _mix64(torch, key, pos) % (vocab - 10)
+    ids = torch.where(pos >= 0, tok, torch.zeros_like(tok)).int().contiguous()
+    return ids, torch.full((nq,), P - d0, dtype=torch.int32, device=dev)
 
 
 LM_GEOM = dict(H=1024, LAYERS=28, NQ=16, NKV=8, DH=128, I=3072, V=151_669)   # Qwen3-Reranker-0.6B
@@ -602,28 +622,40 @@ def leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, dense_ids, n2, a, steps, wa
     z_all = torch.empty((n_pairs, 2), dtype=torch.float16, device=dev)
     lm_ev, stats = [], {}
 
+    share = not a.c3_no_prefix_sharing
+    q0_, d0_, fixed_ = _c3_fixed()
+    P_sh = -(-d0_ // 32) * 32
+    pre_ids, pre_start = c3_shared_tokens(torch, nq, P_sh, V, dev)
+
     def rerank_fuse(ids):
-        """the cross-encoder over every (query, top-k document) pair of the batch, then order and fuse"""
+        """the cross-encoder over every (query, top-k document) pair of the batch, then order and fuse.  With prefix sharing
+        (default) the part the 100 prompts of a query have in common — chat prefix, instruction, query: 79 of ~216 tokens —
+        runs through the LM once per query (rarc_lm_prefix_kv) and only what follows it per pair."""
         doc = ids.reshape(-1)
         ell = c3_pair_lengths(torch, doc)
+        p_lo = d0_ if share else 0
         order = torch.argsort(ell, stable=True)
         ell_s = ell[order]
         starts = list(range(0, n_pairs, CH))
         cmax = [int(v) for v in torch.stack([ell_s[min(s0 + CH, n_pairs) - 1] for s0 in starts]).cpu().tolist()]   # one read-back
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        tokens = 0
+        handle = lm.prefix_kv_device(pre_ids, pre_start) if share else None
+        tokens = nq * P_sh if share else 0
         for s0, mx in zip(starts, cmax):
             sel = order[s0:s0 + CH]
             if sel.numel() % 4:      # (n_pairs is a multiple of 4 whenever k is: not hit at the defaults)
                 sel = torch.cat([sel, sel[-1:].expand(4 - sel.numel() % 4)])
-            Lc = -(-mx // 32) * 32
-            t_ids, t_start, _ = c3_pair_tokens(torch, qidx_all[sel], doc[sel], Lc, V)
-            z_all[sel] = lm.yes_no_logits_device(t_ids, t_start, NO_ID, YES_ID)
+            Lc = -(-(mx - p_lo) // 32) * 32
+            t_ids, t_start, _ = c3_pair_tokens(torch, qidx_all[sel], doc[sel], Lc, V, p_lo)
+            if share:
+                z_all[sel] = lm.yes_no_logits_device(t_ids, t_start, NO_ID, YES_ID, prefix=handle, prefix_of=qidx_all[sel].int())
+            else:
+                z_all[sel] = lm.yes_no_logits_device(t_ids, t_start, NO_ID, YES_ID)
             tokens += int(sel.numel()) * Lc
         e1.record()
         lm_ev.append((e0, e1))
-        stats.update(padded_tokens=tokens, real_tokens=None, ell=ell)
+        stats.update(padded_tokens=tokens, ell=ell)
         z = z_all.view(nq, K, 2)
         _, perm = rr.score_order(z[:, :, 0].contiguous(), z[:, :, 1].contiguous())
         keys = torch.stack([torch.gather(ids, 1, perm.long()), lex], dim=1)
@@ -640,37 +672,55 @@ def leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, dense_ids, n2, a, steps, wa
     torch.cuda.synchronize()
     lm_ms = sum(x.elapsed_time(y) for x, y in lm_ev) / max(1, len(lm_ev))
     ell = stats["ell"].double()
-    real_tokens = float(ell.sum().item())
     g_mix = 2.0 * H * (NQ + 2 * NKV) * DH
     g_rest = 2.0 * (NQ * DH * H + H * 2 * I + I * H)
-    # algorithmic flops of one step's LM work: projections on the REAL tokens (the last layer's output projection and MLP on
-    # the last position only, as rarc_lm_yes_no_logits computes them), causal attention over real keys
-    flops = (LAYERS * (real_tokens * g_mix + 2.0 * NQ * DH * float((ell * (ell + 1)).sum().item()))
-             + (LAYERS - 1) * real_tokens * g_rest + n_pairs * g_rest)
+    att = 2.0 * NQ * DH          # flops per (query token, visible key) pair and layer, per product (q.k, p.v)
+    # algorithmic flops of one step's LM work AS THE PATH RUNS IT: projections on the real tokens (the last layer's output
+    # projection and MLP on the last position only, as rarc_lm_yes_no_logits computes them), causal attention over real keys
+    if share:
+        own = ell - d0_                                   # tokens of a pair after the shared part
+        real_tokens = float(own.sum().item()) + nq * d0_
+        shared_flops = nq * ((LAYERS - 1) * (d0_ * (g_mix + g_rest) + att * 2.0 * d0_ * (d0_ + 1) / 2.0) + d0_ * g_mix)
+        pair_keys = float((own * d0_ + own * (own + 1) / 2.0).sum().item())          # visible keys summed over a pair's own tokens
+        flops = (shared_flops + LAYERS * (float(own.sum().item()) * g_mix + att * 2.0 * pair_keys)
+                 + (LAYERS - 1) * float(own.sum().item()) * g_rest + n_pairs * g_rest)
+    else:
+        real_tokens = float(ell.sum().item())
+        flops = (LAYERS * (real_tokens * g_mix + att * float((ell * (ell + 1)).sum().item()))
+                 + (LAYERS - 1) * real_tokens * g_rest + n_pairs * g_rest)
+    flops_unshared = (LAYERS * (float(ell.sum().item()) * g_mix + att * float((ell * (ell + 1)).sum().item()))
+                      + (LAYERS - 1) * float(ell.sum().item()) * g_rest + n_pairs * g_rest)
     out = {"workload": f"config 3 end to end, cross-encoder included: {n2}x{a.dim} fp16 scan top-{K} -> LM forward on {nq} x {K} = "
                        f"{n_pairs} templated (query, document) prompts of {int(ell.min().item())}-{int(ell.max().item())} tokens "
                        f"(Qwen3-Reranker-0.6B geometry: {LAYERS} layers, hidden {H}, {NQ}/{NKV} heads of {DH}, ffn {I}, vocabulary {V}; "
                        f"seeded fp16 weights) -> p_yes -> stable order -> RRF with a supplied lexical list, batch {nq}, 1 GPU",
            "value": round(nq * st3 / dt, 2), "unit": "queries/s", "ms_per_step": round(dt / st3 * 1e3, 3), "steps": st3, "warmup": w3,
            "pairs_per_s": round(n_pairs * st3 / dt, 1), "lm_ms_per_step": round(lm_ms, 3),
+           "prefix_sharing": (f"the {d0_} tokens every prompt of a query shares run through the LM once per query (k | v cached, "
+                              f"rarc_lm_prefix_kv); each pair runs its remaining {C3_DOC_MIN + C3_TPL['suffix']}-"
+                              f"{C3_DOC_MIN + C3_DOC_SPAN - 1 + C3_TPL['suffix']} tokens") if share else "off (--c3-no-prefix-sharing)",
            "prompt_tokens": {"template": C3_TPL, "document": f"{C3_DOC_MIN}..{C3_DOC_MIN + C3_DOC_SPAN - 1} by a hash of the document id",
-                             "real_tokens_per_step": int(real_tokens), "padded_tokens_per_step": int(stats["padded_tokens"]),
+                             "prompt_tokens_per_step": int(ell.sum().item()),
+                             "tokens_through_the_lm_per_step": int(real_tokens), "padded_tokens_per_step": int(stats["padded_tokens"]),
                              "chunk_pairs": CH, "note": "template token counts are word-count estimates (Qwen's vocabulary does not ship offline)"},
            "fused_entries_per_query": int(fn.min().item()),
            "roofline": {"bound": "mfma", "kernel": "rarc_gemm256_f16_kernel / rarc_gemm256x128_f16_kernel (LM projections), rarc_lm_attention_kernel<128>",
                         "achieved": round(flops / (lm_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(flops / (lm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4), "flops_per_step": flops,
+                        "flops_per_step_without_prefix_sharing": flops_unshared,
                         "timed": "HIP events around the LM calls of a step (token synthesis, chunk gather and scatter included)",
                         "end_to_end_frac": round(flops / (dt / st3) / 1e12 / MFMA_F16_PEAK_TF, 4)},
            "without_lm_forward": no_lm}
     if sd_host is not None:
-        out["cpu_baseline"], out["lm_parity_vs_oracle"] = cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, NO_ID, YES_ID, K)
+        out["cpu_baseline"], out["lm_parity_vs_oracle"] = cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, NO_ID, YES_ID, K,
+                                                                          (pre_ids, pre_start, d0_) if share else None)
     return out
 
 
-def cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, no_id, yes_id, K):
+def cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, no_id, yes_id, K, shared=None):
     """The reranker's LM forward on the host (numpy fp32 oracle, pinned to transformers.Qwen3ForCausalLM) on four of the
-    step's prompts, timed — and the device logits of the same four prompts checked against it."""
+    step's prompts — WHOLE prompts, the reference's way —, timed; and the device logits of the same four prompts (through
+    the shared-prefix path when the leg uses it) checked against it."""
     from oracle import cpu_ref
 
     G = LM_GEOM
@@ -680,7 +730,14 @@ def cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, no_id, yes_i
     pick = order[torch.tensor([0, len(order) // 3, 2 * len(order) // 3, len(order) - 1], device=order.device)]
     Lc = -(-int(ell[pick].max().item()) // 32) * 32
     t_ids, t_start, _ = c3_pair_tokens(torch, qidx_all[pick], doc[pick], Lc, V)
-    got = lm.yes_no_logits_device(t_ids, t_start, no_id, yes_id).float().cpu().numpy()
+    if shared is None:
+        got = lm.yes_no_logits_device(t_ids, t_start, no_id, yes_id).float().cpu().numpy()
+    else:
+        pre_ids, pre_start, d0 = shared
+        Ls = -(-int((ell[pick] - d0).max().item()) // 32) * 32
+        s_ids, s_start, _ = c3_pair_tokens(torch, qidx_all[pick], doc[pick], Ls, V, d0)
+        got = lm.yes_no_logits_device(s_ids, s_start, no_id, yes_id, prefix=lm.prefix_kv_device(pre_ids, pre_start),
+                                      prefix_of=qidx_all[pick].int()).float().cpu().numpy()
     ids_h, start_h = t_ids.cpu().numpy(), t_start.cpu().numpy()
     mask = (np.arange(Lc)[None, :] >= start_h[:, None]).astype(np.int64)
     t0 = time.perf_counter()

@@ -455,6 +455,25 @@ int rarc_lm_yes_no_logits(const RarcLmModel* model, const int32_t* d_ids, const 
                           void* stream);
 
 /*
+ * Shared prompt prefixes.  The prompts Qwen3Reranker.rerank scores for ONE query (Reranker_Qwen3.py:23-27,57-66) are
+ * identical up to the document text — chat prefix, instruction, query: ~80 of ~220 tokens — and in a causal LM the keys and
+ * values of those tokens do not depend on what follows them.  rarc_lm_prefix_kv runs the n_prefix LEFT-padded prefixes
+ * [n_prefix][prefix_len] once and stores every layer's raw k | v rows in d_cache (rarc_lm_prefix_cache_bytes(model,
+ * n_prefix * prefix_len) bytes); rarc_lm_yes_no_logits_prefixed then runs only the REMAINDERS d_ids [n_seq][seq_len] (left
+ * padded), sequence s attending to the cache rows of prefix d_prefix_of[s] (from d_prefix_start[prefix]) and then to its own
+ * tokens; rotary positions continue from prefix_len.  Same logits as rarc_lm_yes_no_logits on the concatenated prompts up to
+ * fp16 rounding (rotary embeddings are relative; the softmax sums run in a different order).  n_prefix * prefix_len and
+ * n_seq * seq_len multiples of 128.  d_prefix_of[s] = -1: no prefix for s.
+ */
+size_t rarc_lm_prefix_cache_bytes(const RarcLmModel* model, int n_prefix_tokens);
+int rarc_lm_prefix_kv(const RarcLmModel* model, const int32_t* d_ids, const int32_t* d_start, int n_prefix, int prefix_len,
+                      void* d_ws, size_t ws_bytes, void* d_cache, size_t cache_bytes, void* stream);
+int rarc_lm_yes_no_logits_prefixed(const RarcLmModel* model, const int32_t* d_ids, const int32_t* d_start, int n_seq,
+                                   int seq_len, const int32_t* d_prefix_of, const void* d_cache, int n_prefix,
+                                   int prefix_len, const int32_t* d_prefix_start, int no_id, int yes_id, void* d_ws,
+                                   size_t ws_bytes, uint16_t* d_out_f16, void* stream);
+
+/*
  * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan
  * kernel with a pair of HIP events recorded on the search's own stream.  rarc_profile_end
  * synchronises, returns the summed scan time and the number of launches measured, and releases

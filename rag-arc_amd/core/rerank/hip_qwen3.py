@@ -126,27 +126,107 @@ class HipCausalLM:
             return out[:n]
 
 
-    def yes_no_logits_device(self, d_ids, d_start, no_id: int, yes_id: int, out=None):
+    def prefix_kv_device(self, d_ids, d_start):
+        """Run shared prompt PREFIXES once (include/rarc.h: rarc_lm_prefix_kv): int32 device tensors [n_prefix][P] (LEFT
+        padded) and [n_prefix] (first real token), n_prefix * P a multiple of 128.  Returns a handle for
+        yes_no_logits_device(..., prefix=handle, prefix_of=...): every layer's k | v rows of the prefix tokens."""
+        t = self.torch
+        if d_ids.dtype != t.int32 or d_start.dtype != t.int32 or d_ids.ndim != 2 or not d_ids.is_cuda:
+            raise ValueError("prefix_kv_device takes int32 device tensors [n_prefix][P], [n_prefix]")
+        n, P = d_ids.shape
+        if n * P == 0 or (n * P) % 128 or d_start.shape != (n,):
+            raise ValueError("n_prefix * P must be a positive multiple of 128")
+        with t.cuda.device(self.device):
+            need = int(self.lib.rarc_lm_workspace_bytes(ctypes.addressof(self._model), n * P))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = t.empty(need, dtype=t.uint8, device=self.device)
+            cache = t.empty(int(self.lib.rarc_lm_prefix_cache_bytes(ctypes.addressof(self._model), n * P)), dtype=t.uint8,
+                            device=self.device)
+            d_start = d_start.contiguous()
+            B.check(self.lib.rarc_lm_prefix_kv(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(), d_start.data_ptr(), n, P,
+                                               self._ws.data_ptr(), self._ws.numel(), cache.data_ptr(), cache.numel(),
+                                               t.cuda.current_stream(self.device).cuda_stream), "rarc_lm_prefix_kv")
+        return {"cache": cache, "n": n, "P": P, "start": d_start}
+
+    def yes_no_logits_device(self, d_ids, d_start, no_id: int, yes_id: int, out=None, prefix=None, prefix_of=None):
         """yes_no_logits() for batches that are already on the device: int32 tensors [n][L] (LEFT padded) and [n]
         (index of each sequence's first real token), n * L a multiple of 128.  Nothing is copied, read back or
-        validated on the host (the kernels clamp token ids into the table).  Returns fp16 [n][2] = (no, yes)."""
+        validated on the host (the kernels clamp token ids into the table).  Returns fp16 [n][2] = (no, yes).
+        With `prefix` (from prefix_kv_device) and `prefix_of` (int32 [n]: the prefix each sequence continues, -1 none) the
+        batch holds only the REMAINDERS of the prompts; the logits are those of prefix + remainder."""
         t = self.torch
         if d_ids.dtype != t.int32 or d_start.dtype != t.int32 or d_ids.ndim != 2 or not d_ids.is_cuda:
             raise ValueError("yes_no_logits_device takes int32 device tensors [n][L], [n]")
         n, L = d_ids.shape
         if n * L == 0 or (n * L) % 128 or d_start.shape != (n,):
             raise ValueError("n * L must be a positive multiple of 128")
+        if (prefix is None) != (prefix_of is None):
+            raise ValueError("prefix and prefix_of go together")
         with t.cuda.device(self.device):
             need = int(self.lib.rarc_lm_workspace_bytes(ctypes.addressof(self._model), n * L))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = t.empty(need, dtype=t.uint8, device=self.device)
             if out is None:
                 out = t.empty((n, 2), dtype=t.float16, device=self.device)
-            B.check(self.lib.rarc_lm_yes_no_logits(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
-                                                   d_start.contiguous().data_ptr(), n, L, int(no_id), int(yes_id),
-                                                   self._ws.data_ptr(), self._ws.numel(), out.data_ptr(),
-                                                   t.cuda.current_stream(self.device).cuda_stream), "rarc_lm_yes_no_logits")
+            st = t.cuda.current_stream(self.device).cuda_stream
+            if prefix is None:
+                B.check(self.lib.rarc_lm_yes_no_logits(ctypes.addressof(self._model), d_ids.contiguous().data_ptr(),
+                                                       d_start.contiguous().data_ptr(), n, L, int(no_id), int(yes_id),
+                                                       self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), st),
+                        "rarc_lm_yes_no_logits")
+            else:
+                if prefix_of.dtype != t.int32 or prefix_of.shape != (n,) or not prefix_of.is_cuda:
+                    raise ValueError("prefix_of must be an int32 device tensor [n]")
+                B.check(self.lib.rarc_lm_yes_no_logits_prefixed(
+                    ctypes.addressof(self._model), d_ids.contiguous().data_ptr(), d_start.contiguous().data_ptr(), n, L,
+                    prefix_of.contiguous().data_ptr(), prefix["cache"].data_ptr(), prefix["n"], prefix["P"],
+                    prefix["start"].data_ptr(), int(no_id), int(yes_id), self._ws.data_ptr(), self._ws.numel(), out.data_ptr(), st),
+                    "rarc_lm_yes_no_logits_prefixed")
             return out
+
+    def yes_no_logits_shared_prefix(self, seqs, no_id: int, yes_id: int, min_prefix: int = 16):
+        """(no, yes) logits of token-id SEQUENCES (lists, unpadded) that may share a common beginning — the prompts of one
+        rerank() call.  When their longest common prefix is worth it, it is run once and only the remainders go through the
+        LM per sequence; otherwise the plain left-padded batch.  Returns a host fp16 array [n][2]."""
+        t = self.torch
+        n = len(seqs)
+        lcp = min(len(s) for s in seqs)
+        first = seqs[0]
+        for s in seqs[1:]:
+            i = 0
+            m = min(lcp, len(s))
+            while i < m and s[i] == first[i]:
+                i += 1
+            lcp = i
+        lcp = min(lcp, min(len(s) for s in seqs) - 1)          # every sequence keeps at least one token of its own
+        if n < 2 or lcp < min_prefix:
+            L = max(len(s) for s in seqs)
+            ids = np.zeros((n, L), np.int32)
+            mask = np.zeros((n, L), np.int8)
+            for r, s in enumerate(seqs):
+                ids[r, L - len(s):] = s
+                mask[r, L - len(s):] = 1
+            return self.yes_no_logits(ids, mask, no_id, yes_id).cpu().numpy()
+        if max(max(s) for s in seqs) >= self.vocab or min(min(s) for s in seqs) < 0:
+            raise ValueError(f"token ids must lie in [0, {self.vocab})")
+        P = -(-lcp // 32) * 32                                  # one prefix sequence, left padded; 4 rows make 128 tokens
+        pre = np.zeros((4, P), np.int32)
+        pre[:, P - lcp:] = first[:lcp]
+        pstart = np.full(4, P - lcp, np.int32)
+        Ls = max(len(s) - lcp for s in seqs)
+        Ls = -(-Ls // 32) * 32
+        n_pad = -(-n // 4) * 4
+        ids = np.zeros((n_pad, Ls), np.int32)
+        start = np.full(n_pad, Ls - 1, np.int32)
+        for r, s in enumerate(seqs):
+            rest = s[lcp:]
+            ids[r, Ls - len(rest):] = rest
+            start[r] = Ls - len(rest)
+        with t.cuda.device(self.device):
+            handle = self.prefix_kv_device(t.from_numpy(pre).to(self.device), t.from_numpy(pstart).to(self.device))
+            z = self.yes_no_logits_device(t.from_numpy(ids).to(self.device), t.from_numpy(start).to(self.device), no_id, yes_id,
+                                          prefix=handle, prefix_of=t.zeros(n_pad, dtype=t.int32, device=self.device))
+        return z[:n].cpu().numpy()
 
 
 class HipQwen3Reranker(HipLogitReranker):
@@ -160,9 +240,10 @@ class HipQwen3Reranker(HipLogitReranker):
     def __init__(self, lm: HipCausalLM, tokenize: Callable[[str], Sequence[int]], yes_id: int, no_id: int,
                  prefix_ids: Optional[Sequence[int]] = None, suffix_ids: Optional[Sequence[int]] = None,
                  max_length: int = 4096, instruction: Optional[str] = None, pad_id: int = 0,
-                 device: Optional[int] = None):
+                 device: Optional[int] = None, share_prefix: bool = True):
         super().__init__(self._logits, instruction=instruction,
                          device=lm.device.index if device is None else device)
+        self.share_prefix = bool(share_prefix)
         self.lm, self.tokenize = lm, tokenize
         self.yes_id, self.no_id, self.pad_id = int(yes_id), int(no_id), int(pad_id)   # token_true_id / token_false_id (:14-15)
         self.prefix, self.suffix = self.PREFIX, self.SUFFIX
@@ -197,10 +278,19 @@ class HipQwen3Reranker(HipLogitReranker):
             mask[r, L - len(s):] = 1
         return ids, mask
 
+    def token_sequences(self, pairs: Sequence[str]) -> List[List[int]]:
+        """The unpadded token sequences process_inputs pads: prefix + truncated pair tokens + suffix."""
+        room = self.max_length - len(self.prefix_ids) - len(self.suffix_ids)
+        return [self.prefix_ids + list(self.tokenize(p))[: max(room, 0)] + self.suffix_ids for p in pairs]
+
     def _logits(self, query: str, contents: Sequence[str]):
         pairs = [self.format_instruction(self.instruction, query, c) for c in contents]
-        ids, mask = self.process_inputs(pairs)
-        z = self.lm.yes_no_logits(ids, mask, self.no_id, self.yes_id).cpu().numpy()   # fp16 [n][2]: 4 bytes per pair
+        if self.share_prefix:
+            # the prompts of one call differ only from the document on: their common beginning runs through the LM once
+            z = self.lm.yes_no_logits_shared_prefix(self.token_sequences(pairs), self.no_id, self.yes_id)
+        else:
+            ids, mask = self.process_inputs(pairs)
+            z = self.lm.yes_no_logits(ids, mask, self.no_id, self.yes_id).cpu().numpy()   # fp16 [n][2]: 4 bytes per pair
         return z[:, 0], z[:, 1]
 
     def compute_logits(self, inputs) -> List[float]:
@@ -214,4 +304,23 @@ class HipQwen3Reranker(HipLogitReranker):
     def compute_scores(self, pairs, instruction=None, **kwargs) -> List[float]:
         """Reranker_Qwen3.py:51-55: `pairs` = [(query, document text), ...] -> p_yes per pair."""
         texts = [self.format_instruction(instruction, q, d) for q, d in pairs]
-        return self.compute_logits(self.process_inputs(texts))
+        if not self.share_prefix:
+            return self.compute_logits(self.process_inputs(texts))
+        z = self.lm.yes_no_logits_shared_prefix(self.token_sequences(texts), self.no_id, self.yes_id)
+        scores, _ = self.score_order(z[:, 0], z[:, 1])
+        return [float(v) for v in scores[0].cpu().numpy()]
+
+    def rerank(self, query: str, documents, k: int = None, batch_size: int = 8, **kwargs):
+        """Reranker_Qwen3.py:57-75.  The reference scores the documents eight at a time (`batch_size`); a left-padded batch
+        gives every prompt the logits it would get alone, so the grouping is free: with share_prefix all prompts of the
+        call go through the LM together (in groups of `lm_batch`, default 128), their common beginning once per group."""
+        if not documents:
+            return []
+        group = max(int(batch_size), int(kwargs.get("lm_batch", 128))) if self.share_prefix else int(batch_size)
+        z_no, z_yes = [], []
+        for s0 in range(0, len(documents), group):
+            a, b = self.logit_fn(query, [d.content for d in documents[s0:s0 + group]])
+            z_no.extend(list(a))
+            z_yes.extend(list(b))
+        _, perm = self.score_order(z_no, z_yes)
+        return self.apply_order(documents, perm[0].tolist(), k)

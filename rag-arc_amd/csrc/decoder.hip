@@ -115,7 +115,7 @@ __device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* 
   }
 }
 
-// ---- causal attention with grouped K/V heads and left padding ----------------------------------------------------
+// ---- causal attention with grouped K/V heads, left padding and an optional shared KEY/VALUE PREFIX -------------------
 // One WORKGROUP (4 waves) per (sequence, K/V head, group of four (q head, 32-query block) units); one wave per unit.
 // Units of a (sequence, K/V head) are ordered query-block major, so the four waves of a workgroup want (nearly) the same
 // keys: every 32-key tile is fetched ONCE per workgroup with coalesced 256-byte row loads, k gets its per-head RMSNorm
@@ -126,77 +126,152 @@ __device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* 
 //                       rotary applied to the fragments as they are loaded, lm_norm_rope): lane l owns query l & 31, the
 //                       softmax statistics of a query sit in the lane pair (l, l ^ 32)
 //   O^T += V^T · P^T    A = V^T fragments from LDS, B = P^T assembled in registers
-// Keys limited to [start[seq], query position].  The wave-per-unit kernel this replaces loaded K and V per wave with
-// 16-byte pieces of 32 different rows, redid k's norm + rotary per wave and needed 366 VGPRs: 357 us per layer at
-// 51 200 tokens (265 us before norm + rotary moved in, plus 198 us for their own pass over the qkv tensor).
+// Round 3 — software pipeline: the raw rows of tile t+1 are fetched into registers (K chunk, its rotary row, the V pair:
+// 32 VGPRs) BEFORE tile t is multiplied, and the LDS image is double buffered, so a tile costs one barrier and the
+// global-memory latency of its rows hides under the previous tile's MFMAs and softmax (it was fully exposed: two
+// barriers and ~15 k cycles per 32-key tile, 1.4 ms per layer at 640 x 256 tokens).
+// Round 3 — prefix: the (query, document) prompts a reranker scores for ONE query share everything up to the document
+// (chat prefix, instruction, query: ~80 of ~220 tokens), and in a causal LM the keys and values of those tokens do not
+// depend on what follows.  `pf` names a cache of raw k | v rows computed once per query (rarc_lm_prefix_kv); a
+// sequence with a prefix attends to cache rows [pstart, P) and then to its own rows.  Keys are walked in a VIRTUAL index
+// u: u < P is cache row u, u >= P is own row start + (u - P) — contiguous, no tile is spent on left padding.  A key's
+// rotary position is u (+ start without a prefix, which makes it the index in the padded sequence: the reference's
+// position ids), a query row i sits at u = P + (i - start).  Keys limited to [u_min, u of the query].
+#ifdef LM_ATTN_TIMELINE   // measurement builds: s_memtime stamps of one workgroup's wave 0 (tools/lm_attn_timeline.py)
+__device__ unsigned long long g_lm_tl[512];
+extern "C" int rarc_lm_debug_timeline(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lm_tl), sizeof(unsigned long long) * (size_t)n);
+}
+#define LM_TL(i) do { const int tl_k_ = (i); if (tl_on && tl_k_ < 512) g_lm_tl[tl_k_] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LM_TL(i) do { } while (0)
+#endif
+struct LmAttnPrefix {
+  const half_t* kv;        // [n_prefix][P][prs]: raw k rows (n_kv*DH) | v rows (n_kv*DH) of this layer; null = none
+  const int32_t* pidx;     // [n_seq]: cache sequence of each sequence (-1: none)
+  const int32_t* pstart;   // [n_prefix]: first real row of each cache sequence (left padded)
+  int P, prs;
+};
 template <int DH>
 __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t* __restrict__ qkv,
                                                                    const int32_t* __restrict__ start, int L, int n_q, int n_kv,
                                                                    int q_blocks, int wg_per_kv, const half_t* __restrict__ qn_w,
                                                                    const half_t* __restrict__ kn_w, float eps,
-                                                                   const half2_t* __restrict__ rope, half_t* __restrict__ ctx) {
+                                                                   const half2_t* __restrict__ rope, int rope_rows,
+                                                                   half_t* __restrict__ ctx, const LmAttnPrefix pf) {
   constexpr int KS = DH / 16;
   constexpr int MB = DH / 32;
   constexpr int VROW = 40;              // halves per V^T row: 32 keys + pad (16-byte aligned rows)
   constexpr int KROW = DH + 8;          // halves per K row: DH + 16 bytes
   constexpr int CH = DH / 8;            // 16-byte chunks per row
   constexpr int RPP = 64 / CH;          // K rows per wave pass (4 at DH = 128, 8 at DH = 64)
-  __shared__ __attribute__((aligned(16))) half_t kimg[32 * KROW];
-  __shared__ __attribute__((aligned(16))) half_t vt[DH * VROW];
+  constexpr int NP = 8 / RPP;           // passes per wave and tile
+  constexpr int VI = (16 * (CH / 4) + 63) / 64;   // V items per lane and tile (1)
+  __shared__ __attribute__((aligned(16))) half_t kimg[2][32 * KROW];
+  __shared__ __attribute__((aligned(16))) half_t vt[2][DH * VROW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int G = n_q / n_kv, units = G * q_blocks;           // units of one (sequence, K/V head)
-  const int wg = blockIdx.x % wg_per_kv, bk = blockIdx.x / wg_per_kv;
+  // Workgroup ids go round-robin over the 8 XCDs, each with its own L2: taken as they come, the workgroups of one
+  // (sequence, K/V head) — which read the SAME k / v rows — would sit on different XCDs and fetch every tile from HBM up
+  // to wg_per_kv times.  XCD x instead owns a contiguous range of the logical ids, so they share an L2 (and run together).
+  const int xcd = blockIdx.x & 7, per = gridDim.x >> 3, rem = gridDim.x & 7;
+  const int lid = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int wg = lid % wg_per_kv, bk = lid / wg_per_kv;
   const int b = bk / n_kv, kvh = bk % n_kv;
   const int u = wg * 4 + wave;                              // this wave's unit (may be past the end: it only helps staging)
   const bool live = u < units;
   const int qb = live ? u / G : 0, hd = kvh * G + (live ? u % G : 0);
   int s0 = start[b];
   s0 = s0 < 0 ? 0 : (s0 > L - 1 ? L - 1 : s0);
+  const int pq = pf.kv ? pf.pidx[b] : -1;
+  const int P = pq >= 0 ? pf.P : 0;
+  int u_min = 0;
+  if (pq >= 0) { u_min = pf.pstart[pq]; u_min = u_min < 0 ? 0 : (u_min > P - 1 ? P - 1 : u_min); }
+  const int pos_base = pq >= 0 ? 0 : s0;                    // rotary position of virtual key u = u + pos_base
   const int col = lane & 31, hh = lane >> 5;
   const size_t rs = (size_t)(n_q + 2 * n_kv) * DH;          // row stride of the fused qkv in halves
   const half_t* qbase = qkv + (size_t)b * L * rs + (size_t)hd * DH;
   const half_t* kbase = qkv + (size_t)b * L * rs + (size_t)(n_q + kvh) * DH;
   const half_t* vbase = qkv + (size_t)b * L * rs + (size_t)(n_q + n_kv + kvh) * DH;
-  const float scale = DH == 128 ? 0.08838834764831845f : 0.125f;  // 1/sqrt(DH)
+  const half_t* pkbase = pq >= 0 ? pf.kv + (size_t)pq * P * pf.prs + (size_t)kvh * DH : nullptr;
+  const half_t* pvbase = pq >= 0 ? pkbase + (size_t)n_kv * DH : nullptr;
+  const float scale2 = (DH == 128 ? 0.08838834764831845f : 0.125f) * 1.44269504088896340736f;  // log2(e) / sqrt(DH)
   const int q0 = qb * 32;
   const int qpos = (q0 + col < L) ? q0 + col : L - 1;
+  const int uq = P + (qpos - s0);                           // this lane's query in the virtual index (< P: a padding row)
+  const int uq_first = P + (q0 - s0);                       // the wave's first query: keys up to it are visible to all 32
+  auto rope_row = [&](int uu) -> const half2_t* {
+    int r = uu + pos_base;
+    r = r < 0 ? 0 : (r > rope_rows - 1 ? rope_rows - 1 : r);
+    return rope + (size_t)r * (DH / 2);
+  };
 
-  half8 qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qbase + (size_t)qpos * rs + 16 * ks + 8 * hh);
-  lm_norm_rope<DH>(qf, qn_w, eps, rope + (size_t)qpos * (DH / 2), hh);
+#ifdef LM_ATTN_TIMELINE
+  const bool tl_on = blockIdx.x == gridDim.x / 2 + 3 && threadIdx.x == 0;
+  int tl_i = 1;
+#endif
   f32x16 o[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
   float m_run = -INFINITY, l_run = 0.f;
-  const int k_end = live ? ((q0 + 32 < L) ? q0 + 32 : L) : 0;  // causal: no key beyond the block's last query
+  // causal: no key beyond the block's last query (virtual index, exclusive)
+  const int k_end = live ? P + (((q0 + 32 < L) ? q0 + 32 : L) - s0) : 0;
   // the workgroup's last unit has the largest query block: its key range is the workgroup's
   const int last_u = (wg * 4 + 3 < units ? wg * 4 + 3 : units - 1), last_q0 = (last_u / G) * 32;
-  const int wg_k_end = (last_q0 + 32 < L) ? last_q0 + 32 : L;
+  const int wg_k_end = P + (((last_q0 + 32 < L) ? last_q0 + 32 : L) - s0);
 
   // staging roles: K row = 8*wave + pass*RPP + lane / CH, chunk c = lane % CH; the k-norm weights and this lane's
   // rotary sign are fixed for the whole kernel
   const int kc = lane % CH, kr_in = lane / CH;
   const half8 kw = *(const half8*)(kn_w + 8 * kc);
   const bool upper = kc >= CH / 2;                           // this chunk holds elements i + DH/2 of the rotation pairs
-
-  for (int k0 = (s0 / 32) * 32; k0 < wg_k_end; k0 += 32) {
-    __syncthreads();                                         // the previous tile's fragments have been read
-    // ---- K rows 8*wave .. +7: load, RMSNorm, rotary, store as the A-operand image ----
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  // row pointers of virtual key uu (cache row or own row; clamped into what exists: out-of-range keys are masked)
+  auto krow_ptr = [&](int uu) -> const half_t* {
+    if (uu < P) return pkbase + (size_t)(uu < 0 ? 0 : uu) * pf.prs;
+    int i = uu - P + s0;
+    return kbase + (size_t)(i > L - 1 ? L - 1 : i) * rs;
+  };
+  auto vrow_ptr = [&](int uu) -> const half_t* {
+    if (uu < P) return pvbase + (size_t)(uu < 0 ? 0 : uu) * pf.prs;
+    int i = uu - P + s0;
+    return vbase + (size_t)(i > L - 1 ? L - 1 : i) * rs;
+  };
+  // ---- prefetch registers: the raw rows of the NEXT tile ----
+  half8 pk_x[NP];
+  u32x4 pk_c0[NP], pk_c1[NP];
+  half8 pv0[VI], pv1[VI];
+  auto prefetch = [&](int k0) {
 #pragma unroll
-    for (int pass = 0; pass < 8 / RPP; ++pass) {
+    for (int pass = 0; pass < NP; ++pass) {
+      const int uu = k0 + 8 * wave + pass * RPP + kr_in;
+      pk_x[pass] = *(const half8*)(krow_ptr(uu) + 8 * kc);
+      const half2_t* cs_row = rope_row(uu) + 8 * (kc % (CH / 2));
+      pk_c0[pass] = *(const u32x4*)cs_row;
+      pk_c1[pass] = *(const u32x4*)(cs_row + 4);
+    }
+#pragma unroll
+    for (int it = 0; it < VI; ++it) {
+      const int i = lane + 64 * it;
+      if (i < 16 * (CH / 4)) {
+        const int p = i & 15, c8 = (CH / 4) * wave + (i >> 4);
+        pv0[it] = *(const half8*)(vrow_ptr(k0 + 2 * p) + 8 * c8);
+        pv1[it] = *(const half8*)(vrow_ptr(k0 + 2 * p + 1) + 8 * c8);
+      }
+    }
+  };
+  // ---- registers -> LDS image `buf`: K rows 8*wave .. +7 (RMSNorm, rotary), this wave's d-chunks of V^T ----
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
       const int r = 8 * wave + pass * RPP + kr_in;
-      const int krow = (k0 + r < L) ? k0 + r : L - 1;
-      const half8 x = *(const half8*)(kbase + (size_t)krow * rs + 8 * kc);
+      const half8 x = pk_x[pass];
       float ss = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)x[e], (float)x[e], ss);
 #pragma unroll
       for (int o2 = 1; o2 < CH; o2 <<= 1) ss += __shfl_xor(ss, o2, 64);
       const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      const half2_t* cs_row = rope + (size_t)krow * (DH / 2) + 8 * (kc % (CH / 2));
-      const u32x4 c0 = *(const u32x4*)cs_row, c1 = *(const u32x4*)(cs_row + 4);
       half8 xn;
 #pragma unroll
       for (int e = 0; e < 8; ++e) xn[e] = (half_t)((float)kw[e] * (float)(half_t)((float)x[e] * inv));
@@ -207,76 +282,157 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
       half8 out;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? c0[e] : c1[e - 4]);
+        const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? pk_c0[pass][e] : pk_c1[pass][e - 4]);
         const float cs = (float)cs2[0], sn = (float)cs2[1];
         // lower half: a cos - b sin with a = own, b = partner; upper half: b cos + a sin with b = own, a = partner
         out[e] = upper ? (half_t)((float)xn[e] * cs + (float)pn[e] * sn) : (half_t)((float)xn[e] * cs - (float)pn[e] * sn);
       }
-      *(half8*)(kimg + r * KROW + 8 * kc) = out;
+      *(half8*)(kimg[buf] + r * KROW + 8 * kc) = out;
     }
-    // ---- V^T: this wave's d-chunks CH/4*wave .., all 32 keys; a lane packs one key pair of one chunk ----
 #pragma unroll
-    for (int i = lane; i < 16 * (CH / 4); i += 64) {
-      const int p = i & 15, c8 = (CH / 4) * wave + (i >> 4);
-      const int r0 = (k0 + 2 * p < L) ? k0 + 2 * p : L - 1, r1 = (k0 + 2 * p + 1 < L) ? k0 + 2 * p + 1 : L - 1;
-      const half8 v0 = *(const half8*)(vbase + (size_t)r0 * rs + 8 * c8), v1 = *(const half8*)(vbase + (size_t)r1 * rs + 8 * c8);
+    for (int it = 0; it < VI; ++it) {
+      const int i = lane + 64 * it;
+      if (i < 16 * (CH / 4)) {
+        const int p = i & 15, c8 = (CH / 4) * wave + (i >> 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) *(half2_t*)(vt + (8 * c8 + e) * VROW + 2 * p) = (half2_t){v0[e], v1[e]};
+        for (int e = 0; e < 8; ++e) *(half2_t*)(vt[buf] + (8 * c8 + e) * VROW + 2 * p) = (half2_t){pv0[it][e], pv1[it][e]};
+      }
     }
+  };
+
+  LM_TL(0);
+  const int k_first = (u_min / 32) * 32;
+  if (k_first < wg_k_end) prefetch(k_first);               // the first tile's rows travel while q is loaded and normed
+  half8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qbase + (size_t)qpos * rs + 16 * ks + 8 * hh);
+  lm_norm_rope<DH>(qf, qn_w, eps, rope_row(uq), hh);
+  LM_TL(tl_i++);
+  int buf = 0;
+  for (int k0 = k_first; k0 < wg_k_end; k0 += 32, buf ^= 1) {
+    // image `buf` was last read while tile k0 - 64 was multiplied; every wave has passed the barrier of tile k0 - 32
+    // since, i.e. finished with it
+    store_tile(buf);
+    LM_TL(tl_i++);
     __syncthreads();
+    LM_TL(tl_i++);
+    if (k0 + 32 < wg_k_end) prefetch(k0 + 32);               // in flight under this tile's MFMAs
     if (k0 >= k_end) continue;                               // beyond this wave's causal range: it only staged
 
+    const half_t* kim = kimg[buf];
+    const half_t* vim = vt[buf];
     f32x16 st = {0};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const half8 kf = *(const half8*)(kimg + col * KROW + 16 * ks + 8 * hh);
+      const half8 kf = *(const half8*)(kim + col * KROW + 16 * ks + 8 * hh);
       st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
     }
-    float s[16];
+    // ---- online softmax in the log2 domain: t = s * (scale * log2 e), p = 2^(t - m) ----
+    // An INTERIOR tile (every key of it visible to every query of the wave: all but the first tile of a left-padded or
+    // prefixed sequence and the tile on the diagonal) needs no mask, no -inf guards.  The running maximum is only raised
+    // when some query's tile maximum exceeds it by more than 2^DEFER (wave-uniform decision): otherwise p = 2^(t - m_old)
+    // <= 2^DEFER fits fp16 with the same relative precision, the accumulators need no rescale (64 multiplies per tile),
+    // and sum and output stay consistent because both use the same m.
+#ifndef LM_INTERIOR
+#define LM_INTERIOR 1
+#endif
+#ifndef LM_DEFER
+#define LM_DEFER 1
+#endif
+#ifndef LM_SWAP_STATS
+#define LM_SWAP_STATS 1
+#endif
+#ifndef LM_SWAP_P
+#define LM_SWAP_P 1
+#endif
+    constexpr float DEFER = 11.0f;
+    const bool interior = LM_INTERIOR && k0 >= u_min && k0 + 31 <= uq_first;
+    float tv[16];
     float tmax = -INFINITY;
+    if (interior) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
-      s[r] = (key >= s0 && key <= qpos) ? st[r] * scale : -INFINITY;
-      tmax = fmaxf(tmax, s[r]);
+      for (int r = 0; r < 16; ++r) { tv[r] = st[r] * scale2; tmax = fmaxf(tmax, tv[r]); }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+        tv[r] = (key >= u_min && key <= uq) ? st[r] * scale2 : -INFINITY;
+        tmax = fmaxf(tmax, tv[r]);
+      }
     }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+    if (LM_SWAP_STATS) {
+      // (inline asm, not the builtin: with the SAME value in both operands hipcc 7.2 keeps only the first result of the
+      //  builtin — the generated code took max(sw[0], sw[0]) — measured as wrong logits; the two v_nop are the wait states
+      //  the VALU-write -> permlane-read hazard asks for)
+      float a = tmax, bcopy = tmax;
+      asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bcopy));
+      const float sw[2] = {a, bcopy};
+      tmax = fmaxf(sw[0], sw[1]);   // max over the lane pair (l, l ^ 32)
+    } else {
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    }
+    const bool defer = LM_DEFER && __builtin_amdgcn_ballot_w64(tmax <= m_run + DEFER) == ~0ull;
+    const float m_new = defer ? m_run : fmaxf(m_run, tmax);
+    if (!defer) {
+      const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= corr;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+      m_run = m_new;
+    }
     float psum = 0.f;
     uint32_t pk[8];
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-      const float p0 = (s[r] == -INFINITY) ? 0.f : __expf(s[r] - m_new);
-      const float p1 = (s[r + 1] == -INFINITY) ? 0.f : __expf(s[r + 1] - m_new);
+      float p0, p1;
+      if (interior) {
+        p0 = __builtin_amdgcn_exp2f(tv[r] - m_new);
+        p1 = __builtin_amdgcn_exp2f(tv[r + 1] - m_new);
+      } else {   // (m_new may still be -inf for a query with no visible key so far: -inf - -inf is not a number)
+        p0 = (tv[r] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(tv[r] - m_new);
+        p1 = (tv[r + 1] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(tv[r + 1] - m_new);
+      }
       psum += p0 + p1;
       const half2_t h2 = {(half_t)p0, (half_t)p1};
       pk[r >> 1] = __builtin_bit_cast(uint32_t, h2);
     }
-    psum += __shfl_xor(psum, 32, 64);
-    l_run = l_run * corr + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+    if (LM_SWAP_STATS) {
+      float a = psum, bcopy = psum;
+      asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bcopy));
+      psum = a + bcopy;
+    } else {
+      psum += __shfl_xor(psum, 32, 64);
+    }
+    l_run += psum;
+    // ---- O^T += V^T · P^T.  k-step ks contracts keys 16ks .. 16ks+15: half hh needs keys 16ks + 8hh .. + 7.  A lane holds
+    // key groups g = 0..3 (keys 8g + 4hh .. + 3) as the word pairs pk[2g], pk[2g+1]; one v_permlane32_swap per word with
+    // vdst = group 2ks, src = group 2ks + 1 leaves [own | partner's] of group 2ks in the low half and [partner's | own] of
+    // group 2ks + 1 in the high half: exactly the two B fragments (the four ds_bpermute + selects this replaces) ----
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const uint32_t mine0 = hh ? (ks ? pk[6] : pk[2]) : (ks ? pk[4] : pk[0]);
-      const uint32_t mine1 = hh ? (ks ? pk[7] : pk[3]) : (ks ? pk[5] : pk[1]);
-      const uint32_t send0 = hh ? (ks ? pk[4] : pk[0]) : (ks ? pk[6] : pk[2]);
-      const uint32_t send1 = hh ? (ks ? pk[5] : pk[1]) : (ks ? pk[7] : pk[3]);
-      const uint32_t recv0 = (uint32_t)__shfl_xor((int)send0, 32, 64), recv1 = (uint32_t)__shfl_xor((int)send1, 32, 64);
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4 bw = hh ? (u32x4){recv0, recv1, mine0, mine1} : (u32x4){mine0, mine1, recv0, recv1};
-      const half8 pf = __builtin_bit_cast(half8, bw);
+      u32x4 bw;
+      if (LM_SWAP_P) {
+        const auto w0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks], pk[4 * ks + 2], false, false);
+        const auto w1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
+        bw = (u32x4){w0[0], w1[0], w0[1], w1[1]};
+      } else {
+        const uint32_t mine0 = hh ? pk[4 * ks + 2] : pk[4 * ks], mine1 = hh ? pk[4 * ks + 3] : pk[4 * ks + 1];
+        const uint32_t send0 = hh ? pk[4 * ks] : pk[4 * ks + 2], send1 = hh ? pk[4 * ks + 1] : pk[4 * ks + 3];
+        const uint32_t recv0 = (uint32_t)__shfl_xor((int)send0, 32, 64), recv1 = (uint32_t)__shfl_xor((int)send1, 32, 64);
+        bw = hh ? (u32x4){recv0, recv1, mine0, mine1} : (u32x4){mine0, mine1, recv0, recv1};
+      }
+      const half8 pfr = __builtin_bit_cast(half8, bw);
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const half8 vf = *(const half8*)(vt + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
-        o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[mb], 0, 0, 0);
+        const half8 vf = *(const half8*)(vim + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
+        o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfr, o[mb], 0, 0, 0);
       }
     }
+    LM_TL(tl_i++);
   }
+  LM_TL(tl_i++);
   if (live && q0 + col < L) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;  // (a padding query attends to nothing: zeros)
     half_t* out = ctx + ((size_t)b * L + q0 + col) * (size_t)n_q * DH + (size_t)hd * DH;
@@ -358,14 +514,33 @@ extern "C" size_t rarc_lm_workspace_bytes(const RarcLmModel* m, int n_tokens) {
          + lm_align(T * (size_t)m->n_q_heads * m->head_dim * 2)  // attention context
          + lm_align(T * 2 * (size_t)m->inter * 2)               // fused gate | up
          + lm_align(T * (size_t)m->inter * 2)                   // silu(gate) * up
-         + lm_align(T * (size_t)(m->head_dim / 2) * 4);         // rotary (cos, sin) table, at most one row per token
+         + lm_align((T + 4096) * (size_t)(m->head_dim / 2) * 4);  // rotary (cos, sin) table: prefix + sequence positions
 }
 
-extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_seq,
-                                     int seq_len, int no_id, int yes_id, void* d_ws, size_t ws_bytes,
-                                     uint16_t* d_out_f16, void* stream) {
-  RARC_RANGE();
-  RARC_REQUIRE(m && m->layers && d_ids && d_start && d_ws && d_out_f16, RARC_E_INVALID, "rarc_lm_yes_no_logits: null pointer");
+// ---- prefix K/V cache (see LmAttnPrefix): per layer [n_prefix * P][2 * n_kv * head_dim] raw k | v rows -----------------
+extern "C" size_t rarc_lm_prefix_cache_bytes(const RarcLmModel* m, int n_prefix_tokens) {
+  if (!m || n_prefix_tokens <= 0) return 0;
+  return (size_t)m->n_layers * lm_align((size_t)n_prefix_tokens * 2 * m->n_kv_heads * m->head_dim * 2);
+}
+
+// k | v columns of the fused qkv rows -> cache rows (16-byte pieces, one wave per row)
+__global__ __launch_bounds__(256) void rarc_lm_copy_kv_kernel(const half_t* __restrict__ qkv, int n_rows, int rs, int q_cols, int kv_cols,
+                                                              half_t* __restrict__ cache) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n_rows) return;
+  const half8* from = (const half8*)(qkv + (size_t)r * rs + q_cols);
+  half8* to = (half8*)(cache + (size_t)r * kv_cols);
+  for (int c = lane; c < kv_cols / 8; c += 64) to[c] = from[c];
+}
+
+// mode 0: logits of the last positions (d_out_f16); `use` = optional prefix cache the sequences attend to first
+// mode 1: fill `fill` (a prefix cache) with the k | v rows of every layer for these sequences; no logits, and the last
+//         layer stops after its q|k|v projection (nothing else of it is ever read)
+struct LmPrefixUse { const half_t* cache; const int32_t* pidx; const int32_t* pstart; int n_prefix, P; };
+static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_seq, int seq_len, int no_id,
+                      int yes_id, void* d_ws, size_t ws_bytes, uint16_t* d_out_f16, void* stream, const LmPrefixUse* use,
+                      half_t* fill) {
+  RARC_REQUIRE(m && m->layers && d_ids && d_start && d_ws && (d_out_f16 || fill), RARC_E_INVALID, "rarc_lm_yes_no_logits: null pointer");
   RARC_REQUIRE(m->embed && m->lm_head && m->final_norm && m->zero_bias, RARC_E_INVALID, "rarc_lm_yes_no_logits: incomplete model");
   const int H = m->hidden, I = m->inter, DH = m->head_dim, NQ = m->n_q_heads, NKV = m->n_kv_heads;
   RARC_REQUIRE(n_seq > 0 && seq_len > 0 && m->n_layers > 0, RARC_E_INVALID, "rarc_lm_yes_no_logits: empty batch or model");
@@ -394,7 +569,12 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
   half2_t* rope = (half2_t*)((char*)act + lm_align((size_t)T * I * 2));
   const int tb = (T + 3) / 4;
 
-  hipLaunchKernelGGL(rarc_lm_rope_table_kernel, dim3((seq_len * (DH / 2) + 255) / 256), dim3(256), 0, s, seq_len, DH,
+  const int P = use ? use->P : 0;
+  const int rope_rows = P + seq_len;
+  RARC_REQUIRE(rope_rows <= T + 4096, RARC_E_UNSUPPORTED, "rarc_lm_yes_no_logits: prefix of %d rows is too long for this batch", P);
+  const size_t kv_cols = (size_t)2 * NKV * DH;
+  const size_t cache_layer = use ? lm_align((size_t)use->n_prefix * P * kv_cols * 2) : (fill ? lm_align((size_t)T * kv_cols * 2) : 0);
+  hipLaunchKernelGGL(rarc_lm_rope_table_kernel, dim3((rope_rows * (DH / 2) + 255) / 256), dim3(256), 0, s, rope_rows, DH,
                      m->rope_theta, rope);
   RARC_HIP_CHECK(hipGetLastError());
 
@@ -411,16 +591,24 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
                        (const half_t*)Ly.in_norm, m->rms_eps, T, H, h);
     RARC_HIP_CHECK(hipGetLastError());
     if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, T, QKV, H, 0, stream)) return rc;
+    if (fill) {   // mode 1: this layer's raw k | v rows go to the cache
+      hipLaunchKernelGGL(rarc_lm_copy_kv_kernel, dim3(tb), dim3(256), 0, s, (const half_t*)qkv, T, QKV, QD, (int)kv_cols,
+                         (half_t*)((char*)fill + (size_t)l * cache_layer));
+      RARC_HIP_CHECK(hipGetLastError());
+      if (l == m->n_layers - 1) return RARC_OK;
+    }
+    LmAttnPrefix pf{nullptr, nullptr, nullptr, 0, (int)kv_cols};
+    if (use) pf = LmAttnPrefix{(const half_t*)((const char*)use->cache + (size_t)l * cache_layer), use->pidx, use->pstart, P, (int)kv_cols};
     if (DH == 128)
       hipLaunchKernelGGL(rarc_lm_attention_kernel<128>, dim3(n_seq * NKV * wg_per_kv), dim3(256), 0, s, (const half_t*)qkv, d_start,
                          seq_len, NQ, NKV, q_blocks, wg_per_kv, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
-                         (const half2_t*)rope, ctx);
+                         (const half2_t*)rope, rope_rows, ctx, pf);
     else
       hipLaunchKernelGGL(rarc_lm_attention_kernel<64>, dim3(n_seq * NKV * wg_per_kv), dim3(256), 0, s, (const half_t*)qkv, d_start,
                          seq_len, NQ, NKV, q_blocks, wg_per_kv, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
-                         (const half2_t*)rope, ctx);
+                         (const half2_t*)rope, rope_rows, ctx, pf);
     RARC_HIP_CHECK(hipGetLastError());
-    if (l == m->n_layers - 1 && last_only) {
+    if (l == m->n_layers - 1 && last_only && !fill) {
       // Only the last position's logits are wanted, and after the last layer's attention nothing mixes positions any
       // more: its output projection, MLP and residual adds run on the n_seq last rows alone (gathered, padded to a
       // multiple of 128 rows) instead of on all T tokens.
@@ -476,4 +664,32 @@ extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids,
                      (const half_t*)m->lm_head, m->rms_eps, seq_len, seq_len - 1, H, no_id, yes_id, (half_t*)d_out_f16);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
+}
+
+extern "C" int rarc_lm_yes_no_logits(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_seq,
+                                     int seq_len, int no_id, int yes_id, void* d_ws, size_t ws_bytes,
+                                     uint16_t* d_out_f16, void* stream) {
+  RARC_RANGE();
+  RARC_REQUIRE(d_out_f16, RARC_E_INVALID, "rarc_lm_yes_no_logits: null pointer");
+  return lm_forward(m, d_ids, d_start, n_seq, seq_len, no_id, yes_id, d_ws, ws_bytes, d_out_f16, stream, nullptr, nullptr);
+}
+
+extern "C" int rarc_lm_prefix_kv(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_prefix, int prefix_len,
+                                 void* d_ws, size_t ws_bytes, void* d_cache, size_t cache_bytes, void* stream) {
+  RARC_RANGE();
+  RARC_REQUIRE(m && d_cache, RARC_E_INVALID, "rarc_lm_prefix_kv: null pointer");
+  RARC_REQUIRE(n_prefix > 0 && prefix_len > 0 && cache_bytes >= rarc_lm_prefix_cache_bytes(m, n_prefix * prefix_len), RARC_E_INVALID,
+               "rarc_lm_prefix_kv: cache too small");
+  return lm_forward(m, d_ids, d_start, n_prefix, prefix_len, 0, 0, d_ws, ws_bytes, nullptr, stream, nullptr, (half_t*)d_cache);
+}
+
+extern "C" int rarc_lm_yes_no_logits_prefixed(const RarcLmModel* m, const int32_t* d_ids, const int32_t* d_start, int n_seq,
+                                              int seq_len, const int32_t* d_prefix_of, const void* d_cache, int n_prefix,
+                                              int prefix_len, const int32_t* d_prefix_start, int no_id, int yes_id, void* d_ws,
+                                              size_t ws_bytes, uint16_t* d_out_f16, void* stream) {
+  RARC_RANGE();
+  RARC_REQUIRE(m && d_prefix_of && d_cache && d_prefix_start && d_out_f16, RARC_E_INVALID, "rarc_lm_yes_no_logits_prefixed: null pointer");
+  RARC_REQUIRE(n_prefix > 0 && prefix_len > 0 && prefix_len <= 4096, RARC_E_INVALID, "rarc_lm_yes_no_logits_prefixed: bad prefix shape");
+  const LmPrefixUse use{(const half_t*)d_cache, d_prefix_of, d_prefix_start, n_prefix, prefix_len};
+  return lm_forward(m, d_ids, d_start, n_seq, seq_len, no_id, yes_id, d_ws, ws_bytes, d_out_f16, stream, &use, nullptr);
 }

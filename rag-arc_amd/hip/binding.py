@@ -139,6 +139,10 @@ SIGNATURES = {
     "rarc_lm_workspace_bytes": (c_size_t, [c_void_p, c_int]),
     "rarc_lm_yes_no_logits": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                       c_void_p]),
+    "rarc_lm_prefix_cache_bytes": (c_size_t, [c_void_p, c_int]),
+    "rarc_lm_prefix_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "rarc_lm_yes_no_logits_prefixed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                                c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "rarc_profile_begin": (c_int, [c_int]),
     "rarc_profile_end": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
 }

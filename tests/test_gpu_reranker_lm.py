@@ -65,6 +65,64 @@ def test_max_length_4096_tokens(oracle):
     _run(oracle, 1024, 2, 16, 8, 128, 3072, 2000, 1, 4096, (1500,), seed=4097, tol_logit=5e-2, tol_p=2e-2)   # left padded
 
 
+@pytest.mark.parametrize("H,LAYERS,NQ,NKV,DH,I", [(256, 2, 4, 2, 64, 512), (1024, 2, 16, 8, 128, 3072), (384, 3, 6, 2, 64, 512)])
+def test_shared_prefix_equals_whole_prompts(oracle, H, LAYERS, NQ, NKV, DH, I):
+    """Prompts that share a beginning (the (query, document) prompts of a reranker: three queries here, each with its own
+    prefix length, 5-9 documents each): the prefix runs through the LM once per query (rarc_lm_prefix_kv), the remainders
+    attend to its cached k | v rows — and the logits are those of the whole prompts run the reference's way (oracle), at
+    the tolerance of the plain path, and within fp16 noise of the plain HIP path."""
+    import torch
+
+    from rag_arc_amd.core.rerank import HipCausalLM
+
+    V = 1000
+    sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=H + 7)
+    lm = HipCausalLM(sd, NQ, NKV, DH, rms_norm_eps=1e-6, rope_theta=1e6)
+    rng = np.random.default_rng(H)
+    plens, P = [75, 33, 96], 96                                # prefix lengths (left padded to P), one of them unpadded
+    prefixes = [rng.integers(5, V, n).tolist() for n in plens]
+    pairs, owner = [], []
+    for qi, ndoc in enumerate((9, 5, 6)):
+        for _ in range(ndoc):
+            pairs.append(rng.integers(5, V, int(rng.integers(1, 140))).tolist())      # remainder: 1 .. 139 tokens
+            owner.append(qi)
+    n = len(pairs)
+    Ls = -(-max(len(p) for p in pairs) // 32) * 32
+    pre = np.zeros((4, P), np.int32)                          # 3 prefixes + a dummy row: 4 x 96 = 384 tokens
+    pstart = np.full(4, P - 1, np.int32)
+    for qi, p in enumerate(prefixes):
+        pre[qi, P - len(p):] = p
+        pstart[qi] = P - len(p)
+    ids = np.zeros((n, Ls), np.int32)
+    start = np.zeros(n, np.int32)
+    for r, p in enumerate(pairs):
+        ids[r, Ls - len(p):] = p
+        start[r] = Ls - len(p)
+    dev = lm.device
+    handle = lm.prefix_kv_device(torch.from_numpy(pre).to(dev), torch.from_numpy(pstart).to(dev))
+    got = lm.yes_no_logits_device(torch.from_numpy(ids).to(dev), torch.from_numpy(start).to(dev), 11, 42, prefix=handle,
+                                  prefix_of=torch.tensor(owner, dtype=torch.int32, device=dev)).float().cpu().numpy()
+    # the whole prompts, left padded, through the oracle and through the plain HIP path
+    full = [prefixes[o] + p for o, p in zip(owner, pairs)]
+    L = -(-max(len(f) for f in full) // 32) * 32
+    f_ids, f_mask = np.zeros((n, L), np.int64), np.zeros((n, L), np.int64)
+    for r, f in enumerate(full):
+        f_ids[r, L - len(f):] = f
+        f_mask[r, L - len(f):] = 1
+    sd16 = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in sd.items()}
+    want = oracle.qwen3_last_logits_f32(sd16, dict(num_attention_heads=NQ, num_key_value_heads=NKV, head_dim=DH, rms_norm_eps=1e-6,
+                                                   rope_theta=1e6), f_ids, f_mask, [11, 42])
+    plain = lm.yes_no_logits(f_ids, f_mask, 11, 42).float().cpu().numpy()
+    sig = lambda z: 1.0 / (1.0 + np.exp(-(z[:, 1] - z[:, 0])))
+    print(f"LM-PREFIX H={H} layers={LAYERS}: prefixed vs oracle max|dlogit|={np.abs(got - want).max():.2e}, plain vs oracle "
+          f"{np.abs(plain - want).max():.2e}, prefixed vs plain {np.abs(got - plain).max():.2e}; max|dp_yes| vs oracle {np.abs(sig(got) - sig(want)).max():.2e}")
+    assert np.abs(got - want).max() <= 3e-2 and np.abs(sig(got) - sig(want)).max() <= 1e-2
+    assert np.abs(got - plain).max() <= 3e-2
+    # list-level entry used by rerank(): longest common prefix found on the host, same numbers
+    z = lm.yes_no_logits_shared_prefix([prefixes[0] + p for p, o in zip(pairs, owner) if o == 0], 11, 42)
+    assert np.abs(z.astype(np.float32) - want[[i for i, o in enumerate(owner) if o == 0]]).max() <= 3e-2
+
+
 def test_reranker_end_to_end_matches_reference_steps(oracle):
     """rerank(): prompt format, truncation, prefix / suffix ids, left padding, batches of 8, p_yes in fp16, stable
     descending order — the steps of core/rerank/Reranker_Qwen3.py:23-75 with a toy tokenizer."""
@@ -96,10 +154,15 @@ def test_reranker_end_to_end_matches_reference_steps(oracle):
         sd16 = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in sd.items()}
         z = oracle.qwen3_last_logits_f32(sd16, dict(num_attention_heads=NQ, num_key_value_heads=NKV, head_dim=DH), ids, mask, [11, 42])
         scores.extend(oracle.rerank_scores_f16(z[:, 0].astype(np.float16), z[:, 1].astype(np.float16)).tolist())
-    got_scores = []
-    for s0 in range(0, len(docs), 8):
-        got_scores.extend(rr.compute_scores([("what is a vector index?", d.content) for d in docs[s0:s0 + 8]]))
+    got_scores = rr.compute_scores([("what is a vector index?", d.content) for d in docs])     # one call, like rerank(): shared prefix
+    plain = HipQwen3Reranker(lm, tok, yes_id=42, no_id=11, prefix_ids=prefix, suffix_ids=suffix, max_length=96, share_prefix=False)
+    plain_scores = []
+    for s0 in range(0, len(docs), 8):                                                          # the reference's batches of 8, no sharing
+        plain_scores.extend(plain.compute_scores([("what is a vector index?", d.content) for d in docs[s0:s0 + 8]]))
+    assert np.max(np.abs(np.array(plain_scores) - np.array(scores, dtype=np.float64))) < 1e-2
     assert np.max(np.abs(np.array(got_scores) - np.array(scores, dtype=np.float64))) < 1e-2
+    assert [d.id for d in plain.rerank("what is a vector index?", docs, k=7)] == \
+        [docs[i].id for i in oracle.stable_desc_order(np.array(plain_scores))[:7]]
     want_order = oracle.stable_desc_order(np.array(got_scores))          # the order of ITS scores, stable
     assert [d.id for d in out] == [docs[i].id for i in want_order[:7]]
     assert len(out) == 7 and all(isinstance(d, Document) for d in out)
