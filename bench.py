@@ -646,7 +646,9 @@ def leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, dense_ids, n2, a, steps, wa
             sel = order[s0:s0 + CH]
             if sel.numel() % 4:      # (n_pairs is a multiple of 4 whenever k is: not hit at the defaults)
                 sel = torch.cat([sel, sel[-1:].expand(4 - sel.numel() % 4)])
-            Lc = -(-(mx - p_lo) // 32) * 32
+            Lc = mx - p_lo               # the chunk's longest remainder: tokens = pairs x Lc must be a multiple of 128 — it is for
+            if (int(sel.numel()) * Lc) % 128:                                  # chunks of 640 pairs; otherwise round the length up
+                Lc = -(-Lc // 32) * 32
             t_ids, t_start, _ = c3_pair_tokens(torch, qidx_all[sel], doc[sel], Lc, V, p_lo)
             if share:
                 z_all[sel] = lm.yes_no_logits_device(t_ids, t_start, NO_ID, YES_ID, prefix=handle, prefix_of=qidx_all[sel].int())

@@ -21,6 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 class _SlowOracleIndex(OracleIndex):
     """An oracle index whose scan takes a while (so that callers pile up behind it) and counts its launches."""
     delay = 0.05
+    gate = None      # a threading.Event the FIRST scan waits for (set once every caller thread is running): the test does not
+                     # depend on how fast a loaded machine starts threads
 
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
@@ -29,8 +31,30 @@ class _SlowOracleIndex(OracleIndex):
     def search(self, queries, k):
         self.launches += 1
         self.batch_sizes.append(len(queries))
+        if self.gate is not None and self.launches == 1:
+            self.gate.wait(timeout=30)
         time.sleep(self.delay)
         return super().search(queries, k)
+
+
+def _run_gated(store, n, call):
+    """n caller threads; the first scan is held until all of them are running (and have had `delay` to enqueue)."""
+    started, lock = [0], threading.Lock()
+    store.index.gate = threading.Event()
+
+    def wrapped(i):
+        with lock:
+            started[0] += 1
+            if started[0] == n:
+                store.index.gate.set()
+        call(i)
+
+    threads = [threading.Thread(target=wrapped, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    store.index.gate = None
 
 
 class _BatchingHashEmbeddings(HashEmbeddings):
@@ -60,11 +84,7 @@ def test_concurrent_one_query_callers_share_scans():
     def call(i):
         got[i] = store.similarity_search_with_score(queries[i], k=ks[i])
 
-    threads = [threading.Thread(target=call, args=(i,)) for i in range(64)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    _run_gated(store, 64, call)
     launches, served = store.coalesced_launches
     assert served == 64 and launches <= 3, (launches, store.index.batch_sizes)      # first caller alone, the rest together
     plain = _store(coalesce=False, engine=OracleIndex)
@@ -98,11 +118,7 @@ def test_text_payloads_are_embedded_once_per_batch():
     emb = _BatchingHashEmbeddings(64)
     store = _store(emb=emb)
     got = [None] * 40
-    threads = [threading.Thread(target=lambda i=i: got.__setitem__(i, store.similarity_search(f"question {i}", k=4))) for i in range(40)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
+    _run_gated(store, 40, lambda i: got.__setitem__(i, store.similarity_search(f"question {i}", k=4)))
     assert sum(emb.calls) == 40 and len(emb.calls) <= 3             # one encoder call per launch, not per caller
     plain = _store(coalesce=False, engine=OracleIndex)
     for i in range(40):
