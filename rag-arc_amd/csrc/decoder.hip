@@ -15,6 +15,9 @@
 // K/V heads, a causal mask and left padding.  Activations and the residual stream are fp16, as in the reference's
 // `torch_dtype=torch.float16` model; norms, RoPE, softmax and the final dot products compute in fp32.
 #include "rarc_common.h"
+#include <string.h>
+#include <stdlib.h>
+#include <stdio.h>
 
 extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
                              int n, int k, int act, void* stream);
@@ -82,6 +85,15 @@ __global__ __launch_bounds__(256) void rarc_lm_rope_table_kernel(int L, int DH, 
   table[idx] = (half2_t){(half_t)cs, (half_t)sn};
 }
 
+// fp32 -> fp16 exactly as the reference's tensors round: the fp32 result first, then the cast.  Written as a plain cast
+// hipcc may pick v_fma_mixlo_f16 for `(half)(a * b)` in one kernel and v_mul_f32 + v_cvt_f16_f32 in another; the two
+// round differently in the rare double-rounding cases (two kernels that should agree bit for bit then differ in ~1e-3 of
+// their outputs by one fp16 ulp — measured).  The value passes through an opaque statement, so it exists as an fp32 number.
+__device__ __forceinline__ half_t lm_f16_of(float t) {
+  asm volatile("" : "+v"(t));
+  return (half_t)t;
+}
+
 // ---- per-head RMSNorm, then rotary embedding (HF rotate_half convention), on MFMA operand fragments ---------------
 // f[ks][e] is element 16 ks + 8 hh + e of one head row (the lane pair (l, l ^ 32) holds the whole row), so the rotation
 // partner i + DH/2 of an element sits in the same lane (fragment ks + KS/2) and the row's sum of squares needs one
@@ -107,10 +119,10 @@ __device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* 
     for (int e = 0; e < 8; ++e) {
       const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? c0[e] : c1[e - 4]);
       const float cs = (float)cs2[0], sn = (float)cs2[1];
-      const float a = (float)(half_t)((float)w0[e] * (float)(half_t)((float)f[ks][e] * inv));
-      const float b = (float)(half_t)((float)w1[e] * (float)(half_t)((float)f[ks + KS / 2][e] * inv));
-      f[ks][e] = (half_t)(a * cs - b * sn);
-      f[ks + KS / 2][e] = (half_t)(b * cs + a * sn);
+      const float a = (float)(half_t)((float)w0[e] * (float)lm_f16_of((float)f[ks][e] * inv));
+      const float b = (float)(half_t)((float)w1[e] * (float)lm_f16_of((float)f[ks + KS / 2][e] * inv));
+      f[ks][e] = lm_f16_of(a * cs - b * sn);
+      f[ks + KS / 2][e] = lm_f16_of(b * cs + a * sn);
     }
   }
 }
@@ -137,6 +149,75 @@ __device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* 
 // u: u < P is cache row u, u >= P is own row start + (u - P) — contiguous, no tile is spent on left padding.  A key's
 // rotary position is u (+ start without a prefix, which makes it the index in the padded sequence: the reference's
 // position ids), a query row i sits at u = P + (i - start).  Keys limited to [u_min, u of the query].
+// ---- online softmax of one 32-key tile in the log2 domain: t = s * (scale * log2 e), p = 2^(t - m) -------------------------
+// st[r] is the raw score of this lane's query against key k0 + 8 (r >> 2) + 4 hh + (r & 3).  An INTERIOR tile (every key of
+// it visible to every query of the wave: all but the first tile of a left-padded or prefixed sequence and the tile on the
+// diagonal) needs no mask and no -inf guards; the two forms are separate instantiations chosen by ONE wave-uniform branch
+// per tile (written as `interior ? a : b` inside the unrolled loops hipcc emitted a branch per pair of scores).  The running
+// maximum is only raised when some query's tile maximum exceeds it by more than 2^DEFER (wave-uniform decision): otherwise
+// p = 2^(t - m_old) <= 2^DEFER fits fp16 with the same relative precision, the accumulators need no rescale (64 multiplies
+// per tile), and sum and output stay consistent because both use the same m.  Returns the tile's probabilities as the packed
+// fp16 pairs pk[r >> 1] = (p[r], p[r + 1]).
+#ifndef LM_DEFER
+#define LM_DEFER_ON 1
+#else
+#define LM_DEFER_ON LM_DEFER
+#endif
+template <bool INTERIOR, int MB>
+__device__ __forceinline__ void lm_softmax_tile(const f32x16& st, float scale2, int k0, int hh, int u_min, int uq, float& m_run,
+                                                float& l_run, f32x16 (&o)[MB], uint32_t (&pk)[8]) {
+  constexpr float DEFER = 11.0f;
+  float tv[16];
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    if (INTERIOR) {
+      tv[r] = st[r] * scale2;
+    } else {
+      const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+      tv[r] = (key >= u_min && key <= uq) ? st[r] * scale2 : -INFINITY;
+    }
+    tmax = fmaxf(tmax, tv[r]);
+  }
+  {
+    // (inline asm, not the builtin: with the SAME value in both operands hipcc 7.2 keeps only the first result of the
+    //  builtin — the generated code took max(sw[0], sw[0]) — measured as wrong logits; the two v_nop are the wait states
+    //  the VALU-write -> permlane-read hazard asks for)
+    float a = tmax, bcopy = tmax;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bcopy));
+    tmax = fmaxf(a, bcopy);   // max over the lane pair (l, l ^ 32)
+  }
+  const bool defer = LM_DEFER_ON && __builtin_amdgcn_ballot_w64(tmax <= m_run + DEFER) == ~0ull;
+  const float m_new = defer ? m_run : fmaxf(m_run, tmax);
+  if (!defer) {
+    const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+    l_run *= corr;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+    m_run = m_new;
+  }
+  float psum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    float p0 = __builtin_amdgcn_exp2f(tv[r] - m_new), p1 = __builtin_amdgcn_exp2f(tv[r + 1] - m_new);
+    if (!INTERIOR) {   // (m_new may still be -inf for a query with no visible key so far: -inf - -inf is not a number)
+      p0 = (tv[r] == -INFINITY) ? 0.f : p0;
+      p1 = (tv[r + 1] == -INFINITY) ? 0.f : p1;
+    }
+    psum += p0 + p1;
+    const half2_t h2 = {(half_t)p0, (half_t)p1};
+    pk[r >> 1] = __builtin_bit_cast(uint32_t, h2);
+  }
+  {
+    float a = psum, bcopy = psum;
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(bcopy));
+    psum = a + bcopy;
+  }
+  l_run += psum;
+}
+
 #ifdef LM_ATTN_TIMELINE   // measurement builds: s_memtime stamps of one workgroup's wave 0 (tools/lm_attn_timeline.py)
 __device__ unsigned long long g_lm_tl[512];
 extern "C" int rarc_lm_debug_timeline(unsigned long long* host, int n) {
@@ -274,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
       const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
       half8 xn;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xn[e] = (half_t)((float)kw[e] * (float)(half_t)((float)x[e] * inv));
+      for (int e = 0; e < 8; ++e) xn[e] = (half_t)((float)kw[e] * (float)lm_f16_of((float)x[e] * inv));
       u32x4 mine = __builtin_bit_cast(u32x4, xn), other;
 #pragma unroll
       for (int w4 = 0; w4 < 4; ++w4) other[w4] = (uint32_t)__shfl_xor((int)mine[w4], CH / 2, 64);
@@ -285,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
         const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? pk_c0[pass][e] : pk_c1[pass][e - 4]);
         const float cs = (float)cs2[0], sn = (float)cs2[1];
         // lower half: a cos - b sin with a = own, b = partner; upper half: b cos + a sin with b = own, a = partner
-        out[e] = upper ? (half_t)((float)xn[e] * cs + (float)pn[e] * sn) : (half_t)((float)xn[e] * cs - (float)pn[e] * sn);
+        out[e] = lm_f16_of(upper ? (float)xn[e] * cs + (float)pn[e] * sn : (float)xn[e] * cs - (float)pn[e] * sn);
       }
       *(half8*)(kimg[buf] + r * KROW + 8 * kc) = out;
     }
@@ -447,6 +528,236 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
   }
 }
 
+// ---- the same attention for SHORT sequences: the whole key range of a (sequence, K/V head) resident in LDS -----------
+// Round 3.  The streaming kernel above stages every 32-key tile once per workgroup of four (q head, query block) units —
+// at 16 units per (sequence, K/V head) that is four times the per-head RMSNorm + rotary work on k and four times the
+// V transposition, one barrier per tile, and ~6 k shader cycles per tile for 16 MFMAs (s_memtime timeline: 2.1-5.5 k cycles
+// for the tile's norm / rotary / LDS image, 3.8 k for a masked tile's scores + softmax + P·V with two workgroups sharing the
+// SIMDs).  When P + L keys fit in the CU's 160 KiB (288 keys at head_dim 128: every reranker prompt whose remainder after
+// the shared prefix is <= ~200 tokens) ONE workgroup of 8 waves owns the (sequence, K/V head):
+//   phase 1  all 512 threads build the operand images of ALL keys — K rows (norm + rotary) and V^T — with every global load
+//            of a group of passes issued before its first use: one exposed memory latency, each key prepared once;
+//   barrier
+//   phase 2  the G x q_blocks units are dealt to the waves largest first, boustrophedon (wave w: units w, 15 - w, 16 + w, ...:
+//            the causal triangle balances to ~87 %), and a wave runs its units with NO further barrier and no global load
+//            in the key loop (the next unit's q rows are fetched under the current one): S^T = K·Q^T of tile t + 1 is issued
+//            before the softmax of tile t, so one wave keeps the matrix pipe busy under its own VALU work.
+// Same arithmetic, same roundings and the same summation order per query as the streaming kernel (tiles of 32 keys in
+// ascending order, deferred rescale): the two kernels return identical bits (tests/test_gpu_reranker_lm.py).
+__host__ __device__ inline int lm_attn_vrow(int keys) { return keys <= 40 ? 40 : 40 + 128 * ((keys - 40 + 127) / 128); }
+template <int DH, int NP>   // NP: passes of K rows the staging registers hold (kcap <= NP * 32 keys at head_dim 128, NP * 64 at 64)
+__global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(const half_t* __restrict__ qkv,
+                                                                            const int32_t* __restrict__ start, int L, int n_q,
+                                                                            int n_kv, int q_blocks, const half_t* __restrict__ qn_w,
+                                                                            const half_t* __restrict__ kn_w, float eps,
+                                                                            const half2_t* __restrict__ rope, int rope_rows,
+                                                                            half_t* __restrict__ ctx, const LmAttnPrefix pf,
+                                                                            int kcap, int VROW) {
+  constexpr int KS = DH / 16;
+  constexpr int MB = DH / 32;
+  constexpr int KROW = DH + 8;          // halves per K row: DH + 16 bytes
+  constexpr int CH = DH / 8;            // 16-byte chunks per row
+  constexpr int RPW = 64 / CH;          // K rows per wave and pass
+  constexpr int RPP = 8 * RPW;          // K rows per workgroup pass (32 at DH = 128, 64 at DH = 64)
+  extern __shared__ __attribute__((aligned(16))) char lm_attn_smem[];
+  half_t* kimg = (half_t*)lm_attn_smem;                 // [kcap][KROW]
+  half_t* vt = kimg + (size_t)kcap * KROW;              // [DH][VROW]: VROW = 40 mod 128 halves, the bank pattern of the streaming kernel's 40
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int G = n_q / n_kv, units = G * q_blocks;
+  const int xcd = blockIdx.x & 7, per = gridDim.x >> 3, rem = gridDim.x & 7;
+  const int lid = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int b = lid / n_kv, kvh = lid % n_kv;
+  int s0 = start[b];
+  s0 = s0 < 0 ? 0 : (s0 > L - 1 ? L - 1 : s0);
+  const int pq = pf.kv ? pf.pidx[b] : -1;
+  const int P = pq >= 0 ? pf.P : 0;
+  int u_min = 0;
+  if (pq >= 0) { u_min = pf.pstart[pq]; u_min = u_min < 0 ? 0 : (u_min > P - 1 ? P - 1 : u_min); }
+  const int pos_base = pq >= 0 ? 0 : s0;
+  const int col = lane & 31, hh = lane >> 5;
+  const size_t rs = (size_t)(n_q + 2 * n_kv) * DH;
+  const half_t* seq_base = qkv + (size_t)b * L * rs;
+  const half_t* kbase = seq_base + (size_t)(n_q + kvh) * DH;
+  const half_t* vbase = seq_base + (size_t)(n_q + n_kv + kvh) * DH;
+  const half_t* pkbase = pq >= 0 ? pf.kv + (size_t)pq * P * pf.prs + (size_t)kvh * DH : nullptr;
+  const half_t* pvbase = pq >= 0 ? pkbase + (size_t)n_kv * DH : nullptr;
+  const float scale2 = (DH == 128 ? 0.08838834764831845f : 0.125f) * 1.44269504088896340736f;
+  auto rope_row = [&](int uu) -> const half2_t* {
+    int r = uu + pos_base;
+    r = r < 0 ? 0 : (r > rope_rows - 1 ? rope_rows - 1 : r);
+    return rope + (size_t)r * (DH / 2);
+  };
+  // (bit blends, not branches — hipcc turns a select between two address computations back into a divergent branch, and a
+  //  load under a divergent branch is waited for before the next one is issued)
+  auto row_ptr = [&](int uu, const half_t* pre, const half_t* own) -> const half_t* {
+    const int i = uu - P + s0;
+    const uint32_t m = uu < P ? 0xffffffffu : 0u;
+    const uint32_t off = (((uint32_t)(uu < 0 ? 0 : uu) * (uint32_t)pf.prs) & m) | (((uint32_t)(i > L - 1 ? L - 1 : i) * (uint32_t)rs) & ~m);
+    const uint64_t m64 = ((uint64_t)m << 32) | m;
+    const uint64_t base = ((uint64_t)pre & m64) | ((uint64_t)own & ~m64);
+    return (const half_t*)base + off;
+  };
+  auto krow_ptr = [&](int uu) -> const half_t* { return row_ptr(uu, pkbase, kbase); };
+  auto vrow_ptr = [&](int uu) -> const half_t* { return row_ptr(uu, pvbase, vbase); };
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int k_first = (u_min / 32) * 32;
+  const int k_total = P + (L - s0);                           // virtual keys [k_first, k_total) exist
+  int n_tiles = (k_total - k_first + 31) / 32;
+  if (n_tiles * 32 > kcap) n_tiles = kcap / 32;               // (the host only launches this kernel when everything fits)
+
+  // ---- the wave's unit list: j-th largest unit = (query block q_blocks - 1 - j / G, q head j % G) ----
+  auto unit_of = [&](int r) -> int { return (r & 1) ? 8 * r + 7 - wave : 8 * r + wave; };
+  half8 qraw[KS];
+  auto load_q = [&](int j) {
+    const int qb = q_blocks - 1 - j / G, hd = kvh * G + j % G;
+    const int q0 = qb * 32, qpos = (q0 + col < L) ? q0 + col : L - 1;
+    const half_t* qp = seq_base + (size_t)qpos * rs + (size_t)hd * DH;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qraw[ks] = *(const half8*)(qp + 16 * ks + 8 * hh);
+  };
+
+  // ---- phase 1: every global load of the workgroup's keys is issued before the first one is used (one workgroup per CU:
+  // nothing else would hide a second round trip), then K rows -> RMSNorm, rotary -> row-major image, V rows -> V^T.
+  // The loads are unconditional (rows past the end are clamped onto the last one, only the LDS writes are predicated):
+  // with a branch per pass hipcc interleaves loads, waits and unpacking ----
+  {
+    constexpr int MAXV = (NP + 1) / 2;                          // V items per thread
+    const int kc = lane % CH, kr_in = lane / CH;
+    const half8 kw = *(const half8*)(kn_w + 8 * kc);
+    const bool upper = kc >= CH / 2;
+    const int rows = n_tiles * 32;                              // <= NP * RPP (host)
+    const int items = n_tiles * 16 * CH;                        // (key pair, 8-d chunk) items of V
+    half8 x[NP];
+    u32x4 c0[NP], c1[NP];
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const int uu = k_first + g * RPP + wave * RPW + kr_in;
+      x[g] = *(const half8*)(krow_ptr(uu) + 8 * kc);
+      const half2_t* cs_row = rope_row(uu) + 8 * (kc % (CH / 2));
+      c0[g] = *(const u32x4*)cs_row;
+      c1[g] = *(const u32x4*)(cs_row + 4);
+    }
+    half8 v0[MAXV], v1[MAXV];
+#pragma unroll
+    for (int g = 0; g < MAXV; ++g) {
+      const int i = threadIdx.x + 512 * g;
+      const int p = i & 15, c8 = (i >> 4) % CH, tile = i / (16 * CH);
+      const int uu = k_first + 32 * tile + 2 * p;
+      v0[g] = *(const half8*)(vrow_ptr(uu) + 8 * c8);
+      v1[g] = *(const half8*)(vrow_ptr(uu + 1) + 8 * c8);
+    }
+    // (every loaded register passes through an opaque statement: nothing of the processing below moves up between the loads)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NP; ++g) asm volatile("" : "+v"(x[g]), "+v"(c0[g]), "+v"(c1[g]));
+#pragma unroll
+    for (int g = 0; g < MAXV; ++g) asm volatile("" : "+v"(v0[g]), "+v"(v1[g]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NP; ++g) {
+      const int r = g * RPP + wave * RPW + kr_in;
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)x[g][e], (float)x[g][e], ss);
+#pragma unroll
+      for (int o2 = 1; o2 < CH; o2 <<= 1) ss += __shfl_xor(ss, o2, 64);
+      const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
+      half8 xn;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xn[e] = (half_t)((float)kw[e] * (float)lm_f16_of((float)x[g][e] * inv));
+      u32x4 mine = __builtin_bit_cast(u32x4, xn), other;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) other[w4] = (uint32_t)__shfl_xor((int)mine[w4], CH / 2, 64);
+      const half8 pn = __builtin_bit_cast(half8, other);
+      half8 out;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? c0[g][e] : c1[g][e - 4]);
+        const float cs = (float)cs2[0], sn = (float)cs2[1];
+        out[e] = lm_f16_of(upper ? (float)xn[e] * cs + (float)pn[e] * sn : (float)xn[e] * cs - (float)pn[e] * sn);
+      }
+      if (r < rows) *(half8*)(kimg + r * KROW + 8 * kc) = out;
+    }
+#pragma unroll
+    for (int g = 0; g < MAXV; ++g) {
+      const int i = threadIdx.x + 512 * g;
+      if (i < items) {
+        const int p = i & 15, c8 = (i >> 4) % CH, tile = i / (16 * CH);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *(half2_t*)(vt + (8 * c8 + e) * VROW + 32 * tile + 2 * p) = (half2_t){v0[g][e], v1[g][e]};
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: this wave's units, no barrier from here on ----
+  for (int r = 0;; ++r) {
+    const int j = unit_of(r);
+    if (j >= units) break;
+    const int qb = q_blocks - 1 - j / G, hd = kvh * G + j % G;
+    const int q0 = qb * 32;
+    const int qpos = (q0 + col < L) ? q0 + col : L - 1;
+    const int uq = P + (qpos - s0);
+    const int uq_first = P + (q0 - s0);
+    half8 qf[KS];
+    load_q(j);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = qraw[ks];
+    lm_norm_rope<DH>(qf, qn_w, eps, rope_row(uq), hh);
+    f32x16 o[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
+    float m_run = -INFINITY, l_run = 0.f;
+    int k_end = P + (((q0 + 32 < L) ? q0 + 32 : L) - s0);     // causal: no key beyond the block's last query (exclusive)
+    if (k_end > k_first + n_tiles * 32) k_end = k_first + n_tiles * 32;
+    auto qk_tile = [&](int k0) -> f32x16 {
+      const half_t* kim = kimg + (size_t)(k0 - k_first) * KROW;
+      f32x16 st = {0};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const half8 kf = *(const half8*)(kim + col * KROW + 16 * ks + 8 * hh);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
+      }
+      return st;
+    };
+    f32x16 st = {0};
+    if (k_first < k_end) st = qk_tile(k_first);
+    for (int k0 = k_first; k0 < k_end; k0 += 32) {
+      f32x16 st_next = {0};
+      if (k0 + 32 < k_end) st_next = qk_tile(k0 + 32);          // the matrix pipe works on the next tile under this softmax
+      uint32_t pk[8];
+      if (k0 >= u_min && k0 + 31 <= uq_first) lm_softmax_tile<true, MB>(st, scale2, k0, hh, u_min, uq, m_run, l_run, o, pk);
+      else lm_softmax_tile<false, MB>(st, scale2, k0, hh, u_min, uq, m_run, l_run, o, pk);
+      const half_t* vim = vt + (k0 - k_first);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const auto w0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks], pk[4 * ks + 2], false, false);
+        const auto w1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
+        const u32x4 bw = (u32x4){w0[0], w1[0], w0[1], w1[1]};
+        const half8 pfr = __builtin_bit_cast(half8, bw);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          const half8 vf = *(const half8*)(vim + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
+          o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfr, o[mb], 0, 0, 0);
+        }
+      }
+      st = st_next;
+    }
+    if (q0 + col < L) {
+      const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+      half_t* out = ctx + ((size_t)b * L + q0 + col) * (size_t)n_q * DH + (size_t)hd * DH;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const half4v w = {(half_t)(o[mb][4 * g] * inv), (half_t)(o[mb][4 * g + 1] * inv),
+                            (half_t)(o[mb][4 * g + 2] * inv), (half_t)(o[mb][4 * g + 3] * inv)};
+          *(half4v*)(out + 32 * mb + 8 * g + 4 * hh) = w;
+        }
+    }
+  }
+}
+
 // ---- SwiGLU: h[t][j] = silu(g[t][j]) · u[t][j] from the fused gate/up GEMM output, whose columns come in groups of 16:
 // 8 gates, then the 8 ups of the same features (RarcLmLayer.gate_up_w, rarc.h).  Only for shapes the GEMM's own
 // SwiGLU epilogue (encoder.hip, act = 3) does not take: small batches.
@@ -508,7 +819,8 @@ static inline size_t lm_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t rarc_lm_workspace_bytes(const RarcLmModel* m, int n_tokens) {
   if (!m || n_tokens <= 0) return 0;
-  const size_t T = (size_t)n_tokens, qkv = (size_t)(m->n_q_heads + 2 * m->n_kv_heads) * m->head_dim;
+  // (buffers hold the token count rounded up to 256 rows: a 128-row remainder is padded inside, see lm_forward)
+  const size_t T = ((size_t)n_tokens + 255) / 256 * 256, qkv = (size_t)(m->n_q_heads + 2 * m->n_kv_heads) * m->head_dim;
   return 3 * lm_align(T * m->hidden * 2)                        // x, h (normed), delta (projection outputs)
          + lm_align(T * qkv * 2)                                // fused q | k | v
          + lm_align(T * (size_t)m->n_q_heads * m->head_dim * 2)  // attention context
@@ -558,15 +870,24 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
   RARC_REQUIRE(ws_bytes >= rarc_lm_workspace_bytes(m, T), RARC_E_WORKSPACE, "rarc_lm_yes_no_logits: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   char* w = (char*)d_ws;
-  const size_t th = lm_align((size_t)T * H * 2);
+  // The 256-row tile kernels (and the SwiGLU epilogue that only they have) take M % 256 == 0: a batch of T = 256 j + 128
+  // tokens runs its GEMMs on Tg = T + 128 rows, the extra rows zero (128 rows of waste against the 128-row kernels for
+  // the whole GEMM, which is what an odd multiple of 128 used to get).  Everything that is not a GEMM works on the T real rows.
+  const int Tg = (T % 256 && T >= 2048) ? T + 128 : T;
+  const size_t Tw = ((size_t)T + 255) / 256 * 256;
+  const size_t th = lm_align(Tw * H * 2);
   half_t* x = (half_t*)w;
   half_t* h = (half_t*)(w + th);
   half_t* delta = (half_t*)(w + 2 * th);
   half_t* qkv = (half_t*)(w + 3 * th);
-  half_t* ctx = (half_t*)((char*)qkv + lm_align((size_t)T * QKV * 2));
-  half_t* gu = (half_t*)((char*)ctx + lm_align((size_t)T * QD * 2));
-  half_t* act = (half_t*)((char*)gu + lm_align((size_t)T * 2 * I * 2));
-  half2_t* rope = (half2_t*)((char*)act + lm_align((size_t)T * I * 2));
+  half_t* ctx = (half_t*)((char*)qkv + lm_align(Tw * QKV * 2));
+  half_t* gu = (half_t*)((char*)ctx + lm_align(Tw * QD * 2));
+  half_t* act = (half_t*)((char*)gu + lm_align(Tw * 2 * I * 2));
+  half2_t* rope = (half2_t*)((char*)act + lm_align(Tw * I * 2));
+  if (Tg > T) {   // the GEMMs' A operands of the padding rows: h (q|k|v, gate|up), ctx (output projection); act follows from h
+    RARC_HIP_CHECK(hipMemsetAsync(h + (size_t)T * H, 0, (size_t)(Tg - T) * H * 2, s));
+    RARC_HIP_CHECK(hipMemsetAsync(ctx + (size_t)T * QD, 0, (size_t)(Tg - T) * QD * 2, s));
+  }
   const int tb = (T + 3) / 4;
 
   const int P = use ? use->P : 0;
@@ -584,13 +905,32 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
   const int Mp = (n_seq + 127) / 128 * 128;
   const bool last_only = 6 * 256 + (size_t)Mp * ((size_t)QD + 3 * (size_t)H + 3 * (size_t)I) * 2 <= (size_t)T * 2 * I * 2;
   const int q_blocks = (seq_len + 31) / 32, wg_per_kv = ((NQ / NKV) * q_blocks + 3) / 4;  // attention workgroups per (sequence, K/V head)
+  // short sequences: all P + seq_len keys of a (sequence, K/V head) resident in LDS (rarc_lm_attention_resident_kernel);
+  // RARC_LM_ATTN=stream forces the streaming kernel (A/B runs, tests)
+  const int attn_kcap = (P + seq_len + 31) / 32 * 32, attn_vrow = lm_attn_vrow(attn_kcap);
+  const size_t attn_lds = (size_t)attn_kcap * (DH + 8) * 2 + (size_t)DH * attn_vrow * 2;
+  const char* attn_env = getenv("RARC_LM_ATTN");   // (read per call: the tests switch it inside one process)
+  const bool attn_stream_only = attn_env && !strcmp(attn_env, "stream");
+  const int attn_np = (attn_kcap + (DH == 128 ? 32 : 64) - 1) / (DH == 128 ? 32 : 64);   // passes of K rows its staging holds in registers
+  const bool resident = !attn_stream_only && attn_lds <= 160 * 1024 && attn_np <= 9;
+  if (resident) {
+    static RarcPerDevice attr_dev;
+    size_t& attr = attr_dev.cur();
+    if (!attr) {
+#define LM_RES_ATTR(DHV, NPV) RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_lm_attention_resident_kernel<DHV, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+      LM_RES_ATTR(128, 3); LM_RES_ATTR(128, 5); LM_RES_ATTR(128, 7); LM_RES_ATTR(128, 9);
+      LM_RES_ATTR(64, 3); LM_RES_ATTR(64, 5); LM_RES_ATTR(64, 7); LM_RES_ATTR(64, 9);
+#undef LM_RES_ATTR
+      attr = 1;
+    }
+  }
   for (int l = 0; l < m->n_layers; ++l) {
     const RarcLmLayer& Ly = m->layers[l];
     // (layer 0: plain norm; later layers: the previous layer's MLP output is added here, then normed)
     hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, l ? (const half_t*)delta : (const half_t*)nullptr,
                        (const half_t*)Ly.in_norm, m->rms_eps, T, H, h);
     RARC_HIP_CHECK(hipGetLastError());
-    if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, T, QKV, H, 0, stream)) return rc;
+    if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, Tg, QKV, H, 0, stream)) return rc;
     if (fill) {   // mode 1: this layer's raw k | v rows go to the cache
       hipLaunchKernelGGL(rarc_lm_copy_kv_kernel, dim3(tb), dim3(256), 0, s, (const half_t*)qkv, T, QKV, QD, (int)kv_cols,
                          (half_t*)((char*)fill + (size_t)l * cache_layer));
@@ -599,7 +939,20 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
     }
     LmAttnPrefix pf{nullptr, nullptr, nullptr, 0, (int)kv_cols};
     if (use) pf = LmAttnPrefix{(const half_t*)((const char*)use->cache + (size_t)l * cache_layer), use->pidx, use->pstart, P, (int)kv_cols};
-    if (DH == 128)
+    if (resident) {
+#define LM_RES_LAUNCH(DHV, NPV)                                                                                              \
+      hipLaunchKernelGGL((rarc_lm_attention_resident_kernel<DHV, NPV>), dim3(n_seq * NKV), dim3(512), attn_lds, s, (const half_t*)qkv, \
+                         d_start, seq_len, NQ, NKV, q_blocks, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,    \
+                         (const half2_t*)rope, rope_rows, ctx, pf, attn_kcap, attn_vrow)
+      if (DH == 128) {
+        if (attn_np <= 3) LM_RES_LAUNCH(128, 3); else if (attn_np <= 5) LM_RES_LAUNCH(128, 5);
+        else if (attn_np <= 7) LM_RES_LAUNCH(128, 7); else LM_RES_LAUNCH(128, 9);
+      } else {
+        if (attn_np <= 3) LM_RES_LAUNCH(64, 3); else if (attn_np <= 5) LM_RES_LAUNCH(64, 5);
+        else if (attn_np <= 7) LM_RES_LAUNCH(64, 7); else LM_RES_LAUNCH(64, 9);
+      }
+#undef LM_RES_LAUNCH
+    } else if (DH == 128)
       hipLaunchKernelGGL(rarc_lm_attention_kernel<128>, dim3(n_seq * NKV * wg_per_kv), dim3(256), 0, s, (const half_t*)qkv, d_start,
                          seq_len, NQ, NKV, q_blocks, wg_per_kv, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
                          (const half2_t*)rope, rope_rows, ctx, pf);
@@ -608,6 +961,15 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
                          seq_len, NQ, NKV, q_blocks, wg_per_kv, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,
                          (const half2_t*)rope, rope_rows, ctx, pf);
     RARC_HIP_CHECK(hipGetLastError());
+#ifdef LM_DUMP_CTX
+    if (l == 0 && getenv("RARC_LM_DUMP_CTX")) {
+      hipStreamSynchronize(s);
+      size_t nb = (size_t)T * QD * 2;
+      void* hb = malloc(nb);
+      hipMemcpy(hb, ctx, nb, hipMemcpyDeviceToHost);
+      FILE* f = fopen(getenv("RARC_LM_DUMP_CTX"), "wb"); fwrite(hb, 1, nb, f); fclose(f); free(hb);
+    }
+#endif
     if (l == m->n_layers - 1 && last_only && !fill) {
       // Only the last position's logits are wanted, and after the last layer's attention nothing mixes positions any
       // more: its output projection, MLP and residual adds run on the n_seq last rows alone (gathered, padded to a
@@ -643,18 +1005,18 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
     }
-    if (int rc = rarc_enc_gemm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, T, H, QD, 0, stream)) return rc;
+    if (int rc = rarc_enc_gemm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, Tg, H, QD, 0, stream)) return rc;
     hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)Ly.post_norm,
                        m->rms_eps, T, H, h);
     RARC_HIP_CHECK(hipGetLastError());
-    if (rarc_gemm_swiglu_fused(T, 2 * I, H)) {  // silu(gate)·up in the GEMM's epilogue: the [T][2I] tensor never exists
-      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)act, T, 2 * I, H, 3, stream)) return rc;
+    if (rarc_gemm_swiglu_fused(Tg, 2 * I, H)) {  // silu(gate)·up in the GEMM's epilogue: the [T][2I] tensor never exists
+      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)act, Tg, 2 * I, H, 3, stream)) return rc;
     } else {
-      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu, T, 2 * I, H, 0, stream)) return rc;
-      hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(2048), dim3(256), 0, s, (const half_t*)gu, T, I, act);
+      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu, Tg, 2 * I, H, 0, stream)) return rc;
+      hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(2048), dim3(256), 0, s, (const half_t*)gu, Tg, I, act);
       RARC_HIP_CHECK(hipGetLastError());
     }
-    if (int rc = rarc_enc_gemm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)delta, T, H, I, 0, stream)) return rc;
+    if (int rc = rarc_enc_gemm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)delta, Tg, H, I, 0, stream)) return rc;
   }
   // the last layer's MLP output joins the residual stream (no norm output wanted: y = null)
   hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)nullptr, m->rms_eps,

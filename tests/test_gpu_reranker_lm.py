@@ -45,6 +45,8 @@ def _run(oracle, H, LAYERS, NQ, NKV, DH, I, V, n, L, pads, seed, tol_logit=3e-2,
                                                                # per (sequence, kv head), attention workgroups of 4 + 4 + 1
     (256, 1, 2, 1, 128, 256, 4, 160, (0, 1, 100, 159)),        # head_dim 128, 2 x 5 units: workgroups of 4 + 4 + 2, five key tiles
     (256, 2, 4, 2, 64, 512, 2, 1024, (0, 700)),                # long prompts: 32 query blocks x up to 32 key tiles
+    (256, 2, 4, 2, 64, 2048, 16, 136, (0, 9, 100, 135)),       # 2176 tokens = 17 x 128: the GEMMs run on 2304 rows (a zero
+                                                               # 128-row pad), sequence length not a multiple of 32
 ])
 def test_yes_no_logits_match_oracle(oracle, H, LAYERS, NQ, NKV, DH, I, n, L, pads):
     _run(oracle, H, LAYERS, NQ, NKV, DH, I, 1000, n, L, pads, seed=H + L)
@@ -121,6 +123,49 @@ def test_shared_prefix_equals_whole_prompts(oracle, H, LAYERS, NQ, NKV, DH, I):
     # list-level entry used by rerank(): longest common prefix found on the host, same numbers
     z = lm.yes_no_logits_shared_prefix([prefixes[0] + p for p, o in zip(pairs, owner) if o == 0], 11, 42)
     assert np.abs(z.astype(np.float32) - want[[i for i, o in enumerate(owner) if o == 0]]).max() <= 3e-2
+
+
+@pytest.mark.parametrize("H,LAYERS,NQ,NKV,DH,I,n,L,P", [
+    (256, 2, 4, 2, 64, 512, 8, 96, 0),            # head_dim 64, 2 x 3 units on 8 waves
+    (1024, 2, 16, 8, 128, 3072, 8, 160, 96),      # 0.6B layer geometry: 2 x 5 units, 96 prefix + 160 own keys = the 288-key limit... minus one tile
+    (384, 2, 6, 2, 64, 512, 4, 192, 64),          # three q heads per kv head x six query blocks: 18 units, three rounds of the deal
+    (256, 1, 2, 1, 128, 256, 4, 256, 32),         # 2 x 8 units: exactly two rounds; 288 keys = the most head_dim 128 holds
+])
+def test_resident_attention_equals_streaming_bit_for_bit(oracle, monkeypatch, H, LAYERS, NQ, NKV, DH, I, n, L, P):
+    """Short sequences run the LDS-resident attention kernel (every key of a (sequence, K/V head) prepared once, the units dealt
+    to 8 waves), long ones the streaming kernel; RARC_LM_ATTN=stream forces the latter.  Same arithmetic in the same order:
+    the logits must be IDENTICAL, with and without a shared prefix, for ragged left padding."""
+    import torch
+
+    from rag_arc_amd.core.rerank import HipCausalLM
+
+    V = 1000
+    sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=H + L)
+    lm = HipCausalLM(sd, NQ, NKV, DH, rms_norm_eps=1e-6, rope_theta=1e6)
+    dev = lm.device
+    rng = np.random.default_rng(L + P)
+    ids = rng.integers(5, V, (n, L)).astype(np.int32)
+    start = np.array([0, L - 1, 7, L // 2, 33, 1, L - 40, 64][:n], np.int32)
+    for r in range(n):
+        ids[r, :start[r]] = 0
+    kw = {}
+    if P:
+        npre = 128 // P if 128 % P == 0 else 4                  # n_prefix * P must be a multiple of 128
+        while (npre * P) % 128:
+            npre += 1
+        pre = rng.integers(5, V, (npre, P)).astype(np.int32)
+        pstart = np.array([(0, P - 1, 5, P // 2)[i % 4] for i in range(npre)], np.int32)
+        for i in range(npre):
+            pre[i, :pstart[i]] = 0
+        handle = lm.prefix_kv_device(torch.from_numpy(pre).to(dev), torch.from_numpy(pstart).to(dev))
+        kw = dict(prefix=handle, prefix_of=torch.tensor([(i % (npre + 1)) - 1 for i in range(n)], dtype=torch.int32, device=dev))
+    run = lambda: lm.yes_no_logits_device(torch.from_numpy(ids).to(dev), torch.from_numpy(start).to(dev), 11, 42, **kw).cpu()
+    monkeypatch.delenv("RARC_LM_ATTN", raising=False)
+    resident = run()
+    monkeypatch.setenv("RARC_LM_ATTN", "stream")
+    streaming = run()
+    assert torch.isfinite(resident.float()).all()
+    assert torch.equal(resident.view(torch.int16), streaming.view(torch.int16))
 
 
 def test_reranker_end_to_end_matches_reference_steps(oracle):
