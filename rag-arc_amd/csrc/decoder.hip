@@ -70,11 +70,12 @@ __global__ __launch_bounds__(256) void rarc_lm_rmsnorm_kernel(half_t* x, const h
   }
 }
 
-// ---- rotary table: (cos, sin) of (position, pair i) as fp16 pairs, [L][DH/2] ------------------------------------------
+// ---- rotary table: per position a row of DH halves, cos of the DH/2 pairs then their sin ---------------------------------
 // inv_freq_i = theta^(-2i/DH); angle = pos * inv_freq_i in fp32, as the reference's rotary module computes them, then cast
 // to the activations' dtype before use.  Positions run over the PADDED sequence (the reference passes no position_ids).
 // Computed once per forward and read from cache by the attention kernel (computing sincosf where it is used cost
-// 374 us per layer at 51 200 tokens: the angles reach thousands of radians and need the accurate routine).
+// 374 us per layer at 51 200 tokens: the angles reach thousands of radians and need the accurate routine).  Planar
+// (cos[DH/2] | sin[DH/2], round 3; it was interleaved pairs) so that a 16-byte load is a packed-fp16 operand.
 __global__ __launch_bounds__(256) void rarc_lm_rope_table_kernel(int L, int DH, float theta, half2_t* table) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= L * (DH / 2)) return;
@@ -82,26 +83,60 @@ __global__ __launch_bounds__(256) void rarc_lm_rope_table_kernel(int L, int DH, 
   const float inv_freq = __builtin_exp2f(-(2.0f * (float)i / (float)DH) * __builtin_log2f(theta));
   float sn, cs;
   sincosf((float)pos * inv_freq, &sn, &cs);
-  table[idx] = (half2_t){(half_t)cs, (half_t)sn};
+  half_t* row = (half_t*)table + (size_t)pos * DH;
+  row[i] = (half_t)cs;
+  row[DH / 2 + i] = (half_t)sn;
 }
 
-// fp32 -> fp16 exactly as the reference's tensors round: the fp32 result first, then the cast.  Written as a plain cast
-// hipcc may pick v_fma_mixlo_f16 for `(half)(a * b)` in one kernel and v_mul_f32 + v_cvt_f16_f32 in another; the two
-// round differently in the rare double-rounding cases (two kernels that should agree bit for bit then differ in ~1e-3 of
-// their outputs by one fp16 ulp — measured).  The value passes through an opaque statement, so it exists as an fp32 number.
-__device__ __forceinline__ half_t lm_f16_of(float t) {
-  asm volatile("" : "+v"(t));
-  return (half_t)t;
+// ---- the arithmetic of RMSNorm + rotary embedding on 8 halves at a time (shared by every kernel below, so that they agree
+// bit for bit) ------------------------------------------------------------------------------------------------------
+// lm_scale8: RN_f16(x * inv) with x fp16, inv fp32 — the reference's `hidden.float() * rsqrt(...)` followed by `.to(fp16)`.
+// Written as a C cast hipcc picks v_fma_mixlo_f16 in one kernel and v_mul_f32 + v_cvt_f16_f32 in another, which round
+// differently in the rare double-rounding cases (two kernels that must agree then differ in ~1e-3 of their outputs by one fp16
+// ulp — measured); the instruction is spelled out: one v_fma_mix per element, straight into the packed halves.
+__device__ __forceinline__ half8 lm_scale8(const half8 x, const float inv) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 in = __builtin_bit_cast(u32x4, x);
+  u32x4 out;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    uint32_t o;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(o) : "v"(in[w]), "v"(inv));
+    out[w] = o;
+  }
+  return __builtin_bit_cast(half8, out);
+}
+// rotation of the pairs (a[e], b[e]) = elements (i, i + DH/2) by the angles whose cos / sin are cs / sn, in packed fp16
+// arithmetic (two roundings: the product b*sn, then the fused a*cs -+ it; the reference's fp16 tensors round three times):
+//   lo = a*cs - b*sn,  hi = b*cs + a*sn
+__device__ __forceinline__ void lm_rotate8(const half8 a, const half8 b, const half8 cs, const half8 sn, half8& lo, half8& hi) {
+  lo = __builtin_elementwise_fma(a, cs, -(b * sn));
+  hi = __builtin_elementwise_fma(b, cs, a * sn);
 }
 
 // ---- per-head RMSNorm, then rotary embedding (HF rotate_half convention), on MFMA operand fragments ---------------
 // f[ks][e] is element 16 ks + 8 hh + e of one head row (the lane pair (l, l ^ 32) holds the whole row), so the rotation
 // partner i + DH/2 of an element sits in the same lane (fragment ks + KS/2) and the row's sum of squares needs one
-// exchange.  Roundings follow the reference's fp16 tensors: x·inv -> fp16, ·weight -> fp16, rotation -> fp16.
+// exchange.  Roundings: x·inv -> fp16 (lm_scale8), ·weight -> fp16, rotation in fp16 (lm_rotate8).  `cs_row`: the row of the
+// rotary table (cos[DH/2] | sin[DH/2]).
 template <int DH>
 __device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* __restrict__ w, float eps,
-                                             const half2_t* __restrict__ cs_row, int hh) {
+                                             const half2_t* __restrict__ cs_row2, int hh) {
   constexpr int KS = DH / 16;
+  const half_t* cs_row = (const half_t*)cs_row2;
+  // every load of the weights and of the row's cos / sin is issued before the first use (round 3: inside the loop below
+  // each k-step waited for its own four loads — four memory round trips, ~9 k cycles per (q head, query block) unit)
+  half8 w0[KS / 2], w1[KS / 2], cs[KS / 2], sn[KS / 2];
+#pragma unroll
+  for (int ks = 0; ks < KS / 2; ++ks) {
+    const int i0 = 16 * ks + 8 * hh;
+    w0[ks] = *(const half8*)(w + i0);
+    w1[ks] = *(const half8*)(w + i0 + DH / 2);
+    cs[ks] = *(const half8*)(cs_row + i0);
+    sn[ks] = *(const half8*)(cs_row + DH / 2 + i0);
+  }
   float ss = 0.f;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -111,19 +146,8 @@ __device__ __forceinline__ void lm_norm_rope(half8 (&f)[DH / 16], const half_t* 
   const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
 #pragma unroll
   for (int ks = 0; ks < KS / 2; ++ks) {
-    const int i0 = 16 * ks + 8 * hh;
-    const half8 w0 = *(const half8*)(w + i0), w1 = *(const half8*)(w + i0 + DH / 2);
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 c0 = *(const u32x4*)(cs_row + i0), c1 = *(const u32x4*)(cs_row + i0 + 4);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? c0[e] : c1[e - 4]);
-      const float cs = (float)cs2[0], sn = (float)cs2[1];
-      const float a = (float)(half_t)((float)w0[e] * (float)lm_f16_of((float)f[ks][e] * inv));
-      const float b = (float)(half_t)((float)w1[e] * (float)lm_f16_of((float)f[ks + KS / 2][e] * inv));
-      f[ks][e] = lm_f16_of(a * cs - b * sn);
-      f[ks + KS / 2][e] = lm_f16_of(b * cs + a * sn);
-    }
+    const half8 a = w0[ks] * lm_scale8(f[ks], inv), b = w1[ks] * lm_scale8(f[ks + KS / 2], inv);
+    lm_rotate8(a, b, cs[ks], sn[ks], f[ks], f[ks + KS / 2]);
   }
 }
 
@@ -327,9 +351,9 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
     for (int pass = 0; pass < NP; ++pass) {
       const int uu = k0 + 8 * wave + pass * RPP + kr_in;
       pk_x[pass] = *(const half8*)(krow_ptr(uu) + 8 * kc);
-      const half2_t* cs_row = rope_row(uu) + 8 * (kc % (CH / 2));
-      pk_c0[pass] = *(const u32x4*)cs_row;
-      pk_c1[pass] = *(const u32x4*)(cs_row + 4);
+      const half_t* cs_row = (const half_t*)rope_row(uu) + 8 * (kc % (CH / 2));
+      pk_c0[pass] = *(const u32x4*)cs_row;                // cos of the chunk's 8 pairs
+      pk_c1[pass] = *(const u32x4*)(cs_row + DH / 2);     // their sin
     }
 #pragma unroll
     for (int it = 0; it < VI; ++it) {
@@ -350,24 +374,21 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
       float ss = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)x[e], (float)x[e], ss);
+      // (the two halves of the row first, then across the chunks: the order the resident kernel's lanes — which hold both
+      //  halves — sum in)
+      ss += __shfl_xor(ss, CH / 2, 64);
 #pragma unroll
-      for (int o2 = 1; o2 < CH; o2 <<= 1) ss += __shfl_xor(ss, o2, 64);
+      for (int o2 = 1; o2 < CH / 2; o2 <<= 1) ss += __shfl_xor(ss, o2, 64);
       const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
-      half8 xn;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xn[e] = (half_t)((float)kw[e] * (float)lm_f16_of((float)x[e] * inv));
+      const half8 xn = kw * lm_scale8(x, inv);
       u32x4 mine = __builtin_bit_cast(u32x4, xn), other;
 #pragma unroll
       for (int w4 = 0; w4 < 4; ++w4) other[w4] = (uint32_t)__shfl_xor((int)mine[w4], CH / 2, 64);
       const half8 pn = __builtin_bit_cast(half8, other);
-      half8 out;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? pk_c0[pass][e] : pk_c1[pass][e - 4]);
-        const float cs = (float)cs2[0], sn = (float)cs2[1];
-        // lower half: a cos - b sin with a = own, b = partner; upper half: b cos + a sin with b = own, a = partner
-        out[e] = lm_f16_of(upper ? (float)xn[e] * cs + (float)pn[e] * sn : (float)xn[e] * cs - (float)pn[e] * sn);
-      }
+      const half8 cs = __builtin_bit_cast(half8, pk_c0[pass]), sn = __builtin_bit_cast(half8, pk_c1[pass]);
+      // lower half: a cos - b sin with a = own, b = partner; upper half: b cos + a sin with b = own, a = partner (lm_rotate8)
+      const half8 t = pn * sn;
+      const half8 out = __builtin_elementwise_fma(xn, cs, upper ? t : -t);
       *(half8*)(kimg[buf] + r * KROW + 8 * kc) = out;
     }
 #pragma unroll
@@ -545,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
 // Same arithmetic, same roundings and the same summation order per query as the streaming kernel (tiles of 32 keys in
 // ascending order, deferred rescale): the two kernels return identical bits (tests/test_gpu_reranker_lm.py).
 __host__ __device__ inline int lm_attn_vrow(int keys) { return keys <= 40 ? 40 : 40 + 128 * ((keys - 40 + 127) / 128); }
-template <int DH, int NP>   // NP: passes of K rows the staging registers hold (kcap <= NP * 32 keys at head_dim 128, NP * 64 at 64)
+template <int DH, int NP>   // NP: passes of K rows the staging registers hold (kcap <= NP * 64 keys at head_dim 128, NP * 128 at 64)
 __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(const half_t* __restrict__ qkv,
                                                                             const int32_t* __restrict__ start, int L, int n_q,
                                                                             int n_kv, int q_blocks, const half_t* __restrict__ qn_w,
@@ -557,8 +578,9 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
   constexpr int MB = DH / 32;
   constexpr int KROW = DH + 8;          // halves per K row: DH + 16 bytes
   constexpr int CH = DH / 8;            // 16-byte chunks per row
-  constexpr int RPW = 64 / CH;          // K rows per wave and pass
-  constexpr int RPP = 8 * RPW;          // K rows per workgroup pass (32 at DH = 128, 64 at DH = 64)
+  constexpr int LPR = CH / 2;           // lanes per K row: a lane owns chunks c and c + CH/2 — both halves of its rotation pairs
+  constexpr int RPW = 64 / LPR;         // K rows per wave and pass
+  constexpr int RPP = 8 * RPW;          // K rows per workgroup pass (64 at DH = 128, 128 at DH = 64)
   extern __shared__ __attribute__((aligned(16))) char lm_attn_smem[];
   half_t* kimg = (half_t*)lm_attn_smem;                 // [kcap][KROW]
   half_t* vt = kimg + (size_t)kcap * KROW;              // [DH][VROW]: VROW = 40 mod 128 halves, the bank pattern of the streaming kernel's 40
@@ -600,6 +622,11 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
   auto krow_ptr = [&](int uu) -> const half_t* { return row_ptr(uu, pkbase, kbase); };
   auto vrow_ptr = [&](int uu) -> const half_t* { return row_ptr(uu, pvbase, vbase); };
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#ifdef LM_ATTN_TIMELINE
+  const bool tl_on = blockIdx.x == gridDim.x / 2 + 3 && threadIdx.x == 0;
+  int tl_i = 1;
+#endif
+  LM_TL(0);
   const int k_first = (u_min / 32) * 32;
   const int k_total = P + (L - s0);                           // virtual keys [k_first, k_total) exist
   int n_tiles = (k_total - k_first + 31) / 32;
@@ -621,21 +648,22 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
   // The loads are unconditional (rows past the end are clamped onto the last one, only the LDS writes are predicated):
   // with a branch per pass hipcc interleaves loads, waits and unpacking ----
   {
-    constexpr int MAXV = (NP + 1) / 2;                          // V items per thread
-    const int kc = lane % CH, kr_in = lane / CH;
-    const half8 kw = *(const half8*)(kn_w + 8 * kc);
-    const bool upper = kc >= CH / 2;
+    constexpr int MAXV = NP;                                    // V items per thread
+    const int kc = lane % LPR, kr_in = lane / LPR;
+    const half8 kw_lo = *(const half8*)(kn_w + 8 * kc), kw_hi = *(const half8*)(kn_w + DH / 2 + 8 * kc);
     const int rows = n_tiles * 32;                              // <= NP * RPP (host)
     const int items = n_tiles * 16 * CH;                        // (key pair, 8-d chunk) items of V
-    half8 x[NP];
+    half8 xl[NP], xh[NP];
     u32x4 c0[NP], c1[NP];
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
       const int uu = k_first + g * RPP + wave * RPW + kr_in;
-      x[g] = *(const half8*)(krow_ptr(uu) + 8 * kc);
-      const half2_t* cs_row = rope_row(uu) + 8 * (kc % (CH / 2));
-      c0[g] = *(const u32x4*)cs_row;
-      c1[g] = *(const u32x4*)(cs_row + 4);
+      const half_t* kp = krow_ptr(uu) + 8 * kc;
+      xl[g] = *(const half8*)kp;
+      xh[g] = *(const half8*)(kp + DH / 2);
+      const half_t* cs_row = (const half_t*)rope_row(uu) + 8 * kc;
+      c0[g] = *(const u32x4*)cs_row;                      // cos of the chunk's 8 pairs
+      c1[g] = *(const u32x4*)(cs_row + DH / 2);           // their sin
     }
     half8 v0[MAXV], v1[MAXV];
 #pragma unroll
@@ -646,38 +674,36 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
       v0[g] = *(const half8*)(vrow_ptr(uu) + 8 * c8);
       v1[g] = *(const half8*)(vrow_ptr(uu + 1) + 8 * c8);
     }
+    LM_TL(tl_i++);   // loads issued
     // (every loaded register passes through an opaque statement: nothing of the processing below moves up between the loads)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < NP; ++g) asm volatile("" : "+v"(x[g]), "+v"(c0[g]), "+v"(c1[g]));
+    for (int g = 0; g < NP; ++g) asm volatile("" : "+v"(xl[g]), "+v"(xh[g]), "+v"(c0[g]), "+v"(c1[g]));
 #pragma unroll
     for (int g = 0; g < MAXV; ++g) asm volatile("" : "+v"(v0[g]), "+v"(v1[g]));
     __builtin_amdgcn_sched_barrier(0);
+    LM_TL(tl_i++);   // loads arrived
 #pragma unroll
     for (int g = 0; g < NP; ++g) {
       const int r = g * RPP + wave * RPW + kr_in;
-      float ss = 0.f;
+      float ss = 0.f, ss_hi = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)x[g][e], (float)x[g][e], ss);
+      for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)xl[g][e], (float)xl[g][e], ss);
 #pragma unroll
-      for (int o2 = 1; o2 < CH; o2 <<= 1) ss += __shfl_xor(ss, o2, 64);
+      for (int e = 0; e < 8; ++e) ss_hi = __builtin_fmaf((float)xh[g][e], (float)xh[g][e], ss_hi);
+      ss += ss_hi;
+#pragma unroll
+      for (int o2 = 1; o2 < LPR; o2 <<= 1) ss += __shfl_xor(ss, o2, 64);
       const float inv = 1.0f / __builtin_sqrtf(ss / (float)DH + eps);
-      half8 xn;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) xn[e] = (half_t)((float)kw[e] * (float)lm_f16_of((float)x[g][e] * inv));
-      u32x4 mine = __builtin_bit_cast(u32x4, xn), other;
-#pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) other[w4] = (uint32_t)__shfl_xor((int)mine[w4], CH / 2, 64);
-      const half8 pn = __builtin_bit_cast(half8, other);
-      half8 out;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const half2_t cs2 = __builtin_bit_cast(half2_t, e < 4 ? c0[g][e] : c1[g][e - 4]);
-        const float cs = (float)cs2[0], sn = (float)cs2[1];
-        out[e] = lm_f16_of(upper ? (float)xn[e] * cs + (float)pn[e] * sn : (float)xn[e] * cs - (float)pn[e] * sn);
+      const half8 a = kw_lo * lm_scale8(xl[g], inv), b = kw_hi * lm_scale8(xh[g], inv);
+      half8 lo, hi;
+      lm_rotate8(a, b, __builtin_bit_cast(half8, c0[g]), __builtin_bit_cast(half8, c1[g]), lo, hi);
+      if (r < rows) {
+        *(half8*)(kimg + r * KROW + 8 * kc) = lo;
+        *(half8*)(kimg + r * KROW + DH / 2 + 8 * kc) = hi;
       }
-      if (r < rows) *(half8*)(kimg + r * KROW + 8 * kc) = out;
     }
+    LM_TL(tl_i++);   // K image written
 #pragma unroll
     for (int g = 0; g < MAXV; ++g) {
       const int i = threadIdx.x + 512 * g;
@@ -688,7 +714,9 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
       }
     }
   }
+  LM_TL(tl_i++);     // V^T written
   __syncthreads();
+  LM_TL(tl_i++);     // barrier passed
 
   // ---- phase 2: this wave's units, no barrier from here on ----
   for (int r = 0;; ++r) {
@@ -703,7 +731,12 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
     load_q(j);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = qraw[ks];
-    lm_norm_rope<DH>(qf, qn_w, eps, rope_row(uq), hh);
+    // (the q-norm weights are the same for every unit: hoisted out of this loop they would sit in 32 registers through the
+    //  key loops — spilled, reloaded from scratch per unit; the pointer goes through an opaque copy instead)
+    const half_t* qn_w_unit = qn_w;
+    asm volatile("" : "+s"(qn_w_unit));
+    lm_norm_rope<DH>(qf, qn_w_unit, eps, rope_row(uq), hh);
+    LM_TL(tl_i++);   // unit: q ready
     f32x16 o[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
@@ -743,6 +776,7 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
       }
       st = st_next;
     }
+    LM_TL(tl_i++);   // unit: key loop done
     if (q0 + col < L) {
       const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
       half_t* out = ctx + ((size_t)b * L + q0 + col) * (size_t)n_q * DH + (size_t)hd * DH;
@@ -756,6 +790,7 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
         }
     }
   }
+  LM_TL(tl_i++);     // all units stored
 }
 
 // ---- SwiGLU: h[t][j] = silu(g[t][j]) · u[t][j] from the fused gate/up GEMM output, whose columns come in groups of 16:
@@ -911,15 +946,16 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
   const size_t attn_lds = (size_t)attn_kcap * (DH + 8) * 2 + (size_t)DH * attn_vrow * 2;
   const char* attn_env = getenv("RARC_LM_ATTN");   // (read per call: the tests switch it inside one process)
   const bool attn_stream_only = attn_env && !strcmp(attn_env, "stream");
-  const int attn_np = (attn_kcap + (DH == 128 ? 32 : 64) - 1) / (DH == 128 ? 32 : 64);   // passes of K rows its staging holds in registers
-  const bool resident = !attn_stream_only && attn_lds <= 160 * 1024 && attn_np <= 9;
+  const int attn_rpp = DH == 128 ? 64 : 128;                  // K rows one pass of its staging covers
+  const int attn_np = (attn_kcap + attn_rpp - 1) / attn_rpp;   // passes its staging holds in registers (<= 5)
+  const bool resident = !attn_stream_only && attn_lds <= 160 * 1024 && attn_np <= 5;
   if (resident) {
     static RarcPerDevice attr_dev;
     size_t& attr = attr_dev.cur();
     if (!attr) {
 #define LM_RES_ATTR(DHV, NPV) RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_lm_attention_resident_kernel<DHV, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-      LM_RES_ATTR(128, 3); LM_RES_ATTR(128, 5); LM_RES_ATTR(128, 7); LM_RES_ATTR(128, 9);
-      LM_RES_ATTR(64, 3); LM_RES_ATTR(64, 5); LM_RES_ATTR(64, 7); LM_RES_ATTR(64, 9);
+      LM_RES_ATTR(128, 2); LM_RES_ATTR(128, 3); LM_RES_ATTR(128, 4); LM_RES_ATTR(128, 5);
+      LM_RES_ATTR(64, 2); LM_RES_ATTR(64, 3); LM_RES_ATTR(64, 4); LM_RES_ATTR(64, 5);
 #undef LM_RES_ATTR
       attr = 1;
     }
@@ -945,11 +981,11 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
                          d_start, seq_len, NQ, NKV, q_blocks, (const half_t*)Ly.q_norm, (const half_t*)Ly.k_norm, m->rms_eps,    \
                          (const half2_t*)rope, rope_rows, ctx, pf, attn_kcap, attn_vrow)
       if (DH == 128) {
-        if (attn_np <= 3) LM_RES_LAUNCH(128, 3); else if (attn_np <= 5) LM_RES_LAUNCH(128, 5);
-        else if (attn_np <= 7) LM_RES_LAUNCH(128, 7); else LM_RES_LAUNCH(128, 9);
+        if (attn_np <= 2) LM_RES_LAUNCH(128, 2); else if (attn_np == 3) LM_RES_LAUNCH(128, 3);
+        else if (attn_np == 4) LM_RES_LAUNCH(128, 4); else LM_RES_LAUNCH(128, 5);
       } else {
-        if (attn_np <= 3) LM_RES_LAUNCH(64, 3); else if (attn_np <= 5) LM_RES_LAUNCH(64, 5);
-        else if (attn_np <= 7) LM_RES_LAUNCH(64, 7); else LM_RES_LAUNCH(64, 9);
+        if (attn_np <= 2) LM_RES_LAUNCH(64, 2); else if (attn_np == 3) LM_RES_LAUNCH(64, 3);
+        else if (attn_np == 4) LM_RES_LAUNCH(64, 4); else LM_RES_LAUNCH(64, 5);
       }
 #undef LM_RES_LAUNCH
     } else if (DH == 128)

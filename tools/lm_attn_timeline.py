@@ -19,6 +19,6 @@ lib.rarc_lm_debug_timeline(buf, 512)
 t = np.array(buf[:64], dtype=np.int64)
 n = int(np.argmax(t == 0)) if (t == 0).any() else len(t)
 t = t[:n] - t[0]
-print("stamps: start | q ready | per tile: (stored, barrier passed, computed) ... | loop end  [s_memtime ticks, 100 MHz]")
+print("stamps (shader cycles)")
 print(t.tolist())
 print("deltas:", np.diff(t).tolist())
