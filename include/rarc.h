@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 300 /* 0.3.0: fp32-class encoder forward (rarc_enc32_*: split-operand fp16 MFMA, fp32 everywhere else) */
+#define RARC_VERSION 310 /* 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
+                            * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
 #define RARC_OK 0
 #define RARC_E_INVALID -1     /* bad argument (null pointer, unsupported d/k, ...) */
@@ -385,6 +386,14 @@ typedef struct RarcEncModel {
   const RarcEncLayer* layers; /* host array [n_layers] */
   int vocab;   /* rows of `word`  (REQUIRED > 0: token ids are clamped into [0, vocab)) */
   int max_pos; /* rows of `pos`   (REQUIRED >= seq_len) */
+  /* MPNet family (the reference's default checkpoint, sentence-transformers/all-mpnet-base-v2, huggingface.py:6): one
+   * relative-position bias shared by all layers, added to the scaled scores before the softmax
+   * (transformers MPNetEncoder.compute_position_bias).  It depends on key - query only:
+   * rel_bias fp32 [heads][2*rel_span - 1], entry [h][key - query + rel_span - 1]; null = none (BERT).
+   * REQUIRED rel_span >= seq_len when set.  (MPNet's position ids start at 2 and it has no token types: pass
+   * pos = table + 2 rows, max_pos = rows - 2, type0 = zeros.) */
+  const float* rel_bias;
+  int rel_span;
 } RarcEncModel;
 size_t rarc_enc_workspace_bytes(int hidden, int inter, int n_tokens);
 int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
@@ -415,6 +424,8 @@ typedef struct RarcEnc32Model {
   const float *word, *pos, *type0, *emb_g, *emb_b; /* fp32 tables and LayerNorm parameters */
   const RarcEnc32Layer* layers;                    /* host array [n_layers] */
   int vocab, max_pos;                              /* REQUIRED, as in RarcEncModel */
+  const float* rel_bias;                           /* relative-position attention bias, as in RarcEncModel (null = none) */
+  int rel_span;
 } RarcEnc32Model;
 int rarc_enc32_split_weight(const float* d_w, int n, int k, uint16_t* d_w3, float* d_rw, void* stream);
 int rarc_enc32_split_rows(const float* d_x, int m, int k, uint16_t* d_a3, float* d_ra, void* stream);

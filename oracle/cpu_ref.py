@@ -417,6 +417,110 @@ def bert_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-12, normalize=Tru
     return normalize_L2(cls) if normalize else cls
 
 
+def mpnet_relative_position_bucket(relative_position, num_buckets=32, max_distance=128):
+    """transformers 4.x MPNetEncoder.relative_position_bucket (models/mpnet/modeling_mpnet.py; third-party dependency of the
+    reference's default checkpoint, sentence-transformers/all-mpnet-base-v2, huggingface.py:6), restated in numpy with its
+    float32 arithmetic: relative_position = key - query; half the buckets per direction, exact below num_buckets/4, then
+    logarithmic up to max_distance.  Pinned to the transformers function over every offset in tests/test_mpnet_oracle.py."""
+    import math
+
+    rp = np.asarray(relative_position, dtype=np.int64)
+    n = -rp
+    nb = num_buckets // 2
+    ret = (n < 0).astype(np.int64) * nb
+    n = np.abs(n)
+    max_exact = nb // 2
+    is_small = n < max_exact
+    with np.errstate(divide="ignore"):
+        val = np.log(n.astype(np.float32) / np.float32(max_exact)) / np.float32(math.log(max_distance / max_exact)) \
+            * np.float32(nb - max_exact)
+    val = np.where(np.isfinite(val), val, 0).astype(np.float32)
+    val_if_large = np.minimum(max_exact + val.astype(np.int64), nb - 1)
+    return ret + np.where(is_small, n, val_if_large)
+
+
+def mpnet_rel_bias_table(rel_weight, span):
+    """[heads][2*span - 1] table of MPNetEncoder.compute_position_bias: entry [h][key - query + span - 1] =
+    relative_attention_bias.weight[bucket(key - query)][h] (the bias depends on key - query only)."""
+    w = np.asarray(rel_weight, dtype=np.float32)                     # [num_buckets][heads]
+    delta = np.arange(-(span - 1), span)
+    return np.ascontiguousarray(w[mpnet_relative_position_bucket(delta, num_buckets=w.shape[0])].T)
+
+
+def mpnet_forward_f32(sd, input_ids, lengths, num_heads, eps=1e-5, normalize=True, pooling="mean", dtype=np.float32):
+    """MPNet encoder forward in numpy (transformers MPNetModel, the architecture of the reference's DEFAULT embedding model,
+    huggingface.py:6), mean pooling over the real tokens + L2 normalisation as the checkpoint's sentence-transformers
+    modules do.  `sd`: MPNetModel state dict (numpy arrays, no prefix).  Differences from BERT: no token types, position
+    ids start at padding_idx + 1 = 2 for the real tokens (right-padded batches), separate q / k / v / o projections under
+    attention.attn, and ONE relative-position bias (32 buckets x heads, shared by all layers) added to the scaled scores.
+    Pinned against transformers.MPNetModel in tests/test_mpnet_oracle.py."""
+    from math import sqrt
+
+    from scipy.special import erf
+
+    g = lambda k: np.asarray(sd[k], dtype=np.float32).astype(dtype)
+    ids = np.asarray(input_ids)
+    n, L = ids.shape
+    lens = np.asarray(lengths)
+
+    def ln(x, w, b):
+        mu = x.mean(-1, keepdims=True)
+        var = ((x - mu) ** 2).mean(-1, keepdims=True)
+        return (x - mu) / np.sqrt(var + eps) * w + b
+
+    x = g("embeddings.word_embeddings.weight")[ids] + g("embeddings.position_embeddings.weight")[None, 2:L + 2]
+    x = ln(x, g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"))
+    H = x.shape[-1]
+    dh = H // num_heads
+    mask = np.where(np.arange(L)[None, :] < lens[:, None], 0.0, -np.inf).astype(dtype)   # [n][L] keys
+    tab = mpnet_rel_bias_table(sd["encoder.relative_attention_bias.weight"], L).astype(dtype)   # [heads][2L-1]
+    idx = np.arange(L)[None, :] - np.arange(L)[:, None] + L - 1                                  # [query][key]
+    bias = tab[:, idx]                                                                          # [heads][L][L]
+    i = 0
+    while f"encoder.layer.{i}.attention.attn.q.weight" in sd:
+        p = f"encoder.layer.{i}."
+        lin = lambda t, name: t @ g(p + name + ".weight").T + g(p + name + ".bias")
+        q = lin(x, "attention.attn.q").reshape(n, L, num_heads, dh).transpose(0, 2, 1, 3)
+        k = lin(x, "attention.attn.k").reshape(n, L, num_heads, dh).transpose(0, 2, 1, 3)
+        v = lin(x, "attention.attn.v").reshape(n, L, num_heads, dh).transpose(0, 2, 1, 3)
+        s = q @ k.transpose(0, 1, 3, 2) / sqrt(dh) + bias[None] + mask[:, None, None, :]
+        s = s - s.max(-1, keepdims=True)
+        pr = np.exp(s)
+        pr = pr / pr.sum(-1, keepdims=True)
+        ctx = (pr @ v).transpose(0, 2, 1, 3).reshape(n, L, H)
+        x = ln(lin(ctx, "attention.attn.o") + x, g(p + "attention.LayerNorm.weight"), g(p + "attention.LayerNorm.bias"))
+        h = lin(x, "intermediate.dense")
+        h = 0.5 * h * (1.0 + erf(h / np.sqrt(2.0)))
+        x = ln(lin(h.astype(dtype), "output.dense") + x, g(p + "output.LayerNorm.weight"), g(p + "output.LayerNorm.bias"))
+        i += 1
+    if pooling == "mean":
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(dtype)[:, :, None]
+        out = ((x * m).sum(1) / m.sum(1)).astype(dtype)
+    else:
+        out = x[:, 0, :].astype(dtype)
+    if dtype != np.float32:
+        return out / np.linalg.norm(out, axis=1, keepdims=True) if normalize else out
+    return normalize_L2(out) if normalize else out
+
+
+def random_mpnet_state_dict(hidden, layers, heads, inter, vocab=1000, max_pos=130, seed=0, scale=0.05, buckets=32):
+    """Seeded synthetic MPNetModel weights (HuggingFace names, no prefix)."""
+    rng = np.random.default_rng(seed)
+    r = lambda *shape: (rng.standard_normal(shape) * scale).astype(np.float32)
+    sd = {"embeddings.word_embeddings.weight": r(vocab, hidden) * 4, "embeddings.position_embeddings.weight": r(max_pos, hidden),
+          "embeddings.LayerNorm.weight": 1 + r(hidden), "embeddings.LayerNorm.bias": r(hidden),
+          "encoder.relative_attention_bias.weight": r(buckets, heads) * 10}
+    for i in range(layers):
+        p = f"encoder.layer.{i}."
+        for nm in ("q", "k", "v", "o"):
+            sd[p + f"attention.attn.{nm}.weight"], sd[p + f"attention.attn.{nm}.bias"] = r(hidden, hidden), r(hidden)
+        sd[p + "attention.LayerNorm.weight"], sd[p + "attention.LayerNorm.bias"] = 1 + r(hidden), r(hidden)
+        sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"] = r(inter, hidden), r(inter)
+        sd[p + "output.dense.weight"], sd[p + "output.dense.bias"] = r(hidden, inter), r(hidden)
+        sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"] = 1 + r(hidden), r(hidden)
+    return sd
+
+
 def random_bert_state_dict(hidden, layers, heads, inter, vocab=1000, max_pos=128, seed=0, scale=0.05):
     """Seeded synthetic BertModel weights (HuggingFace names); LayerNorm weights near 1."""
     rng = np.random.default_rng(seed)

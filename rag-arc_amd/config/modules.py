@@ -43,8 +43,8 @@ class TableEmbeddingsConfig(AbstractConfig):
 class HipBertEmbeddingsConfig(AbstractConfig):
     """The MI355X encoder as a registered embedding provider (the reference's HuggingFaceEmbeddings slot,
     core/file_management/embeddings/huggingface.py:85-98,116-126: texts in, python float lists out).
-    `weights_path`: a BertModel state dict (HuggingFace tensor names) as .safetensors or .npz;
-    `vocab_path`: the checkpoint's vocab.txt (WordPiece)."""
+    `weights_path`: a BertModel or MPNetModel state dict (HuggingFace tensor names; the reference's default checkpoint,
+    all-mpnet-base-v2, is MPNet with pooling = "mean") as .safetensors or .npz; `vocab_path`: the checkpoint's vocab.txt."""
     type: Literal["hip_bert_embeddings"] = "hip_bert_embeddings"
     weights_path: str
     vocab_path: str
@@ -73,8 +73,10 @@ class HipBertEmbeddingsConfig(AbstractConfig):
         enc = HipBertEncoder(load_state_dict(self.weights_path), num_heads=self.num_heads,
                              layer_norm_eps=self.layer_norm_eps, device=self.device, pooling=self.pooling,
                              precision=self.precision)
+        specials = dict(cls_token="<s>", sep_token="</s>", pad_token="<pad>", never_split=["<mask>", "<unk>"]) \
+            if enc.model_type == "mpnet" else {}                       # MPNetTokenizer's specials over the same WordPiece
         tok = WordPieceTokenizer.from_file(self.vocab_path, do_lower_case=self.do_lower_case,
-                                           max_length=min(self.max_length, enc.max_pos))
+                                           max_length=min(self.max_length, enc.max_pos), **specials)
         return BuiltModule(config=self, impl=HipBertEmbeddings(enc, tok, max_length=self.max_length,
                                                                batch_size=self.batch_size,
                                                                normalize_embeddings=self.normalize_embeddings,

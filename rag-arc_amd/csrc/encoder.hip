@@ -1058,11 +1058,12 @@ __global__ __launch_bounds__(256) void rarc_attention_kernel(const half_t* qkv, 
 // Online softmax across key tiles (running max / sum per query, accumulator rescaled per lane).
 // Keys >= lens[seq] are masked; rows >= seq_len are neither loaded past the end nor stored.
 // ------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, bool REL>   // REL: scores get the relative-position bias rel[head][key - query + rel_span - 1] (MPNet)
 __global__ __launch_bounds__(256) void rarc_attention_mfma_kernel(const half_t* __restrict__ qkv,
                                                                   const int32_t* __restrict__ lens, int L, int H,
                                                                   int n_heads, int q_blocks, int n_units,
-                                                                  half_t* __restrict__ ctx) {
+                                                                  half_t* __restrict__ ctx, const float* __restrict__ rel,
+                                                                  int rel_span) {
   constexpr int KS = DH / 16;  // k-steps of the QK^T product
   constexpr int MB = DH / 32;  // 32-row blocks of O^T
   constexpr int VROW = 40;     // halves per row of the transposed V image (32 keys + 8 padding)
@@ -1115,7 +1116,13 @@ __global__ __launch_bounds__(256) void rarc_attention_mfma_kernel(const half_t* 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
-      s[r] = key < len ? st[r] * scale : -INFINITY;
+      float v = st[r] * scale;
+      if (REL) {   // (index clamped into the table: keys past the sequence are masked below anyway)
+        int ri = key - (q0 + col) + rel_span - 1;
+        ri = ri < 0 ? 0 : (ri > 2 * rel_span - 2 ? 2 * rel_span - 2 : ri);
+        v += rel[(size_t)hd * (2 * rel_span - 1) + ri];
+      }
+      s[r] = key < len ? v : -INFINITY;
       tmax = fmaxf(tmax, s[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -1425,22 +1432,32 @@ extern "C" int rarc_enc_add_ln(const uint16_t* d_x, const uint16_t* d_resid, con
   return RARC_OK;
 }
 
-extern "C" int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
-                                  int n_heads, uint16_t* d_ctx, void* stream) {
+static int enc_attention_impl(const uint16_t* d_qkv, const int32_t* d_lens, int n_seq, int seq_len, int hidden, int n_heads,
+                              uint16_t* d_ctx, const float* d_rel, int rel_span, void* stream) {
   RARC_REQUIRE(d_qkv && d_lens && d_ctx, RARC_E_INVALID, "rarc_enc_attention: null pointer");
   RARC_REQUIRE(n_heads > 0 && (hidden == n_heads * 64 || hidden == n_heads * 32) && seq_len > 0 && seq_len <= 512 &&
                    n_seq > 0,
                RARC_E_UNSUPPORTED, "rarc_enc_attention: head_dim must be 32 or 64 and seq_len <= 512");
+  RARC_REQUIRE(!d_rel || rel_span >= seq_len, RARC_E_INVALID,
+               "rarc_enc_forward: the relative-position bias spans %d positions, the batch is %d long", rel_span, seq_len);
   const int q_blocks = (seq_len + 31) / 32;
   const int n_units = n_seq * n_heads * q_blocks;  // one wave each, four per workgroup
-  if (hidden == n_heads * 64)
-    hipLaunchKernelGGL(rarc_attention_mfma_kernel<64>, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, n_units, (half_t*)d_ctx);
-  else
-    hipLaunchKernelGGL(rarc_attention_mfma_kernel<32>, dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, n_units, (half_t*)d_ctx);
+#define ENC_ATTN_LAUNCH(DHV, RELV)                                                                                  \
+  hipLaunchKernelGGL((rarc_attention_mfma_kernel<DHV, RELV>), dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream, \
+                     (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, n_units, (half_t*)d_ctx, d_rel, rel_span)
+  if (hidden == n_heads * 64) {
+    if (d_rel) ENC_ATTN_LAUNCH(64, true); else ENC_ATTN_LAUNCH(64, false);
+  } else {
+    if (d_rel) ENC_ATTN_LAUNCH(32, true); else ENC_ATTN_LAUNCH(32, false);
+  }
+#undef ENC_ATTN_LAUNCH
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
+}
+
+extern "C" int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
+                                  int n_heads, uint16_t* d_ctx, void* stream) {
+  return enc_attention_impl(d_qkv, d_lens, n_seq, seq_len, hidden, n_heads, d_ctx, nullptr, 0, stream);
 }
 
 extern "C" int rarc_enc_pool(const uint16_t* d_hidden, int n_seq, int seq_len, int hidden, int normalize,
@@ -1523,7 +1540,7 @@ extern "C" int rarc_enc_forward(const RarcEncModel* model, const int32_t* d_ids,
   for (int l = 0; l < model->n_layers && rc == RARC_OK; ++l) {
     const RarcEncLayer& L = model->layers[l];
     if ((rc = rarc_enc_gemm(x, L.qkv_w, L.qkv_b, qkv, M, 3 * H, H, 0, stream)) != RARC_OK) break;
-    if ((rc = rarc_enc_attention(qkv, d_lens, n_seq, seq_len, H, model->heads, ctx, stream)) != RARC_OK) break;
+    if ((rc = enc_attention_impl(qkv, d_lens, n_seq, seq_len, H, model->heads, ctx, model->rel_bias, model->rel_span, stream)) != RARC_OK) break;
     if ((rc = proj_ln(ctx, L.o_w, L.o_b, H, s_o, L.ln1_g, L.ln1_b)) != RARC_OK) break;
     if ((rc = rarc_enc_gemm(x, L.f1_w, L.f1_b, mid, M, I, H, 1, stream)) != RARC_OK) break;
     rc = proj_ln(mid, L.f2_w, L.f2_b, I, s_f2, L.ln2_g, L.ln2_b);

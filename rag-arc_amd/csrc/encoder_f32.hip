@@ -239,11 +239,12 @@ __global__ __launch_bounds__(256) void rarc_e32_split_weight_kernel(const float*
 // Online softmax over key tiles with libm expf; keys >= lens[seq] masked; rows >= seq_len neither loaded past the
 // end nor stored.
 // ------------------------------------------------------------------------------------------
-template <int DH>
+template <int DH, bool REL>   // REL: scores get the relative-position bias rel[head][key - query + rel_span - 1] (MPNet)
 __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __restrict__ P, const float* __restrict__ ra,
                                                                  const float* __restrict__ rw, const float* __restrict__ bias,
                                                                  const int32_t* __restrict__ lens, int L, int H, int n_heads,
-                                                                 int q_blocks, int n_units, float* __restrict__ ctx) {
+                                                                 int q_blocks, int n_units, float* __restrict__ ctx,
+                                                                 const float* __restrict__ rel, int rel_span) {
   constexpr int HD = DH / 2;     // floats of a q / k row one lane half contracts
   constexpr int MB = DH / 32;    // 32-row blocks of O^T
   constexpr int VS = DH + 8;     // row stride of the V tile in LDS (floats)
@@ -315,7 +316,13 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
-      pr[r] = key < len ? st[r] * scale : -INFINITY;
+      float v = st[r] * scale;
+      if (REL) {   // (index clamped into the table: keys past the sequence are masked below anyway)
+        int ri = key - (q0 + col) + rel_span - 1;
+        ri = ri < 0 ? 0 : (ri > 2 * rel_span - 2 ? 2 * rel_span - 2 : ri);
+        v += rel[(size_t)hd * (2 * rel_span - 1) + ri];
+      }
+      pr[r] = key < len ? v : -INFINITY;
       tmax = fmaxf(tmax, pr[r]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -454,6 +461,8 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
                    (H == model->heads * 64 || H == model->heads * 32) && seq_len <= 512,
                RARC_E_UNSUPPORTED, "rarc_enc32_forward: hidden %d / inter %d / heads %d / seq_len %d not supported", H, I,
                model->heads, seq_len);
+  RARC_REQUIRE(!model->rel_bias || model->rel_span >= seq_len, RARC_E_INVALID,
+               "rarc_enc32_forward: the relative-position bias spans %d positions, the batch is %d long", model->rel_span, seq_len);
   const long long m_ll = (long long)n_seq * seq_len;
   RARC_REQUIRE(m_ll % 128 == 0 && m_ll < (1ll << 31), RARC_E_UNSUPPORTED,
                "rarc_enc32_forward: n_seq*seq_len must be a multiple of 128 (got %lld)", m_ll);
@@ -481,12 +490,15 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     const RarcEnc32Layer& Ly = model->layers[l];
     // fused q|k|v projection; its scales and bias are applied by the attention kernel's loads
     if ((rc = rarc_gemm_f16_f32out(xs, Ly.qkv_w3, P, M, 3 * H, 3 * H, hs)) != RARC_OK) return rc;
-    if (H == model->heads * 64)
-      hipLaunchKernelGGL(rarc_e32_attention_kernel<64>, dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw,
-                         Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx);
-    else
-      hipLaunchKernelGGL(rarc_e32_attention_kernel<32>, dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw,
-                         Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx);
+#define E32_ATTN_LAUNCH(DHV, RELV)                                                                                     \
+    hipLaunchKernelGGL((rarc_e32_attention_kernel<DHV, RELV>), dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw, \
+                       Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx, model->rel_bias, model->rel_span)
+    if (H == model->heads * 64) {
+      if (model->rel_bias) E32_ATTN_LAUNCH(64, true); else E32_ATTN_LAUNCH(64, false);
+    } else {
+      if (model->rel_bias) E32_ATTN_LAUNCH(32, true); else E32_ATTN_LAUNCH(32, false);
+    }
+#undef E32_ATTN_LAUNCH
     RARC_HIP_CHECK(hipGetLastError());
     if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs))) return rc;
     // attention output projection -> x = LayerNorm(proj + x)

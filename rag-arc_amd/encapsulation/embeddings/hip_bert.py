@@ -33,8 +33,32 @@ def load_state_dict(path: str) -> Dict[str, "np.ndarray"]:
     raise ValueError(f"unsupported weight file (want .safetensors or .npz): {path}")
 
 
+def _mpnet_bucket(delta, num_buckets=32, max_distance=128):
+    """transformers' MPNetEncoder.relative_position_bucket for delta = key - query (float32 arithmetic as there): half the
+    buckets per direction, exact below num_buckets / 4, logarithmic up to max_distance.  tests/test_mpnet_oracle.py pins the
+    oracle's copy of this function to transformers; tests/test_gpu_mpnet.py pins this one to the oracle's."""
+    n = -np.asarray(delta, dtype=np.int64)
+    nb = num_buckets // 2
+    ret = (n < 0).astype(np.int64) * nb
+    n = np.abs(n)
+    max_exact = nb // 2
+    with np.errstate(divide="ignore"):
+        val = np.log(n.astype(np.float32) / np.float32(max_exact)) / np.float32(math.log(max_distance / max_exact)) \
+            * np.float32(nb - max_exact)
+    val = np.where(np.isfinite(val), val, 0).astype(np.float32)
+    return ret + np.where(n < max_exact, n, np.minimum(max_exact + val.astype(np.int64), nb - 1))
+
+
+def _mpnet_rel_bias_table(rel_weight, span: int) -> "np.ndarray":
+    """relative_attention_bias.weight [buckets][heads] -> fp32 [heads][2*span - 1], entry [h][key - query + span - 1]."""
+    w = np.asarray(rel_weight, dtype=np.float32)
+    return np.ascontiguousarray(w[_mpnet_bucket(np.arange(-(span - 1), span), num_buckets=w.shape[0])].T)
+
+
 class HipBertEncoder:
-    """token ids [n_seq][seq_len] (+ lengths) -> fp32 embeddings [n_seq][hidden] on the device.
+    """token ids [n_seq][seq_len] (+ lengths) -> fp32 embeddings [n_seq][hidden] on the device.  Takes a BertModel state
+    dict (bge, MiniLM, gte ...) or an MPNetModel one (all-mpnet-base-v2, the reference's default: relative-position
+    attention bias, no token types) — told apart by their tensor names.
 
     precision = "fp32" (default): the reference's arithmetic class — `SentenceTransformer(...)` at
     huggingface.py:96-98 loads fp32 weights and `.encode` runs an fp32 forward.  Weights are kept as split fp16
@@ -58,7 +82,15 @@ class HipBertEncoder:
             raise ValueError("precision must be 'fp32' (the reference's) or 'fp16'")
         self.precision = precision
         self._pool_bit = 2 if pooling == "mean" else 0
-        sd = {k.replace("bert.", "", 1) if k.startswith("bert.") else k: v for k, v in state_dict.items()}
+        sd = {}
+        for k, v in state_dict.items():     # BertModel / MPNetModel names, bare or under the usual wrappers' prefixes
+            for pre in ("0.auto_model.", "bert.", "mpnet."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            sd[k] = v
+        # MPNet family (the reference's default checkpoint, huggingface.py:6): q / k / v / o under attention.attn, no token
+        # types, position ids from 2, one relative-position bias for all layers (oracle.mpnet_forward_f32 is the restatement)
+        self.model_type = "mpnet" if "encoder.relative_attention_bias.weight" in sd else "bert"
 
         def f32(name):
             v = sd[name]
@@ -70,7 +102,11 @@ class HipBertEncoder:
         ld = f32 if precision == "fp32" else f16
         self.word = ld("embeddings.word_embeddings.weight")
         self.pos = ld("embeddings.position_embeddings.weight")
-        self.type0 = ld("embeddings.token_type_embeddings.weight")[0].contiguous()
+        if self.model_type == "mpnet":
+            self.pos = self.pos[2:].contiguous()                       # real tokens sit at positions padding_idx + 1 + t
+            self.type0 = torch.zeros(self.pos.shape[1], dtype=self.pos.dtype, device=self.device)
+        else:
+            self.type0 = ld("embeddings.token_type_embeddings.weight")[0].contiguous()
         self.emb_g, self.emb_b = ld("embeddings.LayerNorm.weight"), ld("embeddings.LayerNorm.bias")
         self.hidden = int(self.word.shape[1])
         self.heads = int(num_heads)
@@ -78,13 +114,17 @@ class HipBertEncoder:
             raise B.RarcError(f"unsupported encoder shape: hidden={self.hidden}, heads={self.heads}")
         self.layers = []
         i = 0
-        while f"encoder.layer.{i}.attention.self.query.weight" in sd:
+        mp = self.model_type == "mpnet"
+        qkv_names = ("attention.attn.q", "attention.attn.k", "attention.attn.v") if mp else \
+            ("attention.self.query", "attention.self.key", "attention.self.value")
+        o_name, ln1_name = ("attention.attn.o", "attention.LayerNorm") if mp else ("attention.output.dense", "attention.output.LayerNorm")
+        while f"encoder.layer.{i}.{qkv_names[0]}.weight" in sd:
             p = f"encoder.layer.{i}."
-            cat = lambda kind: torch.cat([ld(p + f"attention.self.{n}.{kind}") for n in ("query", "key", "value")]).contiguous()
+            cat = lambda kind: torch.cat([ld(p + f"{n}.{kind}") for n in qkv_names]).contiguous()
             lay = dict(
                 qkv_w=cat("weight"), qkv_b=cat("bias"),
-                o_w=ld(p + "attention.output.dense.weight"), o_b=ld(p + "attention.output.dense.bias"),
-                ln1_g=ld(p + "attention.output.LayerNorm.weight"), ln1_b=ld(p + "attention.output.LayerNorm.bias"),
+                o_w=ld(p + o_name + ".weight"), o_b=ld(p + o_name + ".bias"),
+                ln1_g=ld(p + ln1_name + ".weight"), ln1_b=ld(p + ln1_name + ".bias"),
                 f1_w=ld(p + "intermediate.dense.weight"), f1_b=ld(p + "intermediate.dense.bias"),
                 f2_w=ld(p + "output.dense.weight"), f2_b=ld(p + "output.dense.bias"),
                 ln2_g=ld(p + "output.LayerNorm.weight"), ln2_b=ld(p + "output.LayerNorm.bias"))
@@ -105,9 +145,17 @@ class HipBertEncoder:
         LayerT, ModelT = (B.Enc32Layer, B.Enc32Model) if precision == "fp32" else (B.EncLayer, B.EncModel)
         self._layer_tab = (LayerT * len(self.layers))(*[
             LayerT(**{k: v.data_ptr() for k, v in w.items()}) for w in self.layers])
+        self.rel_bias, rel_span = None, 0
+        if mp:   # [heads][2*span - 1] fp32: entry [h][key - query + span - 1] (csrc: added to the scaled scores)
+            rel_span = min(self.max_pos, 512)
+            w = f32("encoder.relative_attention_bias.weight").cpu().numpy()
+            if w.shape[1] != self.heads:
+                raise B.RarcError(f"relative_attention_bias holds {w.shape[1]} heads, num_heads is {self.heads}")
+            self.rel_bias = torch.from_numpy(_mpnet_rel_bias_table(w, rel_span)).to(self.device).contiguous()
         self._model = ModelT(self.hidden, self.heads, self.inter, len(self.layers), self.eps, self.word.data_ptr(),
                              self.pos.data_ptr(), self.type0.data_ptr(), self.emb_g.data_ptr(),
-                             self.emb_b.data_ptr(), self._layer_tab, self.vocab, self.max_pos)
+                             self.emb_b.data_ptr(), self._layer_tab, self.vocab, self.max_pos,
+                             self.rel_bias.data_ptr() if mp else None, rel_span)
         self._fwd = self.lib.rarc_enc32_forward if precision == "fp32" else self.lib.rarc_enc_forward
         self._ws_bytes = self.lib.rarc_enc32_workspace_bytes if precision == "fp32" else self.lib.rarc_enc_workspace_bytes
         self._ws = None

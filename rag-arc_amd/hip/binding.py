@@ -35,7 +35,8 @@ class EncModel(ctypes.Structure):
     """RarcEncModel (include/rarc.h)."""
     _fields_ = [("hidden", c_int), ("heads", c_int), ("inter", c_int), ("n_layers", c_int), ("ln_eps", c_float),
                 ("word", c_void_p), ("pos", c_void_p), ("type0", c_void_p), ("emb_g", c_void_p), ("emb_b", c_void_p),
-                ("layers", ctypes.POINTER(EncLayer)), ("vocab", c_int), ("max_pos", c_int)]
+                ("layers", ctypes.POINTER(EncLayer)), ("vocab", c_int), ("max_pos", c_int),
+                ("rel_bias", c_void_p), ("rel_span", c_int)]
 
 
 class Enc32Layer(ctypes.Structure):
@@ -48,7 +49,8 @@ class Enc32Model(ctypes.Structure):
     """RarcEnc32Model (include/rarc.h)."""
     _fields_ = [("hidden", c_int), ("heads", c_int), ("inter", c_int), ("n_layers", c_int), ("ln_eps", c_float),
                 ("word", c_void_p), ("pos", c_void_p), ("type0", c_void_p), ("emb_g", c_void_p), ("emb_b", c_void_p),
-                ("layers", ctypes.POINTER(Enc32Layer)), ("vocab", c_int), ("max_pos", c_int)]
+                ("layers", ctypes.POINTER(Enc32Layer)), ("vocab", c_int), ("max_pos", c_int),
+                ("rel_bias", c_void_p), ("rel_span", c_int)]
 
 
 class LmLayer(ctypes.Structure):
