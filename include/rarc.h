@@ -356,6 +356,11 @@ int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16
                       int n_tokens, int seq_len, int hidden, int vocab, uint16_t* d_out, void* stream);
 int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m,
                   int n, int k, int act, void* stream);
+/* The same product for a caller whose bias is KNOWN to be zeros (the reranker LM's projections have none): d_zero_bias holds
+ * n zeros; act 0 or 3.  Lets the large shapes run the tile kernel without a seam between output tiles (round 3), which has
+ * no bias path; every other shape is rarc_enc_gemm. */
+int rarc_enc_gemm_zero_bias(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_zero_bias, uint16_t* d_c, int m,
+                            int n, int k, int act, void* stream);
 int rarc_enc_attention(const uint16_t* d_qkv, const int32_t* d_lens, int n_seq, int seq_len, int hidden,
                        int n_heads, uint16_t* d_ctx, void* stream);
 int rarc_enc_add_ln(const uint16_t* d_x, const uint16_t* d_resid, const uint16_t* d_gamma,

@@ -24,6 +24,7 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
 
 bool rarc_gemm_swiglu_fused(int m, int n, int k);  // encoder.hip: act = 3 available for this shape
 
+
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
 // ---- embedding gather: x[t] = embed[ids[t]] (ids clamped into the table: memory safety, the host validates) ----
@@ -966,7 +967,7 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
     hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, l ? (const half_t*)delta : (const half_t*)nullptr,
                        (const half_t*)Ly.in_norm, m->rms_eps, T, H, h);
     RARC_HIP_CHECK(hipGetLastError());
-    if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, Tg, QKV, H, 0, stream)) return rc;
+    if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, Tg, QKV, H, 0, stream)) return rc;
     if (fill) {   // mode 1: this layer's raw k | v rows go to the cache
       hipLaunchKernelGGL(rarc_lm_copy_kv_kernel, dim3(tb), dim3(256), 0, s, (const half_t*)qkv, T, QKV, QD, (int)kv_cols,
                          (half_t*)((char*)fill + (size_t)l * cache_layer));
@@ -1021,18 +1022,18 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
       hipLaunchKernelGGL(rarc_lm_gather_last_kernel, dim3(gb), dim3(256), 0, s, (const half_t*)ctx, seq_len, QD, n_seq, Mp, ctx_l);
       hipLaunchKernelGGL(rarc_lm_gather_last_kernel, dim3(gb), dim3(256), 0, s, (const half_t*)x, seq_len, H, n_seq, Mp, x_l);
       RARC_HIP_CHECK(hipGetLastError());
-      if (int rc = rarc_enc_gemm((const uint16_t*)ctx_l, Ly.o_w, m->zero_bias, (uint16_t*)d_l, Mp, H, QD, 0, stream)) return rc;
+      if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)ctx_l, Ly.o_w, m->zero_bias, (uint16_t*)d_l, Mp, H, QD, 0, stream)) return rc;
       hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(gb), dim3(256), 0, s, x_l, (const half_t*)d_l, (const half_t*)Ly.post_norm,
                          m->rms_eps, Mp, H, h_l);
       RARC_HIP_CHECK(hipGetLastError());
       if (rarc_gemm_swiglu_fused(Mp, 2 * I, H)) {
-        if (int rc = rarc_enc_gemm((const uint16_t*)h_l, Ly.gate_up_w, m->zero_bias, (uint16_t*)act_l, Mp, 2 * I, H, 3, stream)) return rc;
+        if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)h_l, Ly.gate_up_w, m->zero_bias, (uint16_t*)act_l, Mp, 2 * I, H, 3, stream)) return rc;
       } else {
-        if (int rc = rarc_enc_gemm((const uint16_t*)h_l, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu_l, Mp, 2 * I, H, 0, stream)) return rc;
+        if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)h_l, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu_l, Mp, 2 * I, H, 0, stream)) return rc;
         hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(512), dim3(256), 0, s, (const half_t*)gu_l, Mp, I, act_l);
         RARC_HIP_CHECK(hipGetLastError());
       }
-      if (int rc = rarc_enc_gemm((const uint16_t*)act_l, Ly.down_w, m->zero_bias, (uint16_t*)d_l, Mp, H, I, 0, stream)) return rc;
+      if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)act_l, Ly.down_w, m->zero_bias, (uint16_t*)d_l, Mp, H, I, 0, stream)) return rc;
       hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(gb), dim3(256), 0, s, x_l, (const half_t*)d_l, (const half_t*)nullptr,
                          m->rms_eps, Mp, H, (half_t*)nullptr);
       RARC_HIP_CHECK(hipGetLastError());
@@ -1041,18 +1042,18 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
     }
-    if (int rc = rarc_enc_gemm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, Tg, H, QD, 0, stream)) return rc;
+    if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, Tg, H, QD, 0, stream)) return rc;
     hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)Ly.post_norm,
                        m->rms_eps, T, H, h);
     RARC_HIP_CHECK(hipGetLastError());
     if (rarc_gemm_swiglu_fused(Tg, 2 * I, H)) {  // silu(gate)·up in the GEMM's epilogue: the [T][2I] tensor never exists
-      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)act, Tg, 2 * I, H, 3, stream)) return rc;
+      if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)act, Tg, 2 * I, H, 3, stream)) return rc;
     } else {
-      if (int rc = rarc_enc_gemm((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu, Tg, 2 * I, H, 0, stream)) return rc;
+      if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)h, Ly.gate_up_w, m->zero_bias, (uint16_t*)gu, Tg, 2 * I, H, 0, stream)) return rc;
       hipLaunchKernelGGL(rarc_lm_swiglu_kernel, dim3(2048), dim3(256), 0, s, (const half_t*)gu, Tg, I, act);
       RARC_HIP_CHECK(hipGetLastError());
     }
-    if (int rc = rarc_enc_gemm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)delta, Tg, H, I, 0, stream)) return rc;
+    if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)delta, Tg, H, I, 0, stream)) return rc;
   }
   // the last layer's MLP output joins the residual stream (no norm output wanted: y = null)
   hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)nullptr, m->rms_eps,

@@ -520,6 +520,292 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 3 — the same 256 x 256 x 64 ping-pong schedule with NO SEAM between output tiles ("s" = seamless).
+// The kernel above pays ~7 us per tile round next to 1.62 us per k tile (26 us of matrix work at K = 1024): the operand
+// pipeline drains, the epilogue converts / transposes / stores with the matrix pipe idle (3 us of it is the per-CU issue
+// rate of the stores), the next tile's first operands are fetched cold.  Here a workgroup's tiles form ONE stream of
+// k tiles: the staging of the last two k tiles of an output tile already fetches the first two of the next (its A / W
+// base pointers are computed a tile ahead), and the epilogue is taken apart by QUADRANT — the four 128 x 64 quadrants of
+// a wave's block become final one per phase of the last k tile (A0B0, A0B1, A1B1, A1B0) and each is needed again only
+// four phases later, when the next tile's first k tile (whose first MFMA takes C = 0) reaches the same quadrant.  So
+// quadrant q is drained in the load slot of the phase AFTER it became final (q = 4 in the first slot of the next tile):
+// fp16 conversion, a 32-row transposition through a private 2.5 KiB of LDS per wave (20 KiB next to the 128 KiB of
+// pipeline), four 1-KiB stores of 16 rows x 64 bytes — under the other wave group's MFMAs, no barrier of its own, the
+// pipeline's counted waits widened by exactly the stores in flight (vmcnt counts them, in order).
+//   ACT 0: C = A·Wᵀ (no bias: the reranker LM's projections);  ACT 3: silu(gate)·up over interleaved gate / up columns.
+// ------------------------------------------------------------------------------------------
+constexpr int G256S_EP_STRIDE = 80, G256S_EP_BYTES = 32 * G256S_EP_STRIDE;   // per-wave drain staging: 32 rows x (64 + 16) B
+constexpr int G256S_LDS = 131072 + 8 * G256S_EP_BYTES;
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t* __restrict__ A,
+                                                                   const half_t* __restrict__ W,
+                                                                   half_t* __restrict__ C, int M, int N, int K,
+                                                                   int order) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int row = lane & 31, hh = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_m = M / 256, tiles_n = N / 256, n_tiles = tiles_m * tiles_n;
+  const int KT = K / GK;   // >= 4 (host)
+  const int drow = lane >> 3, dslot = lane & 7;
+  uint32_t soff[4][2];
+#pragma unroll
+  for (int which = 0; which < 4; ++which)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int lr = 8 * (wave * 2 + j) + drow;
+      const int c = dslot ^ ((lr >> 1) & 7);
+      const int h = which & 1;
+      const int trow = which < 2 ? (lr >> 6) * 128 + h * 64 + (lr & 63) : (lr >> 5) * 64 + h * 32 + (lr & 31);
+      soff[which][j] = ((uint32_t)trow * (uint32_t)K + (uint32_t)c * 8u) * 2u;
+    }
+  // staging: half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k tile kt of the output tile whose operand rows start at Ab / Wb
+  auto stage = [&](int par, int which, const half_t* Ab, const half_t* Wb, int kt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int i = wave * 2 + j;
+      const char* base = (const char*)(which < 2 ? Ab : Wb) + (size_t)kt * (GK * 2);
+      __builtin_amdgcn_global_load_lds(RARC_GPTR(base + soff[which][j]),
+                                       RARC_LPTR(smem + par * 65536 + which * 16384 + i * 1024), 16, 0, 0);
+    }
+  };
+  const int sw = (row >> 1) & 7;
+  int xk[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + hh) ^ sw) << 4);
+
+  f32x16 acc[4][2];
+  half8 fa[4][2], fb0[4], fb1[4];
+  typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t uint2v __attribute__((ext_vector_type(2)));
+  typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+
+#define G256_LOAD_A(PAR, H)                                                                             \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    const int ad = xk[kk] + ((PAR) * 65536 + (H) * 16384 + wr * 8192);                                  \
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                               \
+                 : "=&v"(fa[kk][0]), "=&v"(fa[kk][1]) : "v"(ad) : "memory");                            \
+  }
+#define G256_LOAD_B(PAR, H, FB)                                                                         \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    const int ad = xk[kk] + ((PAR) * 65536 + 32768 + (H) * 16384 + wc * 4096);                          \
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(FB[kk]) : "v"(ad) : "memory");                           \
+  }
+#define G256_WAIT()                                                                                     \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                   \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]),        \
+                 "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb0[0]), "+v"(fb0[1]),            \
+                 "+v"(fb0[2]), "+v"(fb0[3]), "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3])     \
+               :: "memory")
+#define G256_MMA(QM, QN, FB)                                                                            \
+  asm volatile("" : "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3]));                                \
+  __builtin_amdgcn_sched_barrier(0);                                                                    \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+    acc[2 * (QM)][QN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[kk], fa[kk][0], acc[2 * (QM)][QN], 0, 0, 0); \
+    acc[2 * (QM) + 1][QN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[kk], fa[kk][1], acc[2 * (QM) + 1][QN], 0, 0, 0); \
+  }                                                                                                     \
+  __builtin_amdgcn_s_setprio(0);                                                                        \
+  asm volatile("" : "+v"(acc[2 * (QM)][QN]), "+v"(acc[2 * (QM) + 1][QN]));                              \
+  __builtin_amdgcn_sched_barrier(0)
+#define G256_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+  // drain of quadrant (QM, QN) of the output tile (TM, TN): acc[2QM + i][QN] is rows wr*128 + (2QM + i)*32 + row, cols
+  // wc*64 + QN*32 + (8g + 4hh .. +3) of the tile.  Per 32-row block: transposition through the wave's own staging (LDS
+  // operations of one wave execute in order: no wait between its writes and reads, and the next block's writes come after
+  // this block's reads), then 16-byte pieces of whole 64-byte (ACT 3: 32-byte) row segments to C; the registers are
+  // cleared for the next output tile.
+#define G256S_DRAIN(QM, QN, TM, TN)                                                                     \
+  {                                                                                                     \
+    int lane_e = lane;                                                                                  \
+    asm volatile("" : "+v"(lane_e));   /* (nothing derived from the lane index is hoisted out of the loop) */ \
+    const int row_e = lane_e & 31, hh_e = lane_e >> 5;                                                  \
+    const int ep_off = 131072 + wave * G256S_EP_BYTES;   /* LDS byte address of the wave's staging (dynamic LDS starts at 0) */ \
+    _Pragma("unroll") for (int i2 = 0; i2 < 2; ++i2) {                                                  \
+      f32x16& blk = acc[2 * (QM) + i2][QN];                                                             \
+      /* the staging accesses are inline asm: to the compiler an LDS read after an LDS-DMA may alias the DMA's */ \
+      /* destination, and it drains the whole operand pipeline (vmcnt(0)) in front of it */             \
+      if constexpr (ACT == 3) {                                                                         \
+        _Pragma("unroll") for (int g = 0; g < 4; g += 2) {                                              \
+          half4 out;                                                                                    \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e) out[e] = rarc_swiglu_f16(blk[4 * g + e], blk[4 * g + 4 + e]); \
+          asm volatile("ds_write_b64 %0, %1" :: "v"(ep_off + row_e * G256S_EP_STRIDE + (4 * g + 4 * hh_e) * 2), \
+                       "v"(__builtin_bit_cast(uint2v, out)) : "memory");                              \
+        }                                                                                               \
+        const int r32 = lane_e >> 1, c = lane_e & 1;                                                    \
+        uint4v v;                                                                                       \
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ep_off + r32 * G256S_EP_STRIDE + c * 16) : "memory"); \
+        half_t* Cw = C + (size_t)((TM) * 256 + wr * 128 + (2 * (QM) + i2) * 32 + r32) * (N / 2) + (TN) * 128 + wc * 32 + (QN) * 16 + c * 8; \
+        *(uint4v*)Cw = v;                                                                               \
+      } else {                                                                                          \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                 \
+          const half4 out = {(half_t)blk[4 * g], (half_t)blk[4 * g + 1], (half_t)blk[4 * g + 2], (half_t)blk[4 * g + 3]}; \
+          asm volatile("ds_write_b64 %0, %1" :: "v"(ep_off + row_e * G256S_EP_STRIDE + (8 * g + 4 * hh_e) * 2), \
+                       "v"(__builtin_bit_cast(uint2v, out)) : "memory");                              \
+        }                                                                                               \
+        const int r16 = lane_e >> 2, c = lane_e & 3;                                                    \
+        uint4v v0, v1;                                                                                  \
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1280\n\ts_waitcnt lgkmcnt(0)"   \
+                     : "=&v"(v0), "=&v"(v1) : "v"(ep_off + r16 * G256S_EP_STRIDE + c * 16) : "memory"); \
+        half_t* Cw = C + (size_t)((TM) * 256 + wr * 128 + (2 * (QM) + i2) * 32 + r16) * N + (TN) * 256 + wc * 64 + (QN) * 32 + c * 8; \
+        *(uint4v*)Cw = v0;                                                                              \
+        *(uint4v*)(Cw + (size_t)16 * N) = v1;                                                           \
+      }                                                                                                 \
+      blk = (f32x16){0};                                                                                \
+    }                                                                                                   \
+    asm volatile("" ::: "memory");   /* the stores are issued before this slot's operand staging */      \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+  constexpr int SD = ACT == 3 ? 2 : 4;   // stores per quadrant drain and wave
+  // the vector-memory wait at the end of a load slot: all but the 10 DMA instructions of the five newest slots, plus the
+  // stores issued in those slots (vmcnt counts stores too, in order; in the stream's order a drain's stores precede
+  // their slot's DMA).  sel 0: none in the window, 1: one drain slot (2 quadrants = 2 SD stores), 2: two drain slots,
+  // 3: everything (the last two k tiles of the stream)
+  auto vm_wait = [&](int sel) __attribute__((always_inline)) {
+    if (sel == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (sel == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(10 + 2 * SD) : "memory");
+    else if (sel == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(10 + 4 * SD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  int bid = blockIdx.x;
+  if (bid >= n_tiles) return;
+  int tm, tn;
+  gemm_tile_of(bid, n_tiles, tiles_m, tiles_n, order, tm, tn);
+  const half_t* Ab = A + (size_t)tm * 256 * K;
+  const half_t* Wb = W + (size_t)tn * 256 * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
+  // prologue of the stream: all of k tile 0, then A0, B0, B1 of k tile 1 (its A1 follows in phase 1 of k tile 0)
+  stage(0, 0, Ab, Wb, 0); stage(0, 2, Ab, Wb, 0); stage(0, 3, Ab, Wb, 0); stage(0, 1, Ab, Wb, 0);
+  stage(1, 0, Ab, Wb, 1); stage(1, 2, Ab, Wb, 1); stage(1, 3, Ab, Wb, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  G256_BAR();
+  if (wr == 1) G256_BAR();  // waves 4-7 run one slot behind
+  int par = 0, np = 1;
+  int ptm = 0, ptn = 0;     // the previous output tile (its second drain runs in this tile's first slot)
+  bool first = true;
+  int nbid = bid + gridDim.x;
+  bool has_next = nbid < n_tiles;
+  int ntm = 0, ntn = 0;
+  if (has_next) gemm_tile_of(nbid, n_tiles, tiles_m, tiles_n, order, ntm, ntn);
+  const half_t* nAb = A + (size_t)ntm * 256 * K;
+  const half_t* nWb = W + (size_t)ntn * 256 * K;
+  // ONE loop over the workgroup's stream of k tiles; what varies at the seams (where the look-ahead's operands come from,
+  // whether a drain runs, how many stores sit in the wait's window) is wave-uniform run-time state, not code variants
+  // (seven instantiations of the four phases spilled the accumulators: the allocator lost track of 128 live registers).
+  for (int kt = 0;;) {
+    // the interior k tiles of an output tile (2 .. KT-3): operands of this tile, no drain, no stores in any window — the
+    // loop of the kernel with a seam, with nothing decided at run time (with the seam logic in every phase a k tile took
+    // 1.95 us instead of 1.51: ~160 cycles of scalar selects and branches per load slot, and the load slots are the
+    // critical path of the ping-pong)
+    for (; kt >= 2 && kt + 2 < KT; ++kt) {
+      G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)
+      stage(np, 1, Ab, Wb, kt + 1);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(0, 0, fb0);
+      G256_BAR();
+      G256_LOAD_B(par, 1, fb1)
+      stage(par, 0, Ab, Wb, kt + 2);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(0, 1, fb1);
+      G256_BAR();
+      G256_LOAD_A(par, 1)
+      stage(par, 2, Ab, Wb, kt + 2);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(1, 1, fb1);
+      G256_BAR();
+      stage(par, 3, Ab, Wb, kt + 2);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(1, 0, fb0);
+      G256_BAR();
+      par ^= 1; np ^= 1;
+    }
+    // ---- a k tile at a seam: 0, 1, KT-2 or KT-1 ----
+    const int k1 = kt + 1, k2 = kt + 2;
+    const bool in1 = k1 < KT, in2 = k2 < KT;
+    const half_t* s1A = in1 ? Ab : nAb;
+    const half_t* s1W = in1 ? Wb : nWb;
+    const half_t* s2A = in2 ? Ab : nAb;
+    const half_t* s2W = in2 ? Wb : nWb;
+    const int s1k = in1 ? k1 : k1 - KT, s2k = in2 ? k2 : k2 - KT;
+    const bool st1 = in1 || has_next, st2 = in2 || has_next;
+    const bool ending = !has_next && kt + 2 >= KT;                    // the last two k tiles of the stream
+    const bool drain_b = kt == 0 && !first, drain_a = kt == KT - 1;
+    // stores in the five-slot window at the end of each phase's load slot (see vm_wait)
+    const int w1 = ending ? 3 : (drain_b ? 2 : (kt == 1 && !first ? 1 : 0));
+    const int w2 = ending ? 3 : (drain_b ? 2 : 0);
+    const int w3 = ending ? 3 : (drain_b ? 2 : (drain_a ? 1 : 0));
+    const int w4 = ending ? 3 : (drain_b ? 1 : (drain_a ? 1 : 0));
+    // ---- phase 1: quadrant A0 x B0 ----
+    if (drain_b) { G256S_DRAIN(1, 1, ptm, ptn) G256S_DRAIN(1, 0, ptm, ptn) }
+    G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)
+    if (st1) stage(np, 1, s1A, s1W, s1k);
+    vm_wait(w1);
+    G256_WAIT();
+    G256_BAR();
+    G256_MMA(0, 0, fb0);
+    G256_BAR();
+    // ---- phase 2: A0 x B1 ----
+    G256_LOAD_B(par, 1, fb1)
+    if (st2) stage(par, 0, s2A, s2W, s2k);
+    vm_wait(w2);
+    G256_WAIT();
+    G256_BAR();
+    G256_MMA(0, 1, fb1);
+    G256_BAR();
+    // ---- phase 3: A1 x B1 (the A fragment registers are dead at its start: the first drain's place) ----
+    if (drain_a) { G256S_DRAIN(0, 0, tm, tn) G256S_DRAIN(0, 1, tm, tn) }
+    G256_LOAD_A(par, 1)
+    if (st2) stage(par, 2, s2A, s2W, s2k);
+    vm_wait(w3);
+    G256_WAIT();
+    G256_BAR();
+    G256_MMA(1, 1, fb1);
+    G256_BAR();
+    // ---- phase 4: A1 x B0 (no LDS reads) ----
+    if (st2) stage(par, 3, s2A, s2W, s2k);
+    vm_wait(w4);
+    G256_WAIT();
+    G256_BAR();
+    G256_MMA(1, 0, fb0);
+    G256_BAR();
+    par ^= 1; np ^= 1;
+    if (++kt < KT) continue;
+    if (!has_next) break;
+    // ---- the next output tile of the stream ----
+    ptm = tm; ptn = tn;
+    bid = nbid; tm = ntm; tn = ntn; Ab = nAb; Wb = nWb;
+    first = false;
+    kt = 0;
+    nbid = bid + gridDim.x;
+    has_next = nbid < n_tiles;
+    if (has_next) gemm_tile_of(nbid, n_tiles, tiles_m, tiles_n, order, ntm, ntn);
+    nAb = A + (size_t)ntm * 256 * K;
+    nWb = W + (size_t)ntn * 256 * K;
+  }
+  if (wr == 0) G256_BAR();
+  G256S_DRAIN(1, 1, tm, tn) G256S_DRAIN(1, 0, tm, tn)
+#undef G256S_DRAIN
+#undef G256_LOAD_A
+#undef G256_LOAD_B
+#undef G256_WAIT
+#undef G256_MMA
+#undef G256_BAR
+}
+
+// ------------------------------------------------------------------------------------------
 // The same ping-pong schedule on 256 x 128 tiles, for N = 1024 (attention output, FFN2: 256 tiles at M = 8192)
 // and for shapes whose 256 x 256 tile count would leave a ragged last round.
 //   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. x cols wc*32..: acc[4] 32x32 blocks.
@@ -1249,6 +1535,8 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256s_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256S_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256s_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
@@ -1305,8 +1593,10 @@ bool rarc_gemm_swiglu_fused(int m, int n, int k) {
 }
 
 // act 0 / 1 / 3 as rarc_enc_gemm; act 4: raw fp32 products, no bias, d_c is float [M][N] (encoder_f32.hip)
+// zero_bias: the caller guarantees d_bias holds zeros (the reranker LM's projections) — the seamless 256 x 256 kernel, which
+// has no bias path, may take the large shapes
 static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m, int n, int k,
-                         int act, void* stream) {
+                         int act, void* stream, bool zero_bias = false) {
   hipStream_t s = (hipStream_t)stream;
   const half_t *a = (const half_t*)d_a, *w = (const half_t*)d_w, *bs = (const half_t*)d_bias;
   half_t* c = (half_t*)d_c;
@@ -1345,6 +1635,15 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
         m_main = full / tiles_n * 256;
       const int t_main = (m_main / 256) * tiles_n;
       const int g256 = persist && t_main > 256 ? 256 : t_main;
+      // The seamless stream of k tiles (rarc_gemm256s_f16_kernel) measured within +-2 % of the kernel with a seam at
+      // K >= 1024 and +3..6 % at K = 256 / 512 (profiles/r03_gemm_seamless.txt): it takes the short streams, where the seam
+      // is a larger share; RARC_GEMM_SEAM=1 / 0 forces it on / off for every eligible shape (A/B runs, tests).
+      static const int seam_env = getenv("RARC_GEMM_SEAM") ? atoi(getenv("RARC_GEMM_SEAM")) : -1;
+      const bool seamless = seam_env < 0 ? k <= 8 * GK : seam_env != 0;
+      if (seamless && zero_bias && (act == 0 || act == 3) && k >= 4 * GK) {
+        if (act == 3) hipLaunchKernelGGL((rarc_gemm256s_f16_kernel<3>), dim3(g256), dim3(512), G256S_LDS, s, a, w, c, m_main, n, k, order);
+        else hipLaunchKernelGGL((rarc_gemm256s_f16_kernel<0>), dim3(g256), dim3(512), G256S_LDS, s, a, w, c, m_main, n, k, order);
+      } else
       if (act == 4) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<4>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
@@ -1352,7 +1651,7 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       RARC_HIP_CHECK(hipGetLastError());
       if (m_main < m)   // (d_c counts 2-byte elements: an fp32 row is 2n of them)
         return enc_gemm_impl(d_a + (size_t)m_main * k, d_w, d_bias, d_c + (size_t)m_main * (act == 3 ? n / 2 : (act == 4 ? 2 * n : n)),
-                             m - m_main, n, k, act, stream);
+                             m - m_main, n, k, act, stream, zero_bias);
       return RARC_OK;
     }
     if (t128 >= 256 && k >= 3 * GK) {
@@ -1395,6 +1694,16 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
                "rarc_enc_gemm: need M,N multiples of 128 and K multiple of 64 (got %d,%d,%d)", m, n, k);
   RARC_REQUIRE(act == 0 || act == 1 || act == 3, RARC_E_INVALID, "rarc_enc_gemm: act must be 0, 1 or 3");
   return enc_gemm_impl(d_a, d_w, d_bias, d_c, m, n, k, act, stream);
+}
+
+// rarc_enc_gemm for callers whose bias is known to be zero (decoder.hip): d_zero_bias must hold max(n) zeros
+extern "C" int rarc_enc_gemm_zero_bias(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_zero_bias, uint16_t* d_c, int m,
+                                       int n, int k, int act, void* stream) {
+  RARC_REQUIRE(d_a && d_w && d_zero_bias && d_c, RARC_E_INVALID, "rarc_enc_gemm: null pointer");
+  RARC_REQUIRE(m > 0 && n > 0 && k > 0 && m % GM == 0 && n % GN == 0 && k % GK == 0, RARC_E_UNSUPPORTED,
+               "rarc_enc_gemm: need M,N multiples of 128 and K multiple of 64 (got %d,%d,%d)", m, n, k);
+  RARC_REQUIRE(act == 0 || act == 3, RARC_E_INVALID, "rarc_enc_gemm_zero_bias: act must be 0 or 3");
+  return enc_gemm_impl(d_a, d_w, d_zero_bias, d_c, m, n, k, act, stream, true);
 }
 
 // fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward
