@@ -1638,7 +1638,8 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       // The seamless stream of k tiles (rarc_gemm256s_f16_kernel) measured within +-2 % of the kernel with a seam at
       // K >= 1024 and +3..6 % at K = 256 / 512 (profiles/r03_gemm_seamless.txt): it takes the short streams, where the seam
       // is a larger share; RARC_GEMM_SEAM=1 / 0 forces it on / off for every eligible shape (A/B runs, tests).
-      static const int seam_env = getenv("RARC_GEMM_SEAM") ? atoi(getenv("RARC_GEMM_SEAM")) : -1;
+      const char* seam_s = getenv("RARC_GEMM_SEAM");   // (read per call: a test switches it inside one process)
+      const int seam_env = seam_s ? atoi(seam_s) : -1;
       const bool seamless = seam_env < 0 ? k <= 8 * GK : seam_env != 0;
       if (seamless && zero_bias && (act == 0 || act == 3) && k >= 4 * GK) {
         if (act == 3) hipLaunchKernelGGL((rarc_gemm256s_f16_kernel<3>), dim3(g256), dim3(512), G256S_LDS, s, a, w, c, m_main, n, k, order);

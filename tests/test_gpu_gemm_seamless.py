@@ -4,14 +4,11 @@ in a child process would give the same): same operands, same k order per output 
 bits.  Shapes cover: one tile per workgroup (no successor), several tiles per workgroup (the seam proper), a ragged last
 round (some workgroups have one tile more), the cut-off tail, K = 256 (the shortest stream: four k tiles) and the SwiGLU
 epilogue; and a torch fp32 product as the outside yardstick."""
-import os
-
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-os.environ["RARC_GEMM_SEAM"] = "1"      # (read once by the library: every eligible shape takes the seamless kernel in this process)
 
 
 @pytest.mark.parametrize("m,n,k,act", [
@@ -22,8 +19,10 @@ os.environ["RARC_GEMM_SEAM"] = "1"      # (read once by the library: every eligi
     (256 * 24, 6144, 1024, 3),       # gate|up with the SwiGLU epilogue, 576 tiles
     (256 * 33, 2048, 320, 3),        # five k tiles, 264 tiles (ragged: 8 workgroups carry two)
 ])
-def test_seamless_kernel_equals_the_kernel_with_a_seam(m, n, k, act):
+def test_seamless_kernel_equals_the_kernel_with_a_seam(monkeypatch, m, n, k, act):
     import torch
+
+    monkeypatch.setenv("RARC_GEMM_SEAM", "1")     # every eligible shape of rarc_enc_gemm_zero_bias takes the seamless kernel
 
     from rag_arc_amd.hip import binding as B
 
