@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 310 /* 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
+#define RARC_VERSION 320 /* 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
+                            * rarc_enc_gemm_zero_bias; 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
                             * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
 #define RARC_OK 0
@@ -454,6 +455,13 @@ int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_ids, const 
  */
 typedef struct RarcLmLayer {
   const uint16_t *in_norm, *qkv_w, *q_norm, *k_norm, *o_w, *post_norm, *gate_up_w, *down_w;
+  /* OPTIONAL (null = not supplied; ABI 320): qkv_w with its columns multiplied by in_norm, gate_up_w with its columns
+   * multiplied by post_norm (products in fp32, rounded to fp16 once).  With both present, batches large enough for the 256-row
+   * tile kernels run WITHOUT the RMSNorm passes: RMSNorm(x)·Wᵀ = r ⊙ (x·(W ⊙ γ)ᵀ) with r = rsqrt(mean(x²) + eps) per row, so
+   * the projection reads the residual stream itself and scales its output rows, and the output / down projections add into
+   * the residual stream in their epilogue.  Same function, one rounding moved: the reference rounds the normed
+   * activations to fp16 before the product. */
+  const uint16_t *qkv_w_folded, *gate_up_w_folded;
   /* qkv_w [(n_q+2*n_kv)*head_dim][hidden] = q_proj | k_proj | v_proj rows;
    * gate_up_w [2*inter][hidden] = gate_proj and up_proj rows INTERLEAVED in groups of 8: rows 16b .. 16b+7 are
    * gate_proj rows 8b .. 8b+7, rows 16b+8 .. 16b+15 the up_proj rows of the same features (so that one lane of the

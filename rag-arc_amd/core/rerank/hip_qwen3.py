@@ -29,7 +29,7 @@ class HipCausalLM:
     """Qwen3-style decoder weights in HBM + the last-position (no, yes) logits of left-padded token batches."""
 
     def __init__(self, state_dict: Dict[str, "np.ndarray"], num_attention_heads: int, num_key_value_heads: int,
-                 head_dim: int, rms_norm_eps: float = 1e-6, rope_theta: float = 1e6, device: int = 0):
+                 head_dim: int, rms_norm_eps: float = 1e-6, rope_theta: float = 1e6, device: int = 0, fold_norms: bool = True):
         import torch
 
         if not torch.cuda.is_available():
@@ -60,6 +60,12 @@ class HipCausalLM:
                 post_norm=f16(sd[p + "post_attention_layernorm.weight"]),
                 gate_up_w=self._interleave8(f16(sd[p + "mlp.gate_proj.weight"]), f16(sd[p + "mlp.up_proj.weight"])),
                 down_w=f16(sd[p + "mlp.down_proj.weight"])))
+            if fold_norms:
+                # RMSNorm folded into its consumers (include/rarc.h, RarcLmLayer): W ⊙ γ over the input columns, product in
+                # fp32, one rounding.  Large batches then read the residual stream directly and scale their output rows.
+                lay = self.layers[-1]
+                lay["qkv_w_folded"] = (lay["qkv_w"].float() * lay["in_norm"].float()[None, :]).half().contiguous()
+                lay["gate_up_w_folded"] = (lay["gate_up_w"].float() * lay["post_norm"].float()[None, :]).half().contiguous()
             i += 1
         if not self.layers:
             raise B.RarcError("state dict holds no model.layers.* tensors")

@@ -23,6 +23,9 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
                              int n, int k, int act, void* stream);
 
 bool rarc_gemm_swiglu_fused(int m, int n, int k);  // encoder.hip: act = 3 available for this shape
+bool rarc_gemm_norm_fusable(int m, int n, int k);  // encoder.hip: the row-scale / residual epilogues are available for this shape
+int rarc_gemm_fused_norm(const uint16_t* d_a, const uint16_t* d_w, const void* d_rowscale_or_zero, uint16_t* d_c, int m, int n, int k,
+                         int act, void* stream);   // act 16 / 19: C = act(rowscale ⊙ A·Wᵀ); 32: C += A·Wᵀ in place
 
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -69,6 +72,23 @@ __global__ __launch_bounds__(256) void rarc_lm_rmsnorm_kernel(half_t* x, const h
     for (int e = 0; e < 8; ++e) o8[e] = (half_t)((float)wv[e] * (float)(half_t)((float)v[e] * inv));  // weight * x.to(fp16)
     *(half8*)(y + (size_t)t * H + c) = o8;
   }
+}
+
+// ---- r[t] = rsqrt(mean(x[t]²) + eps): the row scale of an RMSNorm whose weight is folded into the next projection --------
+__global__ __launch_bounds__(256) void rarc_lm_rowscale_kernel(const half_t* __restrict__ x, float eps, int n_tokens, int H,
+                                                               float* __restrict__ r) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (t >= n_tokens) return;
+  const half_t* xr = x + (size_t)t * H;
+  float ss = 0.f;
+  for (int c = lane * 8; c < H; c += 512) {
+    const half8 v = *(const half8*)(xr + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)v[e], (float)v[e], ss);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if (lane == 0) r[t] = 1.0f / __builtin_sqrtf(ss / (float)H + eps);
 }
 
 // ---- rotary table: per position a row of DH halves, cos of the DH/2 pairs then their sin ---------------------------------
@@ -862,7 +882,8 @@ extern "C" size_t rarc_lm_workspace_bytes(const RarcLmModel* m, int n_tokens) {
          + lm_align(T * (size_t)m->n_q_heads * m->head_dim * 2)  // attention context
          + lm_align(T * 2 * (size_t)m->inter * 2)               // fused gate | up
          + lm_align(T * (size_t)m->inter * 2)                   // silu(gate) * up
-         + lm_align((T + 4096) * (size_t)(m->head_dim / 2) * 4);  // rotary (cos, sin) table: prefix + sequence positions
+         + lm_align((T + 4096) * (size_t)(m->head_dim / 2) * 4)   // rotary (cos, sin) table: prefix + sequence positions
+         + lm_align(T * 4);                                      // row scales of the folded RMSNorms
 }
 
 // ---- prefix K/V cache (see LmAttnPrefix): per layer [n_prefix * P][2 * n_kv * head_dim] raw k | v rows -----------------
@@ -920,10 +941,26 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
   half_t* gu = (half_t*)((char*)ctx + lm_align(Tw * QD * 2));
   half_t* act = (half_t*)((char*)gu + lm_align(Tw * 2 * I * 2));
   half2_t* rope = (half2_t*)((char*)act + lm_align(Tw * I * 2));
-  if (Tg > T) {   // the GEMMs' A operands of the padding rows: h (q|k|v, gate|up), ctx (output projection); act follows from h
+  float* rowscale = (float*)((char*)rope + lm_align((Tw + 4096) * (size_t)(DH / 2) * 4));
+  if (Tg > T) {   // the GEMMs' A operands of the padding rows: h / x (q|k|v, gate|up), ctx (output projection); act follows
     RARC_HIP_CHECK(hipMemsetAsync(h + (size_t)T * H, 0, (size_t)(Tg - T) * H * 2, s));
+    RARC_HIP_CHECK(hipMemsetAsync(x + (size_t)T * H, 0, (size_t)(Tg - T) * H * 2, s));
     RARC_HIP_CHECK(hipMemsetAsync(ctx + (size_t)T * QD, 0, (size_t)(Tg - T) * QD * 2, s));
   }
+  // RMSNorm folded into the projections (RarcLmLayer.qkv_w_folded / gate_up_w_folded): when every projection of a layer runs
+  // a tile kernel with the row-scale / residual epilogues, the norm passes disappear — the output and down projections add
+  // into x in place, rarc_lm_rowscale_kernel reads x once for r = rsqrt(mean(x²) + eps), q|k|v and gate|up multiply x by the
+  // folded weights and scale their rows by r.  (It was: read x, read delta, write x, write the normed copy — 0.41 ms of a
+  // 5.9 ms layer at 163 840 tokens.)  RARC_LM_FUSE_NORM=0: the separate passes (A/B runs, tests).
+  const char* fuse_env = getenv("RARC_LM_FUSE_NORM");
+  bool fuse = !(fuse_env && atoi(fuse_env) == 0) && rarc_gemm_norm_fusable(Tg, QKV, H) && rarc_gemm_norm_fusable(Tg, H, QD) &&
+              rarc_gemm_norm_fusable(Tg, 2 * I, H) && rarc_gemm_swiglu_fused(Tg, 2 * I, H) && rarc_gemm_norm_fusable(Tg, H, I);
+  for (int l = 0; l < m->n_layers && fuse; ++l) fuse = m->layers[l].qkv_w_folded && m->layers[l].gate_up_w_folded;
+  auto row_scales = [&]() -> int {
+    hipLaunchKernelGGL(rarc_lm_rowscale_kernel, dim3((Tg + 3) / 4), dim3(256), 0, s, (const half_t*)x, m->rms_eps, Tg, H, rowscale);
+    RARC_HIP_CHECK(hipGetLastError());
+    return RARC_OK;
+  };
   const int tb = (T + 3) / 4;
 
   const int P = use ? use->P : 0;
@@ -963,11 +1000,15 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
   }
   for (int l = 0; l < m->n_layers; ++l) {
     const RarcLmLayer& Ly = m->layers[l];
-    // (layer 0: plain norm; later layers: the previous layer's MLP output is added here, then normed)
-    hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, l ? (const half_t*)delta : (const half_t*)nullptr,
-                       (const half_t*)Ly.in_norm, m->rms_eps, T, H, h);
-    RARC_HIP_CHECK(hipGetLastError());
-    if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, Tg, QKV, H, 0, stream)) return rc;
+    if (fuse && l > 0) {   // x already holds the previous layer's MLP output; its row scales were taken after the down projection
+      if (int rc = rarc_gemm_fused_norm((const uint16_t*)x, Ly.qkv_w_folded, rowscale, (uint16_t*)qkv, Tg, QKV, H, 16, stream)) return rc;
+    } else {
+      // (layer 0: plain norm; later layers: the previous layer's MLP output is added here, then normed)
+      hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (l && !fuse) ? (const half_t*)delta : (const half_t*)nullptr,
+                         (const half_t*)Ly.in_norm, m->rms_eps, T, H, h);
+      RARC_HIP_CHECK(hipGetLastError());
+      if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)h, Ly.qkv_w, m->zero_bias, (uint16_t*)qkv, Tg, QKV, H, 0, stream)) return rc;
+    }
     if (fill) {   // mode 1: this layer's raw k | v rows go to the cache
       hipLaunchKernelGGL(rarc_lm_copy_kv_kernel, dim3(tb), dim3(256), 0, s, (const half_t*)qkv, T, QKV, QD, (int)kv_cols,
                          (half_t*)((char*)fill + (size_t)l * cache_layer));
@@ -1042,6 +1083,15 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
     }
+    if (fuse) {
+      if (int rc = rarc_gemm_fused_norm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)x, Tg, H, QD, 32, stream)) return rc;
+      if (int rc = row_scales()) return rc;
+      if (int rc = rarc_gemm_fused_norm((const uint16_t*)x, Ly.gate_up_w_folded, rowscale, (uint16_t*)act, Tg, 2 * I, H, 19, stream)) return rc;
+      if (int rc = rarc_gemm_fused_norm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)x, Tg, H, I, 32, stream)) return rc;
+      if (l + 1 < m->n_layers)
+        if (int rc = row_scales()) return rc;
+      continue;
+    }
     if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)delta, Tg, H, QD, 0, stream)) return rc;
     hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)Ly.post_norm,
                        m->rms_eps, T, H, h);
@@ -1055,10 +1105,11 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
     }
     if (int rc = rarc_enc_gemm_zero_bias((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)delta, Tg, H, I, 0, stream)) return rc;
   }
-  // the last layer's MLP output joins the residual stream (no norm output wanted: y = null)
-  hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)nullptr, m->rms_eps,
-                     T, H, (half_t*)nullptr);
-  RARC_HIP_CHECK(hipGetLastError());
+  if (!fuse) {   // the last layer's MLP output joins the residual stream (no norm output wanted: y = null)
+    hipLaunchKernelGGL(rarc_lm_rmsnorm_kernel, dim3(tb), dim3(256), 0, s, x, (const half_t*)delta, (const half_t*)nullptr, m->rms_eps,
+                       T, H, (half_t*)nullptr);
+    RARC_HIP_CHECK(hipGetLastError());
+  }
   hipLaunchKernelGGL(rarc_lm_last_logits_kernel, dim3(n_seq), dim3(64), 0, s, (const half_t*)x, (const half_t*)m->final_norm,
                      (const half_t*)m->lm_head, m->rms_eps, seq_len, seq_len - 1, H, no_id, yes_id, (half_t*)d_out_f16);
   RARC_HIP_CHECK(hipGetLastError());

@@ -245,6 +245,21 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
   }
 }
 
+// ---- epilogue variants of the reranker LM (round 3: RMSNorm folded into its neighbours) ----------------------
+// ACT = base (0 none, 1 GELU, 3 SwiGLU, 4 fp32 out) | 16 (RS) | 32 (RES):
+//   RES  the output joins the residual stream in place: C = fp16(C + fp16(A·Wᵀ)) — the fp16 tensor add the RMSNorm kernel
+//        used to do on its way in;
+//   RS   per-row scale: the kernel's `bias` argument is `const float* rowscale` [M] and C = act(rowscale[m] · A·Wᵀ) — with
+//        W's columns pre-multiplied by the norm weight this is the projection of RMSNorm(x) computed from x itself.
+__device__ __forceinline__ void gemm_store8(half_t* p, const uint4 v, const bool res) {
+  if (res) {
+    const half8 o = *(const half8*)p;
+    *(half8*)p = o + __builtin_bit_cast(half8, v);
+  } else {
+    *(uint4*)p = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // 256 x 256 x 64 tiles for the large GEMMs (QKV, FFN1 at M >= 8192): half the L2 -> LDS bytes per flop of the
 // 256 x 128 kernel above, and an explicit ping-pong between the two waves of every SIMD.
@@ -436,7 +451,14 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   asm volatile("" : "+v"(lane_e));
   const int row_e = lane_e & 31, hh_e = lane_e >> 5;
   char* ep = smem + wave * G256_EP_BYTES;
-  if constexpr (ACT == 4) {  // raw fp32 products, no bias (the split-operand GEMMs of encoder_f32.hip): C is float [M][N]
+  constexpr int BASE = ACT & 15;
+  constexpr bool RS = (ACT & 16) != 0, RES = (ACT & 32) != 0;
+  float rs[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (RS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row_e];
+  }
+  if constexpr (BASE == 4) {  // raw fp32 products, no bias (the split-operand GEMMs of encoder_f32.hip): C is float [M][N]
     // the wave's 128 x 64 block goes through its 18 KiB of staging in two 32-column halves of 128-byte rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
       }
       __builtin_amdgcn_wave_barrier();
     }
-  } else if constexpr (ACT == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
+  } else if constexpr (BASE == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -464,11 +486,12 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
           const int nl = j * 32 + 8 * g + 4 * hh_e;
-          const half4 bg = *(const half4*)(bias + tn * 256 + wc * 64 + nl), bu = *(const half4*)(bias + tn * 256 + wc * 64 + nl + 8);
+          half4 bg = {0, 0, 0, 0}, bu = {0, 0, 0, 0};
+          if constexpr (!RS) { bg = *(const half4*)(bias + tn * 256 + wc * 64 + nl); bu = *(const half4*)(bias + tn * 256 + wc * 64 + nl + 8); }
           half4 out;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            out[e] = rarc_swiglu_f16(acc[i][j][4 * g + e] + (float)bg[e], acc[i][j][4 * g + 4 + e] + (float)bu[e]);
+            out[e] = rarc_swiglu_f16(acc[i][j][4 * g + e] * rs[i] + (float)bg[e], acc[i][j][4 * g + 4 + e] * rs[i] + (float)bu[e]);
           *(half4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + (j * 16 + 4 * g + 4 * hh_e) * 2) = out;
         }
       }
@@ -490,12 +513,13 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = j * 32 + 8 * g + 4 * hh_e;  // column inside the wave's block
-        const half4 b4 = *(const half4*)(bias + tn * 256 + wc * 64 + nl);
+        half4 b4 = {0, 0, 0, 0};
+        if constexpr (!RS) b4 = *(const half4*)(bias + tn * 256 + wc * 64 + nl);
         half4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = acc[i][j][4 * g + e] + (float)b4[e];
-          if (ACT == 1) v = rarc_gelu_erf(v);
+          float v = acc[i][j][4 * g + e] * rs[i] + (float)b4[e];
+          if (BASE == 1) v = rarc_gelu_erf(v);
           out[e] = (half_t)v;
         }
         *(half4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + nl * 2) = out;
@@ -509,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int r = t * 8 + r8;
-      *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16);
+      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16), RES);
     }
   }
   }
@@ -929,7 +953,14 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
   // epilogue: acc[i] is rows wr*128 + i*32 + row, cols wc*32 + (8g + 4hh .. +3); transposed through LDS like above
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
   char* ep = smem + wave * G128_EP_BYTES;
-  if constexpr (ACT == 4) {  // raw fp32 products, no bias: the wave's 128 x 32 block as 128-byte rows (144-byte staging rows)
+  constexpr int BASE = ACT & 15;
+  constexpr bool RS = (ACT & 16) != 0, RES = (ACT & 32) != 0;
+  float rs[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr (RS) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row];
+  }
+  if constexpr (BASE == 4) {  // raw fp32 products, no bias: the wave's 128 x 32 block as 128-byte rows (144-byte staging rows)
     char* ep4 = smem + wave * (128 * 144);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -947,16 +978,17 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
     }
     return;
   }
-  if constexpr (ACT == 3) {  // silu(gate)·up (see rarc_swiglu_f16): the wave's 32 columns are 16 features -> 32-byte rows
+  if constexpr (BASE == 3) {  // silu(gate)·up (see rarc_swiglu_f16): the wave's 32 columns are 16 features -> 32-byte rows
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; g += 2) {
         const int nl = 8 * g + 4 * hh;
-        const half4 bg = *(const half4*)(bias + tn * 128 + wc * 32 + nl), bu = *(const half4*)(bias + tn * 128 + wc * 32 + nl + 8);
+        half4 bg = {0, 0, 0, 0}, bu = {0, 0, 0, 0};
+        if constexpr (!RS) { bg = *(const half4*)(bias + tn * 128 + wc * 32 + nl); bu = *(const half4*)(bias + tn * 128 + wc * 32 + nl + 8); }
         half4 out;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = rarc_swiglu_f16(acc[i][4 * g + e] + (float)bg[e], acc[i][4 * g + 4 + e] + (float)bu[e]);
+        for (int e = 0; e < 4; ++e) out[e] = rarc_swiglu_f16(acc[i][4 * g + e] * rs[i] + (float)bg[e], acc[i][4 * g + 4 + e] * rs[i] + (float)bu[e]);
         *(half4*)(ep + (i * 32 + row) * G128_EP_STRIDE + (4 * g + 4 * hh) * 2) = out;
       }
     }
@@ -976,12 +1008,13 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nl = 8 * g + 4 * hh;
-      const half4 b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
+      half4 b4 = {0, 0, 0, 0};
+      if constexpr (!RS) b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
       half4 out;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = acc[i][4 * g + e] + (float)b4[e];
-        if (ACT == 1) v = rarc_gelu_erf(v);
+        float v = acc[i][4 * g + e] * rs[i] + (float)b4[e];
+        if (BASE == 1) v = rarc_gelu_erf(v);
         out[e] = (half_t)v;
       }
       *(half4*)(ep + (i * 32 + row) * G128_EP_STRIDE + nl * 2) = out;
@@ -994,7 +1027,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int r = t * 16 + r16;
-      *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16);
+      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16), RES);
     }
   }
 }
@@ -1101,7 +1134,9 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
   // epilogue: acc[i] is rows wr*64 + i*32 + row, cols wc*32 + (8g + 4hh .. +3); transposed through LDS into whole
   // 64-byte (fp16) / 128-byte (fp32 partial) row segments
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-  if (ACT == 2) {
+  constexpr int BASE = ACT & 15;
+  constexpr bool RS = (ACT & 16) != 0, RES = (ACT & 32) != 0;
+  if (BASE == 2) {
     constexpr int ST = 32 * 4 + 16;
     char* ep = smem + wave * 64 * ST;
 #pragma unroll
@@ -1121,17 +1156,23 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
   } else {
     constexpr int ST = 32 * 2 + 16;
     char* ep = smem + wave * 64 * ST;
+    float rs[2] = {1.f, 1.f};
+    if constexpr (RS) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 128 + wr * 64 + i * 32 + row];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int nl = 8 * g + 4 * hh;
-        const half4 b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
+        half4 b4 = {0, 0, 0, 0};
+        if constexpr (!RS) b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
         half4 out;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float v = acc[i][4 * g + e] + (float)b4[e];
-          if (ACT == 1) v = rarc_gelu_erf(v);
+          float v = acc[i][4 * g + e] * rs[i] + (float)b4[e];
+          if (BASE == 1) v = rarc_gelu_erf(v);
           out[e] = (half_t)v;
         }
         *(half4*)(ep + (i * 32 + row) * ST + nl * 2) = out;
@@ -1143,7 +1184,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = t * 16 + r16;
-      *(uint4*)(Cw + (size_t)r * N) = *(const uint4*)(ep + r * ST + c * 16);
+      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * ST + c * 16), RES);
     }
   }
 }
@@ -1535,6 +1576,14 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256s_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256s_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
@@ -1592,6 +1641,15 @@ bool rarc_gemm_swiglu_fused(int m, int n, int k) {
   return t128 >= 256 && k >= 3 * GK;
 }
 
+// true when rarc_enc_gemm(m, n, k) AND its cut-off tail run kernels that have the row-scale / residual epilogues (act | 16,
+// act | 32): the 256-row ping-pong kernels for the bulk, the 128 x 128 ping-pong kernel for a tail
+bool rarc_gemm_norm_fusable(int m, int n, int k) {
+  static const int force = getenv("RARC_GEMM_PP") ? atoi(getenv("RARC_GEMM_PP")) : -1;
+  if (force == 0 || m <= 0 || m % 256 || n % GN || k % GK || k < 4 * GK) return false;
+  const int t256 = n % 256 == 0 ? (m / 256) * (n / 256) : 0, t128 = (m / 256) * (n / GN);
+  return (force != 1 && gemm_prefers_256x256(t256, t128)) || t128 >= 256;
+}
+
 // act 0 / 1 / 3 as rarc_enc_gemm; act 4: raw fp32 products, no bias, d_c is float [M][N] (encoder_f32.hip)
 // zero_bias: the caller guarantees d_bias holds zeros (the reranker LM's projections) — the seamless 256 x 256 kernel, which
 // has no bias path, may take the large shapes
@@ -1631,7 +1689,7 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       const int full = t256 / lcm * lcm, rem = t256 - full;
       int m_main = m;
       if (cut_tail && persist && full > 0 && rem > 0 && 4 * rem <= 256 &&
-          (act != 3 || rarc_gemm_swiglu_fused(m - full / tiles_n * 256, n, k)))
+          ((act & 15) != 3 || rarc_gemm_swiglu_fused(m - full / tiles_n * 256, n, k)))
         m_main = full / tiles_n * 256;
       const int t_main = (m_main / 256) * tiles_n;
       const int g256 = persist && t_main > 256 ? 256 : t_main;
@@ -1648,28 +1706,38 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       if (act == 4) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<4>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else if (act == 3) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<3>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else if (act == 1) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<1>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      else if (act == 16) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<16>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      else if (act == 19) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<19>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      else if (act == 32) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<32>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
       if (m_main < m)   // (d_c counts 2-byte elements: an fp32 row is 2n of them)
-        return enc_gemm_impl(d_a + (size_t)m_main * k, d_w, d_bias, d_c + (size_t)m_main * (act == 3 ? n / 2 : (act == 4 ? 2 * n : n)),
-                             m - m_main, n, k, act, stream, zero_bias);
+        return enc_gemm_impl(d_a + (size_t)m_main * k, d_w, (act & 16) ? d_bias + (size_t)2 * m_main : d_bias,   // (RS: `bias` is float rowscale[M])
+                             d_c + (size_t)m_main * ((act & 15) == 3 ? n / 2 : (act == 4 ? 2 * n : n)), m - m_main, n, k, act, stream, zero_bias);
       return RARC_OK;
     }
     if (t128 >= 256 && k >= 3 * GK) {
       if (act == 4) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<4>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 3) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<3>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 1) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<1>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 16) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<16>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 19) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<19>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 32) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<32>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<0>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
     }
   }
-  RARC_REQUIRE(act != 3, RARC_E_UNSUPPORTED, "rarc_enc_gemm: the fused SwiGLU epilogue needs a shape the 256-row kernels take "
+  RARC_REQUIRE((act & 15) != 3, RARC_E_UNSUPPORTED, "rarc_enc_gemm: the fused SwiGLU epilogue needs a shape the 256-row kernels take "
                "(ask rarc_gemm_swiglu_fused first)");
+  RARC_REQUIRE(!(act & 48) || (deep && force != 0 && k >= 4 * GK), RARC_E_UNSUPPORTED,
+               "rarc_enc_gemm: the row-scale / residual epilogues need a shape the ping-pong kernels take (ask rarc_gemm_norm_fusable first)");
   if (act == 4) return enc_gemm_splitk(d_a, d_w, (float*)d_c, m, n, k, 1, s);   // small / odd shapes: the split-K kernels, one slice
   if (deep && force != 0 && k >= 4 * GK) {
     const int grid = (m / GM) * (n / GN);
     if (act == 1) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<1>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
+    else if (act == 16) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<16>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
+    else if (act == 32) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<32>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
     else hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<0>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
   } else if (deep) {
     const int grid = (m / GM) * (n / GN);
@@ -1705,6 +1773,14 @@ extern "C" int rarc_enc_gemm_zero_bias(const uint16_t* d_a, const uint16_t* d_w,
                "rarc_enc_gemm: need M,N multiples of 128 and K multiple of 64 (got %d,%d,%d)", m, n, k);
   RARC_REQUIRE(act == 0 || act == 3, RARC_E_INVALID, "rarc_enc_gemm_zero_bias: act must be 0 or 3");
   return enc_gemm_impl(d_a, d_w, d_zero_bias, d_c, m, n, k, act, stream, true);
+}
+
+// the LM's norm-fused projections (decoder.hip): act 16 / 19 with d_rowscale float [m] in the bias slot, act 32 in place on d_c
+int rarc_gemm_fused_norm(const uint16_t* d_a, const uint16_t* d_w, const void* d_rowscale_or_zero, uint16_t* d_c, int m, int n, int k,
+                         int act, void* stream) {
+  RARC_REQUIRE(d_a && d_w && d_rowscale_or_zero && d_c && (act == 16 || act == 19 || act == 32), RARC_E_INVALID, "rarc_gemm_fused_norm: bad argument");
+  RARC_REQUIRE(rarc_gemm_norm_fusable(m, n, k), RARC_E_UNSUPPORTED, "rarc_gemm_fused_norm: shape %d x %d x %d not fusable", m, n, k);
+  return enc_gemm_impl(d_a, d_w, (const uint16_t*)d_rowscale_or_zero, d_c, m, n, k, act, stream, false);
 }
 
 // fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward

@@ -22,6 +22,7 @@
 //
 // Algorithmic HBM bytes per launch: n_rows × D × 2  (DESIGN.md §kernels).
 #include "rarc_common.h"
+#include <stdlib.h>
 
 struct ScanParams {
   const half_t* corpus;  // [ceil32(n_rows)][D]
@@ -735,6 +736,9 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
   RARC_HIP_CHECK(hipGetDevice(&dev));
   RARC_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   int grid = cus < RARC_MAX_WG ? cus : RARC_MAX_WG;
+  // RARC_SCAN_WGS=n: fewer persistent workgroups than CUs (measurement: do the small kernels of a neighbouring batch on
+  // a second stream find room on the CUs this leaves free?  DESIGN 8 / 11)
+  if (const char* e = getenv("RARC_SCAN_WGS")) { const int g = atoi(e); if (g >= 8 && g < grid) grid = g; }
   if ((uint32_t)grid > p.n_tiles) grid = (int)p.n_tiles;
   *grid_out = grid;
   if (p.n_tiles == 0) return RARC_OK;

@@ -55,7 +55,8 @@ class Enc32Model(ctypes.Structure):
 
 class LmLayer(ctypes.Structure):
     """RarcLmLayer (include/rarc.h): device pointers of one decoder layer."""
-    _fields_ = [(n, c_void_p) for n in ("in_norm", "qkv_w", "q_norm", "k_norm", "o_w", "post_norm", "gate_up_w", "down_w")]
+    _fields_ = [(n, c_void_p) for n in ("in_norm", "qkv_w", "q_norm", "k_norm", "o_w", "post_norm", "gate_up_w", "down_w",
+                                        "qkv_w_folded", "gate_up_w_folded")]
 
 
 class LmModel(ctypes.Structure):

@@ -168,6 +168,52 @@ def test_resident_attention_equals_streaming_bit_for_bit(oracle, monkeypatch, H,
     assert torch.equal(resident.view(torch.int16), streaming.view(torch.int16))
 
 
+@pytest.mark.parametrize("n,L,with_oracle", [(32, 256, True), (68, 256, False), (128, 137, False)])
+def test_rmsnorm_folded_into_the_projections(oracle, monkeypatch, n, L, with_oracle):
+    """Batches large enough for the 256-row tile kernels run without RMSNorm passes: the output / down projections add into the
+    residual stream in their epilogue, q|k|v and gate|up multiply the stream by norm-folded weights and scale their rows by
+    rsqrt(mean(x²) + eps) (RarcLmLayer.qkv_w_folded / gate_up_w_folded; RARC_LM_FUSE_NORM=0 keeps the separate passes).
+    Same function with one rounding moved, so: (a) the fp32 oracle at the tolerance of the plain path, (b) the two paths
+    within fp16 noise of each other.  Qwen3-Reranker-0.6B's layer geometry, three layers; 8192 tokens (256 x 256 and 256 x 128
+    tile kernels), 17 408 tokens (68 row tiles: a cut-off tail on the 128 x 128 kernel, its row scales offset), 17 536 = 128 x 137
+    tokens (an odd multiple of 128: the GEMMs run on a zero-padded 17 664 rows, x's padding rows included)."""
+    import torch
+
+    from rag_arc_amd.core.rerank import HipCausalLM
+
+    H, LAYERS, NQ, NKV, DH, I, V = 1024, 3, 16, 8, 128, 3072, 1000
+    sd = oracle.random_qwen3_state_dict(H, LAYERS, NQ, NKV, DH, I, vocab=V, seed=n + L)
+    lm = HipCausalLM(sd, NQ, NKV, DH, rms_norm_eps=1e-6, rope_theta=1e6)
+    rng = np.random.default_rng(n * L)
+    ids = rng.integers(5, V, (n, L)).astype(np.int32)
+    start = rng.integers(0, L // 2, n).astype(np.int32)
+    start[0] = 0
+    for r in range(n):
+        ids[r, :start[r]] = 0
+    assert (n * L) % 128 == 0
+    dev = lm.device
+    run = lambda: lm.yes_no_logits_device(torch.from_numpy(ids).to(dev), torch.from_numpy(start).to(dev), 11, 42).float().cpu().numpy()
+    monkeypatch.delenv("RARC_LM_FUSE_NORM", raising=False)
+    fused = run()
+    monkeypatch.setenv("RARC_LM_FUSE_NORM", "0")
+    plain = run()
+    sig = lambda z: 1.0 / (1.0 + np.exp(-(z[:, 1] - z[:, 0])))
+    assert np.isfinite(fused).all()
+    d = np.abs(fused - plain).max()
+    print(f"LM-FOLD n={n} L={L}: folded vs separate norm passes max|dlogit|={d:.2e} (|logit| up to {np.abs(plain).max():.2f}), "
+          f"max|dp_yes|={np.abs(sig(fused) - sig(plain)).max():.2e}")
+    assert 0 < d <= 4e-2 and np.abs(sig(fused) - sig(plain)).max() <= 1e-2      # different roundings (d > 0: the folded path did run)
+    if with_oracle:
+        mask = (np.arange(L)[None, :] >= start[:, None]).astype(np.int64)
+        sd16 = {k: np.asarray(v, np.float32).astype(np.float16).astype(np.float32) for k, v in sd.items()}
+        want = oracle.qwen3_last_logits_f32(sd16, dict(num_attention_heads=NQ, num_key_value_heads=NKV, head_dim=DH, rms_norm_eps=1e-6,
+                                                       rope_theta=1e6), ids.astype(np.int64) * mask, mask, [11, 42])
+        e_f, e_p = np.abs(fused - want).max(), np.abs(plain - want).max()
+        print(f"LM-FOLD vs oracle: folded {e_f:.2e}, separate {e_p:.2e}; max|dp_yes| {np.abs(sig(fused) - sig(want)).max():.2e}")
+        # (logits reach 17 here: one fp16 ulp is 1.6e-2; the plain path itself sits at 3.4e-2)
+        assert e_f <= 5e-2 and e_f <= 1.5 * e_p + 1e-2 and np.abs(sig(fused) - sig(want)).max() <= 1e-2
+
+
 def test_reranker_end_to_end_matches_reference_steps(oracle):
     """rerank(): prompt format, truncation, prefix / suffix ids, left padding, batches of 8, p_yes in fp16, stable
     descending order — the steps of core/rerank/Reranker_Qwen3.py:23-75 with a toy tokenizer."""
