@@ -251,13 +251,11 @@ __global__ __launch_bounds__(BM * 2, BM == 128 ? 2 : 1) void rarc_gemm_f16_kerne
 //        used to do on its way in;
 //   RS   per-row scale: the kernel's `bias` argument is `const float* rowscale` [M] and C = act(rowscale[m] · A·Wᵀ) — with
 //        W's columns pre-multiplied by the norm weight this is the projection of RMSNorm(x) computed from x itself.
-__device__ __forceinline__ void gemm_store8(half_t* p, const uint4 v, const bool res) {
-  if (res) {
-    const half8 o = *(const half8*)p;
-    *(half8*)p = o + __builtin_bit_cast(half8, v);
-  } else {
-    *(uint4*)p = v;
-  }
+// (RES: the old values are fetched at the START of the epilogue, `old`, so that their latency hides under the conversion and
+//  the LDS transposition — read inside the store loop every piece waited for its own round trip: +7 % on these GEMMs)
+__device__ __forceinline__ void gemm_store8(half_t* p, const uint4 v, const bool res, const half8 old) {
+  if (res) *(half8*)p = old + __builtin_bit_cast(half8, v);
+  else *(uint4*)p = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -458,6 +456,12 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
     for (int i = 0; i < 4; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row_e];
   }
+  half8 oldv[16];
+  if constexpr (RES) {
+    const half_t* Co = C + (size_t)(tm * 256 + wr * 128 + (lane_e >> 3)) * N + tn * 256 + wc * 64 + (lane_e & 7) * 8;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) oldv[t] = *(const half8*)(Co + (size_t)(t * 8) * N);
+  }
   if constexpr (BASE == 4) {  // raw fp32 products, no bias (the split-operand GEMMs of encoder_f32.hip): C is float [M][N]
     // the wave's 128 x 64 block goes through its 18 KiB of staging in two 32-column halves of 128-byte rows
 #pragma unroll
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int r = t * 8 + r8;
-      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16), RES);
+      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16), RES, oldv[t]);
     }
   }
   }
@@ -960,6 +964,12 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
 #pragma unroll
     for (int i = 0; i < 4; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row];
   }
+  half8 oldv[8];
+  if constexpr (RES) {
+    const half_t* Co = C + (size_t)(tm * 256 + wr * 128 + (lane >> 2)) * N + tn * 128 + wc * 32 + (lane & 3) * 8;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) oldv[t] = *(const half8*)(Co + (size_t)(t * 16) * N);
+  }
   if constexpr (BASE == 4) {  // raw fp32 products, no bias: the wave's 128 x 32 block as 128-byte rows (144-byte staging rows)
     char* ep4 = smem + wave * (128 * 144);
 #pragma unroll
@@ -1027,7 +1037,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int r = t * 16 + r16;
-      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16), RES);
+      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16), RES, oldv[t]);
     }
   }
 }
@@ -1156,6 +1166,12 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
   } else {
     constexpr int ST = 32 * 2 + 16;
     char* ep = smem + wave * 64 * ST;
+    half8 oldv[4];
+    if constexpr (RES) {
+      const half_t* Co = C + (size_t)(tm * 128 + wr * 64 + (lane >> 2)) * N + tn * 128 + wc * 32 + (lane & 3) * 8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) oldv[t] = *(const half8*)(Co + (size_t)(t * 16) * N);
+    }
     float rs[2] = {1.f, 1.f};
     if constexpr (RS) {
 #pragma unroll
@@ -1184,7 +1200,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = t * 16 + r16;
-      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * ST + c * 16), RES);
+      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * ST + c * 16), RES, oldv[t]);
     }
   }
 }
