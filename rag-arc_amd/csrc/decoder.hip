@@ -25,7 +25,8 @@ extern "C" int rarc_enc_gemm(const uint16_t* d_a, const uint16_t* d_w, const uin
 bool rarc_gemm_swiglu_fused(int m, int n, int k);  // encoder.hip: act = 3 available for this shape
 bool rarc_gemm_norm_fusable(int m, int n, int k);  // encoder.hip: the row-scale / residual epilogues are available for this shape
 int rarc_gemm_fused_norm(const uint16_t* d_a, const uint16_t* d_w, const void* d_rowscale_or_zero, uint16_t* d_c, int m, int n, int k,
-                         int act, void* stream);   // act 16 / 19: C = act(rowscale ⊙ A·Wᵀ); 32: C += A·Wᵀ in place
+                         int act, void* stream, float* d_ssq = nullptr);   // act 16 / 19: C = act(rowscale ⊙ A·Wᵀ); 32: C += A·Wᵀ in
+                                                                           // place; 96: the same + sums of squares per 32 columns
 
 
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
@@ -74,21 +75,15 @@ __global__ __launch_bounds__(256) void rarc_lm_rmsnorm_kernel(half_t* x, const h
   }
 }
 
-// ---- r[t] = rsqrt(mean(x[t]²) + eps): the row scale of an RMSNorm whose weight is folded into the next projection --------
-__global__ __launch_bounds__(256) void rarc_lm_rowscale_kernel(const half_t* __restrict__ x, float eps, int n_tokens, int H,
-                                                               float* __restrict__ r) {
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+// ---- r[t] from the partial sums of squares the residual epilogue left (ssq [n_tokens][n_parts], one per 32 columns) -----
+__global__ __launch_bounds__(256) void rarc_lm_rowscale_parts_kernel(const float* __restrict__ ssq, int n_parts, float eps, int n_tokens,
+                                                                     int H, float* __restrict__ r) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n_tokens) return;
-  const half_t* xr = x + (size_t)t * H;
+  const float* p = ssq + (size_t)t * n_parts;
   float ss = 0.f;
-  for (int c = lane * 8; c < H; c += 512) {
-    const half8 v = *(const half8*)(xr + c);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)v[e], (float)v[e], ss);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-  if (lane == 0) r[t] = 1.0f / __builtin_sqrtf(ss / (float)H + eps);
+  for (int i = 0; i < n_parts; ++i) ss += p[i];      // fixed order
+  r[t] = 1.0f / __builtin_sqrtf(ss / (float)H + eps);
 }
 
 // ---- rotary table: per position a row of DH halves, cos of the DH/2 pairs then their sin ---------------------------------
@@ -883,7 +878,8 @@ extern "C" size_t rarc_lm_workspace_bytes(const RarcLmModel* m, int n_tokens) {
          + lm_align(T * 2 * (size_t)m->inter * 2)               // fused gate | up
          + lm_align(T * (size_t)m->inter * 2)                   // silu(gate) * up
          + lm_align((T + 4096) * (size_t)(m->head_dim / 2) * 4)   // rotary (cos, sin) table: prefix + sequence positions
-         + lm_align(T * 4);                                      // row scales of the folded RMSNorms
+         + lm_align(T * 4)                                       // row scales of the folded RMSNorms
+         + lm_align(T * (size_t)(m->hidden / 32) * 4);           // their partial sums of squares (one per 32 columns)
 }
 
 // ---- prefix K/V cache (see LmAttnPrefix): per layer [n_prefix * P][2 * n_kv * head_dim] raw k | v rows -----------------
@@ -942,6 +938,7 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
   half_t* act = (half_t*)((char*)gu + lm_align(Tw * 2 * I * 2));
   half2_t* rope = (half2_t*)((char*)act + lm_align(Tw * I * 2));
   float* rowscale = (float*)((char*)rope + lm_align((Tw + 4096) * (size_t)(DH / 2) * 4));
+  float* ssq = (float*)((char*)rowscale + lm_align(Tw * 4));
   if (Tg > T) {   // the GEMMs' A operands of the padding rows: h / x (q|k|v, gate|up), ctx (output projection); act follows
     RARC_HIP_CHECK(hipMemsetAsync(h + (size_t)T * H, 0, (size_t)(Tg - T) * H * 2, s));
     RARC_HIP_CHECK(hipMemsetAsync(x + (size_t)T * H, 0, (size_t)(Tg - T) * H * 2, s));
@@ -949,15 +946,16 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
   }
   // RMSNorm folded into the projections (RarcLmLayer.qkv_w_folded / gate_up_w_folded): when every projection of a layer runs
   // a tile kernel with the row-scale / residual epilogues, the norm passes disappear — the output and down projections add
-  // into x in place, rarc_lm_rowscale_kernel reads x once for r = rsqrt(mean(x²) + eps), q|k|v and gate|up multiply x by the
-  // folded weights and scale their rows by r.  (It was: read x, read delta, write x, write the normed copy — 0.41 ms of a
+  // into x in place and leave per-row partial sums of squares (one per 32 columns), rarc_lm_rowscale_parts_kernel turns those
+  // into r = rsqrt(mean(x²) + eps), q|k|v and gate|up multiply x by the folded weights and scale their rows by r.  (It was: read x, read delta, write x, write the normed copy — 0.41 ms of a
   // 5.9 ms layer at 163 840 tokens.)  RARC_LM_FUSE_NORM=0: the separate passes (A/B runs, tests).
   const char* fuse_env = getenv("RARC_LM_FUSE_NORM");
   bool fuse = !(fuse_env && atoi(fuse_env) == 0) && rarc_gemm_norm_fusable(Tg, QKV, H) && rarc_gemm_norm_fusable(Tg, H, QD) &&
               rarc_gemm_norm_fusable(Tg, 2 * I, H) && rarc_gemm_swiglu_fused(Tg, 2 * I, H) && rarc_gemm_norm_fusable(Tg, H, I);
   for (int l = 0; l < m->n_layers && fuse; ++l) fuse = m->layers[l].qkv_w_folded && m->layers[l].gate_up_w_folded;
-  auto row_scales = [&]() -> int {
-    hipLaunchKernelGGL(rarc_lm_rowscale_kernel, dim3((Tg + 3) / 4), dim3(256), 0, s, (const half_t*)x, m->rms_eps, Tg, H, rowscale);
+  auto row_scales = [&]() -> int {   // from the partial sums the residual epilogue (act 96) left: 4 H / 32 bytes per row instead of 2 H
+    hipLaunchKernelGGL(rarc_lm_rowscale_parts_kernel, dim3((Tg + 255) / 256), dim3(256), 0, s, (const float*)ssq, H / 32, m->rms_eps, Tg, H,
+                       rowscale);
     RARC_HIP_CHECK(hipGetLastError());
     return RARC_OK;
   };
@@ -1084,10 +1082,10 @@ static int lm_forward(const RarcLmModel* m, const int32_t* d_ids, const int32_t*
       return RARC_OK;
     }
     if (fuse) {
-      if (int rc = rarc_gemm_fused_norm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)x, Tg, H, QD, 32, stream)) return rc;
+      if (int rc = rarc_gemm_fused_norm((const uint16_t*)ctx, Ly.o_w, m->zero_bias, (uint16_t*)x, Tg, H, QD, 96, stream, ssq)) return rc;
       if (int rc = row_scales()) return rc;
       if (int rc = rarc_gemm_fused_norm((const uint16_t*)x, Ly.gate_up_w_folded, rowscale, (uint16_t*)act, Tg, 2 * I, H, 19, stream)) return rc;
-      if (int rc = rarc_gemm_fused_norm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)x, Tg, H, I, 32, stream)) return rc;
+      if (int rc = rarc_gemm_fused_norm((const uint16_t*)act, Ly.down_w, m->zero_bias, (uint16_t*)x, Tg, H, I, 96, stream, ssq)) return rc;
       if (l + 1 < m->n_layers)
         if (int rc = row_scales()) return rc;
       continue;

@@ -257,6 +257,19 @@ __device__ __forceinline__ void gemm_store8(half_t* p, const uint4 v, const bool
   if (res) *(half8*)p = old + __builtin_bit_cast(half8, v);
   else *(uint4*)p = v;
 }
+// RES with statistics: additionally the sum of squares of the 32-column segment this lane's 8 values belong to (4 lanes
+// x 8 columns, fp32, fixed order) goes to ssq[row * (N / 32) + segment] — the RMSNorm that follows needs mean(x²) per row
+// and would otherwise read the whole stream again for it (rarc_lm_rowscale_kernel sums the N / 32 partials instead).
+__device__ __forceinline__ void gemm_store8_ss(half_t* p, const uint4 v, const half8 old, float* ssq, size_t slot, int lane) {
+  const half8 nv = old + __builtin_bit_cast(half8, v);
+  *(half8*)p = nv;
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ss = __builtin_fmaf((float)nv[e], (float)nv[e], ss);
+  ss += __shfl_xor(ss, 1, 64);
+  ss += __shfl_xor(ss, 2, 64);
+  if ((lane & 3) == 0) ssq[slot] = ss;
+}
 
 // ------------------------------------------------------------------------------------------
 // 256 x 256 x 64 tiles for the large GEMMs (QKV, FFN1 at M >= 8192): half the L2 -> LDS bytes per flop of the
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
                                                                   const half_t* __restrict__ W,
                                                                   const half_t* __restrict__ bias,
                                                                   half_t* __restrict__ C, int M, int N, int K,
-                                                                  int order) {
+                                                                  int order, float* __restrict__ ssq = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,10 +439,19 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     G256_TILE(true, false, 10, 8, 6, 4)
     ++kt;
   }
+  // RS (ACT | 16): the four row scales of this lane's rows are fetched before the last k tile, so that their round trip
+  // runs under its MFMAs instead of in front of the epilogue; they are the newest vector-memory operations from here on,
+  // and the last tile's waits let exactly them stay outstanding
+  float rs_pre[4] = {1.f, 1.f, 1.f, 1.f};
+  if constexpr ((ACT & 16) != 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rs_pre[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row];
+  }
   {  // last tile
     const int par = kt & 1, np = par ^ 1;
     (void)np;
-    G256_TILE(false, false, 2, 0, 0, 0)
+    if constexpr ((ACT & 16) != 0) { G256_TILE(false, false, 6, 4, 4, 4) }
+    else { G256_TILE(false, false, 2, 0, 0, 0) }
   }
   if (wr == 0) G256_BAR();
 #undef G256_TILE
@@ -451,11 +473,9 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   char* ep = smem + wave * G256_EP_BYTES;
   constexpr int BASE = ACT & 15;
   constexpr bool RS = (ACT & 16) != 0, RES = (ACT & 32) != 0;
-  float rs[4] = {1.f, 1.f, 1.f, 1.f};
-  if constexpr (RS) {
+  float rs[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row_e];
-  }
+  for (int i = 0; i < 4; ++i) rs[i] = rs_pre[i];
   half8 oldv[16];
   if constexpr (RES) {
     const half_t* Co = C + (size_t)(tm * 256 + wr * 128 + (lane_e >> 3)) * N + tn * 256 + wc * 64 + (lane_e & 7) * 8;
@@ -537,7 +557,11 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int r = t * 8 + r8;
-      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16), RES, oldv[t]);
+      if constexpr ((ACT & 64) != 0)
+        gemm_store8_ss(Cw + (size_t)r * N, *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16), oldv[t], ssq,
+                       (size_t)(tm * 256 + wr * 128 + r) * (N / 32) + tn * 8 + wc * 2 + (c >> 2), lane_e);
+      else
+        gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16), RES, oldv[t]);
     }
   }
   }
@@ -851,7 +875,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
                                                                       const half_t* __restrict__ W,
                                                                       const half_t* __restrict__ bias,
                                                                       half_t* __restrict__ C, int M, int N, int K,
-                                                                      int order) {
+                                                                      int order, float* __restrict__ ssq = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1037,7 +1061,11 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int r = t * 16 + r16;
-      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16), RES, oldv[t]);
+      if constexpr ((ACT & 64) != 0)
+        gemm_store8_ss(Cw + (size_t)r * N, *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16), oldv[t], ssq,
+                       (size_t)(tm * 256 + wr * 128 + r) * (N / 32) + tn * 4 + wc, lane);
+      else
+        gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * G128_EP_STRIDE + c * 16), RES, oldv[t]);
     }
   }
 }
@@ -1057,7 +1085,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
                                                                     const half_t* __restrict__ W,
                                                                     const half_t* __restrict__ bias,
                                                                     half_t* __restrict__ C, int M, int N, int K, int ldk,
-                                                                    int order) {
+                                                                    int order, float* __restrict__ ssq = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1200,7 +1228,11 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = t * 16 + r16;
-      gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * ST + c * 16), RES, oldv[t]);
+      if constexpr ((ACT & 64) != 0)
+        gemm_store8_ss(Cw + (size_t)r * N, *(const uint4*)(ep + r * ST + c * 16), oldv[t], ssq,
+                       (size_t)(tm * 128 + wr * 64 + r) * (N / 32) + tn * 4 + wc, lane);
+      else
+        gemm_store8(Cw + (size_t)r * N, *(const uint4*)(ep + r * ST + c * 16), RES, oldv[t]);
     }
   }
 }
@@ -1600,6 +1632,9 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256s_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G256S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256s_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256x128_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G128_LDS));
@@ -1670,7 +1705,7 @@ bool rarc_gemm_norm_fusable(int m, int n, int k) {
 // zero_bias: the caller guarantees d_bias holds zeros (the reranker LM's projections) — the seamless 256 x 256 kernel, which
 // has no bias path, may take the large shapes
 static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m, int n, int k,
-                         int act, void* stream, bool zero_bias = false) {
+                         int act, void* stream, bool zero_bias = false, float* d_ssq = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   const half_t *a = (const half_t*)d_a, *w = (const half_t*)d_w, *bs = (const half_t*)d_bias;
   half_t* c = (half_t*)d_c;
@@ -1725,11 +1760,13 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       else if (act == 16) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<16>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else if (act == 19) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<19>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       else if (act == 32) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<32>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
+      else if (act == 96) hipLaunchKernelGGL((rarc_gemm256_f16_kernel<96>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order, d_ssq);
       else hipLaunchKernelGGL((rarc_gemm256_f16_kernel<0>), dim3(g256), dim3(512), G256_LDS, s, a, w, bs, c, m_main, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
       if (m_main < m)   // (d_c counts 2-byte elements: an fp32 row is 2n of them)
         return enc_gemm_impl(d_a + (size_t)m_main * k, d_w, (act & 16) ? d_bias + (size_t)2 * m_main : d_bias,   // (RS: `bias` is float rowscale[M])
-                             d_c + (size_t)m_main * ((act & 15) == 3 ? n / 2 : (act == 4 ? 2 * n : n)), m - m_main, n, k, act, stream, zero_bias);
+                             d_c + (size_t)m_main * ((act & 15) == 3 ? n / 2 : (act == 4 ? 2 * n : n)), m - m_main, n, k, act, stream, zero_bias,
+                             d_ssq ? d_ssq + (size_t)m_main * (n / 32) : nullptr);
       return RARC_OK;
     }
     if (t128 >= 256 && k >= 3 * GK) {
@@ -1739,6 +1776,7 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       else if (act == 16) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<16>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 19) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<19>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 32) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<32>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
+      else if (act == 96) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<96>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order, d_ssq);
       else hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<0>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       RARC_HIP_CHECK(hipGetLastError());
       return RARC_OK;
@@ -1746,7 +1784,7 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
   }
   RARC_REQUIRE((act & 15) != 3, RARC_E_UNSUPPORTED, "rarc_enc_gemm: the fused SwiGLU epilogue needs a shape the 256-row kernels take "
                "(ask rarc_gemm_swiglu_fused first)");
-  RARC_REQUIRE(!(act & 48) || (deep && force != 0 && k >= 4 * GK), RARC_E_UNSUPPORTED,
+  RARC_REQUIRE(!(act & 112) || (deep && force != 0 && k >= 4 * GK), RARC_E_UNSUPPORTED,
                "rarc_enc_gemm: the row-scale / residual epilogues need a shape the ping-pong kernels take (ask rarc_gemm_norm_fusable first)");
   if (act == 4) return enc_gemm_splitk(d_a, d_w, (float*)d_c, m, n, k, 1, s);   // small / odd shapes: the split-K kernels, one slice
   if (deep && force != 0 && k >= 4 * GK) {
@@ -1754,6 +1792,7 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
     if (act == 1) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<1>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
     else if (act == 16) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<16>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
     else if (act == 32) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<32>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
+    else if (act == 96) hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<96>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order, d_ssq);
     else hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<0>), dim3(grid), dim3(512), G128S_LDS, s, a, w, bs, c, m, n, k, k, order);
   } else if (deep) {
     const int grid = (m / GM) * (n / GN);
@@ -1792,11 +1831,13 @@ extern "C" int rarc_enc_gemm_zero_bias(const uint16_t* d_a, const uint16_t* d_w,
 }
 
 // the LM's norm-fused projections (decoder.hip): act 16 / 19 with d_rowscale float [m] in the bias slot, act 32 in place on d_c
+// (act 96 = 32 + statistics: d_ssq float [m][n / 32] receives the sums of squares of the new rows' 32-column segments)
 int rarc_gemm_fused_norm(const uint16_t* d_a, const uint16_t* d_w, const void* d_rowscale_or_zero, uint16_t* d_c, int m, int n, int k,
-                         int act, void* stream) {
-  RARC_REQUIRE(d_a && d_w && d_rowscale_or_zero && d_c && (act == 16 || act == 19 || act == 32), RARC_E_INVALID, "rarc_gemm_fused_norm: bad argument");
+                         int act, void* stream, float* d_ssq) {
+  RARC_REQUIRE(d_a && d_w && d_rowscale_or_zero && d_c && (act == 16 || act == 19 || act == 32 || (act == 96 && d_ssq)), RARC_E_INVALID,
+               "rarc_gemm_fused_norm: bad argument");
   RARC_REQUIRE(rarc_gemm_norm_fusable(m, n, k), RARC_E_UNSUPPORTED, "rarc_gemm_fused_norm: shape %d x %d x %d not fusable", m, n, k);
-  return enc_gemm_impl(d_a, d_w, (const uint16_t*)d_rowscale_or_zero, d_c, m, n, k, act, stream, false);
+  return enc_gemm_impl(d_a, d_w, (const uint16_t*)d_rowscale_or_zero, d_c, m, n, k, act, stream, false, d_ssq);
 }
 
 // fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward
