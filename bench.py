@@ -624,7 +624,12 @@ def leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, dense_ids, n2, a, steps, wa
 
     share = not a.c3_no_prefix_sharing
     q0_, d0_, fixed_ = _c3_fixed()
-    P_sh = -(-d0_ // 32) * 32
+    # the shared part as it is (79 tokens), left padded only as far as nq x P needs to be a multiple of 128 (a padded prefix
+    # costs its pad tokens in the prefix pass and, worse, counts toward the key range that decides whether a chunk's attention
+    # fits the LDS-resident kernel: 96 + 201 keys did not, 79 + 201 do)
+    P_sh = d0_
+    while (nq * P_sh) % 128:
+        P_sh += 1
     pre_ids, pre_start = c3_shared_tokens(torch, nq, P_sh, V, dev)
 
     def rerank_fuse(ids):
