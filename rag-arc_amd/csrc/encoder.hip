@@ -586,6 +586,15 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 // pipeline's counted waits widened by exactly the stores in flight (vmcnt counts them, in order).
 //   ACT 0: C = A·Wᵀ (no bias: the reranker LM's projections);  ACT 3: silu(gate)·up over interleaved gate / up columns.
 // ------------------------------------------------------------------------------------------
+#ifdef G256S_TIMELINE   // measurement builds: s_memtime at the start of every k tile of one workgroup's stream (tools/gemm_seam_timeline.py)
+__device__ unsigned long long g_g256s_tl[1024];
+extern "C" int rarc_gemm_debug_timeline(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_g256s_tl), sizeof(unsigned long long) * (size_t)n);
+}
+#define G256S_TL() do { if (tl_on && tl_i < 1024) g_g256s_tl[tl_i++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define G256S_TL() do { } while (0)
+#endif
 constexpr int G256S_EP_STRIDE = 80, G256S_EP_BYTES = 32 * G256S_EP_STRIDE;   // per-wave drain staging: 32 rows x (64 + 16) B
 constexpr int G256S_LDS = 131072 + 8 * G256S_EP_BYTES;
 template <int ACT>
@@ -749,12 +758,17 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t*
   // ONE loop over the workgroup's stream of k tiles; what varies at the seams (where the look-ahead's operands come from,
   // whether a drain runs, how many stores sit in the wait's window) is wave-uniform run-time state, not code variants
   // (seven instantiations of the four phases spilled the accumulators: the allocator lost track of 128 live registers).
+#ifdef G256S_TIMELINE
+  const bool tl_on = blockIdx.x == 100 && threadIdx.x == 0;
+  int tl_i = 0;
+#endif
   for (int kt = 0;;) {
     // the interior k tiles of an output tile (2 .. KT-3): operands of this tile, no drain, no stores in any window — the
     // loop of the kernel with a seam, with nothing decided at run time (with the seam logic in every phase a k tile took
     // 1.95 us instead of 1.51: ~160 cycles of scalar selects and branches per load slot, and the load slots are the
     // critical path of the ping-pong)
     for (; kt >= 2 && kt + 2 < KT; ++kt) {
+      G256S_TL();
       G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)
       stage(np, 1, Ab, Wb, kt + 1);
       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -785,6 +799,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t*
       par ^= 1; np ^= 1;
     }
     // ---- a k tile at a seam: 0, 1, KT-2 or KT-1 ----
+    G256S_TL();
     const int k1 = kt + 1, k2 = kt + 2;
     const bool in1 = k1 < KT, in2 = k2 < KT;
     const half_t* s1A = in1 ? Ab : nAb;
@@ -796,18 +811,24 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t*
     const bool ending = !has_next && kt + 2 >= KT;                    // the last two k tiles of the stream
     const bool drain_b = kt == 0 && !first, drain_a = kt == KT - 1;
     // stores in the five-slot window at the end of each phase's load slot (see vm_wait)
-    const int w1 = ending ? 3 : (drain_b ? 2 : (kt == 1 && !first ? 1 : 0));
-    const int w2 = ending ? 3 : (drain_b ? 2 : 0);
-    const int w3 = ending ? 3 : (drain_b ? 2 : (drain_a ? 1 : 0));
-    const int w4 = ending ? 3 : (drain_b ? 1 : (drain_a ? 1 : 0));
+    // (a drain in the tail of phase p's matrix slot precedes the DMA of phase p + 1's load slot: it belongs to that slot.
+    //  Drain slots of a tile: phase 4 of its last k tile and phase 2 of the next tile's first k tile.)
+    const bool after1 = kt == 1 && !first;
+    const int w1 = ending ? 3 : (drain_b ? 1 : (after1 ? 1 : 0));
+    const int w2 = ending ? 3 : (drain_b ? 2 : (after1 ? 1 : 0));
+    const int w3 = ending ? 3 : (drain_b ? 2 : 0);
+    const int w4 = ending ? 3 : (drain_b ? 2 : (drain_a ? 1 : 0));
     // ---- phase 1: quadrant A0 x B0 ----
-    if (drain_b) { G256S_DRAIN(1, 1, ptm, ptn) G256S_DRAIN(1, 0, ptm, ptn) }
     G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)
     if (st1) stage(np, 1, s1A, s1W, s1k);
     vm_wait(w1);
     G256_WAIT();
     G256_BAR();
     G256_MMA(0, 0, fb0);
+    // the second drain of the previous output tile, in the TAIL of this matrix slot: the wave has issued its eight MFMAs and
+    // would wait ~200 cycles at the barrier for the other group's load slot anyway (s_memtime per k tile: a load slot is
+    // ~460 cycles, a matrix slot ~256; in a load slot the same work extended the phase by its full length)
+    if (drain_b) { G256S_DRAIN(1, 1, ptm, ptn) G256S_DRAIN(1, 0, ptm, ptn) }
     G256_BAR();
     // ---- phase 2: A0 x B1 ----
     G256_LOAD_B(par, 1, fb1)
@@ -817,14 +838,14 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t*
     G256_BAR();
     G256_MMA(0, 1, fb1);
     G256_BAR();
-    // ---- phase 3: A1 x B1 (the A fragment registers are dead at its start: the first drain's place) ----
-    if (drain_a) { G256S_DRAIN(0, 0, tm, tn) G256S_DRAIN(0, 1, tm, tn) }
+    // ---- phase 3: A1 x B1; in its matrix slot's tail the first drain (quadrants A0B0, A0B1 are final) ----
     G256_LOAD_A(par, 1)
     if (st2) stage(par, 2, s2A, s2W, s2k);
     vm_wait(w3);
     G256_WAIT();
     G256_BAR();
     G256_MMA(1, 1, fb1);
+    if (drain_a) { G256S_DRAIN(0, 0, tm, tn) G256S_DRAIN(0, 1, tm, tn) }
     G256_BAR();
     // ---- phase 4: A1 x B0 (no LDS reads) ----
     if (st2) stage(par, 3, s2A, s2W, s2k);
