@@ -69,6 +69,55 @@ def test_random_reranker_lm_geometry(oracle, seed):
     assert np.all(np.isfinite(got)) and err <= 3e-2, (H, layers, nq, nkv, dh, inter, n, L, err)
 
 
+@pytest.mark.parametrize("seed", range(_FIRST, _LAST))
+def test_random_prefixed_batches_resident_equals_streaming(oracle, monkeypatch, seed):
+    """Random decoder geometry, random left padding, a random shared prefix (or none): the LDS-resident attention kernel and the
+    streaming one (RARC_LM_ATTN=stream) must return the same bits — and finite ones."""
+    import torch
+
+    from rag_arc_amd.core.rerank import HipCausalLM
+
+    rng = np.random.default_rng(5000 + seed)
+    dh = int(rng.choice([64, 128]))
+    nq, nkv = [(2, 1), (2, 2), (4, 2), (4, 4), (6, 2), (8, 2), (8, 8), (3, 1), (16, 8)][int(rng.integers(0, 9))]
+    if ((nq + 2 * nkv) * dh) % 128 or (nq * dh) % 64:
+        nq, nkv = 4, 2
+    H, inter = int(rng.choice([128, 256])), int(rng.choice([128, 256]))
+    layers = int(rng.integers(1, 3))
+    P = int(rng.choice([0, 0, 16, 40, 64, 79, 96]))
+    key_cap = 288 if dh == 128 else 544
+    L = int(rng.integers(4, max(5, key_cap - P - 8)))
+    n = int(rng.integers(1, 6)) * (128 // np.gcd(L, 128))          # n * L a multiple of 128
+    if n * L > 40_000:
+        n = 128 // np.gcd(L, 128)
+    V = 300
+    sd = oracle.random_qwen3_state_dict(H, layers, nq, nkv, dh, inter, vocab=V, seed=seed)
+    lm = HipCausalLM(sd, nq, nkv, dh, rms_norm_eps=1e-6, rope_theta=1e6)
+    dev = lm.device
+    ids = rng.integers(5, V, (n, L)).astype(np.int32)
+    start = rng.integers(0, L, n).astype(np.int32)
+    start[0] = 0
+    for r in range(n):
+        ids[r, :start[r]] = 0
+    kw = {}
+    if P:
+        npre = 128 // np.gcd(P, 128)
+        pre = rng.integers(5, V, (npre, P)).astype(np.int32)
+        pstart = rng.integers(0, P, npre).astype(np.int32)
+        pstart[0] = 0
+        for i in range(npre):
+            pre[i, :pstart[i]] = 0
+        handle = lm.prefix_kv_device(torch.from_numpy(pre).to(dev), torch.from_numpy(pstart).to(dev))
+        kw = dict(prefix=handle, prefix_of=torch.from_numpy(rng.integers(-1, npre, n).astype(np.int32)).to(dev))
+    run = lambda: lm.yes_no_logits_device(torch.from_numpy(ids).to(dev), torch.from_numpy(start).to(dev), 7, 9, **kw).cpu()
+    monkeypatch.delenv("RARC_LM_ATTN", raising=False)
+    a = run()
+    monkeypatch.setenv("RARC_LM_ATTN", "stream")
+    b = run()
+    assert torch.isfinite(a.float()).all(), (dh, nq, nkv, H, layers, P, L, n)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16)), (dh, nq, nkv, H, layers, P, L, n)
+
+
 def test_pool_threads_share_one_index(oracle):
     """Callers may be pool threads (core/retrieval/base.py:92-96: a new ThreadPoolExecutor per ainvoke): eight threads
     search one index and one fp8 index at once, every answer equals the serial one."""
