@@ -1869,6 +1869,23 @@ int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, 
   return enc_gemm_impl(a, w, nullptr, (uint16_t*)c, m, n, k, 4, (void*)s);
 }
 
+// The same product as up to `max_parts` fp32 PARTIAL slabs c[part][M][N] (k cut into equal slices; *parts = how many, the
+// caller's epilogue sums them in order).  Small batches only: with at most one output tile per CU (a single query is 128
+// tokens: 8 tiles of an N = 1024 projection) a tile's whole contraction — K' = 3K, 192 k tiles for the FFN's second
+// projection — runs on one CU while 200 others idle; cut four ways it is a quarter as long.  Shapes that fill the chip
+// keep one slab (the 256-row kernels).
+int rarc_gemm_f16_f32out_parts(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, int max_parts, int* parts,
+                               hipStream_t s) {
+  static const bool no_split = getenv("RARC_GEMM32_SPLIT") && atoi(getenv("RARC_GEMM32_SPLIT")) == 0;
+  const int tiles = (m / GM) * (n / GN);
+  int S = 1;
+  if (!no_split && !(m % 256 == 0 && (m / 256) * (n / GN) >= 256))
+    while (2 * S <= max_parts && 2 * S <= 8 && tiles * S * 2 <= 256 && k % (S * 2 * GK) == 0 && k / (S * 2) >= 8 * GK) S *= 2;
+  *parts = S;
+  if (S == 1) return rarc_gemm_f16_f32out(a, w, c, m, n, k, s);
+  return enc_gemm_splitk(a, w, c, m, n, k, S, s);
+}
+
 extern "C" int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,
                                  const uint16_t* d_type0, const uint16_t* d_gamma, const uint16_t* d_beta, float eps,
                                  int n_tokens, int seq_len, int hidden, int vocab, uint16_t* d_out, void* stream) {

@@ -17,6 +17,8 @@
 #include "rarc_common.h"
 
 int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s);  // encoder.hip
+int rarc_gemm_f16_f32out_parts(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, int max_parts, int* parts,
+                               hipStream_t s);   // encoder.hip: up to max_parts fp32 partial slabs c[part][m][n] (small batches)
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const
                                                            const float* resid, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int n,
                                                            float* out32, half_t* __restrict__ out3,
-                                                           float* __restrict__ ra_out) {
+                                                           float* __restrict__ ra_out, int n_parts, size_t part_stride) {
   __shared__ float slot[12];
   const size_t m = blockIdx.x;
   E32Row<NV> r;
@@ -151,6 +153,10 @@ __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const
     const int c = (threadIdx.x + 256 * i) * 4;
     if (c < n) {
       float4 p = *(const float4*)(P + m * n + c);
+      for (int sp = 1; sp < n_parts; ++sp) {   // split-K partial slabs of a small batch's GEMM, summed in order
+        const float4 q = *(const float4*)(P + sp * part_stride + m * n + c);
+        p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
+      }
       if (MODE != 3) {
         const float4 w = *(const float4*)(rw + c), b = *(const float4*)(bias + c);
         // ra, rw are powers of two: the two scalings are exact, the bias add rounds once (as in x·Wᵀ + b)
@@ -402,14 +408,16 @@ __global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 template <int MODE>
 static int e32_epi(const float* P, const float* ra, const float* rw, const float* bias, const float* resid, const float* gamma,
-                   const float* beta, float eps, int m, int n, float* out32, uint16_t* out3, float* ra_out, hipStream_t s) {
+                   const float* beta, float eps, int m, int n, float* out32, uint16_t* out3, float* ra_out, hipStream_t s,
+                   int n_parts = 1) {
+  const size_t part_stride = (size_t)m * n;
   RARC_REQUIRE(n % 4 == 0 && n <= 4096, RARC_E_UNSUPPORTED, "fp32-class encoder: row length %d (need a multiple of 4, <= 4096)", n);
   if (n <= 1024)
     hipLaunchKernelGGL((rarc_e32_epi_kernel<1, MODE>), dim3(m), dim3(256), 0, s, P, ra, rw, bias, resid, gamma, beta, eps, n,
-                       out32, (half_t*)out3, ra_out);
+                       out32, (half_t*)out3, ra_out, n_parts, part_stride);
   else
     hipLaunchKernelGGL((rarc_e32_epi_kernel<4, MODE>), dim3(m), dim3(256), 0, s, P, ra, rw, bias, resid, gamma, beta, eps, n,
-                       out32, (half_t*)out3, ra_out);
+                       out32, (half_t*)out3, ra_out, n_parts, part_stride);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -444,7 +452,7 @@ extern "C" size_t rarc_enc32_workspace_bytes(int hidden, int inter, int n_tokens
   return 2 * e32_align(M * H * 4)      // x (residual stream), ctx
          + e32_align(M * 3 * H * 2)    // split image of x / ctx
          + e32_align(M * 3 * I * 2)    // split image of the GELU output
-         + e32_align(M * wide * 4)     // raw GEMM products
+         + e32_align(M * wide * 4 * (M <= 2048 ? 4 : 1))   // raw GEMM products (small batches: up to four split-K partial slabs)
          + 2 * e32_align(M * 4);       // row scales
 }
 
@@ -475,7 +483,8 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   float* ctx = (float*)w;               w += e32_align((size_t)M * H * 4);
   uint16_t* xs = (uint16_t*)w;          w += e32_align((size_t)M * 3 * H * 2);
   uint16_t* mids = (uint16_t*)w;        w += e32_align((size_t)M * 3 * I * 2);
-  float* P = (float*)w;                 w += e32_align((size_t)M * wide * 4);
+  const int p_slabs = M <= 2048 ? 4 : 1;                    // [M][wide] slabs the product buffer holds
+  float* P = (float*)w;                 w += e32_align((size_t)M * wide * 4 * p_slabs);
   float* ra_a = (float*)w;              w += e32_align((size_t)M * 4);
   float* ra_b = (float*)w;
   const float eps = model->ln_eps;
@@ -485,6 +494,8 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   RARC_HIP_CHECK(hipGetLastError());
   const int q_blocks = (seq_len + 31) / 32;
   const int n_units = n_seq * model->heads * q_blocks;  // one wave each, four per workgroup
+  const int max_parts = (int)(p_slabs * wide / (size_t)H);   // partial slabs of an [M][H] product that fit the buffer P
+  const int max_parts_i = (int)(p_slabs * wide / (size_t)I);  // ... of an [M][I] product
   int rc = RARC_OK;
   for (int l = 0; l < model->n_layers; ++l) {
     const RarcEnc32Layer& Ly = model->layers[l];
@@ -502,13 +513,14 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     RARC_HIP_CHECK(hipGetLastError());
     if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs))) return rc;
     // attention output projection -> x = LayerNorm(proj + x)
-    if ((rc = rarc_gemm_f16_f32out(xs, Ly.o_w3, P, M, H, 3 * H, hs)) != RARC_OK) return rc;
-    if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs))) return rc;
+    int parts = 1;   // (small batches: the N = hidden projections run split-K into partial slabs the LayerNorm epilogue sums)
+    if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.o_w3, P, M, H, 3 * H, max_parts, &parts, hs)) != RARC_OK) return rc;
+    if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs, parts))) return rc;
     // FFN
-    if ((rc = rarc_gemm_f16_f32out(xs, Ly.f1_w3, P, M, I, 3 * H, hs)) != RARC_OK) return rc;
-    if ((rc = e32_epi<1>(P, ra_a, Ly.f1_rw, Ly.f1_b, nullptr, nullptr, nullptr, 0.f, M, I, nullptr, mids, ra_b, hs))) return rc;
-    if ((rc = rarc_gemm_f16_f32out(mids, Ly.f2_w3, P, M, H, 3 * I, hs)) != RARC_OK) return rc;
-    if ((rc = e32_epi<2>(P, ra_b, Ly.f2_rw, Ly.f2_b, x, Ly.ln2_g, Ly.ln2_b, eps, M, H, x, xs, ra_a, hs))) return rc;
+    if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.f1_w3, P, M, I, 3 * H, max_parts_i, &parts, hs)) != RARC_OK) return rc;
+    if ((rc = e32_epi<1>(P, ra_a, Ly.f1_rw, Ly.f1_b, nullptr, nullptr, nullptr, 0.f, M, I, nullptr, mids, ra_b, hs, parts))) return rc;
+    if ((rc = rarc_gemm_f16_f32out_parts(mids, Ly.f2_w3, P, M, H, 3 * I, max_parts, &parts, hs)) != RARC_OK) return rc;
+    if ((rc = e32_epi<2>(P, ra_b, Ly.f2_rw, Ly.f2_b, x, Ly.ln2_g, Ly.ln2_b, eps, M, H, x, xs, ra_a, hs, parts))) return rc;
   }
   hipLaunchKernelGGL(rarc_e32_pool_kernel, dim3(n_seq), dim3(256), 0, hs, x, d_lens, seq_len, H, (normalize & 2) ? 1 : 0,
                      normalize & 1, d_out);
