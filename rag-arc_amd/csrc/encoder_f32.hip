@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
                                                                  const float* __restrict__ rw, const float* __restrict__ bias,
                                                                  const int32_t* __restrict__ lens, int L, int H, int n_heads,
                                                                  int q_blocks, int n_units, float* __restrict__ ctx,
-                                                                 const float* __restrict__ rel, int rel_span) {
+                                                                 const float* __restrict__ rel, int rel_span, int n_parts,
+                                                                 size_t part_stride) {
   constexpr int HD = DH / 2;     // floats of a q / k row one lane half contracts
   constexpr int MB = DH / 32;    // 32-row blocks of O^T
   constexpr int VS = DH + 8;     // row stride of the V tile in LDS (floats)
@@ -283,7 +284,12 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
     const float* w = sb + part * 2 * DH + hh * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-      const float4 p = *(const float4*)(src + c), s4 = *(const float4*)(w + c), b4 = *(const float4*)(w + DH + c);
+      float4 p = *(const float4*)(src + c);
+      for (int sp = 1; sp < n_parts; ++sp) {   // split-K partial slabs of a small batch's q|k|v product, summed in order
+        const float4 q4 = *(const float4*)(src + sp * part_stride + c);
+        p.x += q4.x; p.y += q4.y; p.z += q4.z; p.w += q4.w;
+      }
+      const float4 s4 = *(const float4*)(w + c), b4 = *(const float4*)(w + DH + c);
       dst[c] = p.x * r * s4.x + b4.x; dst[c + 1] = p.y * r * s4.y + b4.y;
       dst[c + 2] = p.z * r * s4.z + b4.z; dst[c + 3] = p.w * r * s4.w + b4.w;
     }
@@ -311,7 +317,11 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
       const int kr = i / (DH / 4), c4 = i % (DH / 4);
       const int vrow = (k0 + kr < L) ? k0 + kr : L - 1;
       const float r = ra[tok0 + vrow];
-      const float4 p = *(const float4*)(P + (tok0 + vrow) * rs + 2 * H + hd * DH + 4 * c4);
+      float4 p = *(const float4*)(P + (tok0 + vrow) * rs + 2 * H + hd * DH + 4 * c4);
+      for (int sp = 1; sp < n_parts; ++sp) {
+        const float4 q4 = *(const float4*)(P + sp * part_stride + (tok0 + vrow) * rs + 2 * H + hd * DH + 4 * c4);
+        p.x += q4.x; p.y += q4.y; p.z += q4.z; p.w += q4.w;
+      }
       const float4 s4 = *(const float4*)(sb + 4 * DH + 4 * c4), b4 = *(const float4*)(sb + 5 * DH + 4 * c4);
       *(float4*)(vs + kr * VS + 4 * c4) =
           make_float4(p.x * r * s4.x + b4.x, p.y * r * s4.y + b4.y, p.z * r * s4.z + b4.z, p.w * r * s4.w + b4.w);
@@ -496,14 +506,18 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   const int n_units = n_seq * model->heads * q_blocks;  // one wave each, four per workgroup
   const int max_parts = (int)(p_slabs * wide / (size_t)H);   // partial slabs of an [M][H] product that fit the buffer P
   const int max_parts_i = (int)(p_slabs * wide / (size_t)I);  // ... of an [M][I] product
+  const int max_parts_qkv = (int)(p_slabs * wide / (size_t)(3 * H));   // ... of the [M][3H] q|k|v product
   int rc = RARC_OK;
   for (int l = 0; l < model->n_layers; ++l) {
     const RarcEnc32Layer& Ly = model->layers[l];
     // fused q|k|v projection; its scales and bias are applied by the attention kernel's loads
-    if ((rc = rarc_gemm_f16_f32out(xs, Ly.qkv_w3, P, M, 3 * H, 3 * H, hs)) != RARC_OK) return rc;
+    int parts = 1;   // (small batches: split-K into partial slabs that the consumer — attention loads, epilogue kernels — sums)
+    if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.qkv_w3, P, M, 3 * H, 3 * H, max_parts_qkv, &parts, hs)) != RARC_OK) return rc;
+    const int qkv_parts = parts;
 #define E32_ATTN_LAUNCH(DHV, RELV)                                                                                     \
     hipLaunchKernelGGL((rarc_e32_attention_kernel<DHV, RELV>), dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw, \
-                       Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx, model->rel_bias, model->rel_span)
+                       Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx, model->rel_bias, model->rel_span,     \
+                       qkv_parts, (size_t)M * 3 * H)
     if (H == model->heads * 64) {
       if (model->rel_bias) E32_ATTN_LAUNCH(64, true); else E32_ATTN_LAUNCH(64, false);
     } else {
@@ -513,7 +527,6 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     RARC_HIP_CHECK(hipGetLastError());
     if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs))) return rc;
     // attention output projection -> x = LayerNorm(proj + x)
-    int parts = 1;   // (small batches: the N = hidden projections run split-K into partial slabs the LayerNorm epilogue sums)
     if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.o_w3, P, M, H, 3 * H, max_parts, &parts, hs)) != RARC_OK) return rc;
     if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs, parts))) return rc;
     // FFN
