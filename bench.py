@@ -711,7 +711,8 @@ def leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, dense_ids, n2, a, steps, wa
                              "tokens_through_the_lm_per_step": int(real_tokens), "padded_tokens_per_step": int(stats["padded_tokens"]),
                              "chunk_pairs": CH, "note": "template token counts are word-count estimates (Qwen's vocabulary does not ship offline)"},
            "fused_entries_per_query": int(fn.min().item()),
-           "roofline": {"bound": "mfma", "kernel": "rarc_gemm256_f16_kernel / rarc_gemm256x128_f16_kernel (LM projections), rarc_lm_attention_kernel<128>",
+           "roofline": {"bound": "mfma", "kernel": "rarc_gemm256_f16_kernel<16 | 19 | 96> (LM projections with RMSNorm folded in: row scale, row scale + SwiGLU, "
+                                                        "residual add + sums of squares), rarc_lm_attention_resident_kernel<128, NP>",
                         "achieved": round(flops / (lm_ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(flops / (lm_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4), "flops_per_step": flops,
                         "flops_per_step_without_prefix_sharing": flops_unshared,
