@@ -386,36 +386,37 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   // in registers for phase 4).  Restaging, one half per phase, each buffer one or two phases after its last read:
   //   phase 1: A1 of tile t+1 (other parity; its buffer was read in phase 3 of tile t-1)
   //   phase 2: A0 of tile t+2, phase 3: B0 of t+2, phase 4: B1 of t+2 (this parity)
-  // -> every half is staged >= 6 phases before its first read, 5-6 stages (80-96 KiB) are in flight, and the
-  // wait at the end of L(p) lets the five newest stages (10 DMA instructions of this wave) stay outstanding.
+  // -> every half is staged >= 6 phases before its first read, 4-5 stages (64-80 KiB) are in flight, and the
+  // wait at the end of L(p) lets the four newest stages (8 DMA instructions of this wave) stay outstanding (round 3: the
+  // DMA of phase p is issued in the tail of M(p), see below; it was issued in L(p) with five stages behind the wait).
 #define G256_TILE(ST1, ST234, VM1, VM2, VM3, VM4)                                                       \
   {                                                                                                     \
     /* phase 1: quadrant A0 x B0 */                                                                     \
     G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)                                                        \
-    if (ST1) stage(np, 1, kt + 1);                                                                      \
     G256_WAIT(VM1);                                                                                     \
     G256_BAR();                                                                                         \
     G256_MMA(0, 0, fb0);                                                                                \
+    if (ST1) stage(np, 1, kt + 1);                                                                      \
     G256_BAR();                                                                                         \
     /* phase 2: A0 x B1 */                                                                              \
     G256_LOAD_B(par, 1, fb1)                                                                            \
-    if (ST234) stage(par, 0, kt + 2);                                                                   \
     G256_WAIT(VM2);                                                                                     \
     G256_BAR();                                                                                         \
     G256_MMA(0, 1, fb1);                                                                                \
+    if (ST234) stage(par, 0, kt + 2);                                                                   \
     G256_BAR();                                                                                         \
     /* phase 3: A1 x B1 */                                                                              \
     G256_LOAD_A(par, 1)                                                                                 \
-    if (ST234) stage(par, 2, kt + 2);                                                                   \
     G256_WAIT(VM3);                                                                                     \
     G256_BAR();                                                                                         \
     G256_MMA(1, 1, fb1);                                                                                \
+    if (ST234) stage(par, 2, kt + 2);                                                                   \
     G256_BAR();                                                                                         \
     /* phase 4: A1 x B0 (no LDS reads) */                                                               \
-    if (ST234) stage(par, 3, kt + 2);                                                                   \
     G256_WAIT(VM4);                                                                                     \
     G256_BAR();                                                                                         \
     G256_MMA(1, 0, fb0);                                                                                \
+    if (ST234) stage(par, 3, kt + 2);                                                                   \
     G256_BAR();                                                                                         \
   }
 
@@ -430,13 +431,18 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   G256_BAR();
   if (wr == 1) G256_BAR();  // waves 4-7 run one slot behind
   int kt = 0;
+  // Round 3: a phase's operand DMA is issued in the TAIL of its matrix slot (after the eight MFMAs), not next to the fragment
+  // reads of its load slot: s_memtime per k tile 2864 -> 2738 cycles (the price of an LDS-DMA instruction depends on what the
+  // CU's LDS / vector-memory queues are doing when it issues).  The wait at the end of a load slot therefore sees one stage
+  // fewer issued: all but the FOUR newest stages (8 instructions) must have landed — reads of phase p + 1 need the stages
+  // of phases <= p - 5, exactly those.
   for (; kt + 2 < KT; ++kt) {
     const int par = kt & 1, np = par ^ 1;
-    G256_TILE(true, true, 10, 10, 10, 10)
+    G256_TILE(true, true, 8, 8, 8, 8)
   }
   if (kt + 1 < KT) {  // second-to-last tile: only the last tile's A1 is still to stage; the waits shrink with the queue
     const int par = kt & 1, np = par ^ 1;
-    G256_TILE(true, false, 10, 8, 6, 4)
+    G256_TILE(true, false, 8, 8, 6, 4)
     ++kt;
   }
   // RS (ACT | 16): the four row scales of this lane's rows are fetched before the last k tile, so that their round trip
@@ -769,6 +775,35 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t*
     // critical path of the ping-pong)
     for (; kt >= 2 && kt + 2 < KT; ++kt) {
       G256S_TL();
+#ifdef G256S_STAGE_IN_M   // experiment: the operand DMA issued in the tail of the matrix slot instead of next to the fragment reads
+      G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(0, 0, fb0);
+      stage(np, 1, Ab, Wb, kt + 1);
+      G256_BAR();
+      G256_LOAD_B(par, 1, fb1)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(0, 1, fb1);
+      stage(par, 0, Ab, Wb, kt + 2);
+      G256_BAR();
+      G256_LOAD_A(par, 1)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(1, 1, fb1);
+      stage(par, 2, Ab, Wb, kt + 2);
+      G256_BAR();
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      G256_WAIT();
+      G256_BAR();
+      G256_MMA(1, 0, fb0);
+      stage(par, 3, Ab, Wb, kt + 2);
+      G256_BAR();
+#else
       G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)
       stage(np, 1, Ab, Wb, kt + 1);
       asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -796,6 +831,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t*
       G256_BAR();
       G256_MMA(1, 0, fb0);
       G256_BAR();
+#endif
       par ^= 1; np ^= 1;
     }
     // ---- a k tile at a seam: 0, 1, KT-2 or KT-1 ----
