@@ -1764,7 +1764,7 @@ bool rarc_gemm_norm_fusable(int m, int n, int k) {
 // zero_bias: the caller guarantees d_bias holds zeros (the reranker LM's projections) — the seamless 256 x 256 kernel, which
 // has no bias path, may take the large shapes
 static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_bias, uint16_t* d_c, int m, int n, int k,
-                         int act, void* stream, bool zero_bias = false, float* d_ssq = nullptr) {
+                         int act, void* stream, bool zero_bias = false, float* d_ssq = nullptr, bool is_tail = false) {
   hipStream_t s = (hipStream_t)stream;
   const half_t *a = (const half_t*)d_a, *w = (const half_t*)d_w, *bs = (const half_t*)d_bias;
   half_t* c = (half_t*)d_c;
@@ -1798,8 +1798,10 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       while (lcm % 256) lcm += tiles_n;
       const int full = t256 / lcm * lcm, rem = t256 - full;
       int m_main = m;
-      if (cut_tail && persist && full > 0 && rem > 0 && 4 * rem <= 256 &&
-          ((act & 15) != 3 || rarc_gemm_swiglu_fused(m - full / tiles_n * 256, n, k)))
+      // (round 3: up to HALF a round is cut off — between a quarter and a half round the tail runs as ONE round of 256 x 128
+      //  tiles, 2 rem <= 256 workgroups, about two thirds of a 256 x 256 round; that kernel has every epilogue)
+      if (cut_tail && persist && full > 0 && rem > 0 && 2 * rem <= 256 &&
+          (4 * rem <= 256 ? ((act & 15) != 3 || rarc_gemm_swiglu_fused(m - full / tiles_n * 256, n, k)) : k >= 3 * GK))
         m_main = full / tiles_n * 256;
       const int t_main = (m_main / 256) * tiles_n;
       const int g256 = persist && t_main > 256 ? 256 : t_main;
@@ -1825,10 +1827,10 @@ static int enc_gemm_impl(const uint16_t* d_a, const uint16_t* d_w, const uint16_
       if (m_main < m)   // (d_c counts 2-byte elements: an fp32 row is 2n of them)
         return enc_gemm_impl(d_a + (size_t)m_main * k, d_w, (act & 16) ? d_bias + (size_t)2 * m_main : d_bias,   // (RS: `bias` is float rowscale[M])
                              d_c + (size_t)m_main * ((act & 15) == 3 ? n / 2 : (act == 4 ? 2 * n : n)), m - m_main, n, k, act, stream, zero_bias,
-                             d_ssq ? d_ssq + (size_t)m_main * (n / 32) : nullptr);
+                             d_ssq ? d_ssq + (size_t)m_main * (n / 32) : nullptr, true);
       return RARC_OK;
     }
-    if (t128 >= 256 && k >= 3 * GK) {
+    if ((t128 >= 256 || (is_tail && t128 > 128)) && k >= 3 * GK) {
       if (act == 4) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<4>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 3) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<3>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);
       else if (act == 1) hipLaunchKernelGGL((rarc_gemm256x128_f16_kernel<1>), dim3(t128), dim3(512), G128_LDS, s, a, w, bs, c, m, n, k, order);

@@ -193,6 +193,9 @@ def test_gemm_kernel_alone(oracle):
     (256 * 3, 256 * 100, 256, 0),  # N >> M: 300 tiles, 8-deep row groups of a 3-row tile grid (partial group only)
     (256 * 70, 256 * 4, 320, 1),   # 280 tiles = one round + 24: the short tail (6 tile rows) is cut off and runs as its own GEMM
     (256 * 200, 256 * 4, 128, 0),  # the reranker LM's projection shape: 800 tiles = 3 rounds + 32
+    (256 * 88, 256 * 4, 256, 1),   # 352 tiles = one round + 96: between a quarter and half a round -> the tail runs as one
+                                   # round of 256 x 128 tiles (192 workgroups), GELU
+    (256 * 80, 256 * 8, 192, 0),   # 640 tiles = two rounds + 128: exactly half a round cut off (256 workgroups of 256 x 128)
 ])
 def test_gemm_large_tile_kernels(oracle, M, N, K, act):
     """Every large-shape GEMM path against a float64 product on a transposition-detecting operand pair

@@ -359,7 +359,8 @@ def test_qwen3_reranker_registry_with_byte_level_bpe_files(oracle, tmp_path):
 
 
 @pytest.mark.parametrize("m,n,k", [(2048, 4096, 256), (4096, 4096, 128), (8192, 6144, 192), (256, 32768, 64 * 3),
-                                   (256 * 134, 1024, 128)])   # 536 tiles: a short last round that must NOT be cut off (its rows alone could not run the fused epilogue)
+                                   (256 * 134, 1024, 128),    # 536 tiles: a short last round that must NOT be cut off (its rows alone could not run the fused epilogue)
+                                   (256 * 80, 2048, 256)])    # 640 tiles = two rounds + 128: half a round cut off, SwiGLU on the 256 x 128 kernel
 def test_swiglu_epilogue_equals_gemm_then_swiglu(m, n, k):
     """rarc_enc_gemm act = 3 (gate / up columns interleaved in groups of 8 -> silu(gate)·up, [m][n/2]) against the
     plain GEMM's own output put through the same roundings on the host side: fp16 GEMM output, fp16 silu, fp16 product.
