@@ -11,8 +11,12 @@
 //     triple buffered, every DMA instruction covering 8 rows × one full 128-B line.
 //     The LDS image is XOR-swizzled on the SOURCE side so that the MFMA A-fragment
 //     ds_read_b128 of every 16-lane group hits 16 distinct 16-B slots (conflict free).
-//   * per tile each wave issues D/16 × v_mfma_f32_32x32x16_f16 (A = 32 corpus rows from LDS,
-//     B = its resident query fragments): lane l ends with 16 scores of query (l & 31).
+//   * per tile each wave issues D/32 × 4 v_mfma_f32_16x16x32_f16 on four accumulators (A = 16 corpus rows
+//     from LDS, B = 16 of its resident queries): lane l ends with 2 x 4 scores of each of the queries
+//     (l & 15) and 16 + (l & 15).  (SCAN_MMA16=0 builds the first form: D/16 chained 32x32x16 on one
+//     accumulator, which issue every ~51 cycles whenever the SIMD's other wave is outside its own chain;
+//     measured 0.370 -> 0.364 ms per 1M x 768 scan in steady state — the board sits at its power limit with
+//     the shader clock near 1.4 GHz under this kernel, so matrix-pipe bubbles removed come back as clock.)
 //   * epilogue: one max + compare against the lane's query threshold.  Survivors (≈1 per
 //     wave-tile) take a slot in the workgroup's private segment of that query's candidate list
 //     (slot counter in LDS — no returning global atomic, nothing to wait for) and bump the
@@ -50,6 +54,11 @@ constexpr int SCAN_WAVES = 8;
 // refill the slot with fragment S+R.  Every asm statement names the registers it touches, so the
 // order between steps is fixed by data flow; immediates come from template parameters.
 constexpr int SCAN_RING = 6;
+#ifdef SCAN_HALFREAD
+constexpr int SCAN_LGK = SCAN_RING / 2 - 1;
+#else
+constexpr int SCAN_LGK = SCAN_RING - 1;
+#endif
 #ifndef SCAN_DMA_B_INLOOP
 #define SCAN_DMA_B_INLOOP 0  // group B's pieces: 0 = all right after the barrier, 1 = spread through its MFMA chain too
 #endif
@@ -67,17 +76,23 @@ struct ScanSteps {
                                              int a2, int a3, Dma& dma) {
     constexpr int slot = S % R;
     if constexpr (S % SCAN_DMA_EVERY == 1 && S / SCAN_DMA_EVERY < KS / 8) dma(S / SCAN_DMA_EVERY);
+#ifdef SCAN_HALFREAD  // timing experiment (wrong results): every second A fragment is not read, its MFMA reuses the neighbour's
+    if constexpr (S + R < KS && ((S + R) & 1)) {
+      if constexpr (S == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(rg[slot ^ 1]), "v"(qf[S]));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(rg[slot ^ 1]), "v"(qf[S]));
+    } else
+#endif
     if constexpr (S + R < KS) {
       constexpr int S2 = S + R;  // fragment that refills this slot
       const int addr = (S2 & 3) == 0 ? a0 : (S2 & 3) == 1 ? a1 : (S2 & 3) == 2 ? a2 : a3;
       if constexpr (S == 0)
         asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\t"
                      "ds_read_b128 %1, %3 offset:%4"
-                     : "=&v"(acc), "+v"(rg[slot]) : "v"(qf[S]), "v"(addr), "n"((S2 >> 2) * 4096), "n"(R - 1));
+                     : "=&v"(acc), "+v"(rg[slot]) : "v"(qf[S]), "v"(addr), "n"((S2 >> 2) * 4096), "n"(SCAN_LGK));
       else
         asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\t"
                      "ds_read_b128 %1, %3 offset:%4"
-                     : "+v"(acc), "+v"(rg[slot]) : "v"(qf[S]), "v"(addr), "n"((S2 >> 2) * 4096), "n"(R - 1));
+                     : "+v"(acc), "+v"(rg[slot]) : "v"(qf[S]), "v"(addr), "n"((S2 >> 2) * 4096), "n"(SCAN_LGK));
     } else if constexpr (S == 0) {
       asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0"
                    : "=&v"(acc) : "v"(rg[slot]), "v"(qf[S]), "n"(KS - 1 - S));
@@ -98,6 +113,71 @@ struct ScanPrologue {
 };
 // MFMA result -> VALU read needs software wait states when the producer is inside asm
 #define RARC_MFMA_DRAIN(acc) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc))
+// ---- the same tile with v_mfma_f32_16x16x32_f16: 2 x 2 blocks of 16 rows x 16 queries per wave (SCAN_MMA16) ----
+// A chain of MFMAs on ONE accumulator with the ring's s_waitcnt / ds_read between them issues every ~51 cycles while the
+// SIMD's other wave is outside its own chain (s_memtime timeline of tools/scan_bench: that is ~40 % of a tile period);
+// four accumulators taken in turn never wait for each other.  Step S covers K = 32: the fragments of rows 0-15 and 16-31
+// (a ring of R steps), four MFMAs, refill.  Same LDS image, same bytes read from LDS, same registers.
+#ifndef SCAN_MMA16
+#define SCAN_MMA16 1
+#endif
+#ifndef SCAN_DMA_OUTSIDE
+#define SCAN_DMA_OUTSIDE 0  // 1: no DMA issue from inside an MFMA chain (measured: 0.3675 vs 0.3636 ms per 1M x 768 scan with it inside)
+#endif
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int SCAN_RING16 = 3;
+template <int S, int KS2, int R>
+struct ScanSteps16 {
+  template <class Dma>
+  static __device__ __forceinline__ void run(f32x4 (&c)[4], half8 (&ra)[R], half8 (&rb)[R], const half8 (&qf)[2 * KS2],
+                                             int ae, int ao, Dma& dma) {
+    constexpr int slot = S % R;
+    if constexpr (S % 4 == 1 && S / 4 < KS2 / 4) dma(S / 4);
+    if constexpr (S + R < KS2) {
+      constexpr int S2 = S + R;  // step that refills this slot
+      const int addr = (S2 & 1) ? ao : ae;
+      if constexpr (S == 0)
+        asm volatile("s_waitcnt lgkmcnt(%11)\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %4, %6, 0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %7, 0\n\t"
+                     "v_mfma_f32_16x16x32_f16 %2, %5, %6, 0\n\tv_mfma_f32_16x16x32_f16 %3, %5, %7, 0\n\t"
+                     "ds_read_b128 %4, %8 offset:%9\n\tds_read_b128 %5, %8 offset:%10"
+                     : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3]), "+v"(ra[slot]), "+v"(rb[slot])
+                     : "v"(qf[2 * S]), "v"(qf[2 * S + 1]), "v"(addr), "n"((S2 >> 1) * 4096), "n"((S2 >> 1) * 4096 + 2048),
+                       "n"(2 * R - 2));
+      else
+        asm volatile("s_waitcnt lgkmcnt(%11)\n\t"
+                     "v_mfma_f32_16x16x32_f16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %7, %1\n\t"
+                     "v_mfma_f32_16x16x32_f16 %2, %5, %6, %2\n\tv_mfma_f32_16x16x32_f16 %3, %5, %7, %3\n\t"
+                     "ds_read_b128 %4, %8 offset:%9\n\tds_read_b128 %5, %8 offset:%10"
+                     : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(ra[slot]), "+v"(rb[slot])
+                     : "v"(qf[2 * S]), "v"(qf[2 * S + 1]), "v"(addr), "n"((S2 >> 1) * 4096), "n"((S2 >> 1) * 4096 + 2048),
+                       "n"(2 * R - 2));
+    } else if constexpr (S == 0) {
+      asm volatile("s_waitcnt lgkmcnt(%8)\n\t"
+                   "v_mfma_f32_16x16x32_f16 %0, %4, %6, 0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %7, 0\n\t"
+                   "v_mfma_f32_16x16x32_f16 %2, %5, %6, 0\n\tv_mfma_f32_16x16x32_f16 %3, %5, %7, 0"
+                   : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                   : "v"(ra[slot]), "v"(rb[slot]), "v"(qf[2 * S]), "v"(qf[2 * S + 1]), "n"(2 * (KS2 - 1 - S)));
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(%8)\n\t"
+                   "v_mfma_f32_16x16x32_f16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_f16 %1, %4, %7, %1\n\t"
+                   "v_mfma_f32_16x16x32_f16 %2, %5, %6, %2\n\tv_mfma_f32_16x16x32_f16 %3, %5, %7, %3"
+                   : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                   : "v"(ra[slot]), "v"(rb[slot]), "v"(qf[2 * S]), "v"(qf[2 * S + 1]), "n"(2 * (KS2 - 1 - S)));
+    }
+    if constexpr (S + 1 < KS2) ScanSteps16<S + 1, KS2, R>::run(c, ra, rb, qf, ae, ao, dma);
+  }
+};
+template <int S, int R>
+struct ScanPrologue16 {
+  static __device__ __forceinline__ void run(half8 (&ra)[R], half8 (&rb)[R], int ae, int ao) {
+    const int addr = (S & 1) ? ao : ae;
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                 : "=&v"(ra[S]), "=&v"(rb[S]) : "v"(addr), "n"((S >> 1) * 4096), "n"((S >> 1) * 4096 + 2048));
+    if constexpr (S + 1 < R) ScanPrologue16<S + 1, R>::run(ra, rb, ae, ao);
+  }
+};
+#define RARC_MFMA_DRAIN4(c) asm volatile("s_nop 15\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]))
 
 // LDS carve (bytes): 3 tile buffers | slot counters [256] | binlo | binscale | bininv | owner landing [256]
 template <int D>
@@ -146,6 +226,21 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     s_bininv[tid] = p.bininv[tid];
   }
 
+#if SCAN_MMA16
+  // resident query fragments (16x16x32 B operands): lane holds Q[q_lo + 16 b][32 s + 8 (lane >> 4) .. +8) in qf[2 s + b]
+  constexpr int KS2 = D / 32;
+  static_assert(KS2 >= SCAN_RING16, "ring deeper than the k-loop");
+  const uint32_t q_lo = wave * 32 + (lane & 15);  // this lane's two queries: q_lo and q_lo + 16
+  half8 qf[2 * KS2];
+  {
+    const half_t* qp = p.q16 + (size_t)q_lo * D + 8 * (lane >> 4);
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+      qf[2 * ks] = *(const half8*)(qp + 32 * ks);
+      qf[2 * ks + 1] = *(const half8*)(qp + 16 * D + 32 * ks);
+    }
+  }
+#else
   // resident query fragments: B operand, lane holds Q[qidx][16*ks + 8*h .. +8)
   half8 qf[KS];
   {
@@ -153,10 +248,22 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
   }
+#endif
 
   // A-fragment LDS offsets: element (r, chunk c) of a panel sits at r*128 + ((c ^ sw(r))<<4),
   // sw(r) = (r >> 1) & 7; k-step kk of a panel reads chunks 2kk (lanes 0-31) / 2kk+1 (32-63).
   // a0..a3 always point into the CURRENT tile buffer (advanced by one buffer per iteration).
+#if SCAN_MMA16
+  // 16x16x32: lane reads row (lane & 15) [+16 through the offset field: same swizzle], chunk 4 (s & 1) + (lane >> 4) of
+  // panel s >> 1; (4 a + g) ^ sw = (g ^ sw) ^ 4 a, so odd steps are the even steps' address ^ 64.  A 16-lane group still
+  // covers 16 distinct 16-B slots (8 (r & 1) + (c ^ (r >> 1))).
+  int a0, a1;
+  {
+    const int r16 = lane & 15, sw = (r16 >> 1) & 7;
+    a0 = r16 * 128 + ((((lane >> 4)) ^ sw) << 4);
+    a1 = a0 ^ 64;
+  }
+#else
   int a0, a1, a2, a3;
   {
     const int sw = (row >> 1) & 7;
@@ -165,14 +272,19 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     a2 = row * 128 + (((4 + h) ^ sw) << 4);
     a3 = row * 128 + (((6 + h) ^ sw) << 4);
   }
+#endif
   // DMA source offsets: instruction (panel pn, row-block b) moves rows 8b..8b+7 × 128 B;
   // lane = 8*(row in block) + slot, and fetches chunk slot ^ sw(row).
   const int drow = lane >> 3, dslot = lane & 7;
   // (odd row-blocks: sw differs by 4, i.e. the chunk offset by 64 bytes -> voff ^ 64)
   const uint32_t voff_even = drow * (D * 2) + ((dslot ^ ((drow >> 1) & 7)) << 4);
 
+#if SCAN_MMA16
+  float thr = __uint_as_float(p.thr[q_lo]), thr1 = __uint_as_float(p.thr[q_lo + 16]);  // seed thresholds; +inf for padding
+#else
   float thr = __uint_as_float(p.thr[qidx]);  // seed threshold; +inf for padding queries
   const float my_binlo = p.binlo[qidx], my_binscale = p.binscale[qidx];  // this lane's query window
+#endif
   bool pend = false;  // a threshold refresh (and, on wave 0, an owned histogram) is in flight to LDS
   int own_q = -1;     // owner (wave 0): query whose histogram is in flight
   int event = 0;
@@ -213,10 +325,37 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     const uint32_t slot = rarc_lds_add_rtn(L::CNT + 4 * q, 1u);
     if (slot < p.seg)
       p.cand[((size_t)q * RARC_MAX_WG + blockIdx.x) * p.seg + slot] = rarc_candkey(s, doc);
+#if SCAN_MMA16
+    const int bin = rarc_bin_of(s, rarc_lds_read_f32(L::BINLO + 4 * q), rarc_lds_read_f32(L::BINSCALE + 4 * q));
+#else
     const int bin = rarc_bin_of(s, my_binlo, my_binscale);
+#endif
     atomicAdd(&p.hist[q * RARC_NB + bin], 1u);
   };
 
+#if SCAN_MMA16
+  // prune one tile's scores: c[2 rb + qb][i] = score of row 16 rb + 4 (lane >> 4) + i against query q_lo + 16 qb
+  auto prune = [&](const f32x4 (&c)[4], uint32_t tile) {
+    float mb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mb[j] = fmaxf(fmaxf(c[j][0], c[j][1]), fmaxf(c[j][2], c[j][3]));
+    const bool hit = fmaxf(mb[0], mb[2]) >= thr || fmaxf(mb[1], mb[3]) >= thr1;
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+      const int ln = rarc_fresh_lane();
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float t = (j & 1) ? thr1 : thr;
+        if (__builtin_amdgcn_ballot_w64(mb[j] >= t) != 0) {
+          const uint32_t q = wave * 32 + 16 * (j & 1) + (ln & 15);
+          const uint32_t row0 = tile * 32 + 16 * (j >> 1) + 4 * (ln >> 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (c[j][i] >= t && row0 + i < p.n_rows) append(c[j][i], row0 + i, q);
+        }
+      }
+    }
+  };
+#else
   // prune one tile's scores: lane holds 16 scores of its query (rows 8*(r>>2) + 4*h + (r&3))
   auto prune = [&](const f32x16& acc, uint32_t tile) {
       const float m0 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
@@ -241,6 +380,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
         }
       }
   };
+#endif
 
   const uint32_t t0 = blockIdx.x, stride = gridDim.x;
   if (t0 < p.n_tiles) issue(0, t0);
@@ -252,7 +392,20 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
   // overlaps its SIMD partner's MFMA stream instead of idling the matrix pipe.
   const bool grp_b = wave >= SCAN_WAVES / 2;
   uint32_t prev = 0xffffffffu;  // group B: tile whose scores are still in acc
+#if SCAN_MMA16
+  f32x4 acc[4];
+#else
   f32x16 acc;
+#endif
+// stamps go to LDS (8 KiB behind the carve, iterations 32..63) and are copied out at the end: a global store per stamp would sit
+// in the vector-memory queue and make every counted vmcnt wait of the instrumented workgroup stricter than the product's
+#define RARC_STAMP_AT(iter, slot)                                                                          \
+  if ((ABL & 64) && blockIdx.x == 0 && (iter) >= 32u && (iter) < 64u) {                                     \
+    const uint32_t t_ = (uint32_t)__builtin_amdgcn_s_memtime();                                             \
+    asm volatile("ds_write_b32 %0, %1" ::"v"((uint32_t)(L::TOTAL + ((((iter)-32u) * SCAN_WAVES + wave) * 8 + (slot)) * 4)), \
+                 "v"(t_) : "memory");                                                                       \
+  }
+#define RARC_STAMP(slot) RARC_STAMP_AT(it, slot)
   for (uint32_t cur = t0; cur < p.n_tiles; cur += stride) {
     // DMA(cur) landed?  Loads return in order, so "at most N outstanding" == everything older than
     // the newest N vector-memory ops has completed.  The newest ops of this wave are, by
@@ -266,11 +419,9 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       else if (ev == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 1) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW + 2) : "memory");
     }
+    RARC_STAMP_AT(it - 1u, 6)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#define RARC_STAMP(slot)                                                                         \
-  if ((ABL & 64) && blockIdx.x == 0 && it < 64 && rarc_fresh_lane() == 0)                         \
-    p.dbg[(it * SCAN_WAVES + wave) * 8 + (slot)] = __builtin_amdgcn_s_memtime();
     RARC_STAMP(0)
     const bool issued = !(ABL & 2) && cur + 2 * stride < p.n_tiles;
     int nb = buf + 2;
@@ -278,18 +429,44 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     // the DMA of tile cur+2 is issued piecewise from inside the MFMA loop (see ScanSteps)
     const uint32_t dma_tile = cur + 2 * stride;
     auto dma = [&](int j) {
+      if (SCAN_DMA_OUTSIDE) return;
       if (issued && (SCAN_DMA_B_INLOOP || !grp_b)) {  // (else group B issued all its pieces right after the barrier)
         asm volatile("" ::: "memory");
         issue_piece(nb, dma_tile, j);
         asm volatile("" ::: "memory");
       }
     };
+#if SCAN_DMA_OUTSIDE
+    // A wave never issues DMA from inside its MFMA chain: with four accumulators one wave keeps its SIMD's matrix pipe full
+    // on its own, so the wave that is OUTSIDE its chain does the vector-memory issue (it may block on a full queue without
+    // costing a matrix slot).  Group B: prune(t-1), DMA(t+2), MFMA(t); group A: MFMA(t), prune(t), DMA(t+2).  Pruning first
+    // keeps its stores OLDER than the pieces, so "at most DPW outstanding" at the next barrier asks for nothing but DMA(t+1).
+    if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
+    if (issued && (grp_b || (ABL & 4))) issue(nb, dma_tile);
+    RARC_STAMP(1)
+#else
     if (issued && ((grp_b && !SCAN_DMA_B_INLOOP) || (ABL & 4))) issue(nb, dma_tile);  // group B (it prunes first anyway)
     RARC_STAMP(1)
     // group B prunes the PREVIOUS tile now, while group A (same SIMDs) already streams MFMAs
     if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
+#endif
 
     // ---- 32 rows x 32 queries per wave: KS chained MFMAs fed by a 6-deep LDS read ring ----
+#if SCAN_MMA16
+    if (ABL & 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] = (f32x4){0}; asm volatile("" : "+v"(acc[j])); }
+    } else {
+      half8 ra[SCAN_RING16], rb[SCAN_RING16];
+      if (ABL & 32) __builtin_amdgcn_s_setprio(1);
+      RARC_STAMP(2)
+      ScanPrologue16<0, SCAN_RING16>::run(ra, rb, a0, a1);
+      ScanSteps16<0, KS2, SCAN_RING16>::run(acc, ra, rb, qf, a0, a1, dma);
+      if (ABL & 32) __builtin_amdgcn_s_setprio(0);
+      RARC_MFMA_DRAIN4(acc);
+      RARC_STAMP(3)
+    }
+#else
     if (ABL & 4) {
       acc = (f32x16){0};
       asm volatile("" : "+v"(acc));
@@ -303,10 +480,12 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       RARC_MFMA_DRAIN(acc);
       RARC_STAMP(3)
     }
+#endif
     if (!(ABL & 1)) {  // group A prunes this tile right away; group B defers it to the next iteration
       if (!grp_b) prune(acc, cur);
       else prev = cur;
     }
+    if (SCAN_DMA_OUTSIDE && issued && !grp_b && !(ABL & 4)) issue(nb, dma_tile);
 
     RARC_STAMP(4)
     // ---- threshold refresh issued one iteration ago: its DMAs are older than this iteration's
@@ -314,7 +493,12 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     if (pend) {
       if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if SCAN_MMA16
+      thr = fmaxf(thr, rarc_lds_read_f32(L::TLAND + wave * 256 + 4 * (rarc_fresh_lane() & 15)));
+      thr1 = fmaxf(thr1, rarc_lds_read_f32(L::TLAND + wave * 256 + 64 + 4 * (rarc_fresh_lane() & 15)));
+#else
       thr = fmaxf(thr, rarc_lds_read_f32(L::TLAND + wave * 256 + 4 * rarc_fresh_lane()));
+#endif
       if (own_q >= 0) {  // wave 0: turn the owned query's histogram into a threshold
         uint32_t c0, c1, c2, c3;
         rarc_lds_read_u32x4(L::HLAND + 16 * rarc_fresh_lane(), c0, c1, c2, c3);
@@ -348,7 +532,16 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       pend = true;
     }
 
-    RARC_STAMP(5)
+    RARC_STAMP_AT(it - 1u, 5)
+#if SCAN_MMA16
+    if (buf == 2) {
+      buf = 0;
+      a0 -= 2 * TILE_BYTES; a1 -= 2 * TILE_BYTES;
+    } else {
+      ++buf;
+      a0 += TILE_BYTES; a1 += TILE_BYTES;
+    }
+#else
     if (buf == 2) {
       buf = 0;
       a0 -= 2 * TILE_BYTES; a1 -= 2 * TILE_BYTES; a2 -= 2 * TILE_BYTES; a3 -= 2 * TILE_BYTES;
@@ -356,9 +549,15 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       ++buf;
       a0 += TILE_BYTES; a1 += TILE_BYTES; a2 += TILE_BYTES; a3 += TILE_BYTES;
     }
+#endif
   }
   if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
   __syncthreads();
+  if ((ABL & 64) && blockIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int i = tid; i < 32 * SCAN_WAVES * 8; i += SCAN_WAVES * 64)
+      p.dbg[32 * SCAN_WAVES * 8 + i] = __float_as_uint(rarc_lds_read_f32(L::TOTAL + 4 * i));
+  }
   {
     const int t2 = wave * 64 + rarc_fresh_lane();
     if (t2 < RARC_MAX_QUERIES) p.cnt2[(size_t)blockIdx.x * RARC_MAX_QUERIES + t2] = s_cnt[t2];

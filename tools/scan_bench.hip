@@ -14,7 +14,7 @@ bool rarc_prof_next(hipEvent_t*, hipEvent_t*) { return false; }
 template <int ABL>
 static float run(const ScanParams& p, int grid, int iters, uint32_t nq, int kprime, RarcWs ws, uint32_t seed_tiles) {
   constexpr int D = 768;
-  constexpr size_t lds = ScanLds<D>::TOTAL;
+  constexpr size_t lds = ScanLds<D>::TOTAL + ((ABL & 64) ? 8192 : 0);
   hipFuncSetAttribute((const void*)rarc_scan_f16_kernel<D, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   float best = 1e30f;
@@ -50,14 +50,14 @@ int main(int argc, char** argv) {
   int grid = 256; uint32_t st = p.n_tiles < 128 ? p.n_tiles : 128;
   const double gb = (double)N * D * 2 / 1e9;
 #define RUN(A) { float us = run<A>(p, grid, 8, NQ, KP, ws, st); printf("ABL=%2d  %8.1f us  %6.2f TB/s\n", A, us, gb / us * 1e-3); }
-  RUN(0) RUN(0)
+  RUN(0) RUN(0) RUN(1) RUN(2) RUN(3)
   run<64>(p, grid, 2, NQ, KP, ws, st);
   { std::vector<unsigned long long> h(64 * 8 * 8); hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
     printf("timeline of workgroup 0 (s_memtime ticks, 100 MHz => x10 ns), relative to wave 0 stamp 0 of each iteration\n");
-    printf("iter wave:  barrier->dmaissued ->mfma_start ->mfma_end ->pruned(A) ->events_done   | next barrier\n");
-    for (int it = 57; it < 62; ++it) for (int w = 0; w < 8; ++w) { const unsigned long long* r = &h[(it * 8 + w) * 8]; unsigned long long b0 = h[(it * 8) * 8];
+    printf("iter wave:  barrier->stamp1 ->mfma_start ->mfma_end ->pruned(A) ->events_done ->dma_landed | next barrier\n");
+    for (int it = 56; it < 60; ++it) for (int w = 0; w < 8; ++w) { const unsigned long long* r = &h[(it * 8 + w) * 8]; unsigned long long b0 = h[(it * 8) * 8];
       unsigned long long nb = h[((it + 1) * 8 + w) * 8];
-      printf("%3d %d: %6lld %6lld %6lld %6lld %6lld %6lld | %6lld\n", it, w, (long long)(r[0] - b0), (long long)(r[1] - b0), (long long)(r[2] - b0), (long long)(r[3] - b0), (long long)(r[4] - b0), (long long)(r[5] - b0), (long long)(nb - b0)); } }
+      printf("%3d %d: %6lld %6lld %6lld %6lld %6lld %6lld %6lld | %6lld\n", it, w, (long long)(r[0] - b0), (long long)(r[1] - b0), (long long)(r[2] - b0), (long long)(r[3] - b0), (long long)(r[4] - b0), (long long)(r[5] - b0), (long long)(r[6] - b0), (long long)(nb - b0)); } }
   run<0>(p, grid, 1, NQ, KP, ws, st);
   std::vector<uint32_t> cnt(256 * 256); hipMemcpy(cnt.data(), ws.cnt2, 256 * 256 * 4, hipMemcpyDeviceToHost);
   uint64_t tot = 0; uint32_t mx = 0; for (auto c : cnt) { tot += c; mx = c > mx ? c : mx; }
