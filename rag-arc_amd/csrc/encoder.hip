@@ -289,6 +289,9 @@ __device__ __forceinline__ void gemm_store8_ss(half_t* p, const uint4 v, const h
 //     WAR  a buffer is restaged >= 2 phases after its last ds_read, and readers wait for lgkmcnt(0) inside the
 //          slot that issued the read.
 // ------------------------------------------------------------------------------------------
+#ifndef G256_PHASES2
+#define G256_PHASES2 1
+#endif
 constexpr int G256_EP_STRIDE = 144, G256_EP_BYTES = 128 * G256_EP_STRIDE;  // epilogue staging, per wave
 constexpr int G256_LDS = 8 * G256_EP_BYTES > 131072 ? 8 * G256_EP_BYTES : 131072;
 template <int ACT>
@@ -356,6 +359,11 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                               \
                  : "=&v"(fa[kk][0]), "=&v"(fa[kk][1]) : "v"(ad) : "memory");                            \
   }
+#ifdef G256_SKIP_A1  /* timing experiment (wrong results): a third of the fragment reads left out */
+#define G256_LOAD_A1(PAR)
+#else
+#define G256_LOAD_A1(PAR) G256_LOAD_A(PAR, 1)
+#endif
 #define G256_LOAD_B(PAR, H, FB)                                                                         \
   _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
     const int ad = xk[kk] + ((PAR) * 65536 + 32768 + (H) * 16384 + wc * 4096);                          \
@@ -406,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     if (ST234) stage(par, 0, kt + 2);                                                                   \
     G256_BAR();                                                                                         \
     /* phase 3: A1 x B1 */                                                                              \
-    G256_LOAD_A(par, 1)                                                                                 \
+    G256_LOAD_A1(par)                                                                                   \
     G256_WAIT(VM3);                                                                                     \
     G256_BAR();                                                                                         \
     G256_MMA(1, 1, fb1);                                                                                \
@@ -417,6 +425,33 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     G256_BAR();                                                                                         \
     G256_MMA(1, 0, fb0);                                                                                \
     if (ST234) stage(par, 3, kt + 2);                                                                   \
+    G256_BAR();                                                                                         \
+  }
+
+  // Two-slot form of the same k tile (G256_PHASES2): a matrix slot is SIXTEEN MFMAs (A0 x B0, A0 x B1 | A1 x B1, A1 x B0), so a
+  // k tile is 4 slots and 4 barriers instead of 8: the other group's load slot (fragment reads, their latency, the counted wait,
+  // the barrier) has 512 matrix cycles to hide under instead of 256 (s_memtime: a four-phase k tile takes 2740 cycles for
+  // 2048 of MFMA issue — ~85 cycles per slot that no operand path accounts for; LDS reads cut by a third: +1-2 %).
+  //   slot L_A: fragments of A0, B0, B1   M_A: 16 MFMAs, then stage A1 of tile t+1 (other parity; last read in L_B(t-1))
+  //   slot L_B: fragments of A1           M_B: 16 MFMAs, then stage A0, B0, B1 of tile t+2 (this parity; last read in L_A(t))
+  // Waves 4-7 one slot behind, as before.  Every half is staged two slots or more after its last read and five slots before
+  // its first; a wave's queue at the end of L_A holds M_B(t-1)'s six instructions (vmcnt(6): A1 of this tile has landed), at
+  // the end of L_B M_A(t)'s two (vmcnt(2): the next tile's A0, B0, B1 have landed).
+#define G256_TILE2(ST_A, ST_B, VMA, VMB)                                                                \
+  {                                                                                                     \
+    G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0) G256_LOAD_B(par, 1, fb1)                               \
+    G256_WAIT(VMA);                                                                                     \
+    G256_BAR();                                                                                         \
+    G256_MMA(0, 0, fb0);                                                                                \
+    G256_MMA(0, 1, fb1);                                                                                \
+    if (ST_A) stage(np, 1, kt + 1);                                                                     \
+    G256_BAR();                                                                                         \
+    G256_LOAD_A(par, 1)                                                                                 \
+    G256_WAIT(VMB);                                                                                     \
+    G256_BAR();                                                                                         \
+    G256_MMA(1, 1, fb1);                                                                                \
+    G256_MMA(1, 0, fb0);                                                                                \
+    if (ST_B) { stage(par, 0, kt + 2); stage(par, 2, kt + 2); stage(par, 3, kt + 2); }                  \
     G256_BAR();                                                                                         \
   }
 
@@ -436,6 +471,17 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   // CU's LDS / vector-memory queues are doing when it issues).  The wait at the end of a load slot therefore sees one stage
   // fewer issued: all but the FOUR newest stages (8 instructions) must have landed — reads of phase p + 1 need the stages
   // of phases <= p - 5, exactly those.
+#if G256_PHASES2
+  for (; kt + 2 < KT; ++kt) {
+    const int par = kt & 1, np = par ^ 1;
+    G256_TILE2(true, true, 6, 2)
+  }
+  if (kt + 1 < KT) {  // second-to-last tile: only the last tile's A1 is still to stage
+    const int par = kt & 1, np = par ^ 1;
+    G256_TILE2(true, false, 6, 2)
+    ++kt;
+  }
+#else
   for (; kt + 2 < KT; ++kt) {
     const int par = kt & 1, np = par ^ 1;
     G256_TILE(true, true, 8, 8, 8, 8)
@@ -445,6 +491,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     G256_TILE(true, false, 8, 8, 6, 4)
     ++kt;
   }
+#endif
   // RS (ACT | 16): the four row scales of this lane's rows are fetched before the last k tile, so that their round trip
   // runs under its MFMAs instead of in front of the epilogue; they are the newest vector-memory operations from here on,
   // and the last tile's waits let exactly them stay outstanding
@@ -456,12 +503,19 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   {  // last tile
     const int par = kt & 1, np = par ^ 1;
     (void)np;
+#if G256_PHASES2
+    if constexpr ((ACT & 16) != 0) { G256_TILE2(false, false, 4, 4) }
+    else { G256_TILE2(false, false, 0, 0) }
+#else
     if constexpr ((ACT & 16) != 0) { G256_TILE(false, false, 6, 4, 4, 4) }
     else { G256_TILE(false, false, 2, 0, 0, 0) }
+#endif
   }
   if (wr == 0) G256_BAR();
 #undef G256_TILE
+#undef G256_TILE2
 #undef G256_LOAD_A
+#undef G256_LOAD_A1
 #undef G256_LOAD_B
 #undef G256_WAIT
 #undef G256_MMA
