@@ -289,9 +289,6 @@ __device__ __forceinline__ void gemm_store8_ss(half_t* p, const uint4 v, const h
 //     WAR  a buffer is restaged >= 2 phases after its last ds_read, and readers wait for lgkmcnt(0) inside the
 //          slot that issued the read.
 // ------------------------------------------------------------------------------------------
-#ifndef G256_PHASES2
-#define G256_PHASES2 1
-#endif
 constexpr int G256_EP_STRIDE = 144, G256_EP_BYTES = 128 * G256_EP_STRIDE;  // epilogue staging, per wave
 constexpr int G256_LDS = 8 * G256_EP_BYTES > 131072 ? 8 * G256_EP_BYTES : 131072;
 template <int ACT>
@@ -341,116 +338,94 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
                                        RARC_LPTR(smem + par * 65536 + which * 16384 + i * 1024), 16, 0, 0);
     }
   };
-  const int sw = (row >> 1) & 7;
-  int xk[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + hh) ^ sw) << 4);
+  // Fragments for v_mfma_f32_16x16x32_f16 (round 3; rounds 1-2 ran 32x32x16): lane reads row (lane & 15) of a 16-row block and the
+  // 16-byte chunk 4 s + (lane >> 4) of the row's eight, s = the k step of 32 inside the k tile.  Same LDS image and swizzle (a 16-lane
+  // group covers 16 distinct slots: 8 (r & 1) + (c ^ (r >> 1))); (4 s + g) ^ sw = (g ^ sw) ^ 4 s, so step 1 is step 0's address ^ 64;
+  // the 16-row blocks of a half are 2 KiB apart (offset field).  Why the smaller shape: per MAC it moves half the accumulator
+  // bytes (4 B read + written per 32 MACs instead of per 16) for twice the operand bytes — 0.5 B instead of 0.625 B of register
+  // traffic per MAC — and the LM / encoder GEMMs run at the board's power limit: the same schedule with the MFMAs swapped for
+  // pairs of 16x16x32 (wrong results) ran 6-9 % faster on real operands and no faster on zeros (profiles/r03_gemm_seamless.txt);
+  // the vendor's kernel for these shapes is MI16x16 as well.
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  int xs[2];
+  {
+    const int r16 = lane & 15, sw16 = (r16 >> 1) & 7;
+    xs[0] = r16 * 128 + (((lane >> 4) ^ sw16) << 4);
+    xs[1] = xs[0] ^ 64;
+  }
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];  // [16-row block of the wave's 128 rows][16-column block of its 64 columns]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16){0};
-  half8 fa[4][2], fb0[4], fb1[4];  // [k step][block]: the A half in use (2 blocks of 32 rows); both B halves
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0, 0, 0, 0};
+  half8 fa[2][4], fb0[2][2], fb1[2][2];  // [k step of 32][16-row block]: the A half in use (64 rows); both B halves (32 columns each)
 
 #define G256_LOAD_A(PAR, H)                                                                             \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
-    const int ad = xk[kk] + ((PAR) * 65536 + (H) * 16384 + wr * 8192);                                  \
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                               \
-                 : "=&v"(fa[kk][0]), "=&v"(fa[kk][1]) : "v"(ad) : "memory");                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+    const int ad = xs[ks] + ((PAR) * 65536 + (H) * 16384 + wr * 8192);                                  \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\t"                          \
+                 "ds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"                   \
+                 : "=&v"(fa[ks][0]), "=&v"(fa[ks][1]), "=&v"(fa[ks][2]), "=&v"(fa[ks][3]) : "v"(ad) : "memory"); \
   }
-#ifdef G256_SKIP_A1  /* timing experiment (wrong results): a third of the fragment reads left out */
-#define G256_LOAD_A1(PAR)
-#else
-#define G256_LOAD_A1(PAR) G256_LOAD_A(PAR, 1)
-#endif
 #define G256_LOAD_B(PAR, H, FB)                                                                         \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
-    const int ad = xk[kk] + ((PAR) * 65536 + 32768 + (H) * 16384 + wc * 4096);                          \
-    asm volatile("ds_read_b128 %0, %1" : "=&v"(FB[kk]) : "v"(ad) : "memory");                           \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+    const int ad = xs[ks] + ((PAR) * 65536 + 32768 + (H) * 16384 + wc * 4096);                          \
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048"                              \
+                 : "=&v"(FB[ks][0]), "=&v"(FB[ks][1]) : "v"(ad) : "memory");                            \
   }
-  // end of a load slot: counted wait for the staged data the NEXT phase reads, then this slot's own ds_reads
+  // end of a load slot: counted wait for the staged data the NEXT slot reads, then this slot's own ds_reads
 #define G256_WAIT(VM)                                                                                   \
   asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)"                                       \
-               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]),        \
-                 "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb0[0]), "+v"(fb0[1]),            \
-                 "+v"(fb0[2]), "+v"(fb0[3]), "+v"(fb1[0]), "+v"(fb1[1]), "+v"(fb1[2]), "+v"(fb1[3])     \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]),        \
+                 "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb0[0][0]), "+v"(fb0[0][1]),      \
+                 "+v"(fb0[1][0]), "+v"(fb0[1][1]), "+v"(fb1[0][0]), "+v"(fb1[0][1]), "+v"(fb1[1][0]), "+v"(fb1[1][1]) \
                :: "memory")
-#define G256_MMA(QM, QN, FB)                                                                            \
-  /* register-only MFMAs drift across s_barrier (they are pure to the optimiser): tie their inputs to */\
-  /* an asm after the slot's first barrier and their results to one before its second */               \
-  asm volatile("" : "+v"(FB[0]), "+v"(FB[1]), "+v"(FB[2]), "+v"(FB[3]));                                \
+  // one matrix slot: the A half QM (four 16-row blocks) against both B halves — 2 k steps x 4 x 4 = 32 MFMAs, every accumulator
+  // block once per k step (16 MFMAs apart).  Register-only MFMAs drift across s_barrier (they are pure to the optimiser): their
+  // inputs are tied to an asm after the slot's first barrier and their results to one before its second.
+#define G256_MMA2(QM)                                                                                   \
+  asm volatile("" : "+v"(fb0[0][0]), "+v"(fb0[0][1]), "+v"(fb0[1][0]), "+v"(fb0[1][1]), "+v"(fb1[0][0]), "+v"(fb1[0][1]), \
+                    "+v"(fb1[1][0]), "+v"(fb1[1][1]));                                                  \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
   __builtin_amdgcn_s_setprio(1);                                                                        \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
-    acc[2 * (QM)][QN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[kk], fa[kk][0], acc[2 * (QM)][QN], 0, 0, 0); \
-    acc[2 * (QM) + 1][QN] = __builtin_amdgcn_mfma_f32_32x32x16_f16(FB[kk], fa[kk][1], acc[2 * (QM) + 1][QN], 0, 0, 0); \
-  }                                                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                     \
+      acc[4 * (QM) + b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[ks][0], fa[ks][b], acc[4 * (QM) + b][0], 0, 0, 0); \
+      acc[4 * (QM) + b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[ks][1], fa[ks][b], acc[4 * (QM) + b][1], 0, 0, 0); \
+      acc[4 * (QM) + b][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[ks][0], fa[ks][b], acc[4 * (QM) + b][2], 0, 0, 0); \
+      acc[4 * (QM) + b][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[ks][1], fa[ks][b], acc[4 * (QM) + b][3], 0, 0, 0); \
+    }                                                                                                   \
   __builtin_amdgcn_s_setprio(0);                                                                        \
-  asm volatile("" : "+v"(acc[2 * (QM)][QN]), "+v"(acc[2 * (QM) + 1][QN]));                              \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                         \
+    asm volatile("" : "+v"(acc[4 * (QM) + b][0]), "+v"(acc[4 * (QM) + b][1]), "+v"(acc[4 * (QM) + b][2]), "+v"(acc[4 * (QM) + b][3])); \
   __builtin_amdgcn_sched_barrier(0)
 #define G256_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-  // one k tile t (parity par) = four phases.  Reads: A0, B0 in phase 1, B1 in phase 2, A1 in phase 3 (B0 stays
-  // in registers for phase 4).  Restaging, one half per phase, each buffer one or two phases after its last read:
-  //   phase 1: A1 of tile t+1 (other parity; its buffer was read in phase 3 of tile t-1)
-  //   phase 2: A0 of tile t+2, phase 3: B0 of t+2, phase 4: B1 of t+2 (this parity)
-  // -> every half is staged >= 6 phases before its first read, 4-5 stages (64-80 KiB) are in flight, and the
-  // wait at the end of L(p) lets the four newest stages (8 DMA instructions of this wave) stay outstanding (round 3: the
-  // DMA of phase p is issued in the tail of M(p), see below; it was issued in L(p) with five stages behind the wait).
-#define G256_TILE(ST1, ST234, VM1, VM2, VM3, VM4)                                                       \
-  {                                                                                                     \
-    /* phase 1: quadrant A0 x B0 */                                                                     \
-    G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0)                                                        \
-    G256_WAIT(VM1);                                                                                     \
-    G256_BAR();                                                                                         \
-    G256_MMA(0, 0, fb0);                                                                                \
-    if (ST1) stage(np, 1, kt + 1);                                                                      \
-    G256_BAR();                                                                                         \
-    /* phase 2: A0 x B1 */                                                                              \
-    G256_LOAD_B(par, 1, fb1)                                                                            \
-    G256_WAIT(VM2);                                                                                     \
-    G256_BAR();                                                                                         \
-    G256_MMA(0, 1, fb1);                                                                                \
-    if (ST234) stage(par, 0, kt + 2);                                                                   \
-    G256_BAR();                                                                                         \
-    /* phase 3: A1 x B1 */                                                                              \
-    G256_LOAD_A1(par)                                                                                   \
-    G256_WAIT(VM3);                                                                                     \
-    G256_BAR();                                                                                         \
-    G256_MMA(1, 1, fb1);                                                                                \
-    if (ST234) stage(par, 2, kt + 2);                                                                   \
-    G256_BAR();                                                                                         \
-    /* phase 4: A1 x B0 (no LDS reads) */                                                               \
-    G256_WAIT(VM4);                                                                                     \
-    G256_BAR();                                                                                         \
-    G256_MMA(1, 0, fb0);                                                                                \
-    if (ST234) stage(par, 3, kt + 2);                                                                   \
-    G256_BAR();                                                                                         \
-  }
-
-  // Two-slot form of the same k tile (G256_PHASES2): a matrix slot is SIXTEEN MFMAs (A0 x B0, A0 x B1 | A1 x B1, A1 x B0), so a
-  // k tile is 4 slots and 4 barriers instead of 8: the other group's load slot (fragment reads, their latency, the counted wait,
-  // the barrier) has 512 matrix cycles to hide under instead of 256 (s_memtime: a four-phase k tile takes 2740 cycles for
-  // 2048 of MFMA issue — ~85 cycles per slot that no operand path accounts for; LDS reads cut by a third: +1-2 %).
-  //   slot L_A: fragments of A0, B0, B1   M_A: 16 MFMAs, then stage A1 of tile t+1 (other parity; last read in L_B(t-1))
-  //   slot L_B: fragments of A1           M_B: 16 MFMAs, then stage A0, B0, B1 of tile t+2 (this parity; last read in L_A(t))
-  // Waves 4-7 one slot behind, as before.  Every half is staged two slots or more after its last read and five slots before
-  // its first; a wave's queue at the end of L_A holds M_B(t-1)'s six instructions (vmcnt(6): A1 of this tile has landed), at
-  // the end of L_B M_A(t)'s two (vmcnt(2): the next tile's A0, B0, B1 have landed).
+  // One k tile t (parity par) = four slots, two per wave group and A half; waves 4-7 run one slot behind waves 0-3, so that
+  // while one of a SIMD's two waves multiplies, the other loads:
+  //   slot L_A: fragments of A0, B0, B1   M_A: 32 MFMAs, then stage A1 of tile t+1 (other parity; last read in L_B(t-1))
+  //   slot L_B: fragments of A1           M_B: 32 MFMAs, then stage A0, B0, B1 of tile t+2 (this parity; last read in L_A(t))
+  // (rounds 1-2 and most of round 3 ran eight slots of 8 MFMAs of 32x32x16 — one output quadrant each; with 4 slots and 4
+  // barriers K = 256 / 512 gained 7-10 %, larger K nothing.)  The DMA of a slot is issued in the TAIL of its matrix slot, not
+  // next to the fragment reads (2864 -> 2738 cycles per k tile when that was introduced).
+  // Ordering (every wave passes every barrier):
+  //   WAR  every half is staged two slots or more after its last ds_read, and readers wait for lgkmcnt(0) inside the slot
+  //        that issued the read;
+  //   RAW  a half is staged five slots before its first read; a wave's queue at the end of L_A holds M_B(t-1)'s six
+  //        instructions (vmcnt(6): A1 of this tile, staged before them, has landed), at the end of L_B M_A(t)'s two (vmcnt(2):
+  //        the next tile's A0, B0, B1 have landed); every wave waits for its own share, a barrier follows before anyone reads.
 #define G256_TILE2(ST_A, ST_B, VMA, VMB)                                                                \
   {                                                                                                     \
     G256_LOAD_A(par, 0) G256_LOAD_B(par, 0, fb0) G256_LOAD_B(par, 1, fb1)                               \
     G256_WAIT(VMA);                                                                                     \
     G256_BAR();                                                                                         \
-    G256_MMA(0, 0, fb0);                                                                                \
-    G256_MMA(0, 1, fb1);                                                                                \
+    G256_MMA2(0);                                                                                       \
     if (ST_A) stage(np, 1, kt + 1);                                                                     \
     G256_BAR();                                                                                         \
     G256_LOAD_A(par, 1)                                                                                 \
     G256_WAIT(VMB);                                                                                     \
     G256_BAR();                                                                                         \
-    G256_MMA(1, 1, fb1);                                                                                \
-    G256_MMA(1, 0, fb0);                                                                                \
+    G256_MMA2(1);                                                                                       \
     if (ST_B) { stage(par, 0, kt + 2); stage(par, 2, kt + 2); stage(par, 3, kt + 2); }                  \
     G256_BAR();                                                                                         \
   }
@@ -466,12 +441,6 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   G256_BAR();
   if (wr == 1) G256_BAR();  // waves 4-7 run one slot behind
   int kt = 0;
-  // Round 3: a phase's operand DMA is issued in the TAIL of its matrix slot (after the eight MFMAs), not next to the fragment
-  // reads of its load slot: s_memtime per k tile 2864 -> 2738 cycles (the price of an LDS-DMA instruction depends on what the
-  // CU's LDS / vector-memory queues are doing when it issues).  The wait at the end of a load slot therefore sees one stage
-  // fewer issued: all but the FOUR newest stages (8 instructions) must have landed — reads of phase p + 1 need the stages
-  // of phases <= p - 5, exactly those.
-#if G256_PHASES2
   for (; kt + 2 < KT; ++kt) {
     const int par = kt & 1, np = par ^ 1;
     G256_TILE2(true, true, 6, 2)
@@ -481,47 +450,29 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     G256_TILE2(true, false, 6, 2)
     ++kt;
   }
-#else
-  for (; kt + 2 < KT; ++kt) {
-    const int par = kt & 1, np = par ^ 1;
-    G256_TILE(true, true, 8, 8, 8, 8)
-  }
-  if (kt + 1 < KT) {  // second-to-last tile: only the last tile's A1 is still to stage; the waits shrink with the queue
-    const int par = kt & 1, np = par ^ 1;
-    G256_TILE(true, false, 8, 8, 6, 4)
-    ++kt;
-  }
-#endif
-  // RS (ACT | 16): the four row scales of this lane's rows are fetched before the last k tile, so that their round trip
+  // RS (ACT | 16): the eight row scales of this lane's rows are fetched before the last k tile, so that their round trip
   // runs under its MFMAs instead of in front of the epilogue; they are the newest vector-memory operations from here on,
   // and the last tile's waits let exactly them stay outstanding
-  float rs_pre[4] = {1.f, 1.f, 1.f, 1.f};
+  float rs_pre[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if constexpr ((ACT & 16) != 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rs_pre[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row];
+    for (int i = 0; i < 8; ++i) rs_pre[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 16 + (lane & 15)];
   }
   {  // last tile
     const int par = kt & 1, np = par ^ 1;
     (void)np;
-#if G256_PHASES2
-    if constexpr ((ACT & 16) != 0) { G256_TILE2(false, false, 4, 4) }
+    if constexpr ((ACT & 16) != 0) { G256_TILE2(false, false, 8, 8) }
     else { G256_TILE2(false, false, 0, 0) }
-#else
-    if constexpr ((ACT & 16) != 0) { G256_TILE(false, false, 6, 4, 4, 4) }
-    else { G256_TILE(false, false, 2, 0, 0, 0) }
-#endif
   }
   if (wr == 0) G256_BAR();
-#undef G256_TILE
 #undef G256_TILE2
+#undef G256_MMA2
 #undef G256_LOAD_A
-#undef G256_LOAD_A1
 #undef G256_LOAD_B
 #undef G256_WAIT
-#undef G256_MMA
 #undef G256_BAR
-  // epilogue: acc[i][j] is rows wr*128 + i*32 + row, cols wc*64 + j*32 + (8g + 4hh .. +3) of the tile.  A lane's
-  // 8-byte pieces lie in 32 different rows: stored directly, every instruction touches 32 cache lines with 16
+  // epilogue: acc[i][j][e] is row wr*128 + 16 i + (lane & 15), column wc*64 + 16 j + 4 (lane >> 4) + e of the tile.  A lane's
+  // 8-byte pieces lie in 16 different rows: stored directly, every instruction would touch 16 cache lines with 32
   // bytes each.  The pipeline buffers are dead now (every wave is past the last barrier), so each wave
   // transposes its 128 x 64 block through its own 18 KiB of LDS (row stride 144 B) and writes whole 128-byte rows.
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -529,13 +480,13 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   //  out of the tile loop and kept in registers through the main loop, which has none to spare)
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
-  const int row_e = lane_e & 31, hh_e = lane_e >> 5;
+  const int row_e = lane_e & 15, q_e = lane_e >> 4;
   char* ep = smem + wave * G256_EP_BYTES;
   constexpr int BASE = ACT & 15;
   constexpr bool RS = (ACT & 16) != 0, RES = (ACT & 32) != 0;
-  float rs[4];
+  float rs[8];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) rs[i] = rs_pre[i];
+  for (int i = 0; i < 8; ++i) rs[i] = rs_pre[i];
   half8 oldv[16];
   if constexpr (RES) {
     const half_t* Co = C + (size_t)(tm * 256 + wr * 128 + (lane_e >> 3)) * N + tn * 256 + wc * 64 + (lane_e & 7) * 8;
@@ -547,11 +498,11 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *(float4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + (8 * g + 4 * hh_e) * 4) =
-              make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        for (int g = 0; g < 2; ++g)
+          *(float4*)(ep + (i * 16 + row_e) * G256_EP_STRIDE + (16 * g + 4 * q_e) * 4) =
+              make_float4(acc[i][2 * j + g][0], acc[i][2 * j + g][1], acc[i][2 * j + g][2], acc[i][2 * j + g][3]);
       __builtin_amdgcn_wave_barrier();
       const int r8 = lane_e >> 3, c = lane_e & 7;
       float* Cw = (float*)C + (size_t)(tm * 256 + wr * 128) * N + tn * 256 + wc * 64 + j * 32 + c * 4;
@@ -563,21 +514,27 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
       __builtin_amdgcn_wave_barrier();
     }
   } else if constexpr (BASE == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
+    // gate / up columns alternate in groups of eight: in a 16-column block the lanes with (lane >> 4) < 2 hold gate values of
+    // features 4 q + e, the lanes 32 above them the up values of the same features.  One v_permlane32_swap per pair of registers
+    // (e, e + 2) leaves the lower lane with (gate, up) of features 4 q + {0, 1} and the upper with those of 4 q + {2, 3}.
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 4; ++j) {
+        const int nl = j * 16 + 4 * q_e;   // this lane's four columns inside the wave's block (gate if q_e < 2, else up)
+        half4 b4 = {0, 0, 0, 0};
+        if constexpr (!RS) b4 = *(const half4*)(bias + tn * 256 + wc * 64 + nl);
+        float v[4];
 #pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          const int nl = j * 32 + 8 * g + 4 * hh_e;
-          half4 bg = {0, 0, 0, 0}, bu = {0, 0, 0, 0};
-          if constexpr (!RS) { bg = *(const half4*)(bias + tn * 256 + wc * 64 + nl); bu = *(const half4*)(bias + tn * 256 + wc * 64 + nl + 8); }
-          half4 out;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            out[e] = rarc_swiglu_f16(acc[i][j][4 * g + e] * rs[i] + (float)bg[e], acc[i][j][4 * g + 4 + e] * rs[i] + (float)bu[e]);
-          *(half4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + (j * 16 + 4 * g + 4 * hh_e) * 2) = out;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * rs[i] + (float)b4[e];
+        // lower half: v0 v1 stay gate(f0) gate(f1), v2 v3 become up(f0) up(f1); upper half: v0 v1 become gate(f2) gate(f3)
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[2]));
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[1]), "+v"(v[3]));
+        half2v out;
+        out[0] = rarc_swiglu_f16(v[0], v[2]);
+        out[1] = rarc_swiglu_f16(v[1], v[3]);
+        *(half2v*)(ep + (i * 16 + row_e) * G256_EP_STRIDE + (j * 8 + 4 * (q_e & 1) + 2 * (q_e >> 1)) * 2) = out;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -591,23 +548,20 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     }
   } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
+      const int nl = j * 16 + 4 * q_e;  // column inside the wave's block
+      half4 b4 = {0, 0, 0, 0};
+      if constexpr (!RS) b4 = *(const half4*)(bias + tn * 256 + wc * 64 + nl);
+      half4 out;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = j * 32 + 8 * g + 4 * hh_e;  // column inside the wave's block
-        half4 b4 = {0, 0, 0, 0};
-        if constexpr (!RS) b4 = *(const half4*)(bias + tn * 256 + wc * 64 + nl);
-        half4 out;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float v = acc[i][j][4 * g + e] * rs[i] + (float)b4[e];
-          if (BASE == 1) v = rarc_gelu_erf(v);
-          out[e] = (half_t)v;
-        }
-        *(half4*)(ep + (i * 32 + row_e) * G256_EP_STRIDE + nl * 2) = out;
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[i][j][e] * rs[i] + (float)b4[e];
+        if (BASE == 1) v = rarc_gelu_erf(v);
+        out[e] = (half_t)v;
       }
+      *(half4*)(ep + (i * 16 + row_e) * G256_EP_STRIDE + nl * 2) = out;
     }
   }
   __builtin_amdgcn_wave_barrier();

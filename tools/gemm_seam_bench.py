@@ -14,6 +14,8 @@ def run(fn, R=10):
 shapes = [(4096, 1024, 0), (1024, 2048, 0), (6144, 1024, 3), (1024, 3072, 0)] + [(4096, k, 0) for k in (256, 512, 1024, 2048, 4096)]
 for (N, K, act) in shapes:
     a = torch.randn((M, K), device="cuda").half(); w = (torch.randn((N, K), device="cuda") * 0.05).half(); b = torch.zeros(N, device="cuda").half()
+    if os.environ.get("PROBE_ZERO") == "1":   # same instruction stream, no operand toggling: what the clock does without the MFMA power
+        a.zero_(); w.zero_()
     c = torch.empty((M, N // 2 if act == 3 else N), device="cuda", dtype=torch.float16)
     st = torch.cuda.current_stream().cuda_stream
     t_seam = run(lambda: lib.rarc_enc_gemm(a.data_ptr(), w.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, act, st))
