@@ -925,9 +925,9 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256s_f16_kernel(const half_t*
 // ------------------------------------------------------------------------------------------
 // The same ping-pong schedule on 256 x 128 tiles, for N = 1024 (attention output, FFN2: 256 tiles at M = 8192)
 // and for shapes whose 256 x 256 tile count would leave a ragged last round.
-//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. x cols wc*32..: acc[4] 32x32 blocks.
+//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. x cols wc*32..: acc[8][2] 16x16 blocks (v_mfma_f32_16x16x32_f16).
 //   LDS 144 KiB = a ring of 3 k tiles x {A0, A1, B} x 16 KiB (A_h as above; B = the 128 rows of W).
-//   Two phases per k tile (8 MFMAs each): A0 x B (reads A0, B), A1 x B (reads A1; B stays in registers).
+//   Two phases per k tile (16 MFMAs each): A0 x B (reads A0, B), A1 x B (reads A1; B stays in registers).
 //   Restaging: phase 2 of tile t refills A0, B of its own slot with tile t+3; phase 1 of tile t with A1 of
 //   tile t+2 (slot of tile t-1) — 5 phases of lead, up to 80 KiB in flight; the wait at the end of L(p) lets
 //   the stages of the last four phases (12 DMA instructions per wave) stay outstanding.
@@ -967,43 +967,50 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
                                        RARC_LPTR(smem + slot * 49152 + which * 16384 + i * 1024), 16, 0, 0);
     }
   };
-  const int sw = (row >> 1) & 7;
-  int xk[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) xk[kk] = row * 128 + (((2 * kk + hh) ^ sw) << 4);
+  // 16x16x32 fragments, as in the 256 x 256 kernel: row (lane & 15) of a 16-row block, chunk 4 s + (lane >> 4); step 1 = step 0 ^ 64
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  int xs[2];
+  {
+    const int r16 = lane & 15, sw16 = (r16 >> 1) & 7;
+    xs[0] = r16 * 128 + (((lane >> 4) ^ sw16) << 4);
+    xs[1] = xs[0] ^ 64;
+  }
 
-  f32x16 acc[4];
+  f32x4 acc[8][2];  // [16-row block of the wave's 128 rows][16-column block of its 32 columns]
 #pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = (f32x16){0};
-  half8 fa[4][2], fb[4];
+  for (int i = 0; i < 8; ++i) { acc[i][0] = (f32x4){0, 0, 0, 0}; acc[i][1] = (f32x4){0, 0, 0, 0}; }
+  half8 fa[2][4], fb[2][2];
 
 #define G128_LOAD_A(SLOT, H)                                                                            \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
-    const int ad = xk[kk] + ((SLOT) * 49152 + (H) * 16384 + wr * 8192);                                 \
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:4096"                               \
-                 : "=&v"(fa[kk][0]), "=&v"(fa[kk][1]) : "v"(ad) : "memory");                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+    const int ad = xs[ks] + ((SLOT) * 49152 + (H) * 16384 + wr * 8192);                                 \
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:2048\n\t"                          \
+                 "ds_read_b128 %2, %4 offset:4096\n\tds_read_b128 %3, %4 offset:6144"                   \
+                 : "=&v"(fa[ks][0]), "=&v"(fa[ks][1]), "=&v"(fa[ks][2]), "=&v"(fa[ks][3]) : "v"(ad) : "memory"); \
   }
 #define G128_LOAD_B(SLOT)                                                                               \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
-    const int ad = xk[kk] + ((SLOT) * 49152 + 32768 + wc * 4096);                                       \
-    asm volatile("ds_read_b128 %0, %1" : "=&v"(fb[kk]) : "v"(ad) : "memory");                           \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                    \
+    const int ad = xs[ks] + ((SLOT) * 49152 + 32768 + wc * 4096);                                       \
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2048"                              \
+                 : "=&v"(fb[ks][0]), "=&v"(fb[ks][1]) : "v"(ad) : "memory");                            \
   }
 #define G128_WAIT(VM)                                                                                   \
   asm volatile("s_waitcnt vmcnt(" #VM ")\n\ts_waitcnt lgkmcnt(0)"                                       \
-               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]),        \
-                 "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), \
-                 "+v"(fb[3])                                                                            \
+               : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fa[1][0]),        \
+                 "+v"(fa[1][1]), "+v"(fa[1][2]), "+v"(fa[1][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), \
+                 "+v"(fb[1][1])                                                                         \
                :: "memory")
 #define G128_MMA(H)                                                                                     \
-  asm volatile("" : "+v"(fb[0]), "+v"(fb[1]), "+v"(fb[2]), "+v"(fb[3]));                                \
+  asm volatile("" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]));                    \
   __builtin_amdgcn_sched_barrier(0);                                                                    \
   __builtin_amdgcn_s_setprio(1);                                                                        \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
-    acc[2 * (H)] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk], fa[kk][0], acc[2 * (H)], 0, 0, 0);    \
-    acc[2 * (H) + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[kk], fa[kk][1], acc[2 * (H) + 1], 0, 0, 0); \
-  }                                                                                                     \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                                     \
+      acc[4 * (H) + b][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ks][0], fa[ks][b], acc[4 * (H) + b][0], 0, 0, 0); \
+      acc[4 * (H) + b][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[ks][1], fa[ks][b], acc[4 * (H) + b][1], 0, 0, 0); \
+    }                                                                                                   \
   __builtin_amdgcn_s_setprio(0);                                                                        \
-  asm volatile("" : "+v"(acc[2 * (H)]), "+v"(acc[2 * (H) + 1]));                                        \
+  _Pragma("unroll") for (int b = 0; b < 4; ++b) asm volatile("" : "+v"(acc[4 * (H) + b][0]), "+v"(acc[4 * (H) + b][1])); \
   __builtin_amdgcn_sched_barrier(0)
 #define G128_BAR() do { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
   // (round 3: a phase's DMA is issued in the tail of its matrix slot, as in the 256 x 256 kernel; the wait at the end of a
@@ -1045,15 +1052,16 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
 #undef G128_WAIT
 #undef G128_MMA
 #undef G128_BAR
-  // epilogue: acc[i] is rows wr*128 + i*32 + row, cols wc*32 + (8g + 4hh .. +3); transposed through LDS like above
+  // epilogue: acc[i][j][e] is row wr*128 + 16 i + (lane & 15), column wc*32 + 16 j + 4 (lane >> 4) + e; transposed through LDS like above
+  const int row16 = lane & 15, q4 = lane >> 4;
   typedef _Float16 half4 __attribute__((ext_vector_type(4)));
   char* ep = smem + wave * G128_EP_BYTES;
   constexpr int BASE = ACT & 15;
   constexpr bool RS = (ACT & 16) != 0, RES = (ACT & 32) != 0;
-  float rs[4] = {1.f, 1.f, 1.f, 1.f};
+  float rs[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
   if constexpr (RS) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 32 + row];
+    for (int i = 0; i < 8; ++i) rs[i] = ((const float*)bias)[(size_t)tm * 256 + wr * 128 + i * 16 + row16];
   }
   half8 oldv[8];
   if constexpr (RES) {
@@ -1064,11 +1072,10 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
   if constexpr (BASE == 4) {  // raw fp32 products, no bias: the wave's 128 x 32 block as 128-byte rows (144-byte staging rows)
     char* ep4 = smem + wave * (128 * 144);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *(float4*)(ep4 + (i * 32 + row) * 144 + (8 * g + 4 * hh) * 4) =
-            make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]);
+      for (int j = 0; j < 2; ++j)
+        *(float4*)(ep4 + (i * 16 + row16) * 144 + (16 * j + 4 * q4) * 4) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     __builtin_amdgcn_wave_barrier();
     const int r8 = lane >> 3, c = lane & 7;
     float* Cw = (float*)C + (size_t)(tm * 256 + wr * 128) * N + tn * 128 + wc * 32 + c * 4;
@@ -1080,17 +1087,24 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
     return;
   }
   if constexpr (BASE == 3) {  // silu(gate)·up (see rarc_swiglu_f16): the wave's 32 columns are 16 features -> 32-byte rows
+    // (gate | up of a feature sit 32 lanes apart: one v_permlane32_swap per register pair, as in the 256 x 256 kernel)
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
-      for (int g = 0; g < 4; g += 2) {
-        const int nl = 8 * g + 4 * hh;
-        half4 bg = {0, 0, 0, 0}, bu = {0, 0, 0, 0};
-        if constexpr (!RS) { bg = *(const half4*)(bias + tn * 128 + wc * 32 + nl); bu = *(const half4*)(bias + tn * 128 + wc * 32 + nl + 8); }
-        half4 out;
+      for (int j = 0; j < 2; ++j) {
+        const int nl = j * 16 + 4 * q4;
+        half4 b4 = {0, 0, 0, 0};
+        if constexpr (!RS) b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
+        float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = rarc_swiglu_f16(acc[i][4 * g + e] * rs[i] + (float)bg[e], acc[i][4 * g + 4 + e] * rs[i] + (float)bu[e]);
-        *(half4*)(ep + (i * 32 + row) * G128_EP_STRIDE + (4 * g + 4 * hh) * 2) = out;
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * rs[i] + (float)b4[e];
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[2]));
+        asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[1]), "+v"(v[3]));
+        half2v out;
+        out[0] = rarc_swiglu_f16(v[0], v[2]);
+        out[1] = rarc_swiglu_f16(v[1], v[3]);
+        *(half2v*)(ep + (i * 16 + row16) * G128_EP_STRIDE + (j * 8 + 4 * (q4 & 1) + 2 * (q4 >> 1)) * 2) = out;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1105,20 +1119,20 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256x128_f16_kernel(const half
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 8; ++i) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nl = 8 * g + 4 * hh;
+    for (int j = 0; j < 2; ++j) {
+      const int nl = 16 * j + 4 * q4;
       half4 b4 = {0, 0, 0, 0};
       if constexpr (!RS) b4 = *(const half4*)(bias + tn * 128 + wc * 32 + nl);
       half4 out;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float v = acc[i][4 * g + e] * rs[i] + (float)b4[e];
+        float v = acc[i][j][e] * rs[i] + (float)b4[e];
         if (BASE == 1) v = rarc_gelu_erf(v);
         out[e] = (half_t)v;
       }
-      *(half4*)(ep + (i * 32 + row) * G128_EP_STRIDE + nl * 2) = out;
+      *(half4*)(ep + (i * 16 + row16) * G128_EP_STRIDE + nl * 2) = out;
     }
   }
   __builtin_amdgcn_wave_barrier();
