@@ -153,7 +153,9 @@ __device__ static inline int rarc_wave_find_from_top_256(uint32_t c0, uint32_t c
   uint32_t suf = mine;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_down(suf, d, 64);
+    // (the source lane is derived from the fresh lane id: __shfl_down's own six lane addresses are loop invariants of the
+    //  caller's scan loop, get hoisted out of it and cost six VGPRs there — or a spill — for a block that runs on wave 0 only)
+    const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + d) & 63) << 2, (int)suf);
     if (lane + d < 64) suf += o;
   }
   const unsigned long long ge = __builtin_amdgcn_ballot_w64(suf >= need);

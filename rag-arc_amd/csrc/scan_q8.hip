@@ -125,7 +125,23 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int row = lane & 31, h = lane >> 5;
-  const uint32_t qidx = wave * 32 + row;  // this lane's query
+  // Round 3, fp8 and int8-shadow rows (M16): the matrix work is v_mfma_i32_16x16x64_i8 on a 2 x 2 grid of 16 rows x 16 queries
+  // per wave instead of one chain of v_mfma_i32_32x32x32_i8.  Per MAC the smaller shape moves half the accumulator bytes for
+  // twice the (one-byte) operand bytes — 0.25 B instead of 0.31 B of register traffic — and these kernels sit at the board's
+  // power limit with the matrix pipe as their bound: same box, alternated, 100M rows: fp8 x 1024 30.4-30.7 -> 29.0-29.1 ms,
+  // int8 shadow x 768 22.1 -> 21.3-21.4 ms (profiles/r03_q8_mma16.txt).  fp16 rows keep the 32x32x32 chain: their scan is
+  // bound by the row fetch and the pruning, the regrouping below costs what the cooler MFMAs give back (27.2-27.3 vs 26.6-26.7 ms).
+  // The 16x16 MFMAs leave a lane with 2 x 4 scores of EACH of the queries q_lo and q_lo + 16; eight v_permlane32_swap
+  // (lane l <-> l + 32) regroup them so that a lane ends, as before, with 16 scores of ONE query — lanes 0-31 serve q_lo, lanes
+  // 32-63 q_lo + 16 — and everything after the MFMAs keeps one query's state per lane (two cost the registers that spilled, or
+  // LDS round trips in the pruning fast path: both were built and measured slower).
+  constexpr bool M16 = (FMT != 0);
+  const uint32_t q_lo = wave * 32 + (lane & 15);      // M16: the MFMA's two query blocks are q_lo (b = 0) and q_lo + 16 (b = 1)
+  const uint32_t qidx = M16 ? q_lo + 16 * (lane >> 5) : wave * 32 + row;  // this lane's query (M16: once the scores are regrouped)
+  const int rq = lane >> 4;                           // M16, MFMA layout: the lane's rows of a 16-row block are 4 rq .. 4 rq + 3
+  const int rql = rq & 1;                             // M16, regrouped: element 8 g + r is row 16 (r >> 2) + 4 (rql + 2 g) + (r & 3)
+  // position of accumulator element r inside the tile, minus the lane's first row (row0 below)
+  auto row_of = [&](uint32_t r) -> uint32_t { return M16 ? (r & 3) + 16 * ((r >> 2) & 1) + 8 * (r >> 3) : (r & 3) + 8 * (r >> 2); };
   const unsigned long long dbg_c0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long dbg_r0 = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
@@ -146,9 +162,18 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     s_hland[tid] = 0;
   }
 
-  // resident query fragments (B operand): lane holds Q8[qidx][32*ks + 16*h .. +16)
+  // resident query fragments (B operands).  32x32x32: lane holds Q8[qidx][32 ks + 16 h .. +16) in qf[ks];
+  // M16: Q8[q_lo + 16 b][64 s + 16 rq .. +16) in qf[2 s + b]
+  constexpr int KS2 = D / 64;
   i32x4 qf[KS];
-  {
+  if constexpr (M16) {
+    const int8_t* qp = p.q8 + (size_t)q_lo * D + 16 * rq;
+#pragma unroll
+    for (int ks = 0; ks < KS2; ++ks) {
+      qf[2 * ks] = *(const i32x4*)(qp + 64 * ks);
+      qf[2 * ks + 1] = *(const i32x4*)(qp + 16 * D + 64 * ks);
+    }
+  } else {
     const int8_t* qp = p.q8 + (size_t)qidx * D + 16 * h;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const i32x4*)(qp + 32 * ks);
@@ -173,7 +198,9 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
 #pragma unroll
     for (int j = 0; j < CPT; ++j) woff[j] = woff_of(j);
   }
-  const uint32_t aoff = row * L::RS + 16 * h;  // A fragment of k-step ks: + 32*ks
+  // A fragment: of k-step ks at + 32 ks; M16: of k step s, row block rb at + 64 s + 16 rb RS (a 16-lane group reads 16 rows: RS = D + 16
+  // puts them in 16 distinct bank groups)
+  const uint32_t aoff = M16 ? (lane & 15) * L::RS + 16 * rq : row * L::RS + 16 * h;
 
   const uint32_t t0 = p.t_begin + blockIdx.x, stride = gridDim.x;
   // the query this workgroup owns (publishes thresholds for), and the histogram word this lane
@@ -249,29 +276,75 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // other LDS buffer.  Unconditional: past the end of the shard the chunks are the tile-0 dummy.
   // (Two accumulators, or running waves w / w+4 of a SIMD in opposite phase order, changed cycles per
   // tile by a few per cent and the clock the other way: the kernel runs at its power limit.)
-  auto mfma_convert = [&](int buf, const Fetch& nx) -> i32x16 {
-    i32x16 c0 = {0};
+  auto mfma_convert = [&](int buf, const Fetch& nx) __attribute__((always_inline)) -> i32x16 {
     const char* a_base = smem + buf * L::TILE + aoff;
     char* dst = smem + (buf ^ 1) * L::TILE;
     const half_t s = q8_tile_scale(nx.meta.x);
-    // (D = 1024 fp8 with PF = 4 and/or one fetch group instead of two — 230-256 VGPRs, no spill — measured the same
-    //  15.7-15.9 ms per 50M rows as this: LDS prefetch depth is not what that kernel waits for)
-    constexpr int PF = (D <= 768) ? 4 : 2;
-    constexpr int CSTEP = KS / CPT;  // one chunk converted every CSTEP MFMAs (KS = 4·CPT for fp16, 8·CPT for fp8)
-    i32x4 a[PF];
-    if (!(ABL & 4)) {
-#pragma unroll
-      for (int i = 0; i < PF; ++i) a[i] = *(const i32x4*)(a_base + 32 * i);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    if constexpr (M16) {
+      i32x4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};  // [row block][query block]
+      // (D = 1024 fp8 with a deeper prefetch and/or one fetch group instead of two — 230-256 VGPRs, no spill — measured the same
+      //  15.7-15.9 ms per 50M rows as this: LDS prefetch depth is not what that kernel waits for)
+      constexpr int PF = (D <= 768) ? 2 : 1;     // k steps of 64 read ahead (two fragments each)
+      constexpr int CSTEP = KS2 / CPT;           // one chunk converted every CSTEP steps (KS2 = 4·CPT for fp8)
+      i32x4 a0[PF], a1[PF];
       if (!(ABL & 4)) {
-        c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks % PF], qf[ks], c0, 0, 0, 0);
-        if (ks + PF < KS) a[ks % PF] = *(const i32x4*)(a_base + 32 * (ks + PF));
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          a0[i] = *(const i32x4*)(a_base + 64 * i);
+          a1[i] = *(const i32x4*)(a_base + 16 * L::RS + 64 * i);
+        }
       }
-      if (ks % CSTEP == CSTEP / 2) convert_chunk(nx, ks / CSTEP, s, dst);
+#pragma unroll
+      for (int ks = 0; ks < KS2; ++ks) {
+        if (!(ABL & 4)) {
+          c00 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[ks % PF], qf[2 * ks], c00, 0, 0, 0);
+          c01 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[ks % PF], qf[2 * ks + 1], c01, 0, 0, 0);
+          c10 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[ks % PF], qf[2 * ks], c10, 0, 0, 0);
+          c11 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[ks % PF], qf[2 * ks + 1], c11, 0, 0, 0);
+          if (ks + PF < KS2) {
+            a0[ks % PF] = *(const i32x4*)(a_base + 64 * (ks + PF));
+            a1[ks % PF] = *(const i32x4*)(a_base + 16 * L::RS + 64 * (ks + PF));
+          }
+        }
+        if (ks % CSTEP == CSTEP / 2) convert_chunk(nx, ks / CSTEP, s, dst);
+      }
+      // as the MFMAs leave them: elements 0-7 = the lane's scores of query block 0 (rows 16 (r >> 2) + 4 rq + (r & 3)), 8-15 = block 1
+      return (i32x16){c00[0], c00[1], c00[2], c00[3], c10[0], c10[1], c10[2], c10[3],
+                      c01[0], c01[1], c01[2], c01[3], c11[0], c11[1], c11[2], c11[3]};
+    } else {
+      i32x16 c0 = {0};
+      constexpr int PF = (D <= 768) ? 4 : 2;
+      constexpr int CSTEP = KS / CPT;  // one chunk converted every CSTEP MFMAs (KS = 4·CPT for fp16)
+      i32x4 a[PF];
+      if (!(ABL & 4)) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) a[i] = *(const i32x4*)(a_base + 32 * i);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (!(ABL & 4)) {
+          c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[ks % PF], qf[ks], c0, 0, 0, 0);
+          if (ks + PF < KS) a[ks % PF] = *(const i32x4*)(a_base + 32 * (ks + PF));
+        }
+        if (ks % CSTEP == CSTEP / 2) convert_chunk(nx, ks / CSTEP, s, dst);
+      }
+      return c0;
     }
-    return c0;
+  };
+  // regroup (at the start of the pruning, not behind the last MFMA: group B prunes a tile one iteration after its MFMAs):
+  // swapping block 1 of lanes 0-31 with block 0 of lanes 32-63 leaves lanes 0-31 with sixteen scores of q_lo (their own block 0,
+  // and in elements 8-15 the block 0 of the lane 32 above: row quad rq + 2) and lanes 32-63 with sixteen of q_lo + 16 (in
+  // elements 0-7 the block 1 of the lane 32 below: row quad rq - 2, then their own): element 8 g + r = row
+  // 16 (r >> 2) + 4 (rql + 2 g) + (r & 3) on every lane.
+  // (the consumers are inline asm: the compiler's hazard recognizer does not place the MFMA-result -> VALU-read wait states
+  //  in front of them — without the s_nops the last MFMAs' registers were read stale: a handful of wrong candidates)
+  auto regroup = [&](i32x16& a) __attribute__((always_inline)) {
+    asm volatile("s_nop 15\n\ts_nop 3\n\t"
+                 "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\t"
+                 "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+                 "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                   "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
   };
 
   // one survivor straight to global memory (flush, and the overflow path of the staging buffer)
@@ -292,7 +365,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   uint32_t wcount = 0;  // wave-uniform: entries staged by this wave since the last flush
   uint64_t* my_skey = s_skey + wave * Q8_WSTAGE;
   uint8_t* my_sq = s_sq + wave * Q8_WSTAGE;
-  auto stage_q = [&](bool want, float a, uint32_t doc, uint32_t qq) {  // called by the whole wave (want: this lane has one)
+  auto stage_q = [&](bool want, float a, uint32_t doc, uint32_t qq) __attribute__((always_inline)) {  // called by the whole wave (want: this lane has one)
     const unsigned long long b = __builtin_amdgcn_ballot_w64(want);
     if (b == 0) return;
     const uint32_t pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
@@ -313,7 +386,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // parked scores one per lane once four slots (64 scores: a full wave) have gathered, before a flush, and at
   // the end.  LDS returns a wave's operations in order, so the reads see the writes.
   uint32_t tb_n = 0;  // wave-uniform: slots in use
-  auto drain = [&]() {
+  auto drain = [&]() __attribute__((always_inline)) {
     if (tb_n == 0) return;
     __builtin_amdgcn_wave_barrier();
     // (the lane index goes through an opaque copy: otherwise the slot address below is hoisted out of the scan loop
@@ -329,13 +402,13 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       const int sv = *(const int*)(sp + 4 * r);
       const i32x4 mt = *(const i32x4*)(sp + 64);
       const float a = (float)sv * __uint_as_float((uint32_t)mt[1]);
-      const uint32_t doc = (uint32_t)mt[3] + (r & 3) + 8 * (r >> 2);
+      const uint32_t doc = (uint32_t)mt[3] + row_of((uint32_t)r);
       stage_q(valid && a >= __uint_as_float((uint32_t)mt[0]) && doc < p.n_rows, a, doc, (uint32_t)mt[2]);
     }
     __builtin_amdgcn_wave_barrier();
     tb_n = 0;
   };
-  // lane holds 16 integer scores of its query: rows 8*(r>>2) + 4*h + (r&3) of the tile.
+  // lane holds 16 integer scores of its query: element r is row 8*(r>>2) + 4*h + (r&3) of the tile (M16: 16*((r>>2)&1) + 8*(r>>3) + 4*rql + (r&3)).
   // Fast path (every tile): max of (score << 4 | r) — the best score and where it sits — and one
   // compare.  When some lane's best clears its threshold, the wave counts per lane how many of the 16
   // scores clear a (conservative) integer threshold: when no lane has more than one — by far the usual
@@ -344,7 +417,9 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // `thr_in` already carries the tile's bonus: every row of tile t is within eps8 − hq·(R − R_t) of its approximate
   // score, so inside the tile the query's threshold may sit hq·(R − R_t) higher (an outlier tile anywhere in the
   // shard sets R; the typical tile is 1.5 - 2x better)
-  auto prune = [&](const i32x16& acc, uint32_t tile, float tinv, float tmw) {
+  auto prune = [&](const i32x16& acc_in, uint32_t tile, float tinv, float tmw) __attribute__((always_inline)) {
+    i32x16 acc = acc_in;
+    if constexpr (M16) regroup(acc);
     const float thr_g = thr;   // the query's threshold as published (flush compares against it)
     const float tsc = (float)q8_tile_scale(tmw);
     const float thr = __builtin_fmaf(my_hq, fmaxf(r_max - q8_tile_rt(tmw), 0.f), thr_g);
@@ -373,7 +448,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     }
     const unsigned long long pmask = __builtin_amdgcn_ballot_w64(pass);
     if (pmask != 0) {
-      const uint32_t row0 = tile * 32 + 4 * h;
+      const uint32_t row0 = tile * 32 + 4 * (M16 ? rql : h);
       const int np = __builtin_popcountll(pmask);
       if (np <= Q8_TB_SLOTS && !(ABL & 4096)) {
         // Usually one to three of the 64 lanes pass.  Instead of every lane walking its own 16 scores, the
@@ -410,13 +485,13 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         }
       }
       if (__builtin_amdgcn_ballot_w64(c > 1) == 0) {
-        const uint32_t doc = row0 + (rs & 3) + 8 * (rs >> 2);
+        const uint32_t doc = row0 + row_of(rs);
         stage_n(pass && doc < p.n_rows, (float)m * sc, doc);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float a = (float)acc[r] * sc;
-          const uint32_t doc = row0 + (r & 3) + 8 * (r >> 2);
+          const uint32_t doc = row0 + row_of((uint32_t)r);
           stage_n(a >= thr && doc < p.n_rows, a, doc);
         }
       }
@@ -425,7 +500,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   };
   // all threads; staged entries -> private candidate segments + global histogram.  Each wave drains
   // its own region (it knows its count; nothing to exchange), so no barrier is needed around it.
-  auto flush = [&]() {
+  auto flush = [&]() __attribute__((always_inline)) {
     drain();
     const uint32_t n = wcount < (uint32_t)Q8_WSTAGE ? wcount : (uint32_t)Q8_WSTAGE;
     for (uint32_t e0 = 0; e0 < n; e0 += 64) {  // wave-uniform trips: the threshold of an entry's query comes by shuffle
@@ -433,7 +508,8 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       const bool v = e < n;
       const uint32_t qq = v ? (uint32_t)my_sq[e] : qidx;
       const uint64_t key = v ? my_skey[e] : 0ull;
-      const float tcur = __shfl(thr, (int)(qq & 31u), 64);  // this wave's lanes l and l+32 hold query 32·wave + l
+      // query 32·wave + j sits on lanes j and j + 32; M16: on lanes (j & 15) + 32 (j >> 4) and 16 above
+      const float tcur = __shfl(thr, (int)(M16 ? (qq & 15u) + 2u * (qq & 16u) : (qq & 31u)), 64);
       const bool hot = (ABL & 16384) || rarc_candscore(key) >= tcur + p.hot_margin * s_eps8[qq];
       // (a survivor staged under an older, lower threshold that no longer clears the current one is dropped:
       //  the final threshold is at least the current one)
