@@ -56,6 +56,9 @@ struct ScanQ8Params {
   unsigned long long* dbg;  // tools/scan_q8_bench: {shader cycles, 100 MHz ticks} of workgroup 0; else null
 };
 
+#ifndef Q8_M16_FP16_ROWS
+#define Q8_M16_FP16_ROWS 0  // 1: fp16 rows on the 16x16x64 form as well (A/B builds)
+#endif
 constexpr int Q8_WAVES = 8;
 constexpr int Q8_THREADS = Q8_WAVES * 64;
 
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // (lane l <-> l + 32) regroup them so that a lane ends, as before, with 16 scores of ONE query — lanes 0-31 serve q_lo, lanes
   // 32-63 q_lo + 16 — and everything after the MFMAs keeps one query's state per lane (two cost the registers that spilled, or
   // LDS round trips in the pruning fast path: both were built and measured slower).
-  constexpr bool M16 = (FMT != 0);
+  constexpr bool M16 = (FMT != 0) || Q8_M16_FP16_ROWS;
   const uint32_t q_lo = wave * 32 + (lane & 15);      // M16: the MFMA's two query blocks are q_lo (b = 0) and q_lo + 16 (b = 1)
   const uint32_t qidx = M16 ? q_lo + 16 * (lane >> 5) : wave * 32 + row;  // this lane's query (M16: once the scores are regrouped)
   const int rq = lane >> 4;                           // M16, MFMA layout: the lane's rows of a 16-row block are 4 rq .. 4 rq + 3
@@ -336,10 +339,11 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // and in elements 8-15 the block 0 of the lane 32 above: row quad rq + 2) and lanes 32-63 with sixteen of q_lo + 16 (in
   // elements 0-7 the block 1 of the lane 32 below: row quad rq - 2, then their own): element 8 g + r = row
   // 16 (r >> 2) + 4 (rql + 2 g) + (r & 3) on every lane.
-  // (the consumers are inline asm: the compiler's hazard recognizer does not place the MFMA-result -> VALU-read wait states
-  //  in front of them — without the s_nops the last MFMAs' registers were read stale: a handful of wrong candidates)
+  // (inline asm consumers get no MFMA-result -> VALU-read wait states from the compiler's hazard recognizer — a first version
+  //  that swapped straight behind the last MFMA read its registers stale: a handful of wrong candidates.  Here the pruning's
+  //  fast path, compiler-scheduled VALU with its own hazard handling, has read every accumulator register before this runs.)
   auto regroup = [&](i32x16& a) __attribute__((always_inline)) {
-    asm volatile("s_nop 15\n\ts_nop 3\n\t"
+    asm volatile("v_nop\n\tv_nop\n\t"
                  "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\t"
                  "v_permlane32_swap_b32 %3, %11\n\tv_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
                  "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
@@ -419,7 +423,6 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // shard sets R; the typical tile is 1.5 - 2x better)
   auto prune = [&](const i32x16& acc_in, uint32_t tile, float tinv, float tmw) __attribute__((always_inline)) {
     i32x16 acc = acc_in;
-    if constexpr (M16) regroup(acc);
     const float thr_g = thr;   // the query's threshold as published (flush compares against it)
     const float tsc = (float)q8_tile_scale(tmw);
     const float thr = __builtin_fmaf(my_hq, fmaxf(r_max - q8_tile_rt(tmw), 0.f), thr_g);
@@ -435,6 +438,15 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         pm = v > pm ? v : pm;
       }
       m = pm >> 4;
+    } else if constexpr (M16) {
+      // the scores are still as the MFMAs left them (8 of q_lo, 8 of q_lo + 16 on every lane): the best score of the lane's
+      // query is the larger of its own half's maximum and its partner's (lane ^ 32) — ONE v_permlane32_swap of the two
+      // maxima instead of the eight that regroup the scores, which only the tiles with a passing lane go on to need
+      int mx = acc[0], my = acc[8];
+#pragma unroll
+      for (int r = 1; r < 8; ++r) { mx = acc[r] > mx ? acc[r] : mx; my = acc[8 + r] > my ? acc[8 + r] : my; }
+      asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(mx), "+v"(my));
+      m = mx > my ? mx : my;
     } else {
       m = acc[0];
 #pragma unroll
@@ -448,6 +460,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
     }
     const unsigned long long pmask = __builtin_amdgcn_ballot_w64(pass);
     if (pmask != 0) {
+      if constexpr (M16) regroup(acc);
       const uint32_t row0 = tile * 32 + 4 * (M16 ? rql : h);
       const int np = __builtin_popcountll(pmask);
       if (np <= Q8_TB_SLOTS && !(ABL & 4096)) {
