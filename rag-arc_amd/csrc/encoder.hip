@@ -274,20 +274,13 @@ __device__ __forceinline__ void gemm_store8_ss(half_t* p, const uint4 v, const h
 // ------------------------------------------------------------------------------------------
 // 256 x 256 x 64 tiles for the large GEMMs (QKV, FFN1 at M >= 8192): half the L2 -> LDS bytes per flop of the
 // 256 x 128 kernel above, and an explicit ping-pong between the two waves of every SIMD.
-//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. x cols wc*64.. of the tile: acc[4][2] 32x32 blocks.
+//   8 waves = 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. x cols wc*64.. of the tile: acc[8][4] blocks of 16 x 16
+//   (v_mfma_f32_16x16x32_f16; rounds 1-2: acc[4][2] blocks of 32 x 32).
 //   LDS 128 KiB = 2 parities x {A0, A1, B0, B1} x 16 KiB.  A "half" h of an operand holds, for every wave, half of
-//   ITS rows: A_h = rows {wr*128 + h*64 + r}, B_h = cols {wc*64 + h*32 + r} — so a K tile is consumed as four
-//   output QUADRANTS (A0B0, A0B1, A1B1, A1B0: one phase each, 8 MFMAs over the whole k = 64), each half is first
-//   needed in a different phase, and the next tile's halves are restaged one per phase, three phases (>= 1500
-//   cycles) ahead of their first read, with 16 KiB x 3 in flight and counted vmcnt waits (never 0 in steady state).
-//   A phase = [L: ds_read the new fragments, issue 2 LDS-DMA, wait] barrier [M: 8 MFMAs] barrier.  Waves 4-7
-//   run one barrier behind waves 0-3: while one group of a SIMD's two waves multiplies, the other loads.
-//   Ordering (every wave passes every barrier):
-//     RAW  a half staged in phase p is read in phase p+3 or later; every wave waits for its own share of all
-//          stages <= p-2 at the end of L(p) (vmcnt(4): the two newest stages may be in flight), a barrier before
-//          anyone's L(p+1) follows.
-//     WAR  a buffer is restaged >= 2 phases after its last ds_read, and readers wait for lgkmcnt(0) inside the
-//          slot that issued the read.
+//   ITS rows: A_h = rows {wr*128 + h*64 + r}, B_h = cols {wc*64 + h*32 + r}.  A K tile is four slots — load A0, B0, B1 |
+//   32 MFMAs (A0 x B0, A0 x B1) | load A1 | 32 MFMAs (A1 x B1, A1 x B0) — with the next tiles' halves restaged in the tails
+//   of the two matrix slots; waves 4-7 run one slot behind waves 0-3: while one of a SIMD's two waves multiplies, the
+//   other loads.  The slot structure, the staging schedule and the RAW / WAR argument are written out at G256_TILE2 below.
 // ------------------------------------------------------------------------------------------
 constexpr int G256_EP_STRIDE = 144, G256_EP_BYTES = 128 * G256_EP_STRIDE;  // epilogue staging, per wave
 constexpr int G256_LDS = 8 * G256_EP_BYTES > 131072 ? 8 * G256_EP_BYTES : 131072;
