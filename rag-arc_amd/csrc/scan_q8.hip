@@ -22,7 +22,7 @@
 //     LDS int8 tile (row stride D+16: the 16-lane groups of the A-fragment ds_read_b128 then hit 16
 //     distinct bank groups).  Two LDS tiles: convert(t+1) overlaps MFMA(t); one barrier per tile.
 //   * per tile and wave: D/32 v_mfma_i32_32x32x32_i8; lane l ends with 16 integer scores of query
-//     l&31.  Prune: integer max, one compare against the lane's threshold; survivors are appended to
+//     l&31.  (fp8 and int8-shadow rows: D/64 x 4 v_mfma_i32_16x16x64_i8 and a regrouping of the scores, see M16 in the kernel.)  Prune: integer max, one compare against the lane's threshold; survivors are appended to
 //     the workgroup's private segment of the query's candidate list and bump the query's histogram.
 //   * thresholds: thr[q] is a lower bound of (k-th best approx score) − 2·eps8[q], or of
 //     (a lower bound of the k-th best canonical score) − eps8[q]; both mean "a row below it cannot be
