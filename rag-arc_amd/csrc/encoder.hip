@@ -318,6 +318,11 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   const half_t* Ab = A + (size_t)tm * 256 * K;
   const half_t* Wb = W + (size_t)tn * 256 * K;
   const int KT = K / GK;
+  // (the eight offsets stay eight 32-bit registers: made opaque once per tile, or hipcc folds them into 64-bit per-lane
+  //  pointers `A + soff` outside the tile loop — sixteen registers, of which the ACT 96 instantiation spilled fourteen and
+  //  reloaded them, with vector-memory scratch loads, in front of every tile)
+#pragma unroll
+  for (int which = 0; which < 4; ++which) asm volatile("" : "+v"(soff[which][0]), "+v"(soff[which][1]));
 
   // staging: half-tile `which` (0 A0, 1 A1, 2 B0, 3 B1) of k tile kt into parity par; this wave's two KiB of it.
   // The lane's source offsets inside a tile fit 32 bits (256 rows x K halves) and do not depend on the tile: eight
@@ -480,11 +485,15 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   float rs[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) rs[i] = rs_pre[i];
+  // RES: the 16 old 16-byte pieces of the residual stream this lane adds into.  All 16 fetched here are 64 VGPRs next to the
+  // 128 accumulator registers still live — 16 of them spilled to scratch (round 3's shipped build).  The first eight
+  // go out now (their round trip hides under the conversion + transposition), the other eight once half of the accumulator
+  // blocks have been converted and their registers are free (their round trip hides under the rest and the first stores).
   half8 oldv[16];
+  const half_t* Co = C + (size_t)(tm * 256 + wr * 128 + (lane_e >> 3)) * N + tn * 256 + wc * 64 + (lane_e & 7) * 8;
   if constexpr (RES) {
-    const half_t* Co = C + (size_t)(tm * 256 + wr * 128 + (lane_e >> 3)) * N + tn * 256 + wc * 64 + (lane_e & 7) * 8;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) oldv[t] = *(const half8*)(Co + (size_t)(t * 8) * N);
+    for (int t = 0; t < 8; ++t) oldv[t] = *(const half8*)(Co + (size_t)(t * 8) * N);
   }
   if constexpr (BASE == 4) {  // raw fp32 products, no bias (the split-operand GEMMs of encoder_f32.hip): C is float [M][N]
     // the wave's 128 x 64 block goes through its 18 KiB of staging in two 32-column halves of 128-byte rows
@@ -542,6 +551,14 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
   } else {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    if constexpr (RES) {
+      if (i == 4) {   // acc[0..3] are dead: room for the second half of the old pieces (kept below the first half's conversion)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 8; t < 16; ++t) oldv[t] = *(const half8*)(Co + (size_t)(t * 8) * N);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int nl = j * 16 + 4 * q_e;  // column inside the wave's block

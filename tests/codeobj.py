@@ -1,0 +1,124 @@
+"""Read the gfx950 code objects out of librarc_hip.so (test infrastructure; no GPU needed).
+
+hipcc embeds one clang offload bundle per translation unit in the `.hip_fatbin` section of the host library.  This
+module cuts the gfx950 ELF images out of those bundles, reads their AMDGPU metadata notes (`llvm-readobj --notes`) and
+disassembles kernels (`llvm-objdump -d`), so that CPU tests can assert properties of the SHIPPED machine code: no
+scratch memory, no spilled VGPRs, and the instruction distances the hand-written hazard padding relies on.
+"""
+import os
+import re
+import struct
+import subprocess
+import tempfile
+from functools import lru_cache
+from typing import Dict, List
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "rag-arc_amd", "lib", "librarc_hip.so")
+_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def _tool(name: str) -> str:
+    path = os.path.join(LLVM_BIN, name)
+    if not os.path.exists(path):
+        raise FileNotFoundError(path)
+    return path
+
+
+@lru_cache(maxsize=4)
+def code_objects(lib_path: str = LIB) -> List[bytes]:
+    """The gfx950 ELF images embedded in the library, one per translation unit."""
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([_tool("llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat], check=True)
+        blob = open(fat, "rb").read()
+    out, pos = [], 0
+    while True:
+        i = blob.find(_MAGIC, pos)
+        if i < 0:
+            break
+        (count,) = struct.unpack_from("<Q", blob, i + len(_MAGIC))
+        p = i + len(_MAGIC) + 8
+        for _ in range(count):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, p)
+            p += 24
+            triple = blob[p:p + tlen].decode()
+            p += tlen
+            if "gfx950" in triple and size:
+                out.append(blob[i + off: i + off + size])
+        pos = i + len(_MAGIC)
+    return out
+
+
+_FIELD = re.compile(r"^\s*(?:-\s+)?\.([a-z_]+):\s+(.*)$")
+_WANTED = ("name", "vgpr_count", "agpr_count", "sgpr_count", "vgpr_spill_count", "sgpr_spill_count",
+           "private_segment_fixed_size", "group_segment_fixed_size", "max_flat_workgroup_size")
+
+
+@lru_cache(maxsize=4)
+def kernel_resources(lib_path: str = LIB) -> Dict[str, dict]:
+    """{mangled kernel name: {vgpr_count, agpr_count, sgpr_count, vgpr_spill_count, sgpr_spill_count,
+    private_segment_fixed_size, group_segment_fixed_size, ...}} for every kernel in the library."""
+    kernels: Dict[str, dict] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for n, image in enumerate(code_objects(lib_path)):
+            path = os.path.join(tmp, f"co{n}.o")
+            open(path, "wb").write(image)
+            text = subprocess.run([_tool("llvm-readobj"), "--notes", path], check=True, capture_output=True,
+                                  text=True).stdout
+            in_kernels, cur = False, None
+            for line in text.splitlines():
+                if line.strip() == "amdhsa.kernels:":
+                    in_kernels = True
+                    continue
+                if in_kernels and re.match(r"^\S", line.replace("\t", " ").lstrip(" ")) and line.startswith("amdhsa."):
+                    in_kernels = False
+                if not in_kernels:
+                    continue
+                # a new kernel entry begins at an item of the top-level list ("  - .agpr_count: ..."): two spaces of indent
+                if re.match(r"^  - \.", line):
+                    if cur and "name" in cur:
+                        kernels[cur["name"]] = cur
+                    cur = {}
+                m = _FIELD.match(line)
+                if m and cur is not None and m.group(1) in _WANTED and re.match(r"^ {2,4}(- )?\.", line):
+                    val = m.group(2).strip()
+                    cur[m.group(1)] = int(val) if re.fullmatch(r"-?\d+", val) else val.strip("'\"")
+            if cur and "name" in cur:
+                kernels[cur["name"]] = cur
+    return kernels
+
+
+def demangle(name: str) -> str:
+    try:
+        return subprocess.run([_tool("llvm-cxxfilt"), name], check=True, capture_output=True, text=True).stdout.strip()
+    except Exception:  # noqa: BLE001
+        return name
+
+
+@lru_cache(maxsize=64)
+def disassemble(kernel_substring: str, lib_path: str = LIB) -> Dict[str, List[str]]:
+    """{mangled name: [instruction text, ...]} for every kernel whose mangled name contains `kernel_substring`."""
+    out: Dict[str, List[str]] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for n, image in enumerate(code_objects(lib_path)):
+            if kernel_substring.encode() not in image:
+                continue
+            path = os.path.join(tmp, f"co{n}.o")
+            open(path, "wb").write(image)
+            text = subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", path], check=True,
+                                  capture_output=True, text=True).stdout
+            cur = None
+            for line in text.splitlines():
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", line)
+                if m:
+                    cur = m.group(1) if kernel_substring in m.group(1) and not m.group(1).endswith(".kd") else None
+                    if cur is not None:
+                        out[cur] = []
+                    continue
+                if cur is not None:
+                    ins = line.split("//")[0].strip()
+                    if ins:
+                        out[cur].append(ins)
+    return out
