@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 320 /* 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
+#define RARC_VERSION 400 /* 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
                             * rarc_enc_gemm_zero_bias; 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
                             * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
@@ -496,6 +496,42 @@ int rarc_lm_yes_no_logits_prefixed(const RarcLmModel* model, const int32_t* d_id
                                    int seq_len, const int32_t* d_prefix_of, const void* d_cache, int n_prefix,
                                    int prefix_len, const int32_t* d_prefix_start, int no_id, int yes_id, void* d_ws,
                                    size_t ws_bytes, uint16_t* d_out_f16, void* stream);
+
+/*
+ * Shard files: bulk movement of stored rows between a file and HBM — the native I/O behind save_local / load_local,
+ * counterpart of faiss.write_index / faiss.read_index at
+ *   encapsulation/database/vector_db/VectorStore_Faiss.py:438 (save_local :432-450) and :467 (load_local :452-482)
+ * for an index whose rows are resident in HBM.  A shard never exists as a host array: both calls stream
+ * `n_seg` byte ranges (file offset h_file_off[s], h_bytes[s] bytes <-> device offset h_dev_off[s] from d_base) through a
+ * ring of pinned host slots cut from h_staging (caller-owned PINNED memory, 4096-byte aligned; 2 * n_threads slots of
+ * staging_bytes / (2 n_threads) bytes, >= 64 KiB each).  n_threads workers each alternate file transfer and DMA (two slots
+ * per worker; the DMA is enqueued on `stream`), so disk and PCIe overlap and the host footprint is the ring whatever the
+ * shard size.
+ *   RARC_IO_DIRECT  also open the file O_DIRECT: chunks whose offset, length and slot are 4096-aligned bypass the page
+ *                   cache (storage DMA -> pinned slot -> GPU DMA); a file system without O_DIRECT is served buffered
+ *   RARC_IO_FSYNC   rarc_device_to_file: fsync before returning
+ * rarc_device_to_file creates the file if needed and never truncates it (the caller writes the header and the small
+ * sections itself — see the .rarc layout in DESIGN.md 3); rarc_file_to_device fails if the file is shorter than a segment.
+ * Both are synchronous (the bytes are in place on return; `stream` is drained).  d_capacity_bytes bounds every
+ * segment's device range.  `stats` (optional) receives what was moved and how fast.
+ */
+#define RARC_IO_DIRECT 1
+#define RARC_IO_FSYNC 2
+typedef struct RarcIoStats {
+  int64_t bytes;            /* bytes moved */
+  double seconds;           /* wall time of the call's transfer phase */
+  double file_seconds;      /* pread / pwrite time summed over the workers */
+  double copy_wait_seconds; /* time the workers waited for their DMA, summed */
+  int64_t direct_bytes;     /* of `bytes`, how many went through O_DIRECT */
+  int64_t n_chunks, slot_bytes;
+  int n_threads, direct;    /* direct: 1 if the O_DIRECT descriptor could be opened */
+} RarcIoStats;
+int rarc_file_to_device(const char* path, int n_seg, const int64_t* h_file_off, const int64_t* h_bytes,
+                        const int64_t* h_dev_off, void* d_base, int64_t d_capacity_bytes, void* h_staging,
+                        size_t staging_bytes, int n_threads, int flags, void* stream, RarcIoStats* stats);
+int rarc_device_to_file(const char* path, int n_seg, const int64_t* h_file_off, const int64_t* h_bytes,
+                        const int64_t* h_dev_off, const void* d_base, int64_t d_capacity_bytes, void* h_staging,
+                        size_t staging_bytes, int n_threads, int flags, void* stream, RarcIoStats* stats);
 
 /*
  * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan

@@ -45,6 +45,22 @@ def _mmr_select(scored, embeddings, query_embedding, k, lambda_mult=0.5):
     return [scored[i][0] for i in chosen]
 
 
+def _shard_files(folder: str, index_name: str) -> List[str]:
+    """Every shard file of `index_name` in the folder, whatever layout wrote it."""
+    import re
+
+    pat = re.compile(re.escape(index_name) + r"(\.r\d+of\d+)?\.rarc$")
+    return [os.path.join(folder, f) for f in sorted(os.listdir(folder)) if pat.fullmatch(f)]
+
+
+def _belongs_to(path: str, index_name: str, world: int) -> bool:
+    """Is `path` one of the files a save with `world` ranks writes?"""
+    base = os.path.basename(path)
+    if world == 1:
+        return base == f"{index_name}.rarc"
+    return any(base == f"{index_name}.r{r}of{world}.rarc" for r in range(world))
+
+
 class _QueryCoalescer:
     """Gathers the queries of CONCURRENT callers into one scan.
 
@@ -373,65 +389,107 @@ class HipFlatVectorStore(VectorStore):
         return self._engine_factory(dim, self._engine_metric(), self.device, self.storage)
 
     # ------------------------------------------------------------------ persistence
+    def _shard_layout(self) -> Tuple[int, int]:
+        """(rank, world size) of this process: a single-GPU store is rank 0 of 1."""
+        return 0, 1
+
+    def _barrier(self) -> None:
+        """All ranks of a sharded store meet here; nothing to do for one process."""
+
+    def _local_engine(self):
+        """The engine that holds THIS process's rows (the sharded store wraps it)."""
+        return self.index
+
+    def _local_blocks(self):
+        """Id map of the local rows, [(first global id, count)]; None = one block at the engine's id_base."""
+        return None
+
     def save_local(self, folder_path: str, index_name: str = "index") -> None:
-        """Flat shard file (64-byte header, raw rows — mmap-able —, then the row scales for fp8 storage)
-        + pickled docstore; cf. VectorStore_Faiss.py:432-450."""
+        """`<index_name>.rarc` (hip/shardfile.py: 64-byte header, page-aligned raw rows, fp8 row scales, id map) + the
+        pickled docstore and parameters, as the reference's `<index_name>.faiss` + `.pkl` (VectorStore_Faiss.py:432-450).
+        The rows stream HBM -> pinned ring -> file inside the library (rarc_device_to_file): no host copy of the corpus
+        exists, whatever its size.  The sharded store writes one file per rank (`<index_name>.r<rank>of<world>.rarc`)."""
+        from ....hip import shardfile as SF
+
         os.makedirs(folder_path, exist_ok=True)
-        shard = os.path.join(folder_path, f"{index_name}.rarc")
-        if self.index is not None and self.index.ntotal:
-            rows = self.index.rows
-            rows = rows.cpu().numpy() if hasattr(rows, "cpu") else np.asarray(rows)
-            f8 = self.storage == "f8"
-            code = {"f16": 0, "f8": 1, "f32": 2}[self.storage]
-            rows = np.ascontiguousarray(rows).view({0: np.float16, 1: np.uint8, 2: np.float32}[code])
-            header = np.array([0x43524152, 2, rows.shape[0], self.index.dim, rows.shape[1], code], dtype=np.int64)
-            tmp = shard + ".tmp"          # written aside and renamed: a crash never leaves a header without its rows
-            with open(tmp, "wb") as fh:
-                fh.write(header.tobytes())
-                fh.write(np.float32(self.index.max_norm).tobytes())
-                fh.write(b"\0" * (64 - header.nbytes - 4))
-                fh.write(rows.tobytes())
-                if f8:
-                    sc = self.index.row_scales
-                    sc = sc.cpu().numpy() if hasattr(sc, "cpu") else np.asarray(sc)
-                    fh.write(np.ascontiguousarray(sc, dtype=np.float32).tobytes())
-            os.replace(tmp, shard)
-        elif os.path.exists(shard):
+        rank, world = self._shard_layout()
+        mine = SF.shard_path(folder_path, index_name, rank, world)
+        if rank == 0:   # shard files of an earlier save under another layout must not survive next to this one
+            for old in _shard_files(folder_path, index_name):
+                if old != mine and not _belongs_to(old, index_name, world):
+                    os.unlink(old)
+        self._barrier()
+        eng = self._local_engine()
+        if eng is not None and self.ntotal:
+            self.last_save_stats = eng.save_shard(mine, blocks=self._local_blocks(), rank=rank, world=world,
+                                                  global_ntotal=self.ntotal)
+        elif os.path.exists(mine):
             # the reference always rewrites the index file (VectorStore_Faiss.py:438); an empty index must not
             # leave the rows of an earlier save behind for load_local to pick up next to an empty docstore
-            os.unlink(shard)
-        meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
-                "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2,
-                "storage": self.storage}
-        with open(os.path.join(folder_path, f"{index_name}.pkl"), "wb") as fh:
-            pickle.dump(meta, fh)
+            os.unlink(mine)
+        if rank == 0:
+            meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
+                    "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2,
+                    "storage": self.storage, "world": world, "ntotal": self.ntotal}
+            tmp = os.path.join(folder_path, f"{index_name}.pkl.tmp")
+            with open(tmp, "wb") as fh:
+                pickle.dump(meta, fh)
+            os.replace(tmp, os.path.join(folder_path, f"{index_name}.pkl"))
+        self._barrier()
 
     @classmethod
     def load_local(cls, folder_path: str, embeddings, index_name: str = "index", **kwargs: Any):
+        """Counterpart of FaissVectorStore.load_local (VectorStore_Faiss.py:452-482).  The rows stream file -> pinned ring ->
+        HBM (rarc_file_to_device).  A save made under ANOTHER layout loads too — eight rank files into one GPU, one file
+        into eight ranks: every process takes a contiguous range of the global ids and reads exactly those rows
+        (shardfile.plan_reshard); search results do not depend on the layout."""
+        from ....hip import shardfile as SF
+
         with open(os.path.join(folder_path, f"{index_name}.pkl"), "rb") as fh:
             meta = pickle.load(fh)
         kwargs.setdefault("storage", meta.get("storage", "f16"))
         store = cls(embedding=embeddings, index_type=meta["index_type"], metric=meta["metric"],
                     normalize_L2=meta["normalize_L2"], **kwargs)
         store.docstore, store.index_to_docstore_id = meta["docstore"], meta["index_to_docstore_id"]
-        path = os.path.join(folder_path, f"{index_name}.rarc")
-        if os.path.exists(path):
-            header = np.fromfile(path, dtype=np.int64, count=6)
-            if header[0] != 0x43524152 or header[1] not in (1, 2):
-                raise ValueError(f"{path}: not a rarc shard file")
-            n, dim, d_pad = int(header[2]), int(header[3]), int(header[4])
-            code = int(header[5]) if header[1] == 2 else 0
-            f8 = code == 1
-            stored = {0: "f16", 1: "f8", 2: "f32"}.get(code)
-            if stored != store.storage:
-                raise ValueError(f"{path}: stored as {stored}, store configured for {store.storage}")
-            max_norm = float(np.fromfile(path, dtype=np.float32, count=1, offset=48 if header[1] == 2 else 40)[0])
-            rows = np.memmap(path, dtype={0: np.float16, 1: np.uint8, 2: np.float32}[code], mode="r", offset=64,
-                             shape=(n, d_pad))
-            scales = np.fromfile(path, dtype=np.float32, count=n, offset=64 + n * d_pad) if f8 else None
-            store.index = store._make_engine(dim)
-            store.index.load_rows(rows, max_norm, row_scales=scales)
+        saved_world = int(meta.get("world", 1))
+        files = [SF.shard_path(folder_path, index_name, r, saved_world) for r in range(saved_world)]
+        files = [f for f in files if os.path.exists(f)]
+        if not files:
+            return store            # an empty index was saved (no shard file), as `index = None` in the reference (:467)
+        headers = [SF.read_header(f) for f in files]
+        for f, h in zip(files, headers):
+            if h.storage != store.storage:
+                raise ValueError(f"{f}: stored as {h.storage}, store configured for {store.storage}")
+        total_saved = sum(h.n_rows for h in headers)
+        if "ntotal" in meta and total_saved != int(meta["ntotal"]):
+            raise ValueError(f"{folder_path}: the shard files hold {total_saved} rows, the store was saved with {meta['ntotal']} "
+                             f"(a rank's file is missing?)")
+        store.index = store._make_engine(headers[0].dim)
+        rank, world = store._shard_layout()
+        eng = store._local_engine()
+        stats = []
+        if world == saved_world and len(files) == saved_world:
+            h = headers[rank]                       # same layout: this rank's own file, rows and id map as saved
+            stats.append(eng.load_shard(files[rank], header=h))
+            blocks, total = list(h.blocks), (h.global_ntotal if h.global_ntotal >= 0 else total_saved)
+        else:
+            segments, blocks, total = SF.plan_reshard([h.blocks for h in headers], rank, world)
+            run: list = []                           # consecutive segments of one file go through one native call
+            for seg in segments + [None]:
+                if run and (seg is None or seg[0] != run[0][0]):
+                    f = run[0][0]
+                    stats.append(eng.load_shard(files[f], row_ranges=[(a, c) for _, a, c in run], header=headers[f]))
+                    run = []
+                if seg is not None:
+                    run.append(seg)
+        store._adopt_loaded(blocks, total)
+        store.last_load_stats = stats
         return store
+
+    def _adopt_loaded(self, blocks, total: int) -> None:
+        """After load_local filled the local engine: a single-GPU store's rows ARE the global ids."""
+        if blocks and (len(blocks) != 1 or blocks[0][0] != getattr(self.index, "id_base", 0)):
+            raise ValueError("a single-GPU store holds one block of rows starting at its id base")
 
     @classmethod
     def from_texts(cls, texts, embedding, metadatas=None, *, ids=None, **kwargs: Any):

@@ -8,6 +8,9 @@ caller has it.
 
   add_texts   all ranks get the whole list; rank r embeds and stores rows [lo_r, hi_r) of it (hip.sharded.shard_range),
               every rank keeps the whole docstore (id -> Document: host memory, as in the reference)
+  save_local  every rank streams ITS rows into `<name>.r<rank>of<world>.rarc` (rank 0 also writes the docstore pickle);
+  load_local  every rank streams its rows back — from its own file when the world size is the one that saved, else from
+              whichever files hold its range of the global ids (hip/shardfile.plan_reshard)
   search      replicated query -> local exact top-k (global ids, canonical scores) -> ONE all-gather of (id, score)
               records over RCCL / xGMI -> merge by (score desc, id asc): bit-identical to the single-shard answer for
               every world size (canonical scores do not depend on the sharding)
@@ -163,6 +166,33 @@ class HipShardedFlatVectorStore(HipFlatVectorStore):
                                       "the candidates' texts, as the reference does")
         return super().max_marginal_relevance_search_by_vector(embedding, k, fetch_k, lambda_mult, **kwargs)
 
-    def save_local(self, folder_path: str, index_name: str = "index") -> None:
-        raise NotImplementedError("the sharded store does not persist its shards yet: build it from the corpus at start-up "
-                                  "(corpus_path of its config), or save a single-GPU HipFlatVectorStore")
+    # -- persistence: one shard file per rank (hip_flat.save_local / load_local do the work) ----------------------------
+    def _shard_layout(self):
+        import torch.distributed as dist
+
+        if self.index is not None:
+            return self.index.rank, self.index.world
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self._group), dist.get_world_size(self._group)
+        return 0, 1
+
+    def _barrier(self) -> None:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
+            dist.barrier(group=self._group)
+
+    def _local_engine(self):
+        return None if self.index is None else self.index.local
+
+    def _local_blocks(self):
+        return list(self.index._blocks)
+
+    def _adopt_loaded(self, blocks, total: int) -> None:
+        """load_local filled the local engine with this rank's rows: their global ids and the global row count."""
+        idx = self.index
+        if sum(c for _, c in blocks) != idx.local.ntotal:
+            raise ValueError("the id map of the loaded shard does not cover the rows that were loaded")
+        idx._blocks = [(int(g), int(c)) for g, c in blocks if c]
+        idx._l2g = None
+        idx.ntotal = int(total)

@@ -53,6 +53,17 @@ class Enc32Model(ctypes.Structure):
                 ("rel_bias", c_void_p), ("rel_span", c_int)]
 
 
+class IoStats(ctypes.Structure):
+    """RarcIoStats (include/rarc.h): what a shard-file transfer moved and how fast."""
+    _fields_ = [("bytes", c_int64), ("seconds", c_double), ("file_seconds", c_double), ("copy_wait_seconds", c_double),
+                ("direct_bytes", c_int64), ("n_chunks", c_int64), ("slot_bytes", c_int64), ("n_threads", c_int),
+                ("direct", c_int)]
+
+
+IO_DIRECT = 1
+IO_FSYNC = 2
+
+
 class LmLayer(ctypes.Structure):
     """RarcLmLayer (include/rarc.h): device pointers of one decoder layer."""
     _fields_ = [(n, c_void_p) for n in ("in_norm", "qkv_w", "q_norm", "k_norm", "o_w", "post_norm", "gate_up_w", "down_w",
@@ -147,6 +158,12 @@ SIGNATURES = {
     "rarc_lm_prefix_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "rarc_lm_yes_no_logits_prefixed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                                 c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "rarc_file_to_device": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
+                                    ctypes.POINTER(c_int64), c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p,
+                                    ctypes.POINTER(IoStats)]),
+    "rarc_device_to_file": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
+                                    ctypes.POINTER(c_int64), c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p,
+                                    ctypes.POINTER(IoStats)]),
     "rarc_profile_begin": (c_int, [c_int]),
     "rarc_profile_end": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),
 }

@@ -7,6 +7,7 @@ device memory and streams only; all arithmetic happens in the HIP kernels.
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Optional, Tuple
 
@@ -15,6 +16,8 @@ import numpy as np
 from . import binding as B
 
 _ROW_ALIGN = 32  # the scan reads whole 32-row tiles
+_IO_RING: dict = {}            # the process's pinned staging ring for shard files (FlatIndexF16._io_staging)
+_IO_LOCK = threading.Lock()    # one shard-file transfer at a time per process: they share the ring
 
 
 def _torch():
@@ -301,6 +304,125 @@ class FlatIndexF16:
             self._version += 1
             self.max_norm = max(self.max_norm, float(max_norm))
             self._requant(old)
+
+    # ------------------------------------------------------------------ shard files
+    IO_THREADS = 8
+    IO_STAGING_BYTES = 256 << 20   # pinned ring: 2 x IO_THREADS slots of 16 MiB; the host footprint of a save / load
+
+    def _io_staging(self, nbytes: Optional[int] = None):
+        """The pinned host ring for rarc_file_to_device / rarc_device_to_file: ONE per process (shared by every index;
+        _IO_LOCK serialises its users), sized exactly — torch's pinned allocator rounds requests up to a power of two."""
+        t = self.torch
+        nbytes = int(nbytes or self.IO_STAGING_BYTES)
+        buf = _IO_RING.get("buf")
+        if buf is None or buf.numel() < nbytes:
+            buf = t.empty(nbytes, dtype=t.uint8, pin_memory=True)
+            if buf.data_ptr() % 4096:       # (hipHostMalloc returns page-aligned memory; kept for other allocators)
+                buf = t.empty(2 * nbytes, dtype=t.uint8, pin_memory=True)
+                buf = buf[(-buf.data_ptr()) % 4096:]
+            _IO_RING["buf"] = buf
+        return buf[:nbytes]
+
+    def _io_call(self, fn_name: str, path: str, segs, tensor, threads, direct, fsync=False):
+        """One native transfer: segs = [(file offset, bytes, device offset in bytes from the tensor's start)]."""
+        import ctypes
+
+        if not segs:
+            return None
+        n = len(segs)
+        arr = lambda j: (ctypes.c_int64 * n)(*[int(sg[j]) for sg in segs])   # noqa: E731
+        stats = B.IoStats()
+        flags = (B.IO_DIRECT if direct else 0) | (B.IO_FSYNC if fsync else 0)
+        fn = getattr(self.lib, fn_name)
+        with _IO_LOCK:
+            staging = self._io_staging()
+            B.check(fn(os.fsencode(path), n, arr(0), arr(1), arr(2), tensor.data_ptr(), tensor.numel() * tensor.element_size(),
+                       staging.data_ptr(), staging.numel(), int(threads or self.IO_THREADS), flags, self._stream(),
+                       ctypes.byref(stats)), fn_name)
+        return dict(bytes=int(stats.bytes), seconds=float(stats.seconds), file_seconds=float(stats.file_seconds),
+                    copy_wait_seconds=float(stats.copy_wait_seconds), direct_bytes=int(stats.direct_bytes),
+                    n_chunks=int(stats.n_chunks), slot_bytes=int(stats.slot_bytes), n_threads=int(stats.n_threads),
+                    direct=int(stats.direct), gb_per_s=(stats.bytes / stats.seconds / 1e9 if stats.seconds > 0 else 0.0))
+
+    def save_shard(self, path: str, blocks=None, rank: int = 0, world: int = 1, global_ntotal: Optional[int] = None,
+                   threads: Optional[int] = None, direct: bool = True, fsync: bool = False) -> dict:
+        """Write this index's stored rows as a `.rarc` shard file (hip/shardfile.py), streaming HBM -> pinned ring -> file:
+        no host copy of the shard exists at any point.  Written aside and renamed, so a crash never leaves a header
+        without its rows.  `blocks`: the id map [(first global id, rows)] of the local rows (default: one block at id_base).
+        Returns the transfer statistics of the row section."""
+        from . import shardfile as SF
+
+        self._not_a_twin()
+        t = self.torch
+        with self._lock, t.cuda.device(self.device):
+            n = int(self.ntotal)
+            blocks = [(self.id_base, n)] if blocks is None else [(int(g), int(c)) for g, c in blocks]
+            if sum(c for _, c in blocks) != n:
+                raise ValueError("the id map must cover exactly the stored rows")
+            hdr = SF.ShardHeader(n, self.dim, self.d_pad, SF.CODES[self.storage], float(self.max_norm), int(rank), int(world),
+                                 int(n if global_ntotal is None else global_ntotal), blocks)
+            tmp = path + ".tmp"
+            with open(tmp, "wb") as fh:
+                fh.write(hdr.pack())
+                fh.truncate(hdr.file_bytes)        # sized once: the workers write into place
+            stats = None
+            if n:
+                stats = self._io_call("rarc_device_to_file", tmp, [(hdr.rows_offset, n * hdr.row_bytes, 0)], self._rows,
+                                      threads, direct, fsync)
+                if self.storage == "f8":
+                    self._io_call("rarc_device_to_file", tmp, [(hdr.scales_offset, 4 * n, 0)], self._rowscale, threads, direct,
+                                  fsync)
+            with open(tmp, "r+b") as fh:
+                fh.seek(hdr.idmap_offset)
+                fh.write(hdr.idmap_bytes())
+                if fsync:
+                    fh.flush()
+                    os.fsync(fh.fileno())
+            os.replace(tmp, path)
+            return stats or dict(bytes=0, seconds=0.0, gb_per_s=0.0)
+
+    def load_shard(self, path: str, row_ranges=None, header=None, threads: Optional[int] = None, direct: bool = False) -> dict:
+        """Append rows of a `.rarc` shard file to this index, streaming file -> pinned ring -> HBM (two slots per worker:
+        one being read into while the other's DMA runs).  `row_ranges`: [(first row in the file, count)] (default: all
+        rows).  `direct` (O_DIRECT reads) is off by default: measured on the GPU box a cold file loads at the storage's
+        20 GB/s either way, a file still in the page cache at 50 GB/s buffered but 20 GB/s direct
+        (profiles/r04_persist_rates.txt).  Returns the transfer statistics of the row section."""
+        from . import shardfile as SF
+
+        self._not_a_twin()
+        t = self.torch
+        hdr = header or SF.read_header(path)
+        if hdr.storage != self.storage:
+            raise ValueError(f"{path}: stored as {hdr.storage}, index configured for {self.storage}")
+        if hdr.d_pad != self.d_pad or hdr.dim != self.dim:
+            raise ValueError(f"{path}: rows are [{hdr.dim} -> {hdr.d_pad}], index is [{self.dim} -> {self.d_pad}]")
+        ranges = [(0, hdr.n_rows)] if row_ranges is None else [(int(a), int(c)) for a, c in row_ranges]
+        for a, c in ranges:
+            if a < 0 or c < 0 or a + c > hdr.n_rows:
+                raise ValueError(f"{path}: rows [{a}, {a + c}) outside the file's {hdr.n_rows}")
+        n_new = sum(c for _, c in ranges)
+        with self._lock, t.cuda.device(self.device):
+            old = self.ntotal
+            if n_new == 0:
+                return dict(bytes=0, seconds=0.0, gb_per_s=0.0)
+            self.reserve(old + n_new)
+            rb = hdr.row_bytes
+            segs, ssegs, at = [], [], old
+            for a, c in ranges:
+                if c:
+                    segs.append((hdr.rows_offset + a * rb, c * rb, at * rb))
+                    ssegs.append((hdr.scales_offset + 4 * a, 4 * c, 4 * at))
+                    at += c
+            stats = self._io_call("rarc_file_to_device", path, segs, self._rows, threads, direct)
+            if self.storage == "f8":
+                self._io_call("rarc_file_to_device", path, ssegs, self._rowscale, threads, direct)
+            if self.storage == "f32":   # the scan's image: the rows rounded to fp16 (round to nearest even)
+                self._image16[old: old + n_new].copy_(self._rows[old: old + n_new])
+            self.ntotal = old + n_new
+            self._version += 1
+            self.max_norm = max(self.max_norm, float(hdr.max_norm))
+            self._requant(old)
+            return stats
 
     def reset(self) -> None:
         self._not_a_twin()

@@ -106,6 +106,39 @@ class OracleIndex:
         self.ntotal = self._rows.shape[0]
         self.max_norm = max(self.max_norm, max_norm)
 
+    # the store's persistence interface towards its engine (hip/engine.py: save_shard / load_shard), served from host
+    # arrays here — this double lives in tests/ and never ships
+    id_base = 0
+
+    def save_shard(self, path, blocks=None, rank=0, world=1, global_ntotal=None, **_):
+        from rag_arc_amd.hip import shardfile as SF
+
+        n = self.ntotal
+        blocks = [(0, n)] if blocks is None else list(blocks)
+        hdr = SF.ShardHeader(n, self.dim, self.d_pad, SF.CODES["f16"], float(self.max_norm), rank, world,
+                             n if global_ntotal is None else global_ntotal, blocks)
+        with open(path + ".tmp", "wb") as fh:
+            fh.write(hdr.pack())
+            fh.truncate(hdr.file_bytes)
+            fh.seek(hdr.rows_offset)
+            fh.write(np.ascontiguousarray(self._rows).tobytes())
+            fh.seek(hdr.idmap_offset)
+            fh.write(hdr.idmap_bytes())
+        os.replace(path + ".tmp", path)
+        return dict(bytes=n * hdr.row_bytes, seconds=0.0, gb_per_s=0.0)
+
+    def load_shard(self, path, row_ranges=None, header=None, **_):
+        from rag_arc_amd.hip import shardfile as SF
+
+        hdr = header or SF.read_header(path)
+        assert hdr.storage == "f16" and hdr.d_pad == self.d_pad and hdr.dim == self.dim
+        rows = np.memmap(path, dtype=np.uint16, mode="r", offset=hdr.rows_offset, shape=(hdr.n_rows, hdr.d_pad))
+        for a, c in ([(0, hdr.n_rows)] if row_ranges is None else row_ranges):
+            self._rows = np.concatenate([self._rows, np.array(rows[a:a + c])])
+        self.ntotal = self._rows.shape[0]
+        self.max_norm = max(self.max_norm, hdr.max_norm)
+        return dict(bytes=0, seconds=0.0, gb_per_s=0.0)
+
     def reset(self):
         self._rows = np.zeros((0, self.d_pad), np.uint16)
         self.ntotal = 0

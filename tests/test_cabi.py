@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = B.load_library()
     for name in _declared():
         assert hasattr(lib, name), f"{name} missing from librarc_hip.so"
-    assert lib.rarc_version() == 320
+    assert lib.rarc_version() == 400
     assert lib.rarc_padded_dim(1) == 128 and lib.rarc_padded_dim(768) == 768 and lib.rarc_padded_dim(769) == 896
     assert lib.rarc_search_workspace_bytes(16384) > 256 * 16384 * 8
 
@@ -63,7 +63,8 @@ def test_model_structs_match_the_header(tmp_path):
     from rag_arc_amd.hip import binding as B
 
     pairs = [("RarcEncLayer", B.EncLayer), ("RarcEncModel", B.EncModel), ("RarcEnc32Layer", B.Enc32Layer),
-             ("RarcEnc32Model", B.Enc32Model), ("RarcLmLayer", B.LmLayer), ("RarcLmModel", B.LmModel)]
+             ("RarcEnc32Model", B.Enc32Model), ("RarcLmLayer", B.LmLayer), ("RarcLmModel", B.LmModel),
+             ("RarcIoStats", B.IoStats)]
     lines = []
     for cname, cls in pairs:
         lines.append(f'printf("%zu\\n", sizeof({cname}));')
