@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 400 /* 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
+#define RARC_VERSION 400 /* 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
                             * rarc_enc_gemm_zero_bias; 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
                             * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
@@ -496,6 +496,28 @@ int rarc_lm_yes_no_logits_prefixed(const RarcLmModel* model, const int32_t* d_id
                                    int seq_len, const int32_t* d_prefix_of, const void* d_cache, int n_prefix,
                                    int prefix_len, const int32_t* d_prefix_start, int no_id, int yes_id, void* d_ws,
                                    size_t ws_bytes, uint16_t* d_out_f16, void* stream);
+
+/*
+ * Batch WordPiece tokenisation on the host (no device involved) — what sits between the texts the reference hands to
+ * `SentenceTransformer.encode` (core/file_management/embeddings/huggingface.py:116-126) and the encoder forward above: the
+ * BERT tokeniser (native and multi-threaded in the reference's dependency too).  Same algorithm as the python restatement
+ * encapsulation/embeddings/wordpiece.py (pinned to transformers.BertTokenizer), for ASCII texts, on n_threads cores.
+ *   rarc_wordpiece_create   vocab_blob: the vocabulary's tokens separated by '\n', id = position (a vocab.txt image);
+ *                           never_split_blob: the SPECIAL tokens, '\n'-separated — cut out of the raw text wherever they
+ *                           occur, before anything else (unk / cls / sep / pad / mask and whatever else the caller lists);
+ *                           the handle is the one object this library allocates — release it with _destroy
+ *   rarc_wordpiece_encode   text i = bytes [text_offsets[i], text_offsets[i+1]) of text_blob;  h_ids [n_texts][ld_ids] int32
+ *                           receives [CLS] ids[: max_length - 2] [SEP] padded to max_length with the pad id, h_lens[i] the
+ *                           number of real ids — or -1 for a text with a byte >= 0x80, which is NOT tokenised here (its
+ *                           Unicode normalisation steps are left to the python tokeniser; row i is then untouched)
+ */
+typedef struct RarcWordPiece RarcWordPiece;
+int rarc_wordpiece_create(const char* vocab_blob, size_t blob_bytes, int do_lower_case, const char* unk_token,
+                          const char* cls_token, const char* sep_token, const char* pad_token, const char* never_split_blob,
+                          size_t never_split_bytes, int max_input_chars_per_word, RarcWordPiece** out);
+void rarc_wordpiece_destroy(RarcWordPiece* wp);
+int rarc_wordpiece_encode(const RarcWordPiece* wp, const char* text_blob, const int64_t* text_offsets, int n_texts,
+                          int max_length, int32_t* h_ids, int64_t ld_ids, int32_t* h_lens, int n_threads);
 
 /*
  * Shard files: bulk movement of stored rows between a file and HBM — the native I/O behind save_local / load_local,

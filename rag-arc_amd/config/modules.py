@@ -50,11 +50,17 @@ class HipBertEmbeddingsConfig(AbstractConfig):
     vocab_path: str
     num_heads: int
     normalize_embeddings: bool = True     # bge models: True (encode_kwargs={"normalize_embeddings": True})
-    pooling: Literal["cls", "mean"] = "cls"   # the checkpoint's sentence-transformers pooling module: bge = cls
+    # None = what the CHECKPOINT says, as SentenceTransformer(model_name) does (config.json, 1_Pooling/config.json,
+    # modules.json next to the weights), else the model family's: BERT / bge = cls + 1e-12, MPNet (all-mpnet-base-v2, the
+    # reference's default model) = mean + 1e-5 + normalised output
+    pooling: Optional[Literal["cls", "mean"]] = None
+    layer_norm_eps: Optional[float] = None
     do_lower_case: bool = True
     max_length: int = 512
-    batch_size: int = 32
-    layer_norm_eps: float = 1e-12
+    # sequences per encoder call; None = by token budget (max_batch_tokens), which keeps the GEMMs out of their
+    # latency-bound small-batch regime (32 sequences x 32 tokens run at a fifth of the large-batch rate)
+    batch_size: Optional[int] = None
+    max_batch_tokens: int = 65536
     device: int = 0
     # "fp32": the reference's arithmetic (SentenceTransformer loads fp32, huggingface.py:96-98) — split-operand MFMA GEMMs,
     # fp32 everywhere else; "fp16": the faster 1e-3-class forward (what model_kwargs={"torch_dtype": float16} would ask for)
@@ -67,19 +73,24 @@ class HipBertEmbeddingsConfig(AbstractConfig):
     prompt: Optional[str] = None
 
     def build(self) -> AbstractModule:
-        from ..encapsulation.embeddings.hip_bert import HipBertEmbeddings, HipBertEncoder, load_state_dict
+        from ..encapsulation.embeddings.hip_bert import (HipBertEmbeddings, HipBertEncoder, checkpoint_defaults,
+                                                         load_state_dict)
         from ..encapsulation.embeddings.wordpiece import WordPieceTokenizer
 
-        enc = HipBertEncoder(load_state_dict(self.weights_path), num_heads=self.num_heads,
-                             layer_norm_eps=self.layer_norm_eps, device=self.device, pooling=self.pooling,
+        sd = load_state_dict(self.weights_path)
+        auto = checkpoint_defaults(self.weights_path, sd)
+        eps = self.layer_norm_eps if self.layer_norm_eps is not None else auto["layer_norm_eps"]
+        pooling = self.pooling if self.pooling is not None else auto["pooling"]
+        enc = HipBertEncoder(sd, num_heads=self.num_heads, layer_norm_eps=eps, device=self.device, pooling=pooling,
                              precision=self.precision)
-        specials = dict(cls_token="<s>", sep_token="</s>", pad_token="<pad>", never_split=["<mask>", "<unk>"]) \
+        specials = dict(cls_token="<s>", sep_token="</s>", pad_token="<pad>", mask_token="<mask>") \
             if enc.model_type == "mpnet" else {}                       # MPNetTokenizer's specials over the same WordPiece
         tok = WordPieceTokenizer.from_file(self.vocab_path, do_lower_case=self.do_lower_case,
                                            max_length=min(self.max_length, enc.max_pos), **specials)
         return BuiltModule(config=self, impl=HipBertEmbeddings(enc, tok, max_length=self.max_length,
                                                                batch_size=self.batch_size,
-                                                               normalize_embeddings=self.normalize_embeddings,
+                                                               max_batch_tokens=self.max_batch_tokens,
+                                                               normalize_embeddings=self.normalize_embeddings or bool(auto["force_normalize"]),
                                                                pad_id=tok.pad, prompts=self.prompts,
                                                                default_prompt_name=self.default_prompt_name,
                                                                prompt_name=self.prompt_name, prompt=self.prompt))

@@ -33,6 +33,52 @@ def load_state_dict(path: str) -> Dict[str, "np.ndarray"]:
     raise ValueError(f"unsupported weight file (want .safetensors or .npz): {path}")
 
 
+def checkpoint_defaults(weights_path: Optional[str], state_dict) -> Dict[str, object]:
+    """What the checkpoint itself says about layer_norm_eps / pooling / output normalisation, for a provider configured
+    without them.  `SentenceTransformer(model_name)` (huggingface.py:96-98) takes all three from the checkpoint's files:
+    the transformer's config.json (`layer_norm_eps`), `1_Pooling/config.json` (`pooling_mode_*`) and the presence of a
+    Normalize module in modules.json; where those files are not next to the weights the model FAMILY decides — BERT
+    (bge): eps 1e-12, CLS pooling; MPNet (all-mpnet-base-v2, the reference's default model, huggingface.py:6): eps 1e-5,
+    mean pooling, normalised output.  BERT's defaults on an MPNet checkpoint give embeddings that are silently not the
+    reference's."""
+    import json
+    import os
+
+    names = list(state_dict)
+    mpnet = any(k.endswith("encoder.relative_attention_bias.weight") for k in names)
+    out: Dict[str, object] = dict(model_type="mpnet" if mpnet else "bert", layer_norm_eps=1e-5 if mpnet else 1e-12,
+                                  pooling="mean" if mpnet else "cls", force_normalize=bool(mpnet), source="model family")
+    folder = os.path.dirname(os.path.abspath(weights_path)) if weights_path else None
+    if not folder:
+        return out
+
+    def read(*parts):
+        path = os.path.join(folder, *parts)
+        if os.path.exists(path):
+            with open(path, encoding="utf-8") as fh:
+                return json.load(fh)
+        return None
+
+    cfg = read("config.json")
+    if cfg and "layer_norm_eps" in cfg:
+        out["layer_norm_eps"], out["source"] = float(cfg["layer_norm_eps"]), "checkpoint files"
+        if "num_attention_heads" in cfg:
+            out["num_heads"] = int(cfg["num_attention_heads"])
+    pool = read("1_Pooling", "config.json")
+    if pool:
+        if pool.get("pooling_mode_cls_token"):
+            out["pooling"] = "cls"
+        elif pool.get("pooling_mode_mean_tokens"):
+            out["pooling"] = "mean"
+        else:
+            raise ValueError(f"{folder}/1_Pooling/config.json asks for a pooling mode other than cls / mean")
+        out["source"] = "checkpoint files"
+    mods = read("modules.json")
+    if mods is not None:
+        out["force_normalize"] = any(str(m.get("type", "")).endswith("Normalize") for m in mods)
+    return out
+
+
 def _mpnet_bucket(delta, num_buckets=32, max_distance=128):
     """transformers' MPNetEncoder.relative_position_bucket for delta = key - query (float32 arithmetic as there): half the
     buckets per direction, exact below num_buckets / 4, logarithmic up to max_distance.  tests/test_mpnet_oracle.py pins the

@@ -158,6 +158,10 @@ SIGNATURES = {
     "rarc_lm_prefix_kv": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "rarc_lm_yes_no_logits_prefixed": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                                 c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "rarc_wordpiece_create": (c_int, [ctypes.c_char_p, c_size_t, c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                      ctypes.c_char_p, ctypes.c_char_p, c_size_t, c_int, ctypes.POINTER(c_void_p)]),
+    "rarc_wordpiece_destroy": (None, [c_void_p]),
+    "rarc_wordpiece_encode": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p, c_int]),
     "rarc_file_to_device": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
                                     ctypes.POINTER(c_int64), c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p,
                                     ctypes.POINTER(IoStats)]),

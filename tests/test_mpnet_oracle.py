@@ -59,6 +59,7 @@ def test_wordpiece_with_mpnet_specials_equals_transformers(tmp_path):
     vp.write_text("\n".join(words) + "\n")
     ref = MPNetTokenizer(str(vp))
     tok = WordPieceTokenizer.from_file(str(vp), cls_token="<s>", sep_token="</s>", pad_token="<pad>", unk_token="[UNK]",
-                                       never_split=["<mask>", "<unk>"])
-    for text in ["The quick brown fox jumps over the lazy dog.", "Unbelievable, café! abc 2024 xyz", "", "  a  ,b. "]:
+                                       mask_token="<mask>")
+    for text in ["The quick brown fox jumps over the lazy dog.", "Unbelievable, café! abc 2024 xyz", "", "  a  ,b. ",
+                 "the <mask> fox", "the<mask>fox <MASK> a<s>a</s> <unk> a<unk>b [UNK]a <pad>a <PAD>", "  <mask>  .<mask>"]:
         assert tok(text) == ref(text)["input_ids"], text
