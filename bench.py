@@ -69,6 +69,8 @@ def parse(argv=None):
                     help="config 5: embed batch i+1 on a side stream under the scan of batch i (measured: no gain on one GPU — "
                          "the persistent scan kernel holds every CU's whole register file, so the forward's kernels wait for it)")
     ap.add_argument("--no-c5-alt", action="store_true", help="config 5: skip the second timed loop in the other encoder precision")
+    ap.add_argument("--no-ingest", action="store_true", help="skip the ingest leg (texts -> tokeniser -> encoder -> stored rows)")
+    ap.add_argument("--ingest-docs", type=int, default=0, help="documents per ingest configuration (0 = sized for ~1-2 s each)")
     ap.add_argument("--verify-queries", type=int, default=256,
                     help="queries whose answer is re-checked by an exact canonical re-scan of the whole shard (eight queries "
                          "per pass over the rows: the default checks the whole batch, ~2 s at 100M rows)")
@@ -474,6 +476,10 @@ def main():
                     world, rank, local_rank, dev, use_dist)
         if rank == 0:
             result["c5"] = c5
+    # ---- ingest: texts -> host WordPiece -> encoder -> normalise / quantise / append, one GPU ----------
+    if world == 1 and not a.no_ingest and a.storage == "f16":
+        torch.cuda.empty_cache()
+        result["ingest"] = leg_ingest(torch, np, a, dev, local_rank)
     if rank == 0:
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if use_dist:
@@ -966,6 +972,143 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
     if sd_host is not None:
         out["cpu_baseline"] = cpu_baseline_c5(np, sd_host, tok_h, lens_h, HEADS, idx, emb0, K, fuse, lex)
         out["encoder_vs_host_fp32_forward"] = out["cpu_baseline"].pop("encoder_check")
+    return out
+
+
+INGEST_GEOMS = {"bge-base": dict(H=768, HEADS=12, FFN=3072, LAYERS=12), "bge-large": dict(H=1024, HEADS=16, FFN=4096, LAYERS=24)}
+
+
+def ingest_vocab(n_words=24000, n_tails=5000, seed=11):
+    """A synthetic uncased WordPiece vocabulary of BERT's size class (no vocabulary ships offline): specials, single
+    characters and their "##" forms, punctuation, `n_words` pseudo-words of 3-9 letters, `n_tails` "##" continuations."""
+    import random
+
+    rnd = random.Random(seed)
+    letters = "abcdefghijklmnopqrstuvwxyz"
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + list(letters) + ["##" + c for c in letters] + list("0123456789") + \
+            ["##" + c for c in "0123456789"] + list(".,;:!?()-'\"")
+    seen = set(vocab)
+    words, tails = [], []
+    while len(words) < n_words:
+        w = "".join(rnd.choice(letters) for _ in range(rnd.randint(3, 9)))
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    while len(tails) < n_tails:
+        w = "##" + "".join(rnd.choice(letters) for _ in range(rnd.randint(2, 5)))
+        if w not in seen:
+            seen.add(w)
+            tails.append(w)
+    return vocab + words + tails, words, [t[2:] for t in tails]
+
+
+def ingest_texts(n_docs, target_tokens, words, tails, seed):
+    """Word-salad documents of roughly `target_tokens` WordPiece tokens: vocabulary words, a fifth of them with a "##" tail
+    glued on, some capitalised, punctuation in between (every text runs into the max_length truncation, like real chunks
+    cut to the model's window)."""
+    import random
+
+    rnd = random.Random(seed)
+    out = []
+    for _ in range(n_docs):
+        parts, n = [], 0
+        while n < target_tokens + 8:
+            w = rnd.choice(words)
+            r = rnd.random()
+            if r < 0.2:
+                w, n = w + rnd.choice(tails), n + 1
+            if r > 0.9:
+                w = w.capitalize()
+            if r > 0.93:
+                w, n = w + rnd.choice(".,;!?"), n + 1
+            parts.append(w)
+            n += 1
+        out.append(" ".join(parts))
+    return out
+
+
+def leg_ingest(torch, np, a, dev, local_rank):
+    """SURVEY 8 f2 — `add_texts` (VectorStore_Faiss.py:156-210) with the HIP encoder as the provider
+    (huggingface.py:105-134): raw texts -> the library's WordPiece threads -> token-budget encoder calls (fp32-class
+    forward, the reference's precision; fp16 beside it) -> normalise + fp16 rows appended in HBM.  docs/s end to end, with
+    the tokeniser's share and the encoder's MFMA fraction (issued flops: the fp32-class forward runs 3x the model's GEMM
+    flops on the fp16 MFMA)."""
+    from rag_arc_amd.encapsulation.database.vector_db import HipFlatVectorStore
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEmbeddings, HipBertEncoder
+    from rag_arc_amd.encapsulation.embeddings.wordpiece import WordPieceTokenizer
+
+    vocab, words, tails = ingest_vocab()
+    out = {"unit": "documents/s", "path": "texts -> rarc_wordpiece_encode (host threads) -> rarc_enc32_forward / rarc_enc_forward -> "
+                                          "rarc_ingest_f16 + rarc_quant_meta_f16 (HipFlatVectorStore.add_texts)",
+           "vocabulary": f"synthetic, {len(vocab)} entries", "host_cpus": os.cpu_count(), "configs": []}
+    g = torch.Generator(device=dev)
+    g.manual_seed(17)
+
+    def rnd(*shape, scale=0.05):
+        return torch.randn(shape, generator=g, device=dev) * scale
+
+    for name, G in INGEST_GEOMS.items():
+        H, FFN, LAYERS = G["H"], G["FFN"], G["LAYERS"]
+        sd = {"embeddings.word_embeddings.weight": rnd(len(vocab), H), "embeddings.position_embeddings.weight": rnd(512, H),
+              "embeddings.token_type_embeddings.weight": rnd(2, H),
+              "embeddings.LayerNorm.weight": 1.0 + rnd(H), "embeddings.LayerNorm.bias": rnd(H)}
+        for i in range(LAYERS):
+            p = f"encoder.layer.{i}."
+            for nm, (o, c) in {"attention.self.query": (H, H), "attention.self.key": (H, H), "attention.self.value": (H, H),
+                               "attention.output.dense": (H, H), "intermediate.dense": (FFN, H), "output.dense": (H, FFN)}.items():
+                sd[p + nm + ".weight"], sd[p + nm + ".bias"] = rnd(o, c), rnd(o)
+            for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
+                sd[p + nm + ".weight"], sd[p + nm + ".bias"] = 1.0 + rnd(H), rnd(H)
+        gemm_flops_per_token = LAYERS * 2.0 * (4 * H * H + 2 * H * FFN)
+        for precision in ("fp32", "fp16"):
+            enc = HipBertEncoder(sd, num_heads=G["HEADS"], device=local_rank, precision=precision)
+            for L in (128, 512):
+                tok = WordPieceTokenizer({t: i for i, t in enumerate(vocab)}, max_length=L)
+                emb = HipBertEmbeddings(enc, tok, max_length=L, pad_id=tok.pad)
+                est = {"bge-base": 9000, "bge-large": 3000}[name] * (128 / L) * (3 if precision == "fp16" else 1)
+                n_docs = a.ingest_docs or int(max(512, min(16384, 1.5 * est)) // 256 * 256)
+                texts = ingest_texts(n_docs, L, words, tails, seed=L + len(name))
+                HipFlatVectorStore(emb).add_texts(texts[: min(n_docs, 512)])        # warm-up (allocations, first launches)
+                torch.cuda.synchronize()
+                store = HipFlatVectorStore(emb)
+                t0 = time.perf_counter()
+                store.add_texts(texts, ids=[str(i) for i in range(n_docs)])
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                st = dict(emb.last_stats)
+                # the encoder alone on the same token arrays (ids already tokenised): what the GPU side sustains
+                ids, lens = tok.encode_batch(texts)
+                order = np.argsort(-lens, kind="stable")
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for s0, e0 in emb._batches(lens[order]):
+                    sel = order[s0:e0]
+                    enc.forward(ids[sel, : int(lens[sel].max())], lens[sel], True, non_blocking=True)
+                torch.cuda.synchronize()
+                dt_enc = time.perf_counter() - t1
+                # the python tokeniser on a sample, for scale
+                t2 = time.perf_counter()
+                for x in texts[:64]:
+                    tok(x)
+                py_tok_s = sum(int(v) for v in lens[:64]) / (time.perf_counter() - t2)
+                issued = gemm_flops_per_token * st["padded_tokens"] * (3.0 if precision == "fp32" else 1.0)
+                out["configs"].append({
+                    "model": f"{name} geometry ({LAYERS} layers, hidden {H}), seeded weights", "precision": precision,
+                    "tokens_per_text": L, "documents": n_docs, "value": round(n_docs / dt, 1),
+                    "tokens_per_s": round(st["tokens"] / dt, 0), "encoder_calls": st["encoder_calls"],
+                    "sequences_per_call": round(n_docs / max(1, st["encoder_calls"]), 1),
+                    "tokenize_share": round(st["tokenize_seconds"] / dt, 3),
+                    "tokenizer_tokens_per_s": round(st["tokens"] / max(st["tokenize_seconds"], 1e-9), 0),
+                    "python_tokenizer_tokens_per_s": round(py_tok_s, 0),
+                    "encoder_only_documents_per_s": round(n_docs / dt_enc, 1),
+                    "encoder_mfma_TFLOPs_issued": round(issued / dt_enc / 1e12, 1),
+                    "encoder_mfma_frac_of_2500": round(issued / dt_enc / 1e12 / 2500.0, 4),
+                    "stored_rows": int(store.ntotal)})
+                del store, emb
+            del enc
+            torch.cuda.empty_cache()
+        del sd
+        torch.cuda.empty_cache()
     return out
 
 

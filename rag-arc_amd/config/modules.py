@@ -60,7 +60,7 @@ class HipBertEmbeddingsConfig(AbstractConfig):
     # sequences per encoder call; None = by token budget (max_batch_tokens), which keeps the GEMMs out of their
     # latency-bound small-batch regime (32 sequences x 32 tokens run at a fifth of the large-batch rate)
     batch_size: Optional[int] = None
-    max_batch_tokens: int = 65536
+    max_batch_tokens: int = 131072
     device: int = 0
     # "fp32": the reference's arithmetic (SentenceTransformer loads fp32, huggingface.py:96-98) — split-operand MFMA GEMMs,
     # fp32 everywhere else; "fp16": the faster 1e-3-class forward (what model_kwargs={"torch_dtype": float16} would ask for)

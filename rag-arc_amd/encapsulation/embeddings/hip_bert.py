@@ -217,7 +217,9 @@ class HipBertEncoder:
             t.cuda.current_stream(self.device).synchronize()     # w32 is released when this returns
         return w3, rw
 
-    def forward(self, input_ids, lengths=None, normalize: bool = True):
+    def forward(self, input_ids, lengths=None, normalize: bool = True, non_blocking: bool = False):
+        """`non_blocking`: the ids travel from PINNED host memory and the call returns as soon as the forward is enqueued
+        (the default copies from pageable memory, which makes the host wait for everything queued before it)."""
         t = self.torch
         ids = np.asarray(input_ids, dtype=np.int32)
         if ids.ndim != 2:
@@ -248,8 +250,12 @@ class HipBertEncoder:
         M, H, I = n_pad * L, self.hidden, self.inter
         with t.cuda.device(self.device):
             st = t.cuda.current_stream(self.device).cuda_stream
-            d_ids = t.from_numpy(np.ascontiguousarray(ids)).to(self.device)
-            d_lens = t.from_numpy(np.ascontiguousarray(lens)).to(self.device)
+            if non_blocking:   # (the pinned allocator keeps a block until the copy that reads it has completed)
+                d_ids = t.from_numpy(np.ascontiguousarray(ids)).pin_memory().to(self.device, non_blocking=True)
+                d_lens = t.from_numpy(np.ascontiguousarray(lens)).pin_memory().to(self.device, non_blocking=True)
+            else:
+                d_ids = t.from_numpy(np.ascontiguousarray(ids)).to(self.device)
+                d_lens = t.from_numpy(np.ascontiguousarray(lens)).to(self.device)
             need = int(self._ws_bytes(H, I, M))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = t.empty(need, dtype=t.uint8, device=self.device)
@@ -295,12 +301,20 @@ class HipBertEmbeddings(Embeddings):
     """Embeddings provider: tokenizer callable + HipBertEncoder."""
 
     def __init__(self, encoder: HipBertEncoder, tokenize: Callable[[str], Sequence[int]], max_length: int = 512,
-                 batch_size: int = 32, normalize_embeddings: bool = True, pad_id: int = 0,
+                 batch_size: Optional[int] = None, normalize_embeddings: bool = True, pad_id: int = 0,
                  prompts: Optional[Dict[str, str]] = None, default_prompt_name: Optional[str] = None,
-                 prompt_name: Optional[str] = None, prompt: Optional[str] = None, **kwargs):
+                 prompt_name: Optional[str] = None, prompt: Optional[str] = None, max_batch_tokens: int = 131072,
+                 tokenize_window: int = 4096, **kwargs):
         super().__init__(**kwargs)
         self.encoder, self.tokenize = encoder, tokenize
-        self.max_length, self.batch_size = min(max_length, encoder.max_pos), batch_size
+        self.max_length = min(max_length, encoder.max_pos)
+        # sequences per encoder call.  sentence-transformers' default is 32 (`encode(batch_size=32)`), which runs this
+        # encoder's GEMMs latency-bound (bge-large, 32 x 32 tokens: 3.76 ms, 256 x 32: 18.3 ms — a fifth of the rate);
+        # None = fill each call up to `max_batch_tokens` padded tokens instead (results do not depend on the batching
+        # beyond fp32 rounding, see embed_documents_device)
+        self.batch_size = None if batch_size is None else max(1, int(batch_size))
+        self.max_batch_tokens = max(128, int(max_batch_tokens))
+        self.tokenize_window = max(1, int(tokenize_window))   # texts tokenised per host call (ahead of the GPU)
         self.normalize, self.pad_id = normalize_embeddings, pad_id
         # sentence-transformers prompts, as the reference passes them (huggingface.py:26-37: model_kwargs
         # 'prompts' / 'default_prompt_name', encode_kwargs 'prompt_name' / 'prompt'): a string put in front of
@@ -311,26 +325,74 @@ class HipBertEmbeddings(Embeddings):
                 raise ValueError(f"prompt name {name!r} not found in the configured prompts {sorted(self.prompts)}")
         self.prompt = prompt if prompt is not None else self.prompts.get(prompt_name if prompt_name is not None
                                                                           else default_prompt_name, None)
+        self.last_stats: Dict[str, float] = {}
+
+    # -- host side: texts -> padded id arrays ----------------------------------------------------------------------
+    def _tokenize_many(self, texts: List[str]):
+        """(ids int32 [n][L], lens int32 [n]) of a list of texts: one call into the library's multi-threaded
+        tokeniser when the tokenizer offers `encode_batch` (wordpiece.WordPieceTokenizer does), else text by text."""
+        if hasattr(self.tokenize, "encode_batch"):
+            return self.tokenize.encode_batch(texts, max_length=self.max_length)
+        rows = [list(self.tokenize(x))[: self.max_length] or [self.pad_id] for x in texts]
+        lens = np.array([len(r) for r in rows], dtype=np.int32)
+        ids = np.full((len(rows), int(lens.max()) if rows else 1), self.pad_id, dtype=np.int32)
+        for r, row in enumerate(rows):
+            ids[r, : len(row)] = row
+        return ids, lens
+
+    def _batches(self, lens: "np.ndarray"):
+        """Cut a run of sequences (given in the order they will be embedded) into encoder calls: `batch_size` sequences
+        each, or as many as fit `max_batch_tokens` once padded to the call's longest (a multiple of 32)."""
+        n, s = len(lens), 0
+        while s < n:
+            if self.batch_size is not None:
+                e = min(n, s + self.batch_size)
+            else:
+                e, longest = s, 0
+                while e < n:
+                    longest_new = max(longest, -(-int(lens[e]) // 32) * 32)
+                    if e > s and (e + 1 - s) * longest_new > self.max_batch_tokens:
+                        break
+                    longest, e = longest_new, e + 1
+            yield s, e
+            s = e
 
     def embed_documents_device(self, texts: List[str]):
         """Same embeddings as embed_documents, left on the device as one fp32 tensor [n][hidden]
         (lets a device-resident store ingest them without the python-list round trip of
-        VectorStore_Faiss.py:169-170)."""
+        VectorStore_Faiss.py:169-170).
+
+        Pipeline: texts are sorted longest first (as sentence-transformers does), tokenised `tokenize_window` at a time by
+        the library's host threads, cut into encoder calls by token budget, and every call is only ENQUEUED — ids go up
+        from pinned memory without blocking — so the host tokenises window i + 1 while the GPU still runs the calls of
+        window i.  An embedding does not depend on its batch mates except through fp32 rounding: the GEMM kernels pick
+        tile shapes and split-K slabs by batch size, so the same text embedded alone or in a batch agrees to ~1e-6 in
+        L2, not bit for bit (tests/test_gpu_ingest.py pins that)."""
+        import time
+
         t = self.encoder.torch
         texts = [x.replace("\n", " ") for x in texts]
         if self.prompt:
             texts = [self.prompt + x for x in texts]
-        out = t.empty((len(texts), self.encoder.hidden), dtype=t.float32, device=self.encoder.device)
-        order = sorted(range(len(texts)), key=lambda i: -len(texts[i]))   # longest first, like sentence-transformers
-        for s in range(0, len(order), self.batch_size):
-            chunk = order[s:s + self.batch_size]
-            toks = [list(self.tokenize(texts[i]))[: self.max_length] or [self.pad_id] for i in chunk]
-            L = max(len(tk) for tk in toks)
-            ids = np.full((len(toks), L), self.pad_id, np.int32)
-            for r, tk in enumerate(toks):
-                ids[r, : len(tk)] = tk
-            emb = self.encoder.forward(ids, [len(tk) for tk in toks], self.normalize)
-            out[t.as_tensor(chunk, device=out.device)] = emb
+        n = len(texts)
+        if n == 0:
+            return t.empty((0, self.encoder.hidden), dtype=t.float32, device=self.encoder.device)
+        order = sorted(range(n), key=lambda i: -len(texts[i]))   # longest first, like sentence-transformers
+        parts, tok_s, calls, tokens, padded = [], 0.0, 0, 0, 0
+        for w0 in range(0, n, self.tokenize_window):
+            idx = order[w0: w0 + self.tokenize_window]
+            t0 = time.perf_counter()
+            ids, lens = self._tokenize_many([texts[i] for i in idx])
+            tok_s += time.perf_counter() - t0
+            for s, e in self._batches(lens):
+                L = int(lens[s:e].max())
+                parts.append(self.encoder.forward(ids[s:e, :L], lens[s:e], self.normalize, non_blocking=True))
+                calls, tokens, padded = calls + 1, tokens + int(lens[s:e].sum()), padded + (e - s) * (-(-L // 32) * 32)
+        cat = parts[0] if len(parts) == 1 else t.cat(parts)
+        out = t.empty_like(cat)
+        perm = t.from_numpy(np.asarray(order, dtype=np.int64)).pin_memory().to(cat.device, non_blocking=True)
+        out.index_copy_(0, perm, cat)
+        self.last_stats = dict(texts=n, encoder_calls=calls, tokens=tokens, padded_tokens=padded, tokenize_seconds=tok_s)
         return out
 
     def embed_documents(self, texts: List[str]) -> List[List[float]]:
