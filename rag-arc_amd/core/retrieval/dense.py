@@ -6,7 +6,7 @@ Unknown keyword arguments (e.g. the `top_k` that MultiPathRetriever leaks down) 
 the store untouched.  Errors are logged and re-raised.
 """
 import logging
-from typing import Any, Dict, List
+from typing import Any, Dict, List, Optional
 
 from ..utils.data_model import Document
 from .base import BaseRetriever
@@ -85,26 +85,77 @@ class VectorStoreRetriever(BaseRetriever):
             logger.error("async retrieval failed: %s", exc)
             raise
 
-    # ------------------------------------------------------------------ passthroughs
+    # ------------------------------------------------------------------ passthroughs (dense.py:219-330: logged, re-raised)
     def add_documents(self, documents: List[Document], **kwargs: Any) -> List[str]:
-        return self.vectorstore.add_documents(documents, **kwargs)
+        try:
+            ids = self.vectorstore.add_documents(documents, **kwargs)
+            logger.info("added %d documents to the vector store", len(documents))
+            return ids
+        except Exception as exc:
+            logger.error("adding documents failed: %s", exc)
+            raise
 
     async def aadd_documents(self, documents: List[Document], **kwargs: Any) -> List[str]:
-        return await self.vectorstore.aadd_documents(documents, **kwargs)
+        try:
+            ids = await self.vectorstore.aadd_documents(documents, **kwargs)
+            logger.info("added %d documents to the vector store (async)", len(documents))
+            return ids
+        except Exception as exc:
+            logger.error("adding documents failed (async): %s", exc)
+            raise
 
-    def delete_documents(self, ids: List[str], **kwargs: Any):
-        return self.vectorstore.delete(ids, **kwargs)
+    def delete_documents(self, ids: Optional[List[str]] = None, **kwargs: Any) -> Optional[bool]:
+        """ids = None deletes everything (dense.py:255-274)."""
+        try:
+            result = self.vectorstore.delete(ids, **kwargs)
+            logger.info("deleted %s documents", len(ids) if ids else "all")
+            return result
+        except Exception as exc:
+            logger.error("deleting documents failed: %s", exc)
+            raise
+
+    async def adelete_documents(self, ids: Optional[List[str]] = None, **kwargs: Any) -> Optional[bool]:
+        try:
+            result = await self.vectorstore.adelete(ids, **kwargs)
+            logger.info("deleted %s documents (async)", len(ids) if ids else "all")
+            return result
+        except Exception as exc:
+            logger.error("deleting documents failed (async): %s", exc)
+            raise
 
     def get_by_ids(self, ids: List[str]) -> List[Document]:
-        return self.vectorstore.get_by_ids(ids)
+        try:
+            return self.vectorstore.get_by_ids(ids)
+        except Exception as exc:
+            logger.error("get_by_ids failed: %s", exc)
+            raise
+
+    async def aget_by_ids(self, ids: List[str]) -> List[Document]:
+        try:
+            return await self.vectorstore.aget_by_ids(ids)
+        except Exception as exc:
+            logger.error("get_by_ids failed (async): %s", exc)
+            raise
 
     def get_vectorstore_info(self) -> Dict[str, Any]:
-        return {"vectorstore_type": type(self.vectorstore).__name__, "search_type": self.search_type,
-                "search_kwargs": dict(self.search_kwargs)}
+        info = {"vectorstore_class": self.vectorstore.__class__.__name__, "search_type": self.search_type,
+                "search_kwargs": self.search_kwargs, "allowed_search_types": list(self.allowed_search_types)}
+        if hasattr(self.vectorstore, "embeddings") and self.vectorstore.embeddings:
+            info["embedding_class"] = self.vectorstore.embeddings.__class__.__name__
+        elif hasattr(self.vectorstore, "embedding"):
+            info["embedding_class"] = self.vectorstore.embedding.__class__.__name__
+        return info
+
+    def get_name(self) -> str:
+        return f"{self.vectorstore.__class__.__name__}Retriever"
 
     def update_search_params(self, **kwargs: Any) -> None:
+        """Every keyword lands in search_kwargs — `search_type` too, besides switching the type (dense.py:357-370)."""
+        self.search_kwargs.update(kwargs)
         if "search_type" in kwargs:
-            self.search_type = kwargs.pop("search_type")
-        if "search_kwargs" in kwargs:
-            self.search_kwargs = kwargs.pop("search_kwargs")
-        self._validate_search_config()
+            self.search_type = kwargs["search_type"]
+            self._validate_search_config()
+
+    def __repr__(self) -> str:
+        return (f"{self.__class__.__name__}(vectorstore={self.vectorstore.__class__.__name__}, "
+                f"search_type='{self.search_type}', search_kwargs={self.search_kwargs})")

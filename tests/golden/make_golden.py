@@ -10,6 +10,8 @@ Pinned here:
   rrf.json        RRFusion.fuse                               core/utils/Fusion.py:45-76
   multipath.json  MultiPathRetriever._get_relevant_documents  core/retrieval/mutipath.py:37-93
   dense.json      VectorStoreRetriever (sync + async)         core/retrieval/dense.py:122-218
+  surface.json    VectorStore.search / asearch, the async twins, from_documents / afrom_*; the retriever's passthroughs
+                                                              VectorStoreBase.py:92-232, :444-627; core/retrieval/dense.py:219-380
   relevance.json  VectorStore.similarity_search_with_relevance_scores + score fns
                                                               VectorStoreBase.py:263-273, :347-392
   cosine.json     spliter.cosine_similarity (numpy branch)    core/file_management/chunker/spliter.py:307-332
@@ -194,6 +196,19 @@ def main():
     run_dense("mmr", {"k": 3, "fetch_k": 6}, {})
     run_dense("bogus", {}, {})
     json.dump(dense_cases, open(os.path.join(OUT, "dense.json"), "w"), indent=0)
+
+    # ------------------------------------------------------------------ the rest of the store / retriever surface
+    # VectorStore.search / asearch dispatch, the async twins (adelete, aget_by_ids, asimilarity_search_by_vector,
+    # amax_marginal_relevance_search(_by_vector), aadd_documents), from_documents / afrom_documents / afrom_texts, and the
+    # retriever's adelete_documents / aget_by_ids / get_vectorstore_info / get_name / update_search_params / repr
+    # (VectorStoreBase.py:92-232, :444-627; core/retrieval/dense.py:219-380), over a store that records its calls.
+    # Where the reference's own plumbing fails (run_in_executor takes no keyword arguments; add_texts' keyword-only `ids`
+    # passed positionally) the recorded outcome is that error.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))      # repo root (tests.helpers imports the oracle package)
+    from tests.helpers import make_recording_store, run_surface_ops
+    Recording = make_recording_store(VectorStore)
+    surface = run_surface_ops(Document, Recording, VectorStoreRetriever, scored)
+    json.dump(surface, open(os.path.join(OUT, "surface.json"), "w"), indent=0, default=str)
 
     # ------------------------------------------------------------------ relevance score quirk
     rel = {"fns": [], "threshold": []}

@@ -272,3 +272,142 @@ CHUNKER_CASES = (
     {"breakpoint_threshold_type": "percentile", "breakpoint_threshold_amount": 50, "min_chunk_size": 120},
 )
 CHUNKER_SHORT_TEXTS = ("One sentence only.", "Two sentences here. That is all.", "")
+
+
+# ---- the store / retriever surface: one script of operations, run by tests/golden/make_golden.py over the REFERENCE's
+# classes (the outcomes are tests/golden/surface.json) and by tests/test_surface_golden.py over this repo's mirror ----------
+def make_recording_store(VectorStoreBase):
+    """A VectorStore over `VectorStoreBase` (the reference's ABC, or the mirror's) that records every call it receives."""
+
+    class Recording(VectorStoreBase):
+        def __init__(self, scored=None, relevance="cosine", **kw):
+            super().__init__()
+            self.scored, self.calls, self.relevance, self.init_kw = (scored if scored is not None else []), [], relevance, kw
+
+        def similarity_search(self, query, k=4, **kwargs):
+            self.calls.append(["similarity_search", query, k, dict(kwargs)])
+            return [d for d, _ in self.scored][:k]
+
+        def similarity_search_with_score(self, query, k=4, **kwargs):
+            self.calls.append(["similarity_search_with_score", query, k, dict(kwargs)])
+            return self.scored[:k]
+
+        def max_marginal_relevance_search(self, query, k=4, fetch_k=20, lambda_mult=0.5, **kwargs):
+            self.calls.append(["max_marginal_relevance_search", query, k, fetch_k, lambda_mult, dict(kwargs)])
+            return [d for d, _ in self.scored][::-1][:k]
+
+        def _select_relevance_score_fn(self):
+            return {"cosine": self._cosine_relevance_score_fn, "ip": self._max_inner_product_relevance_score_fn,
+                    "l2": self._euclidean_relevance_score_fn}[self.relevance]
+
+        def add_texts(self, texts, metadatas=None, *, ids=None, **kwargs):
+            self.calls.append(["add_texts", list(texts), metadatas, ids, dict(kwargs)])
+            return list(ids) if ids else [f"gen{i}" for i, _ in enumerate(texts)]
+
+        def delete(self, ids=None, **kwargs):
+            self.calls.append(["delete", ids, dict(kwargs)])
+            return True if ids != ["nope"] else False
+
+        def get_by_ids(self, ids):
+            self.calls.append(["get_by_ids", list(ids)])
+            return [d for d, _ in self.scored if d.id in ids]
+
+        def similarity_search_by_vector(self, embedding, k=4, **kwargs):
+            self.calls.append(["similarity_search_by_vector", list(embedding), k, dict(kwargs)])
+            return [d for d, _ in self.scored][:k]
+
+        def max_marginal_relevance_search_by_vector(self, embedding, k=4, fetch_k=20, lambda_mult=0.5, **kwargs):
+            self.calls.append(["max_marginal_relevance_search_by_vector", list(embedding), k, fetch_k, lambda_mult, dict(kwargs)])
+            return [d for d, _ in self.scored][::-1][:k]
+
+        @classmethod
+        def from_texts(cls, texts, embedding, metadatas=None, *, ids=None, **kwargs):
+            st = cls(**kwargs)
+            st.calls.append(["from_texts", list(texts), embedding, metadatas, ids])
+            return st
+
+    return Recording
+
+
+def run_surface_ops(Document, Recording, Retriever, scored):
+    """Run the script; returns [{op, result, error, calls}] (JSON-able)."""
+    import asyncio
+    import warnings
+
+    surface = []
+
+    def record(name, fn, is_async=False, show=lambda r: r):
+        st = Recording(scored)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter("always")
+            try:
+                res = asyncio.run(fn(st)) if is_async else fn(st)
+                out, err = show(res), None
+            except Exception as e:   # noqa: BLE001
+                out, err = None, type(e).__name__
+        surface.append({"op": name, "result": out, "error": err, "calls": st.calls})
+
+    names = lambda docs_: [d.content for d in docs_]   # noqa: E731
+    for stype in ("similarity", "similarity_score_threshold", "mmr", "bogus"):
+        record(f"search:{stype}", lambda st, t=stype: st.search("q", t, k=3), show=names)
+        record(f"asearch:{stype}", lambda st, t=stype: st.asearch("q", t, k=3), is_async=True, show=names)
+    record("search:threshold_kw", lambda st: st.search("q", "similarity_score_threshold", k=8, score_threshold=0.5), show=names)
+    record("asearch:threshold_kw", lambda st: st.asearch("q", "similarity_score_threshold", k=8, score_threshold=0.5),
+           is_async=True, show=names)
+    record("asearch:similarity_extra_kw", lambda st: st.asearch("q", "similarity", k=2, top_k=9), is_async=True, show=names)
+    record("adelete:ids", lambda st: st.adelete(["1", "2"]), is_async=True)
+    record("adelete:none", lambda st: st.adelete(), is_async=True)
+    record("adelete:missing", lambda st: st.adelete(["nope"]), is_async=True)
+    record("adelete:kw", lambda st: st.adelete(["1"], soft=True), is_async=True)
+    record("aget_by_ids", lambda st: st.aget_by_ids(["1", "3", "zzz"]), is_async=True, show=names)
+    record("asimilarity_search_by_vector", lambda st: st.asimilarity_search_by_vector([0.5, 0.25], 2), is_async=True, show=names)
+    record("asimilarity_search_by_vector:kw", lambda st: st.asimilarity_search_by_vector([0.5, 0.25], k=2), is_async=True, show=names)
+    record("asimilarity_search_by_vector:extra_kw", lambda st: st.asimilarity_search_by_vector([0.5], 2, flag=1), is_async=True, show=names)
+    record("amax_marginal_relevance_search", lambda st: st.amax_marginal_relevance_search("q", 2, 6, 0.25), is_async=True, show=names)
+    record("amax_marginal_relevance_search:kw", lambda st: st.amax_marginal_relevance_search("q", k=2, fetch_k=6), is_async=True, show=names)
+    record("amax_marginal_relevance_search_by_vector", lambda st: st.amax_marginal_relevance_search_by_vector([1.0, 0.0], 3, 7, 0.75),
+           is_async=True, show=names)
+    record("amax_marginal_relevance_search_by_vector:kw", lambda st: st.amax_marginal_relevance_search_by_vector([1.0], k=3),
+           is_async=True, show=names)
+    some = [Document(content="t0", metadata={"a": 1}, id="i0"), Document(content="t1", metadata={}, id=None)]
+    none = [Document(content="u0", metadata={}, id=None), Document(content="u1", metadata={"b": 2}, id=None)]
+    record("add_documents:some_ids", lambda st: st.add_documents(some))
+    record("add_documents:no_ids", lambda st: st.add_documents(none))
+    record("add_documents:kw_ids", lambda st: st.add_documents(some, ids=["x", "y"]))
+    record("aadd_documents:some_ids", lambda st: st.aadd_documents(some), is_async=True)
+    record("aadd_documents:kw_ids", lambda st: st.aadd_documents(some, ids=["x", "y"]), is_async=True)
+    record("aadd_texts", lambda st: st.aadd_texts(["p", "q"], [{}, {}], ids=["1", "2"]), is_async=True)
+    made = lambda st: st.calls + [["init_kw", st.init_kw]]   # noqa: E731
+    record("from_documents:some_ids", lambda _: Recording.from_documents(some, "EMB"), show=made)
+    record("from_documents:no_ids", lambda _: Recording.from_documents(none, "EMB"), show=made)
+    record("from_documents:kw_ids", lambda _: Recording.from_documents(some, "EMB", ids=["x", "y"]), show=made)
+    record("afrom_documents:some_ids", lambda _: Recording.afrom_documents(some, "EMB"), is_async=True, show=made)
+    record("afrom_documents:no_ids", lambda _: Recording.afrom_documents(none, "EMB"), is_async=True, show=made)
+    record("afrom_texts:ids", lambda _: Recording.afrom_texts(["p", "q"], "EMB", [{"m": 1}, {}], ids=["1", "2"]), is_async=True, show=made)
+    record("afrom_texts:no_ids", lambda _: Recording.afrom_texts(["p", "q"], "EMB"), is_async=True, show=made)
+    record("afrom_texts:extra_kw", lambda _: Recording.afrom_texts(["p"], "EMB", relevance="ip"), is_async=True, show=made)
+
+    def with_retriever(fn, **rkw):
+        return lambda st: fn(Retriever(st, **rkw))
+
+    record("retriever.delete_documents", with_retriever(lambda r: r.delete_documents(["1"])))
+    record("retriever.delete_documents:none", with_retriever(lambda r: r.delete_documents()))
+    record("retriever.adelete_documents", with_retriever(lambda r: r.adelete_documents(["1", "2"])), is_async=True)
+    record("retriever.adelete_documents:none", with_retriever(lambda r: r.adelete_documents()), is_async=True)
+    record("retriever.get_by_ids", with_retriever(lambda r: r.get_by_ids(["2", "zzz"])), show=names)
+    record("retriever.aget_by_ids", with_retriever(lambda r: r.aget_by_ids(["2", "5"])), is_async=True, show=names)
+    record("retriever.add_documents", with_retriever(lambda r: r.add_documents(some)))
+    record("retriever.aadd_documents", with_retriever(lambda r: r.aadd_documents(some)), is_async=True)
+    record("retriever.get_vectorstore_info", with_retriever(lambda r: r.get_vectorstore_info(), search_kwargs={"k": 3}))
+    record("retriever.get_name", with_retriever(lambda r: r.get_name()))
+    record("retriever.repr", with_retriever(lambda r: repr(r), search_type="mmr", search_kwargs={"k": 2}))
+
+    def upd(r, **kw):
+        r.update_search_params(**kw)
+        return {"search_type": r.search_type, "search_kwargs": r.search_kwargs}
+
+    record("retriever.update_search_params:k", with_retriever(lambda r: upd(r, k=7), search_kwargs={"k": 3}))
+    record("retriever.update_search_params:type", with_retriever(lambda r: upd(r, search_type="mmr", fetch_k=9)))
+    record("retriever.update_search_params:bad_type", with_retriever(lambda r: upd(r, search_type="bogus")))
+    record("retriever.update_search_params:threshold_missing", with_retriever(lambda r: upd(r, search_type="similarity_score_threshold")))
+    return surface
