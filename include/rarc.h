@@ -198,7 +198,9 @@ int rarc_repair_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int d_pad, con
  * d_ids / d_scores ([256][k] rows of the batch).  d_counts[i] includes the k - 1 better entries of the answer itself
  * when they are real rows, so an exact answer gives d_counts[i] == (number of valid entries among its first k - 1).
  * A row is read once for all nq queries: the whole batch of 256 is checked against an exact scan in 32 passes.
- * d_counts has SIXTEEN words: d_counts[8 + i] = the rows at or above the k-th entry whose (id, canonical score) pair is an
+ * d_counts has TWENTY-FOUR words (ABI 400; it was sixteen): d_counts[16 + i] = rows at or above the k-th entry that were
+ * not looked up because one thread had met 64 of them for that query already (> 0 means the pair count is a lower bound:
+ * "check truncated", not "answer wrong").  d_counts[8 + i] = the rows at or above the k-th entry whose (id, canonical score) pair is an
  * entry of the answer BIT FOR BIT — an exact answer gives d_counts[8 + i] == (number of valid entries among all k): an entry
  * with a wrong score, a wrong id or a row that does not reach the k-th key is not counted.  (An all-padding answer, k-th id
  * -1, is not pair-checked: d_counts[8 + i] stays 0.)

@@ -66,8 +66,10 @@ class VectorStoreRetriever(BaseRetriever):
         try:
             return [docs[:k] for docs in batched(list(inputs), **params)]
         except Exception as exc:
-            logger.error("batched retrieval failed: %s", exc)
-            raise
+            # element i must equal invoke(inputs[i]): a query that cannot be answered raises from ITS invoke, the ones
+            # before it are not lost to a caller that catches per query (MultiPathRetriever.batch_invoke does)
+            logger.error("batched retrieval failed (%s): answering query by query", exc)
+            return [self.invoke(q, **kwargs) for q in inputs]
 
     # ------------------------------------------------------------------ async
     async def _aget_relevant_documents(self, query: str, **kwargs: Any) -> List[Document]:

@@ -51,8 +51,18 @@ class MultiPathRetriever(BaseRetriever):
                 per_retriever.append([[RetrievalResult(document=d, score=getattr(d, "score", 1.0), rank=i + 1)
                                        for i, d in enumerate(docs)] for docs in lists])
             except Exception as exc:  # noqa: BLE001
-                print(f"retriever {type(retriever).__name__} failed: {exc}")
-                per_retriever.append([[] for _ in inputs])
+                # one bad query must cost what it costs under invoke(): that query's list from this retriever, nothing else
+                print(f"retriever {type(retriever).__name__} failed on the batch ({exc}): answering it query by query")
+                lists = []
+                for q in inputs:
+                    try:
+                        docs = retriever.invoke(q, **{**kwargs, "k": self.top_k_per_retriever})
+                        lists.append([RetrievalResult(document=d, score=getattr(d, "score", 1.0), rank=i + 1)
+                                      for i, d in enumerate(docs)])
+                    except Exception as exc_q:  # noqa: BLE001
+                        print(f"retriever {type(retriever).__name__} failed: {exc_q}")
+                        lists.append([])
+                per_retriever.append(lists)
         gathered = [[lists[qi] for lists in per_retriever] for qi in range(len(inputs))]
         live = [qi for qi, g in enumerate(gathered) if g and not all(len(one) == 0 for one in g)]
         out: List[List[Document]] = [[] for _ in inputs]

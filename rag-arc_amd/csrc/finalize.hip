@@ -768,14 +768,15 @@ struct VerifyParams {
   int64_t id_base;
   const int64_t* ids;      // [*][k] answers (row q of the batch at ids + q*k)
   const float* scores;
-  uint32_t* counts;        // [2 * VERIFY_NQ] out: [i] rows with key > k-th key; [VERIFY_NQ + i] rows with key >= k-th key whose
-                           // (id, canonical score) pair is an entry of the answer, bit for bit
+  uint32_t* counts;        // [3 * VERIFY_NQ] out: [i] rows with key > k-th key; [VERIFY_NQ + i] rows with key >= k-th key whose
+                           // (id, canonical score) pair is an entry of the answer, bit for bit; [2 * VERIFY_NQ + i] rows at or
+                           // above the k-th key that were NOT looked up because a thread had used its lookups up
 };
 
 __global__ __launch_bounds__(256) void rarc_verify_kernel(const VerifyParams p) {
   __shared__ __attribute__((aligned(16))) float s_q[VERIFY_NQ][1024];
   __shared__ uint64_t s_kth[VERIFY_NQ];
-  __shared__ uint32_t s_cnt[2 * VERIFY_NQ];
+  __shared__ uint32_t s_cnt[3 * VERIFY_NQ];
   const int tid = threadIdx.x;
   for (int i = tid; i < VERIFY_NQ * p.d; i += blockDim.x) {
     const int qi = i / p.d, m = i % p.d;
@@ -790,14 +791,19 @@ __global__ __launch_bounds__(256) void rarc_verify_kernel(const VerifyParams p) 
     s_kth[tid] = kth;
     s_cnt[tid] = 0;
     s_cnt[VERIFY_NQ + tid] = 0;
+    s_cnt[2 * VERIFY_NQ + tid] = 0;
   }
   __syncthreads();
   uint32_t mine[VERIFY_NQ];
 #pragma unroll
   for (int qi = 0; qi < VERIFY_NQ; ++qi) mine[qi] = 0;
-  int lookups = 0;   // a thread looks at most 64 rows up: an exact answer needs ~k per query over the WHOLE grid; a corrupted one
-                     // (k-th entry far too low: every row passes) must not turn the scan into n_rows x k loads — it then
-                     // reports too few exact pairs, which is what the host treats as a failure anyway
+  // a thread looks at most 64 rows up PER QUERY: an exact answer needs ~k per query over the WHOLE grid; a corrupted one (k-th
+  // entry far too low: every row passes) must not turn the scan into n_rows x k loads.  A row that is skipped for that reason
+  // is counted in counts[2 * VERIFY_NQ + qi], so the host can tell "check truncated" from "answer wrong" (a
+  // thread owns the rows congruent to it modulo 524,288 — a tiled synthetic corpus can put a query's whole answer there)
+  uint8_t lookups[VERIFY_NQ];
+#pragma unroll
+  for (int qi = 0; qi < VERIFY_NQ; ++qi) lookups[qi] = 0;
   for (uint32_t r = blockIdx.x * blockDim.x + tid; r < p.n_rows; r += gridDim.x * blockDim.x) {
     float a[VERIFY_NQ][8];
 #pragma unroll
@@ -871,8 +877,9 @@ __global__ __launch_bounds__(256) void rarc_verify_kernel(const VerifyParams p) 
       // a row at or above the k-th entry belongs in the answer: look its (id, score) pair up there (about k rows per
       // query in a whole scan take this branch).  The host wants as many exact pairs as the answer has valid entries —
       // an entry whose score was not the row's canonical score, or whose row does not reach the k-th key, is missed.
-      if (qi < p.nq && key >= s_kth[qi] && s_kth[qi] != 0ull && lookups < 64) {
-        ++lookups;
+      if (qi < p.nq && key >= s_kth[qi] && s_kth[qi] != 0ull && lookups[qi] >= 64) atomicAdd(&s_cnt[2 * VERIFY_NQ + qi], 1u);
+      if (qi < p.nq && key >= s_kth[qi] && s_kth[qi] != 0ull && lookups[qi] < 64) {
+        ++lookups[qi];
         const int64_t* ai = p.ids + (size_t)(p.q_first + qi) * p.k;
         const float* as = p.scores + (size_t)(p.q_first + qi) * p.k;
         const int64_t want = (int64_t)r + p.id_base;
@@ -890,13 +897,14 @@ __global__ __launch_bounds__(256) void rarc_verify_kernel(const VerifyParams p) 
   __syncthreads();
   if (tid < p.nq && s_cnt[tid]) atomicAdd(&p.counts[tid], s_cnt[tid]);
   if (tid < p.nq && s_cnt[VERIFY_NQ + tid]) atomicAdd(&p.counts[VERIFY_NQ + tid], s_cnt[VERIFY_NQ + tid]);
+  if (tid < p.nq && s_cnt[2 * VERIFY_NQ + tid]) atomicAdd(&p.counts[2 * VERIFY_NQ + tid], s_cnt[2 * VERIFY_NQ + tid]);
 }
 
 int rarc_verify_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad, const float* q32,
                        int q_first, int nq, int k, int64_t id_base, const int64_t* ids, const float* scores,
                        uint32_t* counts, hipStream_t s) {
   VerifyParams p{corpus, rowscale, fmt, q32, q_first, nq, (uint32_t)n_rows, d_pad, k, id_base, ids, scores, counts};
-  RARC_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * VERIFY_NQ, s));
+  RARC_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(uint32_t) * 3 * VERIFY_NQ, s));
   hipLaunchKernelGGL(rarc_verify_kernel, dim3(2048), dim3(256), 0, s, p);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;

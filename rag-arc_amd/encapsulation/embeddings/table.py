@@ -1,6 +1,7 @@
 """Lookup-table embedding provider: texts whose vectors were computed offline (.npz with `texts`
-and `vectors`).  Unknown texts raise KeyError.  Serves registered pipelines until the HIP encoder
-provider lands, and the plumbing tests."""
+and `vectors`).  Unknown texts raise KeyError.  For pipelines whose embeddings come from elsewhere (a caller that
+keeps its own encoder and hands over vectors) and for the plumbing tests; the encoder on the MI355X is
+`hip_bert.HipBertEmbeddings` (config tag `hip_bert_embeddings`)."""
 from typing import Dict, List, Sequence
 
 import numpy as np

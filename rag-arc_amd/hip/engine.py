@@ -736,7 +736,7 @@ class FlatIndexF16:
             self._workspace()
             b = self._qbuf
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
-            counts = t.zeros(16, dtype=t.int32, device=self.device)
+            counts = t.zeros(24, dtype=t.int32, device=self.device)
             sc_ptr = self._rowscale.data_ptr() if self._rowscale is not None else 0
             for c0 in range(0, nq, B.MAX_QUERIES):
                 c1 = min(nq, c0 + B.MAX_QUERIES)
@@ -757,12 +757,19 @@ class FlatIndexF16:
                                                        sc_c.data_ptr(), counts.data_ptr(), self._stream()),
                             "rarc_verify_batch")
                     c_h = counts.cpu().numpy().astype(np.int64)
-                    got, pairs = c_h[:n], c_h[8:8 + n]
+                    got, pairs, skipped = c_h[:n], c_h[8:8 + n], c_h[16:16 + n]
                     valid_all = (ids_c[first:first + n] >= 0).sum(dim=1).cpu().numpy().astype(np.int64)
                     valid = (ids_c[first:first + n, : k - 1] >= 0).sum(dim=1).cpu().numpy().astype(np.int64)
                     full = (ids_c[first:first + n, k - 1] >= 0).cpu().numpy()      # (short answers are not pair-checked)
                     beating += int(np.maximum(got - valid, 0).sum())
-                    wrong += int(np.where(full, np.maximum(valid_all - pairs, 0), 0).sum())
+                    short = np.where(full, np.maximum(valid_all - pairs, 0), 0)
+                    if bool(((short > 0) & (skipped > 0)).any()):
+                        # the kernel ran out of look-ups for a query (a thread met > 64 rows at or above its k-th entry):
+                        # the pair count is a lower bound there — the check is incomplete, which is not a wrong answer
+                        raise B.RarcError("rarc_verify_batch could not complete the pair check of queries "
+                                          f"{[first + int(i) for i in np.nonzero((short > 0) & (skipped > 0))[0]]}: "
+                                          "too many rows at or above their k-th entry fall to one thread")
+                    wrong += int(short.sum())
                     i = j + 1
         return (beating, wrong) if detail else beating + wrong
 

@@ -7,6 +7,7 @@ import threading
 import time
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -167,6 +168,28 @@ def test_batch_invoke_equals_invoke_query_by_query():
 
     mp_f = MultiPathRetriever([r, Failing(store)], fusion_method=OracleFusion(), top_k_per_retriever=20)
     assert [[d.id for d in docs] for docs in mp_f.batch_invoke(queries[:3], top_k=5)] == [[d.id for d in mp_f.invoke(q, top_k=5)] for q in queries[:3]]
+
+    # ONE query a retriever cannot answer costs that query's list from that retriever — as under invoke() — not the whole
+    # batch's: the retriever's batch call fails, the fan-out falls back to it query by query
+    class OneBad(VectorStoreRetriever):
+        def batch_invoke(self, inputs, **kwargs):
+            if any("poison" in q for q in inputs):
+                raise RuntimeError("cannot batch")
+            return super().batch_invoke(inputs, **kwargs)
+
+        def _get_relevant_documents(self, query, **kwargs):
+            if "poison" in query:
+                raise RuntimeError("cannot answer")
+            return super()._get_relevant_documents(query, **kwargs)
+
+    mixed = queries[:2] + ["poison pill"] + queries[2:4]
+    mp_b = MultiPathRetriever([OneBad(store), other], fusion_method=OracleFusion(), top_k_per_retriever=20)
+    want = [[d.id for d in mp_b.invoke(q, top_k=6)] for q in mixed]
+    got = [[d.id for d in docs] for docs in mp_b.batch_invoke(mixed, top_k=6)]
+    assert got == want and all(len(g) == 6 for g in got)                 # the poisoned query still gets the other path's answer
+    # a dense retriever on its own: the batch equals invoke() element by element up to the query that raises
+    with pytest.raises(RuntimeError):
+        OneBad(store).batch_invoke(mixed)
 
 
 # ------------------------------------------------------------------------------------------- sharded store, 2 ranks over gloo

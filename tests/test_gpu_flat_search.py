@@ -298,6 +298,40 @@ def test_shadow_image_scan_matches_oracle(hip, oracle, n, d, nq, k):
     assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
 
 
+def test_verification_reports_a_truncated_check_as_such(hip):
+    """The pair check gives a thread 64 look-ups per query; a thread owns the rows congruent to it modulo 524,288.  A tiled
+    corpus can put more than 64 of one query's answer rows on one thread: the check is then INCOMPLETE, and says so —
+    it used to report a correct answer as wrong."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 16 * (1 << 30):
+        pytest.skip("needs 16 GiB of free HBM")
+    stride, d = 2048 * 256, 128
+    n = 70 * stride + 1000
+    rows = torch.zeros((((n + 31) // 32) * 32, d), dtype=torch.float16, device="cuda")
+    rows[1::2, 1] = 1.0                                   # filler: unit rows orthogonal to the query (score 0)
+    rows[0::2, 2] = 1.0
+    special = torch.arange(70, device="cuda") * stride + 12345
+    rows[special] = 0
+    rows[special, 0] = 1.0                                # 70 copies of the query itself, all on thread 12345's rows
+    idx = hip.FlatIndexF16(d, metric="cosine")
+    idx.add_rows_f16(rows, 1.0, n_valid=n)
+    q = torch.zeros((1, d), dtype=torch.float32, device="cuda")
+    q[0, 0] = 1.0
+    ids, sc = idx.search_device(q, 60)                    # 60 of the 70 tied rows, lowest ids first: 60 look-ups, complete
+    assert ids[0].tolist() == special[:60].tolist() and bool((sc == 1.0).all())
+    assert idx.verify_batch(q, ids, sc, detail=True) == (0, 0)
+    ids, sc = idx.search_device(q, 70)                    # all 70: one thread meets 70 rows at or above the k-th entry
+    assert ids[0].tolist() == special.tolist()
+    with pytest.raises(B.RarcError, match="could not complete"):
+        idx.verify_batch(q, ids, sc)
+    del idx, rows
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("storage", ["f16", "f8", "f32"])
 def test_batched_exact_verification(hip, oracle, storage):
     """rarc_verify_batch: an exact answer has no row beating its k-th entry, for every query of the batch at once; a

@@ -88,3 +88,14 @@ def test_fp32_storage_wide_rows_and_persistence(oracle, tmp_path):
     rows32, _ = oracle.ingest_f32(Y, normalize=False)
     rI, rD, _ = oracle.flat_search_f32(rows32, Q, 64)
     assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    # save / load: the fp32 rows come back bit for bit (their fp16 scan image is rebuilt on the device), same answer
+    import torch
+
+    path = str(tmp_path / "wide.rarc")
+    st = idx.save_shard(path)
+    assert st["bytes"] == 30_000 * 1024 * 4
+    again = FlatIndexF16(1000, metric="ip", storage="f32")
+    again.load_shard(path)
+    assert again.ntotal == 30_000 and torch.equal(again.rows.view(torch.int32), idx.rows.view(torch.int32))
+    D2, I2 = again.search(Q, 64)
+    assert np.array_equal(I2, rI) and np.array_equal(D2.view(np.uint32), rD.view(np.uint32))
