@@ -123,7 +123,7 @@ static bool roctx_ready() {
 void rarc_roctx_push(const char* name) { if (roctx_ready()) g_roctx_push(name); }
 void rarc_roctx_pop() { if (roctx_ready()) g_roctx_pop(); }
 
-extern "C" int rarc_version(void) { return RARC_VERSION; }
+extern "C" int rarc_version(void) { return RARC_BUILD_VERSION; }
 extern "C" const char* rarc_last_error(void) { return g_err; }
 extern "C" int rarc_padded_dim(int d) {
   return d <= 0 ? 0 : ((d + RARC_DIM_ALIGN - 1) / RARC_DIM_ALIGN) * RARC_DIM_ALIGN;

@@ -5,6 +5,21 @@
 #include <stddef.h>
 #include "../../include/rarc.h"
 
+// ---- measurement-build switches --------------------------------------------------------------------------------------------
+// A few -D switches build kernels that return WRONG results on purpose: ablations, which exist to time a loop with one of
+// its parts removed (SCAN_HALFREAD: every second A fragment of the fp16 scan not read; RARC_Q8_ABLATIONS: the int8 scan with
+// pruning / loads / MFMAs removed, selected at run time by RARC_Q8_ABL; G256_SKIP_A1: a third of a GEMM's fragment reads).
+// None of them may reach a product library: they compile only together with -DRARC_EXPERIMENT, and a library built that
+// way announces itself — rarc_version() returns RARC_VERSION + 100000, which binding.py and tests/test_cabi.py refuse.
+#if (defined(SCAN_HALFREAD) || defined(RARC_Q8_ABLATIONS) || defined(G256_SKIP_A1)) && !defined(RARC_EXPERIMENT)
+#error "SCAN_HALFREAD / RARC_Q8_ABLATIONS / G256_SKIP_A1 build kernels with wrong results: measurement builds only, add -DRARC_EXPERIMENT"
+#endif
+#ifdef RARC_EXPERIMENT
+#define RARC_BUILD_VERSION (RARC_VERSION + 100000)
+#else
+#define RARC_BUILD_VERSION RARC_VERSION
+#endif
+
 typedef _Float16 half_t;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -187,6 +187,10 @@ def load_library() -> ctypes.CDLL:
                     f"{_LIB} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(there is no CPU fallback)")
             lib = ctypes.CDLL(_LIB)
+            lib.rarc_version.restype = c_int
+            if lib.rarc_version() >= 100000 and os.environ.get("RARC_ALLOW_EXPERIMENT") != "1":
+                raise RarcError(f"{_LIB} is a MEASUREMENT build (-DRARC_EXPERIMENT: it may contain kernels that return wrong "
+                                "results on purpose); set RARC_ALLOW_EXPERIMENT=1 to load it from a bench tool")
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)
                 fn.restype = res
