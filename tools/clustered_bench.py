@@ -29,7 +29,8 @@ def make(n, seed):
 
 
 out = {"rows": N, "dim": D, "clusters": NC, "spread": SPREAD, "k": K, "batch": NQ, "paths": {}}
-for scan in ("q8", "mfma16") if D <= 768 else ("q8",):
+PATHS = tuple(os.environ.get("CLUSTERED_PATHS", "q8,mfma16").split(",")) if D <= 768 else ("q8",)
+for scan in PATHS:
     idx = FlatIndexF16(D, metric="cosine", scan=scan, capacity=N)
     slab = 1 << 20
     for s0 in range(0, N, slab):
