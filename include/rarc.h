@@ -50,6 +50,12 @@ extern "C" {
 #define RARC_Q_OK 0u
 #define RARC_Q_UNCERTAIN 1u /* exactness certificate failed (fp16 scan only): call rarc_repair_f16 */
 #define RARC_Q_OVERFLOW 2u  /* candidate buffer overflowed: call rarc_repair_f16 */
+/* diagnostics in the second byte of a flagged query's word (which limit it ran into; hosts treat any non-zero word alike) */
+#define RARC_Q_WHY_SEGMENT 0x100u    /* a scan workgroup's candidate segment for this query filled up */
+#define RARC_Q_WHY_G1 0x200u         /* more rows at or above the k-th approximate score than the rescore buffer holds, no cut found */
+#define RARC_Q_WHY_G2 0x400u         /* rows within the error bound of the k-th exact score exceed the buffer (unbanded path) */
+#define RARC_Q_WHY_BAND_TIES 0x800u  /* banded rescore: a band of equal approximate scores does not fit */
+#define RARC_Q_WHY_BAND_GUARD 0x1000u /* banded rescore: iteration guard exhausted */
 
 int rarc_version(void);
 const char* rarc_last_error(void);

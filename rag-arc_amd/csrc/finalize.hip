@@ -291,7 +291,9 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   __shared__ uint32_t s_hist[RARC_NB];
   __shared__ uint32_t s_cnt[RARC_MAX_WG];  // candidates each scan workgroup produced for this query
   __shared__ float s_t1, s_L;
-  __shared__ uint32_t s_ne, s_over;
+  __shared__ uint32_t s_ne, s_over, s_cmp;
+  __shared__ int s_selb;
+  __shared__ uint32_t s_selabove;
   const int q = blockIdx.x, tid = threadIdx.x;
   const float eps = p.eps8[q];
 #define FIN8_STAMP(i) if (p.dbg && q == 0 && tid == 0) p.dbg[i] = __builtin_amdgcn_s_memrealtime();
@@ -445,6 +447,52 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
     }
   };
 
+  // The k-th largest of the n distinct keys ex[0..n) (1 <= kth <= n).  Up to FIN8_SMALL keys: rank by counting (n²/threads
+  // compares: nothing at the few hundred rows an isotropic corpus leaves).  Beyond: radix select, one byte per pass from the
+  // top, 256 LDS counters (s_hist is free once T1 is known) — O(n) per pass.  On clustered corpora the whole cluster of a
+  // query sits inside the int8 margin, the buffer fills (6144 keys) and ranking by counting was 38M compares per query and
+  // ranking: 5.5 of the 8.8 ms a batch took on 10M clustered rows (profiles/r04_clustered_*).
+  constexpr int FIN8_SMALL = 1024;
+  auto select_kth = [&](int n, int kth) __attribute__((always_inline)) -> uint64_t {
+    if (n <= FIN8_SMALL) {
+      __syncthreads();
+      for (int i = tid; i < n; i += blockDim.x) {
+        const uint64_t mine = ex[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (ex[j] > mine);
+        if (rank == kth - 1) { s_selb = (int)(mine >> 32); s_selabove = (uint32_t)mine; }
+      }
+      __syncthreads();
+      const uint64_t r = ((uint64_t)(uint32_t)s_selb << 32) | s_selabove;
+      __syncthreads();
+      return r;
+    }
+    uint64_t prefix = 0, mask = 0;
+    uint32_t need = (uint32_t)kth;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      __syncthreads();
+      for (int i = tid; i < RARC_NB; i += blockDim.x) s_hist[i] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += blockDim.x) {
+        const uint64_t key = ex[i];
+        if ((key & mask) == prefix) atomicAdd(&s_hist[(uint32_t)(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {
+        uint32_t above = 0;
+        const int b = rarc_wave_find_from_top(s_hist, RARC_NB, need, &above);
+        if (tid == 0) { s_selb = b; s_selabove = above; }
+      }
+      __syncthreads();
+      prefix |= (uint64_t)(uint32_t)s_selb << shift;
+      mask |= 0xFFull << shift;
+      need -= s_selabove;
+    }
+    __syncthreads();
+    return prefix;
+  };
+  static_assert(RARC_NB == 256, "the radix select counts one byte per pass in s_hist");
+
   // ---- step 1: G1 = {a >= T1}: canonical scores, L = k-th best of them ----
   FIN8_STAMP(1)
   collect([&](float a, uint32_t) { return a >= t1; });
@@ -453,8 +501,18 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
     // The histogram's bins were too coarse for this query (a window sized from a sample whose k-th best lies far
     // below the final one): G1 does not fit.  Any cut with k <= |{a >= cut}| <= buffer will do: bisect for one
     // between the histogram's edge and the top of its window, one sweep over the candidate keys per probe.
-    float a_lo = t1, a_hi = p.binlo[q] + (float)RARC_NB * p.bininv[q];
-    for (int probe = 0; probe < 24 && a_hi > a_lo; ++probe) {
+    // (the upper end is the best approximate score actually present, found by one more sweep — NOT the top of the
+    //  histogram's window: on clustered corpora a query's whole cluster, thousands of rows, can lie above a window that
+    //  was sized from a sample the cluster was barely in, and then no cut inside the window holds few enough rows:
+    //  the one query the round-3 tree flagged on every clustered batch, at the price of a second scan of the shard)
+    __syncthreads();
+    if (tid == 0) s_cmp = 0;
+    __syncthreads();
+    collect([&](float a, uint32_t) { atomicMax(&s_cmp, rarc_ordkey(a)); return false; });
+    __syncthreads();
+    float a_lo = t1, a_hi = rarc_unordkey(s_cmp + 1u);   // (the next float up: a cut must be able to sit above the best score)
+    __syncthreads();
+    for (int probe = 0; probe < 40 && a_hi > a_lo; ++probe) {
       const float mid = a_lo + 0.5f * (a_hi - a_lo);
       if (!(mid > a_lo && mid < a_hi)) break;
       __syncthreads();
@@ -481,13 +539,9 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   rescore(0, ne1);
   __syncthreads();
   FIN8_STAMP(3)
-  if (ne1 >= p.k) {  // rank by counting; keys are distinct
-    for (int i = tid; i < ne1; i += blockDim.x) {
-      const uint64_t mine = ex[i];
-      int rank = 0;
-      for (int j = 0; j < ne1; ++j) rank += (ex[j] > mine);
-      if (rank == p.k - 1) s_L = rarc_candscore(mine);
-    }
+  if (ne1 >= p.k) {  // keys are distinct
+    const uint64_t kth = select_kth(ne1, p.k);
+    if (tid == 0) s_L = rarc_candscore(kth);
   }
   __syncthreads();
   const float L = s_L;  // -inf when fewer than k candidates exist (then G1 already holds them all)
@@ -521,19 +575,21 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   uint32_t ne_all = s_ne;
   int ne = ne_all < FIN8_RS ? (int)ne_all : FIN8_RS;
   bool band_fail = false;
+  uint32_t why = 0;   // which limit flagged the query (RARC_Q_WHY_*, the status word's second byte): diagnostics only
+  if (ne1_all > (uint32_t)FIN8_RS) why |= RARC_Q_WHY_G1;
   if (ne_all > (uint32_t)FIN8_RS && ne1_all <= (uint32_t)FIN8_RS && ne1 >= p.k && L > -INFINITY) {
     // G2 does not fit (large k on a large shard: k = 996 at 100M rows wants ~7000 rows).  Take it in bands of
     // approximate score, best band first: keep the k best canonical keys so far in ex[0..k), collect the band's
     // candidates behind them, rescore, keep the k best again.  The k-th best canonical score Lc only rises, so
     // the floor Lc - eps below which nothing can matter rises with it; a band that does not fit is halved.
     uint64_t* tmp = (uint64_t*)fsm;  // (the row staging area is idle while keys are ranked)
-    auto keep_top_k = [&](int n) {   // ex[0..n) -> its k best keys, in order, in ex[0..k); s_L = the k-th
+    auto keep_top_k = [&](int n) {   // ex[0..n) -> its k best keys (any order) in ex[0..k); s_L = the k-th
+      const uint64_t kth = select_kth(n, p.k);
+      if (tid == 0) { s_cmp = 0; s_L = rarc_candscore(kth); }
+      __syncthreads();
       for (int i = tid; i < n; i += blockDim.x) {
         const uint64_t mine = ex[i];
-        int rank = 0;
-        for (int j = 0; j < n; ++j) rank += (ex[j] > mine);
-        if (rank < p.k) tmp[rank] = mine;
-        if (rank == p.k - 1) s_L = rarc_candscore(mine);
+        if (mine >= kth) tmp[atomicAdd(&s_cmp, 1u)] = mine;     // exactly k of them: the keys are distinct
       }
       __syncthreads();
       for (int i = tid; i < p.k; i += blockDim.x) ex[i] = tmp[i];
@@ -558,7 +614,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       const uint32_t cnt = s_ne;
       if (cnt > (uint32_t)FIN8_RS) {  // halve the band from below
         const float mid = lo + 0.5f * (hi - lo);
-        if (!(mid > lo && mid < hi)) { band_fail = true; break; }
+        if (!(mid > lo && mid < hi)) { band_fail = true; why |= RARC_Q_WHY_BAND_TIES; break; }
         lo_try = mid;
         continue;
       }
@@ -569,6 +625,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       hi = lo;
       lo_try = (cnt > (uint32_t)(FIN8_RS / 2)) ? hi - width : hi - 2.0f * width;  // sparse band: try twice the width next
     }
+    if (!reached_floor && !band_fail) why |= RARC_Q_WHY_BAND_GUARD;
     if (!reached_floor) band_fail = true;
     ne = p.k;
     ne_all = band_fail ? (uint32_t)FIN8_RS + 1u : (uint32_t)p.k;
@@ -586,12 +643,31 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
       p.out_scores[(size_t)q * p.k + i] = -INFINITY;
     }
   }
-  for (int i = tid; i < ne; i += blockDim.x) {
-    const uint64_t mine = ex[i];
-    if (rarc_candscore(mine) < L) continue;  // cannot rank inside the top k (k rows of G1 are >= L)
-    int rank = 0;
-    for (int j = 0; j < ne; ++j) rank += (ex[j] > mine);
-    if (rank < p.k) {
+  if (ne <= FIN8_SMALL) {
+    for (int i = tid; i < ne; i += blockDim.x) {
+      const uint64_t mine = ex[i];
+      if (rarc_candscore(mine) < L) continue;  // cannot rank inside the top k (k rows of G1 are >= L)
+      int rank = 0;
+      for (int j = 0; j < ne; ++j) rank += (ex[j] > mine);
+      if (rank < p.k) {
+        p.out_ids[(size_t)q * p.k + rank] = p.id_base + (int64_t)rarc_candrow(mine);
+        p.out_scores[(size_t)q * p.k + rank] = rarc_candscore(mine);
+      }
+    }
+  } else {   // thousands of rescored rows: cut at the k-th key first, rank only what is above it
+    uint64_t* top = (uint64_t*)fsm;  // (the row staging area is idle now)
+    const uint64_t kth = select_kth(ne, kk);
+    if (tid == 0) s_cmp = 0;
+    __syncthreads();
+    for (int i = tid; i < ne; i += blockDim.x) {
+      const uint64_t mine = ex[i];
+      if (mine >= kth) top[atomicAdd(&s_cmp, 1u)] = mine;        // exactly kk keys
+    }
+    __syncthreads();
+    for (int i = tid; i < kk; i += blockDim.x) {
+      const uint64_t mine = top[i];
+      int rank = 0;
+      for (int j = 0; j < kk; ++j) rank += (top[j] > mine);
       p.out_ids[(size_t)q * p.k + rank] = p.id_base + (int64_t)rarc_candrow(mine);
       p.out_scores[(size_t)q * p.k + rank] = rarc_candscore(mine);
     }
@@ -602,6 +678,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   if (tid == 0) {
     uint32_t st = RARC_Q_OK;
     if (s_over || ne_all > (uint32_t)FIN8_RS) st |= RARC_Q_OVERFLOW;
+    if (st) st |= why | (s_over ? RARC_Q_WHY_SEGMENT : 0u) | ((ne_all > (uint32_t)FIN8_RS && !why) ? RARC_Q_WHY_G2 : 0u);
     p.status[q] = st;
     if (st) {
       atomicOr(&p.flags[1], st);

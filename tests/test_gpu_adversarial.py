@@ -164,3 +164,41 @@ def test_overflowing_candidate_segments_are_rerun_from_a_score_floor(oracle, sto
     assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
     assert len(idx.last_repaired) >= nq // 2, "the test is meant to overflow"
     assert idx.last_rerun == len(idx.last_repaired), "the re-run should have settled every flagged query"
+
+
+def test_clustered_corpus_whole_cluster_inside_the_int8_margin(oracle):
+    """What real embedding corpora look like: anisotropic clusters, queries from the same mixture.  A
+    query's WHOLE cluster (12,500 rows here) sits inside the int8 error margin of its k-th best score: more rows at or above
+    the histogram's k-th edge than the 6144-key rescore buffer holds, most of them ABOVE a histogram window that was sized
+    from a sample the cluster was barely in.  The round-3 tree flagged such a query on every batch (a second scan of the
+    shard) and ranked thousands of keys by counting (5.5 of 8.8 ms per batch at 10M rows).  Now: nothing flagged, nothing
+    repaired, ids and scores bit-identical to the oracle."""
+    import torch
+
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(2024)
+    n, d, nc, nq, k = 500_000, 256, 40, 64, 100
+    spec = (np.arange(1, d + 1, dtype=np.float32) ** -0.5)
+    spec = spec / np.linalg.norm(spec) * np.sqrt(d)
+    centers = rng.standard_normal((nc, d)).astype(np.float32) * spec
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+
+    def make(m):
+        c = rng.integers(0, nc, m)
+        return (centers[c] + 0.3 / np.sqrt(d) * rng.standard_normal((m, d)).astype(np.float32) * spec).astype(np.float32)
+
+    X, Q = make(n), make(nq)
+    rows, _ = oracle.ingest_f16(X)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), k)
+    for kk in (k, 10):
+        idx = FlatIndexF16(d, metric="cosine", scan="q8")
+        idx.add(X)
+        ids, sc = idx.search_device(torch.from_numpy(Q).cuda(), kk, repair=False)       # first attempt only
+        st = idx.last_status.cpu().numpy()
+        assert not st.any(), f"flagged on the first attempt: {sorted(set(hex(int(v)) for v in st[st != 0]))}"
+        assert np.array_equal(ids.cpu().numpy(), rI[:, :kk])
+        assert np.array_equal(sc.cpu().numpy().view(np.uint32), rD[:, :kk].view(np.uint32))
+    D, I = idx.search(Q, 1000)                     # k = 1000: the banded rescore with thousands of rows per band
+    rI2, rD2, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), 1000)
+    assert np.array_equal(I, rI2) and np.array_equal(D.view(np.uint32), rD2.view(np.uint32))

@@ -55,7 +55,7 @@ for scan in PATHS:
     out["paths"][scan] = {
         "candidates_per_query": {"min": int(cnt.min()), "mean": float(cnt.mean()), "max": int(cnt.max())},
         "fullest_segment": int(cnt2.max()), "segment_capacity": idx._cap_eff // 256,
-        "flagged_queries": int((st != 0).sum()), "settled_by_rerun": int(getattr(idx, "last_rerun", 0)),
+        "flagged_queries": int((st != 0).sum()), "flag_words": sorted(set(hex(int(v)) for v in st[st != 0])), "settled_by_rerun": int(getattr(idx, "last_rerun", 0)),
         "repaired_one_by_one": int(len(idx.last_repaired) - getattr(idx, "last_rerun", 0)) if idx.last_repaired else 0,
         "ms_per_batch_first_attempt": round(t_scan * 1e3, 3), "qps_first_attempt": round(NQ / t_scan, 1),
         "ms_per_batch_exact": round(t_full * 1e3, 3), "qps_exact": round(NQ / t_full, 1),
