@@ -282,6 +282,10 @@ struct Fin8Params {
   const float* hq;      // [256] ||q8/s_q||: inside tile t the error bound is eps8 - hq·(R - R_t)  (scan_q8.hip)
   unsigned long long* dbg;  // tools: phase stamps of block 0 (100 MHz ticks), else null
   uint32_t* tighten_thr;    // non-null: stop after step 1 and raise thr[q] to L - eps8 (split scan, scan_q8.hip)
+  int tighten_mode;         // 1: raise only.  2: the candidates so far came from the fp16 STAGE of the hybrid search, whose
+                            // thresholds live under an eps16 margin — too high for the int8 stage that follows: thr[q] is
+                            // SET to L - eps8 (no k-th score yet: lowered by eps8 - eps16, which is valid too)
+  const float* eps16;       // hybrid search: some candidates carry fp16 scores (error <= eps16[q]); null otherwise
 };
 
 __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fin8Params p) {
@@ -551,7 +555,13 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
     // best from below, and a row that good scores at least L - eps8 in int8: the rest of the shard runs under that.
     if (tid == 0 && L > -INFINITY) {
       const float t = L - (1.0002f * eps + 1e-7f);
-      if (t > __uint_as_float(p.tighten_thr[q])) p.tighten_thr[q] = __float_as_uint(t);
+      if (p.tighten_mode == 2 || t > __uint_as_float(p.tighten_thr[q])) p.tighten_thr[q] = __float_as_uint(t);
+    } else if (tid == 0 && p.tighten_mode == 2) {
+      // fewer than k candidates so far: the stage's own threshold thr16 <= L_final - eps16 becomes
+      // thr16 - (eps8 - eps16) <= L_final - eps8
+      const float e16 = p.eps16 ? p.eps16[q] : 0.f;
+      const float cur = __uint_as_float(p.tighten_thr[q]);
+      if (cur > -INFINITY && cur < INFINITY) p.tighten_thr[q] = __float_as_uint(cur - (1.0002f * fmaxf(eps - e16, 0.f) + 1e-7f));
     }
     return;
   }
@@ -561,13 +571,15 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
   // <= a + eps8 - hq·(R - R_t) (the bound the scan discarded with): the coarse test first, the tile's metadata word
   // (a 4-byte gather) only for the few thousand rows that pass it — each row it then drops is a whole row not rescored
   const float hqv = p.hq ? p.hq[q] : 0.f;
+  const float e16 = p.eps16 ? p.eps16[q] : 0.f;
   const float r_max = p.tmeta ? p.tmeta[0 - RARC_QMETA_HDR] : 0.f;
   auto reaches = [&](float a, uint32_t row, float ref) {
     if (!(a + eps * 1.0001f >= ref)) return false;
     if (!p.tmeta) return true;
     const uint32_t w = __float_as_uint(p.tmeta[(size_t)(row >> 5) * p.mstride]);
     const float rt = (float)__builtin_bit_cast(half_t, (uint16_t)(w >> 16));
-    return a + (eps - hqv * fmaxf(r_max - rt, 0.f)) * 1.0001f >= ref;
+    // (hybrid search: a candidate of the fp16 stage is only known to eps16, which the tile bound must not undercut)
+    return a + fmaxf(eps - hqv * fmaxf(r_max - rt, 0.f), e16) * 1.0001f >= ref;
   };
   if (ne1_all <= (uint32_t)FIN8_RS && t1 > -INFINITY) collect([&](float a, uint32_t row) { return a < t1 && reaches(a, row, L); });
   __syncthreads();
@@ -690,8 +702,8 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
 unsigned long long* g_fin8_dbg = nullptr;  // set by tools only
 int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
                             const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
-                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, bool tighten,
-                            const float* qmeta, const float* hq) {
+                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, int tighten,
+                            const float* qmeta, const float* hq, const float* eps16) {
   RARC_REQUIRE(d_pad <= FIN8_MAXD, RARC_E_UNSUPPORTED, "rarc_finalize_q8: d_pad %d > %d", d_pad, FIN8_MAXD);
   Fin8Params p;
   p.corpus = corpus;
@@ -718,6 +730,8 @@ int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, 
   p.hq = hq;
   p.dbg = tighten ? nullptr : g_fin8_dbg;
   p.tighten_thr = tighten ? (uint32_t*)ws.thr : nullptr;
+  p.tighten_mode = tighten;
+  p.eps16 = eps16;
   // 8 waves stage 8 rows each up to 1536 bytes per row (97 KB); up to 3072 bytes: 4 waves; fp32 rows of 1024: 2 waves
   const size_t rbytes = (size_t)d_pad * (fmt == 2 ? 4 : (fmt ? 1 : 2));
   const int threads = rbytes <= 1536 ? FIN8_THREADS : (rbytes <= 3072 ? FIN8_THREADS / 2 : FIN8_THREADS / 4);

@@ -13,11 +13,12 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
                         const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
                         const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
                         const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8,
-                        int (*tighten)(void* ctx, int n_wg), void* tighten_ctx, const float* hq, const float* floor);
+                        int (*tighten)(void* ctx, int n_wg, int mode), void* tighten_ctx, const float* hq, const float* floor,
+                        int* hybrid_out);
 int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, int d_pad, const float* q32,
                             const float* eps8, int nq, int k, int64_t id_base, const RarcWs& ws, int cap, int n_wg,
-                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, bool tighten,
-                            const float* qmeta, const float* hq);
+                            int64_t* out_ids, float* out_scores, uint32_t* status, hipStream_t s, int tighten,
+                            const float* qmeta, const float* hq, const float* eps16);
 
 // int8-prefilter search = seed, scan (split in two launches around an exact mid-scan pass on large shards),
 // canonical finalize; shared by the fp16, fp8 and shadow-image entry points
@@ -29,16 +30,17 @@ struct Q8Search {
   int64_t id_base;
   const float *q32, *eps8;
   const float *qmeta, *hq;  // per-tile error bounds for the finalize (finalize.hip: reaches())
+  const float* eps16;       // the fp16 scorer's bound (hybrid search: the first stage's candidates carry fp16 scores)
   const RarcWs* ws;
   int64_t* out_ids;
   float* out_scores;
   uint32_t* status;
   hipStream_t s;
 };
-static int q8_tighten(void* ctx, int n_wg) {
+static int q8_tighten(void* ctx, int n_wg, int mode) {   // mode 1: raise thr; 2: set it (after the fp16 stage of a hybrid search)
   const Q8Search& a = *(const Q8Search*)ctx;
   return rarc_finalize_q8_launch(a.rows, a.rowscale, a.fin_fmt, a.d_pad, a.q32, a.eps8, a.nq, a.k, a.id_base, *a.ws, a.cap,
-                                 n_wg, a.out_ids, a.out_scores, a.status, a.s, true, a.qmeta, a.hq);
+                                 n_wg, a.out_ids, a.out_scores, a.status, a.s, mode, a.qmeta, a.hq, a.eps16);
 }
 int rarc_repair_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                        const float* qv, int k, int64_t id_base, int64_t* ids, float* scores, uint32_t* found,
@@ -164,15 +166,15 @@ extern "C" int rarc_search_f16(const uint16_t* d_corpus_f16, int64_t n_rows, int
   const RarcWs ws = rarc_ws_carve(d_workspace);
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipStream_t s = (hipStream_t)stream;
-  int n_wg = 0;
+  int n_wg = 0, hybrid = 0;
   if (d_qmeta) {  // int8 prefilter scan + two-step canonical finalize (always exact unless a buffer overflows)
-    Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, &ws, d_out_ids, d_out_scores,
+    Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, qb.eps16, &ws, d_out_ids, d_out_scores,
                d_status, s};
     rc = rarc_scan_q8_launch(d_corpus_f16, nullptr, 0, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16,
-                             qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor);
+                             qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor, &hybrid);
     if (rc) return rc;
     return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
-                                   n_wg, d_out_ids, d_out_scores, d_status, s, false, d_qmeta, qb.hq);
+                                   n_wg, d_out_ids, d_out_scores, d_status, s, 0, d_qmeta, qb.hq, hybrid ? qb.eps16 : nullptr);
   }
   // fp16 MFMA scan + k' selection + exactness certificate (kept for comparison)
   rc = rarc_scan_f16_launch(d_corpus_f16, n_rows, d_pad, qb.q16, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s,
@@ -225,14 +227,14 @@ extern "C" int rarc_search_f16_shadow(const uint16_t* d_corpus_f16, const int8_t
   const RarcWs ws = rarc_ws_carve(d_workspace);
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipStream_t s = (hipStream_t)stream;
-  int n_wg = 0;
-  Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, &ws, d_out_ids, d_out_scores,
+  int n_wg = 0, hybrid = 0;
+  Q8Search a{d_corpus_f16, nullptr, 0, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, qb.eps16, &ws, d_out_ids, d_out_scores,
              d_status, s};
   rc = rarc_scan_q8_launch(d_corpus_f16, nullptr, 2, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16, qb.eps8,
-                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, d_shadow8, q8_tighten, &a, qb.hq, qb.floor);
+                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, d_shadow8, q8_tighten, &a, qb.hq, qb.floor, nullptr);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f16, nullptr, 0, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
-                                 n_wg, d_out_ids, d_out_scores, d_status, s, false, d_qmeta, qb.hq);
+                                 n_wg, d_out_ids, d_out_scores, d_status, s, 0, d_qmeta, qb.hq, hybrid ? qb.eps16 : nullptr);
 }
 
 // ---- fp32 rows (the reference's own storage) + their fp16 image: the scan reads the image, every returned score is
@@ -260,14 +262,14 @@ extern "C" int rarc_search_f32(const float* d_corpus_f32, const uint16_t* d_imag
   const RarcWs ws = rarc_ws_carve(d_workspace);
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipStream_t s = (hipStream_t)stream;
-  int n_wg = 0;
-  Q8Search a{d_corpus_f32, nullptr, 2, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, &ws, d_out_ids, d_out_scores,
+  int n_wg = 0, hybrid = 0;
+  Q8Search a{d_corpus_f32, nullptr, 2, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, qb.eps16, &ws, d_out_ids, d_out_scores,
              d_status, s};
   rc = rarc_scan_q8_launch(d_image_f16, nullptr, 0, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16, qb.eps8,
-                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor);
+                           nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor, nullptr);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f32, nullptr, 2, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap, n_wg,
-                                 d_out_ids, d_out_scores, d_status, s, false, d_qmeta, qb.hq);
+                                 d_out_ids, d_out_scores, d_status, s, 0, d_qmeta, qb.hq, hybrid ? qb.eps16 : nullptr);
 }
 
 extern "C" int rarc_repair_f32(const float* d_corpus_f32, int64_t n_rows, int d_pad, const void* d_qblock, int q, int k,
@@ -313,14 +315,14 @@ extern "C" int rarc_search_f8(const uint8_t* d_corpus_f8, const float* d_row_sca
   const RarcWs ws = rarc_ws_carve(d_workspace);
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipStream_t s = (hipStream_t)stream;
-  int n_wg = 0;
-  Q8Search a{d_corpus_f8, d_row_scale, 1, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, &ws, d_out_ids, d_out_scores,
+  int n_wg = 0, hybrid = 0;
+  Q8Search a{d_corpus_f8, d_row_scale, 1, d_pad, nq, k, cand_cap, id_base, qb.q32, qb.eps8, d_qmeta, qb.hq, qb.eps16, &ws, d_out_ids, d_out_scores,
              d_status, s};
   rc = rarc_scan_q8_launch(d_corpus_f8, d_row_scale, 1, n_rows, d_pad, d_qmeta, qb.q16, qb.q8, qb.qinv, qb.eps16,
-                           qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor);
+                           qb.eps8, nq, kprime, bin_lo, bin_hi, ws, cand_cap, &n_wg, s, nullptr, q8_tighten, &a, qb.hq, qb.floor, nullptr);
   if (rc) return rc;
   return rarc_finalize_q8_launch(d_corpus_f8, d_row_scale, 1, d_pad, qb.q32, qb.eps8, nq, k, id_base, ws, cand_cap,
-                                 n_wg, d_out_ids, d_out_scores, d_status, s, false, d_qmeta, qb.hq);
+                                 n_wg, d_out_ids, d_out_scores, d_status, s, 0, d_qmeta, qb.hq, hybrid ? qb.eps16 : nullptr);
 }
 
 extern "C" int rarc_repair_f8(const uint8_t* d_corpus_f8, const float* d_row_scale, int64_t n_rows, int d_pad,

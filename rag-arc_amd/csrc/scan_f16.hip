@@ -44,6 +44,12 @@ struct ScanParams {
   uint32_t kprime;
   uint32_t nq;
   unsigned long long* dbg;  // tools/scan_bench timeline (ABL & 64), else null
+  // Rigorous-margin mode (the fp16 STAGE of the hybrid small-shard search, scan_q8.hip): the owner publishes
+  // edge - margin_scale * margin[q] instead of the bin edge.  With margin = eps16 (|fp16 score - canonical| <= eps16) and
+  // scale 2: >= k' rows score >= edge, so the k'-th best canonical score L >= edge - eps16, and a row as good as L scores
+  // >= L - eps16 >= edge - 2 eps16 — discarding below that loses nothing, with no certificate needed afterwards.
+  const float* margin;      // null: the classic path (k' > k candidates + exactness certificate in rarc_finalize_kernel)
+  float margin_scale;
 };
 
 constexpr int SCAN_WAVES = 8;
@@ -189,7 +195,8 @@ struct ScanLds {
   static constexpr int BININV = BINSCALE + 1024;
   static constexpr int HLAND = BININV + 1024;  // owner: histogram of the owned query, filled by DMA
   static constexpr int TLAND = HLAND + 1024;   // per wave 64 x 4 B: refreshed thresholds, filled by DMA
-  static constexpr int TOTAL = TLAND + 2048;
+  static constexpr int THOFF = TLAND + 2048;   // per query: what the owner takes off a bin edge before publishing it (0, or 2 eps16)
+  static constexpr int TOTAL = THOFF + 1024;
 };
 
 // ABL: ablation bits for tools/scan_bench (0 in the product build)
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     s_binlo[tid] = p.binlo[tid];
     s_binscale[tid] = p.binscale[tid];
     s_bininv[tid] = p.bininv[tid];
+    ((float*)(smem + L::THOFF))[tid] = p.margin ? p.margin_scale * p.margin[tid] + 1e-30f : 0.f;
   }
 
 #if SCAN_MMA16
@@ -505,8 +513,9 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
         const int b = rarc_wave_find_from_top_256(c0, c1, c2, c3, p.kprime);
         if (b >= 2 && rarc_fresh_lane() == 0) {
           // counts only grow, so b (hence t) never decreases; t > lo >= the seed threshold
-          const float t = rarc_bin_threshold(b, rarc_lds_read_f32(L::BINLO + 4 * own_q),
-                                             rarc_lds_read_f32(L::BININV + 4 * own_q));
+          float t = rarc_bin_threshold(b, rarc_lds_read_f32(L::BINLO + 4 * own_q),
+                                       rarc_lds_read_f32(L::BININV + 4 * own_q));
+          t -= rarc_lds_read_f32(L::THOFF + 4 * own_q);   // (from LDS: a global load here would make hipcc drain the DMA queue)
           __hip_atomic_store(&p.thr[own_q], __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         own_q = -1;
@@ -906,6 +915,8 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
   p.kprime = (uint32_t)kprime;
   p.nq = (uint32_t)nq;
   p.dbg = nullptr;
+  p.margin = nullptr;
+  p.margin_scale = 0.f;
 
   const uint32_t seed_tiles = p.n_tiles < (uint32_t)RARC_SEED_TILES ? p.n_tiles : (uint32_t)RARC_SEED_TILES;
 #define RARC_DISPATCH_D(CALL)                                                                         \
@@ -942,6 +953,35 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
   *grid_out = grid;
   if (p.n_tiles == 0) return RARC_OK;
 #define SCAN_CALL(DD) launch_scan<DD>(p, grid, s)
+  RARC_DISPATCH_D(SCAN_CALL)
+  return rc;
+}
+
+
+// The fp16 MFMA scan as the FIRST STAGE of the hybrid small-shard search (scan_q8.hip: rarc_scan_q8_launch): tiles
+// [0, stage_tiles) of the shard, thresholds / histogram windows as the seed pass left them, candidates into the same
+// private segments the int8 stage continues (resume), published thresholds under the rigorous 2·eps16 margin.
+int rarc_scan_f16_stage_launch(const uint16_t* corpus, int64_t n_rows, uint32_t stage_tiles, int d_pad, const uint16_t* q16,
+                               const float* eps16, int nq, int kprime, const RarcWs& ws, int cap, int grid, hipStream_t s) {
+  ScanParams p;
+  p.corpus = (const half_t*)corpus;
+  p.q16 = (const half_t*)q16;
+  p.n_rows = (uint32_t)n_rows;
+  p.n_tiles = stage_tiles;
+  p.thr = (uint32_t*)ws.thr;
+  p.binlo = ws.binlo;
+  p.binscale = ws.binscale;
+  p.bininv = ws.bininv;
+  p.hist = ws.hist;
+  p.cnt2 = ws.cnt2;
+  p.cand = ws.cand;
+  p.seg = (uint32_t)(cap / RARC_MAX_WG);
+  p.kprime = (uint32_t)kprime;
+  p.nq = (uint32_t)nq;
+  p.dbg = nullptr;
+  p.margin = eps16;
+  p.margin_scale = 2.0002f;
+  int rc = RARC_OK;
   RARC_DISPATCH_D(SCAN_CALL)
   return rc;
 }

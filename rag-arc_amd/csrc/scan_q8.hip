@@ -30,6 +30,7 @@
 //
 // Algorithmic HBM bytes per launch: n_rows × D × 2 (+ 8 bytes per tile of metadata).
 #include "rarc_common.h"
+#include <stdio.h>
 
 struct ScanQ8Params {
   const uint4* corpus;   // fp16 (FMT 0), fp8 (FMT 1) or int8-shadow (FMT 2) rows [ceil32(n_rows)][D], 16-byte chunks
@@ -59,6 +60,16 @@ struct ScanQ8Params {
 #ifndef Q8_M16_FP16_ROWS
 #define Q8_M16_FP16_ROWS 0  // 1: fp16 rows on the 16x16x64 form as well (A/B builds)
 #endif
+// build-time knobs of the instantiations without the ping-pong (D > 768; A/B builds: tools/build_variant_any.sh scan_q8 <name> -D...)
+#ifndef Q8_BIG_PF
+#define Q8_BIG_PF 1     // k steps of LDS fragments read ahead of the 16x16x64 MFMAs
+#endif
+#ifndef Q8_BIG_NG
+#define Q8_BIG_NG 2     // fetch groups (tiles of global loads in flight per thread), fp8 / shadow rows
+#endif
+#ifndef Q8_EB
+#define Q8_EB 0         // 1: the iteration's barrier right behind the matrix phase (see EB in the kernel)
+#endif
 constexpr int Q8_WAVES = 8;
 constexpr int Q8_THREADS = Q8_WAVES * 64;
 
@@ -71,9 +82,15 @@ template <bool B>
 struct Q8Flag { static constexpr bool value = B; };
 constexpr int Q8_DEEP_D = 384;  // rows up to this many dimensions run with four fetch groups in flight (see NG)
 
-template <int D>
+// Row stride of the int8 tile.  32x32x32 form (fp16 rows): D + 16 — the 16-lane groups of the A-fragment ds_read_b128 hit
+// 16 distinct bank groups.  16x16x64 form (fp8 / shadow rows, round 3): lane l reads row l & 15, 16-byte k quarter l >> 4;
+// with D + 16 the hardware's ds_read_b128 lane groups ({0-3, 12-15, 20-27}, ...) put two lanes on one bank group in EVERY
+// group — each fragment read took 8 LDS cycles instead of 4 (round 4 PMC, 100M x 1024 fp8: SQ_LDS_BANK_CONFLICT 43 % of
+// SQ_LDS_IDX_ACTIVE, the LDS busy 59 % of the kernel).  D + 32 is conflict-free for that form: with D a multiple of 256 the
+// bank group of a lane is (2·row + quarter) mod 16, a bijection on each of the four lane groups (checked exhaustively).
+template <int D, bool M16V = false>
 struct ScanQ8Lds {
-  static constexpr int RS = D + 16;         // row stride of the int8 tile (bytes)
+  static constexpr int RS = D + (M16V ? 32 : 16);   // row stride of the int8 tile (bytes)
   static constexpr int TILE = 32 * RS;      // one int8 tile
   static constexpr int CNT = 2 * TILE;      // uint32 [256] slot counters of the private segments
   static constexpr int BINLO = CNT + 1024;
@@ -97,9 +114,19 @@ __device__ __forceinline__ void q8_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// (ablation builds: a value that depends on every accumulator element — round 3's "no pruning" build looked at element 0
+//  only, and for the 16x16x64 form hipcc then dropped the three accumulator blocks nobody read: 32 MFMAs per tile, not 128)
+typedef int q8_i32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int q8_all16(const q8_i32x16& a) {
+  int x = a[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) x ^= a[i];
+  return x;
+}
+
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
-// 8 = no threshold refresh, 16 = no conversion, 32 = prune fast path only, 64 = never flush,
-// 256 = no ping-pong between the wave groups, 1024 = s_memtime timeline of workgroup 0 into p.dbg,
+// 8 = no threshold refresh, 16 = no conversion, 32768 = fp8: converted but not written to LDS, 32 = prune fast path only, 64 = never flush,
+// 256 = no ping-pong between the wave groups, 512 = barrier at the end of the iteration where EB would put it behind the matrix phase, 1024 = s_memtime timeline of workgroup 0 into p.dbg,
 // 16384 = every survivor updates the histogram, 4096 = survivors walked per lane (no LDS transposition), 8192 = parked scores walked at once (no batching), 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
 //
 // Vector-memory discipline.  The prefetched tile registers are consumed with counted waits
@@ -115,7 +142,7 @@ template <int D, int FMT = 0, int ABL = 0>
 __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Params p) {
   static_assert(D % 128 == 0 && D >= 128 && D <= 1024, "D must be a multiple of 128, <= 1024");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using L = ScanQ8Lds<D>;
+  using L = ScanQ8Lds<D, (FMT != 0) || Q8_M16_FP16_ROWS>;
   constexpr int KS = D / 32;          // MFMA k-steps
   static_assert(FMT == 0 || D % 256 == 0, "fp8 rows are padded to a multiple of 256");
   constexpr int EPC = FMT ? 16 : 8;   // values per 16-byte chunk (fp8 / int8 : fp16)
@@ -258,7 +285,14 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       const uint4 v = f.c[j];
       *(uint4*)at = make_uint4(v.x ^ opaque_zero, v.y ^ opaque_zero, v.z ^ opaque_zero, v.w ^ opaque_zero);
     } else if constexpr (FMT == 1) {
-      *(uint4*)at = rarc_quant8_chunk_f8(f.c[j], (half_t)f.mul[j]);
+      if (ABL & 16) {            // (ablation: the raw bytes, no conversion arithmetic)
+        const uint4 v = f.c[j];
+        *(uint4*)at = make_uint4(v.x ^ opaque_zero, v.y ^ opaque_zero, v.z ^ opaque_zero, v.w ^ opaque_zero);
+      } else {
+        const uint4 v = rarc_quant8_chunk_f8(f.c[j], (half_t)f.mul[j]);
+        if (ABL & 32768) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));   // (ablation: converted, not written to LDS)
+        else *(uint4*)at = v;
+      }
     } else {
       uint2 o;
       if (ABL & 16) { o.x = f.c[j].x ^ f.c[j].z; o.y = f.c[j].y ^ f.c[j].w; }
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       i32x4 c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};  // [row block][query block]
       // (D = 1024 fp8 with a deeper prefetch and/or one fetch group instead of two — 230-256 VGPRs, no spill — measured the same
       //  15.7-15.9 ms per 50M rows as this: LDS prefetch depth is not what that kernel waits for)
-      constexpr int PF = (D <= 768) ? 2 : 1;     // k steps of 64 read ahead (two fragments each)
+      constexpr int PF = (D <= 768) ? 2 : Q8_BIG_PF;     // k steps of 64 read ahead (two fragments each)
       constexpr int CSTEP = KS2 / CPT;           // one chunk converted every CSTEP steps (KS2 = 4·CPT for fp8)
       i32x4 a0[PF], a1[PF];
       if (!(ABL & 4)) {
@@ -535,7 +569,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // spill would put scratch traffic into the very queue the counted waits rely on); FOUR for narrow rows, where two
   // tiles are too few bytes in flight to cover the HBM latency (48 KB per CU at D = 384 against ~45 KB needed:
   // cycles per tile were 1170 + 2.4 D, the constant being exposed latency — DESIGN.md, narrow rows)
-  constexpr int NG = D <= Q8_DEEP_D ? 4 : ((FMT != 0 || D <= 896) ? 2 : 1);
+  constexpr int NG = D <= Q8_DEEP_D ? 4 : (FMT != 0 ? (D <= 768 ? 2 : Q8_BIG_NG) : (D <= 896 ? 2 : 1));
   // ---- prologue: tile t0 straight into LDS buffer 0; tiles t0+stride, t0+2·stride in flight ----
   // (the launch guarantees gridDim.x <= n_tiles, so tile t0 exists)
   Fetch f[NG];
@@ -552,6 +586,16 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
   // instead of both leaving the matrix pipe idle at the same time.
   constexpr bool PP = (D <= 768) && !(ABL & 256);  // (where the second accumulator still fits in registers)
   const bool grp_b = PP && wave >= Q8_WAVES / 2;
+  // EB — without the ping-pong (D > 768: the fp8 rows of config 5) the iteration's barrier sits right BEHIND the matrix
+  // phase instead of at the end of the iteration.  What the barrier orders is the tile buffers: every wave has finished
+  // reading buffer PAR (its MFMAs) and writing buffer PAR^1 (its share of the next tile's conversion) — both are over when
+  // mfma_convert returns; pruning, survivor staging and the refill of the fetch group touch per-wave LDS and registers only.
+  // With the barrier at the end (round 3), the s_memtime timeline of 100M x 1024 fp8 rows showed (profiles/r04_f8_timeline.txt)
+  // waves 0-3 of a workgroup done with MFMA + prune + refill at ~2700 of a 4350-cycle iteration and then parked at the barrier
+  // until ~4100, waiting for their SIMD partners (waves 4-7 lose the arbitration for the matrix pipe, finish their MFMAs
+  // at ~2850 and prune afterwards) — a third of every iteration with the matrix pipe idle.  Now the early waves wait only
+  // for the partners' MFMAs, and a wave's pruning overlaps the other waves' next matrix phase.
+  constexpr bool EB = Q8_EB && !PP && !(ABL & 512);
   if constexpr (NG == 4) {
     fetch(f[1], clamp_tile(t0 + stride), Q8Flag<true>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -600,8 +644,13 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         thr = fmaxf(thr, __uint_as_float(f[G].thr));                                                  \
         if (lane < 32) s_hland[32 * wave + lane] = f[G].hw;                                           \
       }                                                                                                       \
+      if constexpr (EB) { /* the iteration's ONE barrier, here: see EB above */                               \
+        Q8_STAMP(3)                                                                                           \
+        q8_lds_barrier();                                                                                     \
+        Q8_STAMP(4)                                                                                           \
+      }                                                                                                       \
       if (!(ABL & 1) && live) prune(acc, cur, tinv, tsc);                                                     \
-      else if (acc[0] == 0x7fffffff) p.cnt2[0] = 1; /* keep the MFMAs alive */                                \
+      else if (q8_all16(acc) == 0x7fffffff) p.cnt2[0] = 1; /* keep ALL the MFMAs alive (M16: four accumulators) */ \
       Q8_STAMP(2)                                                                                             \
       /* refill that group with tile cur+3·stride */                                                          \
       if (!(ABL & 2)) fetch(f[G], clamp_tile(cur + (NG + 1) * stride), Q8Flag<Q8_RF(G)>{});           \
@@ -618,11 +667,13 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         thr = fmaxf(thr, __uint_as_float(f[G].thr));                                                          \
         if (lane < 32) s_hland[32 * wave + lane] = f[G].hw;                                                   \
       }                                                                                                       \
-      if ((ABL & 1) && acc_b[0] == 0x7fffffff) p.cnt2[0] = 1;                                                 \
+      if ((ABL & 1) && q8_all16(acc_b) == 0x7fffffff) p.cnt2[0] = 1;                                          \
     }                                                                                                         \
-    Q8_STAMP(3)                                                                                               \
-    q8_lds_barrier();                                                                                         \
-    Q8_STAMP(4)                                                                                               \
+    if constexpr (!EB) {                                                                                      \
+      Q8_STAMP(3)                                                                                             \
+      q8_lds_barrier();                                                                                       \
+      Q8_STAMP(4)                                                                                             \
+    }                                                                                                         \
     ++it;                                                                                                     \
     /* owner: the histogram landed by all waves before this barrier -> a higher threshold */                  \
     if (!(ABL & 8) && wave == 0 && has_own && (it <= 16 || (it & 3) == 0)) {                                  \
@@ -691,10 +742,12 @@ bool rarc_prof_next(hipEvent_t* start, hipEvent_t* stop);  // rarc_api.hip
 int rarc_seed_launch(const void* corpus, const float* rowscale, int fmt, int64_t n_rows, int d_pad,
                      const uint16_t* q16, int nq, int kprime, float bin_lo, float bin_hi, const float* sub_a,
                      const float* sub_b, const RarcWs& ws, hipStream_t s, int64_t rows_covered, const float* floor);  // scan_f16.hip
+int rarc_scan_f16_stage_launch(const uint16_t* corpus, int64_t n_rows, uint32_t stage_tiles, int d_pad, const uint16_t* q16,
+                               const float* eps16, int nq, int kprime, const RarcWs& ws, int cap, int grid, hipStream_t s);  // scan_f16.hip
 
 template <int D, int FMT, int ABL = 0>
 static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
-  constexpr size_t lds = ScanQ8Lds<D>::TOTAL;
+  constexpr size_t lds = ScanQ8Lds<D, (FMT != 0) || Q8_M16_FP16_ROWS>::TOTAL;
   static RarcPerDevice attr_done;
   if (size_t& done = attr_done.cur(); !done) {
     RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, FMT, ABL>,
@@ -709,6 +762,42 @@ static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
     if (abl == 4) return launch_scan_q8<D, FMT, 4>(p, grid, s);
     if (abl == 5) return launch_scan_q8<D, FMT, 5>(p, grid, s);
     if (abl == 9) return launch_scan_q8<D, FMT, 9>(p, grid, s);
+    if constexpr (FMT == 1) {
+      if (abl == 1024 || abl == 1025) {   // s_memtime timeline of workgroup 0, iterations 1000-1015 -> the file RARC_Q8_TIMELINE names
+        static unsigned long long* d_dbg = nullptr;
+        if (!d_dbg) RARC_HIP_CHECK(hipMalloc((void**)&d_dbg, 65536));
+        RARC_HIP_CHECK(hipMemsetAsync(d_dbg, 0, 65536, s));
+        ScanQ8Params pd = p;
+        pd.dbg = d_dbg;
+        hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, FMT, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)rarc_scan_q8_kernel<D, FMT, 1025>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (abl == 1024) hipLaunchKernelGGL((rarc_scan_q8_kernel<D, FMT, 1024>), dim3(grid), dim3(Q8_THREADS), lds, s, pd);
+        else hipLaunchKernelGGL((rarc_scan_q8_kernel<D, FMT, 1025>), dim3(grid), dim3(Q8_THREADS), lds, s, pd);
+        RARC_HIP_CHECK(hipStreamSynchronize(s));
+        if (const char* path = getenv("RARC_Q8_TIMELINE"); path && p.n_tiles - p.t_begin > 1100u * (uint32_t)grid) {
+          static unsigned long long h[8192];
+          RARC_HIP_CHECK(hipMemcpy(h, d_dbg, 65536, hipMemcpyDeviceToHost));
+          if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "launch tiles [%u, %u) abl %d: per iteration and wave, shader cycles relative to wave 0's start of the iteration: start | after mfma+convert | after prune | after fetch issue | after barrier\n", p.t_begin, p.n_tiles, abl);
+            for (int it = 2; it < 10; ++it)
+              for (int w = 0; w < Q8_WAVES; ++w) {
+                const unsigned long long* r = &h[8 + (it * Q8_WAVES + w) * 8];
+                const unsigned long long b0 = h[8 + (it * Q8_WAVES) * 8];
+                fprintf(f, "it %2d w%d: %6lld %6lld %6lld %6lld %6lld   (next iteration starts at %lld)\n", it, w, (long long)(r[0] - b0), (long long)(r[1] - b0),
+                        (long long)(r[2] - b0), (long long)(r[3] - b0), (long long)(r[4] - b0), (long long)(h[8 + ((it + 1) * Q8_WAVES + w) * 8] - b0));
+              }
+            fclose(f);
+          }
+        }
+        return RARC_OK;
+      }
+      // round 4: where the fp8 scan's time goes (profiles/r04_f8_attribution.txt)
+      if (abl == 512) return launch_scan_q8<D, FMT, 512>(p, grid, s);        // round 3's barrier placement (A/B of EB; results are right)
+      if (abl == 17) return launch_scan_q8<D, FMT, 17>(p, grid, s);          // no conversion, no pruning (MFMAs on raw bytes)
+      if (abl == 21) return launch_scan_q8<D, FMT, 21>(p, grid, s);          // fetch + LDS write only
+      if (abl == 32769) return launch_scan_q8<D, FMT, 32769>(p, grid, s);    // converted but not written to LDS, MFMAs on stale LDS, no pruning
+      if (abl == 32773) return launch_scan_q8<D, FMT, 32773>(p, grid, s);    // fetch + conversion only
+    }
   }
 #endif
   hipEvent_t e0, e1;
@@ -750,7 +839,8 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
                         const float* qmeta, const uint16_t* q16, const int8_t* q8, const float* qinv,
                         const float* eps16, const float* eps8, int nq, int kprime, float bin_lo, float bin_hi,
                         const RarcWs& ws, int cap, int* grid_out, hipStream_t s, const int8_t* shadow8,
-                        int (*tighten)(void* ctx, int n_wg), void* tighten_ctx, const float* hq, const float* floor) {
+                        int (*tighten)(void* ctx, int n_wg, int mode), void* tighten_ctx, const float* hq, const float* floor,
+                        int* hybrid_out) {
   ScanQ8Params p;
   p.hq = hq;
   p.corpus = fmt == 2 ? (const uint4*)shadow8 : (const uint4*)corpus;
@@ -818,6 +908,31 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   if (rc) return rc;
   if (p.n_tiles == 0) return RARC_OK;  // (the seed pass above still initialised thresholds, histograms and flags)
   uint32_t begin = 0;
+  // Hybrid search of a SMALL shard (fp16 rows, no cascade cut: below ~2M rows).  There the int8 scan's weakness is its
+  // start: the 4096-row sample puts the threshold two int8 error bounds under a k-th best score that is itself far below
+  // the final one (11 K candidates per query at 1M rows, a 0.1 ms finalize), while the fp16 MFMA scan — tight margin, a few
+  // hundred candidates — is held at 0.36 ms per 1M rows by the matrix pipe's power draw.  So the FIRST EIGHTH of the
+  // shard runs through the fp16 kernel (scan_f16.hip, rigorous 2·eps16 margin: no certificate needed), one exact pass
+  // turns its candidates into L1 = the k-th best canonical score of 1/8 of the rows, and the int8 kernel streams the other
+  // seven eighths under L1 - eps8 from its first tile, continuing the same candidate segments.
+  static const int hybrid_env = getenv("RARC_HYBRID") ? atoi(getenv("RARC_HYBRID")) : 1;
+  static const int hybrid_div = getenv("RARC_HYBRID_DIV") ? atoi(getenv("RARC_HYBRID_DIV")) : 8;
+  if (hybrid_out) *hybrid_out = 0;
+  if (hybrid_out && hybrid_env && tighten && fmt == 0 && d_pad <= 768 && n_cuts == 0 && hybrid_div >= 2) {
+    const uint32_t stage = (p.n_tiles / (uint32_t)hybrid_div) / pair * pair;   // whole pairs of tile rounds, as the cuts
+    if (stage >= 2u * pair && stage < p.n_tiles) {
+      if ((rc = rarc_scan_f16_stage_launch((const uint16_t*)corpus, n_rows, stage, d_pad, q16, eps16, nq, kprime, ws, cap, grid,
+                                           s)) != RARC_OK)
+        return rc;
+      if ((rc = tighten(tighten_ctx, grid, 2)) != RARC_OK) return rc;
+      ScanQ8Params pi = p;
+      pi.t_begin = stage;
+      pi.resume = 1u;
+      pi.hot_margin = 0.f;
+      *hybrid_out = 1;
+      return launch(pi);
+    }
+  }
   for (int i = 0; i <= n_cuts; ++i) {
     ScanQ8Params pi = p;
     pi.t_begin = begin;
@@ -826,7 +941,7 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
     // (after a pass the tightened threshold is no longer "k-th approximate score - 2 eps8": count everything)
     pi.hot_margin = i > 0 ? 0.f : 1.0f;
     if ((rc = launch(pi)) != RARC_OK) return rc;
-    if (i < n_cuts && (rc = tighten(tighten_ctx, grid)) != RARC_OK) return rc;
+    if (i < n_cuts && (rc = tighten(tighten_ctx, grid, 1)) != RARC_OK) return rc;
     begin = pi.n_tiles;
   }
   return RARC_OK;

@@ -534,7 +534,23 @@ class FlatIndexF16:
                                            version=self._rows_version()))
             return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc)
 
-    def _repair_rows(self, q, k, out_ids, out_sc, flagged) -> None:
+    CAND_CAP_LIMIT = 1 << 21    # sticky growth of cand_cap stops here (4.3 GB of candidate keys per 128 results)
+
+    def _grow_if_segments_overflowed(self, words) -> None:
+        """A query flagged with RARC_Q_WHY_SEGMENT ran out of room in a scan workgroup's candidate segment: this CORPUS lets
+        more rows through the int8 margin than `cand_cap` was sized for (clustered data at 100M rows: a query's whole
+        cluster, ~100 K rows).  The re-run below fixes the answer; doubling the capacity for every LATER search fixes the
+        cause — otherwise each batch pays a second scan of the shard (76.9 vs 39.6 ms per batch at 100M clustered rows)."""
+        try:
+            seg = any(int(w) & 0x100 for w in words)
+        except TypeError:
+            seg = False
+        if seg and self.cand_cap < self.CAND_CAP_LIMIT:
+            self.cand_cap = min(self.CAND_CAP_LIMIT, 2 * self.cand_cap)
+            self.cand_cap_grown = getattr(self, "cand_cap_grown", 0) + 1
+            self._ws, self._cap_eff = None, 0          # the next search allocates the larger workspace
+
+    def _repair_rows(self, q, k, out_ids, out_sc, flagged, words=None) -> None:
         """Make the flagged rows of (out_ids, out_sc) exact (the shared query buffers may hold a later batch by now).
 
         First a re-run of the SEARCH for the flagged queries together, started from what the first attempt did
@@ -549,6 +565,8 @@ class FlatIndexF16:
         stream = self._stream()
         left = list(flagged)
         big = None
+        if words is not None:
+            self._grow_if_segments_overflowed(words)
         if left and self.ntotal:
             # the re-run gets a workspace of ITS OWN with four times the candidate capacity, released afterwards: the
             # steady-state workspace (and the cand_cap every later search is launched with) stays what it was.  If HBM
@@ -669,10 +687,11 @@ class FlatIndexF16:
             return
         # one 4-byte read-back per batch (syncs); the per-query words are fetched only if it is set
         any_flag = int(status[B.MAX_QUERIES].item())
-        flagged = t.nonzero(status[:nq]).flatten().tolist() if any_flag else []
+        words = status[:nq].cpu().tolist() if any_flag else []
+        flagged = [i for i, w in enumerate(words) if w]
         self.last_repaired = flagged
         if flagged:
-            self._repair_rows(q, k, out_ids, out_sc, flagged)
+            self._repair_rows(q, k, out_ids, out_sc, flagged, words=[words[i] for i in flagged])
 
     def neighbors_above(self, queries, threshold: float, k_cap: int = 64):
         """Range query by score: for every query, the stored rows whose canonical score is >= threshold
@@ -798,13 +817,15 @@ class PendingSearch:
             if self.done is not None:
                 self.done.synchronize()   # this batch only: later batches keep running
             if int(self.flag[0] if self.done is not None else self.flag.item()):
-                self.repaired = t.nonzero(self.status).flatten().tolist()
+                words = self.status.cpu().tolist()
+                self.repaired = [i for i, w in enumerate(words) if w]
                 if self.version is not None and self.version != self.index._rows_version():
                     raise B.RarcError("the index rows changed while a search was in flight: its flagged queries cannot be "
                                       "repaired against the rows it scanned (collect results before add() / reset())")
                 stream = self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)
                 with self.index._lock, t.cuda.device(self.index.device), t.cuda.stream(stream):
-                    self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired)
+                    self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired,
+                                            words=[words[i] for i in self.repaired])
                     stream.synchronize()
             self.index.last_repaired = self.repaired
         return self.ids, self.scores
