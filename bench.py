@@ -69,6 +69,9 @@ def parse(argv=None):
                     help="config 5: embed batch i+1 on a side stream under the scan of batch i (measured: no gain on one GPU — "
                          "the persistent scan kernel holds every CU's whole register file, so the forward's kernels wait for it)")
     ap.add_argument("--no-c5-alt", action="store_true", help="config 5: skip the second timed loop in the other encoder precision")
+    ap.add_argument("--no-persist", action="store_true", help="skip the shard-file leg (save / load of a 10M-row shard)")
+    ap.add_argument("--persist-rows", type=int, default=10_000_000)
+    ap.add_argument("--persist-dir", default="", help="where the shard file goes (default: a temporary directory)")
     ap.add_argument("--no-ingest", action="store_true", help="skip the ingest leg (texts -> tokeniser -> encoder -> stored rows)")
     ap.add_argument("--ingest-docs", type=int, default=0, help="documents per ingest configuration (0 = sized for ~1-2 s each)")
     ap.add_argument("--verify-queries", type=int, default=256,
@@ -269,8 +272,8 @@ def scan_profile(lib, B, ctypes, fn, max_launches):
 
 
 def recorded_traffic(kernel, rows_per_launch, dim, storage="f16"):
-    """HBM bytes per scan from the committed PMC pass of the same shape (profiles/traffic_r03.json, falling back to the earlier rounds' files), or None."""
-    for name in ("traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+    """HBM bytes per scan from the committed PMC pass of the same shape (profiles/traffic_r04.json, falling back to the earlier rounds' files), or None."""
+    for name in ("traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue
@@ -476,6 +479,13 @@ def main():
                     world, rank, local_rank, dev, use_dist)
         if rank == 0:
             result["c5"] = c5
+    # ---- shard files: a 10M x dim fp16 shard streamed HBM -> file -> HBM by the library, one GPU --------------
+    if world == 1 and not a.no_persist and a.storage == "f16":
+        torch.cuda.empty_cache()
+        try:
+            result["persistence"] = leg_persist(torch, lib, B, FlatIndexF16, a, local_rank)
+        except OSError as exc:      # (no room for the file: the leg reports why instead of failing the bench)
+            result["persistence"] = {"skipped": str(exc)}
     # ---- ingest: texts -> host WordPiece -> encoder -> normalise / quantise / append, one GPU ----------
     if world == 1 and not a.no_ingest and a.storage == "f16":
         torch.cuda.empty_cache()
@@ -973,6 +983,72 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
         out["cpu_baseline"] = cpu_baseline_c5(np, sd_host, tok_h, lens_h, HEADS, idx, emb0, K, fuse, lex)
         out["encoder_vs_host_fp32_forward"] = out["cpu_baseline"].pop("encoder_check")
     return out
+
+
+def leg_persist(torch, lib, B, FlatIndexF16, a, local_rank):
+    """SURVEY 8 f1 — save_local / load_local of a corpus-scale shard (VectorStore_Faiss.py:432-482 -> faiss.write_index /
+    read_index): `--persist-rows` x dim fp16 rows written from HBM and read back into HBM by rarc_device_to_file /
+    rarc_file_to_device (pinned ring, no host copy), GB/s of row bytes for each direction, the process's resident-memory
+    high-water mark, and whether the search after the load equals the search before the save bit for bit."""
+    import shutil
+    import tempfile
+
+    def vm(field):
+        with open("/proc/self/status") as fh:
+            for line in fh:
+                if line.startswith(field + ":"):
+                    return int(line.split()[1])
+        return -1
+
+    n, d = a.persist_rows, a.dim
+    need = n * B.padded_dim(d) * 2
+    folder = a.persist_dir or tempfile.mkdtemp(prefix="rarc_bench_")
+    if shutil.disk_usage(folder).free < need * 1.1:
+        raise OSError(f"{folder}: less than {need * 1.1 / 1e9:.0f} GB free for the shard file")
+    path = os.path.join(folder, "bench.rarc")
+    try:
+        idx = build_index(torch, lib, B, FlatIndexF16, local_rank, d, 0, n)
+        q = torch.empty((a.batch, d), dtype=torch.float32, device=torch.device("cuda", local_rank))
+        B.check(lib.rarc_synth_rows_f32(q.data_ptr(), d, d, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
+        i0, s0 = idx.search_device(q, a.k)
+        torch.cuda.synchronize()
+        rss0 = vm("VmRSS")
+        t0 = time.perf_counter()
+        st_save = idx.save_shard(path)
+        t_save = time.perf_counter() - t0
+        del idx
+        torch.cuda.empty_cache()
+        idx2 = FlatIndexF16(d, metric="cosine", device=local_rank)
+        t0 = time.perf_counter()
+        st_hot = idx2.load_shard(path)                      # the file is still in the page cache
+        torch.cuda.synchronize()
+        t_hot = time.perf_counter() - t0
+        i1, s1 = idx2.search_device(q, a.k)
+        same = bool(torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32)))
+        del idx2
+        torch.cuda.empty_cache()
+        fd = os.open(path, os.O_RDONLY)                    # drop the file's pages: the next load comes from storage
+        os.fsync(fd)
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        os.close(fd)
+        idx3 = FlatIndexF16(d, metric="cosine", device=local_rank)
+        t0 = time.perf_counter()
+        st_cold = idx3.load_shard(path)
+        torch.cuda.synchronize()
+        t_cold = time.perf_counter() - t0
+        del idx3
+        torch.cuda.empty_cache()
+        return {"workload": f"{n}x{d} fp16 shard ({need / 1e9:.1f} GB), rarc_device_to_file / rarc_file_to_device, 8 threads, 256 MB pinned ring",
+                "save_GBps": round(st_save["gb_per_s"], 2), "save_s": round(t_save, 3), "save_o_direct": bool(st_save.get("direct")),
+                "load_GBps_page_cache": round(st_hot["gb_per_s"], 2), "load_s_page_cache": round(t_hot, 3),
+                "load_GBps_cold": round(st_cold["gb_per_s"], 2), "load_s_cold": round(t_cold, 3),
+                "pcie_gen5_x16_GBps": 63.0, "search_after_load_identical": same,
+                "host_rss_kb_before": rss0, "host_hwm_kb_after": vm("VmHWM"), "directory": folder}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+        if not a.persist_dir:
+            shutil.rmtree(folder, ignore_errors=True)
 
 
 INGEST_GEOMS = {"bge-base": dict(H=768, HEADS=12, FFN=3072, LAYERS=12), "bge-large": dict(H=1024, HEADS=16, FFN=4096, LAYERS=24)}

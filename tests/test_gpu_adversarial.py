@@ -164,6 +164,18 @@ def test_overflowing_candidate_segments_are_rerun_from_a_score_floor(oracle, sto
     assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
     assert len(idx.last_repaired) >= nq // 2, "the test is meant to overflow"
     assert idx.last_rerun == len(idx.last_repaired), "the re-run should have settled every flagged query"
+    # the overflow taught the index something about this corpus: the capacity of LATER searches has doubled (sticky), and
+    # after a few batches nothing overflows any more — no batch keeps paying a second scan of the shard
+    assert idx.cand_cap == 8192 and idx.cand_cap_grown == 1
+    for _ in range(6):
+        D2, I2 = idx.search(Q, k)
+        assert np.array_equal(I2, rI) and np.array_equal(D2.view(np.uint32), rD.view(np.uint32))
+        if not idx.last_repaired:
+            break
+    assert not idx.last_repaired and idx.cand_cap <= 4096 * 64
+    grown = idx.cand_cap_grown
+    idx.search(Q, k)
+    assert idx.cand_cap_grown == grown and not idx.last_repaired          # steady state
 
 
 def test_clustered_corpus_whole_cluster_inside_the_int8_margin(oracle):
