@@ -37,6 +37,13 @@ for scan in PATHS:
         idx.add(make(min(slab, N - s0), 100 + s0 // slab))
     q = make(NQ, 7)                                  # queries from the same mixture: they have real neighbours
     ids, sc = idx.search_device(q, K, repair=False)
+    st_cold = idx.last_status.cpu().numpy()          # what the very first batch of this index saw
+    for _ in range(6):                               # exact searches until the candidate capacity has settled (sticky growth)
+        g0 = getattr(idx, "cand_cap_grown", 0)
+        idx.search_device(q, K)
+        if getattr(idx, "cand_cap_grown", 0) == g0:
+            break
+    ids, sc = idx.search_device(q, K, repair=False)
     torch.cuda.synchronize()
     st = idx.last_status.cpu().numpy()
     ws = idx._ws
@@ -55,6 +62,8 @@ for scan in PATHS:
     out["paths"][scan] = {
         "candidates_per_query": {"min": int(cnt.min()), "mean": float(cnt.mean()), "max": int(cnt.max())},
         "fullest_segment": int(cnt2.max()), "segment_capacity": idx._cap_eff // 256,
+        "cand_cap": int(idx.cand_cap), "cand_cap_doublings": int(getattr(idx, "cand_cap_grown", 0)),
+        "flagged_queries_first_batch_ever": int((st_cold != 0).sum()),
         "flagged_queries": int((st != 0).sum()), "flag_words": sorted(set(hex(int(v)) for v in st[st != 0])), "settled_by_rerun": int(getattr(idx, "last_rerun", 0)),
         "repaired_one_by_one": int(len(idx.last_repaired) - getattr(idx, "last_rerun", 0)) if idx.last_repaired else 0,
         "ms_per_batch_first_attempt": round(t_scan * 1e3, 3), "qps_first_attempt": round(NQ / t_scan, 1),
