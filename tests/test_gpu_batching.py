@@ -89,7 +89,8 @@ def test_256_concurrent_invokes_share_three_scans():
             t.join()
 
     _, launches = _scan_launches(storm)
-    scans_per_search = 1          # 1M x 128 rows: one scan launch per search (no cascade below 2.1M rows)
+    scans_per_search = 2          # 1M x 128 rows, k = 10: the int8 path below the cascade's first cut = the hybrid's two stages
+                                  # (fp16 scan of the first eighth, int8 scan of the rest: DESIGN 4.2), no cascade
     assert store.coalesced_launches[1] == 256 and store.coalesced_launches[0] <= 3, store.coalesced_launches
     assert launches <= 3 * scans_per_search, launches
     assert len(emb.query_batches) == store.coalesced_launches[0]            # the queries of a launch were embedded together

@@ -18,6 +18,11 @@ for i in range(LAYERS):
 enc = HipBertEncoder(sd, num_heads=HEADS, precision=os.environ.get("RARC_ENC_PRECISION", "fp16"))
 tok = torch.randint(1, VOCAB, (NQ, L), generator=g, device=dev).int()
 lens = torch.full((NQ,), L, dtype=torch.int32, device=dev)
-for _ in range(6):
+import time
+for _ in range(2):
+    enc.forward_device(tok, lens)
+torch.cuda.synchronize(); t0 = time.time()
+for _ in range(4):
     enc.forward_device(tok, lens)
 torch.cuda.synchronize()
+print(f"ENC seqs={NQ} tokens={L} precision={enc.precision}: {(time.time() - t0) / 4 * 1e3:.3f} ms per forward (wall, 4 back to back)")

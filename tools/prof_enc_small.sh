@@ -1,22 +1,20 @@
 #!/bin/bash
-# small-batch encoder: tests, timing, kernel stats at 32x32 (rocprofv3 under timeout: it has hung at exit before)
+# is the encoder's fixed cost per forward launch overhead?  sum of kernel time (rocprofv3) against wall time, 32 and 256 sequences
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/enc_small; mkdir -p $O
-cd $R
-python3 -m pytest tests/test_gpu_encoder.py -x -q -m gpu 2>&1 | tail -3
-python3 tools/encoder_bench_small.py 2>&1 | grep bge
-cat > /tmp/one.py <<'PY'
-import os, sys
-sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
-import numpy as np, torch
-from oracle import cpu_ref
-from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
-sd = cpu_ref.random_bert_state_dict(1024, 24, 16, 4096, vocab=2000, max_pos=512, seed=1)
-enc = HipBertEncoder(sd, num_heads=16, precision="fp16")
-ids = np.random.default_rng(0).integers(1, 2000, (32, 32)).astype(np.int32)
-for _ in range(6): enc.forward(ids)
-torch.cuda.synchronize()
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_enc_small; rm -rf $O; mkdir -p $O; cd $R
+for P in fp32 fp16; do for S in 32 256; do
+  export PROBE_SEQS=$S RARC_ENC_PRECISION=$P
+  python3 tools/enc_only.py 2>/dev/null | grep ENC
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$P$S -- python3 tools/enc_only.py > $O/$P$S.log 2>&1
+  f=$(ls -t $O/$P$S/*/*kernel_stats.csv | head -1); cp $f $R/gpurun_out/r04_enc_${P}_${S}x32_kernel_stats.csv
+  python3 - $f <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+k = [r for r in rows if "rarc" in r["Name"]]
+tot = sum(int(r["TotalDurationNs"]) for r in k); calls = sum(int(r["Calls"]) for r in k)
+print(f"   kernels: {tot / 6 / 1e6:.3f} ms per forward in {calls // 6} launches")
+for r in sorted(k, key=lambda r: -int(r["TotalDurationNs"]))[:8]:
+    print("     ", r["Name"][:70].ljust(70), int(r["Calls"]) // 6, f'{float(r["AverageNs"]) / 1e3:.1f} us')
 PY
-cd /tmp
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 /tmp/one.py > $O/kt2.log 2>&1
-f=$(ls -t $O/kt2/*/*kernel_stats.csv | head -1); cat $f | cut -c1-160 | head -12
+done; done
+find $O -name "*.db" -delete; find $O -name "*trace.csv" -delete
