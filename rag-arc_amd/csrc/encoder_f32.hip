@@ -15,6 +15,8 @@
 // Everything between the GEMMs is fp32: residual stream, LayerNorm (two-pass statistics), exact erf GELU (libm erff),
 // softmax (libm expf), pooling and the canonical L2 normalisation.  Attention (QKᵀ, PV) runs on the fp32 MFMA (exact fp32).
 #include "rarc_common.h"
+#include <cstring>
+#include <cstdlib>
 
 int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s);  // encoder.hip
 int rarc_gemm_f16_f32out_parts(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, int max_parts, int* parts,
@@ -380,6 +382,286 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4 — the same attention on the fp16 MFMA over SPLIT operands (head_dim 64: bge-base / bge-large / MPNet).
+// The fp32 MFMA runs at 1/16 of the fp16 rate; at 512 tokens the kernel above cost a third of an ingest forward.  Here every
+// operand is a (hi, lo) pair of fp16 images of the fp32 value times a power of two — exactly the GEMMs' form:
+//   S^T = [K_lo | K_hi | K_hi] · [Q_hi | Q_lo | Q_hi]^T / (s_k[key] · s_q[query])          per-row scales
+//   O^T += ( [V_lo | V_hi | V_hi]^T · [P_hi | P_lo | P_hi]^T ) / (s_v[block] · 2^11)       per (16 keys x 32 d) block scale
+// fp16 products are exact in the fp32 accumulator; dropped: the lo·lo terms (2^-22 relative) and the tail of lo (< 2^-22 of
+// the value, or 2^-38 of the row / block maximum where lo is subnormal).  p in [0, 1] is split as p·2^11.  Softmax itself
+// (maximum, libm expf, sum) is fp32 as before.
+// One WORKGROUP (4 waves) per (sequence, head, four consecutive 32-query blocks), one wave per block.  Every 32-key tile is
+// fetched, scaled and split ONCE per workgroup: all four waves share the K image (row-major, 16-byte row pad), wave w builds
+// the V^T image of block (keys 16(w&1).., d 32(w>>1)..) — its block maximum is a wave reduction, no exchange — with key pairs
+// packed into 4-byte writes.  Raw rows of tile t+1 travel in registers while tile t is multiplied; the images are double
+// buffered: one barrier per tile.  P^T fragments are assembled with v_permlane32_swap as in decoder.hip.
+// Keys >= lens[seq] are masked and never read (clamped to the last real token): a result does not depend on the padding.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void e32a_scale_of(float mx, float& s, float& inv) {   // like e32_scale_of, exponent within +-60:
+  s = 1.f; inv = 1.f;                                                              // products of two inverses stay finite
+  if (mx > 0.f && mx < __builtin_inff()) {
+    int e;
+    (void)frexpf(mx, &e);
+    int ex = 14 - e;
+    ex = ex > 60 ? 60 : (ex < -60 ? -60 : ex);
+    s = ldexpf(1.f, ex);
+    inv = ldexpf(1.f, -ex);
+  }
+}
+__device__ __forceinline__ void e32a_split(float x, half_t& hi, half_t& lo) {
+  hi = (half_t)x;
+  lo = (half_t)(x - (float)hi);
+}
+
+template <bool REL>
+__global__ __launch_bounds__(256) void rarc_e32_attention_split_kernel(const float* __restrict__ P, const float* __restrict__ ra,
+                                                                       const float* __restrict__ rw, const float* __restrict__ bias,
+                                                                       const int32_t* __restrict__ lens, int L, int H, int n_heads,
+                                                                       int q_blocks, int q_groups, float* __restrict__ ctx,
+                                                                       const float* __restrict__ rel, int rel_span, int n_parts,
+                                                                       size_t part_stride) {
+  constexpr int DH = 64, MB = 2, KS = 4;
+  constexpr int KROW = DH + 8;   // halves per K row (+16 bytes: conflict-free ds_read_b128 fragments)
+  constexpr int VROW = 40;       // halves per V^T row: 32 keys + pad
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) half_t kh[2][32 * KROW], kl[2][32 * KROW];
+  __shared__ __attribute__((aligned(16))) half_t vh[2][DH * VROW], vl[2][DH * VROW];
+  __shared__ __attribute__((aligned(16))) float skinv[2][32];
+  __shared__ float svinv[2][4];
+  __shared__ __attribute__((aligned(16))) float sb[6 * DH];   // rw | bias of this head's q, k, v columns
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qg = blockIdx.x % q_groups, bh = blockIdx.x / q_groups;
+  const int b = bh / n_heads, hd = bh % n_heads;
+  const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
+  const int col = lane & 31, hh = lane >> 5;
+  const size_t rs = (size_t)3 * H;
+  const size_t tok0 = (size_t)b * L;
+  const int qb = 4 * qg + wave;
+  const bool live = qb < q_blocks;
+  for (int i = tid; i < 3 * DH; i += 256) {
+    const int part = i / DH, c = i % DH;   // 0 q, 1 k, 2 v
+    sb[part * 2 * DH + c] = rw[part * H + hd * DH + c];
+    sb[part * 2 * DH + DH + c] = bias[part * H + hd * DH + c];
+  }
+  __syncthreads();
+
+  auto load4 = [&](const float* src) {   // one 16-byte piece, split-K partial slabs summed in order
+    float4 p = *(const float4*)src;
+    for (int sp = 1; sp < n_parts; ++sp) {
+      const float4 q4 = *(const float4*)(src + sp * part_stride);
+      p.x += q4.x; p.y += q4.y; p.z += q4.z; p.w += q4.w;
+    }
+    return p;
+  };
+  auto affine4 = [&](const float4 p, float r, const float* w) {   // value = P·ra·rw + bias
+    const float4 s4 = *(const float4*)w, b4 = *(const float4*)(w + DH);
+    return make_float4(p.x * r * s4.x + b4.x, p.y * r * s4.y + b4.y, p.z * r * s4.z + b4.z, p.w * r * s4.w + b4.w);
+  };
+
+  // ---- staging roles: K row r = tid >> 3, floats 8c..8c+7 (c = tid & 7); V block (t, mb) = (wave & 1, wave >> 1):
+  //      key pair pp = lane & 7 (keys 16t + 2pp, + 1), floats 32mb + 4cc .. + 3 (cc = lane >> 3) ----
+  const int kr = tid >> 3, kc = tid & 7;
+  const int vt_ = wave & 1, vmb = wave >> 1, vpp = lane & 7, vcc = lane >> 3;
+  float4 kraw0, kraw1, vraw0, vraw1;
+  float kra, vra0, vra1;
+  auto prefetch = [&](int k0) {
+    const int krow = (k0 + kr < len) ? k0 + kr : len - 1;
+    const float* ksrc = P + (tok0 + krow) * rs + H + hd * DH + 8 * kc;
+    kraw0 = load4(ksrc);
+    kraw1 = load4(ksrc + 4);
+    kra = ra[tok0 + krow];
+    const int key0 = k0 + 16 * vt_ + 2 * vpp;
+    const int v0 = key0 < len ? key0 : len - 1, v1 = key0 + 1 < len ? key0 + 1 : len - 1;
+    vraw0 = load4(P + (tok0 + v0) * rs + 2 * H + hd * DH + 32 * vmb + 4 * vcc);
+    vraw1 = load4(P + (tok0 + v1) * rs + 2 * H + hd * DH + 32 * vmb + 4 * vcc);
+    vra0 = ra[tok0 + v0];
+    vra1 = ra[tok0 + v1];
+  };
+  auto store_tile = [&](int buf) {
+    {   // K row piece: scale of the row = max over its 8 lanes
+      const float4 a = affine4(kraw0, kra, sb + 2 * DH + 8 * kc), c4 = affine4(kraw1, kra, sb + 2 * DH + 8 * kc + 4);
+      const float x[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+      float mx = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(x[e]));
+      mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+      float s, inv;
+      e32a_scale_of(mx, s, inv);
+      half8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        half_t h, l;
+        e32a_split(x[e] * s, h, l);
+        hi[e] = h; lo[e] = l;
+      }
+      *(half8*)(kh[buf] + kr * KROW + 8 * kc) = hi;
+      *(half8*)(kl[buf] + kr * KROW + 8 * kc) = lo;
+      if (kc == 0) skinv[buf][kr] = inv;
+    }
+    {   // V block piece: scale of the (16 keys x 32 d) block = max over the wave
+      const float4 a = affine4(vraw0, vra0, sb + 4 * DH + 32 * vmb + 4 * vcc), c4 = affine4(vraw1, vra1, sb + 4 * DH + 32 * vmb + 4 * vcc);
+      const float x0[4] = {a.x, a.y, a.z, a.w}, x1[4] = {c4.x, c4.y, c4.z, c4.w};
+      float mx = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(x0[e]), fabsf(x1[e])));
+      mx = e32_wave_max(mx);
+      float s, inv;
+      e32a_scale_of(mx, s, inv);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        half_t h0, l0, h1, l1;
+        e32a_split(x0[e] * s, h0, l0);
+        e32a_split(x1[e] * s, h1, l1);
+        const int d = 32 * vmb + 4 * vcc + e;
+        *(half2_t*)(vh[buf] + d * VROW + 16 * vt_ + 2 * vpp) = (half2_t){h0, h1};
+        *(half2_t*)(vl[buf] + d * VROW + 16 * vt_ + 2 * vpp) = (half2_t){l0, l1};
+      }
+      if (lane == 0) svinv[buf][2 * vt_ + vmb] = inv * 0.00048828125f;   // · 2^-11: p was split as p · 2^11
+    }
+  };
+
+  prefetch(0);   // the first tile's rows travel while q is loaded and split
+  const int q0 = qb * 32;
+  half8 qh[KS], ql[KS];
+  float sqinv = 1.f;
+  if (live) {
+    const int qrow = (q0 + col < L) ? q0 + col : L - 1;
+    const float r = ra[tok0 + qrow];
+    float x[KS][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float* src = P + (tok0 + qrow) * rs + hd * DH + 16 * ks + 8 * hh;
+      const float4 a = affine4(load4(src), r, sb + 16 * ks + 8 * hh), c4 = affine4(load4(src + 4), r, sb + 16 * ks + 8 * hh + 4);
+      x[ks][0] = a.x; x[ks][1] = a.y; x[ks][2] = a.z; x[ks][3] = a.w;
+      x[ks][4] = c4.x; x[ks][5] = c4.y; x[ks][6] = c4.z; x[ks][7] = c4.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(x[ks][e]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));   // the other half of the row lives in lane l ^ 32
+    float s;
+    e32a_scale_of(mx, s, sqinv);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        half_t h, l;
+        e32a_split(x[ks][e] * s, h, l);
+        qh[ks][e] = h; ql[ks][e] = l;
+      }
+  }
+  const float scale = 0.125f;   // 1/sqrt(64): a power of two, folded into the scale product below
+  f32x16 o[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int buf = 0;
+  for (int k0 = 0; k0 < len; k0 += 32, buf ^= 1) {
+    // image `buf` was last read while tile k0 - 64 was multiplied; every wave has passed the barrier of tile k0 - 32 since
+    store_tile(buf);
+    __syncthreads();
+    if (k0 + 32 < len) prefetch(k0 + 32);   // in flight under this tile's MFMAs and softmax
+    if (!live) continue;                    // (a wave without a query block only stages)
+
+    // ---- S^T tile: keys k0..k0+31 (rows) x this wave's 32 queries (columns), small terms first ----
+    f32x16 st = {0};
+    const half_t* khp = kh[buf] + col * KROW + 8 * hh;
+    const half_t* klp = kl[buf] + col * KROW + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8 ah = *(const half8*)(khp + 16 * ks), al = *(const half8*)(klp + 16 * ks);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[ks], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], st, 0, 0, 0);
+    }
+    // ---- softmax statistics of this lane's query over its 16 keys, then with the partner lane ----
+    float pr[16];
+    float tmax = -INFINITY;
+    const float fq = sqinv * scale;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 ski = *(const float4*)(skinv[buf] + 8 * g + 4 * hh);
+      const float f[4] = {ski.x * fq, ski.y * fq, ski.z * fq, ski.w * fq};   // powers of two: exact
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * g + j;
+        const int key = k0 + 8 * g + 4 * hh + j;
+        float v = st[r] * f[j];
+        if (REL) {   // (index clamped into the table: keys past the sequence are masked below anyway)
+          int ri = key - (q0 + col) + rel_span - 1;
+          ri = ri < 0 ? 0 : (ri > 2 * rel_span - 2 ? 2 * rel_span - 2 : ri);
+          v += rel[(size_t)hd * (2 * rel_span - 1) + ri];
+        }
+        pr[r] = key < len ? v : -INFINITY;
+        tmax = fmaxf(tmax, pr[r]);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float psum = 0.f;
+    uint32_t pkh[8], pkl[8];
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = (pr[r] == -INFINITY) ? 0.f : expf(pr[r] - m_new);
+      const float p1 = (pr[r + 1] == -INFINITY) ? 0.f : expf(pr[r + 1] - m_new);
+      psum += p0;
+      psum += p1;
+      half_t h0, l0, h1, l1;
+      e32a_split(p0 * 2048.f, h0, l0);
+      e32a_split(p1 * 2048.f, h1, l1);
+      pkh[r >> 1] = __builtin_bit_cast(uint32_t, (half2_t){h0, h1});
+      pkl[r >> 1] = __builtin_bit_cast(uint32_t, (half2_t){l0, l1});
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+    // ---- O^T += V^T · P^T.  k-step ks contracts keys 16ks .. 16ks+15: half hh needs keys 16ks + 8hh .. + 7.  A lane holds
+    // key groups g = 0..3 (keys 8g + 4hh .. + 3) as the word pairs pk[2g], pk[2g+1]; one v_permlane32_swap per word with
+    // vdst = group 2ks, src = group 2ks + 1 leaves the two B fragments in place (decoder.hip) ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const auto h0 = __builtin_amdgcn_permlane32_swap(pkh[4 * ks], pkh[4 * ks + 2], false, false);
+      const auto h1 = __builtin_amdgcn_permlane32_swap(pkh[4 * ks + 1], pkh[4 * ks + 3], false, false);
+      const auto l0 = __builtin_amdgcn_permlane32_swap(pkl[4 * ks], pkl[4 * ks + 2], false, false);
+      const auto l1 = __builtin_amdgcn_permlane32_swap(pkl[4 * ks + 1], pkl[4 * ks + 3], false, false);
+      const half8 bhi = __builtin_bit_cast(half8, ((u32x4){h0[0], h1[0], h0[1], h1[1]}));
+      const half8 blo = __builtin_bit_cast(half8, ((u32x4){l0[0], l1[0], l0[1], l1[1]}));
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const half8 vfh = *(const half8*)(vh[buf] + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
+        const half8 vfl = *(const half8*)(vl[buf] + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
+        f32x16 t = {0};
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl, bhi, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, blo, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, bhi, t, 0, 0, 0);
+        const float svi = svinv[buf][2 * ks + mb];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mb][r] = __builtin_fmaf(t[r], svi, o[mb][r]);
+      }
+    }
+  }
+  // ---- store: lane (query, hh) holds d = 32mb + 8(r>>2) + 4hh + (r&3) ----
+  if (live && q0 + col < L) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* out = ctx + (tok0 + q0 + col) * H + hd * DH;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(out + 32 * mb + 8 * g + 4 * hh) =
+            make_float4(o[mb][4 * g] * inv, o[mb][4 * g + 1] * inv, o[mb][4 * g + 2] * inv, o[mb][4 * g + 3] * inv);
+  }
+}
+
 // pooling over fp32 hidden states: CLS row or the mean of the real tokens; optional canonical L2 normalisation
 __global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restrict__ hidden, const int32_t* __restrict__ lens,
                                                             int L, int H, int mean, int normalize, float* __restrict__ out) {
@@ -508,6 +790,9 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   const int max_parts_i = (int)(p_slabs * wide / (size_t)I);  // ... of an [M][I] product
   const int max_parts_qkv = (int)(p_slabs * wide / (size_t)(3 * H));   // ... of the [M][3H] q|k|v product
   int rc = RARC_OK;
+  // head_dim 64: attention on the fp16 MFMA over split operands (round 4); RARC_E32_ATTN=mfma32 keeps the fp32-MFMA kernel (A/B)
+  const char* attn_env = getenv("RARC_E32_ATTN");   // (read per call: tests switch it between forwards)
+  const bool split_attention = !(attn_env && !strcmp(attn_env, "mfma32"));
   for (int l = 0; l < model->n_layers; ++l) {
     const RarcEnc32Layer& Ly = model->layers[l];
     // fused q|k|v projection; its scales and bias are applied by the attention kernel's loads
@@ -518,7 +803,15 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     hipLaunchKernelGGL((rarc_e32_attention_kernel<DHV, RELV>), dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw, \
                        Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx, model->rel_bias, model->rel_span,     \
                        qkv_parts, (size_t)M * 3 * H)
-    if (H == model->heads * 64) {
+    if (H == model->heads * 64 && split_attention) {
+      const int q_groups = (q_blocks + 3) / 4;
+#define E32_SPLIT_LAUNCH(RELV)                                                                                               \
+      hipLaunchKernelGGL((rarc_e32_attention_split_kernel<RELV>), dim3(n_seq * model->heads * q_groups), dim3(256), 0, hs, P, ra_a, \
+                         Ly.qkv_rw, Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, q_groups, ctx, model->rel_bias,          \
+                         model->rel_span, qkv_parts, (size_t)M * 3 * H)
+      if (model->rel_bias) E32_SPLIT_LAUNCH(true); else E32_SPLIT_LAUNCH(false);
+#undef E32_SPLIT_LAUNCH
+    } else if (H == model->heads * 64) {
       if (model->rel_bias) E32_ATTN_LAUNCH(64, true); else E32_ATTN_LAUNCH(64, false);
     } else {
       if (model->rel_bias) E32_ATTN_LAUNCH(32, true); else E32_ATTN_LAUNCH(32, false);

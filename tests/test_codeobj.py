@@ -87,7 +87,7 @@ MFMA_WAIT_STATES = 19    # XDL write of a 16-pass MFMA -> VALU read (the worst c
 VALU_WAIT_STATES = 2     # VALU write -> v_permlane*_swap read
 
 
-@pytest.mark.parametrize("family", ["rarc_scan_q8_kernel", "rarc_gemm", "rarc_lm_attention"])
+@pytest.mark.parametrize("family", ["rarc_scan_q8_kernel", "rarc_gemm", "rarc_lm_attention", "rarc_e32_attention_split"])
 def test_inline_asm_permlane_swaps_keep_their_hazard_distance(family):
     kernels = codeobj.disassemble(family)
     assert kernels, family

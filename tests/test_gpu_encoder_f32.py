@@ -173,3 +173,45 @@ def test_fp16_weights_give_identical_fp32_forward_with_zero_low_halves(oracle):
     d16 = np.linalg.norm(e16 - w64, axis=1).max()
     print(f"fp16-exact weights: ||fp32 mode - f64|| {d32:.2e}   ||fp16 mode - f64|| {d16:.2e}")
     assert d32 <= 2e-5 and d16 >= 20 * d32
+
+
+def test_split_attention_against_the_fp32_mfma_kernel(oracle, monkeypatch):
+    """Round 4: at head_dim 64 attention runs on the fp16 MFMA over (hi, lo) split operands.  Same forward through that kernel
+    and through the exact-product fp32-MFMA kernel it replaces (RARC_E32_ATTN=mfma32), on weights that stress the split: sharp
+    softmaxes (q / k weights x 5), value rows spread over six decades (per-block scales), ragged lengths, five key tiles and
+    five query blocks (a workgroup with three idle waves).  Both must sit in the fp32 class against float64, and next to each other."""
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+
+    H, layers, heads, I, L = 256, 2, 4, 1024, 160
+    sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=400, max_pos=L, seed=77)
+    rng = np.random.default_rng(77)
+    for i in range(layers):
+        p = f"encoder.layer.{i}.attention.self."
+        sd[p + "query.weight"] = sd[p + "query.weight"] * 5.0
+        sd[p + "key.weight"] = sd[p + "key.weight"] * 5.0
+        f = np.exp2(np.round(rng.uniform(-10, 10, H))).astype(np.float32)      # value column d scaled by f[d] (six decades) ...
+        sd[p + "value.weight"] = sd[p + "value.weight"] * f[:, None]
+        sd[p + "value.bias"] = sd[p + "value.bias"] * f
+        po = f"encoder.layer.{i}.attention.output.dense.weight"
+        sd[po] = sd[po] / f[None, :]                                           # ... and undone by the output projection
+    ids, lens = _tokens(rng, 7, L, 400)
+    lens[:] = [160, 1, 33, 97, 128, 159, 64]
+    for r, l in enumerate(lens):
+        ids[r, l:] = 0
+    enc = HipBertEncoder(sd, num_heads=heads, precision="fp32")
+    split = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    monkeypatch.setenv("RARC_E32_ATTN", "mfma32")
+    exact = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    monkeypatch.delenv("RARC_E32_ATTN")
+    again = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    w64 = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=True, dtype=np.float64)
+    w32 = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=True)
+    d_split = np.linalg.norm(split - w64, axis=1).max()
+    d_exact = np.linalg.norm(exact - w64, axis=1).max()
+    d_np = np.linalg.norm(w32 - w64, axis=1).max()
+    print(f"ENC32-ATTN split vs f64 {d_split:.2e}   fp32-MFMA vs f64 {d_exact:.2e}   numpy32 vs f64 {d_np:.2e}   "
+          f"max|split - fp32-MFMA| {np.abs(split - exact).max():.2e}")
+    assert np.array_equal(split, again)                       # the switch is read per call; the kernel is deterministic
+    assert not np.array_equal(split, exact)                   # ... and the two kernels really are different code
+    assert d_split <= 1e-5 and d_split <= 2.0 * max(d_np, d_exact) + 3e-7
+    assert np.abs(split - exact).max() <= 2e-6

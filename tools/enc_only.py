@@ -3,7 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
-H, HEADS, FFN, LAYERS, L, VOCAB, NQ = 1024, 16, 4096, 24, 32, 30522, int(os.environ.get("PROBE_SEQS", 256))
+H, HEADS, FFN, LAYERS, VOCAB = 1024, 16, 4096, 24, 30522
+L, NQ = int(os.environ.get("PROBE_TOKENS", 32)), int(os.environ.get("PROBE_SEQS", 256))
 dev = torch.device("cuda", 0); g = torch.Generator(device=dev); g.manual_seed(5)
 rnd = lambda *s: torch.randn(s, generator=g, device=dev) * 0.05
 sd = {"embeddings.word_embeddings.weight": rnd(VOCAB, H), "embeddings.position_embeddings.weight": rnd(512, H),
