@@ -397,6 +397,10 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
 // packed into 4-byte writes.  Raw rows of tile t+1 travel in registers while tile t is multiplied; the images are double
 // buffered: one barrier per tile.  P^T fragments are assembled with v_permlane32_swap as in decoder.hip.
 // Keys >= lens[seq] are masked and never read (clamped to the last real token): a result does not depend on the padding.
+// Two waves per SIMD (launch bounds): the kernel is bound by VALU issue (softmax, splitting), not by the MFMAs.
+// (Tried and dropped: skipping the accumulator rescale when no query's maximum rose + a mask-free instantiation for
+//  interior tiles — together 2 % at best, and that build returned wrong rows at random on the GPU while either one alone
+//  was exact; the cause was not found in the ISA, so neither is kept.)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void e32a_scale_of(float mx, float& s, float& inv) {   // like e32_scale_of, exponent within +-60:
   s = 1.f; inv = 1.f;                                                              // products of two inverses stay finite
@@ -415,7 +419,7 @@ __device__ __forceinline__ void e32a_split(float x, half_t& hi, half_t& lo) {
 }
 
 template <bool REL>
-__global__ __launch_bounds__(256) void rarc_e32_attention_split_kernel(const float* __restrict__ P, const float* __restrict__ ra,
+__global__ __launch_bounds__(256, 2) void rarc_e32_attention_split_kernel(const float* __restrict__ P, const float* __restrict__ ra,
                                                                        const float* __restrict__ rw, const float* __restrict__ bias,
                                                                        const int32_t* __restrict__ lens, int L, int H, int n_heads,
                                                                        int q_blocks, int q_groups, float* __restrict__ ctx,
