@@ -13,7 +13,8 @@
 // lo is a normal fp16 number for every element within 2^-17 of the row maximum, and an element below that is
 // represented to 2^-39 of the maximum even if subnormal halves were flushed.
 // Everything between the GEMMs is fp32: residual stream, LayerNorm (two-pass statistics), exact erf GELU (libm erff),
-// softmax (libm expf), pooling and the canonical L2 normalisation.  Attention (QKᵀ, PV) runs on the fp32 MFMA (exact fp32).
+// softmax (libm expf), pooling and the canonical L2 normalisation.  Attention (QKᵀ, PV): head_dim 64 on the fp16 MFMA over split
+// operands like the GEMMs (rarc_e32_attention_split_kernel, round 4), head_dim 32 on the fp32 MFMA (exact fp32 products).
 #include "rarc_common.h"
 #include <cstring>
 #include <cstdlib>
