@@ -16,6 +16,8 @@
 //   rarc_enc_add_ln     LayerNorm(x + residual)                                   (HBM-bound)
 //   rarc_enc_pool       CLS row -> fp32 [, L2 normalise with the canonical sum order of prep.hip]
 #include "rarc_common.h"
+#include <cstring>
+#include <cstdlib>
 
 // exact-form GELU 0.5·v·(1 + erf(v/√2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
 // fp16 rounding of the result): 1 - erf(x) = (a1 t + ... + a5 t^5)·exp(-x²), t = 1/(1 + p·x), x >= 0.
@@ -1650,6 +1652,161 @@ __global__ __launch_bounds__(256) void rarc_attention_mfma_kernel(const half_t* 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 4 — the same attention with the key / value tiles SHARED by a workgroup (sequences longer than one query block).
+// Above, every wave fetches the K rows of its head straight from the q|k|v matrix (16-byte pieces of rows 3H halves apart) and
+// transposes its own copy of the V tile with 2-byte LDS writes: at 512 tokens sixteen waves do that work for one (sequence,
+// head).  Here one WORKGROUP (4 waves) takes four consecutive 32-query blocks of one (sequence, head); each 32-key tile is
+// fetched once per workgroup — K by all four waves into a row-major image (16-byte row pad: conflict-free ds_read_b128
+// fragments), V by waves 2 and 3 into the transposed image with key PAIRS packed into 4-byte writes — the raw rows of tile t+1
+// travel in registers while tile t is multiplied, the images are double buffered (one barrier per tile), and the P^T
+// fragments are assembled with v_permlane32_swap (decoder.hip).  Same MFMAs on the same operands in the same order, same
+// softmax arithmetic: the output is bit-identical to rarc_attention_mfma_kernel's (tests/test_gpu_encoder.py).
+// ------------------------------------------------------------------------------------------
+template <int DH, bool REL>
+__global__ __launch_bounds__(256) void rarc_attention_mfma_shared_kernel(const half_t* __restrict__ qkv,
+                                                                         const int32_t* __restrict__ lens, int L, int H,
+                                                                         int n_heads, int q_blocks, int q_groups,
+                                                                         half_t* __restrict__ ctx, const float* __restrict__ rel,
+                                                                         int rel_span) {
+  constexpr int KS = DH / 16;   // k-steps of the QK^T product
+  constexpr int MB = DH / 32;   // 32-row blocks of O^T
+  constexpr int CH = DH / 8;    // 16-byte chunks per row
+  constexpr int KROW = DH + 8;  // halves per K row (+16 bytes)
+  constexpr int VROW = 40;      // halves per row of the transposed V image (32 keys + 8 padding)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) half_t kimg[2][32 * KROW];
+  __shared__ __attribute__((aligned(16))) half_t vt[2][DH * VROW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qg = blockIdx.x % q_groups, bh = blockIdx.x / q_groups;
+  const int b = bh / n_heads, hd = bh % n_heads;
+  const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);  // never an empty softmax, never past the sequence
+  const int col = lane & 31, hh = lane >> 5;
+  const size_t rs = (size_t)3 * H;  // row stride of qkv in halves
+  const half_t* base = qkv + (size_t)b * L * rs + hd * DH;
+  const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;  // 1/sqrt(DH)
+  const int qb = 4 * qg + wave;
+  const bool live = qb < q_blocks;
+  const int q0 = qb * 32;
+
+  // staging roles: K item (row tid / CH, chunk tid % CH) for tid < 32 CH; V item (key pair p, chunk c8) for the
+  // 16 CH threads from 128 on (waves 2 and 3 at head_dim 64)
+  const bool k_role = tid < 32 * CH;
+  const int kr = tid / CH, kc = tid % CH;
+  const int vi = tid - 128;
+  const bool v_role = vi >= 0 && vi < 16 * CH;
+  const int vp = vi & 15, vc8 = vi >> 4;
+  half8 kraw, vraw0, vraw1;
+  auto prefetch = [&](int k0) {
+    if (k_role) {
+      const int krow = (k0 + kr < L) ? k0 + kr : L - 1;
+      kraw = *(const half8*)(base + H + (size_t)krow * rs + 8 * kc);
+    }
+    if (v_role) {
+      const int r0 = (k0 + 2 * vp < L) ? k0 + 2 * vp : L - 1, r1 = (k0 + 2 * vp + 1 < L) ? k0 + 2 * vp + 1 : L - 1;
+      vraw0 = *(const half8*)(base + 2 * H + (size_t)r0 * rs + 8 * vc8);
+      vraw1 = *(const half8*)(base + 2 * H + (size_t)r1 * rs + 8 * vc8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    if (k_role) *(half8*)(kimg[buf] + kr * KROW + 8 * kc) = kraw;
+    if (v_role) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) *(half2_t*)(vt[buf] + (8 * vc8 + e) * VROW + 2 * vp) = (half2_t){vraw0[e], vraw1[e]};
+    }
+  };
+
+  prefetch(0);
+  half8 qf[KS];  // B operand of S^T: this lane's query row, k = 16*ks + 8*hh ..
+  if (live) {
+    const int qrow = (q0 + col < L) ? q0 + col : L - 1;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(base + (size_t)qrow * rs + 16 * ks + 8 * hh);
+  }
+  f32x16 o[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) o[mb] = (f32x16){0};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int buf = 0;
+  for (int k0 = 0; k0 < len; k0 += 32, buf ^= 1) {
+    // image `buf` was last read while tile k0 - 64 was multiplied; every wave has passed the barrier of tile k0 - 32 since
+    store_tile(buf);
+    __syncthreads();
+    if (k0 + 32 < len) prefetch(k0 + 32);   // in flight under this tile's MFMAs and softmax
+    if (!live) continue;                    // (a wave without a query block only stages)
+    const half_t* kim = kimg[buf];
+    const half_t* vim = vt[buf];
+    f32x16 st = {0};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8 kf = *(const half8*)(kim + col * KROW + 16 * ks + 8 * hh);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
+    }
+    // ---- softmax statistics of this lane's query over its 16 keys, then with the partner lane ----
+    float sc[16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + 8 * (r >> 2) + 4 * hh + (r & 3);
+      float v = st[r] * scale;
+      if (REL) {   // (index clamped into the table: keys past the sequence are masked below anyway)
+        int ri = key - (q0 + col) + rel_span - 1;
+        ri = ri < 0 ? 0 : (ri > 2 * rel_span - 2 ? 2 * rel_span - 2 : ri);
+        v += rel[(size_t)hd * (2 * rel_span - 1) + ri];
+      }
+      sc[r] = key < len ? v : -INFINITY;
+      tmax = fmaxf(tmax, sc[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float corr = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_new);
+    float psum = 0.f;
+    uint32_t pk[8];  // fp16 pairs: pk[2g], pk[2g+1] = keys 8g + 4hh + {0,1}, {2,3}
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = (sc[r] == -INFINITY) ? 0.f : __expf(sc[r] - m_new);
+      const float p1 = (sc[r + 1] == -INFINITY) ? 0.f : __expf(sc[r + 1] - m_new);
+      psum += p0 + p1;
+      const half2_t h2 = {(half_t)p0, (half_t)p1};
+      pk[r >> 1] = __builtin_bit_cast(uint32_t, h2);
+    }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * corr + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[mb][r] *= corr;
+    // ---- O^T += V^T · P^T over the tile's 32 keys (two k-steps of 16): B fragments by v_permlane32_swap ----
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const auto w0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks], pk[4 * ks + 2], false, false);
+      const auto w1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
+      const half8 pf = __builtin_bit_cast(half8, ((u32x4){w0[0], w1[0], w0[1], w1[1]}));
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const half8 vf = *(const half8*)(vim + (32 * mb + col) * VROW + 16 * ks + 8 * hh);
+        o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[mb], 0, 0, 0);
+      }
+    }
+  }
+  // ---- store: lane (query, hh) holds d = 32mb + 8(r>>2) + 4hh + (r&3) ----
+  if (live && q0 + col < L) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    half_t* out = ctx + ((size_t)b * L + q0 + col) * H + hd * DH;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        const half4 w = {(half_t)(o[mb][4 * g] * inv), (half_t)(o[mb][4 * g + 1] * inv),
+                         (half_t)(o[mb][4 * g + 2] * inv), (half_t)(o[mb][4 * g + 3] * inv)};
+        *(half4*)(out + 32 * mb + 8 * g + 4 * hh) = w;
+      }
+  }
+}
+
 // CLS pooling (+ optional L2 normalisation with the canonical order of prep.hip)
 __global__ __launch_bounds__(64) void rarc_pool_kernel(const half_t* hidden, int L, int H, int normalize, float* out) {
   const int lane = threadIdx.x, j = lane & 7;
@@ -1998,11 +2155,26 @@ static int enc_attention_impl(const uint16_t* d_qkv, const int32_t* d_lens, int 
 #define ENC_ATTN_LAUNCH(DHV, RELV)                                                                                  \
   hipLaunchKernelGGL((rarc_attention_mfma_kernel<DHV, RELV>), dim3((n_units + 3) / 4), dim3(256), 0, (hipStream_t)stream, \
                      (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, n_units, (half_t*)d_ctx, d_rel, rel_span)
-  if (hidden == n_heads * 64) {
+  // more than one query block per sequence: the workgroup-shared form (round 4); RARC_ENC_ATTN=wave keeps the per-wave kernel (A/B)
+  const char* attn_env = getenv("RARC_ENC_ATTN");
+  const bool shared = q_blocks >= 2 && !(attn_env && !strcmp(attn_env, "wave"));
+  const int q_groups = (q_blocks + 3) / 4;
+#define ENC_ATTN_SHARED(DHV, RELV)                                                                                           \
+  hipLaunchKernelGGL((rarc_attention_mfma_shared_kernel<DHV, RELV>), dim3(n_seq * n_heads * q_groups), dim3(256), 0,         \
+                     (hipStream_t)stream, (const half_t*)d_qkv, d_lens, seq_len, hidden, n_heads, q_blocks, q_groups,        \
+                     (half_t*)d_ctx, d_rel, rel_span)
+  if (shared) {
+    if (hidden == n_heads * 64) {
+      if (d_rel) ENC_ATTN_SHARED(64, true); else ENC_ATTN_SHARED(64, false);
+    } else {
+      if (d_rel) ENC_ATTN_SHARED(32, true); else ENC_ATTN_SHARED(32, false);
+    }
+  } else if (hidden == n_heads * 64) {
     if (d_rel) ENC_ATTN_LAUNCH(64, true); else ENC_ATTN_LAUNCH(64, false);
   } else {
     if (d_rel) ENC_ATTN_LAUNCH(32, true); else ENC_ATTN_LAUNCH(32, false);
   }
+#undef ENC_ATTN_SHARED
 #undef ENC_ATTN_LAUNCH
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;

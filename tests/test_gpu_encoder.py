@@ -265,3 +265,58 @@ def test_store_ingests_device_embeddings_without_round_trip(oracle):
         a, b = fast.similarity_search_with_score(q, k=10), slow.similarity_search_with_score(q, k=10)
         assert [(d.id, s) for d, s in a] == [(d.id, s) for d, s in b]
     assert fast.similarity_search("chunk 42 about topic 8", k=1)[0].content == "chunk 42 about topic 8"
+
+
+@pytest.mark.parametrize("heads,dh,n_seq,L", [(3, 64, 5, 64), (2, 64, 4, 100), (4, 32, 6, 200), (2, 64, 3, 512), (5, 32, 2, 33)])
+def test_shared_attention_kernel_is_bit_identical_to_the_per_wave_kernel(monkeypatch, heads, dh, n_seq, L):
+    """Round 4: sequences of more than one query block take rarc_attention_mfma_shared_kernel (key / value tiles staged once per
+    workgroup).  Same MFMAs, same operands, same order: its output must equal the per-wave kernel's (RARC_ENC_ATTN=wave) to the
+    bit — ragged lengths, lengths of 1 and L, workgroups with idle waves (L = 33, 100), head_dim 32 and 64."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+
+    lib = B.load_library()
+    H = heads * dh
+    g = torch.Generator(device="cuda"); g.manual_seed(L + heads)
+    qkv = (torch.randn((n_seq * L, 3 * H), generator=g, device="cuda") * 1.5).half()
+    lens = torch.randint(1, L + 1, (n_seq,), generator=g, device="cuda").int()
+    lens[0] = L
+    lens[-1] = 1
+    outs = []
+    for mode in ("shared", "wave"):
+        monkeypatch.setenv("RARC_ENC_ATTN", mode)
+        ctx = torch.full((n_seq * L, H), float("nan"), dtype=torch.float16, device="cuda")
+        B.check(lib.rarc_enc_attention(qkv.data_ptr(), lens.data_ptr(), n_seq, L, H, heads, ctx.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "attention")
+        torch.cuda.synchronize()
+        outs.append(ctx.view(torch.int16).cpu().numpy().reshape(n_seq, L, H))
+    for b in range(n_seq):      # (rows past a sequence's length are padding queries: both kernels compute them, compare all)
+        assert np.array_equal(outs[0][b], outs[1][b]), f"sequence {b} (len {int(lens[b])}) differs"
+    # and against a plain fp32 softmax(QK^T / sqrt(d)) V of the same fp16 inputs, real rows only
+    q, k, v = (qkv.float().view(n_seq, L, 3, heads, dh)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = q @ k.transpose(-1, -2) / dh ** 0.5
+    mask = torch.arange(L, device="cuda")[None, None, None, :] >= lens[:, None, None, None]
+    ref = (torch.softmax(s.masked_fill(mask, float("-inf")), -1) @ v).permute(0, 2, 1, 3).reshape(n_seq, L, H)
+    got = torch.from_numpy(outs[0]).view(torch.float16).float().cuda()
+    for b in range(n_seq):
+        n = int(lens[b])
+        assert float((got[b, :n] - ref[b, :n]).abs().max()) <= 4e-3
+
+
+def test_mpnet_forward_same_bits_through_both_attention_kernels(oracle, monkeypatch):
+    """... and with MPNet's relative-position bias (only reachable through the forward)."""
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+
+    sd = oracle.random_mpnet_state_dict(128, 2, 2, 256, vocab=300, max_pos=514, seed=5)
+    enc = HipBertEncoder(sd, num_heads=2, layer_norm_eps=1e-5, precision="fp16", pooling="mean")
+    assert enc.model_type == "mpnet"
+    rng = np.random.default_rng(5)
+    ids = rng.integers(5, 300, (6, 150)).astype(np.int32)
+    lens = np.array([150, 1, 33, 64, 97, 128], np.int32)
+    for r, l in enumerate(lens):
+        ids[r, l:] = 1
+    a = enc.forward(ids, lens).cpu().numpy()
+    monkeypatch.setenv("RARC_ENC_ATTN", "wave")
+    b = enc.forward(ids, lens).cpu().numpy()
+    assert np.array_equal(a, b)

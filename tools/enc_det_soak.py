@@ -1,0 +1,31 @@
+"""Soak of the fp32-class encoder forward (split-operand GEMMs + split-operand attention): one ragged batch through a 4-layer
+bge-base-geometry model SOAK_REPS times while a side stream keeps HBM busy; every embedding compared bit for bit with the first."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from oracle import cpu_ref
+from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+reps = int(os.environ.get("SOAK_REPS", "300"))
+H, heads, I, L, layers = 768, 12, 3072, 192, 4
+sd = cpu_ref.random_bert_state_dict(H, layers, heads, I, vocab=2000, max_pos=L, seed=13)
+rng = np.random.default_rng(13)
+lens = rng.integers(1, L + 1, 48).astype(np.int32); lens[0] = L; lens[1] = 1; lens[2] = 32; lens[3] = 33
+ids = rng.integers(1, 2000, (48, L)).astype(np.int32)
+for r, l in enumerate(lens):
+    ids[r, l:] = 0
+enc = HipBertEncoder(sd, num_heads=heads, pooling="mean", precision="fp32")
+tok = torch.from_numpy(ids).cuda(); ln = torch.from_numpy(lens).cuda()
+first = enc.forward_device(tok, ln).clone()
+w64 = cpu_ref.bert_forward_f32(sd, ids, lens, heads, normalize=True, pooling="mean", dtype=np.float64)
+print("max ||e - e64||:", float(np.linalg.norm(first.cpu().numpy() - w64, axis=1).max()))
+side = torch.cuda.Stream(); junk = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+bad = 0
+for it in range(reps):
+    with torch.cuda.stream(side):
+        junk.mul_(1.0001)
+    e = enc.forward_device(tok, ln)
+    if not torch.equal(e.view(torch.int32), first.view(torch.int32)):
+        bad += 1
+        print("MISMATCH at", it, float((e - first).abs().max()))
+torch.cuda.synchronize()
+print(f"encoder soak: {reps} forwards,", "all identical" if not bad else f"{bad} MISMATCHES")
