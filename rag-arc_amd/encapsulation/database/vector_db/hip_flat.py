@@ -430,7 +430,9 @@ class HipFlatVectorStore(VectorStore):
         if rank == 0:
             meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
                     "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2,
-                    "storage": self.storage, "world": world, "ntotal": self.ntotal}
+                    "storage": self.storage, "world": world, "ntotal": self.ntotal,
+                    # what the searches so far have taught the index about this corpus (engine: sticky candidate capacity)
+                    "cand_cap": int(getattr(self._local_engine(), "cand_cap", 0) or 0) if self.index is not None else 0}
             tmp = os.path.join(folder_path, f"{index_name}.pkl.tmp")
             with open(tmp, "wb") as fh:
                 pickle.dump(meta, fh)
@@ -484,7 +486,16 @@ class HipFlatVectorStore(VectorStore):
                     run.append(seg)
         store._adopt_loaded(blocks, total)
         store.last_load_stats = stats
+        if int(meta.get("cand_cap", 0) or 0) > int(getattr(eng, "cand_cap", 0) or 0):
+            eng.cand_cap = int(meta["cand_cap"])    # (a capacity the saved index had grown to: not learnt a second time)
         return store
+
+    def warm_up(self, k: int = 100) -> int:
+        """Search a sample of the stored rows as queries until the engine's candidate capacity has settled
+        (FlatIndexF16.warm_up): on clustered corpora the first user batch then costs what every later one does.
+        Optional; every rank of a sharded store calls it (no collective inside).  Returns the capacity doublings."""
+        eng = self._local_engine() if self.index is not None else None
+        return int(eng.warm_up(k)) if eng is not None and hasattr(eng, "warm_up") else 0
 
     def _adopt_loaded(self, blocks, total: int) -> None:
         """After load_local filled the local engine: a single-GPU store's rows ARE the global ids."""

@@ -214,3 +214,56 @@ def test_clustered_corpus_whole_cluster_inside_the_int8_margin(oracle):
     D, I = idx.search(Q, 1000)                     # k = 1000: the banded rescore with thousands of rows per band
     rI2, rD2, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), 1000)
     assert np.array_equal(I, rI2) and np.array_equal(D.view(np.uint32), rD2.view(np.uint32))
+
+
+def test_warm_up_pays_the_first_batch_cost_and_a_saved_index_keeps_what_it_learnt(oracle, tmp_path):
+    """Clustered rows and a capacity too small for them: warm_up() (stored rows searched as queries) grows the candidate
+    capacity before any user query; the first user batch is then exact on its first attempt.  The capacity an index has grown
+    to travels with save_local / load_local."""
+    import torch
+
+    from rag_arc_amd.encapsulation.database.vector_db import HipFlatVectorStore
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(77)
+    n, d, nc, nq, k = 300_000, 128, 12, 32, 50
+    centers = rng.standard_normal((nc, d)).astype(np.float32)
+    centers /= np.linalg.norm(centers, axis=1, keepdims=True)
+
+    def make(m):
+        return (centers[rng.integers(0, nc, m)] + 0.25 / np.sqrt(d) * rng.standard_normal((m, d))).astype(np.float32)
+
+    X, Q = make(n), make(nq)
+
+    class _Emb:          # texts are row numbers
+        def embed_documents(self, texts):
+            return [X[int(t)].tolist() for t in texts]
+
+        def embed_query(self, text):
+            return Q[int(text)].tolist()
+
+    small = lambda dim, metric, dev: FlatIndexF16(dim, metric=metric, device=dev, scan="q8", cand_cap=4096)   # noqa: E731
+    store = HipFlatVectorStore(_Emb(), engine_factory=small)
+    store.index = store._make_engine(d)
+    store.index.add(X)
+    cold = FlatIndexF16(d, scan="q8", cand_cap=4096)
+    cold.add(X)
+    cold.search_device(torch.from_numpy(Q).cuda(), k, repair=False)
+    assert (cold.last_status.cpu().numpy() & 0x100).any(), "the test is meant to overflow a cold index"
+    grown = store.warm_up(k)
+    eng = store.index
+    assert grown >= 1 and eng.cand_cap > 4096
+    ids, sc = eng.search_device(torch.from_numpy(Q).cuda(), k, repair=False)          # first USER batch, first attempt only
+    assert not (eng.last_status.cpu().numpy() & 0x100).any()
+    rows, _ = oracle.ingest_f16(X)
+    rI, rD, _ = oracle.flat_search_f16(rows, oracle.normalize_L2(Q), k)
+    D, I = eng.search(Q, k)
+    assert np.array_equal(I, rI) and np.array_equal(D.view(np.uint32), rD.view(np.uint32))
+    assert store.warm_up(k) == 0                                                        # settled
+    # the learnt capacity is part of what save_local writes
+    store.docstore, store.index_to_docstore_id = {}, {}
+    store.save_local(str(tmp_path), "idx")
+    back = HipFlatVectorStore.load_local(str(tmp_path), _Emb(), "idx", engine_factory=small)
+    assert back.index.cand_cap == eng.cand_cap > 4096
+    D2, I2 = back.index.search(Q, k)
+    assert np.array_equal(I2, rI) and np.array_equal(D2.view(np.uint32), rD.view(np.uint32))
