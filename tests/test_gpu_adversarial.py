@@ -267,3 +267,23 @@ def test_warm_up_pays_the_first_batch_cost_and_a_saved_index_keeps_what_it_learn
     assert back.index.cand_cap == eng.cand_cap > 4096
     D2, I2 = back.index.search(Q, k)
     assert np.array_equal(I2, rI) and np.array_equal(D2.view(np.uint32), rD.view(np.uint32))
+
+
+@pytest.mark.parametrize("storage", ["f16", "f8", "f32"])
+def test_warm_up_is_a_no_op_on_a_corpus_the_default_capacity_fits(storage):
+    """Isotropic rows: warm_up() searches a sample of the stored rows (decoded from whatever the storage is), finds nothing
+    to learn, and every sampled row finds itself first."""
+    import torch
+
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((50_000, 256)).astype(np.float32)
+    idx = FlatIndexF16(256, storage=storage)
+    idx.add(X)
+    cap = idx.cand_cap
+    assert idx.warm_up(k=10, n_queries=16) == 0 and idx.cand_cap == cap
+    pick = torch.linspace(0, idx.ntotal - 1, 16, device="cuda").long().cpu().numpy()
+    D, I = idx.search(X[pick], 1)
+    assert np.array_equal(I[:, 0], pick)
+    assert FlatIndexF16(256, storage=storage).warm_up() == 0          # empty index
