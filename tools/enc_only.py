@@ -23,7 +23,7 @@ import time
 for _ in range(2):
     enc.forward_device(tok, lens)
 torch.cuda.synchronize(); t0 = time.time()
-for _ in range(4):
+for _ in range(int(os.environ.get("PROBE_ITERS", 4))):
     enc.forward_device(tok, lens)
 torch.cuda.synchronize()
-print(f"ENC seqs={NQ} tokens={L} precision={enc.precision}: {(time.time() - t0) / 4 * 1e3:.3f} ms per forward (wall, 4 back to back)")
+print(f"ENC seqs={NQ} tokens={L} precision={enc.precision}: {(time.time() - t0) / int(os.environ.get('PROBE_ITERS', 4)) * 1e3:.3f} ms per forward (wall, {os.environ.get('PROBE_ITERS', 4)} back to back)")
