@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 400 /* 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
+#define RARC_VERSION 401 /* 0.4.1: RarcEnc32Layer.f1_colmax (FFN1 with its GELU fused into the GEMM epilogue); 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
                             * rarc_enc_gemm_zero_bias; 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
                             * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
@@ -431,6 +431,10 @@ typedef struct RarcEnc32Layer {
   const uint16_t* o_w3;   const float *o_rw, *o_b, *ln1_g, *ln1_b;
   const uint16_t* f1_w3;  const float *f1_rw, *f1_b;
   const uint16_t* f2_w3;  const float *f2_rw, *f2_b, *ln2_g, *ln2_b;
+  const float* f1_colmax;   /* ABI 401.  float [hidden + 1]: c[k] = max_j |W1[j][k]| of the fp32 FFN1 weight, c[hidden] = max_j |b1[j]|;
+                               NULL = none.  With it, batches that fill the chip run FFN1 with bias + GELU + the split of its output
+                               fused into the GEMM (the row's power-of-two scale comes from the bound sum_k |x_k| c[k] + c[hidden]
+                               >= max_j |gelu(x·W1_j + b1_j)|, known before the GEMM); without it FFN1 is a product + a row pass. */
 } RarcEnc32Layer;
 typedef struct RarcEnc32Model {
   int hidden, heads, inter, n_layers;

@@ -286,12 +286,27 @@ __device__ __forceinline__ void gemm_store8_ss(half_t* p, const uint4 v, const h
 // ------------------------------------------------------------------------------------------
 constexpr int G256_EP_STRIDE = 144, G256_EP_BYTES = 128 * G256_EP_STRIDE;  // epilogue staging, per wave
 constexpr int G256_LDS = 8 * G256_EP_BYTES > 131072 ? 8 * G256_EP_BYTES : 131072;
+// ACT 5 (round 4) — the fp32-class encoder's FFN1 with its activation fused (encoder_f32.hip): A and W are split images
+// ([lo|hi|hi] x [hi|lo|hi], K' = 3K), the fp32 accumulator becomes v = acc·ra[row]·rw[col] + bias[col] (the exact expression of
+// rarc_e32_epi_kernel), g = 0.5 v (1 + erff(v/sqrt 2)) with the library erff, and g·sg[row] is written straight back as the
+// split image [lo | hi | hi] of the NEXT GEMM's A operand (row stride 3N halves) — no fp32 product matrix, no second pass.
+// sg[row] is a power of two chosen BEFORE the GEMM from a bound on the row (|g| <= |v| <= ||x|| ||W_j|| + |b_j|), see
+// encoder_f32.hip; ra, rw are powers of two as well, so the only roundings are the bias add, the GELU and the two halves.
+struct GemmSplitEpi {
+  const float* ra = nullptr;     // [M] inverse scales of the A rows
+  const float* rw = nullptr;     // [N] inverse scales of the W rows
+  const float* bias = nullptr;   // [N] fp32
+  const float* sg = nullptr;     // [M] output scales
+};
+__device__ __forceinline__ float gemm_gelu_libm(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
 template <int ACT>
 __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* __restrict__ A,
                                                                   const half_t* __restrict__ W,
                                                                   const half_t* __restrict__ bias,
                                                                   half_t* __restrict__ C, int M, int N, int K,
-                                                                  int order, float* __restrict__ ssq = nullptr) {
+                                                                  int order, float* __restrict__ ssq = nullptr,
+                                                                  const GemmSplitEpi fx = GemmSplitEpi()) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -514,6 +529,57 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
       for (int t = 0; t < 16; ++t) {
         const int r = t * 8 + r8;
         *(float4*)(Cw + (size_t)r * N) = *(const float4*)(ep + r * G256_EP_STRIDE + c * 16);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  } else if constexpr (BASE == 5) {  // gelu(acc·ra·rw + bias)·sg -> (hi, lo) halves -> split image [lo | hi | hi], row stride 3N
+    float ra_r[8], sg_r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const size_t rg = (size_t)tm * 256 + wr * 128 + i * 16 + row_e;
+      ra_r[i] = fx.ra[rg];
+      sg_r[i] = fx.sg[rg];
+    }
+    // the wave's 128 x 64 block in two 32-column halves: a staging row = 64 bytes of hi | 64 bytes of lo
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * h + jj;
+        const int col0 = tn * 256 + wc * 64 + j * 16 + 4 * q_e;
+        const float4 w4 = *(const float4*)(fx.rw + col0), b4 = *(const float4*)(fx.bias + col0);
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          half4 hi4, lo4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = acc[i][j][e] * ra_r[i] * wv[e] + bv[e];
+            const float x = gemm_gelu_libm(v) * sg_r[i];
+            const half_t hi = (half_t)x;
+            hi4[e] = hi;
+            lo4[e] = (half_t)(x - (float)hi);
+          }
+          char* dst = ep + (i * 16 + row_e) * G256_EP_STRIDE + (jj * 16 + 4 * q_e) * 2;
+          *(half4*)dst = hi4;
+          *(half4*)(dst + 64) = lo4;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int r8 = lane_e >> 3, c = lane_e & 7;
+      const size_t ld3 = (size_t)3 * N;
+      half_t* Cw = C + (size_t)(tm * 256 + wr * 128) * ld3 + tn * 256 + wc * 64 + h * 32;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int r = t * 8 + r8;
+        const uint4 v = *(const uint4*)(ep + r * G256_EP_STRIDE + c * 16);
+        half_t* rowp = Cw + (size_t)r * ld3;
+        if (c < 4) {            // hi: stored twice
+          *(uint4*)(rowp + N + c * 8) = v;
+          *(uint4*)(rowp + 2 * (size_t)N + c * 8) = v;
+        } else {                // lo
+          *(uint4*)(rowp + (c - 4) * 8) = v;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1872,6 +1938,7 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
@@ -2113,6 +2180,30 @@ int rarc_gemm_f16_f32out_parts(const uint16_t* a, const uint16_t* w, float* c, i
   *parts = S;
   if (S == 1) return rarc_gemm_f16_f32out(a, w, c, m, n, k, s);
   return enc_gemm_splitk(a, w, c, m, n, k, S, s);
+}
+
+// FFN1 of the fp32-class encoder with the GELU and the split of its output fused into the GEMM's epilogue (ACT 5).  Only
+// shapes the 256 x 256 kernel takes WHOLE (no tail given to another kernel) and that fill the chip: returns 1 ("not taken",
+// nothing launched) otherwise and the caller runs the unfused pair (fp32 product + rarc_e32_epi_kernel<., 1>).
+bool rarc_gemm_f16_gelu_split_takes(int m, int n, int k3) {
+  const char* e = getenv("RARC_E32_FUSE_GELU");   // (read per call: tests switch it between forwards)
+  if ((e && atoi(e) == 0) || m % 256 || n % 256 || k3 < 4 * GK || k3 % GK) return false;
+  const int t256 = (m / 256) * (n / 256), t128 = (m / 256) * (n / GN);
+  return t256 >= 256 && gemm_prefers_256x256(t256, t128) && (t256 % 256 == 0 || t256 >= 1024);
+}
+int rarc_gemm_f16_gelu_split(const uint16_t* a3, const uint16_t* w3, const float* ra, const float* rw, const float* bias,
+                             const float* sg, uint16_t* out3, int m, int n, int k3, hipStream_t s) {
+  if (!rarc_gemm_f16_gelu_split_takes(m, n, k3)) return 1;
+  const int t256 = (m / 256) * (n / 256);
+  if (int rc = gemm_attrs()) return rc;
+  static const bool swz = !(getenv("RARC_GEMM_SWZ") && atoi(getenv("RARC_GEMM_SWZ")) == 0);
+  const int order = swz ? 2 : (m < n ? 1 : 0);
+  GemmSplitEpi fx;
+  fx.ra = ra; fx.rw = rw; fx.bias = bias; fx.sg = sg;
+  hipLaunchKernelGGL((rarc_gemm256_f16_kernel<5>), dim3(t256 > 256 ? 256 : t256), dim3(512), G256_LDS, s, (const half_t*)a3,
+                     (const half_t*)w3, (const half_t*)nullptr, (half_t*)out3, m, n, k3, order, (float*)nullptr, fx);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
 }
 
 extern "C" int rarc_enc_embed_ln(const int32_t* d_ids, const uint16_t* d_word, const uint16_t* d_pos,

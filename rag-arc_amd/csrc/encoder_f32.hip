@@ -22,6 +22,9 @@
 int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s);  // encoder.hip
 int rarc_gemm_f16_f32out_parts(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, int max_parts, int* parts,
                                hipStream_t s);   // encoder.hip: up to max_parts fp32 partial slabs c[part][m][n] (small batches)
+bool rarc_gemm_f16_gelu_split_takes(int m, int n, int k3);   // encoder.hip: would the fused FFN1 (below) take this shape?
+int rarc_gemm_f16_gelu_split(const uint16_t* a3, const uint16_t* w3, const float* ra, const float* rw, const float* bias,
+                             const float* sg, uint16_t* out3, int m, int n, int k3, hipStream_t s);   // 1 = not taken
 
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
@@ -140,13 +143,29 @@ __device__ __forceinline__ float e32_gelu(float v) { return 0.5f * v * (1.0f + e
 //   1  v = gelu(P·ra·rw + bias)                -> split image
 //   2  v = LayerNorm(P·ra·rw + bias + resid)   -> out32 (may alias resid) and split image
 //   3  v = P (plain fp32 rows, no scales)      -> split image
+// Round 4 — FFN1 with its GELU fused into the GEMM's epilogue (rarc_gemm256_f16_kernel<5>, encoder.hip).  The epilogue of a
+// 256 x 256 tile cannot know the maximum of a 4096-wide row, so the power-of-two scale of the GELU output's split image is
+// fixed BEFORE the GEMM from a bound on the row:
+//     |gelu(v_j)| <= |v_j| = |sum_k x_k W1[j][k] + b1[j]| <= sum_k |x_k| c[k] + c[K],   c[k] = max_j |W1[j][k]|, c[K] = max_j |b1[j]|
+// (RarcEnc32Layer.f1_colmax, computed from the fp32 weights when the model is loaded).  The bound only has to be SAFE (it puts
+// the row maximum below 2^14, fp16 ends at 2^16) and not absurdly loose: an element below 2^-17 of the bound keeps an absolute
+// error of 2^-39 of the bound (header of this file).  This one follows a hot input channel and a heavy weight row exactly and
+// overshoots by the random-sign slack of the sum, ~2^5..2^7 (measured: the fused forward is as close to float64 as the
+// unfused one, also on rows over eight decades with a hot channel — tests/test_gpu_encoder_f32.py); the first form tried,
+// ||x||_2 · max_j ||W1_j||_2, overshot 2^11 on such rows and cost a factor 2.4 in the embedding's error there.
+// The row pass in front of FFN1 (MODE 2, the LayerNorm) computes it: sg_out[m] = scale, sg_out[rows + m] = 1/scale.
+struct E32Fuse {
+  const float* colmax = nullptr; int k = 0; float* sg_out = nullptr; size_t sg_rows = 0;
+};
+
 template <int NV, int MODE>
 __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const float* __restrict__ ra,
                                                            const float* __restrict__ rw, const float* __restrict__ bias,
                                                            const float* resid, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, int n,
                                                            float* out32, half_t* __restrict__ out3,
-                                                           float* __restrict__ ra_out, int n_parts, size_t part_stride) {
+                                                           float* __restrict__ ra_out, int n_parts, size_t part_stride,
+                                                           const E32Fuse fz = E32Fuse()) {
   __shared__ float slot[12];
   const size_t m = blockIdx.x;
   E32Row<NV> r;
@@ -176,6 +195,25 @@ __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const
     }
   }
   if (MODE == 2) e32_layernorm<NV>(r, n, gamma, beta, eps, slot);
+  if (MODE == 2 && fz.colmax) {   // the scale FFN1's fused epilogue will split gelu(.) of this row with
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (threadIdx.x + 256 * i) * 4;
+      if (c < n) {
+        const float4 cm = *(const float4*)(fz.colmax + c);
+        q += (fabsf(r.v[i].x) * cm.x + fabsf(r.v[i].y) * cm.y) + (fabsf(r.v[i].z) * cm.z + fabsf(r.v[i].w) * cm.w);
+      }
+    }
+    const float l1 = e32_block_sum(q, slot);   // (slot[0..3]: every thread is past the LayerNorm's second barrier)
+    const float bound = l1 * 1.0001f + fz.colmax[fz.k];   // (1e-4: the rounding of the 1024-term sum, with room)
+    float sgs, sgi;
+    e32_scale_of(bound, sgs, sgi);
+    if (threadIdx.x == 0) {
+      fz.sg_out[m] = sgs;
+      fz.sg_out[fz.sg_rows + m] = sgi;
+    }
+  }
   if (MODE == 0 || MODE == 2) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -706,15 +744,15 @@ __global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restr
 template <int MODE>
 static int e32_epi(const float* P, const float* ra, const float* rw, const float* bias, const float* resid, const float* gamma,
                    const float* beta, float eps, int m, int n, float* out32, uint16_t* out3, float* ra_out, hipStream_t s,
-                   int n_parts = 1) {
+                   int n_parts = 1, const E32Fuse fz = E32Fuse()) {
   const size_t part_stride = (size_t)m * n;
   RARC_REQUIRE(n % 4 == 0 && n <= 4096, RARC_E_UNSUPPORTED, "fp32-class encoder: row length %d (need a multiple of 4, <= 4096)", n);
   if (n <= 1024)
     hipLaunchKernelGGL((rarc_e32_epi_kernel<1, MODE>), dim3(m), dim3(256), 0, s, P, ra, rw, bias, resid, gamma, beta, eps, n,
-                       out32, (half_t*)out3, ra_out, n_parts, part_stride);
+                       out32, (half_t*)out3, ra_out, n_parts, part_stride, fz);
   else
     hipLaunchKernelGGL((rarc_e32_epi_kernel<4, MODE>), dim3(m), dim3(256), 0, s, P, ra, rw, bias, resid, gamma, beta, eps, n,
-                       out32, (half_t*)out3, ra_out, n_parts, part_stride);
+                       out32, (half_t*)out3, ra_out, n_parts, part_stride, fz);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -750,7 +788,8 @@ extern "C" size_t rarc_enc32_workspace_bytes(int hidden, int inter, int n_tokens
          + e32_align(M * 3 * H * 2)    // split image of x / ctx
          + e32_align(M * 3 * I * 2)    // split image of the GELU output
          + e32_align(M * wide * 4 * (M <= 2048 ? 4 : 1))   // raw GEMM products (small batches: up to four split-K partial slabs)
-         + 2 * e32_align(M * 4);       // row scales
+         + 2 * e32_align(M * 4)        // row scales
+         + e32_align(2 * M * 4);       // fused FFN1: output scales and their inverses
 }
 
 extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
@@ -783,7 +822,8 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   const int p_slabs = M <= 2048 ? 4 : 1;                    // [M][wide] slabs the product buffer holds
   float* P = (float*)w;                 w += e32_align((size_t)M * wide * 4 * p_slabs);
   float* ra_a = (float*)w;              w += e32_align((size_t)M * 4);
-  float* ra_b = (float*)w;
+  float* ra_b = (float*)w;              w += e32_align((size_t)M * 4);
+  float* sg = (float*)w;                                                       // fused FFN1: [M] scales | [M] inverses
   const float eps = model->ln_eps;
 
   hipLaunchKernelGGL(rarc_e32_embed_kernel, dim3(M), dim3(256), 0, hs, d_ids, model->word, model->pos, model->type0,
@@ -798,6 +838,7 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   // head_dim 64: attention on the fp16 MFMA over split operands (round 4); RARC_E32_ATTN=mfma32 keeps the fp32-MFMA kernel (A/B)
   const char* attn_env = getenv("RARC_E32_ATTN");   // (read per call: tests switch it between forwards)
   const bool split_attention = !(attn_env && !strcmp(attn_env, "mfma32"));
+  const bool fuse_shape = rarc_gemm_f16_gelu_split_takes(M, I, 3 * H);   // FFN1's GELU in the GEMM epilogue (big batches)
   for (int l = 0; l < model->n_layers; ++l) {
     const RarcEnc32Layer& Ly = model->layers[l];
     // fused q|k|v projection; its scales and bias are applied by the attention kernel's loads
@@ -823,15 +864,26 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     }
 #undef E32_ATTN_LAUNCH
     RARC_HIP_CHECK(hipGetLastError());
+    const bool fuse_gelu = fuse_shape && Ly.f1_colmax != nullptr;
+    E32Fuse fz2;
+    if (fuse_gelu) { fz2.colmax = Ly.f1_colmax; fz2.k = H; fz2.sg_out = sg; fz2.sg_rows = (size_t)M; }
     if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs))) return rc;
     // attention output projection -> x = LayerNorm(proj + x)
     if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.o_w3, P, M, H, 3 * H, max_parts, &parts, hs)) != RARC_OK) return rc;
-    if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs, parts))) return rc;
-    // FFN
-    if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.f1_w3, P, M, I, 3 * H, max_parts_i, &parts, hs)) != RARC_OK) return rc;
-    if ((rc = e32_epi<1>(P, ra_a, Ly.f1_rw, Ly.f1_b, nullptr, nullptr, nullptr, 0.f, M, I, nullptr, mids, ra_b, hs, parts))) return rc;
+    if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs, parts, fz2))) return rc;
+    // FFN: the first projection with bias + GELU + split fused into its epilogue where the shape allows (big batches),
+    // else the fp32 product and a row pass
+    const float* ra_f2 = ra_b;
+    if (fuse_gelu) {
+      if ((rc = rarc_gemm_f16_gelu_split(xs, Ly.f1_w3, ra_a, Ly.f1_rw, Ly.f1_b, sg, mids, M, I, 3 * H, hs)) != RARC_OK)
+        return rc == 1 ? RARC_E_INVALID : rc;   // (the shape was asked about above)
+      ra_f2 = sg + M;
+    } else {
+      if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.f1_w3, P, M, I, 3 * H, max_parts_i, &parts, hs)) != RARC_OK) return rc;
+      if ((rc = e32_epi<1>(P, ra_a, Ly.f1_rw, Ly.f1_b, nullptr, nullptr, nullptr, 0.f, M, I, nullptr, mids, ra_b, hs, parts))) return rc;
+    }
     if ((rc = rarc_gemm_f16_f32out_parts(mids, Ly.f2_w3, P, M, H, 3 * I, max_parts, &parts, hs)) != RARC_OK) return rc;
-    if ((rc = e32_epi<2>(P, ra_b, Ly.f2_rw, Ly.f2_b, x, Ly.ln2_g, Ly.ln2_b, eps, M, H, x, xs, ra_a, hs, parts))) return rc;
+    if ((rc = e32_epi<2>(P, ra_f2, Ly.f2_rw, Ly.f2_b, x, Ly.ln2_g, Ly.ln2_b, eps, M, H, x, xs, ra_a, hs, parts))) return rc;
   }
   hipLaunchKernelGGL(rarc_e32_pool_kernel, dim3(n_seq), dim3(256), 0, hs, x, d_lens, seq_len, H, (normalize & 2) ? 1 : 0,
                      normalize & 1, d_out);

@@ -175,6 +175,9 @@ class HipBertEncoder:
                 f2_w=ld(p + "output.dense.weight"), f2_b=ld(p + "output.dense.bias"),
                 ln2_g=ld(p + "output.LayerNorm.weight"), ln2_b=ld(p + "output.LayerNorm.bias"))
             if precision == "fp32":
+                # what the fused FFN1 epilogue sizes its output scale with (rarc.h, RarcEnc32Layer.f1_colmax):
+                # c[k] = max_j |W1[j][k]|, c[hidden] = max_j |b1[j]|
+                lay["f1_colmax"] = torch.cat([lay["f1_w"].abs().amax(dim=0), lay["f1_b"].abs().amax().reshape(1)]).float().contiguous()
                 for nm in ("qkv", "o", "f1", "f2"):     # fp32 [n][k] -> split image fp16 [n][3k] + inverse row scales
                     lay[nm + "_w3"], lay[nm + "_rw"] = self._split_weight(lay.pop(nm + "_w"))
             self.layers.append(lay)

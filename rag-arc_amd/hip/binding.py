@@ -42,7 +42,7 @@ class EncModel(ctypes.Structure):
 class Enc32Layer(ctypes.Structure):
     """RarcEnc32Layer (include/rarc.h): split fp16 weight images + fp32 scales / biases / LayerNorm of one layer."""
     _fields_ = [(n, c_void_p) for n in ("qkv_w3", "qkv_rw", "qkv_b", "o_w3", "o_rw", "o_b", "ln1_g", "ln1_b", "f1_w3", "f1_rw",
-                                        "f1_b", "f2_w3", "f2_rw", "f2_b", "ln2_g", "ln2_b")]
+                                        "f1_b", "f2_w3", "f2_rw", "f2_b", "ln2_g", "ln2_b", "f1_colmax")]
 
 
 class Enc32Model(ctypes.Structure):

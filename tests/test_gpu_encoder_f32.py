@@ -215,3 +215,40 @@ def test_split_attention_against_the_fp32_mfma_kernel(oracle, monkeypatch):
     assert not np.array_equal(split, exact)                   # ... and the two kernels really are different code
     assert d_split <= 1e-5 and d_split <= 2.0 * max(d_np, d_exact) + 3e-7
     assert np.abs(split - exact).max() <= 2e-6
+
+
+@pytest.mark.parametrize("stress", [False, True])
+def test_ffn1_gelu_fused_into_the_gemm_epilogue(oracle, monkeypatch, stress):
+    """Round 4: on batches that fill the chip FFN1 runs with bias + GELU + the split of its output fused into the GEMM's
+    epilogue; the scale of that split is fixed before the GEMM from a bound on the row (||x|| ||W_j|| + |b_j|), not from the
+    row's maximum.  Same forward with the fusion off (RARC_E32_FUSE_GELU=0: fp32 product + row pass): both in the fp32 class
+    against float64 and next to each other.  `stress`: FFN1 rows over eight decades, a hot input channel, large biases — the
+    bound overshoots the true row maximum by many more binades than on ordinary weights."""
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
+
+    H, layers, heads, I, n_seq, L = 256, 2, 4, 1024, 128, 128          # 16384 tokens: 64 x 4 tiles of 256 x 256
+    sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=500, max_pos=L, seed=91)
+    rng = np.random.default_rng(91)
+    if stress:
+        for i in range(layers):
+            p = f"encoder.layer.{i}."
+            f = np.exp2(np.round(rng.uniform(-13, 13, I))).astype(np.float32)       # FFN1 row j scaled by f[j] ...
+            sd[p + "intermediate.dense.weight"] = sd[p + "intermediate.dense.weight"] * f[:, None]
+            sd[p + "intermediate.dense.bias"] = sd[p + "intermediate.dense.bias"] * f * 4.0
+            sd[p + "output.dense.weight"] = sd[p + "output.dense.weight"] / np.maximum(f, 1.0)[None, :]   # (keeps FFN2's output finite)
+            sd[p + "attention.output.LayerNorm.weight"][7] = 25.0                     # a hot channel into FFN1
+    ids, lens = _tokens(rng, n_seq, L, 500)
+    enc = HipBertEncoder(sd, num_heads=heads, precision="fp32")
+    fused = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    monkeypatch.setenv("RARC_E32_FUSE_GELU", "0")
+    plain = enc.forward(ids, lens, normalize=True).cpu().numpy()
+    monkeypatch.delenv("RARC_E32_FUSE_GELU")
+    assert np.array_equal(fused, enc.forward(ids, lens, normalize=True).cpu().numpy())
+    assert not np.array_equal(fused, plain), "the fused path did not engage (or is the unfused code)"
+    w64 = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=True, dtype=np.float64)
+    w32 = oracle.bert_forward_f32(sd, ids, lens, heads, normalize=True)
+    d_f, d_p, d_np = (np.linalg.norm(v - w64, axis=1).max() for v in (fused, plain, w32))
+    print(f"ENC32-FUSE stress={stress}: fused vs f64 {d_f:.2e}   unfused vs f64 {d_p:.2e}   numpy32 vs f64 {d_np:.2e}   "
+          f"max|fused - unfused| {np.abs(fused - plain).max():.2e}")
+    assert d_f <= 1e-5 and d_f <= 2.0 * max(d_np, d_p) + 3e-7
+    assert np.abs(fused - plain).max() <= 2e-6
