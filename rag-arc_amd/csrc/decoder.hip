@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
       const half8 kf = *(const half8*)(kim + col * KROW + 16 * ks + 8 * hh);
       st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
     }
+    RARC_MFMA_SETTLE(st);
     // ---- online softmax in the log2 domain: t = s * (scale * log2 e), p = 2^(t - m) ----
     // An INTERIOR tile (every key of it visible to every query of the wave: all but the first tile of a left-padded or
     // prefixed sequence and the tile on the diagonal) needs no mask, no -inf guards.  The running maximum is only raised
@@ -557,6 +558,7 @@ __global__ __launch_bounds__(256, 2) void rarc_lm_attention_kernel(const half_t*
         o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfr, o[mb], 0, 0, 0);
       }
     }
+    RARC_MFMA_SETTLE(o);
     LM_TL(tl_i++);
   }
   LM_TL(tl_i++);
@@ -776,6 +778,7 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
         const half8 kf = *(const half8*)(kim + col * KROW + 16 * ks + 8 * hh);
         st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
       }
+      RARC_MFMA_SETTLE(st);
       return st;
     };
     f32x16 st = {0};
@@ -799,6 +802,7 @@ __global__ __launch_bounds__(512, 1) void rarc_lm_attention_resident_kernel(cons
           o[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfr, o[mb], 0, 0, 0);
         }
       }
+      RARC_MFMA_SETTLE(o);   // (the loop's register moves read the accumulators at once: rarc_common.h)
       st = st_next;
     }
     LM_TL(tl_i++);   // unit: key loop done

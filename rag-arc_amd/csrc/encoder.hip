@@ -1634,6 +1634,7 @@ __global__ __launch_bounds__(256) void rarc_attention_mfma_kernel(const half_t* 
       const half8 kf = *(const half8*)(base + H + (size_t)krow * rs + 16 * ks + 8 * hh);
       st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
     }
+    RARC_MFMA_SETTLE(st);
     // ---- V tile -> transposed LDS image vt[d][key] (each lane: 16-byte row pieces, written as halves) ----
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1809,6 +1810,7 @@ __global__ __launch_bounds__(256) void rarc_attention_mfma_shared_kernel(const h
       const half8 kf = *(const half8*)(kim + col * KROW + 16 * ks + 8 * hh);
       st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st, 0, 0, 0);
     }
+    RARC_MFMA_SETTLE(st);
     // ---- softmax statistics of this lane's query over its 16 keys, then with the partner lane ----
     float sc[16];
     float tmax = -INFINITY;

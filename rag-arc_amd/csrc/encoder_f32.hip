@@ -621,6 +621,7 @@ __global__ __launch_bounds__(256, 2) void rarc_e32_attention_split_kernel(const 
       st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[ks], st, 0, 0, 0);
       st = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[ks], st, 0, 0, 0);
     }
+    RARC_MFMA_SETTLE(st);
     // ---- softmax statistics of this lane's query over its 16 keys, then with the partner lane ----
     float pr[16];
     float tmax = -INFINITY;
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(256, 2) void rarc_e32_attention_split_kernel(const 
         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl, bhi, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, blo, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, bhi, t, 0, 0, 0);
+        RARC_MFMA_SETTLE(t);
         const float svi = svinv[buf][2 * ks + mb];
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[mb][r] = __builtin_fmaf(t[r], svi, o[mb][r]);

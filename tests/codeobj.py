@@ -111,7 +111,7 @@ def disassemble(kernel_substring: str, lib_path: str = LIB) -> Dict[str, List[st
                                   capture_output=True, text=True).stdout
             cur = None
             for line in text.splitlines():
-                m = re.match(r"^[0-9a-f]+ <([^>]+)>:$", line)
+                m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)   # (demangled template names hold '>' themselves)
                 if m:
                     cur = m.group(1) if kernel_substring in m.group(1) and not m.group(1).endswith(".kd") else None
                     if cur is not None:
@@ -121,4 +121,81 @@ def disassemble(kernel_substring: str, lib_path: str = LIB) -> Dict[str, List[st
                     ins = line.split("//")[0].strip()
                     if ins:
                         out[cur].append(ins)
+    return out
+
+
+# ---- MFMA result -> first reader windows (round 4) -------------------------------------------------------------------------
+# Wait states gfx950 needs between an MFMA and a VALU (or accvgpr / LDS / store / permlane) read of its result, measured with
+# tools/mfma_wait_probe.hip (profiles/r04_mfma_wait_probe.txt): the first K at which no read came early.
+MFMA_RESULT_WAIT_STATES = {"v_mfma_f32_32x32x16_f16": 12, "v_mfma_i32_32x32x32_i8": 12, "v_mfma_f32_16x16x32_f16": 8,
+                           "v_mfma_i32_16x16x64_i8": 8, "v_mfma_f32_32x32x2_f32": 18}
+# instructions the sequencer retires without an issue cycle when they have nothing to wait for: hipcc's hazard recognizer counts
+# each as one wait state all the same (measured effect: reads of an MFMA result one to three cycles early, random wrong rows)
+_FREE = ("s_waitcnt", "s_setprio", "s_sleep")
+_STORES = ("global_store", "ds_write", "buffer_store", "flat_store", "scratch_store", "ds_bpermute", "ds_permute", "global_atomic",
+           "ds_add", "ds_max", "ds_min", "ds_inc")
+
+
+def _regs(tok):
+    import re
+    tok = tok.strip()
+    m = re.match(r"([av])\[(\d+):(\d+)\]", tok)
+    if m:
+        return {(m.group(1), k) for k in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.match(r"([av])(\d+)$", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def _operands(text):
+    parts = text.split(None, 1)
+    return [t.strip().split()[0] if t.strip() else "" for t in parts[1].split(",")] if len(parts) > 1 else []
+
+
+def mfma_read_windows(lib_path=None, look_ahead=96):
+    """For every MFMA of every kernel whose destination is next touched by something other than the accumulating MFMA of the same
+    chain: (kernel, opcode, hard, soft, kind, reader) — `soft` = wait states as hipcc counts them (every instruction one, s_nop
+    N is N + 1), `hard` = the same with the free instructions counted as ZERO.  kind: "read" (VALU / LDS / store / permlane / a
+    later MFMA's A or B operand), "overwrite", or "srcc" (another MFMA takes it as SrcC into a different destination:
+    interlocked by the hardware, measured)."""
+    import re
+    out = []
+    for name, ins in disassemble("", lib_path or LIB).items():
+        for n, s in enumerate(ins):
+            if not s.startswith("v_mfma"):
+                continue
+            op, dst = s.split()[0], _regs(_operands(s)[0])
+            soft = hard = 0
+            for t in ins[n + 1: n + 1 + look_ahead]:
+                o, kind = _operands(t), None
+                if t.startswith("v_mfma"):
+                    d2, a, b = _regs(o[0]), _regs(o[1]), _regs(o[2])
+                    c = _regs(o[3]) if len(o) > 3 else set()
+                    if (a | b) & dst:
+                        kind = "read"
+                    elif c & dst and d2 != dst:
+                        kind = "srcc"
+                    elif d2 == dst:
+                        break                      # the chain goes on: the later MFMA is analysed in its own right
+                    elif d2 & dst:
+                        kind = "overwrite"
+                else:
+                    srcs = set()
+                    whole = t.startswith(_STORES) or t.startswith("v_cmp") or t.startswith("v_permlane") or t.startswith("v_swap")
+                    for idx, tok in enumerate(o):
+                        if idx or whole:
+                            srcs |= _regs(tok)
+                    if srcs & dst:
+                        kind = "read"
+                    elif o and _regs(o[0]) & dst and not t.startswith(_STORES):
+                        kind = "overwrite"
+                if kind:
+                    out.append((name, op, hard, soft, kind, t[:70]))
+                    break
+                m = re.match(r"s_nop (\d+)", t)
+                w = int(m.group(1)) + 1 if m else 1
+                soft += w
+                if not t.startswith(_FREE):
+                    hard += w
+                if t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
+                    break
     return out

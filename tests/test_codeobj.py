@@ -120,3 +120,22 @@ def test_the_scan_kernels_fast_path_swap_is_present_in_the_m16_instantiations():
             assert n_swap == 0 and n_16 == 0 and n_32 > 0, name
         else:
             assert n_swap >= 9 and n_16 > 0 and n_32 == 0, name
+
+
+def test_no_mfma_result_is_read_early_once_s_waitcnt_counts_for_nothing():
+    """Round 4.  hipcc sizes the gap between an MFMA and the first read of its result exactly (12 wait states for
+    v_mfma_f32_32x32x16_f16, what the hardware needs: tools/mfma_wait_probe.hip) — and counts an s_waitcnt inside the gap as one
+    of them, although gfx950 retires a satisfied s_waitcnt without an issue cycle.  Such a read then comes early whenever the LDS
+    had already answered: rarc_e32_attention_split_kernel returned random wrong rows in 1.5 % of its forwards, a build with its
+    accumulators in AGPRs in every one, and three instantiations of the LM's attention carried the same window.  RARC_MFMA_SETTLE
+    (rarc_common.h) pads those chains; this test walks EVERY kernel's listing and fails on any window that is short once the
+    free instructions count as zero.  (An MFMA that takes another's result as SrcC is interlocked by the hardware: measured.)"""
+    wins = codeobj.mfma_read_windows()
+    assert len(wins) >= 300 and {w[1] for w in wins} >= {"v_mfma_f32_32x32x16_f16", "v_mfma_i32_16x16x64_i8"}
+    short = [w for w in wins if w[4] != "srcc" and w[2] < codeobj.MFMA_RESULT_WAIT_STATES[w[1]]]
+    assert not short, "MFMA results read early: " + "; ".join(
+        f"{codeobj.demangle(k)[:60]} {op} hard {h} / counted {sft} -> {kind} by `{rd}`" for k, op, h, sft, kind, rd in short[:6])
+    # what hipcc itself guarantees (with every instruction counted) is the measured requirement — the tables agree, the s_waitcnt does not
+    for op, need in codeobj.MFMA_RESULT_WAIT_STATES.items():
+        soft = [w[3] for w in wins if w[1] == op and w[4] == "read"]
+        assert not soft or min(soft) >= need - 1, (op, min(soft), need)

@@ -6,18 +6,20 @@ import numpy as np, torch
 from oracle import cpu_ref
 from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 reps = int(os.environ.get("SOAK_REPS", "300"))
-H, heads, I, L, layers = 768, 12, 3072, 192, 4
+H, heads, I, layers = 768, 12, 3072, 4
+L, NSEQ = int(os.environ.get("SOAK_LEN", 192)), int(os.environ.get("SOAK_SEQS", 48))   # 128 x 256: FFN1 takes the fused-GELU GEMM
 sd = cpu_ref.random_bert_state_dict(H, layers, heads, I, vocab=2000, max_pos=L, seed=13)
 rng = np.random.default_rng(13)
-lens = rng.integers(1, L + 1, 48).astype(np.int32); lens[0] = L; lens[1] = 1; lens[2] = 32; lens[3] = 33
-ids = rng.integers(1, 2000, (48, L)).astype(np.int32)
+lens = rng.integers(1, L + 1, NSEQ).astype(np.int32); lens[0] = L; lens[1] = 1; lens[2] = 32; lens[3] = 33
+ids = rng.integers(1, 2000, (NSEQ, L)).astype(np.int32)
 for r, l in enumerate(lens):
     ids[r, l:] = 0
 enc = HipBertEncoder(sd, num_heads=heads, pooling="mean", precision="fp32")
 tok = torch.from_numpy(ids).cuda(); ln = torch.from_numpy(lens).cuda()
 first = enc.forward_device(tok, ln).clone()
-w64 = cpu_ref.bert_forward_f32(sd, ids, lens, heads, normalize=True, pooling="mean", dtype=np.float64)
-print("max ||e - e64||:", float(np.linalg.norm(first.cpu().numpy() - w64, axis=1).max()))
+if NSEQ * L <= 10000:
+    w64 = cpu_ref.bert_forward_f32(sd, ids, lens, heads, normalize=True, pooling="mean", dtype=np.float64)
+    print("max ||e - e64||:", float(np.linalg.norm(first.cpu().numpy() - w64, axis=1).max()))
 side = torch.cuda.Stream(); junk = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
 bad = 0
 for it in range(reps):
@@ -28,4 +30,4 @@ for it in range(reps):
         bad += 1
         print("MISMATCH at", it, float((e - first).abs().max()))
 torch.cuda.synchronize()
-print(f"encoder soak: {reps} forwards,", "all identical" if not bad else f"{bad} MISMATCHES")
+print(f"encoder soak ({NSEQ} x {L} tokens): {reps} forwards,", "all identical" if not bad else f"{bad} MISMATCHES")
