@@ -67,7 +67,7 @@ def swap_hazard_distances(ins):
             mn = parts[0]
             if mn.startswith("s_nop"):
                 dist += int(parts[1], 0) + 1
-            elif mn.startswith(("s_waitcnt", "s_setprio", "s_sleep")):
+            elif mn.startswith(("s_waitcnt", "s_setprio", "s_sleep", "s_barrier")):
                 pass        # retired without an issue cycle when satisfied: counts for nothing (round 4, codeobj.mfma_read_windows)
             else:
                 wr = set()
