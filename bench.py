@@ -19,6 +19,7 @@ largest power-of-ten row count that does.  The same line also carries, as object
   c5  config 5 end to end: bge-large encoder forward (24 layers, seeded weights) -> fp8 100M x 1024
       sharded scan -> RRF with the supplied lexical list             [every N]
   cpu_baseline  the CPU oracle timed on the host cores               [N = 1]
+  api  the same indexes reached THROUGH the plugin surface: retriever.batch_invoke / invoke, texts -> Documents   [N = 1]
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -55,6 +56,7 @@ def parse(argv=None):
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-api", action="store_true", help="skip the legs through the registered retriever (texts -> Documents)")
     ap.add_argument("--no-lm", action="store_true", help="config 3 without its cross-encoder's LM forward (seeded logits instead)")
     ap.add_argument("--c3-steps", type=int, default=2, help="timed steps of the config-3 leg (one step = 256 x 100 LM prompts, seconds)")
     ap.add_argument("--c3-chunk", type=int, default=640, help="(query, document) prompts per LM call in the config-3 leg")
@@ -468,6 +470,12 @@ def main():
             torch.cuda.empty_cache()
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(np, idx2, q, ids2, sc2, n2, a)
+        if not a.no_api:      # the plugin surface over config 2's index, via the registry (saved index + JSON config)
+            eng2 = {"value": round(a.batch * steps2 / dt2, 1), "unit": "queries/s", "ms_per_batch": round(dt2 / steps2 * 1e3, 4)}
+            result["api"] = {"c2": leg_api(torch, np, lib, B, a, dev, local_rank, idx2, n2, eng2, via_registry=True)}
+            if idx2 is not idx:     # ... and over the headline index (100M rows: columnar docstore, adopted engine)
+                eng = {"value": result["value"], "unit": "queries/s", "ms_per_batch": result["ms_per_step"]}
+                result["api"]["headline"] = leg_api(torch, np, lib, B, a, dev, local_rank, idx, hi - lo, eng, via_registry=False)
         if idx2 is not idx:
             del idx2
 
@@ -808,6 +816,183 @@ def cpu_baseline(np, idx2, q, ids2, sc2, n2, a):
             "parity_vs_gpu": {"ids_bit_exact": bool(np.array_equal(ref_i, gpu_i)),
                               "scores_bit_exact": bool(np.array_equal(ref_s.view(np.uint32), sc2.cpu().numpy().view(np.uint32))),
                               f"recall_at_{a.k}": round(recall, 6)}}
+
+
+# ------------------------------------------------------------------------------------------------ the plugin surface
+def _percentile(xs, p):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, int(round(p / 100.0 * (len(xs) - 1))))]
+
+
+def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_registry):
+    """Throughput and latency THROUGH the registered backend — `retriever.batch_invoke` / `.invoke` of the reference's call
+    chain (core/retrieval/mutipath.py:37-93 -> core/retrieval/dense.py:122-174 -> VectorStore_Faiss.py:225-274), texts in,
+    lists of Documents out — next to the engine-level figure of the same index (`engine`: q/s and ms per 256-query batch
+    at FlatIndexF16.search_async).  The docstore is real: one python Document per row up to 2M rows, byte columns beyond
+    (docstore.py).  Query texts map to the synthetic query vectors through a lookup-table provider whose table sits in HBM
+    (the encoder is timed on its own in c5 / ingest)."""
+    import tempfile
+    import threading
+
+    from rag_arc_amd.config.app_registration import registrator
+    from rag_arc_amd.config.modules import VectorStoreRetrieverConfig
+    from rag_arc_amd.core.retrieval.base import BaseRetriever
+    from rag_arc_amd.core.retrieval.dense import VectorStoreRetriever
+    from rag_arc_amd.core.retrieval.multipath import MultiPathRetriever
+    from rag_arc_amd.core.utils.data_model import Document
+    from rag_arc_amd.core.utils.fusion import HipRRFusion
+    from rag_arc_amd.encapsulation.database.vector_db.docstore import ColumnarDocstore
+    from rag_arc_amd.encapsulation.database.vector_db.hip_flat import HipFlatVectorStore
+    from rag_arc_amd.encapsulation.embeddings.table import TableEmbeddings
+
+    K, NB, NQT = a.k, 256, 2048
+    out = {"workload": f"{n_rows}x{a.dim} fp16, batch {NB} query TEXTS -> lists of {K} Documents, through "
+                       f"{'registrator.get_object(...)' if via_registry else 'VectorStoreRetriever(HipFlatVectorStore)'}",
+           "engine": engine}
+    t0 = time.perf_counter()
+    width = len(str(n_rows - 1))
+    if n_rows <= 2_000_000:
+        docs = [Document(content=f"{i:0{width}d}", metadata={}, id=f"{i:0{width}d}") for i in range(n_rows)]
+        out["docstore"] = f"{n_rows} python Documents (list + the reference's two dicts)"
+    else:
+        docs = ColumnarDocstore.decimal(n_rows)
+        out["docstore"] = f"{n_rows} rows as byte columns (ColumnarDocstore): a Document is built when a search names its row"
+    out["docstore_build_s"] = round(time.perf_counter() - t0, 2)
+    qv = torch.empty((NQT, a.dim), dtype=torch.float32, device=dev)
+    B.check(lib.rarc_synth_rows_f32(qv.data_ptr(), a.dim, a.dim, 0, NQT, 4321, 0), "rarc_synth_rows_f32")
+    texts = [f"q{i}" for i in range(NQT)]
+    qv_h = qv.cpu().numpy()
+    tmp = None
+    if via_registry:
+        # the reference's own route: a saved index + a JSON config, registered and fetched by name (framework/register.py:15-26)
+        tmp = tempfile.TemporaryDirectory(prefix="rarc_api_")
+        HipFlatVectorStore(TableEmbeddings(texts, qv_h), device=local_rank).adopt(idx, docs).save_local(tmp.name)
+        np.savez(os.path.join(tmp.name, "queries.npz"), texts=np.array(texts), vectors=qv_h)
+        cfg = {"type": "vectorstore_retriever", "search_type": "similarity",
+               "vectorstore": {"type": "hip_flat_vectorstore", "metric": "cosine", "device": local_rank,
+                               "index_path": tmp.name,
+                               "embedding": {"type": "table_embeddings", "path": os.path.join(tmp.name, "queries.npz"),
+                                             "device": local_rank}}}
+        with open(os.path.join(tmp.name, "retriever.json"), "w") as fh:
+            json.dump(cfg, fh)
+        t0 = time.perf_counter()
+        registrator.register(os.path.join(tmp.name, "retriever.json"), "rarc_api_bench", VectorStoreRetrieverConfig)
+        retriever = registrator.get_object("rarc_api_bench")
+        out["registry_build_s"] = round(time.perf_counter() - t0, 2)
+        store = retriever.vectorstore
+    else:
+        store = HipFlatVectorStore(TableEmbeddings(texts, qv_h).to_device(local_rank), device=local_rank).adopt(idx, docs)
+        retriever = VectorStoreRetriever(store)
+    big = n_rows > 20_000_000
+    reps = 8 if big else 40
+
+    def rate(fn, n_queries, reps, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        dt = time.perf_counter() - t0
+        return {"value": round(n_queries * reps / dt, 1), "unit": "queries/s", "ms_per_call": round(dt / reps * 1e3, 3)}
+
+    # (a) one caller, batch after batch of 256 texts; host-side phases added up by the store
+    first = texts[:NB]
+    answers = retriever.batch_invoke(first, k=K)
+    ref_ids = idx.search_device(qv[:NB], K)[0].cpu().numpy()
+    base = int(getattr(idx, "id_base", 0))
+    out["answers_equal_engine_ids"] = bool(all([int(d.id) for d in docs_q] == (ref_ids[i] - base).tolist()
+                                               for i, docs_q in enumerate(answers)))
+    one = [retriever.invoke(t, k=K) for t in first[:4]]
+    out["batch_equals_invoke"] = bool(all([d.id for d in x] == [d.id for d in y] for x, y in zip(one, answers[:4])))
+    store.timing = {}
+    r = rate(lambda: retriever.batch_invoke(first, k=K), NB, reps, warm=0)
+    tm, store.timing = store.timing, None
+    r["host_ms_per_call"] = {key[:-2] + "_ms": round(v / reps * 1e3, 3) for key, v in tm.items()}
+    r["vs_engine"] = round(r["value"] / engine["value"], 3)
+    out["batch_invoke_256"] = r
+    # (b) the same with the cyclic garbage collector's old generations frozen: a million-Document docstore is what every
+    # young collection's promotions are measured against (gc.freeze() after building a store is the usual remedy)
+    import gc
+    gc.collect()
+    gc.freeze()
+    r = rate(lambda: retriever.batch_invoke(first, k=K), NB, reps)
+    r["vs_engine"] = round(r["value"] / engine["value"], 3)
+    out["batch_invoke_256_gc_frozen"] = r
+    # (c) one call with 2048 texts: eight scans, each running while the answer before it is mapped
+    r = rate(lambda: retriever.batch_invoke(texts, k=K), NQT, max(2, reps // 8), warm=1)
+    r["vs_engine"] = round(r["value"] / engine["value"], 3)
+    out["batch_invoke_2048"] = r
+    # (d) with (Document, score) pairs: batch_similarity_search_with_score (VectorStore_Faiss.py:250-274 for a batch)
+    r = rate(lambda: store.batch_similarity_search_with_score(first, K), NB, reps)
+    out["batch_with_scores_256"] = r
+    # (e) 256 threads, one invoke each (the reference's ainvoke pattern, core/retrieval/base.py:82-96): the coalescer
+    def storm():
+        go = threading.Barrier(NB + 1)
+        res = [None] * NB
+
+        def call(i):
+            go.wait()
+            res[i] = retriever.invoke(first[i], k=K)
+
+        th = [threading.Thread(target=call, args=(i,)) for i in range(NB)]
+        for t in th:
+            t.start()
+        l0 = store.coalesced_launches[0]
+        t0 = time.perf_counter()
+        go.wait()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0, store.coalesced_launches[0] - l0, res
+
+    storm()
+    runs = [storm() for _ in range(3 if big else 5)]
+    dt, launches, res = min(runs, key=lambda x: x[0])
+    out["threads_256_invoke"] = {"value": round(NB / dt, 1), "unit": "queries/s", "wall_ms": round(dt * 1e3, 3),
+                                 "scans": launches,
+                                 "equal_batch": bool(all([d.id for d in x] == [d.id for d in y] for x, y in zip(res, answers)))}
+    # (f) one caller, one query at a time: latency
+    lat = []
+    for i in range(30 if big else 300):
+        t0 = time.perf_counter()
+        retriever.invoke(texts[i % NQT], k=K)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = lat[5:]
+    eng = []
+    for i in range(10 if big else 50):
+        t0 = time.perf_counter()
+        idx.search(qv[i:i + 1], K)
+        eng.append((time.perf_counter() - t0) * 1e3)
+    out["invoke_latency_ms"] = {"p50": round(_percentile(lat, 50), 3), "p99": round(_percentile(lat, 99), 3),
+                                "mean": round(sum(lat) / len(lat), 3), "calls": len(lat),
+                                "queries_per_s": round(1e3 / (sum(lat) / len(lat)), 1),
+                                "engine_nq1_p50": round(_percentile(eng[2:], 50), 3)}
+    # (g) MultiPathRetriever: dense + the supplied lexical list, RRF over all 256 queries in one launch
+    lex = lexical_lists(torch, torch.from_numpy(ref_ids).to(dev), base + n_rows, K).cpu().numpy() - base
+    lex_docs = {t: [Document(content=f"{r:0{width}d}", metadata={"path": "lexical"}, id=f"L{r}") for r in row.tolist()]
+                for t, row in zip(first, lex)}
+
+    class SuppliedLists(BaseRetriever):
+        """The "supplied BM25 rank list"  as a retriever: query text -> its ordered Documents."""
+
+        def _get_relevant_documents(self, query, **kw):
+            return lex_docs[query][: kw.get("k", 5)]
+
+        def batch_invoke(self, inputs, **kw):
+            return [lex_docs[q][: kw.get("k", 5)] for q in inputs]
+
+    mp = MultiPathRetriever([retriever, SuppliedLists()], HipRRFusion(device=local_rank), top_k_per_retriever=K)
+    fused = mp.batch_invoke(first, top_k=K)
+    single = [mp.invoke(t, top_k=K) for t in first[:4]]
+    r = rate(lambda: mp.batch_invoke(first, top_k=K), NB, reps)
+    r["vs_engine"] = round(r["value"] / engine["value"], 3)
+    r["batch_equals_invoke"] = bool(all([d.content for d in x] == [d.content for d in y] for x, y in zip(single, fused[:4])))
+    out["multipath_batch_invoke_256"] = r
+    gc.unfreeze()
+    if tmp is not None:
+        registrator.registrations.pop("rarc_api_bench", None)
+        tmp.cleanup()
+    return out
 
 
 def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, shard_range, split_range, a, world, rank,

@@ -568,6 +568,26 @@ int rarc_device_to_file(const char* path, int n_seg, const int64_t* h_file_off, 
                         size_t staging_bytes, int n_threads, int flags, void* stream, RarcIoStats* stats);
 
 /*
+ * Growable device arenas: where `index.add` appends to (encapsulation/database/vector_db/VectorStore_Faiss.py:199-202 —
+ * faiss grows a std::vector there).  An arena reserves VIRTUAL address space for the largest size it may reach (no memory)
+ * and is backed slab by slab as rows arrive: the base pointer never moves and nothing is copied, so the peak footprint of
+ * a growing index is its live rows rounded up to one slab (a reallocating buffer holds old + new: up to 3x).
+ * The second kind of object this library allocates (with the tokenizer handle): release it with rarc_vmem_destroy, after
+ * the last kernel that reads it.  slab_bytes (0 = 1 GiB) bounds one physical allocation; sizes are rounded up to the device's
+ * mapping granularity (rarc_vmem_slab / _mapped / _reserved report the rounded figures).
+ * rarc_vmem_grow(min_bytes): back at least the first min_bytes (never shrinks; on failure — HBM exhausted — what was
+ * mapped stays mapped and usable).  Not tied to a stream: mapping is a host-side operation, visible to later launches.
+ */
+typedef struct RarcVmem RarcVmem;
+int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_bytes, RarcVmem** out);
+int rarc_vmem_grow(RarcVmem* arena, size_t min_bytes);
+void* rarc_vmem_base(const RarcVmem* arena);
+size_t rarc_vmem_mapped(const RarcVmem* arena);
+size_t rarc_vmem_reserved(const RarcVmem* arena);
+size_t rarc_vmem_slab(const RarcVmem* arena);
+int rarc_vmem_destroy(RarcVmem* arena);
+
+/*
  * Measurement hooks (bench.py): while profiling is on, every rarc_search_f16 brackets its scan
  * kernel with a pair of HIP events recorded on the search's own stream.  rarc_profile_end
  * synchronises, returns the summed scan time and the number of launches measured, and releases

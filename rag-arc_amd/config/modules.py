@@ -33,11 +33,15 @@ class BuiltModule(AbstractModule):
 class TableEmbeddingsConfig(AbstractConfig):
     type: Literal["table_embeddings"] = "table_embeddings"
     path: str
+    device: Optional[int] = None      # keep the table in this GPU's HBM (query vectors are gathered there)
 
     def build(self) -> AbstractModule:
         from ..encapsulation.embeddings.table import TableEmbeddings
 
-        return BuiltModule(config=self, impl=TableEmbeddings.from_npz(self.path))
+        emb = TableEmbeddings.from_npz(self.path)
+        if self.device is not None:
+            emb.to_device(self.device)
+        return BuiltModule(config=self, impl=emb)
 
 
 class HipBertEmbeddingsConfig(AbstractConfig):
@@ -107,14 +111,36 @@ class HipFlatVectorStoreConfig(AbstractConfig):
     device: int = 0
     storage: Literal["f16", "f8", "f32"] = "f16"  # rows in HBM: fp16, fp8 e4m3fn + per-row scale, or fp32 (the reference's)
     corpus_path: Optional[str] = None  # .npz with `texts` (and optional `ids`) to ingest at build time
+    # a folder written by save_local (`<index_name>.rarc` shard file(s) + `<index_name>.pkl`): the rows stream into HBM at
+    # storage / PCIe rate instead of being embedded again (the reference's FaissVectorStore.load_local, VectorStore_Faiss.py:452-482)
+    index_path: Optional[str] = None
+    index_name: str = "index"
+    coalesce: bool = True              # concurrent one-query callers share scans (hip_flat._QueryCoalescer)
+    coalesce_window_us: float = 0.0
+    # row storage: `capacity` rows are backed at build time; with `growable` the rows live in a virtual-memory arena that
+    # grows IN PLACE up to `max_rows` (0 = what the device could hold) — add_texts never copies the rows already stored
+    capacity: int = 0
+    max_rows: int = 0
+    growable: Optional[bool] = None    # None = the engine's default
 
     def build(self) -> AbstractModule:
         import numpy as np
 
         from ..encapsulation.database.vector_db.hip_flat import HipFlatVectorStore
 
-        store = HipFlatVectorStore(self.embedding.build().impl, metric=self.metric, normalize_L2=self.normalize_L2,
-                                   device=self.device, storage=self.storage)
+        if self.index_path:
+            store = HipFlatVectorStore.load_local(self.index_path, self.embedding.build().impl, self.index_name,
+                                                  device=self.device, coalesce=self.coalesce,
+                                                  coalesce_window_us=self.coalesce_window_us, capacity=self.capacity,
+                                                  max_rows=self.max_rows, growable=self.growable)
+            if (store.metric, store.storage) != (self.metric, self.storage):
+                raise ValueError(f"{self.index_path}: saved as metric={store.metric} storage={store.storage}, "
+                                 f"config says metric={self.metric} storage={self.storage}")
+        else:
+            store = HipFlatVectorStore(self.embedding.build().impl, metric=self.metric, normalize_L2=self.normalize_L2,
+                                       device=self.device, storage=self.storage, coalesce=self.coalesce,
+                                       coalesce_window_us=self.coalesce_window_us, capacity=self.capacity,
+                                       max_rows=self.max_rows, growable=self.growable)
         if self.corpus_path:
             data = np.load(self.corpus_path, allow_pickle=False)
             ids = [str(i) for i in data["ids"]] if "ids" in data else None
@@ -135,6 +161,9 @@ class HipShardedFlatVectorStoreConfig(AbstractConfig):
     normalize_L2: bool = False
     storage: Literal["f16", "f8", "f32"] = "f16"
     corpus_path: Optional[str] = None     # .npz with `texts` (and optional `ids`): EVERY rank reads it, each keeps its slice
+    capacity: int = 0                     # rows PER RANK backed at build time / the arena's limit (see HipFlatVectorStoreConfig)
+    max_rows: int = 0
+    growable: Optional[bool] = None
     backend: Literal["nccl", "gloo"] = "nccl"   # nccl = RCCL over xGMI (the product); gloo: rehearsals on one device / CPU
     one_device: bool = False              # rehearsal: every rank on cuda:0 (needs backend gloo; RCCL refuses it)
 
@@ -162,7 +191,8 @@ class HipShardedFlatVectorStoreConfig(AbstractConfig):
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         store = HipShardedFlatVectorStore(self.embedding.build().impl, metric=self.metric, normalize_L2=self.normalize_L2,
-                                          device=local_rank, storage=self.storage)
+                                          device=local_rank, storage=self.storage, capacity=self.capacity,
+                                          max_rows=self.max_rows, growable=self.growable)
         if self.corpus_path:
             data = np.load(self.corpus_path, allow_pickle=False)
             ids = [str(i) for i in data["ids"]] if "ids" in data else None

@@ -44,6 +44,19 @@ class MultiPathRetriever(BaseRetriever):
         invoke(inputs[i], **kwargs) — same kwargs hand-down, same swallow-and-report of a failing retriever."""
         inputs = list(inputs)
         top_k = kwargs.get("top_k", 10)
+        fuse_docs_many = getattr(self.fusion_method, "fuse_docs_many", None)
+        if fuse_docs_many is not None:
+            # the fusion method takes plain Document lists: no RetrievalResult per hit on the way in or out
+            answers: List[List[List[Document]]] = []
+            for retriever in self.retrievers:
+                answers.append(self._batch_of(retriever, inputs, kwargs))
+            gathered_docs = [[lists[qi] for lists in answers] for qi in range(len(inputs))]
+            live = [qi for qi, g in enumerate(gathered_docs) if g and not all(len(one) == 0 for one in g)]
+            out_docs: List[List[Document]] = [[] for _ in inputs]
+            if live:
+                for qi, docs in zip(live, fuse_docs_many([gathered_docs[qi] for qi in live], top_k)):
+                    out_docs[qi] = docs
+            return out_docs
         per_retriever: List[List[List[RetrievalResult]]] = []
         for retriever in self.retrievers:
             try:
@@ -74,6 +87,21 @@ class MultiPathRetriever(BaseRetriever):
             for qi in live:
                 out[qi] = [r.document for r in self.fusion_method.fuse(gathered[qi], top_k)]
         return out
+
+    def _batch_of(self, retriever: BaseRetriever, inputs: List[str], kwargs) -> List[List[Document]]:
+        """One retriever's answers to the whole list as plain lists (same hand-down and failure handling as above)."""
+        try:
+            return [list(docs) for docs in retriever.batch_invoke(inputs, **{**kwargs, "k": self.top_k_per_retriever})]
+        except Exception as exc:  # noqa: BLE001
+            print(f"retriever {type(retriever).__name__} failed on the batch ({exc}): answering it query by query")
+            lists: List[List[Document]] = []
+            for q in inputs:
+                try:
+                    lists.append(list(retriever.invoke(q, **{**kwargs, "k": self.top_k_per_retriever})))
+                except Exception as exc_q:  # noqa: BLE001
+                    print(f"retriever {type(retriever).__name__} failed: {exc_q}")
+                    lists.append([])
+            return lists
 
     def add_retriever(self, retriever: BaseRetriever) -> None:
         self.retrievers.append(retriever)

@@ -1,0 +1,130 @@
+// vmem.hip — growable device arenas on HIP virtual memory (see include/rarc.h: rarc_vmem_*).
+//
+// index.add in the reference appends (faiss grows its std::vector: VectorStore_Faiss.py:199-202).  A row buffer in HBM that
+// grows by allocate-bigger-and-copy holds old + new at once — up to 3x the live rows — so a store past a third of the
+// part's memory could not grow.  An arena reserves virtual address space for the largest size it may ever reach
+// (hipMemAddressReserve: costs no memory) and backs it slab by slab (hipMemCreate + hipMemMap + hipMemSetAccess) as rows
+// arrive: the base pointer never moves, nothing is copied, the kernels see one contiguous buffer as before, and the peak
+// footprint is the live rows rounded up to a slab.
+#include <mutex>
+#include <new>
+#include <vector>
+#include "rarc_common.h"
+
+struct RarcVmemSlab {
+  hipMemGenericAllocationHandle_t handle;
+  size_t bytes;
+};
+struct RarcVmem {
+  int device;
+  char* base;
+  size_t reserved, mapped, slab, gran;   // slab: the largest single physical allocation; gran: the mapping granularity
+  std::vector<RarcVmemSlab> slabs;
+  std::mutex mu;
+};
+
+static hipMemAllocationProp vmem_prop(int device) {
+  hipMemAllocationProp p = {};
+  p.type = hipMemAllocationTypePinned;
+  p.location.type = hipMemLocationTypeDevice;
+  p.location.id = device;
+  return p;
+}
+
+extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_bytes, RarcVmem** out) {
+  RARC_REQUIRE(out && reserve_bytes > 0 && device >= 0, RARC_E_INVALID, "rarc_vmem_create: bad argument");
+  *out = nullptr;
+  hipMemAllocationProp prop = vmem_prop(device);
+  size_t gran = 0;
+  RARC_HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+  if (gran == 0) gran = 2u << 20;
+  if (slab_bytes == 0) slab_bytes = (size_t)1 << 30;
+  size_t slab = (slab_bytes + gran - 1) / gran * gran;
+  size_t reserve = (reserve_bytes + gran - 1) / gran * gran;
+  void* base = nullptr;
+  RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve, 0, nullptr, 0));
+  RarcVmem* v = new (std::nothrow) RarcVmem();
+  if (!v) {
+    (void)hipMemAddressFree(base, reserve);
+    rarc_set_error("rarc_vmem_create: out of host memory");
+    return RARC_E_INVALID;
+  }
+  v->device = device;
+  v->base = (char*)base;
+  v->reserved = reserve;
+  v->mapped = 0;
+  v->slab = slab;
+  v->gran = gran;
+  *out = v;
+  return RARC_OK;
+}
+
+// Back the arena up to at least min_bytes (rounded up to the mapping granularity, in physical allocations of at most one
+// slab each).  Never shrinks; on failure what was mapped before stays mapped.
+extern "C" int rarc_vmem_grow(RarcVmem* v, size_t min_bytes) {
+  RARC_REQUIRE(v, RARC_E_INVALID, "rarc_vmem_grow: null arena");
+  std::lock_guard<std::mutex> lk(v->mu);
+  RARC_REQUIRE(min_bytes <= v->reserved, RARC_E_INVALID, "rarc_vmem_grow: %zu bytes asked of an arena that reserved %zu",
+               min_bytes, v->reserved);
+  hipMemAllocationProp prop = vmem_prop(v->device);
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  const size_t target = (min_bytes + v->gran - 1) / v->gran * v->gran;
+  while (v->mapped < target) {
+    const size_t piece = target - v->mapped < v->slab ? target - v->mapped : v->slab;
+    hipMemGenericAllocationHandle_t h;
+    hipError_t e = hipMemCreate(&h, piece, &prop, 0);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      rarc_set_error("rarc_vmem_grow: hipMemCreate of %zu bytes failed with %zu bytes mapped: %s", piece, v->mapped,
+                     hipGetErrorString(e));
+      return RARC_E_HIP;
+    }
+    e = hipMemMap(v->base + v->mapped, piece, 0, h, 0);
+    if (e == hipSuccess) {
+      e = hipMemSetAccess(v->base + v->mapped, piece, &acc, 1);
+      if (e != hipSuccess) (void)hipMemUnmap(v->base + v->mapped, piece);
+    }
+    if (e != hipSuccess) {
+      (void)hipMemRelease(h);
+      (void)hipGetLastError();
+      rarc_set_error("rarc_vmem_grow: mapping a slab at offset %zu failed: %s", v->mapped, hipGetErrorString(e));
+      return RARC_E_HIP;
+    }
+    try {
+      v->slabs.push_back(RarcVmemSlab{h, piece});
+    } catch (const std::bad_alloc&) {
+      (void)hipMemUnmap(v->base + v->mapped, piece);
+      (void)hipMemRelease(h);
+      rarc_set_error("rarc_vmem_grow: out of host memory");
+      return RARC_E_INVALID;
+    }
+    v->mapped += piece;
+  }
+  return RARC_OK;
+}
+
+extern "C" void* rarc_vmem_base(const RarcVmem* v) { return v ? (void*)v->base : nullptr; }
+extern "C" size_t rarc_vmem_mapped(const RarcVmem* v) { return v ? v->mapped : 0; }
+extern "C" size_t rarc_vmem_reserved(const RarcVmem* v) { return v ? v->reserved : 0; }
+extern "C" size_t rarc_vmem_slab(const RarcVmem* v) { return v ? v->slab : 0; }
+
+// Unmap and release every slab, free the address range.  The caller makes sure no kernel still reads the arena.
+extern "C" int rarc_vmem_destroy(RarcVmem* v) {
+  if (!v) return RARC_OK;
+  int rc = RARC_OK;
+  size_t at = 0;
+  for (const RarcVmemSlab& sl : v->slabs) {
+    if (hipMemUnmap(v->base + at, sl.bytes) != hipSuccess) rc = RARC_E_HIP;
+    if (hipMemRelease(sl.handle) != hipSuccess) rc = RARC_E_HIP;
+    at += sl.bytes;
+  }
+  if (hipMemAddressFree(v->base, v->reserved) != hipSuccess) rc = RARC_E_HIP;
+  if (rc != RARC_OK) {
+    (void)hipGetLastError();
+    rarc_set_error("rarc_vmem_destroy: releasing the arena failed");
+  }
+  delete v;
+  return rc;
+}

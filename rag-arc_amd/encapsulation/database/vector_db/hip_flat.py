@@ -18,12 +18,13 @@ import numpy as np
 
 from ....core.utils.data_model import Document
 from .base import VectorStore
+from .docstore import ColumnarDocstore, rows_from_dicts
 
 
-def _default_engine(dim: int, metric: str, device: int, storage: str = "f16"):
+def _default_engine(dim: int, metric: str, device: int, storage: str = "f16", **engine_kwargs):
     from ....hip.engine import FlatIndexF16
 
-    return FlatIndexF16(dim, metric=metric, device=device, storage=storage)
+    return FlatIndexF16(dim, metric=metric, device=device, storage=storage, **engine_kwargs)
 
 
 def _mmr_select(scored, embeddings, query_embedding, k, lambda_mult=0.5):
@@ -109,8 +110,18 @@ class _QueryCoalescer:
                 for it, (sc, rows) in zip(batch, results):
                     it.result = (sc[: it.k], rows[: it.k])
             except BaseException as exc:  # noqa: BLE001 - every waiter of the batch must learn of it
-                for it in batch:
-                    it.error = exc
+                if len(batch) == 1 or not isinstance(exc, Exception):
+                    for it in batch:
+                        it.error = exc
+                else:
+                    # one caller's bad query (an unknown text, a vector of the wrong width) must fail THAT caller only, as
+                    # it would have without the coalescer: the batch is answered again, one query per launch
+                    for it in batch:
+                        try:
+                            sc, rows = self.run_batch([it.payload], it.k)[0]
+                            it.result = (sc[: it.k], rows[: it.k])
+                        except BaseException as exc_one:  # noqa: BLE001
+                            it.error = exc_one
             finally:
                 with self.cv:
                     self.launches += 1
@@ -129,8 +140,14 @@ class _QueryCoalescer:
 class HipFlatVectorStore(VectorStore):
     def __init__(self, embedding, metric: str = "cosine", normalize_L2: bool = False, index_type: str = "flat",
                  device: int = 0, engine_factory: Optional[Callable] = None, storage: str = "f16",
-                 coalesce: bool = True, coalesce_window_us: float = 0.0, **kwargs: Any):
+                 coalesce: bool = True, coalesce_window_us: float = 0.0, capacity: int = 0, max_rows: int = 0,
+                 growable: Optional[bool] = None, **kwargs: Any):
         super().__init__(**kwargs)
+        # row storage of the default engine (hip/engine.py): `capacity` rows backed right away, `growable` = rows in a
+        # virtual-memory arena that grows in place up to `max_rows` (0 = what the device could hold) — appending never
+        # copies the rows already there (the reference's index.add, VectorStore_Faiss.py:199-202, grows a std::vector)
+        self._engine_kwargs = {key: v for key, v in (("capacity", int(capacity)), ("max_rows", int(max_rows)),
+                                                     ("growable", growable)) if v}
         # concurrent one-query callers (the reference's only calling pattern) share scans: see _QueryCoalescer
         self._coalescer = (_QueryCoalescer(self._run_query_batch, 256, coalesce_window_us * 1e-6) if coalesce else None)
         if storage not in ("f16", "f8", "f32"):
@@ -148,6 +165,12 @@ class HipFlatVectorStore(VectorStore):
         self.index = None  # created on first add, like the reference
         self.docstore: dict = {}
         self.index_to_docstore_id: dict = {}
+        # row -> Document as a SEQUENCE (docstore.py): what a whole answer is mapped through in one native call.  A list of
+        # the very objects the two dicts above hold, rebuilt from them whenever it may have fallen behind (a re-used id,
+        # dicts assigned from outside); or a ColumnarDocstore for corpus-scale stores (adopt()), the dicts then stay empty
+        self._row_docs = []
+        self._row_docs_stale = False
+        self.timing: Optional[dict] = None   # set to {} to have the batch entry points add up their host-side phases (bench.py)
 
     # ------------------------------------------------------------------ helpers
     def _engine_metric(self) -> str:
@@ -178,10 +201,48 @@ class HipFlatVectorStore(VectorStore):
             self.index = self._make_engine(vectors.shape[1])
         start = self.index.ntotal
         self.index.add(vectors)
-        for i, (text, meta, doc_id) in enumerate(zip(texts, metadatas, ids)):
-            self.docstore[doc_id] = Document(content=text, metadata=meta, id=doc_id)
-            self.index_to_docstore_id[start + i] = doc_id
+        self._remember(start, texts, metadatas, ids)
         return list(ids)
+
+    def _remember(self, start: int, texts, metadatas, ids) -> None:
+        """docstore + index_to_docstore_id entries of rows start.. (VectorStore_Faiss.py:205-208), and the row list."""
+        if isinstance(self._row_docs, ColumnarDocstore):
+            raise ValueError("this store holds a columnar (read-only) docstore: it cannot be added to")
+        rows_ok = not self._row_docs_stale and len(self._row_docs) == start
+        for i, (text, meta, doc_id) in enumerate(zip(texts, metadatas, ids)):
+            if doc_id in self.docstore:
+                rows_ok = False          # an id used again: its EARLIER rows now answer with the new Document too
+            doc = self.docstore[doc_id] = Document(content=text, metadata=meta, id=doc_id)
+            self.index_to_docstore_id[start + i] = doc_id
+            if rows_ok:
+                self._row_docs.append(doc)
+        self._row_docs_stale = not rows_ok
+
+    def _docs_by_row(self):
+        """The row-indexed docstore sequence, brought up to date with the dicts if need be."""
+        seq = self._row_docs
+        if isinstance(seq, list) and (self._row_docs_stale or len(seq) != len(self.index_to_docstore_id)):
+            seq = self._row_docs = rows_from_dicts(self.docstore, self.index_to_docstore_id)
+            self._row_docs_stale = False
+        return seq
+
+    def adopt(self, index, row_docs) -> "HipFlatVectorStore":
+        """Corpus-scale construction: take an engine whose rows are already in HBM (loaded from a shard file, generated,
+        ingested in slabs) together with the row-indexed docstore of those rows (a list of Documents or a
+        ColumnarDocstore).  The reference has no counterpart — its only way in is add_texts (VectorStore_Faiss.py:156-210)."""
+        if len(row_docs) != index.ntotal:
+            raise ValueError(f"{len(row_docs)} documents for {index.ntotal} rows")
+        self.index = index
+        self.docstore, self.index_to_docstore_id = {}, {}
+        if isinstance(row_docs, ColumnarDocstore):
+            self._row_docs = row_docs
+        else:
+            self._row_docs = list(row_docs)
+            for r, d in enumerate(self._row_docs):
+                self.docstore[d.id] = d
+                self.index_to_docstore_id[r] = d.id
+        self._row_docs_stale = False
+        return self
 
     # ------------------------------------------------------------------ search
     def similarity_search(self, query: str, k: int = 4, **kwargs: Any) -> List[Document]:
@@ -211,12 +272,20 @@ class HipFlatVectorStore(VectorStore):
         return self._to_documents(scores, rows)
 
     def _to_documents(self, scores, rows) -> List[Tuple[Document, float]]:
-        out = []
-        for score, row in zip(scores, rows):
-            if row == -1:
-                continue
-            out.append((self.docstore[self.index_to_docstore_id[int(row)]], float(score)))
-        return out
+        """[(Document, float(score))] of one query's answer, row -1 skipped (VectorStore_Faiss.py:265-272)."""
+        return self._map_batch(np.asarray(scores)[None, :], np.asarray(rows)[None, :], True)[0]
+
+    def _map_batch(self, scores, rows, with_scores: bool):
+        """A whole answer (scores fp32 [nq][k], rows int64 [nq][k]) -> per query [(Document, float)] or [Document], in one
+        native call over the row-indexed docstore (csrc/hostmap.c)."""
+        from ....hip import hostmap
+
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        nq, k = rows.shape
+        seq = self._docs_by_row()
+        if with_scores:
+            return hostmap.load().rows_to_pairs(seq, rows, np.ascontiguousarray(scores, dtype=np.float32), nq, k)
+        return hostmap.load().rows_to_docs(seq, rows, nq, k)
 
     # -- batches: many queries, one scan (extension over the reference, which only has nq = 1) ----------------------
     def _batch_embedder(self) -> Optional[Callable]:
@@ -240,31 +309,75 @@ class HipFlatVectorStore(VectorStore):
         scores, rows = self.index.search(q, min(k, self.ntotal))
         return list(zip(scores, rows))
 
+    def _search_chunks(self, q, k: int):
+        """(scores fp32 [n][k], rows int64 [n][k]) numpy pairs, one per 256 queries of q (device tensor or array), in order.
+        Chunk i+1 is on the GPU while chunk i is collected, copied out (pinned) and — in the caller — mapped to Documents."""
+        idx = self.index
+        k = min(int(k), self.ntotal)
+        if not hasattr(idx, "search_async"):            # an engine with the numpy surface only
+            yield idx.search(q, k)
+            return
+        step, pending = 256, None
+        for s0 in range(0, len(q), step):
+            nxt = idx.search_async(q[s0:s0 + step], k)
+            if pending is not None:
+                yield pending.host()
+            pending = nxt
+        if pending is not None:
+            yield pending.host()
+
+    def _embed_batch(self, queries: List[str]):
+        """Query texts -> vectors: a device tensor when the provider can keep them in HBM, else a float32 array."""
+        if hasattr(self.embedding, "embed_queries_device"):
+            return self.embedding.embed_queries_device(queries)
+        if hasattr(self.embedding, "embed_queries"):
+            return np.asarray(self.embedding.embed_queries(queries), dtype=np.float32)
+        return np.asarray([self.embedding.embed_query(t) for t in queries], dtype=np.float32)
+
+    def _tick(self, key: str, t0: float) -> float:
+        """Add the time since t0 to self.timing[key] (when a caller asked for the breakdown); returns now."""
+        import time
+
+        now = time.perf_counter()
+        if self.timing is not None:
+            self.timing[key] = self.timing.get(key, 0.0) + (now - t0)
+        return now
+
     def batch_search_by_vector(self, embeddings, k: int = 4):
-        """Many query vectors in one scan.  Returns (scores fp32 [nq][k], row indices int64 [nq][k])."""
+        """Many query vectors, one scan per 256.  Returns (scores fp32 [nq][k], row indices int64 [nq][k])."""
         if self.ntotal == 0:
             nq = len(embeddings)
             return np.zeros((nq, 0), np.float32), np.zeros((nq, 0), np.int64)
         q = embeddings if hasattr(embeddings, "is_cuda") else np.asarray(embeddings, dtype=np.float32)
-        return self.index.search(q, min(k, self.ntotal))
+        parts = list(self._search_chunks(q, k))
+        if len(parts) == 1:
+            return parts[0]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
 
-    def batch_similarity_search_with_score(self, queries: Sequence[str], k: int = 4, **kwargs: Any):
-        """similarity_search_with_score for a list of queries: one encoder call (when the provider can batch), one scan per
-        256 queries.  Element i equals similarity_search_with_score(queries[i], k)."""
+    def _batch_answers(self, queries: Sequence[str], k: int, with_scores: bool):
+        import time
+
         queries = list(queries)
         if self.ntotal == 0 or not queries:
             return [[] for _ in queries]
-        if hasattr(self.embedding, "embed_queries_device"):
-            q = self.embedding.embed_queries_device(queries)
-        elif hasattr(self.embedding, "embed_queries"):
-            q = np.asarray(self.embedding.embed_queries(queries), dtype=np.float32)
-        else:
-            q = np.asarray([self.embedding.embed_query(t) for t in queries], dtype=np.float32)
-        scores, rows = self.batch_search_by_vector(q, k)
-        return [self._to_documents(s, r) for s, r in zip(scores, rows)]
+        t0 = time.perf_counter()
+        q = self._embed_batch(queries)
+        t0 = self._tick("embed_s", t0)
+        out: list = []
+        for scores, rows in self._search_chunks(q, k):
+            t0 = self._tick("search_s", t0)          # launch + wait + pinned copy-out (the next chunk is already scanning)
+            out.extend(self._map_batch(scores, rows, with_scores))
+            t0 = self._tick("map_s", t0)
+        return out
+
+    def batch_similarity_search_with_score(self, queries: Sequence[str], k: int = 4, **kwargs: Any):
+        """similarity_search_with_score for a list of queries: one encoder call (when the provider can batch), one scan per
+        256 queries, each scan running while the answer before it becomes Documents.  Element i equals
+        similarity_search_with_score(queries[i], k)."""
+        return self._batch_answers(queries, k, True)
 
     def batch_similarity_search(self, queries: Sequence[str], k: int = 4, **kwargs: Any) -> List[List[Document]]:
-        return [[d for d, _ in one] for one in self.batch_similarity_search_with_score(queries, k, **kwargs)]
+        return self._batch_answers(queries, k, False)
 
     @property
     def coalesced_launches(self) -> Tuple[int, int]:
@@ -293,7 +406,8 @@ class HipFlatVectorStore(VectorStore):
         qv32 = np.array([embedding]).astype(np.float32)
         scores, rows = self.index.search(qv32, min(fetch_k, self.ntotal))
         keep = [(float(sc), int(r)) for sc, r in zip(scores[0], rows[0]) if r != -1]
-        scored = [(self.docstore[self.index_to_docstore_id[r]], sc) for sc, r in keep]
+        by_row = self._docs_by_row()
+        scored = [(by_row[r], sc) for sc, r in keep]
         if not scored:
             return []
         if not reembed and getattr(self.index, "lib", None) is not None:
@@ -374,6 +488,9 @@ class HipFlatVectorStore(VectorStore):
         return True
 
     def get_by_ids(self, ids: List[str]) -> List[Document]:
+        if isinstance(self._row_docs, ColumnarDocstore):
+            rows = [self._row_docs.row_of(i) for i in ids]
+            return [self._row_docs[r] for r in rows if r is not None]
         return [self.docstore[i] for i in ids if i in self.docstore]
 
     def _select_relevance_score_fn(self):
@@ -384,6 +501,8 @@ class HipFlatVectorStore(VectorStore):
         raise ValueError(f"unsupported metric: {self.metric}")
 
     def _make_engine(self, dim: int):
+        if self._engine_factory is _default_engine:
+            return _default_engine(dim, self._engine_metric(), self.device, self.storage, **self._engine_kwargs)
         if self.storage == "f16":  # (custom factories keep their three-argument signature)
             return self._engine_factory(dim, self._engine_metric(), self.device)
         return self._engine_factory(dim, self._engine_metric(), self.device, self.storage)
@@ -431,6 +550,8 @@ class HipFlatVectorStore(VectorStore):
             meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
                     "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2,
                     "storage": self.storage, "world": world, "ntotal": self.ntotal,
+                    # a columnar docstore travels as its columns (the dicts above are empty then)
+                    "row_docs": self._row_docs if isinstance(self._row_docs, ColumnarDocstore) else None,
                     # what the searches so far have taught the index about this corpus (engine: sticky candidate capacity)
                     "cand_cap": int(getattr(self._local_engine(), "cand_cap", 0) or 0) if self.index is not None else 0}
             tmp = os.path.join(folder_path, f"{index_name}.pkl.tmp")
@@ -453,6 +574,10 @@ class HipFlatVectorStore(VectorStore):
         store = cls(embedding=embeddings, index_type=meta["index_type"], metric=meta["metric"],
                     normalize_L2=meta["normalize_L2"], **kwargs)
         store.docstore, store.index_to_docstore_id = meta["docstore"], meta["index_to_docstore_id"]
+        if meta.get("row_docs") is not None:
+            store._row_docs = meta["row_docs"]
+        else:
+            store._row_docs_stale = True              # the row list is rebuilt from the dicts at the first search
         saved_world = int(meta.get("world", 1))
         files = [SF.shard_path(folder_path, index_name, r, saved_world) for r in range(saved_world)]
         files = [f for f in files if os.path.exists(f)]

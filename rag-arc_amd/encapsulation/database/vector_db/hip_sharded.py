@@ -99,11 +99,47 @@ class _ShardedIndex:
     def search(self, queries, k: int):
         """(scores fp32 [nq][k], global ids int64 [nq][k]) as numpy, merged over all ranks — identical on every rank."""
         ids, sc = self.exchange.search_device(queries, k)
+        return self._to_host(ids, sc)
+
+    def _to_host(self, ids, sc):
+        if hasattr(self.local, "to_host") and ids.is_cuda:
+            return self.local.to_host(ids, sc)
         return sc.cpu().numpy(), ids.cpu().numpy()
+
+    def search_async(self, queries, k: int):
+        """Enqueue this rank's scan now; `.host()` later runs the exchange (every rank collects its handles in the order
+        it made them: the collectives line up) and returns the merged answer as numpy."""
+        if not hasattr(self.local, "search_async") or self.local.ntotal < k:
+            return _Ready(self.search(queries, k))         # (short shards take the padded synchronous path)
+        return _PendingShard(self, self.local.search_async(queries, k), k)
 
     @property
     def max_norm(self):
         return self.local.max_norm
+
+
+class _Ready:
+    def __init__(self, answer):
+        self.answer = answer
+
+    def host(self):
+        return self.answer
+
+
+class _PendingShard:
+    """A local scan in flight; host() = status check (+ rare repair) -> global ids -> exchange -> numpy."""
+
+    def __init__(self, index: _ShardedIndex, handle, k: int):
+        self.index, self.handle, self.k = index, handle, k
+
+    def host(self):
+        idx, t = self.index, self.index.torch
+        ids, sc = self.handle.result()
+        l2g = idx._global_ids(ids.device)
+        base = int(getattr(idx.local, "id_base", 0))
+        ids = t.where(ids >= 0, l2g[(ids - base).clamp(min=0)], ids)
+        ids, sc = idx.exchange._exchange(ids.contiguous(), sc.contiguous(), self.k)
+        return idx._to_host(ids, sc)
 
 
 class HipShardedFlatVectorStore(HipFlatVectorStore):
@@ -125,7 +161,6 @@ class HipShardedFlatVectorStore(HipFlatVectorStore):
     def add_texts(self, texts, metadatas=None, *, ids=None, **kwargs: Any) -> List[str]:
         import uuid
 
-        from ....core.utils.data_model import Document
         from ....hip.sharded import shard_range
 
         texts = list(texts)
@@ -154,9 +189,7 @@ class HipShardedFlatVectorStore(HipFlatVectorStore):
             vectors = np.zeros((0, self.index.dim), np.float32)
         start = self.index.ntotal
         self.index.add_block(vectors, start + lo, len(texts))
-        for i, (text, meta, doc_id) in enumerate(zip(texts, metadatas, ids)):
-            self.docstore[doc_id] = Document(content=text, metadata=meta, id=doc_id)
-            self.index_to_docstore_id[start + i] = doc_id
+        self._remember(start, texts, metadatas, ids)
         return list(ids)
 
     def max_marginal_relevance_search_by_vector(self, embedding, k: int = 4, fetch_k: int = 20,

@@ -16,6 +16,9 @@ class TableEmbeddings(Embeddings):
         if len(texts) != vectors.shape[0]:
             raise ValueError("texts and vectors differ in length")
         self._table: Dict[str, np.ndarray] = {t: v for t, v in zip(texts, vectors)}
+        self._row: Dict[str, int] = {t: i for i, t in enumerate(texts)}     # (a text listed twice: its last vector, as above)
+        self._vectors = vectors
+        self._device_table = None
         self.dim = int(vectors.shape[1])
 
     @classmethod
@@ -28,3 +31,26 @@ class TableEmbeddings(Embeddings):
 
     def embed_query(self, text: str) -> List[float]:
         return self.embed_documents([text])[0]
+
+    # -- batch forms (what HipFlatVectorStore's batch entry points and its query coalescer look for) --------------------
+    def _rows(self, texts: Sequence[str]) -> List[int]:
+        return [self._row[t.replace("\n", " ")] for t in texts]
+
+    def embed_queries(self, texts: Sequence[str]) -> np.ndarray:
+        """embed_query of every text as one float32 array [n][dim] (no python floats in between)."""
+        return self._vectors[self._rows(texts)]
+
+    def to_device(self, device: int = 0) -> "TableEmbeddings":
+        """Keep the table in HBM: `embed_queries_device` then gathers query vectors there (no H2D per batch)."""
+        import torch
+
+        self._device_table = torch.from_numpy(self._vectors).to(torch.device("cuda", device))
+        self.embed_queries_device = self._embed_queries_device
+        self.embed_documents_device = self._embed_queries_device
+        return self
+
+    def _embed_queries_device(self, texts: Sequence[str]):
+        import torch
+
+        tab = self._device_table
+        return tab[torch.as_tensor(self._rows(texts), dtype=torch.long).to(tab.device, non_blocking=True)]

@@ -28,6 +28,69 @@ def _torch():
     return torch
 
 
+class _DeviceArray:
+    """What torch.as_tensor reads a raw device pointer from (`__cuda_array_interface__`); torch keeps this object — and
+    through it the arena — alive for as long as the tensor's storage lives."""
+
+    def __init__(self, arena, nbytes: int):
+        self.arena = arena
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(arena.base), False),
+                                         "version": 2, "strides": None}
+
+
+class DeviceArena:
+    """A growable HBM buffer on HIP virtual memory (rarc_vmem_*, csrc/vmem.hip): address space reserved up front, backed
+    as it grows, never moved, never copied.  `view(nbytes)` is a uint8 torch tensor over the first nbytes."""
+
+    STEP_MAX = 1 << 30          # growth beyond what is asked: at most this much (= the peak overhead of a growing index)
+
+    def __init__(self, torch, lib, device_index: int, reserve_bytes: int, slab_bytes: int = 0):
+        import ctypes
+
+        self.torch, self.lib, self.device_index = torch, lib, int(device_index)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device_index):
+            B.check(lib.rarc_vmem_create(self.device_index, int(reserve_bytes), int(slab_bytes), ctypes.byref(handle)),
+                    "rarc_vmem_create")
+        self.handle = handle
+        self.base = int(lib.rarc_vmem_base(handle))
+        self.reserved = int(lib.rarc_vmem_reserved(handle))
+
+    @property
+    def mapped(self) -> int:
+        return int(self.lib.rarc_vmem_mapped(self.handle))
+
+    def grow(self, nbytes: int) -> None:
+        """Back at least nbytes; beyond the request a step of mapped/8 (2 MiB .. 1 GiB) so that a stream of small adds
+        maps O(log) + one-per-GiB physical allocations, not one per add."""
+        nbytes = int(nbytes)
+        have = self.mapped
+        if nbytes <= have:
+            return
+        if nbytes > self.reserved:
+            raise B.RarcError(f"the index was created for at most {self.reserved} bytes of rows; {nbytes} asked "
+                              "(give a larger max_rows)")
+        step = min(self.STEP_MAX, max(2 << 20, have // 8))
+        target = min(self.reserved, ((nbytes + step - 1) // step) * step)
+        with self.torch.cuda.device(self.device_index):
+            rc = self.lib.rarc_vmem_grow(self.handle, target)
+            if rc != 0 and self.mapped < nbytes:
+                B.check(rc, "rarc_vmem_grow")       # (a step that did not fit is not an error if the request itself did)
+
+    def view(self, nbytes: int):
+        t = self.torch
+        return t.as_tensor(_DeviceArray(self, nbytes), device=t.device("cuda", self.device_index))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.torch.cuda.synchronize(self.device_index)      # no kernel may still be reading what gets unmapped
+                self.lib.rarc_vmem_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001 - interpreter shutdown: the driver reclaims the memory with the process
+            pass
+
+
 class FlatIndexF16:
     """Exact top-k inner-product search over fp16 (or, with storage="f8", fp8 e4m3fn + per-row scale)
     rows resident in HBM.
@@ -37,9 +100,11 @@ class FlatIndexF16:
     fp32 query with the stored fp16 rows; ties are ordered by id ascending.
     """
 
+    GROWABLE_DEFAULT = False
+
     def __init__(self, dim: int, metric: str = "cosine", device: int = 0, capacity: int = 0,
                  id_base: int = 0, cand_cap: int = 131072, scan: str = "auto", storage: str = "f16",
-                 shadow: bool = False):
+                 shadow: bool = False, growable: Optional[bool] = None, max_rows: int = 0):
         if metric not in ("cosine", "ip"):
             raise ValueError(f"unsupported metric: {metric}")
         if dim <= 0:
@@ -88,6 +153,13 @@ class FlatIndexF16:
         self._version = 0          # bumped by every change of the rows (twin() contexts check it)
         self._parent = None        # twin(): the index whose rows this search context reads
         self._own_stream = None    # twin(): the side stream its searches are enqueued on
+        # growable=True: the row buffers live in DeviceArenas (HIP virtual memory) — add() past the capacity maps more
+        # memory behind the same pointer instead of allocating a bigger buffer and copying (peak = live rows + one step
+        # of at most 1 GiB; the reallocating form peaks at 3x).  max_rows: the address space to reserve (0 = what the
+        # device's whole memory could hold); capacity: rows to back right away.
+        self.growable = self.GROWABLE_DEFAULT if growable is None else bool(growable)
+        self.max_rows = int(max_rows)
+        self._arenas: dict = {}
         if capacity:
             self.reserve(capacity)
 
@@ -96,6 +168,10 @@ class FlatIndexF16:
         t = self.torch
         cap = ((int(n_rows) + _ROW_ALIGN - 1) // _ROW_ALIGN) * _ROW_ALIGN
         if self._rows is not None and self._rows.shape[0] >= cap:
+            return
+        if self.growable:
+            self._reserve_arenas(cap)
+            self._fit_qmeta()
             return
         new = t.zeros((cap, self.d_pad), dtype=self._row_dtype(), device=self.device)
         if self._rows is not None and self.ntotal:
@@ -117,6 +193,60 @@ class FlatIndexF16:
                 ni[: self.ntotal].copy_(self._image16[: self.ntotal])
             self._image16 = ni
         self._fit_qmeta()
+
+    def _arena_view(self, name: str, row_bytes: int, cap: int, dtype, cols: Optional[int]):
+        """Grow arena `name` to cap rows of row_bytes each and return (tensor [rows][cols] or [rows], rows backed).  A buffer
+        that did not come from the arena (rows adopted by add_rows_f16) is copied into it once."""
+        t = self.torch
+        arena = self._arenas.get(name)
+        if arena is None:
+            max_rows = self.max_rows or int(t.cuda.get_device_properties(self.device).total_memory // max(row_bytes, 1))
+            max_rows = max(((max_rows + _ROW_ALIGN - 1) // _ROW_ALIGN) * _ROW_ALIGN, cap)
+            arena = self._arenas[name] = DeviceArena(t, self.lib, self.device.index or 0, max_rows * row_bytes)
+        old_mapped = arena.mapped
+        arena.grow(cap * row_bytes)
+        rows = (arena.mapped // (row_bytes * _ROW_ALIGN)) * _ROW_ALIGN          # whole 32-row tiles of what is backed
+        flat = arena.view(rows * row_bytes)
+        if arena.mapped > old_mapped:       # fresh memory reads as zeros (padding rows and columns rely on it)
+            flat[old_mapped:].zero_()
+        out = flat.view(dtype)
+        return (out.view(rows, cols) if cols else out), rows
+
+    def _reserve_arenas(self, cap: int) -> None:
+        t = self.torch
+        esz = {"f8": 1, "f16": 2, "f32": 4}[self.storage]
+
+        def adopt(name, row_bytes, dtype, cols, current):
+            new, _ = self._arena_view(name, row_bytes, cap, dtype, cols)
+            if current is not None and current.data_ptr() != new.data_ptr() and self.ntotal:
+                new[: self.ntotal].copy_(current[: self.ntotal])
+            return new
+
+        self._rows = adopt("rows", self.d_pad * esz, self._row_dtype(), self.d_pad, self._rows)
+        if self.shadow:
+            self._shadow = adopt("shadow", self.d_pad, t.int8, self.d_pad, self._shadow)
+        if self.storage == "f8":
+            had = 0 if self._rowscale is None else max(int(self._rowscale.shape[0]), self.ntotal)
+            from_arena = "rowscale" in self._arenas
+            self._rowscale = adopt("rowscale", 4, t.float32, None, self._rowscale)
+            self._rowscale[(had if from_arena else self.ntotal):].fill_(1.0)     # rows not yet written: scale 1, as t.ones() gave
+        if self.storage == "f32":
+            self._image16 = adopt("image16", self.d_pad * 2, t.float16, self.d_pad, self._image16)
+        # every buffer must cover the same rows: the smallest backing decides (they grow in proportion, so this is `cap`
+        # rounded up to the coarsest step)
+        n = min(x.shape[0] for x in (self._rows, self._shadow, self._rowscale, self._image16) if x is not None)
+        self._rows = self._rows[:n]
+
+    def memory_bytes(self) -> dict:
+        """HBM held by the row buffers: {'live': bytes of the stored rows, 'backed': bytes physically mapped / allocated}."""
+        esz = {"f8": 1, "f16": 2, "f32": 4}[self.storage]
+        per_row = self.d_pad * esz + (self.d_pad if self.shadow else 0) + (4 if self.storage == "f8" else 0) \
+            + (2 * self.d_pad if self.storage == "f32" else 0)
+        if self._arenas:
+            backed = sum(a.mapped for a in self._arenas.values())
+        else:
+            backed = 0 if self._rows is None else int(self._rows.shape[0]) * per_row
+        return {"live": int(self.ntotal) * per_row, "backed": int(backed)}
 
     def _row_dtype(self):
         t = self.torch
@@ -472,7 +602,22 @@ class FlatIndexF16:
         """index.search: returns (scores fp32 [nq][k], ids int64 [nq][k]) like faiss (D, I);
         entries beyond ntotal are (-inf, -1)."""
         ids, scores = self.search_device(queries, k, repair=repair)
-        return scores.cpu().numpy(), ids.cpu().numpy()
+        return self.to_host(ids, scores)
+
+    def to_host(self, ids, scores) -> Tuple[np.ndarray, np.ndarray]:
+        """A device answer as numpy (scores fp32 [nq][k], ids int64 [nq][k]): both copies go to pinned memory behind the
+        search on its stream and ONE event is waited for (two pageable `.cpu()` calls are two synchronous staged copies).
+        The arrays own their pinned block (torch's caching host allocator recycles it when they die)."""
+        t = self.torch
+        with t.cuda.device(self.device):
+            h_i = t.empty(tuple(ids.shape), dtype=t.int64, pin_memory=True)
+            h_s = t.empty(tuple(scores.shape), dtype=t.float32, pin_memory=True)
+            h_i.copy_(ids, non_blocking=True)
+            h_s.copy_(scores, non_blocking=True)
+            done = t.cuda.Event()
+            done.record()
+            done.synchronize()
+        return h_s.numpy(), h_i.numpy()
 
     def search_device(self, queries, k: int, repair: bool = True):
         """Same as search() but returns device tensors (ids int64, scores fp32)."""
@@ -856,6 +1001,13 @@ class PendingSearch:
             self.index.last_repaired = self.repaired
         return self.ids, self.scores
 
+    def host(self):
+        """result() as numpy (scores fp32 [nq][k], ids int64 [nq][k]) through pinned memory (FlatIndexF16.to_host)."""
+        ids, scores = self.result()
+        t = self.index.torch
+        with t.cuda.stream(self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)):
+            return self.index.to_host(ids, scores)
+
 
 class PendingBatches:
     """search_async over more than 256 queries: one PendingSearch per 256-query launch, one result."""
@@ -872,3 +1024,10 @@ class PendingBatches:
                 self.repaired += [i * B.MAX_QUERIES + r for r in p.repaired]
             self.parts[0].index.last_repaired = self.repaired
         return self.ids, self.scores
+
+    def host(self):
+        ids, scores = self.result()
+        p = self.parts[0]
+        t = p.index.torch
+        with t.cuda.stream(p.stream if p.stream is not None else t.cuda.current_stream(p.index.device)):
+            return p.index.to_host(ids, scores)

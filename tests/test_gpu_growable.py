@@ -1,0 +1,157 @@
+"""Row storage that grows in place: `index.add` in the reference appends to a std::vector
+(VectorStore_Faiss.py:199-202); here the rows live in HIP virtual-memory arenas (csrc/vmem.hip) — address space reserved
+up front, physical memory mapped behind the same pointer as rows arrive, nothing copied.
+
+* small: a growable index fed in ragged steps answers exactly as the oracle (and as a reallocating index) after every
+  step, for every storage format; the base pointer never moves; backed memory tracks the live rows;
+* corpus scale (skipped under 200 GB of free HBM): one index grown by repeated `add` from nothing past 60 % of the free
+  HBM; the device's used memory never exceeds the live rows + one growth step (1 GiB) + the fixed staging of the test;
+  after every growth step the answers are exact (exhaustive device re-scan) and the rows they name, regenerated and
+  ingested by the ORACLE, score to the same bits; save_local / load_local unchanged.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    from rag_arc_amd.hip import engine
+
+    return engine
+
+
+def _oracle_search(oracle, storage, X, Q, k):
+    qn = oracle.normalize_L2(Q)
+    if storage == "f16":
+        rows, _ = oracle.ingest_f16(X)
+        I, D, _ = oracle.flat_search_f16(rows, qn, k)
+    elif storage == "f8":
+        rows, scales, _ = oracle.ingest_f8(X)
+        I, D = oracle.flat_search_f8(rows, scales, qn, k)[:2]
+    else:
+        rows = oracle.ingest_f32(X)[0]
+        I, D = oracle.flat_search_f32(rows, qn, k)[:2]
+    return I, D
+
+
+@pytest.mark.parametrize("storage,dim", [("f16", 384), ("f8", 520), ("f32", 200)])
+def test_growable_index_equals_oracle_after_every_add(hip, oracle, storage, dim):
+    rng = np.random.default_rng(11)
+    steps = [1, 31, 1000, 40_000, 7, 90_000]
+    X = rng.standard_normal((sum(steps), dim)).astype(np.float32)
+    Q = rng.standard_normal((12, dim)).astype(np.float32)
+    grow = hip.FlatIndexF16(dim, metric="cosine", storage=storage, growable=True, max_rows=200_000)
+    plain = hip.FlatIndexF16(dim, metric="cosine", storage=storage, growable=False)
+    at, base = 0, None
+    for n in steps:
+        grow.add(X[at:at + n])
+        plain.add(X[at:at + n])
+        at += n
+        base = base or grow.rows.data_ptr()
+        assert grow.rows.data_ptr() == base, "the rows moved"
+        k = min(10, at)
+        D, I = grow.search(Q, k)
+        D2, I2 = plain.search(Q, k)
+        ref_I, ref_D = _oracle_search(oracle, storage, X[:at], Q, k)
+        assert np.array_equal(I, ref_I) and np.array_equal(D.view(np.uint32), ref_D.view(np.uint32)), (storage, at)
+        assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
+        mem = grow.memory_bytes()
+        assert mem["live"] <= mem["backed"] <= mem["live"] + len(grow._arenas) * max(4 << 20, mem["live"] // 4), mem
+    with pytest.raises(hip.B.RarcError):
+        grow.add(X[:70_000])                      # past max_rows: refused, nothing lost
+    D3, I3 = grow.search(Q, 10)
+    assert np.array_equal(I3, I) and np.array_equal(D3.view(np.uint32), D.view(np.uint32))
+
+
+def test_adopted_rows_move_into_the_arena_on_first_growth(hip, oracle):
+    import torch
+
+    d, n = 256, 4096
+    rows16 = torch.from_numpy(oracle.synth_rows_f16(n, d).view(np.float16)).cuda()
+    idx = hip.FlatIndexF16(d, metric="cosine", growable=True, max_rows=20_000)
+    idx.add_rows_f16(rows16, 1.001)               # adopted without a copy: not arena memory yet
+    more = oracle.synth_rows_f32(3000, d, first_row=n, seed=1234)
+    idx.add(more)
+    assert idx._arenas and idx.rows.data_ptr() == idx._arenas["rows"].base
+    both = np.concatenate([oracle.synth_rows_f16(n, d), oracle.ingest_f16(more)[0]])
+    Q = oracle.synth_rows_f32(5, d)
+    ref_I, ref_D, _ = oracle.flat_search_f16(both, oracle.normalize_L2(Q), 20)
+    D, I = idx.search(Q, 20)
+    assert np.array_equal(I, ref_I) and np.array_equal(D.view(np.uint32), ref_D.view(np.uint32))
+
+
+def test_growable_store_through_the_config(hip, tmp_path):
+    """`capacity` / `max_rows` / `growable` reach the engine through HipFlatVectorStoreConfig; save / load unchanged."""
+    from rag_arc_amd.config.modules import HipFlatVectorStoreConfig
+    from tests.helpers import HashEmbeddings
+
+    texts = [f"grown note {i}" for i in range(3000)]
+    np.savez(tmp_path / "emb.npz", texts=np.array(texts), vectors=np.asarray(HashEmbeddings(96).embed_documents(texts), dtype=np.float32))
+    cfg = HipFlatVectorStoreConfig(embedding={"type": "table_embeddings", "path": str(tmp_path / "emb.npz")},
+                                   growable=True, capacity=1000, max_rows=50_000)
+    store = cfg.build().impl
+    store.add_texts(texts[:900], ids=[f"g{i}" for i in range(900)])
+    eng = store.index
+    assert eng.growable and eng.rows.data_ptr() == eng._arenas["rows"].base and eng._rows.shape[0] >= 1000
+    base = eng.rows.data_ptr()
+    store.add_texts(texts[900:], ids=[f"g{i}" for i in range(900, 3000)])
+    assert eng.rows.data_ptr() == base and store.ntotal == 3000
+    before = [(d.id, s) for d, s in store.similarity_search_with_score(texts[1234], k=7)]
+    assert before[0][0] == "g1234"
+    store.save_local(str(tmp_path / "saved"))
+    again = type(store).load_local(str(tmp_path / "saved"), store.embedding, growable=True, max_rows=50_000)
+    assert [(d.id, s) for d, s in again.similarity_search_with_score(texts[1234], k=7)] == before
+
+
+def test_grow_past_60_percent_of_hbm_without_a_transient(hip, oracle):
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+
+    free0, total = torch.cuda.mem_get_info()
+    if free0 < 200 * (1 << 30):
+        pytest.skip("needs 200 GB of free HBM")
+    lib = B.load_library()
+    d, slab, k = 768, 2_000_000, 50
+    target_rows = int(0.62 * free0 / (d * 2))
+    buf = torch.empty((slab, d), dtype=torch.float32, device="cuda")          # the test's own staging (6 GB), allocated first
+    idx = hip.FlatIndexF16(d, metric="cosine", growable=True, scan="q8")
+    Q = torch.from_numpy(oracle.synth_rows_f32(8, d)).cuda()
+    torch.cuda.synchronize()
+    used0 = total - torch.cuda.mem_get_info()[0]
+    peak_over, checks, at = 0, 0, 0
+    next_check = 4_000_000
+    while at < target_rows:
+        m = min(slab, target_rows - at)
+        B.check(lib.rarc_synth_rows_f32(buf.data_ptr(), d, d, at, m, 1234, 0), "rarc_synth_rows_f32")
+        idx.add(buf[:m])
+        at += m
+        torch.cuda.synchronize()
+        used = total - torch.cuda.mem_get_info()[0] - used0
+        live = idx.memory_bytes()["live"]
+        # what the index holds beyond its live rows: one growth step + the metadata (8 B per 32-row tile) + the search scratch
+        peak_over = max(peak_over, used - live)
+        if at >= next_check or at >= target_rows:
+            next_check = at * 2
+            ids, sc = idx.search_device(Q, k)
+            assert idx.verify_batch(Q, ids, sc) == 0, f"inexact answer at {at} rows"
+            ids_h, sc_h = ids.cpu().numpy(), sc.cpu().numpy()
+            qn = oracle.normalize_L2(Q.cpu().numpy())
+            for qi in (0, 7):
+                for j in (0, k // 2, k - 1):
+                    rid = int(ids_h[qi, j])
+                    row = oracle.ingest_f16(oracle.synth_rows_f32(1, d, first_row=rid, seed=1234))[0]
+                    want = oracle.score_rows_f16(row, qn[qi], np.array([0]))
+                    assert want.view(np.uint32)[0] == sc_h[qi, j:j + 1].view(np.uint32)[0], (at, qi, j)
+            checks += 1
+    assert idx.ntotal == target_rows and idx.ntotal * d * 2 > 0.6 * free0 and checks >= 4
+    # live rows + ONE step (1 GiB) + metadata + the search workspace (~0.4 GB) + allocator slack: well under 3 GiB, where a
+    # reallocating buffer would have peaked at twice the live rows
+    assert peak_over < 3 * (1 << 30), f"peak beyond the live rows: {peak_over / 2**30:.2f} GiB"
+    print(f"grown to {idx.ntotal} rows ({idx.ntotal * d * 2 / 2**30:.1f} GiB live), peak beyond live rows "
+          f"{peak_over / 2**30:.2f} GiB, {checks} exactness checks")
