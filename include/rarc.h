@@ -574,7 +574,7 @@ int rarc_device_to_file(const char* path, int n_seg, const int64_t* h_file_off, 
  * a growing index is its live rows rounded up to one slab (a reallocating buffer holds old + new: up to 3x).
  * The second kind of object this library allocates (with the tokenizer handle): release it with rarc_vmem_destroy, after
  * the last kernel that reads it.  slab_bytes (0 = 1 GiB) bounds one physical allocation; sizes are rounded up to the device's
- * mapping granularity (rarc_vmem_slab / _mapped / _reserved report the rounded figures).
+ * mapping granularity (rarc_vmem_slab / _granularity / _mapped / _reserved report the figures in force).
  * rarc_vmem_grow(min_bytes): back at least the first min_bytes (never shrinks; on failure — HBM exhausted — what was
  * mapped stays mapped and usable).  Not tied to a stream: mapping is a host-side operation, visible to later launches.
  */
@@ -585,6 +585,7 @@ void* rarc_vmem_base(const RarcVmem* arena);
 size_t rarc_vmem_mapped(const RarcVmem* arena);
 size_t rarc_vmem_reserved(const RarcVmem* arena);
 size_t rarc_vmem_slab(const RarcVmem* arena);
+size_t rarc_vmem_granularity(const RarcVmem* arena);
 int rarc_vmem_destroy(RarcVmem* arena);
 
 /*

@@ -19,7 +19,87 @@
 
 #define PREFETCH_AHEAD 12
 
-static PyObject *s_content;   /* interned "content" */
+static PyObject *s_content, *s_metadata, *s_id;   /* interned attribute names */
+
+/* The cyclic collector counts container allocations: a 256 x 100 answer allocates tens of thousands of lists / tuples /
+ * Documents in one burst, i.e. dozens of young collections, every tenth of which promotes into — and eventually triggers —
+ * the old generations, whose cost is the size of the PROCESS (a million-Document docstore: 100+ ms).  Nothing allocated
+ * here is cyclic garbage: the collector is held off for the duration of a bulk call (process-wide, microseconds to
+ * milliseconds) and the one young collection that follows sees the survivors once. */
+#define GC_HOLD() int gc_was_on_ = PyGC_Disable()
+#define GC_RELEASE() do { if (gc_was_on_) PyGC_Enable(); } while (0)
+
+/* A ColumnarDocstore (encapsulation/database/vector_db/docstore.py) seen from C: byte columns + offsets; a Document is
+ * built per hit WITHOUT running the dataclass __init__ (object.__new__ + three attribute stores — the same instance
+ * dict; tests/test_hostmap.py compares with Document(content=..., metadata=..., id=...)). */
+typedef struct {
+    PyTypeObject *doc_type;
+    Py_buffer text_blob, text_off, id_blob, id_off;
+    int has_ids;
+    PyObject *metadatas;      /* NULL / None: every document gets a fresh {} */
+    Py_ssize_t n;
+} Columns;
+
+static void columns_release(Columns *c) {
+    if (c->text_blob.obj) PyBuffer_Release(&c->text_blob);
+    if (c->text_off.obj) PyBuffer_Release(&c->text_off);
+    if (c->id_blob.obj) PyBuffer_Release(&c->id_blob);
+    if (c->id_off.obj) PyBuffer_Release(&c->id_off);
+}
+
+/* columns: (Document type, text_blob, text_off, id_blob | None, id_off | None, metadatas | None) */
+static int columns_parse(PyObject *tup, Columns *c) {
+    memset(c, 0, sizeof(*c));
+    PyObject *type_o, *tb, *to, *ib, *io, *md;
+    if (!PyArg_ParseTuple(tup, "OOOOOO", &type_o, &tb, &to, &ib, &io, &md)) return -1;
+    if (!PyType_Check(type_o)) { PyErr_SetString(PyExc_TypeError, "columns[0] must be the Document class"); return -1; }
+    c->doc_type = (PyTypeObject *)type_o;
+    if (PyObject_GetBuffer(tb, &c->text_blob, PyBUF_C_CONTIGUOUS) < 0) goto fail;
+    if (PyObject_GetBuffer(to, &c->text_off, PyBUF_C_CONTIGUOUS) < 0) goto fail;
+    if (c->text_off.len < 8 || c->text_off.len % 8) { PyErr_SetString(PyExc_ValueError, "text offsets: int64 [n + 1]"); goto fail; }
+    c->n = c->text_off.len / 8 - 1;
+    c->has_ids = (ib != Py_None);
+    if (c->has_ids) {
+        if (PyObject_GetBuffer(ib, &c->id_blob, PyBUF_C_CONTIGUOUS) < 0) goto fail;
+        if (PyObject_GetBuffer(io, &c->id_off, PyBUF_C_CONTIGUOUS) < 0) goto fail;
+        if (c->id_off.len != c->text_off.len) { PyErr_SetString(PyExc_ValueError, "one id per text"); goto fail; }
+    }
+    c->metadatas = (md == Py_None) ? NULL : md;
+    return 0;
+fail:
+    columns_release(c);
+    return -1;
+}
+
+static PyObject *column_str(const Py_buffer *blob, const Py_buffer *off, Py_ssize_t row) {
+    const int64_t *o = (const int64_t *)off->buf;
+    if (o[row] < 0 || o[row + 1] < o[row] || o[row + 1] > blob->len) {
+        PyErr_Format(PyExc_ValueError, "row %zd: offsets outside the blob", row);
+        return NULL;
+    }
+    return PyUnicode_DecodeUTF8((const char *)blob->buf + o[row], (Py_ssize_t)(o[row + 1] - o[row]), "strict");
+}
+
+static PyObject *columns_item(const Columns *c, int64_t row) {
+    if (row < 0 || row >= c->n) {
+        PyErr_Format(PyExc_IndexError, "row %lld is outside the docstore (%zd rows)", (long long)row, c->n);
+        return NULL;
+    }
+    PyObject *content = column_str(&c->text_blob, &c->text_off, (Py_ssize_t)row);
+    if (!content) return NULL;
+    PyObject *doc_id, *meta, *doc = NULL;
+    if (c->has_ids) doc_id = column_str(&c->id_blob, &c->id_off, (Py_ssize_t)row);
+    else { doc_id = content; Py_INCREF(doc_id); }
+    meta = c->metadatas ? PySequence_GetItem(c->metadatas, (Py_ssize_t)row) : PyDict_New();
+    if (doc_id && meta) doc = c->doc_type->tp_alloc(c->doc_type, 0);
+    if (doc && (PyObject_SetAttr(doc, s_content, content) < 0 || PyObject_SetAttr(doc, s_metadata, meta) < 0 ||
+                PyObject_SetAttr(doc, s_id, doc_id) < 0))
+        Py_CLEAR(doc);
+    Py_DECREF(content);
+    Py_XDECREF(doc_id);
+    Py_XDECREF(meta);
+    return doc;
+}
 
 static int get_buffer(PyObject *obj, Py_buffer *view, Py_ssize_t itemsize, Py_ssize_t need, const char *what) {
     if (PyObject_GetBuffer(obj, view, PyBUF_C_CONTIGUOUS) < 0) return -1;
@@ -57,11 +137,19 @@ static PyObject *map_rows(PyObject *args, int with_scores) {
     }
     if (nq < 0 || k < 0) { PyErr_SetString(PyExc_ValueError, "negative shape"); return NULL; }
     int is_list = PyList_CheckExact(seq);
-    Py_ssize_t n = is_list ? PyList_GET_SIZE(seq) : PySequence_Size(seq);
+    Columns cols;
+    int is_cols = PyTuple_CheckExact(seq);          /* a ColumnarDocstore's columns (see columns_parse) */
+    if (is_cols && columns_parse(seq, &cols) < 0) return NULL;
+    Py_ssize_t n = is_list ? PyList_GET_SIZE(seq) : (is_cols ? cols.n : PySequence_Size(seq));
     if (n < 0) return NULL;
     Py_buffer rv, sv;
-    if (get_buffer(rows_o, &rv, 8, nq * k, "rows") < 0) return NULL;
-    if (with_scores && get_buffer(scores_o, &sv, 4, nq * k, "scores") < 0) { PyBuffer_Release(&rv); return NULL; }
+    if (get_buffer(rows_o, &rv, 8, nq * k, "rows") < 0) { if (is_cols) columns_release(&cols); return NULL; }
+    if (with_scores && get_buffer(scores_o, &sv, 4, nq * k, "scores") < 0) {
+        PyBuffer_Release(&rv);
+        if (is_cols) columns_release(&cols);
+        return NULL;
+    }
+    GC_HOLD();
     const int64_t *rows = (const int64_t *)rv.buf;
     const float *scores = with_scores ? (const float *)sv.buf : NULL;
     PyObject *out = PyList_New(nq);
@@ -77,8 +165,28 @@ static PyObject *map_rows(PyObject *args, int with_scores) {
                 const int64_t ahead = rows[at + PREFETCH_AHEAD] - base;
                 if (ahead >= 0 && ahead < n) __builtin_prefetch(PyList_GET_ITEM(seq, (Py_ssize_t)ahead), 1, 1);
             }
+            if (is_cols) {          /* the offset of a row, then its bytes: two misses per hit in corpus-sized columns */
+                if (at + PREFETCH_AHEAD < total) {
+                    const int64_t r = rows[at + PREFETCH_AHEAD] - base;
+                    if (r >= 0 && r < n) {
+                        __builtin_prefetch((const int64_t *)cols.text_off.buf + r, 0, 1);
+                        if (cols.has_ids) __builtin_prefetch((const int64_t *)cols.id_off.buf + r, 0, 1);
+                    }
+                }
+                if (at + PREFETCH_AHEAD / 2 < total) {
+                    const int64_t r = rows[at + PREFETCH_AHEAD / 2] - base;
+                    if (r >= 0 && r < n) {
+                        const int64_t o = ((const int64_t *)cols.text_off.buf)[r];
+                        if (o >= 0 && o < cols.text_blob.len) __builtin_prefetch((const char *)cols.text_blob.buf + o, 0, 1);
+                        if (cols.has_ids) {
+                            const int64_t oi = ((const int64_t *)cols.id_off.buf)[r];
+                            if (oi >= 0 && oi < cols.id_blob.len) __builtin_prefetch((const char *)cols.id_blob.buf + oi, 0, 1);
+                        }
+                    }
+                }
+            }
             if (rows[at] == -1) continue;
-            PyObject *doc = seq_item(seq, is_list, n, rows[at] - base);
+            PyObject *doc = is_cols ? columns_item(&cols, rows[at] - base) : seq_item(seq, is_list, n, rows[at] - base);
             if (!doc) goto fail_out;
             PyObject *item = doc;
             if (with_scores) {
@@ -93,14 +201,18 @@ static PyObject *map_rows(PyObject *args, int with_scores) {
             if (rc < 0) goto fail_out;
         }
     }
+    GC_RELEASE();
     PyBuffer_Release(&rv);
     if (with_scores) PyBuffer_Release(&sv);
+    if (is_cols) columns_release(&cols);
     return out;
 fail_out:
     Py_DECREF(out);
 fail:
+    GC_RELEASE();
     PyBuffer_Release(&rv);
     if (with_scores) PyBuffer_Release(&sv);
+    if (is_cols) columns_release(&cols);
     return NULL;
 }
 
@@ -117,6 +229,7 @@ static PyObject *rrf_tables(PyObject *self, PyObject *args) {
     if (!PyArg_ParseTuple(args, "O!nn", &PyList_Type, &batch, &n_lists, &max_len)) return NULL;
     if (n_lists < 0 || max_len < 0) { PyErr_SetString(PyExc_ValueError, "negative shape"); return NULL; }
     const Py_ssize_t nq = PyList_GET_SIZE(batch);
+    GC_HOLD();
     PyObject *keys_b = PyBytes_FromStringAndSize(NULL, nq * n_lists * max_len * 8);
     PyObject *lens_b = PyBytes_FromStringAndSize(NULL, nq * n_lists * 4);
     PyObject *docs = PyList_New(nq);
@@ -144,7 +257,26 @@ static PyObject *rrf_tables(PyObject *self, PyObject *args) {
                 goto fail;
             }
             lens[q * n_lists + l] = (int32_t)PyList_GET_SIZE(one);
-            for (Py_ssize_t p = 0; p < PyList_GET_SIZE(one); ++p) {
+            const Py_ssize_t len = PyList_GET_SIZE(one);
+            for (Py_ssize_t p = 0; p < len; ++p) {
+                /* the documents of an answer are scattered over a corpus-sized heap: every one is a chain of cache misses
+                 * (object -> its dict -> the values array -> the content string).  Walk the chain a few items ahead. */
+                if (p + 12 < len) __builtin_prefetch(PyList_GET_ITEM(one, p + 12), 0, 1);
+                if (p + 8 < len) {
+                    PyObject **dp = _PyObject_GetDictPtr(PyList_GET_ITEM(one, p + 8));
+                    if (dp && *dp) __builtin_prefetch(*dp, 0, 1);
+                }
+                if (p + 5 < len) {
+                    PyObject **dp = _PyObject_GetDictPtr(PyList_GET_ITEM(one, p + 5));
+                    if (dp && *dp && PyDict_CheckExact(*dp) && ((PyDictObject *)*dp)->ma_values)
+                        __builtin_prefetch(((PyDictObject *)*dp)->ma_values, 0, 1);
+                }
+                if (p + 2 < len) {
+                    PyObject **dp = _PyObject_GetDictPtr(PyList_GET_ITEM(one, p + 2));
+                    if (dp && *dp && PyDict_CheckExact(*dp) && ((PyDictObject *)*dp)->ma_values &&
+                        ((PyDictObject *)*dp)->ma_values[0])
+                        __builtin_prefetch(((PyDictObject *)*dp)->ma_values[0], 0, 1);   /* first attribute set: content */
+                }
                 PyObject *doc = PyList_GET_ITEM(one, p);
                 PyObject *content = PyObject_GetAttr(doc, s_content);
                 if (!content) goto fail;
@@ -169,11 +301,13 @@ static PyObject *rrf_tables(PyObject *self, PyObject *args) {
         Py_CLEAR(table);
     }
     {
+        GC_RELEASE();
         PyObject *ret = PyTuple_Pack(3, keys_b, lens_b, docs);
         Py_DECREF(keys_b); Py_DECREF(lens_b); Py_DECREF(docs);
         return ret;
     }
 fail:
+    GC_RELEASE();
     Py_XDECREF(table);
     Py_XDECREF(keys_b); Py_XDECREF(lens_b); Py_XDECREF(docs);
     return NULL;
@@ -235,6 +369,8 @@ static struct PyModuleDef module = {PyModuleDef_HEAD_INIT, "_rarc_hostmap",
 
 PyMODINIT_FUNC PyInit__rarc_hostmap(void) {
     s_content = PyUnicode_InternFromString("content");
-    if (!s_content) return NULL;
+    s_metadata = PyUnicode_InternFromString("metadata");
+    s_id = PyUnicode_InternFromString("id");
+    if (!s_content || !s_metadata || !s_id) return NULL;
     return PyModule_Create(&module);
 }

@@ -109,6 +109,7 @@ extern "C" void* rarc_vmem_base(const RarcVmem* v) { return v ? (void*)v->base :
 extern "C" size_t rarc_vmem_mapped(const RarcVmem* v) { return v ? v->mapped : 0; }
 extern "C" size_t rarc_vmem_reserved(const RarcVmem* v) { return v ? v->reserved : 0; }
 extern "C" size_t rarc_vmem_slab(const RarcVmem* v) { return v ? v->slab : 0; }
+extern "C" size_t rarc_vmem_granularity(const RarcVmem* v) { return v ? v->gran : 0; }
 
 // Unmap and release every slab, free the address range.  The caller makes sure no kernel still reads the arena.
 extern "C" int rarc_vmem_destroy(RarcVmem* v) {

@@ -86,6 +86,10 @@ class ColumnarDocstore:
         meta = {} if self.metadatas is None else self.metadatas[row]
         return Document(content=content, metadata=meta, id=doc_id)
 
+    def columns(self):
+        """What csrc/hostmap.c builds Documents from without calling back into python (see its `Columns`)."""
+        return (Document, self.text_blob, self.text_off, self.id_blob, self.id_off, self.metadatas)
+
     def row_of(self, doc_id: str) -> Optional[int]:
         """Row of the document with this id (None if there is none); builds an id -> row dict on first use."""
         if self._row_of_id is None:

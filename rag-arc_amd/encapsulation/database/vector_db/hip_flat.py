@@ -90,7 +90,8 @@ class _QueryCoalescer:
             self.payload, self.k, self.result, self.error, self.done = payload, k, None, None, False
 
     def submit(self, payload, k: int):
-        """payload: a query text or a query vector; returns (scores fp32 [k], rows int64 [k]) of that query."""
+        """payload: a query text or a query vector; returns that query's [(Document, score)], at most k of them (the
+        leader of a batch turns the whole answer into Documents in one native call: a waiter wakes up to a finished list)."""
         item = self._Item(payload, int(k))
         while True:
             with self.cv:
@@ -107,8 +108,8 @@ class _QueryCoalescer:
                 del self.queue[: self.max_batch]
             try:
                 results = self.run_batch([it.payload for it in batch], max(it.k for it in batch))
-                for it, (sc, rows) in zip(batch, results):
-                    it.result = (sc[: it.k], rows[: it.k])
+                for it, pairs in zip(batch, results):
+                    it.result = pairs[: it.k]
             except BaseException as exc:  # noqa: BLE001 - every waiter of the batch must learn of it
                 if len(batch) == 1 or not isinstance(exc, Exception):
                     for it in batch:
@@ -118,8 +119,7 @@ class _QueryCoalescer:
                     # it would have without the coalescer: the batch is answered again, one query per launch
                     for it in batch:
                         try:
-                            sc, rows = self.run_batch([it.payload], it.k)[0]
-                            it.result = (sc[: it.k], rows[: it.k])
+                            it.result = self.run_batch([it.payload], it.k)[0][: it.k]
                         except BaseException as exc_one:  # noqa: BLE001
                             it.error = exc_one
             finally:
@@ -253,7 +253,7 @@ class HipFlatVectorStore(VectorStore):
             return []
         if self._coalescer is not None and self._batch_embedder() is not None:
             # text goes into the queue: the leader embeds the whole batch in one encoder call, then scans once
-            return self._to_documents(*self._coalescer.submit(query, min(k, self.ntotal)))
+            return self._coalescer.submit(query, min(k, self.ntotal))
         return self.similarity_search_by_vector_with_score(self.embedding.embed_query(query), k, **kwargs)
 
     def similarity_search_by_vector(self, embedding: List[float], k: int = 4, **kwargs: Any) -> List[Document]:
@@ -264,12 +264,10 @@ class HipFlatVectorStore(VectorStore):
             return []
         k = min(k, self.ntotal)
         if self._coalescer is not None:
-            scores, rows = self._coalescer.submit(np.asarray(embedding, dtype=np.float32), k)
-        else:
-            qv = np.array([embedding]).astype(np.float32)
-            scores, rows = self.index.search(qv, k)
-            scores, rows = scores[0], rows[0]
-        return self._to_documents(scores, rows)
+            return self._coalescer.submit(np.asarray(embedding, dtype=np.float32), k)
+        qv = np.array([embedding]).astype(np.float32)
+        scores, rows = self.index.search(qv, k)
+        return self._to_documents(scores[0], rows[0])
 
     def _to_documents(self, scores, rows) -> List[Tuple[Document, float]]:
         """[(Document, float(score))] of one query's answer, row -1 skipped (VectorStore_Faiss.py:265-272)."""
@@ -283,6 +281,8 @@ class HipFlatVectorStore(VectorStore):
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         nq, k = rows.shape
         seq = self._docs_by_row()
+        if isinstance(seq, ColumnarDocstore):
+            seq = seq.columns()
         if with_scores:
             return hostmap.load().rows_to_pairs(seq, rows, np.ascontiguousarray(scores, dtype=np.float32), nq, k)
         return hostmap.load().rows_to_docs(seq, rows, nq, k)
@@ -294,7 +294,7 @@ class HipFlatVectorStore(VectorStore):
         return getattr(self.embedding, "embed_queries_device", None) or getattr(self.embedding, "embed_queries", None)
 
     def _run_query_batch(self, payloads: Sequence, k: int):
-        """One scan for a batch of queries given as texts and / or vectors; returns [(scores [k], rows [k])] per query."""
+        """One scan for a batch of queries given as texts and / or vectors; returns [(Document, score)] x k per query."""
         texts = [i for i, p in enumerate(payloads) if isinstance(p, str)]
         if texts and len(texts) == len(payloads) and hasattr(self.embedding, "embed_queries_device"):
             q = self.embedding.embed_queries_device([payloads[i] for i in texts])        # stays in HBM
@@ -307,7 +307,7 @@ class HipFlatVectorStore(VectorStore):
                     vecs[i] = np.asarray(v, dtype=np.float32)
             q = np.stack([np.asarray(v, dtype=np.float32) for v in vecs])
         scores, rows = self.index.search(q, min(k, self.ntotal))
-        return list(zip(scores, rows))
+        return self._map_batch(scores, rows, True)
 
     def _search_chunks(self, q, k: int):
         """(scores fp32 [n][k], rows int64 [n][k]) numpy pairs, one per 256 queries of q (device tensor or array), in order.

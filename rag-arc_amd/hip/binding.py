@@ -174,6 +174,7 @@ SIGNATURES = {
     "rarc_vmem_mapped": (c_size_t, [c_void_p]),
     "rarc_vmem_reserved": (c_size_t, [c_void_p]),
     "rarc_vmem_slab": (c_size_t, [c_void_p]),
+    "rarc_vmem_granularity": (c_size_t, [c_void_p]),
     "rarc_vmem_destroy": (c_int, [c_void_p]),
     "rarc_profile_begin": (c_int, [c_int]),
     "rarc_profile_end": (c_int, [ctypes.POINTER(c_double), ctypes.POINTER(c_int)]),

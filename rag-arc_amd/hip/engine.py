@@ -55,6 +55,7 @@ class DeviceArena:
         self.handle = handle
         self.base = int(lib.rarc_vmem_base(handle))
         self.reserved = int(lib.rarc_vmem_reserved(handle))
+        self.granularity = int(lib.rarc_vmem_granularity(handle))
 
     @property
     def mapped(self) -> int:
@@ -70,7 +71,7 @@ class DeviceArena:
         if nbytes > self.reserved:
             raise B.RarcError(f"the index was created for at most {self.reserved} bytes of rows; {nbytes} asked "
                               "(give a larger max_rows)")
-        step = min(self.STEP_MAX, max(2 << 20, have // 8))
+        step = min(self.STEP_MAX, max(self.granularity, have // 8))
         target = min(self.reserved, ((nbytes + step - 1) // step) * step)
         with self.torch.cuda.device(self.device_index):
             rc = self.lib.rarc_vmem_grow(self.handle, target)

@@ -44,6 +44,16 @@ def test_rows_to_pairs_and_docs_equal_the_reference_hit_loop():
     # any sequence will do (the columnar docstore is one), and rows may carry a base
     col = ColumnarDocstore.from_texts([d.content for d in docs], [d.id for d in docs], [d.metadata for d in docs])
     assert H.rows_to_docs(col, rows, 37, 25) == [[d for d, _ in one] for one in want]
+    # ... and the columnar docstore's native form: Documents built in C equal Document(content=, metadata=, id=)
+    got_c = H.rows_to_pairs(col.columns(), rows, scores, 37, 25)
+    assert got_c == want and all(type(d) is Document and d.__dict__ == w.__dict__ and list(d.__dict__) == list(w.__dict__)
+                                 for gc_, wc in zip(got_c, want) for (d, _), (w, _) in zip(gc_, wc))
+    plain = ColumnarDocstore.decimal(1000)
+    docs_p = H.rows_to_docs(plain.columns(), rows, 37, 25)
+    assert docs_p == [[plain[int(r)] for r in row if r != -1] for row in rows]
+    assert docs_p[0][0].metadata == {} and docs_p[0][0].metadata is not docs_p[0][1].metadata and docs_p[0][0].id is docs_p[0][0].content
+    with pytest.raises(IndexError):
+        H.rows_to_docs(plain.columns(), np.array([[1000]], dtype=np.int64), 1, 1)
     assert H.rows_to_docs(docs, rows + np.where(rows >= 0, 500, 0), 37, 25, 500) == [[d for d, _ in one] for one in want]
     with pytest.raises(IndexError):
         H.rows_to_docs(docs, np.array([[1000]], dtype=np.int64), 1, 1)
