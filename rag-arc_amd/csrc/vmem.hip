@@ -42,7 +42,13 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
   size_t slab = (slab_bytes + gran - 1) / gran * gran;
   size_t reserve = (reserve_bytes + gran - 1) / gran * gran;
   void* base = nullptr;
-  RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve, 0, nullptr, 0));
+  // 2 MiB-aligned addresses let the driver map the slabs with large page-table fragments (the scan streams the arena at
+  // HBM rate: TLB reach matters); a runtime that refuses the alignment gets its default
+  if (hipMemAddressReserve(&base, reserve, (size_t)2 << 20, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    base = nullptr;
+    RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve, 0, nullptr, 0));
+  }
   RarcVmem* v = new (std::nothrow) RarcVmem();
   if (!v) {
     (void)hipMemAddressFree(base, reserve);

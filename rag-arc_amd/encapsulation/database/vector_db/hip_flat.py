@@ -319,7 +319,7 @@ class HipFlatVectorStore(VectorStore):
             return
         step, pending = 256, None
         for s0 in range(0, len(q), step):
-            nxt = idx.search_async(q[s0:s0 + step], k)
+            nxt = idx.search_async(q[s0:s0 + step], k, to_host=True)
             if pending is not None:
                 yield pending.host()
             pending = nxt

@@ -106,7 +106,7 @@ class _ShardedIndex:
             return self.local.to_host(ids, sc)
         return sc.cpu().numpy(), ids.cpu().numpy()
 
-    def search_async(self, queries, k: int):
+    def search_async(self, queries, k: int, to_host: bool = False):
         """Enqueue this rank's scan now; `.host()` later runs the exchange (every rank collects its handles in the order
         it made them: the collectives line up) and returns the merged answer as numpy."""
         if not hasattr(self.local, "search_async") or self.local.ntotal < k:

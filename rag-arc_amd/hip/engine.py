@@ -71,7 +71,7 @@ class DeviceArena:
         if nbytes > self.reserved:
             raise B.RarcError(f"the index was created for at most {self.reserved} bytes of rows; {nbytes} asked "
                               "(give a larger max_rows)")
-        step = min(self.STEP_MAX, max(self.granularity, have // 8))
+        step = min(self.STEP_MAX, max(2 << 20, self.granularity, have // 8))
         target = min(self.reserved, ((nbytes + step - 1) // step) * step)
         with self.torch.cuda.device(self.device_index):
             rc = self.lib.rarc_vmem_grow(self.handle, target)
@@ -643,10 +643,12 @@ class FlatIndexF16:
             return out_ids, out_sc
 
     # ------------------------------------------------------------------ pipelined search
-    def search_async(self, queries, k: int) -> "PendingSearch":
+    def search_async(self, queries, k: int, to_host: bool = False) -> "PendingSearch":
         """Enqueue one batch and return at once; `.result()` later performs the status read-back (and the rare
         repair).  Lets a caller keep the GPU queue full: launch batch i+1, then collect batch i.  Results are
-        identical to search_device().  More than 256 queries are enqueued as consecutive 256-query launches."""
+        identical to search_device().  More than 256 queries are enqueued as consecutive 256-query launches.
+        to_host=True also enqueues the copy of the answer into pinned host memory RIGHT BEHIND the search — ahead of
+        whatever the caller enqueues next on this stream — so that `.host()` waits for this batch only."""
         t = self.torch
         if not (1 <= k <= B.MAX_K):
             raise ValueError("k out of range")
@@ -656,7 +658,7 @@ class FlatIndexF16:
             # (result() waits for the batch's own event on the host, so the answer is safe to use on any stream)
             self._own_stream.wait_stream(t.cuda.current_stream(self.device))
             with t.cuda.stream(self._own_stream):
-                return self.search_async(queries, k)
+                return self.search_async(queries, k, to_host)
         with self._lock, t.cuda.device(self.device):
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
             if q.ndim != 2 or q.shape[1] != self.dim or q.shape[0] < 1:
@@ -665,10 +667,15 @@ class FlatIndexF16:
             out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
             out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
             parts = []
+            h_ids = t.empty((nq, k), dtype=t.int64, pin_memory=True) if to_host else None
+            h_sc = t.empty((nq, k), dtype=t.float32, pin_memory=True) if to_host else None
             for s0 in range(0, nq, B.MAX_QUERIES):
                 e0 = min(nq, s0 + B.MAX_QUERIES)
                 status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this launch's own words
                 self._search_chunk(q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], repair=False, status=status)
+                if to_host:
+                    h_ids[s0:e0].copy_(out_ids[s0:e0], non_blocking=True)
+                    h_sc[s0:e0].copy_(out_sc[s0:e0], non_blocking=True)
                 # the batch's one status word goes to pinned host memory behind the search, with an event of its
                 # own: result() waits for THIS batch only, not for whatever was enqueued after it
                 flag_h = t.empty(1, dtype=t.int32, pin_memory=True)
@@ -677,8 +684,10 @@ class FlatIndexF16:
                 done.record()
                 parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], flag_h,
                                            status[:e0 - s0], done, stream=t.cuda.current_stream(self.device),
-                                           version=self._rows_version()))
-            return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc)
+                                           version=self._rows_version(),
+                                           host=(h_ids[s0:e0], h_sc[s0:e0]) if to_host else None))
+            return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc,
+                                                                   host=(h_ids, h_sc) if to_host else None)
 
     CAND_CAP_LIMIT = 1 << 21    # sticky growth of cand_cap stops here (4.3 GB of candidate keys per 128 results)
 
@@ -968,8 +977,9 @@ class FlatIndexF16:
 class PendingSearch:
     """Handle returned by FlatIndexF16.search_async."""
 
-    def __init__(self, index, q, k, ids, scores, flag, status, done=None, stream=None, version=None):
+    def __init__(self, index, q, k, ids, scores, flag, status, done=None, stream=None, version=None, host=None):
         self.index, self.q, self.k, self.ids, self.scores, self.flag, self.status = index, q, k, ids, scores, flag, status
+        self.host_copy = host   # (ids, scores) pinned tensors the answer was copied into behind the search (to_host=True)
         self.done = done        # event recorded behind the copy of the status word into pinned memory (`flag`)
         self.stream = stream    # the stream the search was enqueued on (a twin's side stream, else the caller's)
         self.version = version  # version of the rows when it was enqueued
@@ -1003,8 +1013,12 @@ class PendingSearch:
         return self.ids, self.scores
 
     def host(self):
-        """result() as numpy (scores fp32 [nq][k], ids int64 [nq][k]) through pinned memory (FlatIndexF16.to_host)."""
+        """result() as numpy (scores fp32 [nq][k], ids int64 [nq][k]) through pinned memory.  With to_host=True the copy
+        was enqueued behind the search and is complete once the batch's event is (nothing later on the stream is waited
+        for); a repaired batch — rare — is copied again."""
         ids, scores = self.result()
+        if self.host_copy is not None and not self.repaired:
+            return self.host_copy[1].numpy(), self.host_copy[0].numpy()
         t = self.index.torch
         with t.cuda.stream(self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)):
             return self.index.to_host(ids, scores)
@@ -1013,8 +1027,9 @@ class PendingSearch:
 class PendingBatches:
     """search_async over more than 256 queries: one PendingSearch per 256-query launch, one result."""
 
-    def __init__(self, parts, ids, scores):
+    def __init__(self, parts, ids, scores, host=None):
         self.parts, self.ids, self.scores = parts, ids, scores
+        self.host_copy = host
         self.repaired = None
 
     def result(self):
@@ -1028,6 +1043,8 @@ class PendingBatches:
 
     def host(self):
         ids, scores = self.result()
+        if self.host_copy is not None and not self.repaired:
+            return self.host_copy[1].numpy(), self.host_copy[0].numpy()
         p = self.parts[0]
         t = p.index.torch
         with t.cuda.stream(p.stream if p.stream is not None else t.cuda.current_stream(p.index.device)):
