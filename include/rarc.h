@@ -568,6 +568,19 @@ int rarc_device_to_file(const char* path, int n_seg, const int64_t* h_file_off, 
                         size_t staging_bytes, int n_threads, int flags, void* stream, RarcIoStats* stats);
 
 /*
+ * Deleting rows of a resident index: stable in-place compaction.  The reference deletes by clearing the index and
+ * embedding every surviving text again (encapsulation/database/vector_db/VectorStore_Faiss.py:374-415); the surviving
+ * rows are in HBM already, so here they move down over the holes: row i of the result is the i-th surviving row.
+ * d_rows: n_rows rows of row_bytes (a multiple of 4) — the fp16 / fp8 / fp32 rows, and likewise the fp8 row scales
+ * (row_bytes 4), the fp32 index's fp16 image, the int8 shadow.  d_adj: device int64 [n_holes], d_adj[j] = h_j - j for
+ * the sorted distinct hole rows h_j; first_hole = h_0.  d_tmp: caller-owned scratch (>= one row; the rows move through
+ * it chunk by chunk).  The vacated tail [n_rows - n_holes, n_rows) is zeroed.  Tile metadata is NOT updated: call
+ * rarc_quant_meta_* from first_hole afterwards.
+ */
+int rarc_compact_rows(void* d_rows, int64_t row_bytes, int64_t n_rows, const int64_t* d_adj, int64_t n_holes,
+                      int64_t first_hole, void* d_tmp, size_t tmp_bytes, void* stream);
+
+/*
  * Growable device arenas: where `index.add` appends to (encapsulation/database/vector_db/VectorStore_Faiss.py:199-202 —
  * faiss grows a std::vector there).  An arena reserves VIRTUAL address space for the largest size it may reach (no memory)
  * and is backed slab by slab as rows arrive: the base pointer never moves and nothing is copied, so the peak footprint of

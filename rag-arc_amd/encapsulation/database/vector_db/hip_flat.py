@@ -164,7 +164,13 @@ class HipFlatVectorStore(VectorStore):
         self._engine_factory = engine_factory or _default_engine
         self.index = None  # created on first add, like the reference
         self.docstore: dict = {}
-        self.index_to_docstore_id: dict = {}
+        self._i2d: Optional[dict] = {}       # index_to_docstore_id (a property: rebuilt from the row list when asked for)
+        # id -> slot, for delete(): a row's SLOT is the ordinal it was inserted with and never changes; its row number is
+        # the slot minus the deleted slots before it (rows only ever move down over holes).  An id used for several rows
+        # maps to a list.  None = not built yet (a loaded / adopted store builds it at its first delete).
+        self._slot_of_id: Optional[dict] = {}
+        self._dead_slots = np.zeros(0, dtype=np.int64)
+        self._next_slot = 0
         # row -> Document as a SEQUENCE (docstore.py): what a whole answer is mapped through in one native call.  A list of
         # the very objects the two dicts above hold, rebuilt from them whenever it may have fallen behind (a re-used id,
         # dicts assigned from outside); or a ColumnarDocstore for corpus-scale stores (adopt()), the dicts then stay empty
@@ -204,27 +210,62 @@ class HipFlatVectorStore(VectorStore):
         self._remember(start, texts, metadatas, ids)
         return list(ids)
 
+    @property
+    def index_to_docstore_id(self) -> dict:
+        """row -> document id (VectorStore_Faiss.py:97).  The row LIST is what searches go through; this dict is its
+        reference-shaped twin, materialised when somebody asks (the pickle of save_local, user code) — a delete renumbers
+        every later row, which costs nothing until then."""
+        if self._i2d is None:
+            seq = self._row_docs
+            self._i2d = {r: d.id for r, d in enumerate(seq)} if isinstance(seq, list) else {}
+        return self._i2d
+
+    @index_to_docstore_id.setter
+    def index_to_docstore_id(self, value: dict) -> None:
+        self._i2d = value
+        self._row_docs_stale = True         # dicts handed in from outside: the row list follows them at the next search
+        self._slot_of_id = None
+
     def _remember(self, start: int, texts, metadatas, ids) -> None:
         """docstore + index_to_docstore_id entries of rows start.. (VectorStore_Faiss.py:205-208), and the row list."""
         if isinstance(self._row_docs, ColumnarDocstore):
             raise ValueError("this store holds a columnar (read-only) docstore: it cannot be added to")
         rows_ok = not self._row_docs_stale and len(self._row_docs) == start
+        if not rows_ok:
+            self._slot_of_id = None
+        slots = self._slot_of_id
         for i, (text, meta, doc_id) in enumerate(zip(texts, metadatas, ids)):
-            if doc_id in self.docstore:
-                rows_ok = False          # an id used again: its EARLIER rows now answer with the new Document too
+            if doc_id in self.docstore and rows_ok:
+                # an id used again: its EARLIER rows now answer with the new Document too (docstore[id] is overwritten) —
+                # the dicts become the truth, the row list is rebuilt from them at the next search
+                _ = self.index_to_docstore_id
+                rows_ok, slots, self._slot_of_id = False, None, None
             doc = self.docstore[doc_id] = Document(content=text, metadata=meta, id=doc_id)
-            self.index_to_docstore_id[start + i] = doc_id
+            if self._i2d is not None:
+                self._i2d[start + i] = doc_id
             if rows_ok:
                 self._row_docs.append(doc)
+                if slots is not None:
+                    slots[doc_id] = self._next_slot + i
+        self._next_slot += len(texts)
         self._row_docs_stale = not rows_ok
 
     def _docs_by_row(self):
         """The row-indexed docstore sequence, brought up to date with the dicts if need be."""
         seq = self._row_docs
-        if isinstance(seq, list) and (self._row_docs_stale or len(seq) != len(self.index_to_docstore_id)):
+        if isinstance(seq, list) and self._row_docs_stale:
             seq = self._row_docs = rows_from_dicts(self.docstore, self.index_to_docstore_id)
             self._row_docs_stale = False
         return seq
+
+    def _rows_of_ids(self, ids):
+        """(current row numbers, slots) of the documents with these ids (each id names exactly one row: see delete)."""
+        seq = self._docs_by_row()
+        if self._slot_of_id is None:               # a loaded / adopted store: slots = today's row numbers
+            self._slot_of_id = {d.id: r for r, d in enumerate(seq)}
+            self._dead_slots, self._next_slot = np.zeros(0, dtype=np.int64), len(seq)
+        slots = np.fromiter((self._slot_of_id[i] for i in ids), dtype=np.int64, count=len(ids))
+        return slots - np.searchsorted(self._dead_slots, slots), slots
 
     def adopt(self, index, row_docs) -> "HipFlatVectorStore":
         """Corpus-scale construction: take an engine whose rows are already in HBM (loaded from a shard file, generated,
@@ -233,14 +274,14 @@ class HipFlatVectorStore(VectorStore):
         if len(row_docs) != index.ntotal:
             raise ValueError(f"{len(row_docs)} documents for {index.ntotal} rows")
         self.index = index
-        self.docstore, self.index_to_docstore_id = {}, {}
+        self.docstore, self._i2d, self._slot_of_id = {}, None, None
         if isinstance(row_docs, ColumnarDocstore):
             self._row_docs = row_docs
         else:
             self._row_docs = list(row_docs)
-            for r, d in enumerate(self._row_docs):
-                self.docstore[d.id] = d
-                self.index_to_docstore_id[r] = d.id
+            self.docstore = {d.id: d for d in self._row_docs}
+            if len(self.docstore) != len(self._row_docs):
+                raise ValueError("adopt(): document ids must be distinct")
         self._row_docs_stale = False
         return self
 
@@ -468,9 +509,14 @@ class HipFlatVectorStore(VectorStore):
 
     # ------------------------------------------------------------------ maintenance
     def delete(self, ids: Optional[List[str]] = None, **kwargs: Any) -> Optional[bool]:
+        """FaissVectorStore.delete (VectorStore_Faiss.py:374-415): None clears the store, an unknown id anywhere in the list
+        -> False and nothing changes, otherwise the documents go and True comes back.  The reference rebuilds the index by
+        embedding every surviving text again; the surviving embeddings are in HBM already, so here the rows are compacted
+        in place (rarc_compact_rows: stable, the survivors keep their order — exactly the rows a rebuild from the docstore
+        would produce, without the encoder and without its batch-shape rounding noise) and the docstore follows."""
         if ids is None:
             self.docstore.clear()
-            self.index_to_docstore_id.clear()
+            self._forget_rows()
             if self.index is not None:
                 self.index.reset()
             return True
@@ -478,12 +524,46 @@ class HipFlatVectorStore(VectorStore):
             return True
         if any(i not in self.docstore for i in ids):
             return False
-        keep = [d for i, d in self.docstore.items() if i not in ids]
+        if isinstance(self._row_docs, ColumnarDocstore):
+            raise ValueError("this store holds a columnar (read-only) docstore: documents cannot be deleted from it")
+        if len(self.docstore) != self.ntotal or not hasattr(self.index, "remove_rows"):
+            return self._delete_by_rebuild(ids)
+        gone = list(dict.fromkeys(ids))
+        rows, slots = self._rows_of_ids(gone)
+        self._remove_index_rows(rows)
+        order = np.argsort(rows)
+        rows, slots = rows[order], slots[order]
+        for i in gone:
+            del self.docstore[i]
+            del self._slot_of_id[i]
+        seq, kept, prev = self._row_docs, [], 0
+        for r in rows.tolist():                    # the row list without the holes, slice by slice
+            kept.extend(seq[prev:r])
+            prev = r + 1
+        kept.extend(seq[prev:])
+        self._row_docs = kept
+        self._dead_slots = np.union1d(self._dead_slots, slots)
+        self._i2d = None                           # (every later row was renumbered: rebuilt when somebody asks for it)
+        return True
+
+    def _remove_index_rows(self, rows: np.ndarray) -> None:
+        self.index.remove_rows(rows)
+
+    def _forget_rows(self) -> None:
+        self._row_docs, self._row_docs_stale, self._i2d = [], False, {}
+        self._slot_of_id, self._dead_slots, self._next_slot = {}, np.zeros(0, dtype=np.int64), 0
+
+    def _delete_by_rebuild(self, ids) -> bool:
+        """The reference's own way (VectorStore_Faiss.py:390-413): reset, then add the surviving documents — one per ID, in
+        docstore order — again.  Taken when an id names several rows (the rebuild collapses them into one: compaction
+        cannot reproduce that) or the engine cannot compact."""
+        drop = set(ids)
+        keep = [d for i, d in self.docstore.items() if i not in drop]
         self.docstore.clear()
-        self.index_to_docstore_id.clear()
+        self._forget_rows()
         if self.index is not None:
             self.index.reset()
-        if keep:  # a flat index has no holes: rebuild from the surviving texts, as the reference does
+        if keep:
             self.add_texts([d.content for d in keep], [d.metadata for d in keep], ids=[d.id for d in keep])
         return True
 
@@ -573,11 +653,9 @@ class HipFlatVectorStore(VectorStore):
         kwargs.setdefault("storage", meta.get("storage", "f16"))
         store = cls(embedding=embeddings, index_type=meta["index_type"], metric=meta["metric"],
                     normalize_L2=meta["normalize_L2"], **kwargs)
-        store.docstore, store.index_to_docstore_id = meta["docstore"], meta["index_to_docstore_id"]
+        store.docstore, store.index_to_docstore_id = meta["docstore"], meta["index_to_docstore_id"]   # (marks the row list stale)
         if meta.get("row_docs") is not None:
-            store._row_docs = meta["row_docs"]
-        else:
-            store._row_docs_stale = True              # the row list is rebuilt from the dicts at the first search
+            store._row_docs, store._row_docs_stale = meta["row_docs"], False
         saved_world = int(meta.get("world", 1))
         files = [SF.shard_path(folder_path, index_name, r, saved_world) for r in range(saved_world)]
         files = [f for f in files if os.path.exists(f)]

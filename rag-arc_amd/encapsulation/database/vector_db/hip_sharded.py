@@ -57,6 +57,28 @@ class _ShardedIndex:
         self.local.reset()
         self._blocks, self._l2g, self.ntotal = [], None, 0
 
+    def remove_rows(self, global_rows) -> None:
+        """Delete rows by GLOBAL id (every rank is handed the same list): this rank compacts the ones it holds
+        (FlatIndexF16.remove_rows), and every block's first id drops by the holes before it — the global numbering stays
+        "position among the surviving rows", as on one GPU.  No collective."""
+        holes = np.unique(np.asarray(global_rows, dtype=np.int64).reshape(-1))
+        if holes.size == 0:
+            return
+        if holes[0] < 0 or holes[-1] >= self.ntotal:
+            raise IndexError(f"rows to remove must lie in [0, {self.ntotal})")
+        local_holes, blocks, at = [], [], 0
+        for g0, n in self._blocks:
+            a, b = np.searchsorted(holes, g0), np.searchsorted(holes, g0 + n)
+            local_holes.append(holes[a:b] - g0 + at)
+            if n - (b - a) > 0:
+                blocks.append((int(g0 - a), int(n - (b - a))))
+            at += n
+        mine = np.concatenate(local_holes) if local_holes else np.zeros(0, dtype=np.int64)
+        if mine.size:
+            self.local.remove_rows(mine)
+        self._blocks, self._l2g = blocks, None
+        self.ntotal -= int(holes.size)
+
     def _global_ids(self, device):
         t = self.torch
         if self._l2g is None or self._l2g.device != device:

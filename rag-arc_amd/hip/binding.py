@@ -168,6 +168,7 @@ SIGNATURES = {
     "rarc_device_to_file": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
                                     ctypes.POINTER(c_int64), c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p,
                                     ctypes.POINTER(IoStats)]),
+    "rarc_compact_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "rarc_vmem_create": (c_int, [c_int, c_size_t, c_size_t, ctypes.POINTER(c_void_p)]),
     "rarc_vmem_grow": (c_int, [c_void_p, c_size_t]),
     "rarc_vmem_base": (c_void_p, [c_void_p]),

@@ -555,6 +555,46 @@ class FlatIndexF16:
             self._requant(old)
             return stats
 
+    COMPACT_TMP_BYTES = 256 << 20      # scratch the rows move through when rows are removed (rarc_compact_rows)
+
+    def remove_rows(self, rows) -> int:
+        """Delete stored rows (local row numbers, any order) by stable in-place compaction: the survivors keep their
+        order and move down over the holes, so a later row's number drops by the holes before it.  No encoder call — the
+        reference re-embeds every surviving text (VectorStore_Faiss.py:374-415).  Tile metadata is recomputed from the
+        first hole on.  Returns the number of rows removed."""
+        self._not_a_twin()
+        t = self.torch
+        holes = np.unique(np.asarray(rows, dtype=np.int64).reshape(-1))
+        if holes.size == 0:
+            return 0
+        if holes[0] < 0 or holes[-1] >= self.ntotal:
+            raise IndexError(f"rows to remove must lie in [0, {self.ntotal})")
+        with self._lock, t.cuda.device(self.device):
+            adj = t.from_numpy(holes - np.arange(holes.size, dtype=np.int64)).to(self.device)
+            first, n = int(holes[0]), int(self.ntotal)
+            bufs = [(self._rows, self._rows.shape[1] * self._rows.element_size())]
+            if self._rowscale is not None:
+                bufs.append((self._rowscale, 4))
+            if self._image16 is not None:
+                bufs.append((self._image16, self.d_pad * 2))
+            if self._shadow is not None:
+                bufs.append((self._shadow, self.d_pad))
+            need = max((n - holes.size - first) * rb for _, rb in bufs)
+            tmp = t.empty(max(min(self.COMPACT_TMP_BYTES, need), max(rb for _, rb in bufs)), dtype=t.uint8, device=self.device)
+            for buf, rb in bufs:
+                B.check(self.lib.rarc_compact_rows(buf.data_ptr(), rb, n, adj.data_ptr(), holes.size, first,
+                                                   tmp.data_ptr(), tmp.numel(), self._stream()), "rarc_compact_rows")
+            self.ntotal = n - int(holes.size)
+            self._version += 1
+            if self.ntotal == 0:
+                self.max_norm = 0.0
+                if self._qmeta is not None:
+                    self._qmeta[:4].zero_()
+            else:
+                self._requant(min(first, self.ntotal - 1))
+            t.cuda.current_stream(self.device).synchronize()      # `tmp` and `adj` are released on return
+        return int(holes.size)
+
     def reset(self) -> None:
         self._not_a_twin()
         with self._lock:
