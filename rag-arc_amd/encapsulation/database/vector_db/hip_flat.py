@@ -633,7 +633,10 @@ class HipFlatVectorStore(VectorStore):
                     # a columnar docstore travels as its columns (the dicts above are empty then)
                     "row_docs": self._row_docs if isinstance(self._row_docs, ColumnarDocstore) else None,
                     # what the searches so far have taught the index about this corpus (engine: sticky candidate capacity)
-                    "cand_cap": int(getattr(self._local_engine(), "cand_cap", 0) or 0) if self.index is not None else 0}
+                    "cand_cap": int(getattr(self._local_engine(), "cand_cap", 0) or 0) if self.index is not None else 0,
+                    # ... and whether that capacity was ever put to the test (a search overflowed and it grew, or warm_up ran)
+                    "cand_cap_settled": bool(self.index is not None and (getattr(self._local_engine(), "cand_cap_grown", 0)
+                                                                         or getattr(self._local_engine(), "warmed_up", False)))}
             tmp = os.path.join(folder_path, f"{index_name}.pkl.tmp")
             with open(tmp, "wb") as fh:
                 pickle.dump(meta, fh)
@@ -651,6 +654,7 @@ class HipFlatVectorStore(VectorStore):
         with open(os.path.join(folder_path, f"{index_name}.pkl"), "rb") as fh:
             meta = pickle.load(fh)
         kwargs.setdefault("storage", meta.get("storage", "f16"))
+        warm_up = bool(kwargs.pop("warm_up", True))
         store = cls(embedding=embeddings, index_type=meta["index_type"], metric=meta["metric"],
                     normalize_L2=meta["normalize_L2"], **kwargs)
         store.docstore, store.index_to_docstore_id = meta["docstore"], meta["index_to_docstore_id"]   # (marks the row list stale)
@@ -689,8 +693,22 @@ class HipFlatVectorStore(VectorStore):
                     run.append(seg)
         store._adopt_loaded(blocks, total)
         store.last_load_stats = stats
-        if int(meta.get("cand_cap", 0) or 0) > int(getattr(eng, "cand_cap", 0) or 0):
-            eng.cand_cap = int(meta["cand_cap"])    # (a capacity the saved index had grown to: not learnt a second time)
+        saved_cap = int(meta.get("cand_cap", 0) or 0)
+        if saved_cap > int(getattr(eng, "cand_cap", 0) or 0):
+            # a capacity the saved index had grown to is not learnt a second time — as far as THIS device can hold its
+            # workspace (a tenth of its memory at most: the file may come from a larger part)
+            import torch
+
+            lib, total = getattr(eng, "lib", None), 0
+            if lib is not None and torch.cuda.is_available():
+                total = int(torch.cuda.get_device_properties(eng.device).total_memory)
+            while lib is not None and saved_cap > eng.cand_cap and int(lib.rarc_search_workspace_bytes(saved_cap)) > total // 10:
+                saved_cap //= 2
+            eng.cand_cap = max(int(eng.cand_cap), saved_cap)
+        if not meta.get("cand_cap_settled", False) and warm_up and hasattr(eng, "warm_up") and eng.ntotal:
+            # the file carries no learnt capacity (its index never overflowed and was never warmed up): learn it now, not
+            # in the first user batch — one search of 64 stored rows on corpora the default capacity fits
+            eng.warm_up()
         return store
 
     def warm_up(self, k: int = 100) -> int:

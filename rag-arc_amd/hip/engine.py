@@ -300,9 +300,20 @@ class FlatIndexF16:
         t = self.torch
         cap = self.cand_cap * max(1, -(-int(k) // 128)) * max(1, int(scale))
         if self._ws is None or cap > self._cap_eff:
-            self._cap_eff = max(cap, self._cap_eff)
-            nbytes = self.lib.rarc_search_workspace_bytes(self._cap_eff)
-            self._ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+            want = max(cap, self._cap_eff)
+            try:
+                ws = t.empty(self.lib.rarc_search_workspace_bytes(want), dtype=t.uint8, device=self.device)
+            except (t.cuda.OutOfMemoryError, RuntimeError) as exc:
+                # HBM cannot hold the capacity this index has GROWN to (sticky growth below): fall back to the capacity it
+                # had before — such a corpus is then answered through the re-run / exact per-query scan again (slowly), but
+                # it is answered.  Anything else (the default capacity does not fit either) is the caller's to see.
+                prev = getattr(self, "_cand_cap_before_growth", None)
+                if "out of memory" not in str(exc).lower() or prev is None or prev >= self.cand_cap:
+                    raise
+                self.cand_cap, self._cand_cap_before_growth = prev, None
+                self.cand_cap_growth_refused = True
+                return self._workspace(k, scale)
+            self._ws, self._cap_eff = ws, want
         if self._qbuf is None:
             mq = B.MAX_QUERIES
             self._qbuf = dict(
@@ -675,6 +686,9 @@ class FlatIndexF16:
             if q.shape[1] != self.dim:
                 raise ValueError(f"expected [nq][{self.dim}] queries, got {tuple(q.shape)}")
             nq = q.shape[0]
+            if self.ntotal == 0:        # an empty index answers (-1, -inf) like faiss; no kernel has anything to read
+                return (t.full((nq, k), -1, dtype=t.int64, device=self.device),
+                        t.full((nq, k), float("-inf"), dtype=t.float32, device=self.device))
             out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
             out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
             for s in range(0, nq, B.MAX_QUERIES):
@@ -725,25 +739,42 @@ class FlatIndexF16:
                 parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], flag_h,
                                            status[:e0 - s0], done, stream=t.cuda.current_stream(self.device),
                                            version=self._rows_version(),
-                                           host=(h_ids[s0:e0], h_sc[s0:e0]) if to_host else None))
+                                           host=(h_ids[s0:e0], h_sc[s0:e0]) if to_host else None, cand_cap=self.cand_cap))
             return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc,
                                                                    host=(h_ids, h_sc) if to_host else None)
 
     CAND_CAP_LIMIT = 1 << 21    # sticky growth of cand_cap stops here (4.3 GB of candidate keys per 128 results)
 
-    def _grow_if_segments_overflowed(self, words) -> None:
+    def _grow_if_segments_overflowed(self, words, launched_with: Optional[int] = None) -> None:
         """A query flagged with RARC_Q_WHY_SEGMENT ran out of room in a scan workgroup's candidate segment: this CORPUS lets
         more rows through the int8 margin than `cand_cap` was sized for (clustered data at 100M rows: a query's whole
         cluster, ~100 K rows).  The re-run below fixes the answer; doubling the capacity for every LATER search fixes the
-        cause — otherwise each batch pays a second scan of the shard (76.9 vs 39.6 ms per batch at 100M clustered rows)."""
+        cause — otherwise each batch pays a second scan of the shard (76.9 vs 39.6 ms per batch at 100M clustered rows).
+
+        One overflow, one doubling: a batch that was LAUNCHED under a smaller capacity than today's (`launched_with` — with
+        search_async several are in flight when the first of them reports) says nothing about today's, and does not
+        double it again.  The growth stops where the workspace would take more than a tenth of the device's memory
+        (CAND_CAP_LIMIT at most), is undone if that workspace cannot be allocated after all (_workspace), and is the
+        capacity the index keeps: it does not decay (a corpus does not un-cluster)."""
         try:
             seg = any(int(w) & 0x100 for w in words)
         except TypeError:
             seg = False
-        if seg and self.cand_cap < self.CAND_CAP_LIMIT:
-            self.cand_cap = min(self.CAND_CAP_LIMIT, 2 * self.cand_cap)
-            self.cand_cap_grown = getattr(self, "cand_cap_grown", 0) + 1
-            self._ws, self._cap_eff = None, 0          # the next search allocates the larger workspace
+        if not seg or self.cand_cap >= self.CAND_CAP_LIMIT:
+            return
+        if launched_with is not None and launched_with < self.cand_cap:
+            return
+        new_cap = min(self.CAND_CAP_LIMIT, 2 * self.cand_cap)
+        total = int(self.torch.cuda.get_device_properties(self.device).total_memory)
+        if int(self.lib.rarc_search_workspace_bytes(new_cap)) > total // 10:
+            return
+        self._cand_cap_before_growth = self.cand_cap
+        self.cand_cap = new_cap
+        self.cand_cap_grown = getattr(self, "cand_cap_grown", 0) + 1
+        # the next search allocates the larger workspace.  Launches still in flight keep reading the old one: they are
+        # on this index's stream, and the caching allocator hands a freed block to later work of the SAME stream only
+        # (a twin's workspace is its own, allocated on the twin's stream)
+        self._ws, self._cap_eff = None, 0
 
     def warm_up(self, k: int = 100, n_queries: int = 64, rounds: int = 6) -> int:
         """Let the index learn its corpus before the first user batch: stored rows (evenly spaced) are searched as queries
@@ -769,9 +800,10 @@ class FlatIndexF16:
                 self.search_device(q, kk)
                 if getattr(self, "cand_cap_grown", 0) == grown:
                     break
+            self.warmed_up = True
             return getattr(self, "cand_cap_grown", 0) - before
 
-    def _repair_rows(self, q, k, out_ids, out_sc, flagged, words=None) -> None:
+    def _repair_rows(self, q, k, out_ids, out_sc, flagged, words=None, launched_with: Optional[int] = None) -> None:
         """Make the flagged rows of (out_ids, out_sc) exact (the shared query buffers may hold a later batch by now).
 
         First a re-run of the SEARCH for the flagged queries together, started from what the first attempt did
@@ -786,19 +818,21 @@ class FlatIndexF16:
         stream = self._stream()
         left = list(flagged)
         big = None
+        cap_then = int(launched_with or self.cand_cap)      # the capacity the flagged batch ran with (before any growth)
         if words is not None:
-            self._grow_if_segments_overflowed(words)
+            self._grow_if_segments_overflowed(words, launched_with)
         if left and self.ntotal:
-            # the re-run gets a workspace of ITS OWN with four times the candidate capacity, released afterwards: the
-            # steady-state workspace (and the cand_cap every later search is launched with) stays what it was.  If HBM
-            # cannot spare it the re-run is skipped — the exact per-query scan below needs no extra memory.
-            cap_big = 4 * self.cand_cap * max(1, -(-int(k) // 128))
+            # the re-run gets a workspace of ITS OWN with four times the candidate capacity the batch ran with, released
+            # afterwards.  If HBM cannot spare it the re-run is skipped — the exact per-query scan below needs no extra
+            # memory (62 ms per query at 100M rows: `last_rerun_skipped` says when that happened).
+            cap_big = 4 * cap_then * max(1, -(-int(k) // 128))
             try:
                 big = t.empty(int(self.lib.rarc_search_workspace_bytes(cap_big)), dtype=t.uint8, device=self.device)
             except (t.cuda.OutOfMemoryError, RuntimeError) as exc:
                 if "out of memory" not in str(exc).lower():
                     raise
                 big = None
+                self.last_rerun_skipped = getattr(self, "last_rerun_skipped", 0) + 1
         if big is not None:
             sel = t.as_tensor(left, dtype=t.long, device=self.device)
             sub_q = q[sel].contiguous()
@@ -1017,8 +1051,9 @@ class FlatIndexF16:
 class PendingSearch:
     """Handle returned by FlatIndexF16.search_async."""
 
-    def __init__(self, index, q, k, ids, scores, flag, status, done=None, stream=None, version=None, host=None):
+    def __init__(self, index, q, k, ids, scores, flag, status, done=None, stream=None, version=None, host=None, cand_cap=None):
         self.index, self.q, self.k, self.ids, self.scores, self.flag, self.status = index, q, k, ids, scores, flag, status
+        self.cand_cap = cand_cap   # the candidate capacity this batch was launched with
         self.host_copy = host   # (ids, scores) pinned tensors the answer was copied into behind the search (to_host=True)
         self.done = done        # event recorded behind the copy of the status word into pinned memory (`flag`)
         self.stream = stream    # the stream the search was enqueued on (a twin's side stream, else the caller's)
@@ -1047,7 +1082,7 @@ class PendingSearch:
                 stream = self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)
                 with self.index._lock, t.cuda.device(self.index.device), t.cuda.stream(stream):
                     self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired,
-                                            words=[words[i] for i in self.repaired])
+                                            words=[words[i] for i in self.repaired], launched_with=self.cand_cap)
                     stream.synchronize()
             self.index.last_repaired = self.repaired
         return self.ids, self.scores
