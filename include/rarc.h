@@ -586,11 +586,15 @@ int rarc_compact_rows(void* d_rows, int64_t row_bytes, int64_t n_rows, const int
  * and is backed slab by slab as rows arrive: the base pointer never moves and nothing is copied, so the peak footprint of
  * a growing index is its live rows rounded up to one slab (a reallocating buffer holds old + new: up to 3x).
  * The second kind of object this library allocates (with the tokenizer handle): release it with rarc_vmem_destroy, after
- * the last kernel that reads it.  slab_bytes (0 = 1 GiB) bounds one physical allocation; sizes are rounded up to the device's
- * mapping granularity (rarc_vmem_slab / _granularity / _mapped / _reserved report the figures in force).
- * rarc_vmem_grow(min_bytes): back at least the first min_bytes (never shrinks; on failure — HBM exhausted — what was
- * mapped stays mapped and usable).  Not tied to a stream: mapping is a host-side operation, visible to later launches.
+ * the last kernel that reads it.  Every piece of physical memory is one SLAB (slab_bytes, 0 = RARC_VMEM_DEFAULT_SLAB,
+ * rounded up to the device's mapping granularity); the reservation is rounded up to whole slabs.  One slab size per
+ * process: the first create fixes it and a create with another size returns RARC_E_UNSUPPORTED (this HIP runtime
+ * mis-maps pieces of different sizes in reused address ranges — csrc/vmem.hip, tools/vmem_probe.py).
+ * rarc_vmem_grow(min_bytes): back at least the first min_bytes, in whole slabs (never shrinks; on failure — HBM
+ * exhausted — what was mapped stays mapped and usable).  Not tied to a stream: mapping is a host-side operation,
+ * visible to later launches.
  */
+#define RARC_VMEM_DEFAULT_SLAB (16u << 20)
 typedef struct RarcVmem RarcVmem;
 int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_bytes, RarcVmem** out);
 int rarc_vmem_grow(RarcVmem* arena, size_t min_bytes);

@@ -6,6 +6,13 @@
 // (hipMemAddressReserve: costs no memory) and backs it slab by slab (hipMemCreate + hipMemMap + hipMemSetAccess) as rows
 // arrive: the base pointer never moves, nothing is copied, the kernels see one contiguous buffer as before, and the peak
 // footprint is the live rows rounded up to a slab.
+//
+// ONE slab size per process, every piece exactly one slab.  Measured on this runtime (ROCm 7.0.2 / HIP 7.0.51831,
+// tools/vmem_probe.py, every sequence in a fresh process): inside one reservation the second mapped piece fixes the size
+// of all later ones (2,30 ok; 2,8,8,8 ok then 6 -> hipErrorInvalidValue; 2,2 then 4 -> invalid), and a reservation
+// whose address range is reused after hipMemAddressFree by pieces of ANOTHER size maps without error but reads back
+// wrong data.  Uniform pieces (any size, power of two or not) behave in every sequence tried, including destroy /
+// re-create.  So: the first rarc_vmem_create of a process fixes the slab size; a later call asking for another is refused.
 #include <mutex>
 #include <new>
 #include <vector>
@@ -38,9 +45,18 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
   size_t gran = 0;
   RARC_HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
   if (gran == 0) gran = 2u << 20;
-  if (slab_bytes == 0) slab_bytes = (size_t)1 << 30;
+  if (slab_bytes == 0) slab_bytes = (size_t)RARC_VMEM_DEFAULT_SLAB;
   size_t slab = (slab_bytes + gran - 1) / gran * gran;
-  size_t reserve = (reserve_bytes + gran - 1) / gran * gran;
+  {
+    static std::mutex g_mu;
+    static size_t g_slab = 0;        // the process's one piece size (see the header of this file)
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_slab == 0) g_slab = slab;
+    RARC_REQUIRE(g_slab == slab, RARC_E_UNSUPPORTED,
+                 "rarc_vmem_create: this process maps %zu-byte slabs; an arena of %zu-byte slabs cannot coexist with them "
+                 "(HIP runtime: pieces of different sizes in reused address ranges corrupt mappings)", g_slab, slab);
+  }
+  size_t reserve = (reserve_bytes + slab - 1) / slab * slab;
   void* base = nullptr;
   // 2 MiB-aligned addresses let the driver map the slabs with large page-table fragments (the scan streams the arena at
   // HBM rate: TLB reach matters); a runtime that refuses the alignment gets its default
@@ -65,8 +81,8 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
   return RARC_OK;
 }
 
-// Back the arena up to at least min_bytes (rounded up to the mapping granularity, in physical allocations of at most one
-// slab each).  Never shrinks; on failure what was mapped before stays mapped.
+// Back the arena up to at least min_bytes (rounded up to whole slabs: one physical allocation each).  Never shrinks; on
+// failure what was mapped before stays mapped.
 extern "C" int rarc_vmem_grow(RarcVmem* v, size_t min_bytes) {
   RARC_REQUIRE(v, RARC_E_INVALID, "rarc_vmem_grow: null arena");
   std::lock_guard<std::mutex> lk(v->mu);
@@ -76,9 +92,9 @@ extern "C" int rarc_vmem_grow(RarcVmem* v, size_t min_bytes) {
   hipMemAccessDesc acc = {};
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
-  const size_t target = (min_bytes + v->gran - 1) / v->gran * v->gran;
+  const size_t target = (min_bytes + v->slab - 1) / v->slab * v->slab;
   while (v->mapped < target) {
-    const size_t piece = target - v->mapped < v->slab ? target - v->mapped : v->slab;
+    const size_t piece = v->slab;
     hipMemGenericAllocationHandle_t h;
     hipError_t e = hipMemCreate(&h, piece, &prop, 0);
     if (e != hipSuccess) {

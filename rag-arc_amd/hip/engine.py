@@ -40,43 +40,36 @@ class _DeviceArray:
 
 class DeviceArena:
     """A growable HBM buffer on HIP virtual memory (rarc_vmem_*, csrc/vmem.hip): address space reserved up front, backed
-    as it grows, never moved, never copied.  `view(nbytes)` is a uint8 torch tensor over the first nbytes."""
+    slab by slab as it grows, never moved, never copied.  `view(nbytes)` is a uint8 torch tensor over the first nbytes."""
 
-    STEP_MAX = 1 << 30          # growth beyond what is asked: at most this much (= the peak overhead of a growing index)
-
-    def __init__(self, torch, lib, device_index: int, reserve_bytes: int, slab_bytes: int = 0):
+    def __init__(self, torch, lib, device_index: int, reserve_bytes: int):
         import ctypes
 
         self.torch, self.lib, self.device_index = torch, lib, int(device_index)
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device_index):
-            B.check(lib.rarc_vmem_create(self.device_index, int(reserve_bytes), int(slab_bytes), ctypes.byref(handle)),
-                    "rarc_vmem_create")
+            # (slab size 0 = the library's default: ONE size per process, see csrc/vmem.hip)
+            B.check(lib.rarc_vmem_create(self.device_index, int(reserve_bytes), 0, ctypes.byref(handle)), "rarc_vmem_create")
         self.handle = handle
         self.base = int(lib.rarc_vmem_base(handle))
         self.reserved = int(lib.rarc_vmem_reserved(handle))
         self.granularity = int(lib.rarc_vmem_granularity(handle))
+        self.slab = int(lib.rarc_vmem_slab(handle))
 
     @property
     def mapped(self) -> int:
         return int(self.lib.rarc_vmem_mapped(self.handle))
 
     def grow(self, nbytes: int) -> None:
-        """Back at least nbytes; beyond the request a step of mapped/8 (2 MiB .. 1 GiB) so that a stream of small adds
-        maps O(log) + one-per-GiB physical allocations, not one per add."""
+        """Back at least nbytes (whole slabs of 16 MiB: what an arena holds beyond its live bytes is under one slab)."""
         nbytes = int(nbytes)
-        have = self.mapped
-        if nbytes <= have:
+        if nbytes <= self.mapped:
             return
         if nbytes > self.reserved:
             raise B.RarcError(f"the index was created for at most {self.reserved} bytes of rows; {nbytes} asked "
                               "(give a larger max_rows)")
-        step = min(self.STEP_MAX, max(2 << 20, self.granularity, have // 8))
-        target = min(self.reserved, ((nbytes + step - 1) // step) * step)
         with self.torch.cuda.device(self.device_index):
-            rc = self.lib.rarc_vmem_grow(self.handle, target)
-            if rc != 0 and self.mapped < nbytes:
-                B.check(rc, "rarc_vmem_grow")       # (a step that did not fit is not an error if the request itself did)
+            B.check(self.lib.rarc_vmem_grow(self.handle, nbytes), "rarc_vmem_grow")
 
     def view(self, nbytes: int):
         t = self.torch
@@ -171,6 +164,8 @@ class FlatIndexF16:
         if self._rows is not None and self._rows.shape[0] >= cap:
             return
         if self.growable:
+            if self.max_rows and cap > ((self.max_rows + _ROW_ALIGN - 1) // _ROW_ALIGN) * _ROW_ALIGN:
+                raise B.RarcError(f"the index was created for at most {self.max_rows} rows; {int(n_rows)} asked (give a larger max_rows)")
             self._reserve_arenas(cap)
             self._fit_qmeta()
             return
@@ -369,7 +364,9 @@ class FlatIndexF16:
             if n == 0:
                 return
             if self._rows is None or self.ntotal + n > self._rows.shape[0]:
-                self.reserve(max(self.ntotal + n, 2 * self.ntotal))
+                # an arena grows in place, slab by slab: ask for what is needed; a plain buffer is reallocated and copied:
+                # double it so that a stream of adds copies O(log) times
+                self.reserve(self.ntotal + n if self.growable else max(self.ntotal + n, 2 * self.ntotal))
             norm2 = t.empty(n, dtype=t.float32, device=self.device)
             dst = self._rows[self.ntotal: self.ntotal + n]
             if self.storage == "f8":

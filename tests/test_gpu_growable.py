@@ -5,7 +5,7 @@ up front, physical memory mapped behind the same pointer as rows arrive, nothing
 * small: a growable index fed in ragged steps answers exactly as the oracle (and as a reallocating index) after every
   step, for every storage format; the base pointer never moves; backed memory tracks the live rows;
 * corpus scale (skipped under 200 GB of free HBM): one index grown by repeated `add` from nothing past 60 % of the free
-  HBM; the device's used memory never exceeds the live rows + one growth step (1 GiB) + the fixed staging of the test;
+  HBM; the device's used memory never exceeds the live rows + one slab (16 MiB) + search scratch;
   after every growth step the answers are exact (exhaustive device re-scan) and the rows they name, regenerated and
   ingested by the ORACLE, score to the same bits; save_local / load_local unchanged.
 """
@@ -61,8 +61,8 @@ def test_growable_index_equals_oracle_after_every_add(hip, oracle, storage, dim)
         assert np.array_equal(I, ref_I) and np.array_equal(D.view(np.uint32), ref_D.view(np.uint32)), (storage, at)
         assert np.array_equal(I, I2) and np.array_equal(D.view(np.uint32), D2.view(np.uint32))
         mem = grow.memory_bytes()
-        step = max(2 << 20, max(a.granularity for a in grow._arenas.values()))       # the smallest growth step
-        assert mem["live"] <= mem["backed"] <= mem["live"] * 9 // 8 + len(grow._arenas) * 2 * step, (mem, step)
+        slab = max(a.slab for a in grow._arenas.values())       # every arena holds its live bytes + less than one slab
+        assert mem["live"] <= mem["backed"] <= mem["live"] + len(grow._arenas) * slab + 32 * mem["live"] // max(at, 1), (mem, slab)
     with pytest.raises(hip.B.RarcError):
         grow.add(X[:70_000])                      # past max_rows: refused, nothing lost
     D3, I3 = grow.search(Q, 10)
@@ -166,8 +166,8 @@ def test_grow_past_60_percent_of_hbm_without_a_transient(hip, oracle):
     tbs = idx.ntotal * d * 2 / (ms * 1e-3) / 1e12
     print(f"scan of the grown index: {ms:.2f} ms per 256-query batch = {tbs:.2f} TB/s")
     assert tbs > 4.8, "the arena-backed rows stream slower than a plain allocation (5.8 TB/s end to end)"
-    # live rows + ONE step (1 GiB) + metadata + the search workspace (~0.4 GB) + allocator slack: well under 3 GiB, where a
+    # live rows + one 16 MiB slab + metadata + the search workspace (~0.4 GB) + allocator slack: under 1.5 GiB, where a
     # reallocating buffer would have peaked at twice the live rows
-    assert peak_over < 3 * (1 << 30), f"peak beyond the live rows: {peak_over / 2**30:.2f} GiB"
+    assert peak_over < 3 * (1 << 29), f"peak beyond the live rows: {peak_over / 2**30:.2f} GiB"
     print(f"grown to {idx.ntotal} rows ({idx.ntotal * d * 2 / 2**30:.1f} GiB live), peak beyond live rows "
           f"{peak_over / 2**30:.2f} GiB, {checks} exactness checks")
