@@ -919,6 +919,23 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
     r = rate(lambda: retriever.batch_invoke(first, k=K), NB, reps)
     r["vs_engine"] = round(r["value"] / engine["value"], 3)
     out["batch_invoke_256_gc_frozen"] = r
+    # (b2) two callers, each batch after batch of 256: one's scan runs while the other's answer becomes Documents
+    def two_callers(n_each):
+        def loop():
+            for _ in range(n_each):
+                retriever.batch_invoke(first, k=K)
+        th = [threading.Thread(target=loop) for _ in range(2)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    two_callers(1)
+    dt2c = two_callers(max(2, reps // 2))
+    out["batch_invoke_256_two_callers"] = {"value": round(2 * max(2, reps // 2) * NB / dt2c, 1), "unit": "queries/s",
+                                           "vs_engine": round(2 * max(2, reps // 2) * NB / dt2c / engine["value"], 3)}
     # (c) one call with 2048 texts: eight scans, each running while the answer before it is mapped
     r = rate(lambda: retriever.batch_invoke(texts, k=K), NQT, max(2, reps // 8), warm=1)
     r["vs_engine"] = round(r["value"] / engine["value"], 3)
