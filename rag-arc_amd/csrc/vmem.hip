@@ -58,12 +58,16 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
   }
   size_t reserve = (reserve_bytes + slab - 1) / slab * slab;
   void* base = nullptr;
-  // 2 MiB-aligned addresses let the driver map the slabs with large page-table fragments (the scan streams the arena at
-  // HBM rate: TLB reach matters); a runtime that refuses the alignment gets its default
-  if (hipMemAddressReserve(&base, reserve, (size_t)2 << 20, nullptr, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    base = nullptr;
-    RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve, 0, nullptr, 0));
+  // Reservations start on the slab grid (address % slab == 0): every piece any arena of this process ever maps then
+  // covers one of the SAME address ranges [k * slab, (k + 1) * slab) — an address range that is freed and reserved again
+  // (another index, another size) is re-mapped with pieces identical to the ones the runtime has seen there (pieces at
+  // other phases of a reused range read back wrong data on this runtime: tests in sequence showed it, see the header).
+  // Slab-aligned addresses also let the driver use large page-table fragments: the scan streams an arena at HBM rate.
+  RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve, slab, nullptr, 0));
+  if (((uintptr_t)base) % slab != 0) {
+    (void)hipMemAddressFree(base, reserve);
+    rarc_set_error("rarc_vmem_create: the runtime returned a reservation off the %zu-byte slab grid", slab);
+    return RARC_E_UNSUPPORTED;
   }
   RarcVmem* v = new (std::nothrow) RarcVmem();
   if (!v) {

@@ -231,10 +231,12 @@ class FlatIndexF16:
             self._rowscale[(had if from_arena else self.ntotal):].fill_(1.0)     # rows not yet written: scale 1, as t.ones() gave
         if self.storage == "f32":
             self._image16 = adopt("image16", self.d_pad * 2, t.float16, self.d_pad, self._image16)
-        # every buffer must cover the same rows: the smallest backing decides (they grow in proportion, so this is `cap`
-        # rounded up to the coarsest step)
+        # every buffer covers the same rows: the smallest backing decides
         n = min(x.shape[0] for x in (self._rows, self._shadow, self._rowscale, self._image16) if x is not None)
         self._rows = self._rows[:n]
+        self._shadow = None if self._shadow is None else self._shadow[:n]
+        self._rowscale = None if self._rowscale is None else self._rowscale[:n]
+        self._image16 = None if self._image16 is None else self._image16[:n]
 
     def memory_bytes(self) -> dict:
         """HBM held by the row buffers: {'live': bytes of the stored rows, 'backed': bytes physically mapped / allocated}."""
