@@ -24,7 +24,9 @@ struct RarcVmemSlab {
 };
 struct RarcVmem {
   int device;
-  char* base;
+  char* base;          // first slab-grid address inside the reservation [va_base, va_base + va_bytes)
+  void* va_base;
+  size_t va_bytes;
   size_t reserved, mapped, slab, gran;   // slab: the largest single physical allocation; gran: the mapping granularity
   std::vector<RarcVmemSlab> slabs;
   std::mutex mu;
@@ -63,20 +65,22 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
   // (another index, another size) is re-mapped with pieces identical to the ones the runtime has seen there (pieces at
   // other phases of a reused range read back wrong data on this runtime: tests in sequence showed it, see the header).
   // Slab-aligned addresses also let the driver use large page-table fragments: the scan streams an arena at HBM rate.
-  RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve, slab, nullptr, 0));
-  if (((uintptr_t)base) % slab != 0) {
-    (void)hipMemAddressFree(base, reserve);
-    rarc_set_error("rarc_vmem_create: the runtime returned a reservation off the %zu-byte slab grid", slab);
-    return RARC_E_UNSUPPORTED;
-  }
+  // (the runtime ignores hipMemAddressReserve's alignment argument — measured: it hands out 2 MiB-aligned ranges — so one
+  // extra slab is reserved and the arena starts at the first grid point inside the range)
+  RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve + slab, slab, nullptr, 0));
+  void* const va_base = base;
+  const size_t va_bytes = reserve + slab;
+  base = (void*)(((uintptr_t)base + slab - 1) / slab * slab);
   RarcVmem* v = new (std::nothrow) RarcVmem();
   if (!v) {
-    (void)hipMemAddressFree(base, reserve);
+    (void)hipMemAddressFree(va_base, va_bytes);
     rarc_set_error("rarc_vmem_create: out of host memory");
     return RARC_E_INVALID;
   }
   v->device = device;
   v->base = (char*)base;
+  v->va_base = va_base;
+  v->va_bytes = va_bytes;
   v->reserved = reserve;
   v->mapped = 0;
   v->slab = slab;
@@ -147,7 +151,7 @@ extern "C" int rarc_vmem_destroy(RarcVmem* v) {
     if (hipMemRelease(sl.handle) != hipSuccess) rc = RARC_E_HIP;
     at += sl.bytes;
   }
-  if (hipMemAddressFree(v->base, v->reserved) != hipSuccess) rc = RARC_E_HIP;
+  if (hipMemAddressFree(v->va_base, v->va_bytes) != hipSuccess) rc = RARC_E_HIP;
   if (rc != RARC_OK) {
     (void)hipGetLastError();
     rarc_set_error("rarc_vmem_destroy: releasing the arena failed");
