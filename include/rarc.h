@@ -582,14 +582,15 @@ int rarc_compact_rows(void* d_rows, int64_t row_bytes, int64_t n_rows, const int
 
 /*
  * Growable device arenas: where `index.add` appends to (encapsulation/database/vector_db/VectorStore_Faiss.py:199-202 —
- * faiss grows a std::vector there).  An arena reserves VIRTUAL address space for the largest size it may reach (no memory)
- * and is backed slab by slab as rows arrive: the base pointer never moves and nothing is copied, so the peak footprint of
- * a growing index is its live rows rounded up to one slab (a reallocating buffer holds old + new: up to 3x).
+ * faiss grows a std::vector there).  An arena owns VIRTUAL addresses for the largest size it may reach (no memory) and is
+ * backed slab by slab as rows arrive: the base pointer never moves and nothing is copied, so the peak footprint of a
+ * growing index is its live rows rounded up to one slab (a reallocating buffer holds old + new: up to 3x).
  * The second kind of object this library allocates (with the tokenizer handle): release it with rarc_vmem_destroy, after
- * the last kernel that reads it.  Every piece of physical memory is one SLAB (slab_bytes, 0 = RARC_VMEM_DEFAULT_SLAB,
- * rounded up to the device's mapping granularity); the reservation is rounded up to whole slabs.  One slab size per
- * process: the first create fixes it and a create with another size returns RARC_E_UNSUPPORTED (this HIP runtime
- * mis-maps pieces of different sizes in reused address ranges — csrc/vmem.hip, tools/vmem_probe.py).
+ * the last kernel that reads it.  Arenas are slab-aligned sub-ranges of ONE address space the first create reserves for
+ * the process and never frees (RARC_VMEM_SPACE_TIB TiB, default 16); every piece of physical memory is one SLAB
+ * (slab_bytes, 0 = RARC_VMEM_DEFAULT_SLAB, rounded up to the device's mapping granularity), ONE slab size per process — a
+ * create with another size returns RARC_E_UNSUPPORTED, a create the space has no room for RARC_E_WORKSPACE.  (What this HIP
+ * runtime does with anything else is written down in csrc/vmem.hip and reproducible with tools/vmem_probe.py.)
  * rarc_vmem_grow(min_bytes): back at least the first min_bytes, in whole slabs (never shrinks; on failure — HBM
  * exhausted — what was mapped stays mapped and usable).  Not tied to a stream: mapping is a host-side operation,
  * visible to later launches.

@@ -136,8 +136,8 @@ class HipRRFusion(FusionMethod):
         keys_b, lens_b, docs = H.rrf_tables(batch, n_lists, max_len)
         dev = torch.device("cuda", self.device)
         nq = len(batch)
-        keys = torch.from_numpy(np.frombuffer(keys_b, dtype=np.int64).reshape(nq, n_lists, max_len)).to(dev)
-        lens = torch.from_numpy(np.frombuffer(lens_b, dtype=np.int32).reshape(nq, n_lists)).to(dev)
+        keys = torch.from_numpy(np.frombuffer(keys_b, dtype=np.int64).reshape(nq, n_lists, max_len).copy()).to(dev)
+        lens = torch.from_numpy(np.frombuffer(lens_b, dtype=np.int32).reshape(nq, n_lists).copy()).to(dev)
         width = min(top_k, n_lists * max_len)
         fk, _, fn = self.fuse_ids(keys, lens, width)
         return H.pick_docs(docs, fk.contiguous().cpu().numpy(), fn.cpu().numpy(), width)

@@ -2,33 +2,85 @@
 //
 // index.add in the reference appends (faiss grows its std::vector: VectorStore_Faiss.py:199-202).  A row buffer in HBM that
 // grows by allocate-bigger-and-copy holds old + new at once — up to 3x the live rows — so a store past a third of the
-// part's memory could not grow.  An arena reserves virtual address space for the largest size it may ever reach
-// (hipMemAddressReserve: costs no memory) and backs it slab by slab (hipMemCreate + hipMemMap + hipMemSetAccess) as rows
-// arrive: the base pointer never moves, nothing is copied, the kernels see one contiguous buffer as before, and the peak
-// footprint is the live rows rounded up to a slab.
+// part's memory could not grow.  An arena owns a range of virtual addresses as large as it may ever get (costs no memory)
+// and backs it slab by slab (hipMemCreate + hipMemMap + hipMemSetAccess) as rows arrive: the base pointer never moves,
+// nothing is copied, the kernels see one contiguous buffer as before, and the peak footprint is the live rows rounded up
+// to a slab.
 //
-// ONE slab size per process, every piece exactly one slab.  Measured on this runtime (ROCm 7.0.2 / HIP 7.0.51831,
-// tools/vmem_probe.py, every sequence in a fresh process): inside one reservation the second mapped piece fixes the size
-// of all later ones (2,30 ok; 2,8,8,8 ok then 6 -> hipErrorInvalidValue; 2,2 then 4 -> invalid), and a reservation
-// whose address range is reused after hipMemAddressFree by pieces of ANOTHER size maps without error but reads back
-// wrong data.  Uniform pieces (any size, power of two or not) behave in every sequence tried, including destroy /
-// re-create.  So: the first rarc_vmem_create of a process fixes the slab size; a later call asking for another is refused.
+// How the address space is managed is dictated by what this runtime (ROCm 7.0.2 / HIP 7.0.51831) does, measured with
+// tools/vmem_probe.py and by running the GPU suite in sequence:
+//   * inside one reservation the second mapped piece fixes the size of all later ones (2,30 MiB ok; 2,8,8,8 ok, then 6 ->
+//     hipErrorInvalidValue; 2,2 then 4 -> invalid);
+//   * an address range that was hipMemAddressFree'd and handed out again by a later hipMemAddressReserve — another size,
+//     another phase — maps without error and then loses writes / reads back stale data (tests passed alone and failed
+//     in sequence; a reservation per arena, however aligned, did not cure it);
+//   * hipMemAddressReserve ignores its alignment argument (2 MiB-aligned ranges whatever is asked).
+// What always behaved is what PyTorch's expandable segments do: ONE reservation that is never freed, pieces of ONE size
+// on one grid, unmapped and mapped again in place.  So: the first rarc_vmem_create reserves one address space for the
+// process (RARC_VMEM_SPACE_TIB TiB, default 16; halved until the runtime grants it), slab-aligned by hand; arenas are
+// slab-aligned sub-ranges of it handed out first-fit and returned (coalesced) on destroy; every piece is one slab.
+#include <map>
 #include <mutex>
 #include <new>
 #include <vector>
 #include "rarc_common.h"
 
-struct RarcVmemSlab {
-  hipMemGenericAllocationHandle_t handle;
-  size_t bytes;
-};
+namespace {
+std::mutex g_mu;
+char* g_base = nullptr;            // first slab-grid address of the process's reservation
+size_t g_bytes = 0, g_slab = 0;    // its size (whole slabs) and THE slab size
+std::map<size_t, size_t> g_free;   // free ranges of the space: offset -> length (bytes, whole slabs), coalesced
+
+int space_init(size_t slab) {      // caller holds g_mu
+  if (g_base) return RARC_OK;
+  size_t tib = 16;
+  if (const char* e = getenv("RARC_VMEM_SPACE_TIB")) {
+    const long v = atol(e);
+    if (v > 0) tib = (size_t)v;
+  }
+  size_t want = tib << 40;
+  void* p = nullptr;
+  while (want >= ((size_t)1 << 36)) {          // give up below 64 GiB
+    if (hipMemAddressReserve(&p, want + slab, 0, nullptr, 0) == hipSuccess) break;
+    (void)hipGetLastError();
+    p = nullptr;
+    want >>= 1;
+  }
+  if (!p) {
+    rarc_set_error("rarc_vmem_create: hipMemAddressReserve refused every size from %zu TiB down to 64 GiB", tib);
+    return RARC_E_HIP;
+  }
+  g_base = (char*)(((uintptr_t)p + slab - 1) / slab * slab);
+  g_bytes = want / slab * slab;
+  g_slab = slab;
+  g_free.clear();
+  g_free[0] = g_bytes;
+  return RARC_OK;
+}
+
+void space_release(size_t off, size_t len) {   // caller holds g_mu
+  auto it = g_free.emplace(off, len).first;
+  auto nx = std::next(it);
+  if (nx != g_free.end() && it->first + it->second == nx->first) {
+    it->second += nx->second;
+    g_free.erase(nx);
+  }
+  if (it != g_free.begin()) {
+    auto pv = std::prev(it);
+    if (pv->first + pv->second == it->first) {
+      pv->second += it->second;
+      g_free.erase(it);
+    }
+  }
+}
+}  // namespace
+
 struct RarcVmem {
   int device;
-  char* base;          // first slab-grid address inside the reservation [va_base, va_base + va_bytes)
-  void* va_base;
-  size_t va_bytes;
-  size_t reserved, mapped, slab, gran;   // slab: the largest single physical allocation; gran: the mapping granularity
-  std::vector<RarcVmemSlab> slabs;
+  char* base;      // = g_base + offset
+  size_t offset;   // of the arena inside the process's address space
+  size_t reserved, mapped, slab, gran;
+  std::vector<hipMemGenericAllocationHandle_t> slabs;   // one handle per mapped slab, in address order
   std::mutex mu;
 };
 
@@ -48,39 +100,39 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
   RARC_HIP_CHECK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
   if (gran == 0) gran = 2u << 20;
   if (slab_bytes == 0) slab_bytes = (size_t)RARC_VMEM_DEFAULT_SLAB;
-  size_t slab = (slab_bytes + gran - 1) / gran * gran;
-  {
-    static std::mutex g_mu;
-    static size_t g_slab = 0;        // the process's one piece size (see the header of this file)
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (g_slab == 0) g_slab = slab;
-    RARC_REQUIRE(g_slab == slab, RARC_E_UNSUPPORTED,
-                 "rarc_vmem_create: this process maps %zu-byte slabs; an arena of %zu-byte slabs cannot coexist with them "
-                 "(HIP runtime: pieces of different sizes in reused address ranges corrupt mappings)", g_slab, slab);
-  }
-  size_t reserve = (reserve_bytes + slab - 1) / slab * slab;
-  void* base = nullptr;
-  // Reservations start on the slab grid (address % slab == 0): every piece any arena of this process ever maps then
-  // covers one of the SAME address ranges [k * slab, (k + 1) * slab) — an address range that is freed and reserved again
-  // (another index, another size) is re-mapped with pieces identical to the ones the runtime has seen there (pieces at
-  // other phases of a reused range read back wrong data on this runtime: tests in sequence showed it, see the header).
-  // Slab-aligned addresses also let the driver use large page-table fragments: the scan streams an arena at HBM rate.
-  // (the runtime ignores hipMemAddressReserve's alignment argument — measured: it hands out 2 MiB-aligned ranges — so one
-  // extra slab is reserved and the arena starts at the first grid point inside the range)
-  RARC_HIP_CHECK(hipMemAddressReserve(&base, reserve + slab, slab, nullptr, 0));
-  void* const va_base = base;
-  const size_t va_bytes = reserve + slab;
-  base = (void*)(((uintptr_t)base + slab - 1) / slab * slab);
+  const size_t slab = (slab_bytes + gran - 1) / gran * gran;
+  const size_t reserve = (reserve_bytes + slab - 1) / slab * slab;
   RarcVmem* v = new (std::nothrow) RarcVmem();
-  if (!v) {
-    (void)hipMemAddressFree(va_base, va_bytes);
-    rarc_set_error("rarc_vmem_create: out of host memory");
-    return RARC_E_INVALID;
+  RARC_REQUIRE(v, RARC_E_INVALID, "rarc_vmem_create: out of host memory");
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int rc = space_init(slab);
+    if (rc == RARC_OK && g_slab != slab) {
+      rarc_set_error("rarc_vmem_create: this process maps %zu-byte slabs; an arena of %zu-byte slabs cannot coexist with "
+                     "them (one piece size per process: see csrc/vmem.hip)", g_slab, slab);
+      rc = RARC_E_UNSUPPORTED;
+    }
+    if (rc == RARC_OK) {
+      auto it = g_free.begin();
+      while (it != g_free.end() && it->second < reserve) ++it;       // first fit
+      if (it == g_free.end()) {
+        rarc_set_error("rarc_vmem_create: no %zu-byte range left in the process's %zu-byte address space (live arenas hold "
+                       "it; RARC_VMEM_SPACE_TIB raises the space, max_rows lowers an index's share)", reserve, g_bytes);
+        rc = RARC_E_WORKSPACE;
+      } else {
+        const size_t off = it->first, len = it->second;
+        g_free.erase(it);
+        if (len > reserve) g_free[off + reserve] = len - reserve;
+        v->offset = off;
+      }
+    }
+    if (rc != RARC_OK) {
+      delete v;
+      return rc;
+    }
   }
   v->device = device;
-  v->base = (char*)base;
-  v->va_base = va_base;
-  v->va_bytes = va_bytes;
+  v->base = g_base + v->offset;
   v->reserved = reserve;
   v->mapped = 0;
   v->slab = slab;
@@ -123,7 +175,7 @@ extern "C" int rarc_vmem_grow(RarcVmem* v, size_t min_bytes) {
       return RARC_E_HIP;
     }
     try {
-      v->slabs.push_back(RarcVmemSlab{h, piece});
+      v->slabs.push_back(h);
     } catch (const std::bad_alloc&) {
       (void)hipMemUnmap(v->base + v->mapped, piece);
       (void)hipMemRelease(h);
@@ -141,20 +193,22 @@ extern "C" size_t rarc_vmem_reserved(const RarcVmem* v) { return v ? v->reserved
 extern "C" size_t rarc_vmem_slab(const RarcVmem* v) { return v ? v->slab : 0; }
 extern "C" size_t rarc_vmem_granularity(const RarcVmem* v) { return v ? v->gran : 0; }
 
-// Unmap and release every slab, free the address range.  The caller makes sure no kernel still reads the arena.
+// Unmap and release every slab, hand the address range back to the process's space (the space itself is never given back
+// to the runtime).  The caller makes sure no kernel still reads the arena.
 extern "C" int rarc_vmem_destroy(RarcVmem* v) {
   if (!v) return RARC_OK;
   int rc = RARC_OK;
-  size_t at = 0;
-  for (const RarcVmemSlab& sl : v->slabs) {
-    if (hipMemUnmap(v->base + at, sl.bytes) != hipSuccess) rc = RARC_E_HIP;
-    if (hipMemRelease(sl.handle) != hipSuccess) rc = RARC_E_HIP;
-    at += sl.bytes;
+  for (size_t i = 0; i < v->slabs.size(); ++i) {
+    if (hipMemUnmap(v->base + i * v->slab, v->slab) != hipSuccess) rc = RARC_E_HIP;
+    if (hipMemRelease(v->slabs[i]) != hipSuccess) rc = RARC_E_HIP;
   }
-  if (hipMemAddressFree(v->va_base, v->va_bytes) != hipSuccess) rc = RARC_E_HIP;
   if (rc != RARC_OK) {
     (void)hipGetLastError();
     rarc_set_error("rarc_vmem_destroy: releasing the arena failed");
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    space_release(v->offset, v->reserved);
   }
   delete v;
   return rc;

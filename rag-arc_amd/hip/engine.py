@@ -49,7 +49,13 @@ class DeviceArena:
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device_index):
             # (slab size 0 = the library's default: ONE size per process, see csrc/vmem.hip)
-            B.check(lib.rarc_vmem_create(self.device_index, int(reserve_bytes), 0, ctypes.byref(handle)), "rarc_vmem_create")
+            rc = lib.rarc_vmem_create(self.device_index, int(reserve_bytes), 0, ctypes.byref(handle))
+            if rc == -3:        # the process's address space is held by arenas nobody uses any more: collect them, once
+                import gc
+
+                gc.collect()
+                rc = lib.rarc_vmem_create(self.device_index, int(reserve_bytes), 0, ctypes.byref(handle))
+            B.check(rc, "rarc_vmem_create")
         self.handle = handle
         self.base = int(lib.rarc_vmem_base(handle))
         self.reserved = int(lib.rarc_vmem_reserved(handle))
