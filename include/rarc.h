@@ -587,7 +587,8 @@ int rarc_compact_rows(void* d_rows, int64_t row_bytes, int64_t n_rows, const int
  * growing index is its live rows rounded up to one slab (a reallocating buffer holds old + new: up to 3x).
  * The second kind of object this library allocates (with the tokenizer handle): release it with rarc_vmem_destroy, after
  * the last kernel that reads it.  Arenas are slab-aligned sub-ranges of ONE address space the first create reserves for
- * the process and never frees (RARC_VMEM_SPACE_TIB TiB, default 16); every piece of physical memory is one SLAB
+ * the process and never frees (RARC_VMEM_SPACE_TIB TiB, default 16; addresses that were backed once are not handed out
+ * again, so the space lasts for that many TiB of slabs mapped over the life of the process); every piece of physical memory is one SLAB
  * (slab_bytes, 0 = RARC_VMEM_DEFAULT_SLAB, rounded up to the device's mapping granularity), ONE slab size per process — a
  * create with another size returns RARC_E_UNSUPPORTED, a create the space has no room for RARC_E_WORKSPACE.  (What this HIP
  * runtime does with anything else is written down in csrc/vmem.hip and reproducible with tools/vmem_probe.py.)

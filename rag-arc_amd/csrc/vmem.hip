@@ -15,10 +15,16 @@
 //     another phase — maps without error and then loses writes / reads back stale data (tests passed alone and failed
 //     in sequence; a reservation per arena, however aligned, did not cure it);
 //   * hipMemAddressReserve ignores its alignment argument (2 MiB-aligned ranges whatever is asked).
-// What always behaved is what PyTorch's expandable segments do: ONE reservation that is never freed, pieces of ONE size
-// on one grid, unmapped and mapped again in place.  So: the first rarc_vmem_create reserves one address space for the
+//   * even inside ONE never-freed reservation with uniform pieces, an address that was unmapped and then mapped again
+//     (a destroyed index's range handed to the next one) lost data now and then: rows written by kernels read back as
+//     zeros ~120 tests into the suite, each test passing alone.
+// The sequences the runtime answers differently from box to box (tools/vmem_probe.py: "2 then 8" maps on one box and
+// fails on the next), so the design uses nothing but what never misbehaved: ONE reservation that is never freed, pieces of
+// ONE size on one grid, and NO ADDRESS EVER MAPPED TWICE.  The first rarc_vmem_create reserves one address space for the
 // process (RARC_VMEM_SPACE_TIB TiB, default 16; halved until the runtime grants it), slab-aligned by hand; arenas are
-// slab-aligned sub-ranges of it handed out first-fit and returned (coalesced) on destroy; every piece is one slab.
+// slab-aligned sub-ranges of it handed out first-fit; a destroyed arena returns the part of its range that was never
+// backed and RETIRES the part that was.  The space therefore lasts for 16 TiB of slabs mapped over the life of the process
+// (a hundred 150 GB indexes); a process that churns through more raises RARC_VMEM_SPACE_TIB.
 #include <map>
 #include <mutex>
 #include <new>
@@ -193,8 +199,9 @@ extern "C" size_t rarc_vmem_reserved(const RarcVmem* v) { return v ? v->reserved
 extern "C" size_t rarc_vmem_slab(const RarcVmem* v) { return v ? v->slab : 0; }
 extern "C" size_t rarc_vmem_granularity(const RarcVmem* v) { return v ? v->gran : 0; }
 
-// Unmap and release every slab, hand the address range back to the process's space (the space itself is never given back
-// to the runtime).  The caller makes sure no kernel still reads the arena.
+// Unmap and release every slab (the memory goes back to the device at once); of the address range, the part that was
+// never backed returns to the process's space, the part that was is retired (see the header).  The caller makes sure no
+// kernel still reads the arena.
 extern "C" int rarc_vmem_destroy(RarcVmem* v) {
   if (!v) return RARC_OK;
   int rc = RARC_OK;
@@ -206,9 +213,9 @@ extern "C" int rarc_vmem_destroy(RarcVmem* v) {
     (void)hipGetLastError();
     rarc_set_error("rarc_vmem_destroy: releasing the arena failed");
   }
-  {
+  if (v->reserved > v->mapped) {   // the never-backed tail is clean address space; [offset, offset + mapped) is retired
     std::lock_guard<std::mutex> lk(g_mu);
-    space_release(v->offset, v->reserved);
+    space_release(v->offset + v->mapped, v->reserved - v->mapped);
   }
   delete v;
   return rc;
