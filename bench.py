@@ -19,6 +19,7 @@ largest power-of-ten row count that does.  The same line also carries, as object
   c5  config 5 end to end: bge-large encoder forward (24 layers, seeded weights) -> fp8 100M x 1024
       sharded scan -> RRF with the supplied lexical list             [every N]
   cpu_baseline  the CPU oracle timed on the host cores               [N = 1]
+  f32  storage="f32" (the reference's row format): 10M x 768, the only mode inside 1e-5 on arbitrary embeddings   [N = 1]
   api  the same indexes reached THROUGH the plugin surface: retriever.batch_invoke / invoke, texts -> Documents   [N = 1]
 Rank 0 prints ONE JSON line.
 """
@@ -56,6 +57,7 @@ def parse(argv=None):
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the storage=f32 leg (10M x 768 fp32 rows)")
     ap.add_argument("--no-api", action="store_true", help="skip the legs through the registered retriever (texts -> Documents)")
     ap.add_argument("--no-lm", action="store_true", help="config 3 without its cross-encoder's LM forward (seeded logits instead)")
     ap.add_argument("--c3-steps", type=int, default=2, help="timed steps of the config-3 leg (one step = 256 x 100 LM prompts, seconds)")
@@ -479,6 +481,13 @@ def main():
         if idx2 is not idx:
             del idx2
 
+    # ---- storage="f32": the reference's own row format, 10M x 768 (one GPU) ---------------------------
+    if world == 1 and a.storage == "f16" and not a.no_f32:
+        free = torch.cuda.mem_get_info(dev)[0]
+        if free > 60 * (1 << 30):
+            result["f32"] = leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank)
+        else:
+            result["f32"] = {"skipped": f"needs 60 GiB of free HBM next to the headline index, {free >> 30} GiB free"}
     # ---- config 5 end to end (every N): encoder forward -> fp8 sharded scan -> RRF ----------------
     if not a.no_c5 and a.storage == "f16":
         del searcher, idx, l_ids, l_sc
@@ -816,6 +825,47 @@ def cpu_baseline(np, idx2, q, ids2, sc2, n2, a):
             "parity_vs_gpu": {"ids_bit_exact": bool(np.array_equal(ref_i, gpu_i)),
                               "scores_bit_exact": bool(np.array_equal(ref_s.view(np.uint32), sc2.cpu().numpy().view(np.uint32))),
                               f"recall_at_{a.k}": round(recall, 6)}}
+
+
+def leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank, rows=10_000_000):
+    """storage="f32": the reference's own row format (fp32 rows in faiss, VectorStore_Faiss.py:170) — the one mode whose
+    scores sit within north_star's 1e-5 of the float64 cosine on ARBITRARY fp32 embeddings (tests/test_gpu_storage_precision.py).
+    The scan streams the rows' fp16 image (2 bytes per element, int8 prefilter with the image's own error bound added to
+    the margin); survivors are rescored canonically from the fp32 rows.  10M x 768, batch 256, k = 100."""
+    idx = FlatIndexF16(a.dim, metric="cosine", device=local_rank, storage="f32", capacity=rows)
+    slab = 1 << 20
+    buf = torch.empty((slab, a.dim), dtype=torch.float32, device=dev)
+    t0 = time.perf_counter()
+    for s0 in range(0, rows, slab):
+        m = min(slab, rows - s0)
+        B.check(lib.rarc_synth_rows_f32(buf.data_ptr(), a.dim, a.dim, s0, m, 1234, 0), "rarc_synth_rows_f32")
+        idx.add(buf[:m])
+    torch.cuda.synchronize()
+    t_ingest = time.perf_counter() - t0
+    del buf
+    q = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev)
+    B.check(lib.rarc_synth_rows_f32(q.data_ptr(), a.dim, a.dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
+    steps, warm = max(a.steps, 20), max(a.warmup, 3)
+    passes = (a.batch + 255) // 256
+    (dt, (ids, sc)), tot, nl = scan_profile(
+        lib, B, ctypes,
+        lambda: timed_loop(torch, dist, lambda: idx.search_async(q, a.k), lambda h: h.result(), steps, warm, False),
+        8 * (steps + warm) * passes + 16)
+    scan_ms = tot / max(1, steps + warm)
+    d_pad = B.padded_dim(a.dim)
+    bytes_img = rows * d_pad * 2
+    beat = idx.verify_batch(q, ids, sc, list(range(0, a.batch, 8)))
+    out = {"workload": f"{rows}x{a.dim} fp32 rows (+ fp16 image for the scan: 6 bytes per element in HBM), batch {a.batch}, top-{a.k}",
+           "value": round(a.batch * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
+           "scan_ms_per_pass": round(scan_ms, 4), "ingest_rows_per_s": round(rows / t_ingest, 1),
+           "rows_beating_kth": int(beat), "queries_verified_by_exact_rescan": len(range(0, a.batch, 8)),
+           "roofline": {"bound": "hbm", "kernel": "rarc_scan_q8_kernel", "achieved": round(bytes_img / (scan_ms * 1e-3) / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_img / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_pass": int(bytes_img),
+                        "end_to_end_frac": round(bytes_img / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+    del idx
+    torch.cuda.empty_cache()
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ the plugin surface
