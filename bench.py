@@ -53,6 +53,9 @@ def parse(argv=None):
                     help="keep the int8 image of the fp16 rows (+50%% HBM): the prefilter scan reads it instead")
     ap.add_argument("--scan", choices=("auto", "q8", "mfma16"), default="auto",
                     help="scan kernel (auto: the engine's choice by shard size)")
+    ap.add_argument("--twin", action="store_true",
+                    help="alternate the batches between the index and a twin() search context on a side stream: the small "
+                         "kernels either side of one batch's scan (prep, seed, finalize, exchange) run under the other's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
@@ -365,6 +368,21 @@ def main():
     idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi, scan=a.scan, storage=a.storage,
                       shadow=a.shadow)
     searcher = ShardedFlatSearch(idx, force_collective=use_dist)
+    if a.twin:
+        class _Alternating:
+            """search_async goes to the index and its twin in turn (two search contexts, two streams)."""
+
+            def __init__(self, contexts):
+                self.contexts, self.i = contexts, 0
+
+            def search_async(self, queries, k):
+                self.i += 1
+                return self.contexts[self.i % len(self.contexts)].search_async(queries, k)
+
+            def __getattr__(self, name):
+                return getattr(self.contexts[0], name)
+
+        searcher = ShardedFlatSearch(_Alternating([idx, idx.twin()]), force_collective=use_dist)
     q = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev)
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), a.dim, a.dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
     torch.cuda.synchronize()
