@@ -590,7 +590,9 @@ int rarc_compact_rows(void* d_rows, int64_t row_bytes, int64_t n_rows, const int
  * the process and never frees (RARC_VMEM_SPACE_TIB TiB, default 16; addresses that were backed once are not handed out
  * again, so the space lasts for that many TiB of slabs mapped over the life of the process); every piece of physical memory is one SLAB
  * (slab_bytes, 0 = RARC_VMEM_DEFAULT_SLAB, rounded up to the device's mapping granularity), ONE slab size per process — a
- * create with another size returns RARC_E_UNSUPPORTED, a create the space has no room for RARC_E_WORKSPACE.  (What this HIP
+ * create with another size returns RARC_E_UNSUPPORTED, a create the space has no room for RARC_E_WORKSPACE.
+ * min_reserve_bytes (0 = reserve_bytes): when no free range holds reserve_bytes, the largest one that holds at least this
+ * much is taken whole — rarc_vmem_reserved reports what the arena got.  (What this HIP
  * runtime does with anything else is written down in csrc/vmem.hip and reproducible with tools/vmem_probe.py.)
  * rarc_vmem_grow(min_bytes): back at least the first min_bytes, in whole slabs (never shrinks; on failure — HBM
  * exhausted — what was mapped stays mapped and usable).  Not tied to a stream: mapping is a host-side operation,
@@ -598,7 +600,7 @@ int rarc_compact_rows(void* d_rows, int64_t row_bytes, int64_t n_rows, const int
  */
 #define RARC_VMEM_DEFAULT_SLAB (16u << 20)
 typedef struct RarcVmem RarcVmem;
-int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_bytes, RarcVmem** out);
+int rarc_vmem_create(int device, size_t reserve_bytes, size_t min_reserve_bytes, size_t slab_bytes, RarcVmem** out);
 int rarc_vmem_grow(RarcVmem* arena, size_t min_bytes);
 void* rarc_vmem_base(const RarcVmem* arena);
 size_t rarc_vmem_mapped(const RarcVmem* arena);

@@ -98,8 +98,12 @@ static hipMemAllocationProp vmem_prop(int device) {
   return p;
 }
 
-extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_bytes, RarcVmem** out) {
-  RARC_REQUIRE(out && reserve_bytes > 0 && device >= 0, RARC_E_INVALID, "rarc_vmem_create: bad argument");
+// reserve_bytes: the address range wanted; min_reserve_bytes (0 = reserve_bytes): the least the caller can live with — when
+// no free range holds reserve_bytes the largest one that holds min_reserve_bytes is taken whole (an index created "as
+// large as the device" does not need the last slab of that; rarc_vmem_reserved says what it got).
+extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t min_reserve_bytes, size_t slab_bytes, RarcVmem** out) {
+  RARC_REQUIRE(out && reserve_bytes > 0 && device >= 0 && min_reserve_bytes <= reserve_bytes, RARC_E_INVALID,
+               "rarc_vmem_create: bad argument");
   *out = nullptr;
   hipMemAllocationProp prop = vmem_prop(device);
   size_t gran = 0;
@@ -107,7 +111,8 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
   if (gran == 0) gran = 2u << 20;
   if (slab_bytes == 0) slab_bytes = (size_t)RARC_VMEM_DEFAULT_SLAB;
   const size_t slab = (slab_bytes + gran - 1) / gran * gran;
-  const size_t reserve = (reserve_bytes + slab - 1) / slab * slab;
+  size_t reserve = (reserve_bytes + slab - 1) / slab * slab;
+  const size_t least = min_reserve_bytes ? (min_reserve_bytes + slab - 1) / slab * slab : reserve;
   RarcVmem* v = new (std::nothrow) RarcVmem();
   RARC_REQUIRE(v, RARC_E_INVALID, "rarc_vmem_create: out of host memory");
   {
@@ -121,9 +126,18 @@ extern "C" int rarc_vmem_create(int device, size_t reserve_bytes, size_t slab_by
     if (rc == RARC_OK) {
       auto it = g_free.begin();
       while (it != g_free.end() && it->second < reserve) ++it;       // first fit
+      if (it == g_free.end()) {                                      // ... else the largest range that holds the minimum
+        auto best = g_free.end();
+        for (auto j = g_free.begin(); j != g_free.end(); ++j)
+          if (j->second >= least && (best == g_free.end() || j->second > best->second)) best = j;
+        if (best != g_free.end()) {
+          it = best;
+          reserve = best->second;
+        }
+      }
       if (it == g_free.end()) {
         rarc_set_error("rarc_vmem_create: no %zu-byte range left in the process's %zu-byte address space (live arenas hold "
-                       "it; RARC_VMEM_SPACE_TIB raises the space, max_rows lowers an index's share)", reserve, g_bytes);
+                       "it; RARC_VMEM_SPACE_TIB raises the space, max_rows lowers an index's share)", least, g_bytes);
         rc = RARC_E_WORKSPACE;
       } else {
         const size_t off = it->first, len = it->second;

@@ -169,7 +169,7 @@ SIGNATURES = {
                                     ctypes.POINTER(c_int64), c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p,
                                     ctypes.POINTER(IoStats)]),
     "rarc_compact_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
-    "rarc_vmem_create": (c_int, [c_int, c_size_t, c_size_t, ctypes.POINTER(c_void_p)]),
+    "rarc_vmem_create": (c_int, [c_int, c_size_t, c_size_t, c_size_t, ctypes.POINTER(c_void_p)]),
     "rarc_vmem_grow": (c_int, [c_void_p, c_size_t]),
     "rarc_vmem_base": (c_void_p, [c_void_p]),
     "rarc_vmem_mapped": (c_size_t, [c_void_p]),

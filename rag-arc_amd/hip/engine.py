@@ -42,19 +42,21 @@ class DeviceArena:
     """A growable HBM buffer on HIP virtual memory (rarc_vmem_*, csrc/vmem.hip): address space reserved up front, backed
     slab by slab as it grows, never moved, never copied.  `view(nbytes)` is a uint8 torch tensor over the first nbytes."""
 
-    def __init__(self, torch, lib, device_index: int, reserve_bytes: int):
+    def __init__(self, torch, lib, device_index: int, reserve_bytes: int, min_reserve_bytes: int = 0):
+        """reserve_bytes of address space; min_reserve_bytes (0 = the same): what the caller can live with when the
+        process's space has no range that large left (`reserved` says what the arena got)."""
         import ctypes
 
         self.torch, self.lib, self.device_index = torch, lib, int(device_index)
         handle = ctypes.c_void_p()
+        args = (self.device_index, int(reserve_bytes), int(min_reserve_bytes), 0)   # slab 0 = the library's (one per process)
         with torch.cuda.device(self.device_index):
-            # (slab size 0 = the library's default: ONE size per process, see csrc/vmem.hip)
-            rc = lib.rarc_vmem_create(self.device_index, int(reserve_bytes), 0, ctypes.byref(handle))
+            rc = lib.rarc_vmem_create(*args, ctypes.byref(handle))
             if rc == -3:        # the process's address space is held by arenas nobody uses any more: collect them, once
                 import gc
 
                 gc.collect()
-                rc = lib.rarc_vmem_create(self.device_index, int(reserve_bytes), 0, ctypes.byref(handle))
+                rc = lib.rarc_vmem_create(*args, ctypes.byref(handle))
             B.check(rc, "rarc_vmem_create")
         self.handle = handle
         self.base = int(lib.rarc_vmem_base(handle))
@@ -204,10 +206,15 @@ class FlatIndexF16:
         that did not come from the arena (rows adopted by add_rows_f16) is copied into it once."""
         t = self.torch
         arena = self._arenas.get(name)
+        if arena is not None and cap * row_bytes > arena.reserved and not self.max_rows:
+            arena = None        # it outgrew a range it had to settle for (see `least` below): a new arena, rows copied once
         if arena is None:
             max_rows = self.max_rows or int(t.cuda.get_device_properties(self.device).total_memory // max(row_bytes, 1))
             max_rows = max(((max_rows + _ROW_ALIGN - 1) // _ROW_ALIGN) * _ROW_ALIGN, cap)
-            arena = self._arenas[name] = DeviceArena(t, self.lib, self.device.index or 0, max_rows * row_bytes)
+            # an explicit max_rows is a promise; "as large as the device" (max_rows = 0) settles for what the space has
+            least = max_rows if self.max_rows else max(cap, min(max_rows, 1 << 20))
+            arena = self._arenas[name] = DeviceArena(t, self.lib, self.device.index or 0, max_rows * row_bytes,
+                                                     least * row_bytes)
         old_mapped = arena.mapped
         arena.grow(cap * row_bytes)
         rows = (arena.mapped // (row_bytes * _ROW_ALIGN)) * _ROW_ALIGN          # whole 32-row tiles of what is backed
