@@ -568,6 +568,23 @@ int rarc_device_to_file(const char* path, int n_seg, const int64_t* h_file_off, 
                         size_t staging_bytes, int n_threads, int flags, void* stream, RarcIoStats* stats);
 
 /*
+ * Exact top-k beyond what the register-resident scans take: rows wider than 1024 padded dimensions (up to 4096) and k up
+ * to 8192 — faiss.IndexFlatIP takes any d and any k (encapsulation/database/vector_db/VectorStore_Faiss.py:101-115, :262-263;
+ * the reference's other embedding source returns 1536- / 3072-d vectors, encapsulation/llm/openai_llm.py:139-161).
+ * The score matrix goes through the encoder's MFMA GEMM one chunk of rows at a time (fp16 scores, never more than 64 MB of
+ * them), a select pass nominates rows against a rising, rigorous threshold, and the finalize rescores the nominees with the
+ * canonical fp32 inner product and orders them (score desc, id asc): ids and scores are the oracle's, bit for bit
+ * (csrc/wide.hip has the bound).  fmt 0: fp16 rows; fmt 2: fp32 rows + their fp16 image (what the GEMM reads; rho >=
+ * ||row - image||, as qmeta[1]).  d_qblock as written by rarc_prep_queries (which takes d_pad up to 4096).  d_status:
+ * uint32 [256], a query whose candidate list filled up carries RARC_Q_OVERFLOW — call again with a larger cand_cap
+ * (cand_cap >= n_rows cannot overflow; it must be at least max(2048, 2k) rounded up to 128).
+ */
+size_t rarc_wide_workspace_bytes(int d_pad, int cand_cap);
+int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, int fmt, int64_t n_rows, int d_pad, float max_norm,
+                     float rho, const void* d_qblock, int nq, int k, int64_t id_base, int64_t* d_out_ids,
+                     float* d_out_scores, uint32_t* d_status, void* d_ws, size_t ws_bytes, int cand_cap, void* stream);
+
+/*
  * Deleting rows of a resident index: stable in-place compaction.  The reference deletes by clearing the index and
  * embedding every surviving text again (encapsulation/database/vector_db/VectorStore_Faiss.py:374-415); the surviving
  * rows are in HBM already, so here they move down over the holes: row i of the result is the i-th surviving row.

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void rarc_ingest_f8_kernel(const float* in, in
 // One block per query slot (all RARC_MAX_QUERIES rows are written; padding rows are zero).  Only the
 // squared-norm has a prescribed order (8 lanes run the canonical chains out of LDS); scaling, the
 // fp16 / int8 copies and the error-bound sums are order-free and use the whole block.
-constexpr int PREP_MAX_D = 2048;
+constexpr int PREP_MAX_D = 4096;   // (rows beyond 1024 padded dimensions take the wide path, wide.hip)
 __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in, int64_t ld_in, int nq, int d,
                                                                 int d_pad, int normalize, float corpus_max_norm,
                                                                 const float* qmeta, float* q32, half_t* q16,

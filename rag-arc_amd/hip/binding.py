@@ -14,7 +14,9 @@ _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _LIB = os.environ.get("RARC_LIBRARY") or os.path.join(_PKG, "lib", "librarc_hip.so")
 
 MAX_QUERIES = 256
-MAX_K = 1024
+MAX_K = 1024          # the register-resident scans; beyond it (and beyond 1024 padded dims): the wide path
+WIDE_MAX_K = 8192
+WIDE_MAX_DPAD = 4096
 DIM_ALIGN = 128
 Q_UNCERTAIN = 1
 Q_OVERFLOW = 2
@@ -168,6 +170,9 @@ SIGNATURES = {
     "rarc_device_to_file": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int64), ctypes.POINTER(c_int64),
                                     ctypes.POINTER(c_int64), c_void_p, c_int64, c_void_p, c_size_t, c_int, c_int, c_void_p,
                                     ctypes.POINTER(IoStats)]),
+    "rarc_wide_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "rarc_search_wide": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_float, c_void_p, c_int, c_int, c_int64,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "rarc_compact_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "rarc_vmem_create": (c_int, [c_int, c_size_t, c_size_t, c_size_t, ctypes.POINTER(c_void_p)]),
     "rarc_vmem_grow": (c_int, [c_void_p, c_size_t]),

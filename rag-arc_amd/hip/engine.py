@@ -129,7 +129,13 @@ class FlatIndexF16:
         if storage in ("f8", "f32") and scan == "mfma16":
             raise ValueError("fp8 / fp32 rows are scanned by the int8-prefilter kernel only")
         limit = 768 if scan == "mfma16" else 1024
-        if self.d_pad > limit:
+        # rows beyond 1024 padded dimensions (up to 4096: the reference's OpenAI embeddings are 1536- / 3072-d) take the
+        # WIDE path — score GEMM in chunks + select + canonical finalize (csrc/wide.hip) — as does k beyond 1024
+        self.wide = self.d_pad > 1024
+        if self.wide and (scan != "auto" or storage == "f8" or shadow or self.d_pad > B.WIDE_MAX_DPAD):
+            raise B.RarcError(f"dim {dim} pads to {self.d_pad}: rows wider than 1024 take the wide path (fp16 / fp32 rows, "
+                              f"scan='auto', at most {B.WIDE_MAX_DPAD} padded dimensions)")
+        if not self.wide and self.d_pad > limit:
             raise B.RarcError(f"dim {dim} pads to {self.d_pad} > {limit}: not supported by the {scan} scan kernel")
         # "q8": int8-prefilter scan (HBM-bound; its error margin costs candidates, which only matters on
         # small shards); "mfma16": fp16 MFMA scan + certificate (tight margin, matrix-pipe bound);
@@ -269,6 +275,8 @@ class FlatIndexF16:
     def _fit_qmeta(self) -> None:
         """Size the quantisation metadata for the current row buffer (keeps what is already there)."""
         t = self.torch
+        if self.wide:
+            return
         fn = self.lib.rarc_quant_meta_floats_f8 if self.storage == "f8" else self.lib.rarc_quant_meta_floats
         need = int(fn(self._rows.shape[0]))
         if self._qmeta is None or self._qmeta.numel() < need:
@@ -279,6 +287,8 @@ class FlatIndexF16:
 
     def _requant(self, first_row: int) -> None:
         """(Re)compute tile scales + residual bound for the tiles touched by rows [first_row, ntotal)."""
+        if self.wide:
+            return            # no int8 prefilter over wide rows: nothing to keep up to date
         self._fit_qmeta()
         if self.storage == "f8":
             B.check(self.lib.rarc_quant_meta_f8(self._rows.data_ptr(), self._rowscale.data_ptr(), self.ntotal, self.d_pad,
@@ -327,6 +337,11 @@ class FlatIndexF16:
                 self.cand_cap_growth_refused = True
                 return self._workspace(k, scale)
             self._ws, self._cap_eff = ws, want
+        self._ensure_qbuf()
+        return self._ws
+
+    def _ensure_qbuf(self) -> None:
+        t = self.torch
         if self._qbuf is None:
             mq = B.MAX_QUERIES
             self._qbuf = dict(
@@ -334,7 +349,6 @@ class FlatIndexF16:
                 status=t.zeros(mq + 1, dtype=t.int32, device=self.device),
                 found=t.empty(1, dtype=t.int32, device=self.device),
             )
-        return self._ws
 
     # "auto": measured crossover of the two scans (768 dims, ms per 256-query batch, int8 vs fp16 MFMA):
     #   1M rows: k=10 0.44 / 0.50, k=50 0.51 / 0.52, k=100 0.56 / 0.53, k=400 0.82 / 0.66;  300K rows: k=10 0.24 / 0.25,
@@ -691,8 +705,7 @@ class FlatIndexF16:
         t = self.torch
         if k < 1:
             raise ValueError("k must be >= 1")
-        if k > B.MAX_K:
-            raise B.RarcError(f"k={k} exceeds the kernel limit {B.MAX_K}")
+        wide = self._takes_wide_path(k)
         self._check_twin()
         with self._lock, t.cuda.device(self.device):
             q = t.as_tensor(queries, dtype=t.float32).to(self.device).contiguous()
@@ -708,8 +721,62 @@ class FlatIndexF16:
             out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
             for s in range(0, nq, B.MAX_QUERIES):
                 e = min(nq, s + B.MAX_QUERIES)
-                self._search_chunk(q[s:e], k, out_ids[s:e], out_sc[s:e], repair)
+                if wide:
+                    self._search_wide_chunk(q[s:e], k, out_ids[s:e], out_sc[s:e])
+                else:
+                    self._search_chunk(q[s:e], k, out_ids[s:e], out_sc[s:e], repair)
             return out_ids, out_sc
+
+    # ------------------------------------------------------------------ wide rows / large k (csrc/wide.hip)
+    def _takes_wide_path(self, k: int) -> bool:
+        """Rows wider than 1024 padded dimensions, or k beyond the register-resident scans' 1024: the chunked-GEMM path."""
+        if not (self.wide or k > B.MAX_K):
+            return False
+        if k > B.WIDE_MAX_K:
+            raise B.RarcError(f"k={k} exceeds the kernel limit {B.WIDE_MAX_K}")
+        if self.storage == "f8" or self.shadow:
+            raise B.RarcError(f"k={k} > {B.MAX_K} takes the wide path, which reads fp16 / fp32 rows (storage={self.storage})")
+        return True
+
+    def _rho(self) -> float:
+        """fp32 storage: >= max ||row32 - image16|| (2^-11 relative per normal half, 2^-25 absolute per subnormal one)."""
+        return float(self.max_norm) * 2.0 ** -11 * 1.001 + 2.0 ** -25 * float(self.d_pad) ** 0.5
+
+    def _search_wide_chunk(self, q, k, out_ids, out_sc) -> None:
+        """<= 256 queries through rarc_search_wide.  The candidate capacity starts at max(16384, 4k) entries per query; a
+        query whose list filled up (rows within the error margin of its k-th best score: near-duplicates) is answered again
+        with four times the capacity, up to the capacity that cannot overflow (one entry per stored row)."""
+        t = self.torch
+        nq = q.shape[0]
+        self._ensure_qbuf()
+        norm = 1 if self.metric == "cosine" else 0
+        mn = max(self.max_norm, 1.0) if norm else self.max_norm
+        stream = self._stream()
+        B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], nq, self.dim, self.d_pad, norm, mn, 0,
+                                           self._qbuf["qblock"].data_ptr(), stream), "rarc_prep_queries")
+        first = ((max(2048, 2 * k) + 127) // 128) * 128
+        cap = max(16384, 4 * k, first)
+        sure = ((self.ntotal + 127) // 128) * 128 + first    # every stored row + the first chunk: cannot overflow
+        status = t.zeros(B.MAX_QUERIES, dtype=t.int32, device=self.device)
+        image = self._image16.data_ptr() if self.storage == "f32" else 0
+        fmt = 2 if self.storage == "f32" else 0
+        rho = self._rho() if self.storage == "f32" else 0.0
+        while True:
+            nbytes = int(self.lib.rarc_wide_workspace_bytes(self.d_pad, cap))
+            if getattr(self, "_wide_ws", None) is None or self._wide_ws.numel() < nbytes:
+                self._wide_ws = None
+                self._wide_ws = t.empty(nbytes, dtype=t.uint8, device=self.device)
+            B.check(self.lib.rarc_search_wide(self._rows.data_ptr(), image, fmt, self.ntotal, self.d_pad, mn, rho,
+                                              self._qbuf["qblock"].data_ptr(), nq, k, self.id_base, out_ids.data_ptr(),
+                                              out_sc.data_ptr(), status.data_ptr(), self._wide_ws.data_ptr(),
+                                              self._wide_ws.numel(), cap, stream), "rarc_search_wide")
+            flagged = bool((status[:nq] != 0).any().item())
+            if not flagged:
+                self.last_repaired = []
+                return
+            if cap >= sure:
+                raise B.RarcError("rarc_search_wide flagged a query at a capacity that holds every row")
+            cap = min(4 * cap, sure)
 
     # ------------------------------------------------------------------ pipelined search
     def search_async(self, queries, k: int, to_host: bool = False) -> "PendingSearch":
@@ -719,8 +786,10 @@ class FlatIndexF16:
         to_host=True also enqueues the copy of the answer into pinned host memory RIGHT BEHIND the search — ahead of
         whatever the caller enqueues next on this stream — so that `.host()` waits for this batch only."""
         t = self.torch
-        if not (1 <= k <= B.MAX_K):
+        if k < 1:
             raise ValueError("k out of range")
+        if self._takes_wide_path(k):       # (the wide path runs to completion: its handle is born finished)
+            return _FinishedSearch(self, *self.search_device(queries, k))
         self._check_twin()
         if self._own_stream is not None and t.cuda.current_stream(self.device) != self._own_stream:
             # a twin: enqueue on its side stream, behind whatever produced the queries on the caller's stream
@@ -798,7 +867,7 @@ class FlatIndexF16:
         first-batch cost (at 100M clustered rows: 77 ms instead of 41) once, at load time, instead of in a user's call.
         A no-op on corpora the default capacity already fits.  Returns the number of capacity doublings it caused."""
         t = self.torch
-        if self.ntotal == 0:
+        if self.ntotal == 0 or self.wide:
             return 0
         with t.cuda.device(self.device):
             n = min(int(n_queries), B.MAX_QUERIES, self.ntotal)
@@ -1061,6 +1130,19 @@ class FlatIndexF16:
                     wrong += int(short.sum())
                     i = j + 1
         return (beating, wrong) if detail else beating + wrong
+
+
+class _FinishedSearch:
+    """search_async over the wide path: the answer is complete when the handle is made."""
+
+    def __init__(self, index, ids, scores):
+        self.index, self.ids, self.scores, self.repaired = index, ids, scores, []
+
+    def result(self):
+        return self.ids, self.scores
+
+    def host(self):
+        return self.index.to_host(self.ids, self.scores)
 
 
 class PendingSearch:
