@@ -19,6 +19,7 @@ largest power-of-ten row count that does.  The same line also carries, as object
   c5  config 5 end to end: bge-large encoder forward (24 layers, seeded weights) -> fp8 100M x 1024
       sharded scan -> RRF with the supplied lexical list             [every N]
   cpu_baseline  the CPU oracle timed on the host cores               [N = 1]
+  wide  10M x 1536 (OpenAI-sized embeddings) through the wide path: chunked score GEMM + select + canonical finalize   [N = 1]
   f32  storage="f32" (the reference's row format): 10M x 768, the only mode inside 1e-5 on arbitrary embeddings   [N = 1]
   api  the same indexes reached THROUGH the plugin surface: retriever.batch_invoke / invoke, texts -> Documents   [N = 1]
 Rank 0 prints ONE JSON line.
@@ -60,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--no-c2", action="store_true")
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
+    ap.add_argument("--no-wide", action="store_true", help="skip the wide-row leg (10M x 1536 through rarc_search_wide)")
     ap.add_argument("--no-f32", action="store_true", help="skip the storage=f32 leg (10M x 768 fp32 rows)")
     ap.add_argument("--no-api", action="store_true", help="skip the legs through the registered retriever (texts -> Documents)")
     ap.add_argument("--no-lm", action="store_true", help="config 3 without its cross-encoder's LM forward (seeded logits instead)")
@@ -506,6 +508,12 @@ def main():
             result["f32"] = leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank)
         else:
             result["f32"] = {"skipped": f"needs 60 GiB of free HBM next to the headline index, {free >> 30} GiB free"}
+    # ---- rows wider than 1024 dimensions: 10M x 1536 through the wide path (one GPU) ----------------------
+    if world == 1 and a.storage == "f16" and not a.no_wide:
+        if torch.cuda.mem_get_info(dev)[0] > 45 * (1 << 30):
+            result["wide"] = leg_wide(torch, lib, B, FlatIndexF16, a, dev, local_rank)
+        else:
+            result["wide"] = {"skipped": "needs 45 GiB of free HBM"}
     # ---- config 5 end to end (every N): encoder forward -> fp8 sharded scan -> RRF ----------------
     if not a.no_c5 and a.storage == "f16":
         del searcher, idx, l_ids, l_sc
@@ -882,6 +890,47 @@ def leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank, rows=
                         "algorithmic_bytes_per_pass": int(bytes_img),
                         "end_to_end_frac": round(bytes_img / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}}
     del idx
+    torch.cuda.empty_cache()
+    return out
+
+
+def leg_wide(torch, lib, B, FlatIndexF16, a, dev, local_rank, rows=10_000_000, dim=1536):
+    """Rows wider than the register-resident scans take (the reference's OpenAI embeddings: 1536-d, openai_llm.py:139-161):
+    the wide path (csrc/wide.hip) — score GEMM on the encoder's MFMA tiles, one chunk of 131072 rows at a time, select against
+    a rigorous threshold, canonical finalize.  10M x 1536 fp16, batch 256, k = 100 and k = 2000."""
+    d_pad = B.padded_dim(dim)
+    buf = torch.empty((rows, d_pad), dtype=torch.float16, device=dev)
+    B.check(lib.rarc_synth_rows_f16(buf.data_ptr(), d_pad, dim, 0, rows, 1234, 0), "rarc_synth_rows_f16")
+    idx = FlatIndexF16(dim, metric="cosine", device=local_rank, growable=False)
+    idx.add_rows_f16(buf, 1.001)
+    q = torch.empty((a.batch, dim), dtype=torch.float32, device=dev)
+    B.check(lib.rarc_synth_rows_f32(q.data_ptr(), dim, dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
+    out = {"workload": f"{rows}x{dim} fp16, batch {a.batch}: rarc_search_wide (chunked score GEMM -> select -> canonical finalize)"}
+    bytes_rows = rows * d_pad * 2
+    flops = 2.0 * 256 * rows * d_pad
+    for k in (a.k, 2000):
+        for _ in range(2):
+            ids, sc = idx.search_device(q, k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            ids, sc = idx.search_device(q, k)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out[f"k{k}"] = {"value": round(a.batch / (ms * 1e-3), 1), "unit": "queries/s", "ms_per_step": round(ms, 3),
+                        "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TF,
+                                     "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),
+                                     "hbm_frac_of_row_bytes": round(bytes_rows / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    # full-size property (parity itself: tests/test_gpu_wide.py, bit-exact vs the oracle up to 200k rows at these widths): an
+    # exact top-k under a total order is a prefix of the exact top-k' for k' > k — two independent runs, different
+    # thresholds and candidate sets, must agree bit for bit on the first k entries
+    ids_h, sc_h = ids.cpu().numpy(), sc.cpu().numpy()
+    ids_k, sc_k = idx.search_device(q, a.k)
+    out["top_k_is_prefix_of_top_2000"] = bool((ids_k.cpu().numpy() == ids_h[:, : a.k]).all()
+                                              and (sc_k.cpu().numpy().view("uint32") == sc_h[:, : a.k].view("uint32")).all())
+    out["descending"] = bool((sc_h[:, :-1] >= sc_h[:, 1:]).all())
+    del idx, buf
     torch.cuda.empty_cache()
     return out
 
