@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 401 /* 0.4.1: RarcEnc32Layer.f1_colmax (FFN1 with its GELU fused into the GEMM epilogue); 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
+#define RARC_VERSION 500 /* 0.5.0: rarc_search_wide (rows to 4096 padded dims, k to 8192), rarc_compact_rows (delete by compaction), rarc_vmem_* (growable arenas), RARC_E_IO / RARC_IO_TRUNCATE; 0.4.1: RarcEnc32Layer.f1_colmax (FFN1 with its GELU fused into the GEMM epilogue); 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
                             * rarc_enc_gemm_zero_bias; 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
                             * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
@@ -40,6 +40,7 @@ extern "C" {
 #define RARC_E_HIP -2         /* a HIP runtime call or kernel launch failed */
 #define RARC_E_WORKSPACE -3   /* workspace too small / misaligned */
 #define RARC_E_UNSUPPORTED -4 /* shape outside what the kernels were built for */
+#define RARC_E_IO -5          /* a file operation failed (open, read, write, fsync: ENOSPC, EIO, a short file ...) */
 
 /* Limits of the fused scan kernels (int8 prefilter: d_pad <= 1024; fp16 scan: d_pad <= 768). */
 #define RARC_MAX_QUERIES 256 /* queries per scan pass (register-resident) */
@@ -544,13 +545,17 @@ int rarc_wordpiece_encode(const RarcWordPiece* wp, const char* text_blob, const 
  *   RARC_IO_DIRECT  also open the file O_DIRECT: chunks whose offset, length and slot are 4096-aligned bypass the page
  *                   cache (storage DMA -> pinned slot -> GPU DMA); a file system without O_DIRECT is served buffered
  *   RARC_IO_FSYNC   rarc_device_to_file: fsync before returning
- * rarc_device_to_file creates the file if needed and never truncates it (the caller writes the header and the small
- * sections itself — see the .rarc layout in DESIGN.md 3); rarc_file_to_device fails if the file is shorter than a segment.
+ *   RARC_IO_TRUNCATE rarc_device_to_file: cut the file at the end of the furthest segment first (a caller overwriting a
+ *                   LONGER file in one call; without it the file is never truncated: the .rarc writer sizes the file, writes
+ *                   its header and small sections itself and lets this call fill the row section — DESIGN.md 3)
+ * rarc_device_to_file creates the file if needed; rarc_file_to_device fails if the file is shorter than a segment.  File
+ * errors (open, read / write, fsync: ENOSPC, EIO ...) return RARC_E_IO, HIP errors RARC_E_HIP.
  * Both are synchronous (the bytes are in place on return; `stream` is drained).  d_capacity_bytes bounds every
  * segment's device range.  `stats` (optional) receives what was moved and how fast.
  */
 #define RARC_IO_DIRECT 1
 #define RARC_IO_FSYNC 2
+#define RARC_IO_TRUNCATE 4
 typedef struct RarcIoStats {
   int64_t bytes;            /* bytes moved */
   double seconds;           /* wall time of the call's transfer phase */

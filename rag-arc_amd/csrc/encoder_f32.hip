@@ -407,6 +407,10 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
       for (int mb = 0; mb < MB; ++mb)
         o[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vs[key * VS + 32 * mb + col], pr[s], o[mb], 0, 0, 0);
     }
+    // (the last O^T MFMA of the key loop is read — accumulators copied out of their AGPRs — right behind the loop's exit
+    //  branch: a window that holds free instructions; the pad sits INSIDE the loop because the copies are placed after
+    //  scheduling and would slip in front of a pad behind it.  tests/codeobj.py follows branches since round 5)
+    RARC_MFMA_SETTLE(o);
   }
   // ---- store: lane (query, hh) holds d = 32mb + 8(r>>2) + 4hh + (r&3) ----
   if (q0 + col < L) {

@@ -257,6 +257,9 @@ __host__ __device__ static inline float rarc_canon_tree(const float a[8]) {
 // 1.5 % of forwards; a build with the accumulators in AGPRs: every forward).  Put this behind the LAST MFMA of a chain whose
 // result VALU code consumes soon: five real wait states on top of whatever the compiler inserts (inline asm is not counted).
 // tests/test_codeobj.py walks every kernel's listing and fails on a window that is short once s_waitcnt counts as zero.
+// The pad is `s_nop 4` = five wait states: it covers a window with up to five free instructions in it (the worst found: three).
+// Where the consumer is a register copy the compiler materialises after scheduling (accumulators leaving their AGPRs at a
+// loop exit), put the pad INSIDE the loop, behind the last MFMA of the body: behind the loop the copies slip in front of it.
 // (Not tied to the accumulator: with an in/out operand hipcc may copy the MFMA result into the operand's register first — a
 //  read in front of the pad.  The two scheduling barriers keep the pad directly behind the MFMA and everything else behind it.)
 #define RARC_MFMA_SETTLE(acc)                  \

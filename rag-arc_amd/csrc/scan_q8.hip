@@ -345,6 +345,10 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         }
         if (ks % CSTEP == CSTEP / 2) convert_chunk(nx, ks / CSTEP, s, dst);
       }
+      // (narrow rows: the chain is short and the pruning reads the scores right behind a branch — a window with free
+      //  instructions in it once the walk of tests/codeobj.py follows branches; the wide instantiations have the next tile's
+      //  conversion between the last MFMA and the first read and are left as measured)
+      if constexpr (D <= 512) RARC_MFMA_SETTLE(c11);
       // as the MFMAs leave them: elements 0-7 = the lane's scores of query block 0 (rows 16 (r >> 2) + 4 rq + (r & 3)), 8-15 = block 1
       return (i32x16){c00[0], c00[1], c00[2], c00[3], c10[0], c10[1], c10[2], c10[3],
                       c01[0], c01[1], c01[2], c01[3], c11[0], c11[1], c11[2], c11[3]};
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
         }
         if (ks % CSTEP == CSTEP / 2) convert_chunk(nx, ks / CSTEP, s, dst);
       }
+      if constexpr (D <= 512) RARC_MFMA_SETTLE(c0);
       return c0;
     }
   };

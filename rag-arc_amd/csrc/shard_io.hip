@@ -49,6 +49,7 @@ struct IoJob {
   std::vector<Chunk> chunks;
   std::atomic<size_t> next{0};
   std::atomic<int> failed{0};
+  std::atomic<int> io_failed{0};   // the failure was a file operation (reported as RARC_E_IO, not RARC_E_HIP)
   std::atomic<int64_t> direct_bytes{0};
   std::atomic<int64_t> file_ns{0}, copy_wait_ns{0};
   char err[256] = "";
@@ -74,10 +75,12 @@ bool xfer_file(IoJob& job, bool direct_ok, bool write, char* buf, int64_t bytes,
                             : pread(fd, buf + done, (size_t)(bytes - done), (off_t)(off + done));
     if (r < 0) {
       if (errno == EINTR) continue;
+      job.io_failed.store(1);
       job.fail(write ? "pwrite" : "pread", strerror(errno));
       return false;
     }
     if (r == 0) {
+      job.io_failed.store(1);
       job.fail(write ? "pwrite" : "pread", "unexpected end of file");
       return false;
     }
@@ -172,6 +175,14 @@ int run(bool to_device, const char* path, int n_seg, const int64_t* file_off, co
   IoJob job;
   job.to_device = to_device;
   int64_t total = 0;
+  try {
+    size_t n_chunks = 0;
+    for (int s = 0; s < n_seg; ++s) n_chunks += bytes[s] > 0 ? (size_t)((bytes[s] + (int64_t)slot_bytes - 1) / (int64_t)slot_bytes) : 0;
+    job.chunks.reserve(n_chunks);
+  } catch (const std::exception&) {
+    rarc_set_error("%s: out of host memory for the chunk list", fn);
+    return RARC_E_INVALID;
+  }
   for (int s = 0; s < n_seg; ++s) {
     RARC_REQUIRE(file_off[s] >= 0 && bytes[s] >= 0 && dev_off[s] >= 0 && dev_off[s] + bytes[s] <= d_capacity, RARC_E_INVALID,
                  "%s: segment %d (file %lld, %lld bytes, device offset %lld) outside the device buffer of %lld bytes", fn, s,
@@ -184,18 +195,27 @@ int run(bool to_device, const char* path, int n_seg, const int64_t* file_off, co
   }
   const int oflags = to_device ? O_RDONLY : (O_WRONLY | O_CREAT);
   job.fd_buf = open(path, oflags | O_CLOEXEC, 0644);
-  RARC_REQUIRE(job.fd_buf >= 0, RARC_E_INVALID, "%s: cannot open %s: %s", fn, path, strerror(errno));
+  RARC_REQUIRE(job.fd_buf >= 0, RARC_E_IO, "%s: cannot open %s: %s", fn, path, strerror(errno));
   if (flags & RARC_IO_DIRECT) job.fd_direct = open(path, oflags | O_CLOEXEC | O_DIRECT, 0644);   // may fail (tmpfs): buffered then
+  int64_t need = 0;      // where the furthest segment ends in the file
+  for (int s = 0; s < n_seg; ++s) need = file_off[s] + bytes[s] > need ? file_off[s] + bytes[s] : need;
   if (to_device) {
-    struct stat sb;
-    int64_t need = 0;
-    for (int s = 0; s < n_seg; ++s) need = file_off[s] + bytes[s] > need ? file_off[s] + bytes[s] : need;
-    if (fstat(job.fd_buf, &sb) != 0 || (int64_t)sb.st_size < need) {
+    struct stat sb = {};
+    const int st_rc = fstat(job.fd_buf, &sb);
+    if (st_rc != 0 || (int64_t)sb.st_size < need) {
+      const int err_no = errno;
       close(job.fd_buf);
       if (job.fd_direct >= 0) close(job.fd_direct);
-      rarc_set_error("%s: %s is shorter (%lld bytes) than the segments ask for (%lld)", fn, path, (long long)sb.st_size, (long long)need);
-      return RARC_E_INVALID;
+      if (st_rc != 0) rarc_set_error("%s: fstat(%s): %s", fn, path, strerror(err_no));
+      else rarc_set_error("%s: %s is shorter (%lld bytes) than the segments ask for (%lld)", fn, path, (long long)sb.st_size, (long long)need);
+      return st_rc != 0 ? RARC_E_IO : RARC_E_INVALID;
     }
+  } else if ((flags & RARC_IO_TRUNCATE) && ftruncate(job.fd_buf, (off_t)need) != 0) {
+    const int err_no = errno;
+    close(job.fd_buf);
+    if (job.fd_direct >= 0) close(job.fd_direct);
+    rarc_set_error("%s: ftruncate(%s, %lld): %s", fn, path, (long long)need, strerror(err_no));
+    return RARC_E_IO;
   }
   job.d_base = (char*)d_base;
   job.staging = (char*)h_staging;
@@ -207,19 +227,30 @@ int run(bool to_device, const char* path, int n_seg, const int64_t* file_off, co
   if (e == hipSuccess) {
     const int n_workers = (int)job.chunks.size() < n_threads ? (job.chunks.empty() ? 0 : (int)job.chunks.size()) : n_threads;
     std::vector<std::thread> th;
-    for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, &job, w);
+    try {               // (thread creation can fail — EAGAIN under a process limit — and must not unwind through extern "C")
+      th.reserve((size_t)n_workers);
+      for (int w = 0; w < n_workers; ++w) th.emplace_back(worker, &job, w);
+    } catch (const std::exception& ex) {
+      job.fail("starting a worker thread", ex.what());     // the workers already running see `failed` and stop
+    }
     for (auto& t : th) t.join();
-    if (!to_device && !job.failed.load() && (flags & RARC_IO_FSYNC) && fsync(job.fd_buf) != 0) job.fail("fsync", strerror(errno));
+    if (!to_device && !job.failed.load() && (flags & RARC_IO_FSYNC) && fsync(job.fd_buf) != 0) {
+      job.io_failed.store(1);
+      job.fail("fsync", strerror(errno));
+    }
   } else {
     job.fail("hipGetDevice", hipGetErrorString(e));
   }
   if (e == hipSuccess && hipStreamSynchronize(job.caller_stream) != hipSuccess) job.fail("hipStreamSynchronize", "caller's stream");
   const int64_t t1 = now_ns();
   if (job.fd_direct >= 0) close(job.fd_direct);
-  if (close(job.fd_buf) != 0 && !to_device && !job.failed.load()) job.fail("close", strerror(errno));
+  if (close(job.fd_buf) != 0 && !to_device && !job.failed.load()) {
+    job.io_failed.store(1);
+    job.fail("close", strerror(errno));
+  }
   if (job.failed.load()) {
     rarc_set_error("%s(%s): %s", fn, path, job.err);
-    rc = RARC_E_HIP;
+    rc = job.io_failed.load() ? RARC_E_IO : RARC_E_HIP;
   }
   if (stats) {
     stats->bytes = total;

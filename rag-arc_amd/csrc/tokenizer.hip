@@ -130,7 +130,10 @@ extern "C" int rarc_wordpiece_create(const char* vocab_blob, size_t blob_bytes, 
                                      RarcWordPiece** out) {
   RARC_REQUIRE(vocab_blob && unk_token && cls_token && sep_token && pad_token && out, RARC_E_INVALID, "rarc_wordpiece_create: null argument");
   RARC_REQUIRE(max_input_chars_per_word > 0, RARC_E_INVALID, "rarc_wordpiece_create: max_input_chars_per_word must be positive");
-  auto* wp = new RarcWordPiece();
+  *out = nullptr;
+  RarcWordPiece* wp = nullptr;
+  try {      // (vocabulary tables: allocation failures must not unwind through extern "C")
+  wp = new RarcWordPiece();
   wp->lower = do_lower_case != 0;
   wp->max_chars = max_input_chars_per_word;
   size_t a = 0;
@@ -188,6 +191,11 @@ extern "C" int rarc_wordpiece_create(const char* vocab_blob, size_t blob_bytes, 
     wp->special_id.swap(id);
     for (const auto& t : wp->specials) wp->special_first[(unsigned char)t[0]] = true;
   }
+  } catch (const std::exception& ex) {
+    delete wp;
+    rarc_set_error("rarc_wordpiece_create: %s", ex.what());
+    return RARC_E_INVALID;
+  }
   *out = wp;
   return RARC_OK;
 }
@@ -201,8 +209,10 @@ extern "C" int rarc_wordpiece_encode(const RarcWordPiece* wp, const char* text_b
                "rarc_wordpiece_encode: need max_length >= 2 and a row stride >= max_length");
   RARC_REQUIRE(n_threads >= 1 && n_threads <= 256, RARC_E_INVALID, "rarc_wordpiece_encode: n_threads must be 1..256");
   std::atomic<int> next{0};
+  std::atomic<int> oom{0};
   constexpr int BLOCK = 32;
   auto work = [&]() {
+    try {
     std::vector<int32_t> ids;
     std::string word, sub;
     ids.reserve((size_t)max_length);
@@ -225,14 +235,28 @@ extern "C" int rarc_wordpiece_encode(const RarcWordPiece* wp, const char* text_b
         h_lens[i] = len;
       }
     }
+    } catch (const std::exception&) {
+      oom.store(1);
+    }
   };
   const int nt = n_texts < n_threads * BLOCK ? (n_texts + BLOCK - 1) / BLOCK : n_threads;
   if (nt <= 1) {
     work();
   } else {
     std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) th.emplace_back(work);
+    bool started_all = true;
+    try {
+      th.reserve((size_t)nt);
+      for (int t = 0; t < nt; ++t) th.emplace_back(work);
+    } catch (const std::exception&) {
+      started_all = false;          // (EAGAIN under a thread limit: the threads that did start finish the work)
+    }
+    if (!started_all && th.empty()) work();
     for (auto& t : th) t.join();
+  }
+  if (oom.load()) {
+    rarc_set_error("rarc_wordpiece_encode: out of host memory");
+    return RARC_E_INVALID;
   }
   return RARC_OK;
 }

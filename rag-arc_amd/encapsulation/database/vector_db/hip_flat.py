@@ -613,19 +613,27 @@ class HipFlatVectorStore(VectorStore):
         os.makedirs(folder_path, exist_ok=True)
         rank, world = self._shard_layout()
         mine = SF.shard_path(folder_path, index_name, rank, world)
-        if rank == 0:   # shard files of an earlier save under another layout must not survive next to this one
-            for old in _shard_files(folder_path, index_name):
-                if old != mine and not _belongs_to(old, index_name, world):
-                    os.unlink(old)
-        self._barrier()
-        eng = self._local_engine()
-        if eng is not None and self.ntotal:
-            self.last_save_stats = eng.save_shard(mine, blocks=self._local_blocks(), rank=rank, world=world,
-                                                  global_ntotal=self.ntotal)
-        elif os.path.exists(mine):
-            # the reference always rewrites the index file (VectorStore_Faiss.py:438); an empty index must not
-            # leave the rows of an earlier save behind for load_local to pick up next to an empty docstore
-            os.unlink(mine)
+        fsync = bool(getattr(self, "durable_saves", False))
+        # Order: every rank writes its new file aside-and-renamed, then the ranks AGREE on the outcome (a rank that failed —
+        # no space, an I/O error — makes every rank raise instead of leaving the others in a barrier), then rank 0
+        # replaces the pickle, and only after that do files of an EARLIER layout go: a failure at any point leaves the
+        # previous save loadable.  (An earlier save under the SAME layout is overwritten file by file, as the reference
+        # overwrites its index file in place, VectorStore_Faiss.py:438.)
+        problem: Optional[BaseException] = None
+        try:
+            eng = self._local_engine()
+            if eng is not None and self.ntotal:
+                self.last_save_stats = eng.save_shard(mine, blocks=self._local_blocks(), rank=rank, world=world,
+                                                      global_ntotal=self.ntotal, fsync=fsync)
+            elif os.path.exists(mine):
+                # the reference always rewrites the index file; an empty index must not leave the rows of an earlier save
+                # behind for load_local to pick up next to an empty docstore
+                os.unlink(mine)
+        except BaseException as exc:  # noqa: BLE001 - reported to every rank below, then re-raised here
+            problem = exc
+        if not self._all_ranks_ok(problem is None):
+            raise RuntimeError(f"save_local: rank {rank} of {world} could not write its shard file"
+                               + (f": {problem}" if problem is not None else " (another rank failed)")) from problem
         if rank == 0:
             meta = {"docstore": self.docstore, "index_to_docstore_id": self.index_to_docstore_id,
                     "index_type": self.index_type, "metric": self.metric, "normalize_L2": self.normalize_L2,
@@ -640,8 +648,24 @@ class HipFlatVectorStore(VectorStore):
             tmp = os.path.join(folder_path, f"{index_name}.pkl.tmp")
             with open(tmp, "wb") as fh:
                 pickle.dump(meta, fh)
+                if fsync:
+                    fh.flush()
+                    os.fsync(fh.fileno())
             os.replace(tmp, os.path.join(folder_path, f"{index_name}.pkl"))
+            if fsync:
+                dfd = os.open(folder_path, os.O_RDONLY)
+                try:
+                    os.fsync(dfd)
+                finally:
+                    os.close(dfd)
+            for old in _shard_files(folder_path, index_name):       # files of an earlier save under ANOTHER layout
+                if not _belongs_to(old, index_name, world):
+                    os.unlink(old)
         self._barrier()
+
+    def _all_ranks_ok(self, ok: bool) -> bool:
+        """Did every rank of a sharded store succeed?  (One process: its own outcome.)"""
+        return ok
 
     @classmethod
     def load_local(cls, folder_path: str, embeddings, index_name: str = "index", **kwargs: Any):

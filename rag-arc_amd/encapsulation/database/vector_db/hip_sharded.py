@@ -237,6 +237,18 @@ class HipShardedFlatVectorStore(HipFlatVectorStore):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1:
             dist.barrier(group=self._group)
 
+    def _all_ranks_ok(self, ok: bool) -> bool:
+        """All-reduce of the ranks' outcomes: a failing rank must not leave the others waiting in a barrier."""
+        import torch
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self._group) > 1):
+            return ok
+        on_gpu = dist.get_backend(self._group) == "nccl"
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=torch.device("cuda", self.device) if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._group)
+        return int(flag.item()) == 0
+
     def _local_engine(self):
         return None if self.index is None else self.index.local
 

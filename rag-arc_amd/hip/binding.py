@@ -64,6 +64,7 @@ class IoStats(ctypes.Structure):
 
 IO_DIRECT = 1
 IO_FSYNC = 2
+IO_TRUNCATE = 4
 
 
 class LmLayer(ctypes.Structure):

@@ -136,6 +136,46 @@ _STORES = ("global_store", "ds_write", "buffer_store", "flat_store", "scratch_st
            "ds_add", "ds_max", "ds_min", "ds_inc")
 
 
+@lru_cache(maxsize=8)
+def disassemble_addr(kernel_substring: str, lib_path: str = LIB) -> Dict[str, List[tuple]]:
+    """{mangled name: [(byte address, instruction text), ...]} — disassemble() with the address llvm-objdump prints in each
+    line's comment, which is what a branch's target (address + 4 + 4 * simm16) is resolved against."""
+    out: Dict[str, List[tuple]] = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for n, image in enumerate(code_objects(lib_path)):
+            if kernel_substring.encode() not in image:
+                continue
+            path = os.path.join(tmp, f"co{n}.o")
+            open(path, "wb").write(image)
+            text = subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", path], check=True,
+                                  capture_output=True, text=True).stdout
+            cur = None
+            for line in text.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+                if m:
+                    cur = m.group(1) if kernel_substring in m.group(1) and not m.group(1).endswith(".kd") else None
+                    if cur is not None:
+                        out[cur] = []
+                    continue
+                if cur is not None and "//" in line:
+                    ins, comment = line.split("//", 1)
+                    a = re.match(r"\s*([0-9A-Fa-f]+):", comment)
+                    if ins.strip() and a:
+                        out[cur].append((int(a.group(1), 16), ins.strip()))
+    return out
+
+
+def _branch_target(addr: int, text: str):
+    """Byte address a PC-relative branch goes to (s_branch / s_cbranch_*: simm16 dwords from the next instruction)."""
+    m = re.match(r"s_c?branch\S*\s+(\d+)", text)
+    if not m:
+        return None
+    imm = int(m.group(1))
+    if imm >= 0x8000:
+        imm -= 0x10000
+    return addr + 4 + 4 * imm
+
+
 def _regs(tok):
     import re
     tok = tok.strip()
@@ -151,51 +191,75 @@ def _operands(text):
     return [t.strip().split()[0] if t.strip() else "" for t in parts[1].split(",")] if len(parts) > 1 else []
 
 
-def mfma_read_windows(lib_path=None, look_ahead=96):
+def mfma_read_windows(lib_path=None, look_ahead=96, max_paths=64):
     """For every MFMA of every kernel whose destination is next touched by something other than the accumulating MFMA of the same
     chain: (kernel, opcode, hard, soft, kind, reader) — `soft` = wait states as hipcc counts them (every instruction one, s_nop
     N is N + 1), `hard` = the same with the free instructions counted as ZERO.  kind: "read" (VALU / LDS / store / permlane / a
     later MFMA's A or B operand), "overwrite", or "srcc" (another MFMA takes it as SrcC into a different destination:
-    interlocked by the hardware, measured)."""
-    import re
+    interlocked by the hardware, measured).
+
+    The walk follows the control flow (round 5): an unconditional branch continues at its target, a conditional one
+    on BOTH sides — the loop-carried window of an MFMA at the bottom of a key loop whose result is read at the loop head is a
+    path like any other.  One record per path that reaches a toucher; a path that runs `look_ahead` instructions (or leaves
+    the kernel) without one ends silently (the result was not consumed that soon)."""
     out = []
-    for name, ins in disassemble("", lib_path or LIB).items():
+    for name, listing in disassemble_addr("", lib_path or LIB).items():
+        ins = [t for _, t in listing]
+        index_of = {a: i for i, (a, _) in enumerate(listing)}
         for n, s in enumerate(ins):
             if not s.startswith("v_mfma"):
                 continue
             op, dst = s.split()[0], _regs(_operands(s)[0])
-            soft = hard = 0
-            for t in ins[n + 1: n + 1 + look_ahead]:
-                o, kind = _operands(t), None
-                if t.startswith("v_mfma"):
-                    d2, a, b = _regs(o[0]), _regs(o[1]), _regs(o[2])
-                    c = _regs(o[3]) if len(o) > 3 else set()
-                    if (a | b) & dst:
-                        kind = "read"
-                    elif c & dst and d2 != dst:
-                        kind = "srcc"
-                    elif d2 == dst:
-                        break                      # the chain goes on: the later MFMA is analysed in its own right
-                    elif d2 & dst:
-                        kind = "overwrite"
-                else:
-                    srcs = set()
-                    whole = t.startswith(_STORES) or t.startswith("v_cmp") or t.startswith("v_permlane") or t.startswith("v_swap")
-                    for idx, tok in enumerate(o):
-                        if idx or whole:
-                            srcs |= _regs(tok)
-                    if srcs & dst:
-                        kind = "read"
-                    elif o and _regs(o[0]) & dst and not t.startswith(_STORES):
-                        kind = "overwrite"
-                if kind:
-                    out.append((name, op, hard, soft, kind, t[:70]))
-                    break
-                m = re.match(r"s_nop (\d+)", t)
-                w = int(m.group(1)) + 1 if m else 1
-                soft += w
-                if not t.startswith(_FREE):
-                    hard += w
-                if t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc")):
-                    break
+            stack, seen, paths = [(n + 1, 0, 0, 0)], {}, 0      # (instruction index, soft, hard, instructions walked)
+            while stack and paths < max_paths:
+                i, soft, hard, steps = stack.pop()
+                while True:
+                    if i >= len(ins) or steps >= look_ahead or seen.get(i, 1 << 30) <= hard:
+                        break
+                    seen[i] = hard
+                    t = ins[i]
+                    o, kind = _operands(t), None
+                    if t.startswith("v_mfma"):
+                        d2, a, b = _regs(o[0]), _regs(o[1]), _regs(o[2])
+                        c = _regs(o[3]) if len(o) > 3 else set()
+                        if (a | b) & dst:
+                            kind = "read"
+                        elif c & dst and d2 != dst:
+                            kind = "srcc"
+                        elif d2 == dst:
+                            break                      # the chain goes on: the later MFMA is analysed in its own right
+                        elif d2 & dst:
+                            kind = "overwrite"
+                    else:
+                        srcs = set()
+                        whole = t.startswith(_STORES) or t.startswith("v_cmp") or t.startswith("v_permlane") or t.startswith("v_swap")
+                        for idx, tok in enumerate(o):
+                            if idx or whole:
+                                srcs |= _regs(tok)
+                        if srcs & dst:
+                            kind = "read"
+                        elif o and _regs(o[0]) & dst and not t.startswith(_STORES):
+                            kind = "overwrite"
+                    if kind:
+                        out.append((name, op, hard, soft, kind, t[:70]))
+                        paths += 1
+                        break
+                    m = re.match(r"s_nop (\d+)", t)
+                    w = int(m.group(1)) + 1 if m else 1
+                    soft += w
+                    if not t.startswith(_FREE):
+                        hard += w
+                    steps += 1
+                    if t.startswith(("s_endpgm", "s_setpc", "s_swappc")):
+                        break
+                    if t.startswith(("s_cbranch", "s_branch")):
+                        target = index_of.get(_branch_target(listing[i][0], t))
+                        if t.startswith("s_cbranch") and target is not None:
+                            stack.append((target, soft, hard, steps))      # taken; the fall-through goes on below
+                        elif t.startswith("s_branch"):
+                            if target is None:
+                                break
+                            i = target
+                            continue
+                    i += 1
     return out
