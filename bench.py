@@ -517,6 +517,9 @@ def main():
     # ---- config 5 end to end (every N): encoder forward -> fp8 sharded scan -> RRF ----------------
     if not a.no_c5 and a.storage == "f16":
         del searcher, idx, l_ids, l_sc
+        import gc
+
+        gc.collect()
         torch.cuda.empty_cache()
         c5 = leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, shard_range, split_range, a,
                     world, rank, local_rank, dev, use_dist)
@@ -1126,6 +1129,10 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
     if tmp is not None:
         registrator.registrations.pop("rarc_api_bench", None)
         tmp.cleanup()
+    # the store, its coalescer and the retrievers hold each other in cycles: collect them now, or the index they adopted
+    # (153.6 GB at 100M rows) stays allocated under the legs that follow
+    del store, retriever, mp, fused, single, answers, docs, lex_docs
+    gc.collect()
     return out
 
 
