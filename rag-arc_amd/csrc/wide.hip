@@ -109,23 +109,54 @@ __global__ __launch_bounds__(256) void wide_select_kernel(const uint16_t* __rest
                                                           uint32_t* count, uint32_t cap, uint32_t* status) {
   const int tid = threadIdx.x;
   const int qg = tid & 31;                       // queries [8 qg, 8 qg + 8)
-  float t[8];
+  half_t t[8];                                   // the thresholds rounded DOWN to fp16: a pre-screen on the raw halves (never rejects what the fp32 threshold takes)
+  half_t tmin = (half_t)65504.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) t[j] = thr[8 * qg + j];
-  for (uint32_t r = blockIdx.x * 8 + (tid >> 5); r < m_rows; r += gridDim.x * 8) {
-    if (r >= n_valid) break;                     // rows past the shard's end (zero padding of the last block)
-    const half8 s8 = *(const half8*)(scores + (size_t)r * WIDE_NQ + 8 * qg);
+  for (int j = 0; j < 8; ++j) {
+    const float tf = thr[8 * qg + j];
+    half_t h = (half_t)tf;                       // round to nearest ...
+    if ((float)h > tf && tf > -65504.f) h = __builtin_bit_cast(half_t, (uint16_t)(__builtin_bit_cast(uint16_t, h) + ((float)h > 0.f ? -1 : 1)));   // ... then down to <= tf
+    if (!(tf > -65504.f)) h = (half_t)-65504.f;  // -inf: everything passes (scores are finite)
+    if (tf > 65504.f) h = (half_t)65504.f;       // +inf (padding queries): nothing finite reaches it — handled below
+    t[j] = h;
+    tmin = h < tmin ? h : tmin;
+  }
+  const bool dead = thr[8 * qg] > 65504.f && thr[8 * qg + 7] > 65504.f;   // (a whole group of padding queries)
+  auto take = [&](uint32_t r, const half8& s8) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float s = (float)s8[j];
-      if (s >= t[j]) {
+      if (s8[j] >= t[j]) {
+        const float s = (float)s8[j];
         const uint32_t q = 8 * qg + j;
-        const uint32_t pos = atomicAdd(&count[q], 1u);
-        if (pos < cap) cand[(size_t)q * cap + pos] = rarc_candkey(s, row0 + r);
-        else atomicOr(&status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
+        if (s >= thr[q]) {                       // the exact (fp32) threshold decides: the fp16 one only pre-screens
+          const uint32_t pos = atomicAdd(&count[q], 1u);
+          if (pos < cap) cand[(size_t)q * cap + pos] = rarc_candkey(s, row0 + r);
+          else atomicOr(&status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
+        }
       }
     }
+  };
+  // four rows in flight per thread (the pass is a pure stream of 16-byte loads: 64 MB per chunk)
+  const uint32_t stride = gridDim.x * 8;
+  uint32_t r = blockIdx.x * 8 + (tid >> 5);
+  for (; r + 3 * stride < n_valid; r += 4 * stride) {
+    half8 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *(const half8*)(scores + (size_t)(r + u * stride) * WIDE_NQ + 8 * qg);
+    if (dead) continue;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      half_t mx = v[u][0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) mx = v[u][j] > mx ? v[u][j] : mx;
+      if (mx >= tmin) take(r + u * stride, v[u]);
+    }
   }
+  for (; r < n_valid; r += stride) {
+    const half8 s8 = *(const half8*)(scores + (size_t)r * WIDE_NQ + 8 * qg);
+    if (!dead) take(r, s8);
+  }
+  (void)m_rows;
 }
 
 // k-th largest 32-bit value among n words read through `at(i)` by the whole block: four rounds of an 8-bit radix
@@ -328,6 +359,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
   uint32_t *ccur = w.count, *cother = w.count2;
   int64_t at = 0;
   int64_t chunk = first;
+  int n_chunk = 0;
   while (at < n_rows) {
     int64_t m = n_rows - at < chunk ? n_rows - at : chunk;
     const int64_t m_full = m / 128 * 128;
@@ -350,12 +382,18 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
     hipLaunchKernelGGL(wide_select_kernel, dim3(grid), dim3(256), 0, s, w.scores, m_sel, (uint32_t)at, (uint32_t)m, w.thr, cur, ccur,
                        (uint32_t)cand_cap, d_status);
     RARC_HIP_CHECK(hipGetLastError());
-    hipLaunchKernelGGL(wide_tighten_kernel, dim3(WIDE_NQ), dim3(1024), 0, s, cur, other, ccur, cother, (uint32_t)cand_cap, (uint32_t)k,
-                       w.eps, w.thr);
-    RARC_HIP_CHECK(hipGetLastError());
-    { uint64_t* t = cur; cur = other; other = t; }
-    { uint32_t* t = ccur; ccur = cother; cother = t; }
     at += m;
+    // the threshold is raised (and the lists cut back) after every chunk while the chunks still grow, then after every
+    // fourth: a full-size chunk adds a handful of rows to a list (k·131072/n), the radix select over it costs what a
+    // third of the chunk's GEMM does
+    ++n_chunk;
+    if (chunk < WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {
+      hipLaunchKernelGGL(wide_tighten_kernel, dim3(WIDE_NQ), dim3(1024), 0, s, cur, other, ccur, cother, (uint32_t)cand_cap,
+                         (uint32_t)k, w.eps, w.thr);
+      RARC_HIP_CHECK(hipGetLastError());
+      { uint64_t* t = cur; cur = other; other = t; }
+      { uint32_t* t = ccur; ccur = cother; cother = t; }
+    }
     chunk = chunk * 8 < WIDE_CHUNK ? chunk * 8 : WIDE_CHUNK;
   }
   uint32_t pow2 = 1;
