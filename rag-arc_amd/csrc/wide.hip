@@ -16,7 +16,7 @@
 // >= a_k - eps, so the true k-th best canonical score L >= a_k - eps, and a row with canonical score >= L has s >= a_k - 2 eps:
 // nothing below thr = a_k - 2 eps can be in the answer, ever (a_k only rises).  The candidates that reach the finalize
 // therefore contain every row with canonical score >= L, ties included; their canonical scores are computed in the
-// oracle's order (8 chains + tree) and ranked by (score desc, id asc).  The chunks grow 8x from a first one of max(2048,
+// oracle's order (8 chains + tree) and ranked by (score desc, id asc).  The chunks double from a first one of max(2048,
 // 2k) rows, so the list of a query holds its k best plus a margin of rows, not a share of the corpus.  A candidate list
 // that fills up sets the query's status word (the caller re-runs with a larger capacity; capacity >= n cannot overflow).
 //
@@ -106,9 +106,21 @@ __global__ __launch_bounds__(256) void wide_eps_kernel(const float* q32, const u
 // margin — and the whole first chunk, which is what sizes it).
 __global__ __launch_bounds__(256) void wide_select_kernel(const uint16_t* __restrict__ scores, uint32_t m_rows, uint32_t row0,
                                                           uint32_t n_valid, const float* __restrict__ thr, uint64_t* cand,
-                                                          uint32_t* count, uint32_t cap, uint32_t* status) {
+                                                          uint32_t* count, uint32_t cap, uint32_t* status, uint32_t nq, int first) {
   const int tid = threadIdx.x;
   const int qg = tid & 31;                       // queries [8 qg, 8 qg + 8)
+  if (first) {
+    // the shard's first chunk: no threshold yet, every row is a candidate of every live query — its place in the list is
+    // its row number (n_valid <= cap), no counter to fight over
+    for (uint32_t r = blockIdx.x * 8 + (tid >> 5); r < n_valid; r += gridDim.x * 8) {
+      const half8 s8 = *(const half8*)(scores + (size_t)r * WIDE_NQ + 8 * qg);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((uint32_t)(8 * qg + j) < nq) cand[(size_t)(8 * qg + j) * cap + r] = rarc_candkey((float)s8[j], row0 + r);
+    }
+    if (blockIdx.x == 0 && (uint32_t)tid < nq) count[tid] = n_valid;
+    return;
+  }
   half_t t[8];                                   // the thresholds rounded DOWN to fp16: a pre-screen on the raw halves (never rejects what the fp32 threshold takes)
   half_t tmin = (half_t)65504.f;
 #pragma unroll
@@ -380,7 +392,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
     const uint32_t m_sel = (uint32_t)((m + 127) / 128 * 128);
     const int grid = (int)((m + 7) / 8 < 2048 ? (m + 7) / 8 : 2048);
     hipLaunchKernelGGL(wide_select_kernel, dim3(grid), dim3(256), 0, s, w.scores, m_sel, (uint32_t)at, (uint32_t)m, w.thr, cur, ccur,
-                       (uint32_t)cand_cap, d_status);
+                       (uint32_t)cand_cap, d_status, (uint32_t)nq, at == 0 ? 1 : 0);
     RARC_HIP_CHECK(hipGetLastError());
     at += m;
     // the threshold is raised (and the lists cut back) after every chunk while the chunks still grow, then after every
@@ -394,7 +406,9 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
       { uint64_t* t = cur; cur = other; other = t; }
       { uint32_t* t = ccur; ccur = cother; cother = t; }
     }
-    chunk = chunk * 8 < WIDE_CHUNK ? chunk * 8 : WIDE_CHUNK;
+    // chunks DOUBLE up to the full size: under the k-th best score of the S rows seen so far a chunk of S more rows lets
+    // about k of them through (growing 8x it was 7k: for k in the thousands that filled the lists)
+    chunk = chunk * 2 < WIDE_CHUNK ? chunk * 2 : WIDE_CHUNK;
   }
   uint32_t pow2 = 1;
   while (pow2 < (uint32_t)k) pow2 <<= 1;
