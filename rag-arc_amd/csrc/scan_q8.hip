@@ -127,6 +127,7 @@ __device__ __forceinline__ int q8_all16(const q8_i32x16& a) {
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
 // 8 = no threshold refresh, 16 = no conversion, 32768 = fp8: converted but not written to LDS, 32 = prune fast path only, 64 = never flush,
 // 256 = no ping-pong between the wave groups, 512 = barrier at the end of the iteration where EB would put it behind the matrix phase, 1024 = s_memtime timeline of workgroup 0 into p.dbg,
+// 65536 = waves 4-7 issue no MFMAs (fp8 / shadow form: half the matrix work per CU, everything else unchanged — round 5's overlap question),
 // 16384 = every survivor updates the histogram, 4096 = survivors walked per lane (no LDS transposition), 8192 = parked scores walked at once (no batching), 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
 //
 // Vector-memory discipline.  The prefetched tile registers are consumed with counted waits
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       constexpr int PF = (D <= 768) ? 2 : Q8_BIG_PF;     // k steps of 64 read ahead (two fragments each)
       constexpr int CSTEP = KS2 / CPT;           // one chunk converted every CSTEP steps (KS2 = 4·CPT for fp8)
       i32x4 a0[PF], a1[PF];
-      if (!(ABL & 4)) {
+      if (!(ABL & 4) && !((ABL & 65536) && wave >= 4)) {
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
           a0[i] = *(const i32x4*)(a_base + 64 * i);
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
       }
 #pragma unroll
       for (int ks = 0; ks < KS2; ++ks) {
-        if (!(ABL & 4)) {
+        if (!(ABL & 4) && !((ABL & 65536) && wave >= 4)) {
           c00 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[ks % PF], qf[2 * ks], c00, 0, 0, 0);
           c01 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[ks % PF], qf[2 * ks + 1], c01, 0, 0, 0);
           c10 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[ks % PF], qf[2 * ks], c10, 0, 0, 0);
@@ -802,6 +803,9 @@ static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
       if (abl == 21) return launch_scan_q8<D, FMT, 21>(p, grid, s);          // fetch + LDS write only
       if (abl == 32769) return launch_scan_q8<D, FMT, 32769>(p, grid, s);    // converted but not written to LDS, MFMAs on stale LDS, no pruning
       if (abl == 32773) return launch_scan_q8<D, FMT, 32773>(p, grid, s);    // fetch + conversion only
+      // round 5: do the streaming phase and the matrix phase overlap?  half the MFMAs (waves 4-7 issue none), with and without pruning
+      if (abl == 65536) return launch_scan_q8<D, FMT, 65536>(p, grid, s);
+      if (abl == 65537) return launch_scan_q8<D, FMT, 65537>(p, grid, s);
     }
   }
 #endif
