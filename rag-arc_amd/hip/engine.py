@@ -18,6 +18,7 @@ from . import binding as B
 _ROW_ALIGN = 32  # the scan reads whole 32-row tiles
 _IO_RING: dict = {}            # the process's pinned staging ring for shard files (FlatIndexF16._io_staging)
 _IO_LOCK = threading.Lock()    # one shard-file transfer at a time per process: they share the ring
+_PIN_LOCK = threading.Lock()   # the pinned answer-staging rings (FlatIndexF16._pinned_pair) are handed out one at a time
 
 
 def _torch():
@@ -690,15 +691,41 @@ class FlatIndexF16:
         search on its stream and ONE event is waited for (two pageable `.cpu()` calls are two synchronous staged copies).
         The arrays own their pinned block (torch's caching host allocator recycles it when they die)."""
         t = self.torch
-        with t.cuda.device(self.device):
-            h_i = t.empty(tuple(ids.shape), dtype=t.int64, pin_memory=True)
-            h_s = t.empty(tuple(scores.shape), dtype=t.float32, pin_memory=True)
+        with _PIN_LOCK, t.cuda.device(self.device):        # (callers may be pool threads: one staging pair, one copy at a time)
+            h_i, h_s = self._pinned_pair(ids.shape[0], ids.shape[1])
             h_i.copy_(ids, non_blocking=True)
             h_s.copy_(scores, non_blocking=True)
             done = t.cuda.Event()
             done.record()
             done.synchronize()
-        return h_s.numpy(), h_i.numpy()
+            return h_s.numpy().copy(), h_i.numpy().copy()  # (the caller owns its arrays: the staging pair is reused)
+
+    def _pinned_flag(self):
+        """One pinned int32 for a batch's status word, from a ring of 64 (a handle holds its word until result())."""
+        t = self.torch
+        ring = self.__dict__.setdefault("_flag_ring", {"at": 0, "buf": None})
+        if ring["buf"] is None:
+            ring["buf"] = t.zeros(64, dtype=t.int32, pin_memory=True)
+        ring["at"] = (ring["at"] + 1) % 64
+        return ring["buf"][ring["at"]: ring["at"] + 1]
+
+    PINNED_RING = 6     # staging pairs per index: more than the searches a caller keeps in flight (two) plus the one being mapped
+
+    def _pinned_pair(self, nq: int, k: int):
+        """A pinned (ids int64 [nq][k], scores fp32 [nq][k]) staging pair from the index's ring.  Allocating pinned memory
+        per search is what NOT to do: hipHostMalloc takes milliseconds and waits for the device — measured as the eight
+        scans of a 2048-query call running one after the other (0.82 of the engine where two callers reached 0.96)."""
+        t = self.torch
+        ring = self.__dict__.setdefault("_pin_ring", {"at": 0, "slots": []})      # (shared with the index's twins)
+        if len(ring["slots"]) < self.PINNED_RING:
+            ring["slots"].append(None)
+        ring["at"] = (ring["at"] + 1) % len(ring["slots"])
+        slot = ring["slots"][ring["at"]]
+        need = int(nq) * int(k)
+        if slot is None or slot[0].numel() < need:
+            cap = max(need, B.MAX_QUERIES * 128)
+            slot = ring["slots"][ring["at"]] = (t.empty(cap, dtype=t.int64, pin_memory=True), t.empty(cap, dtype=t.float32, pin_memory=True))
+        return slot[0][:need].view(nq, k), slot[1][:need].view(nq, k)
 
     def search_device(self, queries, k: int, repair: bool = True):
         """Same as search() but returns device tensors (ids int64, scores fp32)."""
@@ -805,8 +832,7 @@ class FlatIndexF16:
             out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
             out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
             parts = []
-            h_ids = t.empty((nq, k), dtype=t.int64, pin_memory=True) if to_host else None
-            h_sc = t.empty((nq, k), dtype=t.float32, pin_memory=True) if to_host else None
+            h_ids, h_sc = self._pinned_pair(nq, k) if to_host else (None, None)
             for s0 in range(0, nq, B.MAX_QUERIES):
                 e0 = min(nq, s0 + B.MAX_QUERIES)
                 status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this launch's own words
@@ -816,7 +842,7 @@ class FlatIndexF16:
                     h_sc[s0:e0].copy_(out_sc[s0:e0], non_blocking=True)
                 # the batch's one status word goes to pinned host memory behind the search, with an event of its
                 # own: result() waits for THIS batch only, not for whatever was enqueued after it
-                flag_h = t.empty(1, dtype=t.int32, pin_memory=True)
+                flag_h = self._pinned_flag()
                 flag_h.copy_(status[B.MAX_QUERIES:], non_blocking=True)
                 done = t.cuda.Event()
                 done.record()
@@ -1187,7 +1213,8 @@ class PendingSearch:
     def host(self):
         """result() as numpy (scores fp32 [nq][k], ids int64 [nq][k]) through pinned memory.  With to_host=True the copy
         was enqueued behind the search and is complete once the batch's event is (nothing later on the stream is waited
-        for); a repaired batch — rare — is copied again."""
+        for); a repaired batch — rare — is copied again.  The arrays of a to_host=True batch are VIEWS of the index's
+        staging ring: consume (or copy) them before PINNED_RING - 1 more batches are enqueued."""
         ids, scores = self.result()
         if self.host_copy is not None and not self.repaired:
             return self.host_copy[1].numpy(), self.host_copy[0].numpy()
