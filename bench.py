@@ -1088,6 +1088,22 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
     out["threads_256_invoke"] = {"value": round(NB / dt, 1), "unit": "queries/s", "wall_ms": round(dt * 1e3, 3),
                                  "scans": launches,
                                  "equal_batch": bool(all([d.id for d in x] == [d.id for d in y] for x, y in zip(res, answers)))}
+    # (e2) 256 coroutines, one ainvoke each, from one event loop: no thread per caller (hip_flat._AsyncFront)
+    import asyncio
+
+    async def astorm():
+        return await asyncio.gather(*[retriever.ainvoke(t, k=K) for t in first])
+
+    asyncio.run(astorm())
+    l0 = store._async_front().launches
+    t0 = time.perf_counter()
+    n_rep = 3 if big else 10
+    for _ in range(n_rep):
+        ares = asyncio.run(astorm())
+    dta = (time.perf_counter() - t0) / n_rep
+    out["coroutines_256_ainvoke"] = {"value": round(NB / dta, 1), "unit": "queries/s", "wall_ms": round(dta * 1e3, 3),
+                                     "scans": round((store._async_front().launches - l0) / n_rep, 2),
+                                     "equal_batch": bool(all([d.id for d in x] == [d.id for d in y] for x, y in zip(ares, answers)))}
     # (f) one caller, one query at a time: latency
     lat = []
     for i in range(30 if big else 300):

@@ -244,3 +244,55 @@ def test_two_rank_sharded_store_equals_single_store(tmp_path):
             one, many, scored = pickle.load(fh)
         assert one == want and many == want, f"rank {rank}"
         assert scored == want_scored and len(scored[0]) == 358
+
+
+def test_256_coroutines_share_scans_without_a_thread_each():
+    """`ainvoke` from one event loop: the callers enqueue and await, ONE worker thread answers them in a few scans — with
+    the answers of `invoke`, the async quirks of the retriever kept (no default k, no truncation: dense.py:176-218), and a
+    caller whose query cannot be answered failing alone."""
+    import asyncio
+
+    class Picky(_BatchingHashEmbeddings):
+        def embed_queries(self, texts):
+            if any("poison" in t for t in texts):
+                raise KeyError("poison")
+            return super().embed_queries(texts)
+
+        def embed_query(self, text):
+            if "poison" in text:
+                raise KeyError("poison")
+            return super().embed_query(text)
+
+    emb = Picky(64)
+    store = _store(emb=emb)
+    store.index.delay = 0.02
+    r = VectorStoreRetriever(store)
+    queries = [f"question {i}" for i in range(256)]
+    before_threads = threading.active_count()
+
+    async def storm():
+        peak = [0]
+
+        async def one(q):
+            out = await r.ainvoke(q, k=6)
+            peak[0] = max(peak[0], threading.active_count())
+            return out
+
+        return await asyncio.gather(*[one(q) for q in queries]), peak[0]
+
+    got, peak = asyncio.run(storm())
+    assert [[d.id for d in docs] for docs in got] == [[d.id for d in r.invoke(q, k=6)] for q in queries]
+    assert store.index.launches - 256 <= 6, store.index.batch_sizes[:8]        # (the 256 invokes above ran one scan each)
+    assert peak <= before_threads + 2, "the async twins started a thread per caller"
+    assert store._afront.served == 256 and store._afront.launches <= 6
+
+    async def mixed():
+        return await asyncio.gather(*[r.ainvoke(q, k=3) for q in ["question 1", "poison pill", "question 2"]], return_exceptions=True)
+
+    a, b, c = asyncio.run(mixed())
+    assert [d.id for d in a] == [d.id for d in r.invoke("question 1", k=3)] and isinstance(b, KeyError)
+    assert [d.id for d in c] == [d.id for d in r.invoke("question 2", k=3)]
+    # a provider that cannot batch keeps the reference's route (a pool thread per call), same answers
+    plain = _store(engine=OracleIndex)
+    rp = VectorStoreRetriever(plain)
+    assert [d.id for d in asyncio.run(rp.ainvoke("question 9", k=4))] == [d.id for d in rp.invoke("question 9", k=4)]
