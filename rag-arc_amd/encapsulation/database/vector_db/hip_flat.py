@@ -173,6 +173,11 @@ class _AsyncFront:
         else:
             fut.set_result(result)
 
+    @classmethod
+    def _deliver_many(cls, items) -> None:
+        for fut, res, err in items:
+            cls._deliver(fut, res, err)
+
     def _work(self) -> None:
         while True:
             with self.cv:
@@ -195,10 +200,13 @@ class _AsyncFront:
                         outcomes.append((None, exc_one))
             self.launches += 1
             self.served += len(batch)
+            per_loop: dict = {}          # ONE wake-up per event loop, not one per future (each is a write to the loop's pipe)
             for (_, _, fut, loop), (res, err) in zip(batch, outcomes):
+                per_loop.setdefault(loop, []).append((fut, res, err))
+            for loop, items in per_loop.items():
                 try:
-                    loop.call_soon_threadsafe(self._deliver, fut, res, err)
-                except RuntimeError:          # the caller's loop is closed: nobody is waiting any more
+                    loop.call_soon_threadsafe(self._deliver_many, items)
+                except RuntimeError:          # the callers' loop is closed: nobody is waiting any more
                     pass
 
 
