@@ -136,7 +136,7 @@ def _sharded_worker(rank, world, port, cfg_path, out_dir):
     store = registrator.get_object("sharded").impl
     assert store.shard[:2] == (rank, world) and store.shard[3] == 4001 and store.shard[2] in (2000, 2001)
     r = VectorStoreRetriever(store)
-    queries = [f"query {i}" for i in range(20)]
+    queries = [f"query {i}" for i in range(300)]        # two chunks of 256 / 44: the pipelined path (_PendingShard) on every rank
     one = [[(d.id, s) for d, s in store.similarity_search_with_score(q, k=25)] for q in queries[:6]]
     many = [[d.id for d in docs] for docs in r.batch_invoke(queries, k=25)]
     with open(os.path.join(out_dir, f"r{rank}.json"), "w") as fh:
@@ -154,7 +154,7 @@ def test_sharded_store_from_json_on_two_ranks_equals_single_store(tmp_path):
 
     rng = np.random.default_rng(31)
     n, d = 4001, 96
-    texts = [f"chunk {i}" for i in range(n)] + [f"query {i}" for i in range(20)]
+    texts = [f"chunk {i}" for i in range(n)] + [f"query {i}" for i in range(300)]
     vecs = rng.standard_normal((len(texts), d)).astype(np.float32)
     np.savez(tmp_path / "table.npz", texts=np.array(texts), vectors=vecs)
     np.savez(tmp_path / "corpus.npz", texts=np.array(texts[:n]), ids=np.array([str(i) for i in range(n)]))
@@ -165,7 +165,7 @@ def test_sharded_store_from_json_on_two_ranks_equals_single_store(tmp_path):
     single = HipFlatVectorStore(TableEmbeddings(texts, vecs))
     single.add_texts(texts[:n], ids=[str(i) for i in range(n)])
     r = VectorStoreRetriever(single)
-    queries = [f"query {i}" for i in range(20)]
+    queries = [f"query {i}" for i in range(300)]
     want_one = [[[d_.id, s] for d_, s in single.similarity_search_with_score(q, k=25)] for q in queries[:6]]
     want_many = [[d_.id for d_ in r.invoke(q, k=25)] for q in queries]
     for rank in range(2):
