@@ -297,6 +297,13 @@ struct GemmSplitEpi {
   const float* rw = nullptr;     // [N] inverse scales of the W rows
   const float* bias = nullptr;   // [N] fp32
   const float* sg = nullptr;     // [M] output scales
+  // ACT 6 (wide.hip, round 5): no C at all — the fp32 product of row r and column q is a SCORE, compared with thr[q]; what
+  // reaches it goes to query q's candidate list as (ordered score key << 32 | ~row).  N = 256 (one column tile).
+  const float* thr = nullptr;            // [N]
+  unsigned long long* cand = nullptr;    // [N][cap]
+  uint32_t* count = nullptr;             // [N]
+  uint32_t* status = nullptr;            // [N]
+  uint32_t cap = 0, row0 = 0, n_valid = 0;
 };
 __device__ __forceinline__ float gemm_gelu_libm(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -582,6 +589,31 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
         }
       }
       __builtin_amdgcn_wave_barrier();
+    }
+  } else if constexpr (BASE == 6) {  // scores against per-column thresholds -> candidate lists; nothing is stored (wide.hip)
+    float t16[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t4 = *(const float4*)(fx.thr + tn * 256 + wc * 64 + j * 16 + 4 * q_e);
+      t16[j][0] = t4.x; t16[j][1] = t4.y; t16[j][2] = t4.z; t16[j][3] = t4.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t r = (uint32_t)(tm * 256 + wr * 128 + i * 16 + row_e);
+      if (r < fx.n_valid) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float sc = acc[i][j][e];
+            if (sc >= t16[j][e]) {
+              const uint32_t q = (uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e);
+              const uint32_t pos = atomicAdd(&fx.count[q], 1u);
+              if (pos < fx.cap) fx.cand[(size_t)q * fx.cap + pos] = rarc_candkey(sc, fx.row0 + r);
+              else atomicOr(&fx.status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
+            }
+          }
+      }
     }
   } else if constexpr (BASE == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
     // gate / up columns alternate in groups of eight: in a 16-column block the lanes with (lane >> 4) < 2 hold gate values of
@@ -1949,6 +1981,7 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<19>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm256_f16_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, G256_LDS));
@@ -2165,6 +2198,25 @@ int rarc_gemm_fused_norm(const uint16_t* d_a, const uint16_t* d_w, const void* d
                "rarc_gemm_fused_norm: bad argument");
   RARC_REQUIRE(rarc_gemm_norm_fusable(m, n, k), RARC_E_UNSUPPORTED, "rarc_gemm_fused_norm: shape %d x %d x %d not fusable", m, n, k);
   return enc_gemm_impl(d_a, d_w, (const uint16_t*)d_rowscale_or_zero, d_c, m, n, k, act, stream, false, d_ssq);
+}
+
+// The score GEMM of the wide search path with its select in the epilogue (wide.hip, round 5): S = A[M][K]·W[256][K]ᵀ in fp32,
+// never stored — S[r][q] >= thr[q] sends (score, row0 + r) to query q's candidate list.  M a multiple of 256, K of 64, >= 256.
+bool rarc_gemm_f16_select_takes(int m, int k) { return m > 0 && m % 256 == 0 && k % GK == 0 && k >= 4 * GK; }
+int rarc_gemm_f16_select(const uint16_t* a, const uint16_t* w, int m, int k, const float* thr, unsigned long long* cand,
+                         uint32_t* count, uint32_t* status, uint32_t cap, uint32_t row0, uint32_t n_valid, hipStream_t s) {
+  RARC_REQUIRE(a && w && thr && cand && count && status && rarc_gemm_f16_select_takes(m, k), RARC_E_INVALID,
+               "rarc_gemm_f16_select: bad arguments (m=%d k=%d)", m, k);
+  if (int rc = gemm_attrs()) return rc;
+  static const bool swz = !(getenv("RARC_GEMM_SWZ") && atoi(getenv("RARC_GEMM_SWZ")) == 0);
+  const int order = swz ? 2 : 0;
+  GemmSplitEpi fx;
+  fx.thr = thr; fx.cand = cand; fx.count = count; fx.status = status; fx.cap = cap; fx.row0 = row0; fx.n_valid = n_valid;
+  const int tiles = m / 256;
+  hipLaunchKernelGGL((rarc_gemm256_f16_kernel<6>), dim3(tiles > 256 ? 256 : tiles), dim3(512), G256_LDS, s, (const half_t*)a,
+                     (const half_t*)w, (const half_t*)nullptr, (half_t*)nullptr, m, 256, k, order, (float*)nullptr, fx);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
 }
 
 // fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward

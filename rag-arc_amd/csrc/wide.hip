@@ -24,6 +24,9 @@
 // Bound: the MFMA pipe (2·256·n·d_pad flops on the encoder's GEMM).
 #include "rarc_common.h"
 
+bool rarc_gemm_f16_select_takes(int m, int k);   // encoder.hip: the same GEMM with the select in its epilogue (no score matrix)
+int rarc_gemm_f16_select(const uint16_t* a, const uint16_t* w, int m, int k, const float* thr, unsigned long long* cand,
+                         uint32_t* count, uint32_t* status, uint32_t cap, uint32_t row0, uint32_t n_valid, hipStream_t s);
 extern "C" int rarc_enc_gemm_zero_bias(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_zero_bias, uint16_t* d_c, int m,
                                        int n, int k, int act, void* stream);
 
@@ -374,8 +377,31 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
   int n_chunk = 0;
   while (at < n_rows) {
     int64_t m = n_rows - at < chunk ? n_rows - at : chunk;
-    const int64_t m_full = m / 128 * 128;
     int rc;
+    // every chunk but the first: the GEMM nominates in its epilogue (fp32 scores against the thresholds, no 64 MB of
+    // scores written and read back) for the whole 256-row blocks; what is left of the chunk takes the two-kernel form below
+    static const bool fuse = !(getenv("RARC_WIDE_FUSE") && atoi(getenv("RARC_WIDE_FUSE")) == 0);
+    if (fuse && at > 0 && m >= 256 && rarc_gemm_f16_select_takes((int)(m / 256 * 256), d_pad)) {
+      const int64_t mf = m / 256 * 256;
+      if ((rc = rarc_gemm_f16_select(a16 + (size_t)at * d_pad, qb.q16, (int)mf, d_pad, w.thr, (unsigned long long*)cur, ccur, d_status,
+                                     (uint32_t)cand_cap, (uint32_t)at, (uint32_t)mf, s)) != RARC_OK)
+        return rc;
+      at += mf;
+      m -= mf;
+      if (m == 0) {
+        ++n_chunk;
+        if (chunk < WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {
+          hipLaunchKernelGGL(wide_tighten_kernel, dim3(WIDE_NQ), dim3(1024), 0, s, cur, other, ccur, cother, (uint32_t)cand_cap,
+                             (uint32_t)k, w.eps, w.thr);
+          RARC_HIP_CHECK(hipGetLastError());
+          { uint64_t* t = cur; cur = other; other = t; }
+          { uint32_t* t = ccur; ccur = cother; cother = t; }
+        }
+        chunk = chunk * 2 < WIDE_CHUNK ? chunk * 2 : WIDE_CHUNK;
+        continue;
+      }
+    }
+    const int64_t m_full = m / 128 * 128;
     if (m_full > 0) {
       if ((rc = rarc_enc_gemm_zero_bias(a16 + (size_t)at * d_pad, qb.q16, w.zero_bias, w.scores, (int)m_full, WIDE_NQ, d_pad, 0,
                                         stream)) != RARC_OK)
