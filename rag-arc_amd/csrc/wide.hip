@@ -32,7 +32,8 @@ extern "C" int rarc_enc_gemm_zero_bias(const uint16_t* d_a, const uint16_t* d_w,
 
 namespace {
 constexpr int WIDE_NQ = RARC_MAX_QUERIES;     // score columns per row (queries beyond nq are padding)
-constexpr int WIDE_CHUNK = 131072;            // rows per GEMM (64 MB of fp16 scores)
+constexpr int WIDE_CHUNK = 131072;            // rows per GEMM that stores its scores (64 MB of fp16)
+constexpr int WIDE_FUSED_CHUNK = 1 << 20;     // rows per GEMM that nominates in its epilogue (no buffer to size it by)
 constexpr int WIDE_KMAX = 8192;               // largest k (the finalize sorts its answer in LDS: 64 KB)
 
 struct WideWs {
@@ -390,16 +391,22 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
       m -= mf;
       if (m == 0) {
         ++n_chunk;
-        if (chunk < WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {
+        if (chunk < WIDE_CHUNK || chunk >= 4 * WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {
           hipLaunchKernelGGL(wide_tighten_kernel, dim3(WIDE_NQ), dim3(1024), 0, s, cur, other, ccur, cother, (uint32_t)cand_cap,
                              (uint32_t)k, w.eps, w.thr);
           RARC_HIP_CHECK(hipGetLastError());
           { uint64_t* t = cur; cur = other; other = t; }
           { uint32_t* t = ccur; ccur = cother; cother = t; }
         }
-        chunk = chunk * 2 < WIDE_CHUNK ? chunk * 2 : WIDE_CHUNK;
+        // (nothing is stored per row any more: past the ramp a fused chunk may be eight times the score buffer's rows —
+        //  fewer launches, a tighten per ~1M rows)
+        chunk = chunk * 2 < WIDE_FUSED_CHUNK ? chunk * 2 : WIDE_FUSED_CHUNK;
         continue;
       }
+    }
+    if (m > WIDE_CHUNK) {        // (the remainder of a fused-size chunk that could not be fused: back to the buffer's size)
+      chunk = WIDE_CHUNK;
+      m = WIDE_CHUNK;
     }
     const int64_t m_full = m / 128 * 128;
     if (m_full > 0) {
