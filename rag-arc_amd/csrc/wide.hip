@@ -376,6 +376,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
   int64_t at = 0;
   int64_t chunk = first;
   int n_chunk = 0;
+  const int64_t fused_max = k <= 256 ? WIDE_FUSED_CHUNK : WIDE_CHUNK;
   while (at < n_rows) {
     int64_t m = n_rows - at < chunk ? n_rows - at : chunk;
     int rc;
@@ -400,7 +401,9 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
         }
         // (nothing is stored per row any more: past the ramp a fused chunk may be eight times the score buffer's rows —
         //  fewer launches, a tighten per ~1M rows)
-        chunk = chunk * 2 < WIDE_FUSED_CHUNK ? chunk * 2 : WIDE_FUSED_CHUNK;
+        //  (k in the thousands: measured slower with the large chunks — thousands of nominations per query and chunk
+        //   all go through one counter each, inside the GEMM: 17.0 vs 35.2 ms at k = 2000 — so those keep the small ones)
+        chunk = chunk * 2 < fused_max ? chunk * 2 : fused_max;
         continue;
       }
     }
