@@ -77,6 +77,13 @@ def parse(argv=None):
     ap.add_argument("--encoder-overlap", action="store_true",
                     help="config 5: embed batch i+1 on a side stream under the scan of batch i (measured: no gain on one GPU — "
                          "the persistent scan kernel holds every CU's whole register file, so the forward's kernels wait for it)")
+    ap.add_argument("--c5-split", choices=("slice", "rotate"), default="slice",
+                    help="config 5 on N > 1 ranks, who runs the query encoder: 'slice' = every rank embeds batch/N queries of "
+                         "every batch (one all-gather); 'rotate' = rank (i mod N) embeds ALL the queries of batch i and broadcasts "
+                         "them (a 256-query forward every N batches instead of a latency-bound 32-query one every batch)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="config 5 on ONE GPU: give the encoder the share one rank of this many would carry (the other queries' "
+                         "embeddings are taken as already received) — one rank's step of an N-rank run, collectives excluded")
     ap.add_argument("--no-c5-alt", action="store_true", help="config 5: skip the second timed loop in the other encoder precision")
     ap.add_argument("--no-persist", action="store_true", help="skip the shard-file leg (save / load of a 10M-row shard)")
     ap.add_argument("--persist-rows", type=int, default=10_000_000)
@@ -1206,6 +1213,14 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
     split = use_dist and nq % world == 0
     if not split:
         q_lo, q_hi = 0, nq
+    # who embeds what on N ranks (--c5-split); --emulate-world W plays ONE rank of W on this GPU (no collective: the other
+    # ranks' embeddings are a copy of what the first forward produced)
+    emu = a.emulate_world if (world == 1 and a.emulate_world > 1 and nq % a.emulate_world == 0) else 0
+    rotate = a.c5_split == "rotate" and (split or emu) and world * max(emu, 1) > 1
+    if emu:
+        q_lo, q_hi = split_range(nq, 0, emu)
+    if rotate:
+        split = False
     # The encoder of batch i+1 runs on a SIDE stream under the scan of batch i (the scan leaves the matrix pipe about half
     # idle and the encoder barely touches HBM); the scan's stream waits on the event that closes the forward.  Two result
     # buffers alternate: a search copies its queries into the index's query block first thing, so a buffer is free again
@@ -1223,12 +1238,28 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         with torch.cuda.stream(enc_stream):
             e0.record()
-            mine = encoders[active[0]].forward_device(tok[q_lo:q_hi], lens[q_lo:q_hi], normalize=True, out=mine_buf[slot])   # token ids already in HBM
-            if split:
-                dist.all_gather_into_tensor(full_buf[slot], mine)
+            if rotate:
+                # batch i belongs to rank i mod N: it embeds all the queries, the others receive them
+                n_ranks = emu or world
+                turn = (n_emb[0] - 1) % n_ranks
                 out = full_buf[slot]
+                if turn == (0 if emu else rank):
+                    encoders[active[0]].forward_device(tok, lens, normalize=True, out=out)
+                elif emu:
+                    out.copy_(emb_all[0])
+                if not emu:
+                    dist.broadcast(out, src=turn)
             else:
-                out = mine
+                mine = encoders[active[0]].forward_device(tok[q_lo:q_hi], lens[q_lo:q_hi], normalize=True, out=mine_buf[slot])   # token ids already in HBM
+                if split:
+                    dist.all_gather_into_tensor(full_buf[slot], mine)
+                    out = full_buf[slot]
+                elif emu:
+                    out = full_buf[slot]
+                    out.copy_(emb_all[0])
+                    out[q_lo:q_hi].copy_(mine)
+                else:
+                    out = mine
             e1.record()
         if overlap:
             main_stream.wait_event(e1)
@@ -1247,6 +1278,7 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
 
     enc_alone_ms, enc_other_ms = time_alone(enc), time_alone(enc_other)
     encoders = {a.encoder_precision: enc, other: enc_other}
+    emb_all = [enc.forward_device(tok, lens, normalize=True).clone()] if emu else [None]
 
     emb0 = embed().clone()
     ids0, _ = searcher.search_device(emb0, K)
@@ -1300,6 +1332,10 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
                        f"with a supplied lexical list",
            "encoder_precision": a.encoder_precision,
            "encoder_overlap": "side stream under the previous batch's scan" if overlap else "none (same stream)",
+           "encoder_split": ("rotate: rank i mod N embeds the whole batch i and broadcasts it" if rotate else
+                             "slice: every rank embeds batch/N queries of every batch") if (use_dist or emu) else "one rank",
+           **({"emulated_world": emu, "note_emulation": f"ONE rank of {emu} played on this GPU: its shard, its share of the encoder "
+               "work; the other ranks' embeddings are copies; no collective — a per-rank step time for the projection, not a measurement of N GPUs"} if emu else {}),
            "encoder_alone_ms": round(enc_alone_ms, 4), f"encoder_alone_ms_{other}": round(enc_other_ms, 4),
            "value": round(nq * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
            "n_gpus": world, "rows_per_gpu": hi - lo, "queries_embedded_per_gpu": q_hi - q_lo,

@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_bench_runs_with_n_ranks_on_one_device(world):
+@pytest.mark.parametrize("world,split", [(2, "slice"), (8, "slice"), (4, "rotate")])
+def test_bench_runs_with_n_ranks_on_one_device(world, split):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--one-device",
                         "--rows", "4000000", "--c5-rows", "2000000", "--c5-layers", "2", "--steps", "3", "--warmup", "1",
-                        "--verify-queries", "4"], capture_output=True, text=True, timeout=900, env=env)
+                        "--verify-queries", "4", "--c5-split", split], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -33,4 +33,5 @@ def test_bench_runs_with_n_ranks_on_one_device(world):
     assert out["config"]["repaired_queries_last_step"] == 0 and out["config"]["exchange_ms_per_step"] > 0
     c5 = out["c5"]
     assert c5["n_gpus"] == world and c5["queries_embedded_per_gpu"] == 256 // world and c5["fused_entries_per_query"] == 100
+    assert c5["encoder_split"].startswith(split)
     assert c5["full_size_check"]["rows_beating_kth"] == 0
