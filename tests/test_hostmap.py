@@ -133,3 +133,46 @@ def test_row_list_follows_the_dicts():
     store.docstore = {"k": Document(content="only", metadata={}, id="k")}
     store.index_to_docstore_id = {0: "k"}
     assert [d.content for d in store._docs_by_row()] == ["only"]
+
+
+def test_hostmap_is_reference_count_neutral():
+    """A C extension that leaks or over-releases a reference shows up as a slow memory leak or a crash in somebody's server:
+    after the results are dropped every Document, list and buffer is back at the count it started with — on the error paths
+    too."""
+    import gc
+    import sys
+
+    H = hostmap.load()
+    docs, _, _ = _corpus(300)
+    rng = np.random.default_rng(3)
+    rows = rng.integers(0, 300, (16, 20)).astype(np.int64)
+    rows[2, 15:] = -1
+    scores = rng.standard_normal((16, 20)).astype(np.float32)
+    col = ColumnarDocstore.from_texts([d.content for d in docs], [d.id for d in docs], [d.metadata for d in docs])
+    cols = col.columns()
+    batch = [[[docs[i] for i in rng.integers(0, 300, 12)], [docs[i] for i in rng.integers(0, 300, 9)]] for _ in range(7)]
+    fused = np.zeros((7, 4), dtype=np.int64)
+    counts = np.full(7, 3, dtype=np.int32)
+    watched = [docs[int(r)] for r in rows[0, :5]] + [docs, rows, scores, col.text_blob, col.text_off, cols, batch, batch[0][0]]
+
+    def snapshot():
+        gc.collect()
+        return [sys.getrefcount(o) for o in watched]
+
+    before = snapshot()
+    for _ in range(50):
+        a = H.rows_to_pairs(docs, rows, scores, 16, 20)
+        b = H.rows_to_docs(docs, rows, 16, 20)
+        c = H.rows_to_pairs(cols, rows, scores, 16, 20)
+        d = H.rows_to_docs(col, rows, 16, 20)
+        keys_b, lens_b, by_key = H.rrf_tables(batch, 2, 12)
+        e = H.pick_docs(by_key, fused, counts, 4)
+        for bad in (lambda: H.rows_to_docs(docs, np.array([[999]], dtype=np.int64), 1, 1),
+                    lambda: H.rows_to_pairs(cols, np.array([[999]], dtype=np.int64), np.zeros((1, 1), np.float32), 1, 1),
+                    lambda: H.rows_to_docs(docs, rows, 17, 20),
+                    lambda: H.rrf_tables(batch, 1, 12),
+                    lambda: H.pick_docs(by_key, np.full((7, 4), 99, dtype=np.int64), counts, 4)):
+            with pytest.raises((IndexError, ValueError)):
+                bad()
+        del a, b, c, d, keys_b, lens_b, by_key, e
+    assert snapshot() == before
