@@ -137,6 +137,77 @@ class _QueryCoalescer:
         return item.result
 
 
+class _RowsGuard:
+    """Readers-writer guard over a store's rows AND its row -> Document list.  A search holds it shared from its launch until
+    its answer has become Documents; add_texts / delete hold it exclusively — a delete renumbers every later row, and an
+    answer whose row numbers were taken before it must not be looked up in the list after it.  (The reference is not
+    thread-safe at all — plain dicts, framework/register.py — but this store invites concurrent callers: the coalescer, the
+    async front, two-caller pipelining.)  Writers are re-entrant (delete -> rebuild -> add_texts) and have priority."""
+
+    def __init__(self):
+        self.cv = threading.Condition()
+        self.readers = 0
+        self.writer: Optional[int] = None
+        self.depth = 0
+        self.waiting_writers = 0
+
+    class _Shared:
+        def __init__(self, g):
+            self.g = g
+
+        def __enter__(self):
+            g = self.g
+            with g.cv:
+                me = threading.get_ident()
+                if g.writer == me:          # the writer's own searches (a rebuild calling search): already exclusive
+                    g.depth += 1
+                    return
+                while g.writer is not None or g.waiting_writers:
+                    g.cv.wait()
+                g.readers += 1
+
+        def __exit__(self, *exc):
+            g = self.g
+            with g.cv:
+                if g.writer == threading.get_ident():
+                    g.depth -= 1
+                    return
+                g.readers -= 1
+                if g.readers == 0:
+                    g.cv.notify_all()
+
+    class _Exclusive:
+        def __init__(self, g):
+            self.g = g
+
+        def __enter__(self):
+            g = self.g
+            with g.cv:
+                me = threading.get_ident()
+                if g.writer == me:
+                    g.depth += 1
+                    return
+                g.waiting_writers += 1
+                while g.writer is not None or g.readers:
+                    g.cv.wait()
+                g.waiting_writers -= 1
+                g.writer, g.depth = me, 1
+
+        def __exit__(self, *exc):
+            g = self.g
+            with g.cv:
+                g.depth -= 1
+                if g.depth == 0:
+                    g.writer = None
+                    g.cv.notify_all()
+
+    def shared(self):
+        return self._Shared(self)
+
+    def exclusive(self):
+        return self._Exclusive(self)
+
+
 class _AsyncFront:
     """The coalescer for coroutines: callers enqueue (payload, k, future) and await; one worker thread, started when there is
     work and gone after a second without any, answers up to `max_batch` of them per scan."""
@@ -249,6 +320,7 @@ class HipFlatVectorStore(VectorStore):
         # dicts assigned from outside); or a ColumnarDocstore for corpus-scale stores (adopt()), the dicts then stay empty
         self._row_docs = []
         self._row_docs_stale = False
+        self._guard = _RowsGuard()
         self.timing: Optional[dict] = None   # set to {} to have the batch entry points add up their host-side phases (bench.py)
 
     # ------------------------------------------------------------------ helpers
@@ -264,6 +336,10 @@ class HipFlatVectorStore(VectorStore):
         texts = list(texts)
         if not texts:
             return []
+        with self._guard.exclusive():
+            return self._add_texts_locked(texts, metadatas, ids)
+
+    def _add_texts_locked(self, texts, metadatas, ids) -> List[str]:
         if hasattr(self.embedding, "embed_documents_device"):
             vectors = self.embedding.embed_documents_device(texts)   # stays in HBM: fp32 [n][d] device tensor
         else:
@@ -406,8 +482,9 @@ class HipFlatVectorStore(VectorStore):
         if self._coalescer is not None:
             return self._coalescer.submit(np.asarray(embedding, dtype=np.float32), k)
         qv = np.array([embedding]).astype(np.float32)
-        scores, rows = self.index.search(qv, k)
-        return self._to_documents(scores[0], rows[0])
+        with self._guard.shared():
+            scores, rows = self.index.search(qv, k)
+            return self._to_documents(scores[0], rows[0])
 
     def _to_documents(self, scores, rows) -> List[Tuple[Document, float]]:
         """[(Document, float(score))] of one query's answer, row -1 skipped (VectorStore_Faiss.py:265-272)."""
@@ -446,8 +523,9 @@ class HipFlatVectorStore(VectorStore):
                 for i, v in zip(texts, emb):
                     vecs[i] = np.asarray(v, dtype=np.float32)
             q = np.stack([np.asarray(v, dtype=np.float32) for v in vecs])
-        scores, rows = self.index.search(q, min(k, self.ntotal))
-        return self._map_batch(scores, rows, True)
+        with self._guard.shared():
+            scores, rows = self.index.search(q, min(k, self.ntotal))
+            return self._map_batch(scores, rows, True)
 
     def _search_chunks(self, q, k: int):
         """(scores fp32 [n][k], rows int64 [n][k]) numpy pairs, one per 256 queries of q (device tensor or array), in order.
@@ -504,10 +582,11 @@ class HipFlatVectorStore(VectorStore):
         q = self._embed_batch(queries)
         t0 = self._tick("embed_s", t0)
         out: list = []
-        for scores, rows in self._search_chunks(q, k):
-            t0 = self._tick("search_s", t0)          # launch + wait + pinned copy-out (the next chunk is already scanning)
-            out.extend(self._map_batch(scores, rows, with_scores))
-            t0 = self._tick("map_s", t0)
+        with self._guard.shared():
+            for scores, rows in self._search_chunks(q, k):
+                t0 = self._tick("search_s", t0)          # launch + wait + pinned copy-out (the next chunk is already scanning)
+                out.extend(self._map_batch(scores, rows, with_scores))
+                t0 = self._tick("map_s", t0)
         return out
 
     def batch_similarity_search_with_score(self, queries: Sequence[str], k: int = 4, **kwargs: Any):
@@ -544,10 +623,11 @@ class HipFlatVectorStore(VectorStore):
         if self.ntotal == 0:
             return []
         qv32 = np.array([embedding]).astype(np.float32)
-        scores, rows = self.index.search(qv32, min(fetch_k, self.ntotal))
-        keep = [(float(sc), int(r)) for sc, r in zip(scores[0], rows[0]) if r != -1]
-        by_row = self._docs_by_row()
-        scored = [(by_row[r], sc) for sc, r in keep]
+        with self._guard.shared():
+            scores, rows = self.index.search(qv32, min(fetch_k, self.ntotal))
+            keep = [(float(sc), int(r)) for sc, r in zip(scores[0], rows[0]) if r != -1]
+            by_row = self._docs_by_row()
+            scored = [(by_row[r], sc) for sc, r in keep]
         if not scored:
             return []
         if not reembed and getattr(self.index, "lib", None) is not None:
@@ -613,6 +693,10 @@ class HipFlatVectorStore(VectorStore):
         embedding every surviving text again; the surviving embeddings are in HBM already, so here the rows are compacted
         in place (rarc_compact_rows: stable, the survivors keep their order — exactly the rows a rebuild from the docstore
         would produce, without the encoder and without its batch-shape rounding noise) and the docstore follows."""
+        with self._guard.exclusive():
+            return self._delete_locked(ids)
+
+    def _delete_locked(self, ids: Optional[List[str]]) -> Optional[bool]:
         if ids is None:
             self.docstore.clear()
             self._forget_rows()

@@ -188,6 +188,14 @@ class HipShardedFlatVectorStore(HipFlatVectorStore):
         texts = list(texts)
         if not texts:
             return []
+        with self._guard.exclusive():
+            return self._add_texts_sharded(texts, metadatas, ids)
+
+    def _add_texts_sharded(self, texts, metadatas, ids) -> List[str]:
+        import uuid
+
+        from ....hip.sharded import shard_range
+
         if ids is None:
             # every rank must name the documents alike: ids are derived from the global row numbers, not drawn at random
             start = self.ntotal

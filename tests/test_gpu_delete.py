@@ -216,3 +216,41 @@ def test_two_rank_sharded_delete_equals_single_store(tmp_path):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     assert "DELETE_OK" in outs[0][0]
+
+
+def test_searches_stay_consistent_while_another_thread_deletes_and_adds(hip):
+    """A delete renumbers every later row; an answer whose row numbers were taken before it must not be turned into Documents
+    after it.  Four threads search for texts that are never deleted (top-1 must be that very text, score ~ 1) while the main
+    thread deletes and adds around them — the store's readers-writer guard is what keeps each answer whole."""
+    import threading
+
+    from rag_arc_amd.encapsulation.database.vector_db import HipFlatVectorStore
+    from tests.helpers import HashEmbeddings
+
+    emb = HashEmbeddings(128)
+    texts = [f"steady text {i}" for i in range(4000)]
+    store = HipFlatVectorStore.from_texts(texts, emb, ids=[f"s{i}" for i in range(4000)])
+    kept = list(range(3000, 4000))                 # rows behind everything that gets deleted: renumbered by every delete
+    stop, errors, done = threading.Event(), [], [0]
+
+    def searcher(seed):
+        rng = np.random.default_rng(seed)
+        while not stop.is_set():
+            j = int(rng.choice(kept))
+            got = store.similarity_search_with_score(texts[j], k=1)
+            if not got or got[0][0].id != f"s{j}" or got[0][0].content != texts[j] or abs(got[0][1] - 1.0) > 1e-3:
+                errors.append((j, got[0][0].id if got else None))
+                return
+            done[0] += 1
+
+    threads = [threading.Thread(target=searcher, args=(s,)) for s in range(4)]
+    for t in threads:
+        t.start()
+    for step in range(30):
+        assert store.delete([f"s{step * 50 + i}" for i in range(50)]) is True
+        store.add_texts([f"churn {step} {i}" for i in range(20)], ids=[f"c{step}_{i}" for i in range(20)])
+    stop.set()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    assert done[0] > 50 and store.ntotal == 4000 - 1500 + 600
