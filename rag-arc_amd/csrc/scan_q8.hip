@@ -127,6 +127,7 @@ __device__ __forceinline__ int q8_all16(const q8_i32x16& a) {
 // ABL (tools/scan_q8_bench): 1 = no pruning, 2 = no global loads after the prologue, 4 = no MFMA,
 // 8 = no threshold refresh, 16 = no conversion, 32768 = fp8: converted but not written to LDS, 32 = prune fast path only, 64 = never flush,
 // 256 = no ping-pong between the wave groups, 512 = barrier at the end of the iteration where EB would put it behind the matrix phase, 1024 = s_memtime timeline of workgroup 0 into p.dbg,
+// 131072 = fp8 / shadow form: only the first two k steps' A fragments are read from LDS (the MFMAs reuse them: what the other 7/8 of the ds_read_b128 cost),
 // 65536 = waves 4-7 issue no MFMAs (fp8 / shadow form: half the matrix work per CU, everything else unchanged — round 5's overlap question),
 // 16384 = every survivor updates the histogram, 4096 = survivors walked per lane (no LDS transposition), 8192 = parked scores walked at once (no batching), 2048 = fast path carries the position of the best score along (the earlier form; 0.5 % slower at 100M rows)
 //
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(Q8_THREADS) void rarc_scan_q8_kernel(const ScanQ8Pa
           c01 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0[ks % PF], qf[2 * ks + 1], c01, 0, 0, 0);
           c10 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[ks % PF], qf[2 * ks], c10, 0, 0, 0);
           c11 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1[ks % PF], qf[2 * ks + 1], c11, 0, 0, 0);
-          if (ks + PF < KS2) {
+          if (ks + PF < KS2 && !(ABL & 131072)) {   // (131072: the first PF k steps' fragments feed every MFMA — no further LDS reads)
             a0[ks % PF] = *(const i32x4*)(a_base + 64 * (ks + PF));
             a1[ks % PF] = *(const i32x4*)(a_base + 16 * L::RS + 64 * (ks + PF));
           }
@@ -804,6 +805,7 @@ static int launch_scan_q8(const ScanQ8Params& p, int grid, hipStream_t s) {
       if (abl == 32769) return launch_scan_q8<D, FMT, 32769>(p, grid, s);    // converted but not written to LDS, MFMAs on stale LDS, no pruning
       if (abl == 32773) return launch_scan_q8<D, FMT, 32773>(p, grid, s);    // fetch + conversion only
       // round 5: do the streaming phase and the matrix phase overlap?  half the MFMAs (waves 4-7 issue none), with and without pruning
+      if (abl == 131073) return launch_scan_q8<D, FMT, 131073>(p, grid, s);   // no pruning, all MFMAs, 1/8 of the LDS fragment reads: what do the reads cost?
       if (abl == 65536) return launch_scan_q8<D, FMT, 65536>(p, grid, s);
       if (abl == 65537) return launch_scan_q8<D, FMT, 65537>(p, grid, s);
     }
