@@ -138,7 +138,9 @@ static PyObject *map_rows(PyObject *args, int with_scores) {
     if (nq < 0 || k < 0) { PyErr_SetString(PyExc_ValueError, "negative shape"); return NULL; }
     int is_list = PyList_CheckExact(seq);
     Columns cols;
-    int is_cols = PyTuple_CheckExact(seq);          /* a ColumnarDocstore's columns (see columns_parse) */
+    /* a ColumnarDocstore's columns (see columns_parse): a 6-tuple that starts with a class — any other tuple is a sequence
+     * of Documents like a list */
+    int is_cols = PyTuple_CheckExact(seq) && PyTuple_GET_SIZE(seq) == 6 && PyType_Check(PyTuple_GET_ITEM(seq, 0));
     if (is_cols && columns_parse(seq, &cols) < 0) return NULL;
     Py_ssize_t n = is_list ? PyList_GET_SIZE(seq) : (is_cols ? cols.n : PySequence_Size(seq));
     if (n < 0) return NULL;
@@ -266,6 +268,7 @@ static PyObject *rrf_tables(PyObject *self, PyObject *args) {
                     PyObject **dp = _PyObject_GetDictPtr(PyList_GET_ITEM(one, p + 8));
                     if (dp && *dp) __builtin_prefetch(*dp, 0, 1);
                 }
+#if PY_VERSION_HEX < 0x030B0000   /* (the layout of a split dict below is 3.10's; later versions keep the first two steps) */
                 if (p + 5 < len) {
                     PyObject **dp = _PyObject_GetDictPtr(PyList_GET_ITEM(one, p + 5));
                     if (dp && *dp && PyDict_CheckExact(*dp) && ((PyDictObject *)*dp)->ma_values)
@@ -277,6 +280,7 @@ static PyObject *rrf_tables(PyObject *self, PyObject *args) {
                         ((PyDictObject *)*dp)->ma_values[0])
                         __builtin_prefetch(((PyDictObject *)*dp)->ma_values[0], 0, 1);   /* first attribute set: content */
                 }
+#endif
                 PyObject *doc = PyList_GET_ITEM(one, p);
                 PyObject *content = PyObject_GetAttr(doc, s_content);
                 if (!content) goto fail;
