@@ -41,6 +41,9 @@ def test_rows_to_pairs_and_docs_equal_the_reference_hit_loop():
     assert all(a[0] is b[0] for ga, wa in zip(got, want) for a, b in zip(ga, wa))      # the very objects
     assert all(type(p[1]) is float for one in got for p in one)
     assert H.rows_to_docs(docs, rows, 37, 25) == [[d for d, _ in one] for one in want]
+    # a plain tuple of Documents is a sequence like any other (only a 6-tuple that starts with a class is read as columns)
+    assert H.rows_to_docs(tuple(docs), rows, 37, 25) == H.rows_to_docs(docs, rows, 37, 25)
+    assert H.rows_to_docs(tuple(docs[:6]), np.array([[5, 0]], dtype=np.int64), 1, 2) == [[docs[5], docs[0]]]
     # any sequence will do (the columnar docstore is one), and rows may carry a base
     col = ColumnarDocstore.from_texts([d.content for d in docs], [d.id for d in docs], [d.metadata for d in docs])
     assert H.rows_to_docs(col, rows, 37, 25) == [[d for d, _ in one] for one in want]
