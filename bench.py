@@ -932,7 +932,8 @@ def leg_wide(torch, lib, B, FlatIndexF16, a, dev, local_rank, rows=10_000_000, d
         out[f"k{k}"] = {"value": round(a.batch / (ms * 1e-3), 1), "unit": "queries/s", "ms_per_step": round(ms, 3),
                         "roofline": {"bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": MFMA_F16_PEAK_TF,
                                      "unit": "TFLOP/s", "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),
-                                     "hbm_frac_of_row_bytes": round(bytes_rows / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                                     "hbm_frac_of_row_bytes": round(bytes_rows / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                        "candidate_capacity_per_query": int(getattr(idx, "last_wide_cap", 0))}
     # full-size property (parity itself: tests/test_gpu_wide.py, bit-exact vs the oracle up to 200k rows at these widths): an
     # exact top-k under a total order is a prefix of the exact top-k' for k' > k — two independent runs, different
     # thresholds and candidate sets, must agree bit for bit on the first k entries

@@ -597,23 +597,34 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
       const float4 t4 = *(const float4*)(fx.thr + tn * 256 + wc * 64 + j * 16 + 4 * q_e);
       t16[j][0] = t4.x; t16[j][1] = t4.y; t16[j][2] = t4.z; t16[j][3] = t4.w;
     }
+    // A register (i, j, e) holds one query per group of 16 lanes (q_e) and 16 rows across the group: the lanes of a group
+    // that nominate take their places in the query's list with ONE atomic (k in the thousands lets thousands of rows per
+    // query and chunk through — a counter per nomination made the GEMM 1.7x as long); nothing but a ballot when no lane does.
+    const unsigned long long grp_mask = 0xFFFFull << (16 * q_e);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const uint32_t r = (uint32_t)(tm * 256 + wr * 128 + i * 16 + row_e);
-      if (r < fx.n_valid) {
+      const bool row_ok = r < fx.n_valid;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float sc = acc[i][j][e];
-            if (sc >= t16[j][e]) {
-              const uint32_t q = (uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e);
-              const uint32_t pos = atomicAdd(&fx.count[q], 1u);
-              if (pos < fx.cap) fx.cand[(size_t)q * fx.cap + pos] = rarc_candkey(sc, fx.row0 + r);
-              else atomicOr(&fx.status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
-            }
+        for (int e = 0; e < 4; ++e) {
+          const float sc = acc[i][j][e];
+          const bool hit = row_ok && sc >= t16[j][e];
+          const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
+          if (bal == 0) continue;
+          if (hit) {
+            const unsigned long long grp = bal & grp_mask;
+            const int leader = __builtin_ctzll(grp);
+            const uint32_t q = (uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e);
+            uint32_t base = 0;
+            if (lane_e == leader) base = atomicAdd(&fx.count[q], (uint32_t)__builtin_popcountll(grp));
+            base = (uint32_t)__builtin_amdgcn_ds_bpermute(leader << 2, (int)base);
+            const uint32_t pos = base + (uint32_t)__builtin_popcountll(grp & ((1ull << lane_e) - 1ull));
+            if (pos < fx.cap) fx.cand[(size_t)q * fx.cap + pos] = rarc_candkey(sc, fx.row0 + r);
+            else atomicOr(&fx.status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
           }
-      }
+        }
     }
   } else if constexpr (BASE == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
     // gate / up columns alternate in groups of eight: in a 16-column block the lanes with (lane >> 4) < 2 hold gate values of

@@ -188,15 +188,14 @@ __device__ uint32_t wide_kth_largest_u32(At at, uint32_t n, uint32_t k, uint32_t
       if ((v & mask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255u], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      uint32_t above = 0;
-      int b = 255;
-      for (; b > 0; --b) {
-        if (above + s_hist[b] >= need) break;
-        above += s_hist[b];
+    if (threadIdx.x < 64) {      // the bin holding the need-th largest, by one wave (a serial walk of the 256 counters by one
+      uint32_t above = 0;        //  thread was 7 us a round — 28 of the 40 us a tighten took)
+      int b = rarc_wave_find_from_top(s_hist, 256, need, &above);
+      if (b < 0) { b = 0; above = 0; }           // (n >= need: cannot happen)
+      if (threadIdx.x == 0) {
+        s_pick[0] = (uint32_t)b;
+        s_pick[1] = need - above;
       }
-      s_pick[0] = (uint32_t)b;
-      s_pick[1] = need - above;
     }
     __syncthreads();
     prefix |= s_pick[0] << shift;
@@ -376,7 +375,10 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
   int64_t at = 0;
   int64_t chunk = first;
   int n_chunk = 0;
-  const int64_t fused_max = k <= 256 ? WIDE_FUSED_CHUNK : WIDE_CHUNK;
+  int64_t fused_max = WIDE_FUSED_CHUNK;
+  if (const char* e = getenv("RARC_WIDE_FUSED_ROWS")) {   // (experiments: tools/wide_chunk_sweep.sh)
+    if (atoll(e) >= WIDE_CHUNK) fused_max = atoll(e) / WIDE_CHUNK * WIDE_CHUNK;
+  }
   while (at < n_rows) {
     int64_t m = n_rows - at < chunk ? n_rows - at : chunk;
     int rc;
@@ -392,7 +394,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
       m -= mf;
       if (m == 0) {
         ++n_chunk;
-        if (chunk < WIDE_CHUNK || chunk >= 4 * WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {
+        if (chunk < fused_max || chunk >= 4 * WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {   // (every chunk while they still grow: a stale threshold lets chunk/seen x k rows through)
           hipLaunchKernelGGL(wide_tighten_kernel, dim3(WIDE_NQ), dim3(1024), 0, s, cur, other, ccur, cother, (uint32_t)cand_cap,
                              (uint32_t)k, w.eps, w.thr);
           RARC_HIP_CHECK(hipGetLastError());
@@ -400,9 +402,10 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
           { uint32_t* t = ccur; ccur = cother; cother = t; }
         }
         // (nothing is stored per row any more: past the ramp a fused chunk may be eight times the score buffer's rows —
-        //  fewer launches, a tighten per ~1M rows)
-        //  (k in the thousands: measured slower with the large chunks — thousands of nominations per query and chunk
-        //   all go through one counter each, inside the GEMM: 17.0 vs 35.2 ms at k = 2000 — so those keep the small ones)
+        //  fewer launches, a tighten per ~1M rows.  k in the thousands was 2x slower with them at first, for two reasons since
+        //  removed: a counter update per nomination inside the GEMM (now one per 16-lane group), and no tighten between the
+        //  growing chunks past 131072 rows — a threshold from 126K rows let 8 x k rows of a 524K-row chunk through and the lists
+        //  overflowed, i.e. every search ran twice.  10M x 1536, k = 2000: 16.8 -> 13.3 ms.)
         chunk = chunk * 2 < fused_max ? chunk * 2 : fused_max;
         continue;
       }

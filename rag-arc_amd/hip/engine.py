@@ -798,6 +798,7 @@ class FlatIndexF16:
                                               out_sc.data_ptr(), status.data_ptr(), self._wide_ws.data_ptr(),
                                               self._wide_ws.numel(), cap, stream), "rarc_search_wide")
             flagged = bool((status[:nq] != 0).any().item())
+            self.last_wide_cap = cap          # (diagnostics: the capacity this batch was answered at)
             if not flagged:
                 self.last_repaired = []
                 return
