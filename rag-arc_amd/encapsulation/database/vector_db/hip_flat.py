@@ -150,6 +150,7 @@ class _RowsGuard:
         self.writer: Optional[int] = None
         self.depth = 0
         self.waiting_writers = 0
+        self.held = threading.local()       # .n: how many times THIS thread holds the guard shared (nested searches)
 
     class _Shared:
         def __init__(self, g):
@@ -162,15 +163,23 @@ class _RowsGuard:
                 if g.writer == me:          # the writer's own searches (a rebuild calling search): already exclusive
                     g.depth += 1
                     return
+                n = getattr(g.held, "n", 0)
+                if n:                       # a reader's nested search: waiting for a queued writer here would wait for itself
+                    g.held.n = n + 1
+                    return
                 while g.writer is not None or g.waiting_writers:
                     g.cv.wait()
                 g.readers += 1
+                g.held.n = 1
 
         def __exit__(self, *exc):
             g = self.g
             with g.cv:
                 if g.writer == threading.get_ident():
                     g.depth -= 1
+                    return
+                g.held.n -= 1
+                if g.held.n:
                     return
                 g.readers -= 1
                 if g.readers == 0:
@@ -628,16 +637,17 @@ class HipFlatVectorStore(VectorStore):
             keep = [(float(sc), int(r)) for sc, r in zip(scores[0], rows[0]) if r != -1]
             by_row = self._docs_by_row()
             scored = [(by_row[r], sc) for sc, r in keep]
-        if not scored:
-            return []
-        if not reembed and getattr(self.index, "lib", None) is not None:
-            # candidates stay in HBM: gather the resident rows, run the greedy selection in rarc_mmr_select
-            order = self._mmr_on_device([r for _, r in keep], embedding, k, lambda_mult)
-            return [scored[i][0] for i in order]
+            if not scored:
+                return []
+            # (the row numbers are good for as long as the guard is held: the resident rows are read under it)
+            if not reembed and getattr(self.index, "lib", None) is not None:
+                # candidates stay in HBM: gather the resident rows, run the greedy selection in rarc_mmr_select
+                order = self._mmr_on_device([r for _, r in keep], embedding, k, lambda_mult)
+                return [scored[i][0] for i in order]
+            if not reembed:
+                cand = self._stored_vectors([r for _, r in keep])
         if reembed:
             cand = np.array([self.embedding.embed_query(d.content) for d, _ in scored])  # re-embedded, as the reference
-        else:
-            cand = self._stored_vectors([r for _, r in keep])
         qv = np.array(embedding)
         if self.normalize_L2 or self.metric == "cosine":
             qv = qv / np.linalg.norm(qv)
