@@ -2248,8 +2248,10 @@ int rarc_gemm_f16_f32out_parts(const uint16_t* a, const uint16_t* w, float* c, i
   static const bool no_split = getenv("RARC_GEMM32_SPLIT") && atoi(getenv("RARC_GEMM32_SPLIT")) == 0;
   const int tiles = (m / GM) * (n / GN);
   int S = 1;
+  static const int min_kt = getenv("RARC_GEMM32_MIN_KT") ? atoi(getenv("RARC_GEMM32_MIN_KT")) : 6;      // (tools/enc_small_split_sweep.sh: 4 x 32 tokens 2.26 -> 2.14 ms with 6 / 16 instead of 8 / 8)
+  static const int max_s = getenv("RARC_GEMM32_MAX_S") ? atoi(getenv("RARC_GEMM32_MAX_S")) : 16;
   if (!no_split && !(m % 256 == 0 && (m / 256) * (n / GN) >= 256))
-    while (2 * S <= max_parts && 2 * S <= 8 && tiles * S * 2 <= 256 && k % (S * 2 * GK) == 0 && k / (S * 2) >= 8 * GK) S *= 2;
+    while (2 * S <= max_parts && 2 * S <= max_s && tiles * S * 2 <= 256 && k % (S * 2 * GK) == 0 && k / (S * 2) >= min_kt * GK) S *= 2;
   *parts = S;
   if (S == 1) return rarc_gemm_f16_f32out(a, w, c, m, n, k, s);
   return enc_gemm_splitk(a, w, c, m, n, k, S, s);
