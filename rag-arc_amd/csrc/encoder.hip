@@ -1287,7 +1287,8 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
                                                                     const half_t* __restrict__ W,
                                                                     const half_t* __restrict__ bias,
                                                                     half_t* __restrict__ C, int M, int N, int K, int ldk,
-                                                                    int order, float* __restrict__ ssq = nullptr) {
+                                                                    int order, float* __restrict__ ssq = nullptr,
+                                                                    const GemmSplitEpi fx = GemmSplitEpi()) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1392,6 +1393,50 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
     for (int t = 0; t < 8; ++t) {
       const int r = t * 8 + r8;
       *(float4*)(P + (size_t)r * N) = *(const float4*)(ep + r * ST + c * 16);
+    }
+  } else if (BASE == 5) {  // gelu(acc·ra·rw + bias)·sg -> (hi, lo) halves -> split image [lo | hi | hi], row stride 3N (as the
+                           // 256 x 256 kernel's ACT 5: FFN1 of the fp32-class encoder at 768..1024 tokens, one tile per CU)
+    constexpr int ST = 64 + 64 + 16;     // a staging row: 64 bytes of hi | 64 bytes of lo
+    char* ep = smem + wave * 64 * ST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const size_t rg = (size_t)tm * 128 + wr * 64 + i * 32 + row;
+      const float ra_r = fx.ra[rg], sg_r = fx.sg[rg];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = 8 * g + 4 * hh;
+        const int col0 = tn * 128 + wc * 32 + nl;
+        const float4 w4 = *(const float4*)(fx.rw + col0), b4 = *(const float4*)(fx.bias + col0);
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+        half4 hi4, lo4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = acc[i][4 * g + e] * ra_r * wv[e] + bv[e];
+          const float x = gemm_gelu_libm(v) * sg_r;
+          const half_t hi = (half_t)x;
+          hi4[e] = hi;
+          lo4[e] = (half_t)(x - (float)hi);
+        }
+        char* dst = ep + (i * 32 + row) * ST + nl * 2;
+        *(half4*)dst = hi4;
+        *(half4*)(dst + 64) = lo4;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int r8 = lane >> 3, c = lane & 7;
+    const size_t ld3 = (size_t)3 * N;
+    half_t* Cw = C + (size_t)(tm * 128 + wr * 64) * ld3 + tn * 128 + wc * 32;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int r = t * 8 + r8;
+      const uint4 v = *(const uint4*)(ep + r * ST + c * 16);
+      half_t* rowp = Cw + (size_t)r * ld3;
+      if (c < 4) {            // hi: stored twice
+        *(uint4*)(rowp + N + c * 8) = v;
+        *(uint4*)(rowp + 2 * (size_t)N + c * 8) = v;
+      } else {                // lo
+        *(uint4*)(rowp + (c - 4) * 8) = v;
+      }
     }
   } else {
     constexpr int ST = 32 * 2 + 16;
@@ -2013,6 +2058,7 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   attr = 1;
   return RARC_OK;
 }
@@ -2260,9 +2306,18 @@ int rarc_gemm_f16_f32out_parts(const uint16_t* a, const uint16_t* w, float* c, i
 // FFN1 of the fp32-class encoder with the GELU and the split of its output fused into the GEMM's epilogue (ACT 5).  Only
 // shapes the 256 x 256 kernel takes WHOLE (no tail given to another kernel) and that fill the chip: returns 1 ("not taken",
 // nothing launched) otherwise and the caller runs the unfused pair (fp32 product + rarc_e32_epi_kernel<., 1>).
+// ... and, round 5, batches whose 128 x 128 tiles number 192..256 (FFN1 at 768..1024 tokens): the small-batch ping-pong kernel
+// with the same epilogue, one tile per CU, no partial slabs, no row pass after it (bge-large, 32 x 32 tokens: 3.81 -> 3.68 ms;
+// at 128 tiles the unfused pair wins — split-K x2 fills the chip, the fused form half of it: 2.78 vs 2.93 ms at 16 x 32).
+static bool gemm_gelu_split_small(int m, int n, int k3) {
+  const int t = (m / 128) * (n / 128);
+  return m % 128 == 0 && n % 128 == 0 && t >= 192 && t <= 256 && k3 >= 4 * GK && k3 % GK == 0;
+}
 bool rarc_gemm_f16_gelu_split_takes(int m, int n, int k3) {
   const char* e = getenv("RARC_E32_FUSE_GELU");   // (read per call: tests switch it between forwards)
-  if ((e && atoi(e) == 0) || m % 256 || n % 256 || k3 < 4 * GK || k3 % GK) return false;
+  if (e && atoi(e) == 0) return false;
+  if (gemm_gelu_split_small(m, n, k3)) return !(e && atoi(e) == 2);      // (2: the big-batch form only — A/B)
+  if (m % 256 || n % 256 || k3 < 4 * GK || k3 % GK) return false;
   const int t256 = (m / 256) * (n / 256), t128 = (m / 256) * (n / GN);
   return t256 >= 256 && gemm_prefers_256x256(t256, t128) && (t256 % 256 == 0 || t256 >= 1024);
 }
@@ -2275,6 +2330,12 @@ int rarc_gemm_f16_gelu_split(const uint16_t* a3, const uint16_t* w3, const float
   const int order = swz ? 2 : (m < n ? 1 : 0);
   GemmSplitEpi fx;
   fx.ra = ra; fx.rw = rw; fx.bias = bias; fx.sg = sg;
+  if (gemm_gelu_split_small(m, n, k3)) {
+    hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<5>), dim3((m / 128) * (n / 128), 1), dim3(512), G128S_LDS, s, (const half_t*)a3,
+                       (const half_t*)w3, (const half_t*)nullptr, (half_t*)out3, m, n, k3, k3, order, (float*)nullptr, fx);
+    RARC_HIP_CHECK(hipGetLastError());
+    return RARC_OK;
+  }
   hipLaunchKernelGGL((rarc_gemm256_f16_kernel<5>), dim3(t256 > 256 ? 256 : t256), dim3(512), G256_LDS, s, (const half_t*)a3,
                      (const half_t*)w3, (const half_t*)nullptr, (half_t*)out3, m, n, k3, order, (float*)nullptr, fx);
   RARC_HIP_CHECK(hipGetLastError());

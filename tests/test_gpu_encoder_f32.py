@@ -217,16 +217,19 @@ def test_split_attention_against_the_fp32_mfma_kernel(oracle, monkeypatch):
     assert np.abs(split - exact).max() <= 2e-6
 
 
+@pytest.mark.parametrize("n_seq", [128, 32, 24])
 @pytest.mark.parametrize("stress", [False, True])
-def test_ffn1_gelu_fused_into_the_gemm_epilogue(oracle, monkeypatch, stress):
+def test_ffn1_gelu_fused_into_the_gemm_epilogue(oracle, monkeypatch, stress, n_seq):
     """Round 4: on batches that fill the chip FFN1 runs with bias + GELU + the split of its output fused into the GEMM's
     epilogue; the scale of that split is fixed before the GEMM from a bound on the row (||x|| ||W_j|| + |b_j|), not from the
     row's maximum.  Same forward with the fusion off (RARC_E32_FUSE_GELU=0: fp32 product + row pass): both in the fp32 class
     against float64 and next to each other.  `stress`: FFN1 rows over eight decades, a hot input channel, large biases — the
-    bound overshoots the true row maximum by many more binades than on ordinary weights."""
+    bound overshoots the true row maximum by many more binades than on ordinary weights.
+    Round 5: batches of 192..256 tiles of 128 x 128 (n_seq 32 and 24 here; FFN1 of bge-large at 768..1024 tokens) take the same
+    epilogue in the small-batch kernel (rarc_gemm128pp_f16_kernel<5>)."""
     from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEncoder
 
-    H, layers, heads, I, n_seq, L = 256, 2, 4, 1024, 128, 128          # 16384 tokens: 64 x 4 tiles of 256 x 256
+    H, layers, heads, I, L = 256, 2, 4, 1024, 128          # n_seq 128: 16384 tokens = 64 x 4 tiles of 256 x 256; 32 / 24: 256 / 192 tiles of 128 x 128
     sd = oracle.random_bert_state_dict(H, layers, heads, I, vocab=500, max_pos=L, seed=91)
     rng = np.random.default_rng(91)
     if stress:
