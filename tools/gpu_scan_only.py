@@ -21,6 +21,8 @@ for _ in range(iters):
 torch.cuda.synchronize()
 tot, n = ctypes.c_double(0), ctypes.c_int(0)
 B.check(lib.rarc_profile_end(ctypes.byref(tot), ctypes.byref(n)))
+if n.value == 0:      # (rows wider than 1024 dims take rarc_search_wide: its kernels are not in the library's scan brackets)
+    print(f"SCAN rows={N} dim={D} storage={ST}: wide path, {iters} searches (no scan-kernel brackets)"); sys.exit(0)
 esize = {"f16": 2, "f8": 1}[ST]
 gb = N * idx.d_pad * esize / 1e9
 print(f"SCAN rows={N} dim={D} storage={ST} abl={os.environ.get('RARC_Q8_ABL', '0')}: {tot.value / iters:.3f} ms per scan "

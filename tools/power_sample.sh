@@ -2,6 +2,7 @@
 # Samples socket power, sclk and mclk (rocm-smi / sysfs, whichever the unprivileged user can read) every ~50 ms while a
 # command runs:  tools/power_sample.sh <out.txt> <command...>      (GPU box; evidence for the power-limit statements)
 out=$1; shift
+rm -f /tmp/power_sample.stop
 ( i=0
   while [ ! -e /tmp/power_sample.stop ]; do
     ts=$(date +%s.%N)
@@ -16,7 +17,6 @@ out=$1; shift
 spid=$!
 ( while [ ! -e /tmp/power_sample.stop ]; do rocm-smi --showpower --showclocks --showtemp 2>&1 | grep -E "GPU\[|Power|sclk|mclk|Temp" ; echo "--- $(date +%s.%N)"; sleep 0.2; done ) > $out.smi 2>&1 &
 mpid=$!
-rm -f /tmp/power_sample.stop
 "$@"
 rc=$?
 touch /tmp/power_sample.stop; sleep 0.4; kill $spid $mpid 2>/dev/null
