@@ -1136,6 +1136,14 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
     out["threads_256_invoke"] = {"value": round(NB / dt, 1), "unit": "queries/s", "wall_ms": round(dt * 1e3, 3),
                                  "scans": launches,
                                  "equal_batch": bool(all([d.id for d in x] == [d.id for d in y] for x, y in zip(res, answers)))}
+    co = getattr(store, "_coalescer", None)
+    if co is not None:          # the same burst with the store's `coalesce_window_us` = 200: an idle-index leader waits that long for company
+        w0, co.window_s = co.window_s, 200e-6
+        storm()
+        dtw, launches_w, _ = min((storm() for _ in range(3 if big else 5)), key=lambda x: x[0])
+        co.window_s = w0
+        out["threads_256_invoke"]["with_coalesce_window_200us"] = {"value": round(NB / dtw, 1), "wall_ms": round(dtw * 1e3, 3),
+                                                                   "scans": launches_w}
     # (e2) 256 coroutines, one ainvoke each, from one event loop: no thread per caller (hip_flat._AsyncFront)
     import asyncio
 
