@@ -11,6 +11,7 @@ products defined in DESIGN.md, ties ordered by insertion index.  IVF / HNSW / L2
 import os
 import pickle
 import threading
+import time
 import uuid
 from typing import Any, Callable, List, Optional, Sequence, Tuple
 
@@ -70,7 +71,10 @@ class _QueryCoalescer:
     full pass over the corpus.  Here a caller that finds the index idle launches at once (no added latency, alone if
     nobody else is waiting); callers that arrive WHILE a scan is running queue up, and whoever is woken first takes the
     whole queue — up to 256 queries — through ONE scan.  256 threads calling together cost two or three scans instead
-    of 256.  `window_s` > 0 additionally lets an idle-index leader wait that long for company.
+    of 256.  `window_s` > 0 additionally lets an idle-index leader wait that long for company; with window_s = 0 the leader
+    still waits — 2 % of the last scan's duration, at most half a millisecond — when the launch before this one served more
+    than one caller (a burst is likely under way: at 100M rows 256 threads then share ONE scan instead of 1 + 255; a lone
+    sequential caller never waits).
 
     An exact top-k under a total order (score desc, id asc) is a prefix of the top-k' for k' > k, so one launch with the
     largest k of the batch serves every caller."""
@@ -82,6 +86,10 @@ class _QueryCoalescer:
         self.busy = False
         self.launches = 0        # scans issued
         self.served = 0          # queries answered
+        self.last_batch = 1      # callers served by the previous launch, and how long it took
+        self.last_scan_s = 0.0
+
+    ADAPTIVE_MAX_S = 500e-6
 
     class _Item:
         __slots__ = ("payload", "k", "result", "error", "done")
@@ -102,10 +110,14 @@ class _QueryCoalescer:
                 if item.done:
                     break
                 self.busy = True                       # this caller leads the next launch
-                if self.window_s > 0 and len(self.queue) < self.max_batch:
-                    self.cv.wait(timeout=self.window_s)
+                window = self.window_s
+                if window <= 0 and self.last_batch > 1:
+                    window = min(self.ADAPTIVE_MAX_S, 0.02 * self.last_scan_s)
+                if window > 0 and len(self.queue) < self.max_batch:
+                    self.cv.wait(timeout=window)
                 batch = self.queue[: self.max_batch]   # FIFO (the leader's own item is among them unless > max_batch queued)
                 del self.queue[: self.max_batch]
+            t_launch = time.perf_counter()
             try:
                 results = self.run_batch([it.payload for it in batch], max(it.k for it in batch))
                 for it, pairs in zip(batch, results):
@@ -126,6 +138,7 @@ class _QueryCoalescer:
                 with self.cv:
                     self.launches += 1
                     self.served += len(batch)
+                    self.last_batch, self.last_scan_s = len(batch), time.perf_counter() - t_launch
                     for it in batch:
                         it.done = True
                     self.busy = False

@@ -97,6 +97,34 @@ def test_concurrent_one_query_callers_share_scans():
     assert len(one) == 3 and store.coalesced_launches == (launches + 1, 65)
 
 
+def test_the_leader_waits_for_company_only_after_a_shared_launch():
+    """window 0: a sequential caller is never delayed (the launch before it served one caller); after a launch that served
+    several, the next idle-index leader waits a moment (2 % of that scan, at most 0.5 ms) — the second burst's callers end up
+    in fewer scans than the first one's 1 + rest."""
+    import time
+
+    store = _store(n=50, dim=16)
+    store.index.delay = 0.0
+    co = store._coalescer
+    t0 = time.perf_counter()
+    for i in range(40):
+        store.similarity_search(f"alone {i}", k=2)
+    assert co.last_batch == 1 and time.perf_counter() - t0 < 2.0
+    store.index.delay = 0.02                                         # a 20 ms scan: the adaptive window is 0.4 ms
+    got = [None] * 48
+    _run_gated(store, 48, lambda i: got.__setitem__(i, store.similarity_search(f"burst {i}", k=2)))
+    assert co.last_batch > 1 and all(len(g) == 2 for g in got)
+    waited = []
+    real_wait = co.cv.wait
+    co.cv.wait = lambda timeout=None: (waited.append(timeout), real_wait(timeout))[1]
+    try:
+        store.similarity_search("right after the burst", k=2)       # idle index, but the last launch was shared: waits
+    finally:
+        co.cv.wait = real_wait
+    assert waited and 0 < waited[0] <= co.ADAPTIVE_MAX_S
+    assert co.last_batch == 1                                        # ... and that one was alone again: no wait next time
+
+
 def test_more_than_256_waiters_take_several_launches_and_window_mode():
     store = _store(n=50, dim=16, coalesce_window_us=20_000)         # 20 ms window: even the first caller waits for company
     store.index.delay = 0.0
