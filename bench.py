@@ -62,6 +62,7 @@ def parse(argv=None):
     ap.add_argument("--no-c3", action="store_true")
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--no-wide", action="store_true", help="skip the wide-row leg (10M x 1536 through rarc_search_wide)")
+    ap.add_argument("--no-pairs", action="store_true", help="skip the all-pairs cosine leg (100k x 1024 entities, SURVEY 8(f) rank 4)")
     ap.add_argument("--no-f32", action="store_true", help="skip the storage=f32 leg (10M x 768 fp32 rows)")
     ap.add_argument("--no-api", action="store_true", help="skip the legs through the registered retriever (texts -> Documents)")
     ap.add_argument("--no-lm", action="store_true", help="config 3 without its cross-encoder's LM forward (seeded logits instead)")
@@ -522,6 +523,9 @@ def main():
             result["wide"] = leg_wide(torch, lib, B, FlatIndexF16, a, dev, local_rank)
         else:
             result["wide"] = {"skipped": "needs 45 GiB of free HBM"}
+    # ---- all pairs with cosine >= 0.95 among 100k entity embeddings (the graph store's dedup step), one GPU --------
+    if world == 1 and a.storage == "f16" and not a.no_pairs:
+        result["pairs"] = leg_pairs(torch, np, lib, B, a, dev)
     # ---- config 5 end to end (every N): encoder forward -> fp8 sharded scan -> RRF ----------------
     if not a.no_c5 and a.storage == "f16":
         del searcher, idx, l_ids, l_sc
@@ -947,6 +951,57 @@ def leg_wide(torch, lib, B, FlatIndexF16, a, dev, local_rank, rows=10_000_000, d
     return out
 
 
+def leg_pairs(torch, np, lib, B, a, dev, n=100_000, d=1024, dup=2000):
+    """the entity de-duplication step of the reference's graph store (Base_Neo4j.py:559-583: sklearn
+    cosine_similarity over all entity embeddings + a python loop over i < j) as `similar_pairs`: n synthetic embeddings with
+    `dup` planted near-duplicates, every pair with cosine >= 0.95.  CPU side: the same function on a bounded sample."""
+    from rag_arc_amd.encapsulation.database.graph_db import similar_pairs
+
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    B.check(lib.rarc_synth_rows_f32(x.data_ptr(), d, d, 0, n, 777, 0), "rarc_synth_rows_f32")
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    src = torch.randint(0, n, (dup,), generator=g, device=dev)
+    dst = torch.randint(0, n, (dup,), generator=g, device=dev)
+    x[dst] = x[src] + 0.05 * torch.randn((dup, d), generator=g, device=dev) * x[src].norm(dim=1, keepdim=True) / d ** 0.5
+    for _ in range(3):                                  # warm-up (kernel attributes, allocator, clocks)
+        similar_pairs(x, 0.95)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        pairs = similar_pairs(x, 0.95)
+    dt = (time.perf_counter() - t0) / reps
+    d_pad = max(256, (d + 63) // 64 * 64)
+    # the GEMM multiplies rows [0, end of the column super-block) with each super-block of 4096 columns
+    n_pad = (n + 255) // 256 * 256
+    flops = sum(2.0 * min(n_pad, c0 + 4096) * min(4096, n_pad - c0) * d_pad for c0 in range(0, n, 4096))
+    out = {"workload": f"{n} embeddings x {d} dims, {dup} planted near-duplicates: every pair i < j with cosine >= 0.95 "
+                       "(rag_arc_amd...graph_db.similar_pairs -> rarc_similar_pairs: fp16 score GEMM with the select in its epilogue, "
+                       "exact float64 rescoring of the nominated pairs)",
+           "value": round(n / dt, 1), "unit": "entities/s", "ms_per_call": round(dt * 1e3, 2), "pairs_found": len(pairs),
+           "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(flops / dt / 1e12 / MFMA_F16_PEAK_TF, 4),
+                        "note": "whole call, host side included (upload of nothing: the embeddings are resident; download + sort of the pairs)"}}
+    if not a.no_cpu_baseline:
+        from oracle import cpu_ref
+
+        m = 6000
+        xs = x[:m].cpu().numpy().astype(np.float64)
+        t0 = time.perf_counter()
+        want = cpu_ref.similar_pairs_f64(xs, 0.95)
+        cpu_s = time.perf_counter() - t0
+        got = similar_pairs(x[:m], 0.95)
+        out["cpu_baseline"] = {"value": round(m / cpu_s, 1), "unit": "entities/s", "cores": os.cpu_count(), "kind": "port",
+                               "sample": f"numpy float64 restatement (oracle/cpu_ref.similar_pairs_f64) of the first {m} embeddings in {cpu_s:.2f} s "
+                                         f"(cost grows with n^2: {n} entities are {(n / m) ** 2:.0f}x that, and the reference's python "
+                                         "double loop is ~100x slower than the vectorised restatement)"}
+        out["parity_vs_oracle_on_sample"] = {"pairs": len(want), "same_pairs": [(i, j) for i, j, _ in got] == [(i, j) for i, j, _ in want],
+                                             "max_abs_dscore": float(max([abs(a_[2] - b_[2]) for a_, b_ in zip(got, want)] or [0.0]))}
+    del x
+    torch.cuda.empty_cache()
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ the plugin surface
 def _ordered_for_readers(result):
     """The same line, keys ordered so that whoever keeps only the END of a long line still sees what matters most: the
@@ -959,7 +1014,7 @@ def _ordered_for_readers(result):
                 return None
             d = d[k]
         return d
-    late = ["ingest", "persistence", "c3", "c2", "f32", "wide", "c5", "api"]
+    late = ["ingest", "persistence", "c3", "pairs", "c2", "f32", "wide", "c5", "api"]
     out = {k: v for k, v in result.items() if k not in late}
     for k in late:
         if k in result:
@@ -979,6 +1034,7 @@ def _ordered_for_readers(result):
         "api_100M_two_callers_vs_engine": pick(result, "api", "headline", "batch_invoke_256_two_callers", "vs_engine"),
         "api_256_coroutines_ms": [pick(result, "api", "c2", "coroutines_256_ainvoke", "wall_ms"),
                                   pick(result, "api", "headline", "coroutines_256_ainvoke", "wall_ms")],
+        "all_pairs_100k_x_1024_ms": pick(result, "pairs", "ms_per_call"),
         "cpu_q_per_s": pick(result, "cpu_baseline", "value"),
         "shard_file_GBps_save_load_cached": [pick(result, "persistence", "save_GBps"), pick(result, "persistence", "load_GBps_from_storage"),
                                             pick(result, "persistence", "load_GBps_from_page_cache")],

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 500 /* 0.5.0: rarc_search_wide (rows to 4096 padded dims, k to 8192), rarc_compact_rows (delete by compaction), rarc_vmem_* (growable arenas), RARC_E_IO / RARC_IO_TRUNCATE; 0.4.1: RarcEnc32Layer.f1_colmax (FFN1 with its GELU fused into the GEMM epilogue); 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
+#define RARC_VERSION 501 /* 0.5.1: rarc_similar_pairs (all-pairs cosine >= threshold: the graph store's entity dedup); 0.5.0: rarc_search_wide (rows to 4096 padded dims, k to 8192), rarc_compact_rows (delete by compaction), rarc_vmem_* (growable arenas), RARC_E_IO / RARC_IO_TRUNCATE; 0.4.1: RarcEnc32Layer.f1_colmax (FFN1 with its GELU fused into the GEMM epilogue); 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
                             * rarc_enc_gemm_zero_bias; 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
                             * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
@@ -588,6 +588,25 @@ size_t rarc_wide_workspace_bytes(int d_pad, int cand_cap);
 int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, int fmt, int64_t n_rows, int d_pad, float max_norm,
                      float rho, const void* d_qblock, int nq, int k, int64_t id_base, int64_t* d_out_ids,
                      float* d_out_scores, uint32_t* d_status, void* d_ws, size_t ws_bytes, int cand_cap, void* stream);
+
+/*
+ * All pairs (i < j) of n embeddings whose cosine reaches a threshold — the entity de-duplication of the reference's graph
+ * store (encapsulation/database/graph_db/Base_Neo4j.py:538-583: sklearn.metrics.pairwise.cosine_similarity over every entity
+ * embedding, then a python loop over i < j keeping similarity >= 0.95); SURVEY 8(f) rank 4.  The n x n matrix is never
+ * formed: the rows are normalised into an fp16 image, the score GEMM of rarc_search_wide (select in its epilogue) nominates
+ * the pairs whose approximate cosine reaches threshold - eps (eps bounds the fp16 / fp32-accumulation error), and each
+ * nominated pair is scored exactly (double-precision dot product of the fp32 rows, double-precision norms) and kept if that
+ * reaches the threshold (csrc/pairs.hip).
+ * d_rows: fp32 [n_rows][ld], device, any scale; 1 <= d <= 4096; 0 < threshold <= 1.
+ * Output, in no particular order: d_out_pairs int64 [out_cap][2] = (i, j), d_out_scores double [out_cap];
+ * *d_out_count (uint64) = how many pairs reached the threshold, also when that exceeds out_cap.
+ * *d_flags (uint32): bit 0 = a column's nomination list (cand_cap entries) overflowed — call again with a larger cand_cap
+ * (cand_cap >= n_rows cannot overflow); bit 1 = more pairs than out_cap — call again with out_cap >= *d_out_count.
+ */
+size_t rarc_similar_pairs_workspace_bytes(int64_t n_rows, int d, int cand_cap);
+int rarc_similar_pairs(const float* d_rows, int64_t ld, int64_t n_rows, int d, double threshold, void* d_ws, size_t ws_bytes,
+                       int cand_cap, int64_t* d_out_pairs, double* d_out_scores, int64_t out_cap,
+                       unsigned long long* d_out_count, uint32_t* d_flags, void* stream);
 
 /*
  * Deleting rows of a resident index: stable in-place compaction.  The reference deletes by clearing the index and

@@ -20,6 +20,10 @@ What is restated here, and how it is pinned:
   score->order step (core/rerank/Reranker_Qwen3.py:41-49, :70-74): pure python / numpy below,
   PINNED against outputs of the reference's own importable code, committed under tests/golden/
   by tests/golden/make_golden.py.
+* all-pairs cosine >= threshold (`similar_pairs_f64`: the entity de-duplication of
+  encapsulation/database/graph_db/Base_Neo4j.py:559-583, which calls scikit-learn's cosine_similarity — a
+  dependency, not vendored): float64 numpy restatement, PINNED against scikit-learn itself (installed here:
+  tests/test_similar_pairs_host.py) and against tests/golden/similar_pairs.json.
 """
 from __future__ import annotations
 
@@ -308,6 +312,29 @@ def adjacent_cosine_distances(x: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------- RRF
+def similar_pairs_f64(embeddings, threshold: float = 0.95) -> List[Tuple[int, int, float]]:
+    """The entity de-duplication arithmetic of the reference's graph store (encapsulation/database/graph_db/Base_Neo4j.py:
+    559-583): `similarity_matrix = cosine_similarity(np.array(embeddings))`, then `for i ... for j in range(i + 1, n): if
+    similarity_matrix[i][j] >= 0.95` — returned as [(i, j, float(similarity))] in that loop's order.  cosine_similarity is
+    scikit-learn's (a dependency of the reference, not vendored): rows divided by their Euclidean norms (a zero row stays
+    zero), then X_n @ X_n.T, all in float64 — restated here; PINNED against sklearn.metrics.pairwise.cosine_similarity itself
+    where that is installed (tests/test_similar_pairs_host.py) and through tests/golden/similar_pairs.json."""
+    x = np.array(embeddings, dtype=np.float64)
+    if x.ndim != 2 or x.shape[0] < 2:
+        return []
+    norms = np.sqrt(np.einsum("ij,ij->i", x, x))
+    norms[norms == 0.0] = 1.0                       # sklearn.preprocessing.normalize: zero rows are left alone
+    xn = x / norms[:, None]
+    sim = xn @ xn.T
+    out = []
+    n = x.shape[0]
+    for i in range(n):
+        row = sim[i]
+        for j in np.nonzero(row[i + 1:] >= threshold)[0]:
+            out.append((i, int(i + 1 + j), float(row[i + 1 + j])))
+    return out
+
+
 def rrf_fuse(lists: Sequence[Sequence[Hashable]], rrf_k: float = 60.0, top_k: int = 10) -> List[Tuple[Hashable, float]]:
     """RRFusion.fuse (core/utils/Fusion.py:45-76) on bare keys (the reference keys on
     `document.content`): rank = position + 1 in every list; score[key] += 1.0 / (k + rank) in list

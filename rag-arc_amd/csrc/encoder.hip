@@ -2276,6 +2276,24 @@ int rarc_gemm_f16_select(const uint16_t* a, const uint16_t* w, int m, int k, con
   return RARC_OK;
 }
 
+// The same with N columns (a multiple of 256; thr / count / status are [N], cand is [N][cap]): the all-pairs cosine of pairs.hip,
+// whose columns are a block of the rows themselves.
+int rarc_gemm_f16_select_n(const uint16_t* a, const uint16_t* w, int m, int n, int k, const float* thr, unsigned long long* cand,
+                           uint32_t* count, uint32_t* status, uint32_t cap, uint32_t row0, uint32_t n_valid, hipStream_t s) {
+  RARC_REQUIRE(a && w && thr && cand && count && status && rarc_gemm_f16_select_takes(m, k) && n > 0 && n % 256 == 0, RARC_E_INVALID,
+               "rarc_gemm_f16_select_n: bad arguments (m=%d n=%d k=%d)", m, n, k);
+  if (int rc = gemm_attrs()) return rc;
+  static const bool swz = !(getenv("RARC_GEMM_SWZ") && atoi(getenv("RARC_GEMM_SWZ")) == 0);
+  const int order = swz ? 2 : 0;
+  GemmSplitEpi fx;
+  fx.thr = thr; fx.cand = cand; fx.count = count; fx.status = status; fx.cap = cap; fx.row0 = row0; fx.n_valid = n_valid;
+  const long long tiles = (long long)(m / 256) * (n / 256);
+  hipLaunchKernelGGL((rarc_gemm256_f16_kernel<6>), dim3(tiles > 256 ? 256 : (int)tiles), dim3(512), G256_LDS, s, (const half_t*)a,
+                     (const half_t*)w, (const half_t*)nullptr, (half_t*)nullptr, m, n, k, order, (float*)nullptr, fx);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
 // fp32 product of fp16 operands, no bias: C32[M][N] = A[M][K]·W[N][K]ᵀ — the GEMM of the fp32-class forward
 // (encoder_f32.hip: split operands, K = 3x the model's k), on the same tile kernels with an fp32 epilogue.
 int rarc_gemm_f16_f32out(const uint16_t* a, const uint16_t* w, float* c, int m, int n, int k, hipStream_t s) {

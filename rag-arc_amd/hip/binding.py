@@ -174,6 +174,9 @@ SIGNATURES = {
     "rarc_wide_workspace_bytes": (c_size_t, [c_int, c_int]),
     "rarc_search_wide": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_float, c_float, c_void_p, c_int, c_int, c_int64,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "rarc_similar_pairs_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "rarc_similar_pairs": (c_int, [c_void_p, c_int64, c_int64, c_int, ctypes.c_double, c_void_p, c_size_t, c_int, c_void_p, c_void_p,
+                                   c_int64, c_void_p, c_void_p, c_void_p]),
     "rarc_compact_rows": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "rarc_vmem_create": (c_int, [c_int, c_size_t, c_size_t, c_size_t, ctypes.POINTER(c_void_p)]),
     "rarc_vmem_grow": (c_int, [c_void_p, c_size_t]),

@@ -9,6 +9,7 @@
 #                                        trace options next to --pmc); default counter FETCH_SIZE -> HBM bytes per launch
 #   tools/prof.sh api                    the plugin-surface legs only (bench.py `api` object)
 #   tools/prof.sh wide                   the wide-row leg (10M x 1536) with a kernel trace
+#   tools/prof.sh pairs                  the all-pairs cosine leg (100k x 1024 entities) with a kernel trace
 #   tools/prof.sh f32                    the storage="f32" leg (10M x 768 fp32 rows)
 #   tools/prof.sh enc [fp32|fp16]        encoder batch sweep (tools/enc_batch_sweep.py)
 #   tools/prof.sh power <out> <cmd...>   board power / clocks sampled while <cmd> runs (tools/power_sample.sh)
@@ -17,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 what=${1:-bench}; shift
 O=$R/gpurun_out/prof_$what; mkdir -p "$O"; cd "$R"
-QUIET="--no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-wide --no-cpu-baseline"
+QUIET="--no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-wide --no-pairs --no-cpu-baseline"
 stats() { f=$(ls -t "$1"/*/*kernel_stats.csv "$1"/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cut -d, -f1-5 "$f" | cut -c1-140 | head -${2:-14}; }
 case $what in
   bench)
@@ -32,9 +33,10 @@ case $what in
     export PROBE_ROWS=${1:-100000000} PROBE_DIM=${2:-768} PROBE_STORAGE=${3:-f16} PROBE_ITERS=3; shift; shift; shift
     timeout 900 rocprofv3 --pmc ${@:-FETCH_SIZE} -d "$O/pmc" -- python3 tools/gpu_scan_only.py > "$O/pmc.log" 2>&1
     python3 tools/pmc_summary.py "$O/pmc" all | tee "$O/pmc_summary.txt" | grep -i scan | head -6;;
-  api)   timeout 900 python3 bench.py --no-c3 --no-c5 --no-persist --no-ingest --no-f32 --no-wide "$@" > "$O/api.json" 2> "$O/api.err"; python3 -c "import json; print(json.dumps(json.load(open('$O/api.json'))['api'], indent=1))";;
-  wide)  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --rows 1000000 --no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-cpu-baseline --verify-queries 8 "$@" > "$O/wide.json" 2> "$O/wide.err"; stats "$O/kt" 10; python3 -c "import json; print(json.dumps(json.load(open('$O/wide.json'))['wide']))";;
-  f32)   timeout 900 python3 bench.py --rows 1000000 --no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-wide --no-cpu-baseline --verify-queries 8 "$@" > "$O/f32.json" 2> "$O/f32.err"; python3 -c "import json; print(json.dumps(json.load(open('$O/f32.json'))['f32']))";;
+  api)   timeout 900 python3 bench.py --no-c3 --no-c5 --no-persist --no-ingest --no-f32 --no-wide --no-pairs "$@" > "$O/api.json" 2> "$O/api.err"; python3 -c "import json; print(json.dumps(json.load(open('$O/api.json'))['api'], indent=1))";;
+  wide)  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --rows 1000000 --no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-pairs --no-cpu-baseline --verify-queries 8 "$@" > "$O/wide.json" 2> "$O/wide.err"; stats "$O/kt" 10; python3 -c "import json; print(json.dumps(json.load(open('$O/wide.json'))['wide']))";;
+  f32)   timeout 900 python3 bench.py --rows 1000000 --no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-wide --no-pairs --no-cpu-baseline --verify-queries 8 "$@" > "$O/f32.json" 2> "$O/f32.err"; python3 -c "import json; print(json.dumps(json.load(open('$O/f32.json'))['f32']))";;
+  pairs) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --rows 1000000 --no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-wide --verify-queries 8 "$@" > "$O/pairs.json" 2> "$O/pairs.err"; stats "$O/kt" 8; python3 -c "import json; print(json.dumps(json.load(open('$O/pairs.json'))['pairs']))";;
   enc)   RARC_ENC_PRECISION=${1:-fp32} python3 tools/enc_batch_sweep.py 2>/dev/null | grep ENC | tee "$O/enc_${1:-fp32}.txt";;
   power) out=$1; shift; tools/power_sample.sh "$O/$out" "$@";;
   vmem)  python3 tools/vmem_probe.py 2>&1 | grep -v amdgpu.ids | tee "$O/vmem_probe.txt";;
