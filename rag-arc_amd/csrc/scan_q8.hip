@@ -901,8 +901,14 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   uint32_t cuts[3];
   int n_cuts = 0;
   if (tighten && split_mode > 0) {
-    const uint32_t div[3] = {512u, 64u, 8u};
+    uint32_t div[3] = {512u, 64u, 8u};
+    if (const char* e = getenv("RARC_SPLIT_DIVS")) {          // (experiments: "64,8" / "0,0,16" ...; 0 = no cut)
+      unsigned a = 0, b = 0, c = 0;
+      const int got = sscanf(e, "%u,%u,%u", &a, &b, &c);
+      if (got >= 1) { div[0] = a; div[1] = got >= 2 ? b : 0; div[2] = got >= 3 ? c : 0; }
+    }
     for (int i = (split_mode >= 3 ? 0 : (split_mode == 2 ? 1 : 2)); i < 3; ++i) {
+      if (div[i] == 0) continue;
       const uint32_t t = (p.n_tiles / div[i]) / pair * pair;
       // (a stretch shorter than 8 pairs of tile rounds per workgroup costs more in launches than it saves; the
       //  1/8 cut keeps its measured limit of 16: below ~2M rows the second launch does not pay)
