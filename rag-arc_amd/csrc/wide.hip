@@ -16,8 +16,8 @@
 // >= a_k - eps, so the true k-th best canonical score L >= a_k - eps, and a row with canonical score >= L has s >= a_k - 2 eps:
 // nothing below thr = a_k - 2 eps can be in the answer, ever (a_k only rises).  The candidates that reach the finalize
 // therefore contain every row with canonical score >= L, ties included; their canonical scores are computed in the
-// oracle's order (8 chains + tree) and ranked by (score desc, id asc).  The chunks double from a first one of max(2048,
-// 2k) rows, so the list of a query holds its k best plus a margin of rows, not a share of the corpus.  A candidate list
+// oracle's order (8 chains + tree) and ranked by (score desc, id asc).  The chunks grow geometrically from a first one of
+// max(16384, 2k) rows, so the list of a query holds its k best plus a margin of rows, not a share of the corpus.  A candidate list
 // that fills up sets the query's status word (the caller re-runs with a larger capacity; capacity >= n cannot overflow).
 //
 // HBM traffic per row: 2·d_pad bytes of row + 512 B of scores written + 512 B read back (+33 % at d = 1536, +17 % at 3072).
@@ -241,16 +241,34 @@ __global__ __launch_bounds__(1024) void wide_tighten_kernel(const uint64_t* __re
 
 // canonical fp32 score of a query with one stored row, by 8 lanes: lane j runs chain j (elements 8m + j, m ascending), the
 // tree of rarc_canon_tree joins them — the same arithmetic, in the same order, as canon_dot_f16 / oracle canon_dot.
+// fp16 rows: the group fetches 128 contiguous bytes per step (lane j the 16 bytes of elements 8(8b + j) .. + 7) and passes them
+// through its 128 bytes of LDS, from which lane j picks element j of each of the eight pieces in ascending order — one
+// 16-byte load per 64 elements and lane instead of eight 2-byte ones (the finalize was 100 us of a 490 us search of 100,000
+// rows, 2 ms of 13 at k = 2000: all of it these loads).  A wave's LDS operations execute in order, so the lanes of a group
+// (always inside one wave) see each other's writes without a barrier.  q: the query in LDS (fp32).
 template <bool F32ROWS>
-__device__ __forceinline__ float wide_canon_dot8(const float* __restrict__ q, const void* __restrict__ rows, size_t row, int d_pad,
-                                                 int j) {
+__device__ __forceinline__ float wide_canon_dot8(const float* q, const void* __restrict__ rows, size_t row, int d_pad, int j,
+                                                 uint4* stage) {
   float a = 0.f;
   if (F32ROWS) {
     const float* r = (const float*)rows + row * (size_t)d_pad;
     for (int m = j; m < d_pad; m += 8) a = __builtin_fmaf(q[m], r[m], a);
   } else {
-    const half_t* r = (const half_t*)rows + row * (size_t)d_pad;
-    for (int m = j; m < d_pad; m += 8) a = __builtin_fmaf(q[m], (float)r[m], a);
+    const uint4* r = (const uint4*)((const half_t*)rows + row * (size_t)d_pad) + j;
+    const half_t* sh = (const half_t*)stage + j;
+    const int nblk = d_pad >> 6;                    // 64 elements per step (d_pad is a multiple of 64)
+    uint4 v0 = r[0], v1 = nblk > 1 ? r[8] : v0;     // two steps in flight
+    for (int b = 0; b < nblk; ++b) {
+      const uint4 vn = b + 2 < nblk ? r[(b + 2) * 8] : v1;
+      stage[j] = v0;
+      asm volatile("" ::: "memory");
+      const float* qb = q + 64 * b + j;
+#pragma unroll
+      for (int mm = 0; mm < 8; ++mm) a = __builtin_fmaf(qb[8 * mm], (float)sh[8 * mm], a);
+      asm volatile("" ::: "memory");
+      v0 = v1;
+      v1 = vn;
+    }
   }
   // ((a0 + a4) + (a2 + a6)) + ((a1 + a5) + (a3 + a7)): lanes j and j ^ 4, then j ^ 2, then j ^ 1
   a = a + __shfl_xor(a, 4, 8);
@@ -275,14 +293,18 @@ __global__ __launch_bounds__(1024) void wide_finalize_kernel(const void* __restr
   const uint32_t c_all = count[q], c = c_all < cap ? c_all : cap;
   if (c_all > cap && threadIdx.x == 0) atomicOr(&status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
   uint64_t* keys = cand + (size_t)q * cap;
-  const float* qv = q32 + (size_t)q * d_pad;
+  __shared__ float s_q[4096];                               // the query (d_pad <= 4096)
+  __shared__ uint4 s_stage[1024];                           // 128 bytes per 8-lane group
+  for (int m = threadIdx.x; m < d_pad; m += blockDim.x) s_q[m] = q32[(size_t)q * d_pad + m];
+  __syncthreads();
   // 1. canonical keys, in place (8 lanes per candidate)
   {
     const int j = threadIdx.x & 7;
+    uint4* stage = s_stage + (threadIdx.x & ~7);
     for (uint32_t i = threadIdx.x >> 3; i < ((c + 127u) & ~127u); i += blockDim.x >> 3) {
       const bool live = i < c;
       const uint32_t row = live ? rarc_candrow(keys[i]) : 0u;
-      const float s = wide_canon_dot8<F32ROWS>(qv, rows, row, d_pad, j);
+      const float s = wide_canon_dot8<F32ROWS>(s_q, rows, row, d_pad, j, stage);
       if (live && j == 0) keys[i] = rarc_candkey(s, row);
     }
   }
@@ -345,7 +367,7 @@ extern "C" size_t rarc_wide_workspace_bytes(int d_pad, int cand_cap) {
 // d_rows: the stored rows (fp16 [n][d_pad]; fmt 2: fp32 [n][d_pad] with d_image16 their fp16 image, what the GEMM reads).
 // d_qblock: written by rarc_prep_queries (q32, q16).  max_norm: the largest stored row norm; rho: fmt 2, >= ||row32 - image16||.
 // d_status: uint32 [256], per-query flag words (RARC_Q_OVERFLOW: re-run with a larger cand_cap; cand_cap >= n_rows cannot
-// overflow).  cand_cap >= max(2048, 2k) rounded up to 128.
+// overflow).  cand_cap >= max(16384, 2k) rounded up to 256, + 256.
 extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, int fmt, int64_t n_rows, int d_pad, float max_norm,
                                 float rho, const void* d_qblock, int nq, int k, int64_t id_base, int64_t* d_out_ids,
                                 float* d_out_scores, uint32_t* d_status, void* d_ws, size_t ws_bytes, int cand_cap, void* stream) {
@@ -357,9 +379,15 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
                "rarc_search_wide: padded dim %d unsupported (multiple of %d, <= 4096)", d_pad, RARC_DIM_ALIGN);
   RARC_REQUIRE(nq >= 1 && nq <= RARC_MAX_QUERIES && k >= 1 && k <= WIDE_KMAX && n_rows >= 0 && n_rows < (int64_t)0xffffff00ll,
                RARC_E_INVALID, "rarc_search_wide: need 1 <= nq <= %d, 1 <= k <= %d (nq=%d k=%d)", RARC_MAX_QUERIES, WIDE_KMAX, nq, k);
-  int first = 2 * k > 2048 ? 2 * k : 2048;
-  first = (first + 127) / 128 * 128;
-  RARC_REQUIRE(cand_cap >= first, RARC_E_WORKSPACE, "rarc_search_wide: cand_cap %d < %d (the first chunk of rows)", cand_cap, first);
+  // The first chunk — no threshold yet: every one of its rows is a candidate of every query, written by row number — is
+  // max(16384, 2k) rows plus whatever makes the REST of the shard a whole number of 256-row blocks (the fused GEMM's unit; the
+  // ragged end is dealt with here, once, by the kernel pair that takes any row count).  It was 2048 rows and the chunks
+  // doubled: a 100,000-row shard then went through five fused GEMMs of 16..142 tiles, each a tile's full latency (60-100 us)
+  // on a corner of the chip — 0.65 ms per batch for 0.08 ms of matrix work; 16384 rows fill the chip on the 128 x 128 kernel.
+  int first = 2 * k > 16384 ? 2 * k : 16384;
+  first = (first + 255) / 256 * 256;
+  RARC_REQUIRE(cand_cap >= first + 256, RARC_E_WORKSPACE, "rarc_search_wide: cand_cap %d < %d (the first chunk of rows)", cand_cap,
+               first + 256);
   char* wsb = (char*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
   RARC_REQUIRE(wsb + wide_ws_bytes(d_pad, cand_cap) <= (char*)d_ws + ws_bytes, RARC_E_WORKSPACE,
                "rarc_search_wide: workspace of %zu bytes, %zu needed", ws_bytes, wide_ws_bytes(d_pad, cand_cap) + 256);
@@ -373,7 +401,9 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
   uint64_t *cur = w.cand, *other = w.cand2;
   uint32_t *ccur = w.count, *cother = w.count2;
   int64_t at = 0;
-  int64_t chunk = first;
+  int64_t chunk = n_rows > first ? first + (n_rows - first) % 256 : n_rows;
+  int64_t nominal = first;                    // the chunk sizes' geometric ladder: first, first * g, ... up to fused_max
+  const int64_t growth = k <= 1024 ? 4 : 2;   // (a chunk of g x the rows seen lets ~g k rows per query through: lists of 16384)
   int n_chunk = 0;
   int64_t fused_max = WIDE_FUSED_CHUNK;
   if (const char* e = getenv("RARC_WIDE_FUSED_ROWS")) {   // (experiments: tools/wide_chunk_sweep.sh)
@@ -406,7 +436,8 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
         //  removed: a counter update per nomination inside the GEMM (now one per 16-lane group), and no tighten between the
         //  growing chunks past 131072 rows — a threshold from 126K rows let 8 x k rows of a 524K-row chunk through and the lists
         //  overflowed, i.e. every search ran twice.  10M x 1536, k = 2000: 16.8 -> 13.3 ms.)
-        chunk = chunk * 2 < fused_max ? chunk * 2 : fused_max;
+        nominal = nominal * growth < fused_max ? nominal * growth : fused_max;
+        chunk = nominal;
         continue;
       }
     }
@@ -445,9 +476,12 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
       { uint64_t* t = cur; cur = other; other = t; }
       { uint32_t* t = ccur; ccur = cother; cother = t; }
     }
-    // chunks DOUBLE up to the full size: under the k-th best score of the S rows seen so far a chunk of S more rows lets
-    // about k of them through (growing 8x it was 7k: for k in the thousands that filled the lists)
-    chunk = chunk * 2 < WIDE_CHUNK ? chunk * 2 : WIDE_CHUNK;
+    // chunks grow geometrically (x4, x2 for k in the thousands) up to the full size: under the k-th best score of the S rows
+    // seen so far a chunk of g S more rows lets about g k of them through (growing 8x it was 7k: for k in the thousands that
+    // filled the lists).  (The fused form above takes over after the first chunk wherever the GEMM takes the shape; this
+    // branch continues the ladder for what it leaves.)
+    nominal = nominal * growth < fused_max ? nominal * growth : fused_max;
+    chunk = nominal < WIDE_CHUNK ? nominal : WIDE_CHUNK;
   }
   uint32_t pow2 = 1;
   while (pow2 < (uint32_t)k) pow2 <<= 1;

@@ -770,7 +770,7 @@ class FlatIndexF16:
         return float(self.max_norm) * 2.0 ** -11 * 1.001 + 2.0 ** -25 * float(self.d_pad) ** 0.5
 
     def _search_wide_chunk(self, q, k, out_ids, out_sc) -> None:
-        """<= 256 queries through rarc_search_wide.  The candidate capacity starts at max(16384, 4k) entries per query; a
+        """<= 256 queries through rarc_search_wide.  The candidate capacity starts at max(16640, 4k) entries per query; a
         query whose list filled up (rows within the error margin of its k-th best score: near-duplicates) is answered again
         with four times the capacity, up to the capacity that cannot overflow (one entry per stored row)."""
         t = self.torch
@@ -781,9 +781,9 @@ class FlatIndexF16:
         stream = self._stream()
         B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], nq, self.dim, self.d_pad, norm, mn, 0,
                                            self._qbuf["qblock"].data_ptr(), stream), "rarc_prep_queries")
-        first = ((max(2048, 2 * k) + 127) // 128) * 128
-        cap = max(16384, 4 * k, first)
-        sure = ((self.ntotal + 127) // 128) * 128 + first    # every stored row + the first chunk: cannot overflow
+        first = ((max(16384, 2 * k) + 255) // 256) * 256 + 256   # the library's first chunk of rows (csrc/wide.hip) at its largest
+        cap = max(4 * k, first)
+        sure = ((self.ntotal + 255) // 256) * 256 + first    # every stored row + the first chunk: cannot overflow
         status = t.zeros(B.MAX_QUERIES, dtype=t.int32, device=self.device)
         image = self._image16.data_ptr() if self.storage == "f32" else 0
         fmt = 2 if self.storage == "f32" else 0
