@@ -1069,10 +1069,18 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
     from rag_arc_amd.encapsulation.database.vector_db.hip_flat import HipFlatVectorStore
     from rag_arc_amd.encapsulation.embeddings.table import TableEmbeddings
 
+    import gc
+
+    # what the earlier legs of THIS process left on the heap (the LM's and the encoder's python objects, result dicts, ...) is not
+    # part of a retrieval service: out of the cyclic collector's way before the leg builds its own docstore, back at the end
+    # (tools/gc_probe.py: in a process that holds the store and nothing else an answer's collection costs ~1 ms per 256 x 100)
+    gc.collect()
+    gc.freeze()
     K, NB, NQT = a.k, 256, 2048
     out = {"workload": f"{n_rows}x{a.dim} fp16, batch {NB} query TEXTS -> lists of {K} Documents, through "
                        f"{'registrator.get_object(...)' if via_registry else 'VectorStoreRetriever(HipFlatVectorStore)'}",
-           "engine": engine}
+           "engine": engine,
+           "gc": "enabled; the objects of the bench's earlier legs were frozen out of its generations before this leg built its docstore"}
     t0 = time.perf_counter()
     width = len(str(n_rows - 1))
     if n_rows <= 2_000_000:
