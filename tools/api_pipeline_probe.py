@@ -29,3 +29,12 @@ for rep in range(2):
     sc, rows = pending.host(); out.extend(store._map_batch(sc, rows, False))
     torch.cuda.synchronize(); total = time.perf_counter() - t_all
     print(f"rep {rep}: total {total*1e3:.1f} ms; per chunk (launch, wait, map) ms:", [tuple(round(x * 1e3, 2) for x in m) for m in marks])
+import cProfile, pstats, gc
+for rep in range(2):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ans = store.batch_search_by_vector(q, K)
+    torch.cuda.synchronize(); print(f"store.batch_search_by_vector(2048): {(time.perf_counter() - t0) * 1e3:.1f} ms")
+    del ans
+pr = cProfile.Profile(); pr.enable()
+ans = store.batch_search_by_vector(q, K)
+pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(10)
