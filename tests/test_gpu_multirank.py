@@ -56,7 +56,8 @@ def _worker(rank, world, port, n, d, nq, k, out_dir, backend="gloo"):
     cap = ((hi - lo + 31) // 32) * 32
     rows = torch.zeros((max(cap, 32), d), dtype=torch.float16, device="cuda")
     B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d, d, lo, hi - lo, 1234, 0))
-    idx = FlatIndexF16(d, device=dev, id_base=lo, scan="q8" if rank % 2 else "auto")     # mixed scan kernels across ranks
+    wide = B.padded_dim(d) > 1024 or k > 1024                                            # (the wide path takes scan="auto" only)
+    idx = FlatIndexF16(d, device=dev, id_base=lo, scan="q8" if rank % 2 and not wide else "auto")     # mixed scan kernels across ranks
     idx.add_rows_f16(rows, 1.001, n_valid=hi - lo)
     q = torch.zeros((nq, d), dtype=torch.float32, device="cuda")
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), d, d, 0, nq, 4321, 0))
@@ -72,8 +73,14 @@ def _worker(rank, world, port, n, d, nq, k, out_dir, backend="gloo"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,backend", [(2, "gloo"), (8, "gloo"), (2, "nccl"), (4, "nccl"), (8, "nccl")])
-def test_sharded_search_across_real_ranks(tmp_path, world, backend):
+# shapes: the register-resident scans; rows of 1536 dimensions and k = 1500 (the wide path, round 5) behind the same exchange
+_SHAPES = {"narrow": (300_001, 256, 96, 50), "wide_rows": (60_001, 1536, 40, 50), "wide_k": (40_001, 256, 24, 1500)}
+
+
+@pytest.mark.parametrize("world,backend,shape", [(2, "gloo", "narrow"), (8, "gloo", "narrow"), (2, "gloo", "wide_rows"),
+                                                 (4, "gloo", "wide_k"), (2, "nccl", "narrow"), (4, "nccl", "narrow"),
+                                                 (8, "nccl", "narrow"), (2, "nccl", "wide_rows")])
+def test_sharded_search_across_real_ranks(tmp_path, world, backend, shape):
     import torch
     import torch.multiprocessing as mp
 
@@ -81,9 +88,9 @@ def test_sharded_search_across_real_ranks(tmp_path, world, backend):
     from rag_arc_amd.hip.engine import FlatIndexF16
 
     _need_gpus(world, backend)
-    n, d, nq, k = 300_001, 256, 96, 50
-    mp.spawn(_worker, args=(world, 29650 + world + (20 if backend == "nccl" else 0), n, d, nq, k, str(tmp_path), backend),
-             nprocs=world, join=True)
+    n, d, nq, k = _SHAPES[shape]
+    port = 29650 + world + (20 if backend == "nccl" else 0) + 40 * list(_SHAPES).index(shape)
+    mp.spawn(_worker, args=(world, port, n, d, nq, k, str(tmp_path), backend), nprocs=world, join=True)
     lib = B.load_library()
     rows = torch.zeros((((n + 31) // 32) * 32, d), dtype=torch.float16, device="cuda")
     B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d, d, 0, n, 1234, 0))
