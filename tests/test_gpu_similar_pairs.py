@@ -86,3 +86,31 @@ def test_edges():
         similar_pairs([[1.0, 2.0], [2.0, 1.0]], 0.0)
     with pytest.raises(RarcError):
         similar_pairs(np.zeros((3, 5000), dtype=np.float32), 0.95)
+
+
+_FIRST, _LAST = (int(v) for v in os.environ.get("RARC_FUZZ_SEEDS", "0:10").split(":"))
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _LAST))
+def test_random_shapes(oracle, seed):
+    """Seeded sweep (RARC_FUZZ_SEEDS widens it): sizes around the 256-row blocks and the 4096-column super-blocks, dimensions
+    off every grid, thresholds from loose to 1, duplicates at distances that straddle the threshold."""
+    from rag_arc_amd.encapsulation.database.graph_db import similar_pairs
+
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([2, 3, 255, 256, 257, 1000, 4095, 4096, 4097, 6000, 8193]))
+    d = int(rng.choice([1, 2, 7, 64, 100, 257, 768, 1024, 1500, 3072]))
+    thr = float(rng.choice([0.5, 0.8, 0.9, 0.95, 0.99, 0.9999]))
+    if d <= 7:
+        n = min(n, 300)                      # (few dimensions: most pairs are similar — keep the answer small)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    n_dup = max(1, n // 10)
+    src, dst = rng.integers(0, n, n_dup), rng.integers(0, n, n_dup)
+    # distances chosen so that the planted pairs' cosines spread on both sides of the threshold
+    noise = np.sqrt(max(1.0 / thr ** 2 - 1.0, 1e-6)) * rng.uniform(0.3, 2.0, (n_dup, 1))
+    x[dst] = (x[src] + noise * rng.standard_normal((n_dup, d)) * np.linalg.norm(x[src], axis=1, keepdims=True) / np.sqrt(d)).astype(np.float32)
+    if seed % 3 == 0:
+        x[rng.integers(0, n, max(1, n // 50))] = 0.0          # zero rows
+    got = similar_pairs(x, thr)
+    want = oracle.similar_pairs_f64(x.astype(np.float64), thr)
+    _same(got, want, thr, (seed, n, d, thr))

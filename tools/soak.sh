@@ -7,6 +7,7 @@ S=${1:-14:134}; M=${2:-8:40}
 { echo "tree: $(git -C "$R" rev-parse --short HEAD 2>/dev/null || echo snapshot)  $(date -u +%FT%TZ)"
   echo "== shape sweep, seeds $S (tests/test_gpu_fuzz_shapes.py)";      RARC_FUZZ_SEEDS=$S timeout 3000 python3 -m pytest tests/test_gpu_fuzz_shapes.py -q -x 2>&1 | tail -2
   echo "== lifecycle sweep, seeds $S (tests/test_gpu_fuzz_lifecycle.py)"; RARC_FUZZ_SEEDS=$S timeout 3000 python3 -m pytest tests/test_gpu_fuzz_lifecycle.py -q -x 2>&1 | tail -2
+  echo "== all-pairs cosine sweep, seeds $S (tests/test_gpu_similar_pairs.py)"; RARC_FUZZ_SEEDS=$S timeout 3000 python3 -m pytest tests/test_gpu_similar_pairs.py -q -x 2>&1 | tail -2
   echo "== model sweep, seeds $M (tests/test_gpu_fuzz_models.py)";       RARC_FUZZ_SEEDS=$M timeout 3000 python3 -m pytest tests/test_gpu_fuzz_models.py -q -x 2>&1 | tail -2
   echo "== search repeatability (tools/search_soak.py)";                 timeout 1200 python3 tools/search_soak.py 2>&1 | tail -6
   echo "== encoder repeatability (tools/enc_det_soak.py)";               timeout 1200 python3 tools/enc_det_soak.py 2>&1 | tail -4
