@@ -597,35 +597,50 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
       const float4 t4 = *(const float4*)(fx.thr + tn * 256 + wc * 64 + j * 16 + 4 * q_e);
       t16[j][0] = t4.x; t16[j][1] = t4.y; t16[j][2] = t4.z; t16[j][3] = t4.w;
     }
-    // A register (i, j, e) holds one query per group of 16 lanes (q_e) and 16 rows across the group: the lanes of a group
-    // that nominate take their places in the query's list with ONE atomic (k in the thousands lets thousands of rows per
-    // query and chunk through — a counter per nomination made the GEMM 1.7x as long); nothing but a ballot when no lane does.
+    // A register (i, j, e) holds one query per group of 16 lanes (q_e) and 16 rows across the group.  Phase A counts, per column
+    // (j, e), the wave's rows that reach the threshold and reserves their places in the query's list with ONE atomic per
+    // column and group — all sixteen issued before any result is needed; phase B hands the places out.  (An atomic per
+    // nomination made the GEMM 1.7x as long at k = 2000; an atomic per REGISTER, awaited before the next register was looked
+    // at, still cost the growing chunks of every search 3x their time: under their loose thresholds a third of the registers
+    // have a hit somewhere in the wave — 40 round trips to L2 per tile, one after the other.)
     const unsigned long long grp_mask = 0xFFFFull << (16 * q_e);
+    const int leader = 16 * q_e;
+    uint32_t tot16[4][4], base16[4][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const uint32_t r = (uint32_t)(tm * 256 + wr * 128 + i * 16 + row_e);
-      const bool row_ok = r < fx.n_valid;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int e = 0; e < 4; ++e) {
+        uint32_t tot = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int i = 0; i < 8; ++i) {
+          const bool hit = (uint32_t)(tm * 256 + wr * 128 + i * 16 + row_e) < fx.n_valid && acc[i][j][e] >= t16[j][e];
+          tot += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit) & grp_mask);
+        }
+        tot16[j][e] = tot;
+        base16[j][e] = 0;
+        if (tot && lane_e == leader) base16[j][e] = atomicAdd(&fx.count[(uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e)], tot);
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (tot16[j][e] == 0) continue;                      // (uniform over the group: its sixteen lanes go on together)
+        const uint32_t q = (uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e);
+        uint32_t at = (uint32_t)__builtin_amdgcn_ds_bpermute(leader << 2, (int)base16[j][e]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t r = (uint32_t)(tm * 256 + wr * 128 + i * 16 + row_e);
           const float sc = acc[i][j][e];
-          const bool hit = row_ok && sc >= t16[j][e];
-          const unsigned long long bal = __builtin_amdgcn_ballot_w64(hit);
-          if (bal == 0) continue;
+          const bool hit = r < fx.n_valid && sc >= t16[j][e];
+          const unsigned long long grp = __builtin_amdgcn_ballot_w64(hit) & grp_mask;
           if (hit) {
-            const unsigned long long grp = bal & grp_mask;
-            const int leader = __builtin_ctzll(grp);
-            const uint32_t q = (uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e);
-            uint32_t base = 0;
-            if (lane_e == leader) base = atomicAdd(&fx.count[q], (uint32_t)__builtin_popcountll(grp));
-            base = (uint32_t)__builtin_amdgcn_ds_bpermute(leader << 2, (int)base);
-            const uint32_t pos = base + (uint32_t)__builtin_popcountll(grp & ((1ull << lane_e) - 1ull));
+            const uint32_t pos = at + (uint32_t)__builtin_popcountll(grp & ((1ull << lane_e) - 1ull));
             if (pos < fx.cap) fx.cand[(size_t)q * fx.cap + pos] = rarc_candkey(sc, fx.row0 + r);
             else atomicOr(&fx.status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
           }
+          at += (uint32_t)__builtin_popcountll(grp);
         }
-    }
+      }
   } else if constexpr (BASE == 3) {  // silu(gate)·up: the wave's 64 columns are 32 features -> 64-byte output rows
     // gate / up columns alternate in groups of eight: in a 16-column block the lanes with (lane >> 4) < 2 hold gate values of
     // features 4 q + e, the lanes 32 above them the up values of the same features.  One v_permlane32_swap per pair of registers
@@ -1438,6 +1453,54 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
         *(uint4*)(rowp + (c - 4) * 8) = v;
       }
     }
+  } else if (BASE == 6) {  // scores against per-column thresholds -> candidate lists, nothing stored (as the 256 x 256 kernel's ACT 6;
+                           // wide.hip's chunks of at most one 256 x 256 tile per CU: four of these tiles per CU pipeline, one does not)
+    // register (i, 4g + e): rows wr*64 + i*32 + row, column wc*32 + 8g + 4hh + e — one query per half-wave (hh), 32 rows across it;
+    // counted first, one atomic per column and half-wave, then written (see the 256 x 256 kernel's ACT 6)
+    const unsigned long long grp_mask = hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
+    const int leader = 32 * hh;
+    float t16[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 t4 = *(const float4*)(fx.thr + tn * 128 + wc * 32 + 8 * g + 4 * hh);
+      t16[g][0] = t4.x; t16[g][1] = t4.y; t16[g][2] = t4.z; t16[g][3] = t4.w;
+    }
+    uint32_t tot16[4][4], base16[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const bool hit = (uint32_t)(tm * 128 + wr * 64 + i * 32 + row) < fx.n_valid && acc[i][4 * g + e] >= t16[g][e];
+          tot += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hit) & grp_mask);
+        }
+        tot16[g][e] = tot;
+        base16[g][e] = 0;
+        if (tot && lane == leader) base16[g][e] = atomicAdd(&fx.count[(uint32_t)(tn * 128 + wc * 32 + 8 * g + 4 * hh + e)], tot);
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (tot16[g][e] == 0) continue;
+        const uint32_t q = (uint32_t)(tn * 128 + wc * 32 + 8 * g + 4 * hh + e);
+        uint32_t at = (uint32_t)__builtin_amdgcn_ds_bpermute(leader << 2, (int)base16[g][e]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint32_t r = (uint32_t)(tm * 128 + wr * 64 + i * 32 + row);
+          const float sc = acc[i][4 * g + e];
+          const bool hit = r < fx.n_valid && sc >= t16[g][e];
+          const unsigned long long grp = __builtin_amdgcn_ballot_w64(hit) & grp_mask;
+          if (hit) {
+            const uint32_t pos = at + (uint32_t)__builtin_popcountll(grp & ((1ull << lane) - 1ull));
+            if (pos < fx.cap) fx.cand[(size_t)q * fx.cap + pos] = rarc_candkey(sc, fx.row0 + r);
+            else atomicOr(&fx.status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
+          }
+          at += (uint32_t)__builtin_popcountll(grp);
+        }
+      }
   } else {
     constexpr int ST = 32 * 2 + 16;
     char* ep = smem + wave * 64 * ST;
@@ -2059,6 +2122,7 @@ static int gemm_attrs() {
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
+  RARC_HIP_CHECK(hipFuncSetAttribute((const void*)rarc_gemm128pp_f16_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, G128S_LDS));
   attr = 1;
   return RARC_OK;
 }
@@ -2270,6 +2334,16 @@ int rarc_gemm_f16_select(const uint16_t* a, const uint16_t* w, int m, int k, con
   GemmSplitEpi fx;
   fx.thr = thr; fx.cand = cand; fx.count = count; fx.status = status; fx.cap = cap; fx.row0 = row0; fx.n_valid = n_valid;
   const int tiles = m / 256;
+  // up to one 256 x 256 tile per CU: the tiles start in lockstep, every CU fetches, then every CU multiplies — a lone tile took
+  // 169 us where a streamed one takes 53.  The 128 x 128 ping-pong kernel (four tiles per CU's worth of work, a four-deep
+  // operand ring) takes those chunks: the ramp of every search and all of a small shard.
+  static const int small_max = getenv("RARC_WIDE_SMALL_TILES") ? atoi(getenv("RARC_WIDE_SMALL_TILES")) : 256;   // (A/B: 0 = never)
+  if (tiles <= small_max) {
+    hipLaunchKernelGGL((rarc_gemm128pp_f16_kernel<6>), dim3((m / 128) * 2, 1), dim3(512), G128S_LDS, s, (const half_t*)a, (const half_t*)w,
+                       (const half_t*)nullptr, (half_t*)nullptr, m, 256, k, k, order, (float*)nullptr, fx);
+    RARC_HIP_CHECK(hipGetLastError());
+    return RARC_OK;
+  }
   hipLaunchKernelGGL((rarc_gemm256_f16_kernel<6>), dim3(tiles > 256 ? 256 : tiles), dim3(512), G256_LDS, s, (const half_t*)a,
                      (const half_t*)w, (const half_t*)nullptr, (half_t*)nullptr, m, 256, k, order, (float*)nullptr, fx);
   RARC_HIP_CHECK(hipGetLastError());
