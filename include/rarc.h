@@ -582,7 +582,7 @@ int rarc_device_to_file(const char* path, int n_seg, const int64_t* h_file_off, 
  * (csrc/wide.hip has the bound).  fmt 0: fp16 rows; fmt 2: fp32 rows + their fp16 image (what the GEMM reads; rho >=
  * ||row - image||, as qmeta[1]).  d_qblock as written by rarc_prep_queries (which takes d_pad up to 4096).  d_status:
  * uint32 [256], a query whose candidate list filled up carries RARC_Q_OVERFLOW — call again with a larger cand_cap
- * (cand_cap >= n_rows cannot overflow; it must be at least max(16384, 2k) rounded up to 256, plus 256: the first chunk of rows).
+ * (cand_cap >= n_rows cannot overflow; it must be at least max(16384, 2k) rounded up to 256, plus 256: the first chunk of rows — and a multiple of 8).
  */
 size_t rarc_wide_workspace_bytes(int d_pad, int cand_cap);
 int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, int fmt, int64_t n_rows, int d_pad, float max_norm,

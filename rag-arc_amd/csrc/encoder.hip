@@ -304,6 +304,9 @@ struct GemmSplitEpi {
   uint32_t* count = nullptr;             // [N]
   uint32_t* status = nullptr;            // [N]
   uint32_t cap = 0, row0 = 0, n_valid = 0;
+  // a query's list is `shards` (1 or 8) sub-lists of cap / shards entries with a counter each (count is [N][shards]); a workgroup
+  // nominates into sub-list blockIdx.x % shards — 1000 workgroups adding to ONE counter per query serialise on it (wide.hip)
+  uint32_t shards = 1;
 };
 __device__ __forceinline__ float gemm_gelu_libm(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
     // have a hit somewhere in the wave — 40 round trips to L2 per tile, one after the other.)
     const unsigned long long grp_mask = 0xFFFFull << (16 * q_e);
     const int leader = 16 * q_e;
+    const uint32_t shard = blockIdx.x & (fx.shards - 1u), cap_s = fx.cap / fx.shards;
     uint32_t tot16[4][4], base16[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -618,7 +622,8 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
         }
         tot16[j][e] = tot;
         base16[j][e] = 0;
-        if (tot && lane_e == leader) base16[j][e] = atomicAdd(&fx.count[(uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e)], tot);
+        if (tot && lane_e == leader)
+          base16[j][e] = atomicAdd(&fx.count[(uint32_t)(tn * 256 + wc * 64 + j * 16 + 4 * q_e + e) * fx.shards + shard], tot);
       }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -635,7 +640,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
           const unsigned long long grp = __builtin_amdgcn_ballot_w64(hit) & grp_mask;
           if (hit) {
             const uint32_t pos = at + (uint32_t)__builtin_popcountll(grp & ((1ull << lane_e) - 1ull));
-            if (pos < fx.cap) fx.cand[(size_t)q * fx.cap + pos] = rarc_candkey(sc, fx.row0 + r);
+            if (pos < cap_s) fx.cand[(size_t)q * fx.cap + (size_t)shard * cap_s + pos] = rarc_candkey(sc, fx.row0 + r);
             else atomicOr(&fx.status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
           }
           at += (uint32_t)__builtin_popcountll(grp);
@@ -1459,6 +1464,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
     // counted first, one atomic per column and half-wave, then written (see the 256 x 256 kernel's ACT 6)
     const unsigned long long grp_mask = hh ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;
     const int leader = 32 * hh;
+    const uint32_t shard = blockIdx.x & (fx.shards - 1u), cap_s = fx.cap / fx.shards;
     float t16[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1478,7 +1484,8 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
         }
         tot16[g][e] = tot;
         base16[g][e] = 0;
-        if (tot && lane == leader) base16[g][e] = atomicAdd(&fx.count[(uint32_t)(tn * 128 + wc * 32 + 8 * g + 4 * hh + e)], tot);
+        if (tot && lane == leader)
+          base16[g][e] = atomicAdd(&fx.count[(uint32_t)(tn * 128 + wc * 32 + 8 * g + 4 * hh + e) * fx.shards + shard], tot);
       }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -1495,7 +1502,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm128pp_f16_kernel(const half_t
           const unsigned long long grp = __builtin_amdgcn_ballot_w64(hit) & grp_mask;
           if (hit) {
             const uint32_t pos = at + (uint32_t)__builtin_popcountll(grp & ((1ull << lane) - 1ull));
-            if (pos < fx.cap) fx.cand[(size_t)q * fx.cap + pos] = rarc_candkey(sc, fx.row0 + r);
+            if (pos < cap_s) fx.cand[(size_t)q * fx.cap + (size_t)shard * cap_s + pos] = rarc_candkey(sc, fx.row0 + r);
             else atomicOr(&fx.status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
           }
           at += (uint32_t)__builtin_popcountll(grp);
@@ -2325,14 +2332,17 @@ int rarc_gemm_fused_norm(const uint16_t* d_a, const uint16_t* d_w, const void* d
 // never stored — S[r][q] >= thr[q] sends (score, row0 + r) to query q's candidate list.  M a multiple of 256, K of 64, >= 256.
 bool rarc_gemm_f16_select_takes(int m, int k) { return m > 0 && m % 256 == 0 && k % GK == 0 && k >= 4 * GK; }
 int rarc_gemm_f16_select(const uint16_t* a, const uint16_t* w, int m, int k, const float* thr, unsigned long long* cand,
-                         uint32_t* count, uint32_t* status, uint32_t cap, uint32_t row0, uint32_t n_valid, hipStream_t s) {
-  RARC_REQUIRE(a && w && thr && cand && count && status && rarc_gemm_f16_select_takes(m, k), RARC_E_INVALID,
-               "rarc_gemm_f16_select: bad arguments (m=%d k=%d)", m, k);
+                         uint32_t* count, uint32_t* status, uint32_t cap, uint32_t row0, uint32_t n_valid, uint32_t shards,
+                         hipStream_t s) {
+  RARC_REQUIRE(a && w && thr && cand && count && status && rarc_gemm_f16_select_takes(m, k) && (shards == 1 || shards == 8) &&
+                   cap % shards == 0,
+               RARC_E_INVALID, "rarc_gemm_f16_select: bad arguments (m=%d k=%d shards=%u cap=%u)", m, k, shards, cap);
   if (int rc = gemm_attrs()) return rc;
   static const bool swz = !(getenv("RARC_GEMM_SWZ") && atoi(getenv("RARC_GEMM_SWZ")) == 0);
   const int order = swz ? 2 : 0;
   GemmSplitEpi fx;
   fx.thr = thr; fx.cand = cand; fx.count = count; fx.status = status; fx.cap = cap; fx.row0 = row0; fx.n_valid = n_valid;
+  fx.shards = shards;
   const int tiles = m / 256;
   // up to one 256 x 256 tile per CU: the tiles start in lockstep, every CU fetches, then every CU multiplies — a lone tile took
   // 169 us where a streamed one takes 53.  The 128 x 128 ping-pong kernel (four tiles per CU's worth of work, a four-deep

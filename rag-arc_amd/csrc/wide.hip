@@ -26,7 +26,8 @@
 
 bool rarc_gemm_f16_select_takes(int m, int k);   // encoder.hip: the same GEMM with the select in its epilogue (no score matrix)
 int rarc_gemm_f16_select(const uint16_t* a, const uint16_t* w, int m, int k, const float* thr, unsigned long long* cand,
-                         uint32_t* count, uint32_t* status, uint32_t cap, uint32_t row0, uint32_t n_valid, hipStream_t s);
+                         uint32_t* count, uint32_t* status, uint32_t cap, uint32_t row0, uint32_t n_valid, uint32_t shards,
+                         hipStream_t s);
 extern "C" int rarc_enc_gemm_zero_bias(const uint16_t* d_a, const uint16_t* d_w, const uint16_t* d_zero_bias, uint16_t* d_c, int m,
                                        int n, int k, int act, void* stream);
 
@@ -35,6 +36,12 @@ constexpr int WIDE_NQ = RARC_MAX_QUERIES;     // score columns per row (queries 
 constexpr int WIDE_CHUNK = 131072;            // rows per GEMM that stores its scores (64 MB of fp16)
 constexpr int WIDE_FUSED_CHUNK = 1 << 20;     // rows per GEMM that nominates in its epilogue (no buffer to size it by)
 constexpr int WIDE_KMAX = 8192;               // largest k (the finalize sorts its answer in LDS: 64 KB)
+// A query's candidate list is WIDE_SHARDS sub-lists of cap / WIDE_SHARDS entries with a counter each; a workgroup nominates
+// into sub-list blockIdx.x % WIDE_SHARDS.  With one counter per query the ~400 nominations a growing chunk makes per query came
+// from a thousand workgroups at once and queued on one address: 100 of the 150 us such a chunk took (in the fused GEMM and in
+// the select pass alike).  The tighten reads the sub-lists one after the other and deals its survivors round-robin over them
+// (flat, into sub-list 0's place onward, before the finalize).
+constexpr int WIDE_SHARDS = 8;
 
 struct WideWs {
   uint16_t* scores;     // [WIDE_CHUNK][256] fp16
@@ -42,13 +49,13 @@ struct WideWs {
   uint16_t* tail;       // [128][d_pad] fp16: the last, partial 128-row block of a shard, zero padded
   float* thr;           // [256]
   float* eps;           // [256]
-  uint32_t* count;      // [256]
-  uint32_t* count2;     // [256]
+  uint32_t* count;      // [256][WIDE_SHARDS]
+  uint32_t* count2;     // [256][WIDE_SHARDS]
   uint64_t* cand;       // [256][cap]
   uint64_t* cand2;      // [256][cap]  (compaction target; the two swap roles)
 };
 size_t wide_ws_bytes(int d_pad, int cap) {
-  return (size_t)WIDE_CHUNK * WIDE_NQ * 2 + 4096 + (size_t)128 * d_pad * 2 + 4 * 4096 + 2 * (size_t)WIDE_NQ * cap * 8;
+  return (size_t)WIDE_CHUNK * WIDE_NQ * 2 + 4096 + (size_t)128 * d_pad * 2 + 8 * 4096 + 2 * (size_t)WIDE_NQ * cap * 8;
 }
 WideWs wide_carve(void* base, int d_pad, int cap) {
   char* b = (char*)base;
@@ -58,9 +65,9 @@ WideWs wide_carve(void* base, int d_pad, int cap) {
   w.tail = (uint16_t*)b; b += (size_t)128 * d_pad * 2;
   w.thr = (float*)b; b += 1024;
   w.eps = (float*)b; b += 1024;
-  w.count = (uint32_t*)b; b += 1024;
-  w.count2 = (uint32_t*)b; b += 1024;
-  b += 4 * 4096 - 4096;
+  w.count = (uint32_t*)b; b += 8192;
+  w.count2 = (uint32_t*)b; b += 8192;
+  b += 8 * 4096 - (2 * 1024 + 2 * 8192);
   w.cand = (uint64_t*)b; b += (size_t)WIDE_NQ * cap * 8;
   w.cand2 = (uint64_t*)b;
   return w;
@@ -98,8 +105,10 @@ __global__ __launch_bounds__(256) void wide_eps_kernel(const float* q32, const u
                      6.0e-08 + 1e-30;
     eps[q] = (float)e * 1.0001f;
     thr[q] = q < nq ? -INFINITY : INFINITY;     // padding queries never nominate anything
-    count[q] = 0;
-    count2[q] = 0;
+    for (int sh = 0; sh < WIDE_SHARDS; ++sh) {
+      count[q * WIDE_SHARDS + sh] = 0;
+      count2[q * WIDE_SHARDS + sh] = 0;
+    }
     status[q] = 0;
     zero_bias[q] = 0;
   }
@@ -116,15 +125,22 @@ __global__ __launch_bounds__(256) void wide_select_kernel(const uint16_t* __rest
   if (first) {
     // the shard's first chunk: no threshold yet, every row is a candidate of every live query — its place in the list is
     // its row number (n_valid <= cap), no counter to fight over
+    // sub-list s takes the rows [s R, (s + 1) R), R = ceil(n_valid / 8) <= cap / 8: each one written front to back
+    const uint32_t cap_f = cap / WIDE_SHARDS, per = (n_valid + WIDE_SHARDS - 1u) / WIDE_SHARDS;
     for (uint32_t r = blockIdx.x * 8 + (tid >> 5); r < n_valid; r += gridDim.x * 8) {
       const half8 s8 = *(const half8*)(scores + (size_t)r * WIDE_NQ + 8 * qg);
+      const uint32_t sh = r / per;
+      const size_t at = (size_t)sh * cap_f + (r - sh * per);
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if ((uint32_t)(8 * qg + j) < nq) cand[(size_t)(8 * qg + j) * cap + r] = rarc_candkey((float)s8[j], row0 + r);
+        if ((uint32_t)(8 * qg + j) < nq) cand[(size_t)(8 * qg + j) * cap + at] = rarc_candkey((float)s8[j], row0 + r);
     }
-    if (blockIdx.x == 0 && (uint32_t)tid < nq) count[tid] = n_valid;
+    if (blockIdx.x == 0 && (uint32_t)tid < nq)
+      for (uint32_t sh = 0; sh < WIDE_SHARDS; ++sh)
+        count[tid * WIDE_SHARDS + sh] = sh * per >= n_valid ? 0u : (n_valid - sh * per < per ? n_valid - sh * per : per);
     return;
   }
+  const uint32_t shard = blockIdx.x % WIDE_SHARDS, cap_s = cap / WIDE_SHARDS;
   half_t t[8];                                   // the thresholds rounded DOWN to fp16: a pre-screen on the raw halves (never rejects what the fp32 threshold takes)
   half_t tmin = (half_t)65504.f;
 #pragma unroll
@@ -145,8 +161,8 @@ __global__ __launch_bounds__(256) void wide_select_kernel(const uint16_t* __rest
         const float s = (float)s8[j];
         const uint32_t q = 8 * qg + j;
         if (s >= thr[q]) {                       // the exact (fp32) threshold decides: the fp16 one only pre-screens
-          const uint32_t pos = atomicAdd(&count[q], 1u);
-          if (pos < cap) cand[(size_t)q * cap + pos] = rarc_candkey(s, row0 + r);
+          const uint32_t pos = atomicAdd(&count[q * WIDE_SHARDS + shard], 1u);
+          if (pos < cap_s) cand[(size_t)q * cap + (size_t)shard * cap_s + pos] = rarc_candkey(s, row0 + r);
           else atomicOr(&status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
         }
       }
@@ -206,20 +222,68 @@ __device__ uint32_t wide_kth_largest_u32(At at, uint32_t n, uint32_t k, uint32_t
   return prefix;
 }
 
-// thr[q] = max(thr[q], (k-th best approximate score so far) - 2 eps[q]); the list is copied without what fell under it.
+// The same over entries a caller ENUMERATES (each(f): f(value) for every entry of this thread's share): the tighten's sub-lists.
+template <typename Each>
+__device__ uint32_t wide_kth_largest_each(Each each, uint32_t k, uint32_t* s_hist, uint32_t* s_pick) {
+  uint32_t prefix = 0, mask = 0, need = k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    each([&](uint32_t v) {
+      if ((v & mask) == prefix) atomicAdd(&s_hist[(v >> shift) & 255u], 1u);
+    });
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      uint32_t above = 0;
+      int b = rarc_wave_find_from_top(s_hist, 256, need, &above);
+      if (b < 0) { b = 0; above = 0; }
+      if (threadIdx.x == 0) {
+        s_pick[0] = (uint32_t)b;
+        s_pick[1] = need - above;
+      }
+    }
+    __syncthreads();
+    prefix |= s_pick[0] << shift;
+    mask |= 255u << shift;
+    need = s_pick[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// thr[q] = max(thr[q], (k-th best approximate score so far) - 2 eps[q]); the list is copied without what fell under it: the
+// sub-lists are read one after the other (entry L of the query = entry L - first[s] of sub-list s), the survivors dealt
+// round-robin over the target's sub-lists — or laid out flat from its start (flat_out: the last pass, before the finalize).
 __global__ __launch_bounds__(1024) void wide_tighten_kernel(const uint64_t* __restrict__ cand, uint64_t* __restrict__ cand2,
                                                             uint32_t* count, uint32_t* count2, uint32_t cap, uint32_t k,
-                                                            const float* __restrict__ eps, float* thr) {
+                                                            const float* __restrict__ eps, float* thr, int flat_out) {
   __shared__ uint32_t s_hist[256];
   __shared__ uint32_t s_pick[2];
   __shared__ uint32_t s_n;
   const uint32_t q = blockIdx.x;
-  const uint32_t c_all = count[q], c = c_all < cap ? c_all : cap;
+  const uint32_t cap_s = cap / WIDE_SHARDS;
+  uint32_t first[WIDE_SHARDS + 1];
+  first[0] = 0;
+#pragma unroll
+  for (int sh = 0; sh < WIDE_SHARDS; ++sh) {
+    const uint32_t c_sh = count[q * WIDE_SHARDS + sh];
+    first[sh + 1] = first[sh] + (c_sh < cap_s ? c_sh : cap_s);
+  }
+  const uint32_t c = first[WIDE_SHARDS];
   const uint64_t* src = cand + (size_t)q * cap;
   uint64_t* dst = cand2 + (size_t)q * cap;
+  // every entry of the query once: 128 threads per sub-list (blockDim = 1024 = 8 x 128), each walking its own front to back
+  static_assert(WIDE_SHARDS == 8, "wide_tighten_kernel: 1024 threads = 8 sub-lists x 128");
+  const uint32_t my_sh = threadIdx.x >> 7, my_lane = threadIdx.x & 127u;
+  const uint64_t* my_src = src + (size_t)my_sh * cap_s;
+  const uint32_t my_n = count[q * WIDE_SHARDS + my_sh] < cap_s ? count[q * WIDE_SHARDS + my_sh] : cap_s;
+  auto each_key = [&](auto&& f) {
+    for (uint32_t i = my_lane; i < my_n; i += 128u) f(my_src[i]);
+  };
   float t = thr[q];
   if (c >= k) {
-    const uint32_t kth = wide_kth_largest_u32([&](uint32_t i) { return (uint32_t)(src[i] >> 32); }, c, k, s_hist, s_pick);
+    const uint32_t kth = wide_kth_largest_each([&](auto&& g) { each_key([&](uint64_t key) { g((uint32_t)(key >> 32)); }); }, k, s_hist,
+                                               s_pick);
     const float a_k = rarc_unordkey(kth);
     float nt = a_k - 2.0f * eps[q] * 1.000001f;
     nt = nt - fabsf(nt) * 1.2e-7f - 1e-37f;        // (rounded down: the bound must not be overstated by the subtraction)
@@ -227,15 +291,18 @@ __global__ __launch_bounds__(1024) void wide_tighten_kernel(const uint64_t* __re
   }
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
-    const uint64_t key = src[i];
-    if (rarc_candscore(key) >= t) dst[atomicAdd(&s_n, 1u)] = key;
-  }
+  each_key([&](uint64_t key) {
+    if (rarc_candscore(key) >= t) {
+      const uint32_t p = atomicAdd(&s_n, 1u);
+      dst[flat_out ? (size_t)p : (size_t)(p % WIDE_SHARDS) * cap_s + p / WIDE_SHARDS] = key;
+    }
+  });
   __syncthreads();
-  if (threadIdx.x == 0) {
-    thr[q] = t;
-    count2[q] = s_n;
-    count[q] = 0;            // this buffer is the next compaction's target
+  if (threadIdx.x < WIDE_SHARDS) {
+    const uint32_t sh = threadIdx.x, n_out = s_n;
+    if (sh == 0) thr[q] = t;
+    count2[q * WIDE_SHARDS + sh] = flat_out ? (sh == 0 ? n_out : 0u) : (n_out + WIDE_SHARDS - 1u - sh) / WIDE_SHARDS;
+    count[q * WIDE_SHARDS + sh] = 0;            // this buffer is the next compaction's target
   }
 }
 
@@ -290,7 +357,7 @@ __global__ __launch_bounds__(1024) void wide_finalize_kernel(const void* __restr
   __shared__ uint32_t s_n;
   const uint32_t q = blockIdx.x;
   if (q >= nq) return;
-  const uint32_t c_all = count[q], c = c_all < cap ? c_all : cap;
+  const uint32_t c_all = count[q * WIDE_SHARDS], c = c_all < cap ? c_all : cap;     // (laid out flat by the last tighten pass)
   if (c_all > cap && threadIdx.x == 0) atomicOr(&status[q], RARC_Q_OVERFLOW | RARC_Q_WHY_SEGMENT);
   uint64_t* keys = cand + (size_t)q * cap;
   __shared__ float s_q[4096];                               // the query (d_pad <= 4096)
@@ -388,6 +455,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
   first = (first + 255) / 256 * 256;
   RARC_REQUIRE(cand_cap >= first + 256, RARC_E_WORKSPACE, "rarc_search_wide: cand_cap %d < %d (the first chunk of rows)", cand_cap,
                first + 256);
+  RARC_REQUIRE(cand_cap % WIDE_SHARDS == 0, RARC_E_INVALID, "rarc_search_wide: cand_cap %d must be a multiple of %d", cand_cap, WIDE_SHARDS);
   char* wsb = (char*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
   RARC_REQUIRE(wsb + wide_ws_bytes(d_pad, cand_cap) <= (char*)d_ws + ws_bytes, RARC_E_WORKSPACE,
                "rarc_search_wide: workspace of %zu bytes, %zu needed", ws_bytes, wide_ws_bytes(d_pad, cand_cap) + 256);
@@ -418,7 +486,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
     if (fuse && at > 0 && m >= 256 && rarc_gemm_f16_select_takes((int)(m / 256 * 256), d_pad)) {
       const int64_t mf = m / 256 * 256;
       if ((rc = rarc_gemm_f16_select(a16 + (size_t)at * d_pad, qb.q16, (int)mf, d_pad, w.thr, (unsigned long long*)cur, ccur, d_status,
-                                     (uint32_t)cand_cap, (uint32_t)at, (uint32_t)mf, s)) != RARC_OK)
+                                     (uint32_t)cand_cap, (uint32_t)at, (uint32_t)mf, (uint32_t)WIDE_SHARDS, s)) != RARC_OK)
         return rc;
       at += mf;
       m -= mf;
@@ -426,7 +494,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
         ++n_chunk;
         if (chunk < fused_max || chunk >= 4 * WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {   // (every chunk while they still grow: a stale threshold lets chunk/seen x k rows through)
           hipLaunchKernelGGL(wide_tighten_kernel, dim3(WIDE_NQ), dim3(1024), 0, s, cur, other, ccur, cother, (uint32_t)cand_cap,
-                             (uint32_t)k, w.eps, w.thr);
+                             (uint32_t)k, w.eps, w.thr, at >= n_rows ? 1 : 0);
           RARC_HIP_CHECK(hipGetLastError());
           { uint64_t* t = cur; cur = other; other = t; }
           { uint32_t* t = ccur; ccur = cother; cother = t; }
@@ -471,7 +539,7 @@ extern "C" int rarc_search_wide(const void* d_rows, const uint16_t* d_image16, i
     ++n_chunk;
     if (chunk < WIDE_CHUNK || n_chunk % 4 == 0 || at >= n_rows) {
       hipLaunchKernelGGL(wide_tighten_kernel, dim3(WIDE_NQ), dim3(1024), 0, s, cur, other, ccur, cother, (uint32_t)cand_cap,
-                         (uint32_t)k, w.eps, w.thr);
+                         (uint32_t)k, w.eps, w.thr, at >= n_rows ? 1 : 0);
       RARC_HIP_CHECK(hipGetLastError());
       { uint64_t* t = cur; cur = other; other = t; }
       { uint32_t* t = ccur; ccur = cother; cother = t; }

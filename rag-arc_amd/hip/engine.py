@@ -782,7 +782,7 @@ class FlatIndexF16:
         B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], nq, self.dim, self.d_pad, norm, mn, 0,
                                            self._qbuf["qblock"].data_ptr(), stream), "rarc_prep_queries")
         first = ((max(16384, 2 * k) + 255) // 256) * 256 + 256   # the library's first chunk of rows (csrc/wide.hip) at its largest
-        cap = max(4 * k, first)
+        cap = (max(4 * k, first) + 7) // 8 * 8           # (a query's list is eight sub-lists)
         sure = ((self.ntotal + 255) // 256) * 256 + first    # every stored row + the first chunk: cannot overflow
         status = t.zeros(B.MAX_QUERIES, dtype=t.int32, device=self.device)
         image = self._image16.data_ptr() if self.storage == "f32" else 0
