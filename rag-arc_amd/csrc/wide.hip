@@ -262,28 +262,39 @@ __global__ __launch_bounds__(1024) void wide_tighten_kernel(const uint64_t* __re
   __shared__ uint32_t s_n;
   const uint32_t q = blockIdx.x;
   const uint32_t cap_s = cap / WIDE_SHARDS;
-  uint32_t first[WIDE_SHARDS + 1];
-  first[0] = 0;
-#pragma unroll
-  for (int sh = 0; sh < WIDE_SHARDS; ++sh) {
-    const uint32_t c_sh = count[q * WIDE_SHARDS + sh];
-    first[sh + 1] = first[sh] + (c_sh < cap_s ? c_sh : cap_s);
-  }
-  const uint32_t c = first[WIDE_SHARDS];
-  const uint64_t* src = cand + (size_t)q * cap;
-  uint64_t* dst = cand2 + (size_t)q * cap;
-  // every entry of the query once: 128 threads per sub-list (blockDim = 1024 = 8 x 128), each walking its own front to back
+  // 128 threads per sub-list (blockDim = 1024 = 8 x 128): my_first = where this thread's sub-list starts in the query's entries
   static_assert(WIDE_SHARDS == 8, "wide_tighten_kernel: 1024 threads = 8 sub-lists x 128");
   const uint32_t my_sh = threadIdx.x >> 7, my_lane = threadIdx.x & 127u;
+  uint32_t c = 0, my_first = 0, my_n = 0;
+#pragma unroll
+  for (int sh = 0; sh < WIDE_SHARDS; ++sh) {
+    const uint32_t c_raw = count[q * WIDE_SHARDS + sh], c_sh = c_raw < cap_s ? c_raw : cap_s;
+    if ((uint32_t)sh < my_sh) my_first += c_sh;
+    if ((uint32_t)sh == my_sh) my_n = c_sh;
+    c += c_sh;
+  }
+  const uint64_t* src = cand + (size_t)q * cap;
+  uint64_t* dst = cand2 + (size_t)q * cap;
+  // every entry of the query once: each thread walks its own sub-list front to back
   const uint64_t* my_src = src + (size_t)my_sh * cap_s;
-  const uint32_t my_n = count[q * WIDE_SHARDS + my_sh] < cap_s ? count[q * WIDE_SHARDS + my_sh] : cap_s;
   auto each_key = [&](auto&& f) {
     for (uint32_t i = my_lane; i < my_n; i += 128u) f(my_src[i]);
   };
   float t = thr[q];
+  // the list after a search's FIRST chunk is that whole chunk (16,640 entries x 256 queries = 34 MB): four select rounds and
+  // the compaction read it five times — 30 of that pass's 37 us.  Up to TIGHTEN_LDS_KEYS entries the score words are read
+  // once into LDS and the rounds run there.
+  constexpr uint32_t TIGHTEN_LDS_KEYS = 20480;
+  __shared__ uint32_t s_keys[TIGHTEN_LDS_KEYS];
   if (c >= k) {
-    const uint32_t kth = wide_kth_largest_each([&](auto&& g) { each_key([&](uint64_t key) { g((uint32_t)(key >> 32)); }); }, k, s_hist,
-                                               s_pick);
+    uint32_t kth;
+    if (c <= TIGHTEN_LDS_KEYS) {
+      for (uint32_t i = my_lane; i < my_n; i += 128u) s_keys[my_first + i] = (uint32_t)(my_src[i] >> 32);
+      __syncthreads();
+      kth = wide_kth_largest_u32([&](uint32_t i) { return s_keys[i]; }, c, k, s_hist, s_pick);
+    } else {
+      kth = wide_kth_largest_each([&](auto&& g) { each_key([&](uint64_t key) { g((uint32_t)(key >> 32)); }); }, k, s_hist, s_pick);
+    }
     const float a_k = rarc_unordkey(kth);
     float nt = a_k - 2.0f * eps[q] * 1.000001f;
     nt = nt - fabsf(nt) * 1.2e-7f - 1e-37f;        // (rounded down: the bound must not be overstated by the subtraction)
