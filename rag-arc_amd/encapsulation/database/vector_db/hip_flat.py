@@ -72,9 +72,9 @@ class _QueryCoalescer:
     nobody else is waiting); callers that arrive WHILE a scan is running queue up, and whoever is woken first takes the
     whole queue — up to 256 queries — through ONE scan.  256 threads calling together cost two or three scans instead
     of 256.  `window_s` > 0 additionally lets an idle-index leader wait that long for company; with window_s = 0 the leader
-    still waits — 2 % of the last scan's duration, at most half a millisecond — when the launch before this one served more
-    than one caller (a burst is likely under way: at 100M rows 256 threads then share ONE scan instead of 1 + 255; a lone
-    sequential caller never waits).
+    still waits when the launch before this one served more than one caller (a burst is likely under way) — for as long as
+    callers keep arriving, at most 3/4 of the last launch's duration: at 100M rows 256 threads then share ONE scan instead
+    of 6 + 250.  A lone sequential caller never waits.
 
     An exact top-k under a total order (score desc, id asc) is a prefix of the top-k' for k' > k, so one launch with the
     largest k of the batch serves every caller."""
@@ -89,7 +89,8 @@ class _QueryCoalescer:
         self.last_batch = 1      # callers served by the previous launch, and how long it took
         self.last_scan_s = 0.0
 
-    ADAPTIVE_MAX_S = 500e-6
+    QUIET_S = 200e-6         # a leader that expects company stops waiting after this long without a new caller
+    BURST_SHARE = 0.75       # ... and in any case after this share of the last launch's duration
 
     class _Item:
         __slots__ = ("payload", "k", "result", "error", "done")
@@ -110,11 +111,21 @@ class _QueryCoalescer:
                 if item.done:
                     break
                 self.busy = True                       # this caller leads the next launch
-                window = self.window_s
-                if window <= 0 and self.last_batch > 1:
-                    window = min(self.ADAPTIVE_MAX_S, 0.02 * self.last_scan_s)
-                if window > 0 and len(self.queue) < self.max_batch:
-                    self.cv.wait(timeout=window)
+                if self.window_s > 0:
+                    if len(self.queue) < self.max_batch:
+                        self.cv.wait(timeout=self.window_s)
+                elif self.last_batch > 1:
+                    # a burst is likely under way (the launch before this one served several callers): collect it — wait
+                    # while callers keep arriving (a quiet interval of QUIET_S ends the wait), for at most three quarters
+                    # of what the last launch took: 256 python threads need ~20 ms to get through their own prologues,
+                    # a 100M-row scan is 27 ms — one scan of 256 beats a scan of six followed by a scan of 250
+                    t_end = time.perf_counter() + self.BURST_SHARE * self.last_scan_s
+                    quiet = min(self.QUIET_S, self.BURST_SHARE * self.last_scan_s)
+                    while len(self.queue) < self.max_batch and time.perf_counter() < t_end:
+                        n0 = len(self.queue)
+                        self.cv.wait(timeout=quiet)
+                        if len(self.queue) == n0:
+                            break
                 batch = self.queue[: self.max_batch]   # FIFO (the leader's own item is among them unless > max_batch queued)
                 del self.queue[: self.max_batch]
             t_launch = time.perf_counter()
