@@ -6,10 +6,16 @@
 // CU's register file is 512 KB — so beyond that the score matrix goes through the GEMM the encoder already has
 // (encoder.hip: 256 x 256 x 64 ping-pong MFMA tiles, fp16 in, fp32 accumulate), one chunk of rows at a time:
 //
-//   per chunk of <= 131072 rows:  S16[rows][256] = rows16 · Q16^T        rarc_enc_gemm_zero_bias   (MFMA; 64 MB of fp16 scores)
-//                                 candidates += {(row, s) : s >= thr[q]}  wide_select_kernel        (reads S16 once)
-//                                 thr[q] = (k-th best s so far) - 2 eps   wide_tighten_kernel       (radix select; drops what fell under)
+//   first chunk (16384 rows + the shard's ragged end; no threshold yet):
+//                                 S16[rows][256] = rows16 · Q16^T         rarc_enc_gemm_zero_bias   (MFMA; fp16 scores)
+//                                 every row a candidate of every query    wide_select_kernel        (written by row number)
+//   every later chunk (x4, up to 1,048,576 rows):
+//                                 candidates += {(row, s) : s >= thr[q]}  rarc_gemm_f16_select      (the same GEMM, fp32 scores compared in its
+//                                                                                                    epilogue, nothing stored: encoder.hip ACT 6)
+//   after a chunk:                thr[q] = (k-th best s so far) - 2 eps   wide_tighten_kernel       (radix select; drops what fell under)
 //   at the end, per query:        canonical fp32 score of every candidate, exact order, top-k      wide_finalize_kernel
+//   (a chunk the fused GEMM does not take — RARC_WIDE_FUSE=0, odd shapes — goes through the first chunk's kernel pair with
+//    the select pass comparing against thr)
 //
 // Exactness.  eps[q] bounds |s - canonical| for every row (fp16 rounding of the query and of the stored score, fp32
 // accumulation: wide_eps_kernel).  If a_k is the k-th best approximate score seen so far, k rows have canonical scores
@@ -20,8 +26,9 @@
 // max(16384, 2k) rows, so the list of a query holds its k best plus a margin of rows, not a share of the corpus.  A candidate list
 // that fills up sets the query's status word (the caller re-runs with a larger capacity; capacity >= n cannot overflow).
 //
-// HBM traffic per row: 2·d_pad bytes of row + 512 B of scores written + 512 B read back (+33 % at d = 1536, +17 % at 3072).
-// Bound: the MFMA pipe (2·256·n·d_pad flops on the encoder's GEMM).
+// HBM traffic per row: the 2·d_pad bytes of the row, once (PMC: 31.7 GB fetched per search of 30.7 GB of rows).
+// Bound: the MFMA pipe (2·256·n·d_pad flops on the encoder's GEMM, which runs at the board's power limit: 10M x 1536 rows in
+// 8.3 ms where the GEMM alone takes 8.28).
 #include "rarc_common.h"
 
 bool rarc_gemm_f16_select_takes(int m, int k);   // encoder.hip: the same GEMM with the select in its epilogue (no score matrix)
