@@ -99,13 +99,20 @@ __global__ void pairs_reset_kernel(float* thr, uint32_t* count, uint32_t* status
 }
 
 // one workgroup per column j = col0 + q: every nominated row i < j is scored exactly (a wave per pair) and kept if it reaches
-// the threshold.  out_count counts every kept pair, also those beyond out_cap (the caller then knows how many there are).
+// the threshold.  The kept pairs of up to 1024 candidates are collected in LDS and take their places in the output with ONE
+// atomic (a counter update per pair queues on its single address at ~350 ns each: half a million duplicate pairs would
+// cost 0.16 s next to a 10 ms GEMM).  out_count counts every kept pair, also those beyond out_cap.
 __global__ __launch_bounds__(256) void pairs_finalize_kernel(const float* __restrict__ rows, int64_t ld, int d,
                                                              const double* __restrict__ inv_norm, const unsigned long long* cand,
                                                              const uint32_t* count, uint32_t cap, int64_t col0, int64_t n,
                                                              double threshold, int64_t* out_pairs, double* out_scores,
                                                              unsigned long long out_cap, unsigned long long* out_count,
                                                              uint32_t* flags) {
+  constexpr uint32_t BLOCK = 1024;
+  __shared__ double s_cos[BLOCK];
+  __shared__ uint32_t s_row[BLOCK];
+  __shared__ uint32_t s_keep;
+  __shared__ unsigned long long s_base;
   const int q = blockIdx.x;
   const int64_t j = col0 + q;
   if (j >= n) return;
@@ -114,24 +121,39 @@ __global__ __launch_bounds__(256) void pairs_finalize_kernel(const float* __rest
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* y = rows + (size_t)j * ld;
   const double inv_j = inv_norm[j];
-  for (uint32_t e = wave; e < c; e += 4) {
-    const int64_t i = (int64_t)rarc_candrow(cand[(size_t)q * cap + e]);
-    if (i >= j) continue;                                            // (wave-uniform: the whole wave reads the same entry)
-    const float* x = rows + (size_t)i * ld;
-    double acc = 0.0;
-    for (int m = lane; m < d; m += 64) acc += (double)x[m] * (double)y[m];
-    acc = pairs_wave_sum(acc);
-    const double cosv = acc * inv_norm[i] * inv_j;
-    if (lane == 0 && cosv >= threshold) {
-      const unsigned long long pos = atomicAdd(out_count, 1ull);
+  for (uint32_t e0 = 0; e0 < c; e0 += BLOCK) {
+    if (threadIdx.x == 0) s_keep = 0;
+    __syncthreads();
+    const uint32_t e1 = e0 + BLOCK < c ? e0 + BLOCK : c;
+    for (uint32_t e = e0 + wave; e < e1; e += 4) {
+      const int64_t i = (int64_t)rarc_candrow(cand[(size_t)q * cap + e]);
+      if (i >= j) continue;                                          // (wave-uniform: the whole wave reads the same entry)
+      const float* x = rows + (size_t)i * ld;
+      double acc = 0.0;
+      for (int m = lane; m < d; m += 64) acc += (double)x[m] * (double)y[m];
+      acc = pairs_wave_sum(acc);
+      const double cosv = acc * inv_norm[i] * inv_j;
+      if (lane == 0 && cosv >= threshold) {
+        const uint32_t slot = atomicAdd(&s_keep, 1u);
+        s_row[slot] = (uint32_t)i;
+        s_cos[slot] = cosv;
+      }
+    }
+    __syncthreads();
+    const uint32_t kept = s_keep;
+    if (threadIdx.x == 0 && kept) s_base = atomicAdd(out_count, (unsigned long long)kept);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < kept; t += blockDim.x) {
+      const unsigned long long pos = s_base + t;
       if (pos < out_cap) {
-        out_pairs[2 * pos] = i;
+        out_pairs[2 * pos] = (int64_t)s_row[t];
         out_pairs[2 * pos + 1] = j;
-        out_scores[pos] = cosv;
+        out_scores[pos] = s_cos[t];
       } else {
         atomicOr(flags, 2u);                                         // more pairs than the output holds
       }
     }
+    __syncthreads();
   }
 }
 

@@ -114,3 +114,16 @@ def test_random_shapes(oracle, seed):
     got = similar_pairs(x, thr)
     want = oracle.similar_pairs_f64(x.astype(np.float64), thr)
     _same(got, want, thr, (seed, n, d, thr))
+
+
+def test_arrays_form(oracle):
+    from rag_arc_amd.encapsulation.database.graph_db import similar_pairs
+
+    rng = np.random.default_rng(3)
+    x = _planted(rng, 2000, 96, 200, 0.05)
+    as_list = similar_pairs(x, 0.95)
+    pairs, cos = similar_pairs(x, 0.95, as_arrays=True)
+    assert pairs.dtype == np.int64 and cos.dtype == np.float64 and pairs.shape == (len(as_list), 2)
+    assert as_list == list(zip(pairs[:, 0].tolist(), pairs[:, 1].tolist(), cos.tolist()))
+    p0, c0 = similar_pairs(x[:1], 0.95, as_arrays=True)
+    assert p0.shape == (0, 2) and c0.shape == (0,)

@@ -30,3 +30,11 @@ import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(10): similar_pairs(x, 0.95)
 pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(8)
+# many pairs: 100k entities in 10k groups of 10 near-identical ones -> 450k pairs
+g = torch.Generator(device=dev); g.manual_seed(7)
+base = torch.randn((n // 10, d), generator=g, device=dev)
+xd = base.repeat_interleave(10, dim=0) + 0.01 * torch.randn((n // 10 * 10, d), generator=g, device=dev)
+for _ in range(2): pd = similar_pairs(xd, 0.95)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): pd = similar_pairs(xd, 0.95, as_arrays=True)[0]
+torch.cuda.synchronize(); print(f"groups of 10: {len(pd)} pairs, {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms per call (as arrays)")
