@@ -158,6 +158,27 @@ struct E32Fuse {
   const float* colmax = nullptr; int k = 0; float* sg_out = nullptr; size_t sg_rows = 0;
 };
 
+// slab 0 + slab 1 + ... of a split-K product, IN ORDER (the sum is what an unsplit k loop would have rounded differently, but it
+// is the same for every consumer); the loads of three slabs go out together — a runtime loop of load-then-add is a chain of
+// round trips to L2, and a single query's FFN2 product comes in sixteen slabs.
+__device__ __forceinline__ float4 e32_sum_parts(const float* __restrict__ src, int n_parts, size_t part_stride) {
+  float4 p = *(const float4*)src;
+  int sp = 1;
+  for (; sp + 2 < n_parts; sp += 3) {
+    const float4 a = *(const float4*)(src + (size_t)sp * part_stride);
+    const float4 b = *(const float4*)(src + (size_t)(sp + 1) * part_stride);
+    const float4 c = *(const float4*)(src + (size_t)(sp + 2) * part_stride);
+    p.x += a.x; p.y += a.y; p.z += a.z; p.w += a.w;
+    p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w;
+    p.x += c.x; p.y += c.y; p.z += c.z; p.w += c.w;
+  }
+  for (; sp < n_parts; ++sp) {
+    const float4 a = *(const float4*)(src + (size_t)sp * part_stride);
+    p.x += a.x; p.y += a.y; p.z += a.z; p.w += a.w;
+  }
+  return p;
+}
+
 template <int NV, int MODE>
 __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const float* __restrict__ ra,
                                                            const float* __restrict__ rw, const float* __restrict__ bias,
@@ -174,11 +195,7 @@ __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const
   for (int i = 0; i < NV; ++i) {
     const int c = (threadIdx.x + 256 * i) * 4;
     if (c < n) {
-      float4 p = *(const float4*)(P + m * n + c);
-      for (int sp = 1; sp < n_parts; ++sp) {   // split-K partial slabs of a small batch's GEMM, summed in order
-        const float4 q = *(const float4*)(P + sp * part_stride + m * n + c);
-        p.x += q.x; p.y += q.y; p.z += q.z; p.w += q.w;
-      }
+      float4 p = e32_sum_parts(P + m * n + c, n_parts, part_stride);   // split-K partial slabs of a small batch's GEMM, summed in order
       if (MODE != 3) {
         const float4 w = *(const float4*)(rw + c), b = *(const float4*)(bias + c);
         // ra, rw are powers of two: the two scalings are exact, the bias add rounds once (as in x·Wᵀ + b)
@@ -325,11 +342,7 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
     const float* w = sb + part * 2 * DH + hh * HD;
 #pragma unroll
     for (int c = 0; c < HD; c += 4) {
-      float4 p = *(const float4*)(src + c);
-      for (int sp = 1; sp < n_parts; ++sp) {   // split-K partial slabs of a small batch's q|k|v product, summed in order
-        const float4 q4 = *(const float4*)(src + sp * part_stride + c);
-        p.x += q4.x; p.y += q4.y; p.z += q4.z; p.w += q4.w;
-      }
+      const float4 p = e32_sum_parts(src + c, n_parts, part_stride);   // split-K partial slabs of a small batch's q|k|v product
       const float4 s4 = *(const float4*)(w + c), b4 = *(const float4*)(w + DH + c);
       dst[c] = p.x * r * s4.x + b4.x; dst[c + 1] = p.y * r * s4.y + b4.y;
       dst[c + 2] = p.z * r * s4.z + b4.z; dst[c + 3] = p.w * r * s4.w + b4.w;
@@ -358,11 +371,7 @@ __global__ __launch_bounds__(256) void rarc_e32_attention_kernel(const float* __
       const int kr = i / (DH / 4), c4 = i % (DH / 4);
       const int vrow = (k0 + kr < L) ? k0 + kr : L - 1;
       const float r = ra[tok0 + vrow];
-      float4 p = *(const float4*)(P + (tok0 + vrow) * rs + 2 * H + hd * DH + 4 * c4);
-      for (int sp = 1; sp < n_parts; ++sp) {
-        const float4 q4 = *(const float4*)(P + sp * part_stride + (tok0 + vrow) * rs + 2 * H + hd * DH + 4 * c4);
-        p.x += q4.x; p.y += q4.y; p.z += q4.z; p.w += q4.w;
-      }
+      const float4 p = e32_sum_parts(P + (tok0 + vrow) * rs + 2 * H + hd * DH + 4 * c4, n_parts, part_stride);
       const float4 s4 = *(const float4*)(sb + 4 * DH + 4 * c4), b4 = *(const float4*)(sb + 5 * DH + 4 * c4);
       *(float4*)(vs + kr * VS + 4 * c4) =
           make_float4(p.x * r * s4.x + b4.x, p.y * r * s4.y + b4.y, p.z * r * s4.z + b4.z, p.w * r * s4.w + b4.w);
@@ -494,12 +503,7 @@ __global__ __launch_bounds__(256, 2) void rarc_e32_attention_split_kernel(const 
   __syncthreads();
 
   auto load4 = [&](const float* src) {   // one 16-byte piece, split-K partial slabs summed in order
-    float4 p = *(const float4*)src;
-    for (int sp = 1; sp < n_parts; ++sp) {
-      const float4 q4 = *(const float4*)(src + sp * part_stride);
-      p.x += q4.x; p.y += q4.y; p.z += q4.z; p.w += q4.w;
-    }
-    return p;
+    return e32_sum_parts(src, n_parts, part_stride);
   };
   auto affine4 = [&](const float4 p, float r, const float* w) {   // value = P·ra·rw + bias
     const float4 s4 = *(const float4*)w, b4 = *(const float4*)(w + DH);
