@@ -50,3 +50,16 @@ def test_oracle_equals_committed_vectors(oracle):
         got = oracle.similar_pairs_f64(emb, case["threshold"])
         assert [[i, j] for i, j, _ in got] == case["pairs"], case["name"]
         assert np.allclose([s for *_, s in got], [float.fromhex(v) for v in case["scores_hex"]], rtol=0, atol=1e-14), case["name"]
+
+
+def test_no_cpu_fallback():
+    """Without a ROCm device the product call fails loudly (the oracle above is test infrastructure, never a fallback)."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: tests/test_gpu_similar_pairs.py covers the call")
+    from rag_arc_amd.encapsulation.database.graph_db import similar_pairs
+    from rag_arc_amd.hip.binding import RarcError
+
+    with pytest.raises(RarcError):
+        similar_pairs([[1.0, 2.0], [2.0, 1.0]], 0.95)
