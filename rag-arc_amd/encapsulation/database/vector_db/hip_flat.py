@@ -246,6 +246,8 @@ class _AsyncFront:
     work and gone after a second without any, answers up to `max_batch` of them per scan."""
 
     IDLE_S = 1.0
+    QUIET_S = 200e-6         # the worker stops collecting a burst after this long without a new caller
+    BURST_MIN_S = 2e-3       # ... and after max(this, 3/4 of the last launch's duration) in any case
 
     def __init__(self, run_batch: Callable, max_batch: int = 256):
         self.run_batch, self.max_batch = run_batch, int(max_batch)
@@ -254,6 +256,8 @@ class _AsyncFront:
         self.worker: Optional[threading.Thread] = None
         self.launches = 0
         self.served = 0
+        self.last_batch = 1      # callers served by the previous launch, and how long it took
+        self.last_scan_s = 0.0
 
     async def submit(self, payload, k: int):
         import asyncio
@@ -290,8 +294,19 @@ class _AsyncFront:
                 if not self.queue:
                     self.worker = None
                     return
+                if len(self.queue) < self.max_batch and (len(self.queue) > 1 or self.last_batch > 1):
+                    # a burst is arriving (the event loop is still running its callers up to their awaits; the interpreter may
+                    # hand this thread the GIL in the middle of that): collect it — wait while callers keep coming, a quiet
+                    # QUIET_S ends the wait.  A lone awaiting caller after a lone one is launched at once.
+                    t_end = time.perf_counter() + max(self.BURST_MIN_S, 0.75 * self.last_scan_s)
+                    while len(self.queue) < self.max_batch and time.perf_counter() < t_end:
+                        n0 = len(self.queue)
+                        self.cv.wait(timeout=self.QUIET_S)
+                        if len(self.queue) == n0:
+                            break
                 batch = self.queue[: self.max_batch]
                 del self.queue[: self.max_batch]
+            t_launch = time.perf_counter()
             outcomes = []
             try:
                 results = self.run_batch([p for p, _, _, _ in batch], max(k for _, k, _, _ in batch))
@@ -304,6 +319,7 @@ class _AsyncFront:
                         outcomes.append((None, exc_one))
             self.launches += 1
             self.served += len(batch)
+            self.last_batch, self.last_scan_s = len(batch), time.perf_counter() - t_launch
             per_loop: dict = {}          # ONE wake-up per event loop, not one per future (each is a write to the loop's pipe)
             for (_, _, fut, loop), (res, err) in zip(batch, outcomes):
                 per_loop.setdefault(loop, []).append((fut, res, err))
