@@ -8,6 +8,7 @@ in HBM and scored by the HIP kernels behind `FlatIndexF16`; scores are the canon
 products defined in DESIGN.md, ties ordered by insertion index.  IVF / HNSW / L2 are out of scope
 (SURVEY.md §8 a4).  There is no CPU fallback: without a GPU the default engine raises.
 """
+import logging
 import os
 import pickle
 import threading
@@ -20,6 +21,8 @@ import numpy as np
 from ....core.utils.data_model import Document
 from .base import VectorStore
 from .docstore import ColumnarDocstore, rows_from_dicts
+
+logger = logging.getLogger(__name__)
 
 
 def _default_engine(dim: int, metric: str, device: int, storage: str = "f16", **engine_kwargs):
@@ -306,6 +309,20 @@ class _AsyncFront:
                             break
                 batch = self.queue[: self.max_batch]
                 del self.queue[: self.max_batch]
+            try:
+                self._serve(batch)
+            except BaseException as exc:  # noqa: BLE001 - the batch's callers have been told (_serve's finally); the worker
+                # stays: a thread that is on its way out still reads as alive to submit(), which would then queue a
+                # caller for nobody
+                logger.error("async search front: a batch failed outside the per-query handling: %r", exc)
+
+    def _serve(self, batch) -> None:
+        """Answer one dequeued batch.  Whatever happens in here — a BaseException out of the scan, a loop object that
+        raises something other than RuntimeError, a bug in the delivery code — every caller of the batch gets an answer or
+        an exception: a future nobody resolves is a coroutine that hangs for ever."""
+        settled: set = set()
+        failure: Optional[BaseException] = None
+        try:
             t_launch = time.perf_counter()
             outcomes = []
             try:
@@ -328,6 +345,20 @@ class _AsyncFront:
                     loop.call_soon_threadsafe(self._deliver_many, items)
                 except RuntimeError:          # the callers' loop is closed: nobody is waiting any more
                     pass
+                settled.update(id(fut) for fut, _, _ in items)
+        except BaseException as exc:  # noqa: BLE001
+            failure = exc
+            raise
+        finally:
+            left = [(fut, loop) for _, _, fut, loop in batch if id(fut) not in settled]
+            if left:
+                err = RuntimeError(f"the async search front failed while serving this batch: {failure!r}")
+                err.__cause__ = failure
+                for fut, loop in left:
+                    try:
+                        loop.call_soon_threadsafe(self._deliver, fut, None, err)
+                    except BaseException:  # noqa: BLE001 - that caller's loop is gone (or broken): nobody to tell
+                        pass
 
 
 class HipFlatVectorStore(VectorStore):
@@ -578,20 +609,37 @@ class HipFlatVectorStore(VectorStore):
 
     def _search_chunks(self, q, k: int):
         """(scores fp32 [n][k], rows int64 [n][k]) numpy pairs, one per 256 queries of q (device tensor or array), in order.
-        Chunk i+1 is on the GPU while chunk i is collected, copied out (pinned) and — in the caller — mapped to Documents."""
+        Chunk i+1 is on the GPU while chunk i is collected, copied out (pinned) and — in the caller — mapped to Documents.
+
+        A yielded pair is a zero-copy VIEW of its search handle's pinned staging slot: it is the consumer's for the body
+        of its loop iteration only.  The slot goes back to the index's pool when the generator is resumed (or closed);
+        a consumer that keeps a pair must copy it (batch_search_by_vector does)."""
         idx = self.index
         k = min(int(k), self.ntotal)
         if not hasattr(idx, "search_async"):            # an engine with the numpy surface only
             yield idx.search(q, k)
             return
         step, pending = 256, None
-        for s0 in range(0, len(q), step):
-            nxt = idx.search_async(q[s0:s0 + step], k, to_host=True)
+        view = lambda h: h.host_view() if hasattr(h, "host_view") else h.host()
+        done = lambda h: h.release() if hasattr(h, "release") else None
+        try:
+            for s0 in range(0, len(q), step):
+                nxt = idx.search_async(q[s0:s0 + step], k, to_host=True)
+                if pending is not None:
+                    try:
+                        yield view(pending)
+                    finally:
+                        done(pending)
+                pending = nxt
             if pending is not None:
-                yield pending.host()
-            pending = nxt
-        if pending is not None:
-            yield pending.host()
+                last, pending = pending, None
+                try:
+                    yield view(last)
+                finally:
+                    done(last)
+        finally:
+            if pending is not None:     # the consumer stopped early: the launch in flight still has to let go of its slot
+                done(pending)
 
     def _embed_batch(self, queries: List[str]):
         """Query texts -> vectors: a device tensor when the provider can keep them in HBM, else a float32 array."""
@@ -616,10 +664,12 @@ class HipFlatVectorStore(VectorStore):
             nq = len(embeddings)
             return np.zeros((nq, 0), np.float32), np.zeros((nq, 0), np.int64)
         q = embeddings if hasattr(embeddings, "is_cuda") else np.asarray(embeddings, dtype=np.float32)
-        parts = list(self._search_chunks(q, k))
-        if len(parts) == 1:
-            return parts[0]
-        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        nq, kk, at = len(q), min(int(k), self.ntotal), 0
+        scores, rows = np.empty((nq, kk), np.float32), np.empty((nq, kk), np.int64)
+        for sc, rw in self._search_chunks(q, k):        # (views of pinned staging: copied out before the next chunk is asked for)
+            scores[at: at + len(sc)], rows[at: at + len(rw)] = sc, rw
+            at += len(sc)
+        return scores, rows
 
     def _batch_answers(self, queries: Sequence[str], k: int, with_scores: bool):
         import time

@@ -18,7 +18,84 @@ from . import binding as B
 _ROW_ALIGN = 32  # the scan reads whole 32-row tiles
 _IO_RING: dict = {}            # the process's pinned staging ring for shard files (FlatIndexF16._io_staging)
 _IO_LOCK = threading.Lock()    # one shard-file transfer at a time per process: they share the ring
-_PIN_LOCK = threading.Lock()   # the pinned answer-staging rings (FlatIndexF16._pinned_pair) are handed out one at a time
+
+
+class _PinSlot:
+    """One pinned (ids int64, scores fp32) staging pair on loan from a _PinnedPool.  Whoever holds the slot owns the memory:
+    it goes back to the pool when release() is called or when the last reference to the slot dies — never while a search
+    handle that was told to copy its answer into it is alive."""
+
+    __slots__ = ("pool", "ids", "scores", "__weakref__")
+
+    def __init__(self, pool, ids, scores):
+        self.pool, self.ids, self.scores = pool, ids, scores
+
+    def views(self, nq: int, k: int):
+        need = int(nq) * int(k)
+        return self.ids[:need].view(nq, k), self.scores[:need].view(nq, k)
+
+    def release(self) -> None:
+        pool, self.pool = self.pool, None
+        if pool is not None:
+            pool._give_back(self.ids, self.scores)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:       # interpreter shutdown
+            pass
+
+
+class _PinnedPool:
+    """Pinned host staging for answers.  Allocating pinned memory per search is what NOT to do (hipHostMalloc takes
+    milliseconds and waits for the device — measured as the eight scans of a 2048-query call running one after the other),
+    and a ring that hands a slot out again after N more searches is what not to do either (a 2048-query call's
+    chunk 7 landed on chunk 1's slot before chunk 1 had been read).  So: a free list.  A slot is taken for a search and
+    comes back when its handle lets go of it; the pool grows to the number of answers the callers really keep alive at
+    once (two or three in the pipelined paths) and allocates nothing after that."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free: list = []
+        self.allocated = 0          # slots ever created (diagnostics / tests)
+
+    def acquire(self, torch, nq: int, k: int) -> _PinSlot:
+        need = int(nq) * int(k)
+        with self._lock:
+            for i in range(len(self._free) - 1, -1, -1):
+                if self._free[i][0].numel() >= need:
+                    ids, scores = self._free.pop(i)
+                    return _PinSlot(self, ids, scores)
+            self.allocated += 1
+        cap = max(need, B.MAX_QUERIES * 128)
+        return _PinSlot(self, torch.empty(cap, dtype=torch.int64, pin_memory=True),
+                        torch.empty(cap, dtype=torch.float32, pin_memory=True))
+
+    def _give_back(self, ids, scores) -> None:
+        with self._lock:
+            if len(self._free) < 16:        # (a burst's extra slots are dropped again: torch's host allocator keeps them)
+                self._free.append((ids, scores))
+
+
+class _FlagPool:
+    """Pinned int32 status words, one per launch in flight: taken for a launch, given back when its handle has read it (or
+    dies).  A free list over blocks of 64 — never a ring: a call of 70 x 256 queries has 70 launches in flight before the
+    first result() and a ring of 64 would hand the first launch's word to the 65th."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._free: list = []
+
+    def acquire(self, torch):
+        with self._lock:
+            if not self._free:
+                block = torch.zeros(64, dtype=torch.int32, pin_memory=True)
+                self._free.extend(block[i: i + 1] for i in range(64))
+            return self._free.pop()
+
+    def give_back(self, word) -> None:
+        with self._lock:
+            self._free.append(word)
 
 
 def _torch():
@@ -164,6 +241,8 @@ class FlatIndexF16:
         self._qbuf = None
         self._version = 0          # bumped by every change of the rows (twin() contexts check it)
         self._parent = None        # twin(): the index whose rows this search context reads
+        self._pins = _PinnedPool()  # pinned staging for answers (shared with the index's twins: copy.copy keeps the object)
+        self._flags = _FlagPool()   # pinned status words, one per launch in flight
         self._own_stream = None    # twin(): the side stream its searches are enqueued on
         # growable=True: the row buffers live in DeviceArenas (HIP virtual memory) — add() past the capacity maps more
         # memory behind the same pointer instead of allocating a bigger buffer and copying (peak = live rows + one step
@@ -225,9 +304,12 @@ class FlatIndexF16:
         old_mapped = arena.mapped
         arena.grow(cap * row_bytes)
         rows = (arena.mapped // (row_bytes * _ROW_ALIGN)) * _ROW_ALIGN          # whole 32-row tiles of what is backed
+        if arena.mapped > old_mapped:
+            # fresh memory reads as zeros (padding rows and columns rely on it) — zeroed over the MAPPED byte range, not over
+            # the row view: a slab's ragged end (16 MiB is not a whole number of 32-row tiles at d = 768) belongs to rows that
+            # only become whole once the next slab is mapped, and that call starts zeroing at old_mapped
+            arena.view(arena.mapped)[old_mapped:].zero_()
         flat = arena.view(rows * row_bytes)
-        if arena.mapped > old_mapped:       # fresh memory reads as zeros (padding rows and columns rely on it)
-            flat[old_mapped:].zero_()
         out = flat.view(dtype)
         return (out.view(rows, cols) if cols else out), rows
 
@@ -691,41 +773,18 @@ class FlatIndexF16:
         search on its stream and ONE event is waited for (two pageable `.cpu()` calls are two synchronous staged copies).
         The arrays own their pinned block (torch's caching host allocator recycles it when they die)."""
         t = self.torch
-        with _PIN_LOCK, t.cuda.device(self.device):        # (callers may be pool threads: one staging pair, one copy at a time)
-            h_i, h_s = self._pinned_pair(ids.shape[0], ids.shape[1])
-            h_i.copy_(ids, non_blocking=True)
-            h_s.copy_(scores, non_blocking=True)
-            done = t.cuda.Event()
-            done.record()
-            done.synchronize()
-            return h_s.numpy().copy(), h_i.numpy().copy()  # (the caller owns its arrays: the staging pair is reused)
-
-    def _pinned_flag(self):
-        """One pinned int32 for a batch's status word, from a ring of 64 (a handle holds its word until result())."""
-        t = self.torch
-        ring = self.__dict__.setdefault("_flag_ring", {"at": 0, "buf": None})
-        if ring["buf"] is None:
-            ring["buf"] = t.zeros(64, dtype=t.int32, pin_memory=True)
-        ring["at"] = (ring["at"] + 1) % 64
-        return ring["buf"][ring["at"]: ring["at"] + 1]
-
-    PINNED_RING = 6     # staging pairs per index: more than the searches a caller keeps in flight (two) plus the one being mapped
-
-    def _pinned_pair(self, nq: int, k: int):
-        """A pinned (ids int64 [nq][k], scores fp32 [nq][k]) staging pair from the index's ring.  Allocating pinned memory
-        per search is what NOT to do: hipHostMalloc takes milliseconds and waits for the device — measured as the eight
-        scans of a 2048-query call running one after the other (0.82 of the engine where two callers reached 0.96)."""
-        t = self.torch
-        ring = self.__dict__.setdefault("_pin_ring", {"at": 0, "slots": []})      # (shared with the index's twins)
-        if len(ring["slots"]) < self.PINNED_RING:
-            ring["slots"].append(None)
-        ring["at"] = (ring["at"] + 1) % len(ring["slots"])
-        slot = ring["slots"][ring["at"]]
-        need = int(nq) * int(k)
-        if slot is None or slot[0].numel() < need:
-            cap = max(need, B.MAX_QUERIES * 128)
-            slot = ring["slots"][ring["at"]] = (t.empty(cap, dtype=t.int64, pin_memory=True), t.empty(cap, dtype=t.float32, pin_memory=True))
-        return slot[0][:need].view(nq, k), slot[1][:need].view(nq, k)
+        with t.cuda.device(self.device):        # (callers may be pool threads: each takes a staging slot of its own)
+            slot = self._pins.acquire(t, ids.shape[0], ids.shape[1])
+            try:
+                h_i, h_s = slot.views(ids.shape[0], ids.shape[1])
+                h_i.copy_(ids, non_blocking=True)
+                h_s.copy_(scores, non_blocking=True)
+                done = t.cuda.Event()
+                done.record()
+                done.synchronize()
+                return h_s.numpy().copy(), h_i.numpy().copy()  # (the caller owns its arrays: the slot goes back)
+            finally:
+                slot.release()
 
     def search_device(self, queries, k: int, repair: bool = True):
         """Same as search() but returns device tensors (ids int64, scores fp32)."""
@@ -833,7 +892,9 @@ class FlatIndexF16:
             out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
             out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
             parts = []
-            h_ids, h_sc = self._pinned_pair(nq, k) if to_host else (None, None)
+            # the answer's pinned staging slot belongs to the handle returned below until it is released / dies
+            slot = self._pins.acquire(t, nq, k) if to_host else None
+            h_ids, h_sc = slot.views(nq, k) if to_host else (None, None)
             for s0 in range(0, nq, B.MAX_QUERIES):
                 e0 = min(nq, s0 + B.MAX_QUERIES)
                 status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this launch's own words
@@ -843,16 +904,17 @@ class FlatIndexF16:
                     h_sc[s0:e0].copy_(out_sc[s0:e0], non_blocking=True)
                 # the batch's one status word goes to pinned host memory behind the search, with an event of its
                 # own: result() waits for THIS batch only, not for whatever was enqueued after it
-                flag_h = self._pinned_flag()
+                flag_h = self._flags.acquire(t)
                 flag_h.copy_(status[B.MAX_QUERIES:], non_blocking=True)
                 done = t.cuda.Event()
                 done.record()
                 parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], flag_h,
                                            status[:e0 - s0], done, stream=t.cuda.current_stream(self.device),
                                            version=self._rows_version(),
-                                           host=(h_ids[s0:e0], h_sc[s0:e0]) if to_host else None, cand_cap=self.cand_cap))
+                                           host=(h_ids[s0:e0], h_sc[s0:e0]) if to_host else None, cand_cap=self.cand_cap,
+                                           slot=slot))
             return parts[0] if len(parts) == 1 else PendingBatches(parts, out_ids, out_sc,
-                                                                   host=(h_ids, h_sc) if to_host else None)
+                                                                   host=(h_ids, h_sc) if to_host else None, slot=slot)
 
     CAND_CAP_LIMIT = 1 << 21    # sticky growth of cand_cap stops here (4.3 GB of candidate keys per 128 results)
 
@@ -1171,18 +1233,43 @@ class _FinishedSearch:
     def host(self):
         return self.index.to_host(self.ids, self.scores)
 
+    host_view = host
+
+    def release(self) -> None:
+        pass
+
 
 class PendingSearch:
     """Handle returned by FlatIndexF16.search_async."""
 
-    def __init__(self, index, q, k, ids, scores, flag, status, done=None, stream=None, version=None, host=None, cand_cap=None):
+    def __init__(self, index, q, k, ids, scores, flag, status, done=None, stream=None, version=None, host=None, cand_cap=None,
+                 slot=None):
         self.index, self.q, self.k, self.ids, self.scores, self.flag, self.status = index, q, k, ids, scores, flag, status
         self.cand_cap = cand_cap   # the candidate capacity this batch was launched with
         self.host_copy = host   # (ids, scores) pinned tensors the answer was copied into behind the search (to_host=True)
+        self.slot = slot        # the _PinSlot those tensors are views of: ours (shared with the sibling launches of one call)
         self.done = done        # event recorded behind the copy of the status word into pinned memory (`flag`)
         self.stream = stream    # the stream the search was enqueued on (a twin's side stream, else the caller's)
         self.version = version  # version of the rows when it was enqueued
         self.repaired = None
+
+    def _flag_word(self) -> int:
+        """The launch's status word, read once; its pinned word goes back to the pool."""
+        if self.done is not None:
+            self.done.synchronize()   # this batch only: later batches keep running
+            word = int(self.flag[0])
+            flag, self.flag = self.flag, None
+            self.index._flags.give_back(flag)
+            return word
+        return int(self.flag.item())
+
+    def __del__(self):
+        try:                        # a handle dropped without result(): its launch may still be writing the word
+            if self.done is not None and self.flag is not None:
+                self.done.synchronize()
+                self.index._flags.give_back(self.flag)
+        except Exception:
+            pass
 
     def result(self):
         """(ids int64 [nq][k], scores fp32 [nq][k]) device tensors, exact.
@@ -1195,9 +1282,7 @@ class PendingSearch:
         if self.repaired is None:
             t = self.index.torch
             self.repaired = []
-            if self.done is not None:
-                self.done.synchronize()   # this batch only: later batches keep running
-            if int(self.flag[0] if self.done is not None else self.flag.item()):
+            if self._flag_word():
                 words = self.status.cpu().tolist()
                 self.repaired = [i for i, w in enumerate(words) if w]
                 if self.version is not None and self.version != self.index._rows_version():
@@ -1211,11 +1296,11 @@ class PendingSearch:
             self.index.last_repaired = self.repaired
         return self.ids, self.scores
 
-    def host(self):
-        """result() as numpy (scores fp32 [nq][k], ids int64 [nq][k]) through pinned memory.  With to_host=True the copy
-        was enqueued behind the search and is complete once the batch's event is (nothing later on the stream is waited
-        for); a repaired batch — rare — is copied again.  The arrays of a to_host=True batch are VIEWS of the index's
-        staging ring: consume (or copy) them before PINNED_RING - 1 more batches are enqueued."""
+    def host_view(self):
+        """result() as numpy (scores fp32 [nq][k], ids int64 [nq][k]) WITHOUT a copy when the answer was staged behind the
+        search (to_host=True): the arrays are views of this handle's pinned slot — valid until release() or until the
+        handle dies, whichever comes first; nothing else can be handed that memory meanwhile.  A repaired batch — rare — is
+        copied again (and then owns its arrays)."""
         ids, scores = self.result()
         if self.host_copy is not None and not self.repaired:
             return self.host_copy[1].numpy(), self.host_copy[0].numpy()
@@ -1223,13 +1308,33 @@ class PendingSearch:
         with t.cuda.stream(self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)):
             return self.index.to_host(ids, scores)
 
+    def host(self):
+        """result() as numpy arrays the caller owns.  With to_host=True the copy to pinned memory was enqueued behind the
+        search and is complete once the batch's event is (nothing later on the stream is waited for); the staging slot is
+        released here."""
+        scores, ids = self.host_view()
+        if self.host_copy is not None and not self.repaired:
+            scores, ids = scores.copy(), ids.copy()
+        self.release()
+        return scores, ids
+
+    def release(self) -> None:
+        """Give the pinned staging slot back (arrays from host_view() must not be read afterwards)."""
+        self.host_copy = None
+        slot, self.slot = self.slot, None
+        if slot is not None:
+            slot.release()
+
 
 class PendingBatches:
     """search_async over more than 256 queries: one PendingSearch per 256-query launch, one result."""
 
-    def __init__(self, parts, ids, scores, host=None):
+    def __init__(self, parts, ids, scores, host=None, slot=None):
         self.parts, self.ids, self.scores = parts, ids, scores
         self.host_copy = host
+        self.slot = slot
+        for p in parts:             # the one slot is this handle's: a part must not hand it back on its own
+            p.slot = None
         self.repaired = None
 
     def result(self):
@@ -1241,7 +1346,7 @@ class PendingBatches:
             self.parts[0].index.last_repaired = self.repaired
         return self.ids, self.scores
 
-    def host(self):
+    def host_view(self):
         ids, scores = self.result()
         if self.host_copy is not None and not self.repaired:
             return self.host_copy[1].numpy(), self.host_copy[0].numpy()
@@ -1249,3 +1354,18 @@ class PendingBatches:
         t = p.index.torch
         with t.cuda.stream(p.stream if p.stream is not None else t.cuda.current_stream(p.index.device)):
             return p.index.to_host(ids, scores)
+
+    def host(self):
+        scores, ids = self.host_view()
+        if self.host_copy is not None and not self.repaired:
+            scores, ids = scores.copy(), ids.copy()
+        self.release()
+        return scores, ids
+
+    def release(self) -> None:
+        self.host_copy = None
+        for p in self.parts:
+            p.host_copy = None
+        slot, self.slot = self.slot, None
+        if slot is not None:
+            slot.release()

@@ -324,3 +324,36 @@ def test_256_coroutines_share_scans_without_a_thread_each():
     plain = _store(engine=OracleIndex)
     rp = VectorStoreRetriever(plain)
     assert [d.id for d in asyncio.run(rp.ainvoke("question 9", k=4))] == [d.id for d in rp.invoke("question 9", k=4)]
+
+
+def test_async_front_never_leaves_a_future_unresolved():
+    """anything that is not an ordinary Exception inside the worker (here a BaseException out of the scan) used to
+    kill the worker after the batch had left the queue — its callers awaited for ever.  Every caller of the batch is told,
+    and a later caller gets a new worker."""
+    import asyncio
+
+    class Abort(BaseException):
+        pass
+
+    class Fatal(_SlowOracleIndex):
+        armed = True
+
+        def search(self, queries, k):
+            if Fatal.armed:
+                raise Abort("not an Exception")
+            return super().search(queries, k)
+
+    store = _store(emb=_BatchingHashEmbeddings(64), engine=Fatal)
+    store.index.delay = 0.0
+    r = VectorStoreRetriever(store)
+
+    async def burst():
+        return await asyncio.wait_for(asyncio.gather(*[r.ainvoke(f"question {i}", k=3) for i in range(5)],
+                                                     return_exceptions=True), timeout=20)
+
+    got = asyncio.run(burst())
+    assert all(isinstance(g, RuntimeError) and "async search front failed" in str(g) for g in got), got
+    assert all(isinstance(g.__cause__, Abort) for g in got)
+    Fatal.armed = False
+    docs = asyncio.run(asyncio.wait_for(r.ainvoke("question 1", k=3), timeout=20))
+    assert [d.id for d in docs] == [d.id for d in r.invoke("question 1", k=3)]

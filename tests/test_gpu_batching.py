@@ -172,3 +172,53 @@ def test_sharded_store_from_json_on_two_ranks_equals_single_store(tmp_path):
         got = json.loads((tmp_path / f"r{rank}.json").read_text())
         assert got["one"] == want_one, f"rank {rank}: (id, score) lists differ from the single store's"
         assert got["many"] == want_many, f"rank {rank}"
+
+
+def test_2560_query_vectors_in_one_call_and_many_threads_keep_their_own_answers():
+    """answers were handed out as views of a 6-slot pinned ring.  A call of more than 1536 queries kept
+    seven chunks' views while chunks 7, 8 … were copied over the first ones; more than three threads in a batched call
+    overwrote each other.  Staging slots are now owned by their search handle (engine._PinnedPool): ten chunks in one
+    call, then eight threads at once, all equal to chunk-by-chunk searches — and an answer returned earlier does not
+    change under later searches."""
+    import torch
+
+    from rag_arc_amd.encapsulation.database.vector_db import HipFlatVectorStore
+
+    emb = _SynthEmbeddings(128)
+    store = HipFlatVectorStore(emb, coalesce=False)
+    n = 60_000
+    store.add_texts([f"doc{i}" for i in range(n)], ids=[str(i) for i in range(n)])
+    q = emb._rows(0, 2560, 4321)
+    want_s, want_r = [], []
+    for s0 in range(0, 2560, 256):
+        s, r = store.index.search(q[s0:s0 + 256], 20)
+        want_s.append(s), want_r.append(r)
+    want_s, want_r = np.concatenate(want_s), np.concatenate(want_r)
+    assert len({tuple(r) for r in want_r.tolist()}) > 2000        # (the queries really have different answers)
+    got_s, got_r = store.batch_search_by_vector(q, 20)
+    assert np.array_equal(got_r, want_r) and np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
+    one_s, one_r = store.batch_search_by_vector(q[:100], 20)       # one chunk: the caller owns these arrays
+    keep_s, keep_r = one_s.copy(), one_r.copy()
+    for s0 in range(256, 2560, 256):
+        store.batch_search_by_vector(q[s0:s0 + 256], 20)
+    assert np.array_equal(one_r, keep_r) and np.array_equal(one_s, keep_s)
+    # eight threads, 768 queries each (three chunks per call), all at once
+    out, errors = {}, []
+
+    def work(t):
+        try:
+            torch.cuda.set_device(0)
+            out[t] = store.batch_search_by_vector(q[t * 256:t * 256 + 768], 20)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for t in range(8):
+        assert np.array_equal(out[t][1], want_r[t * 256:t * 256 + 768]), t
+        assert np.array_equal(out[t][0].view(np.uint32), want_s[t * 256:t * 256 + 768].view(np.uint32)), t
+    assert store.index._pins.allocated <= 24, store.index._pins.allocated     # slots come back: the pool stays small

@@ -10,7 +10,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-
 api=../build/rarc_api.o
 case " $* " in *RARC_EXPERIMENT*) /opt/rocm/bin/hipcc $FLAGS -DRARC_EXPERIMENT -c rarc_api.hip -o /tmp/var_api_$name.o && api=/tmp/var_api_$name.o;; esac
 objs=""
-for o in rarc_api scan_f16 scan_q8 quant finalize prep fuse encoder encoder_f32 decoder shard_io tokenizer vmem compact wide; do
+# the object list is the Makefile's SRCS: a source added there is linked here too (pairs was missing)
+for o in $(sed -n 's/^SRCS *= *//p' Makefile | sed 's/\.hip//g'); do
   if [ $o = $stem ]; then objs="$objs /tmp/var_${stem}_$name.o"; elif [ $o = rarc_api ]; then objs="$objs $api"; else objs="$objs ../build/$o.o"; fi
 done
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o /tmp/var_${stem}_$name.o && \

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_wide_small; rm -rf $O; mkdir -p $O; cd $R
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/prof_wide_small; rm -rf $O; mkdir -p $O; cd $R
 PROBE_SIZES=100000 rocprofv3 --kernel-trace --output-format csv -d $O -- python3 tools/wide_size_sweep.py > $O/log.txt 2>&1
 f=$(ls $O/*/*kernel_trace.csv | head -1)
 python3 - $f <<'PY'
