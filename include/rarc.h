@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RARC_VERSION 501 /* 0.5.1: rarc_similar_pairs (all-pairs cosine >= threshold: the graph store's entity dedup); 0.5.0: rarc_search_wide (rows to 4096 padded dims, k to 8192), rarc_compact_rows (delete by compaction), rarc_vmem_* (growable arenas), RARC_E_IO / RARC_IO_TRUNCATE; 0.4.1: RarcEnc32Layer.f1_colmax (FFN1 with its GELU fused into the GEMM epilogue); 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
+#define RARC_VERSION 600 /* 0.6.0: the encoder's QUERY PATH (RarcEnc32Layer.*_wq, rarc_enc32_pack_query_weight: forwards of 32 / 64 / 128 tokens as weight streams), rarc_stream_read (the measured HBM read ceiling a bench line reports next to the nominal one); 0.5.1: rarc_similar_pairs (all-pairs cosine >= threshold: the graph store's entity dedup); 0.5.0: rarc_search_wide (rows to 4096 padded dims, k to 8192), rarc_compact_rows (delete by compaction), rarc_vmem_* (growable arenas), RARC_E_IO / RARC_IO_TRUNCATE; 0.4.1: RarcEnc32Layer.f1_colmax (FFN1 with its GELU fused into the GEMM epilogue); 0.4.0: shard-file streaming (rarc_file_to_device, rarc_device_to_file), host WordPiece (rarc_wordpiece_*); 0.3.2: RMSNorm folded into the reranker LM's projections (RarcLmLayer.qkv_w_folded, gate_up_w_folded),
                             * rarc_enc_gemm_zero_bias; 0.3.1: relative-position attention bias in both encoder forwards (MPNet family: RarcEncModel / RarcEnc32Model
                             * rel_bias, rel_span); 0.3.0: fp32-class encoder forward (rarc_enc32_*) */
 
@@ -436,6 +436,12 @@ typedef struct RarcEnc32Layer {
                                NULL = none.  With it, batches that fill the chip run FFN1 with bias + GELU + the split of its output
                                fused into the GEMM (the row's power-of-two scale comes from the bound sum_k |x_k| c[k] + c[hidden]
                                >= max_j |gelu(x·W1_j + b1_j)|, known before the GEMM); without it FFN1 is a product + a row pass. */
+  /* ABI 600 — the QUERY PATH's weight images (rarc_enc32_pack_query_weight), one per projection, NULL = none.  With all four
+   * present in every layer, a forward of 32 / 64 / 128 tokens (one to four 32-token queries: the reference's embed_query,
+   * core/file_management/embeddings/huggingface.py:136-145) runs its projections as weight streams over these images instead
+   * of the 128 x 128 tile kernels over *_w3.  uint16 (fp16 bits) [n / 32][k / 16][2][64][8]: per 32 output features and 16-wide
+   * k step the W_hi fragment, then the W_lo fragment, each in the lane order of a v_mfma_f32_32x32x16_f16 A operand. */
+  const uint16_t *qkv_wq, *o_wq, *f1_wq, *f2_wq;
 } RarcEnc32Layer;
 typedef struct RarcEnc32Model {
   int hidden, heads, inter, n_layers;
@@ -447,6 +453,9 @@ typedef struct RarcEnc32Model {
   int rel_span;
 } RarcEnc32Model;
 int rarc_enc32_split_weight(const float* d_w, int n, int k, uint16_t* d_w3, float* d_rw, void* stream);
+/* d_w3: the split rows of an [n][k] weight (rarc_enc32_split_weight) -> d_wq: n*k*2 halves, the query path's image of the same
+ * weight (RarcEnc32Layer.*_wq).  n a multiple of 32, k a multiple of 128. */
+int rarc_enc32_pack_query_weight(const uint16_t* d_w3, int n, int k, uint16_t* d_wq, void* stream);
 int rarc_enc32_split_rows(const float* d_x, int m, int k, uint16_t* d_a3, float* d_ra, void* stream);
 int rarc_enc32_gemm(const uint16_t* d_a3, const float* d_ra, const uint16_t* d_w3, const float* d_rw,
                     const float* d_bias, float* d_c, int m, int n, int k, void* stream);

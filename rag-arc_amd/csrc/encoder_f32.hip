@@ -80,9 +80,19 @@ struct E32Row {
   float4 v[NV];
 };
 
-// row -> split image [lo | hi | hi] (3n halves) + the row's inverse scale
+// Fragment-major split image of the query path (round 6; rarc_e32_skinny_gemm_kernel reads it): element (m, c) of a
+// [M][n] matrix lives where the lane of a v_mfma_f32_32x32x16_f16 B operand wants it — per (32-token block, 16-wide k step):
+// the hi fragment then the lo fragment, each 64 lanes x 8 halves = 1 KiB contiguous (lane = token + 32·(k half), natural k
+// order inside a fragment).  Offset in halves of the hi value of (m, c); the lo value sits 512 halves further.
+__device__ __forceinline__ size_t e32_frag_offset(size_t m, int c, int n) {
+  return ((((m >> 5) * (size_t)(n >> 4) + (size_t)(c >> 4)) * 2) * 64 + (m & 31) + 32 * ((c >> 3) & 1)) * 8 + (c & 7);
+}
+
+// row -> split image [lo | hi | hi] (3n halves) + the row's inverse scale; frag: the fragment-major image instead (out3 is
+// then the base of the whole image and `row` the row's index in it)
 template <int NV>
-__device__ __forceinline__ void e32_store_split(const E32Row<NV>& r, int n, half_t* out3, float* ra_out, float* slot) {
+__device__ __forceinline__ void e32_store_split(const E32Row<NV>& r, int n, half_t* out3, float* ra_out, float* slot,
+                                                bool frag = false, size_t row = 0) {
   float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i)
@@ -97,9 +107,15 @@ __device__ __forceinline__ void e32_store_split(const E32Row<NV>& r, int n, half
     if (c < n) {
       half4_t hi, lo;
       e32_split4(r.v[i], s, hi, lo);
-      *(half4_t*)(out3 + c) = lo;
-      *(half4_t*)(out3 + n + c) = hi;
-      *(half4_t*)(out3 + 2 * n + c) = hi;
+      if (frag) {
+        half_t* o = out3 + e32_frag_offset(row, c, n);
+        *(half4_t*)o = hi;
+        *(half4_t*)(o + 512) = lo;
+      } else {
+        *(half4_t*)(out3 + c) = lo;
+        *(half4_t*)(out3 + n + c) = hi;
+        *(half4_t*)(out3 + 2 * n + c) = hi;
+      }
     }
   }
   if (threadIdx.x == 0) *ra_out = inv;
@@ -156,6 +172,7 @@ __device__ __forceinline__ float e32_gelu(float v) { return 0.5f * v * (1.0f + e
 // The row pass in front of FFN1 (MODE 2, the LayerNorm) computes it: sg_out[m] = scale, sg_out[rows + m] = 1/scale.
 struct E32Fuse {
   const float* colmax = nullptr; int k = 0; float* sg_out = nullptr; size_t sg_rows = 0;
+  bool frag = false;   // the query path: the split image is written fragment-major (e32_frag_offset)
 };
 
 // slab 0 + slab 1 + ... of a split-K product, IN ORDER (the sum is what an unsplit k loop would have rounded differently, but it
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const
       if (c < n) *(float4*)(out32 + m * n + c) = r.v[i];
     }
   }
-  if (MODE != 0) e32_store_split<NV>(r, n, out3 + m * 3 * n, ra_out + m, slot + 8);
+  if (MODE != 0) e32_store_split<NV>(r, n, fz.frag ? out3 : out3 + m * 3 * n, ra_out + m, slot + 8, fz.frag, m);
 }
 
 // x = LayerNorm(word[id] + pos[t % L] + type0) -> fp32 rows + split image
@@ -246,7 +263,8 @@ __global__ __launch_bounds__(256) void rarc_e32_embed_kernel(const int32_t* __re
                                                              const float* __restrict__ pos, const float* __restrict__ type0,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, int L, int H, int vocab, float* __restrict__ out32,
-                                                             half_t* __restrict__ out3, float* __restrict__ ra_out) {
+                                                             half_t* __restrict__ out3, float* __restrict__ ra_out,
+                                                             bool frag = false) {
   __shared__ float slot[12];
   const size_t t = blockIdx.x;
   int id = ids[t];
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(256) void rarc_e32_embed_kernel(const int32_t* __re
   }
   e32_layernorm<1>(r, H, gamma, beta, eps, slot);
   if (c < H) *(float4*)(out32 + t * H + c) = r.v[0];
-  e32_store_split<1>(r, H, out3 + t * 3 * H, ra_out + t, slot + 8);
+  e32_store_split<1>(r, H, frag ? out3 : out3 + t * 3 * H, ra_out + t, slot + 8, frag, t);
 }
 
 // weight rows at load time: W fp32 [N][K] -> [W_hi | W_lo | W_hi] (3K halves per row) + inverse row scale
@@ -748,6 +766,138 @@ __global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restr
   for (int c = tid; c < H; c += 256) out[(size_t)b * H + c] = s_vec[c] * inv;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The QUERY PATH (round 6): forwards of at most 128 tokens — the call the reference issues per search, one query's
+// `embed_query` (huggingface.py:136-145 -> VectorStore_Faiss.py:240).  At 32..128 tokens a projection is a weight STREAM: the
+// FFN's 8M parameters against 32 rows of activations.  The tile GEMMs of encoder.hip run it as 128 x 128 tiles with split-K,
+// one or two hundred workgroups each walking a k loop of dependent LDS-DMA stages: 15 µs per projection, 1.2 TB/s of weight
+// bytes, on a kernel built for 256-row tiles.  rarc_e32_skinny_gemm_kernel is the other shape:
+//   * the weights are the MFMA's A operand straight from HBM: a load-time image in FRAGMENT order (rarc_enc32_pack_query_weight:
+//     per 32 output features and 16-wide k step the W_hi fragment then the W_lo fragment, 1 KiB each — every wave-wide load
+//     instruction is one contiguous KiB; W_hi is read ONCE, not twice as in the [W_hi | W_lo | W_hi] rows the tile kernels
+//     stream: 4 bytes per parameter instead of 6);
+//   * the activations are the B operand from a fragment-major split image the row passes write (e32_frag_offset): L2 hits;
+//   * a wave owns 32 features x KR k steps: ALL of its loads (2·KR weight KiB + 2·KR activation KiB per 32 tokens) are issued
+//     before the first MFMA — the kernel is one memory round trip deep, not a pipeline;
+//   * the four waves of a workgroup hold consecutive k slices of the same features and add their accumulators through LDS
+//     in wave order (deterministic); workgroup y writes partial slab y — the consumers (attention loads, row passes) sum the
+//     slabs in order, as they do for the tile kernels' split-K.
+// Arithmetic per output element: the same three split products (lo·hi and hi·lo first, then hi·hi), fp16 products exact in
+// the fp32 accumulator; only the GROUPING of the k range differs from the tile kernels' (slices of KR·16 here), i.e. the
+// two forwards differ by fp32 summation order, not by method (tests/test_gpu_encoder_query.py bounds it).
+// ------------------------------------------------------------------------------------------
+template <int MT, int KR>   // MT: 32-token blocks (M = 32·MT), KR: k steps (of 16) per wave
+__global__ __launch_bounds__(256) void rarc_e32_skinny_gemm_kernel(const half_t* __restrict__ wq, const half_t* __restrict__ xq,
+                                                                   float* __restrict__ P, int N, int KS, int M) {
+  constexpr int TS = 36;   // floats per token row of a wave's tile in LDS (32 + 4: the rows start on different banks)
+  __shared__ __attribute__((aligned(16))) float red[4][32 * TS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = blockIdx.x, ks0 = (blockIdx.y * 4 + wave) * KR;
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) acc[mb] = (f32x16){0};
+  if (ks0 < KS) {   // (a k range that is not a multiple of four slices leaves the last workgroup's upper waves idle: zeros)
+    const half8* wp = (const half8*)(wq + ((size_t)nb * KS + ks0) * 1024) + lane;
+    half8 wh[KR], wl[KR];
+#pragma unroll
+    for (int i = 0; i < KR; ++i) {
+      wh[i] = __builtin_nontemporal_load(wp + i * 128);        // streamed once per forward: do not displace the activations in L2
+      wl[i] = __builtin_nontemporal_load(wp + i * 128 + 64);
+    }
+    half8 xh[MT][KR], xl[MT][KR];
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) {
+      const half8* xp = (const half8*)(xq + ((size_t)mb * KS + ks0) * 1024) + lane;
+#pragma unroll
+      for (int i = 0; i < KR; ++i) {
+        xh[mb][i] = xp[i * 128];
+        xl[mb][i] = xp[i * 128 + 64];
+      }
+    }
+    // every load of the wave is in flight before the first MFMA waits for one: ONE memory round trip.  (Left to itself the
+    // scheduler starts the chain behind the first four loads and issues the rest between its waits: three to four round trips.)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mb = 0; mb < MT; ++mb) {
+#pragma unroll
+      for (int i = 0; i < KR; ++i) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl[mb][i], acc[mb], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < KR; ++i) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh[mb][i], acc[mb], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < KR; ++i) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[mb][i], acc[mb], 0, 0, 0);
+    }
+    RARC_MFMA_SETTLE(acc);
+  }
+  // lane (token = lane & 31, h = lane >> 5) holds features 8g + 4h + e in acc[4g + e]
+  const int tok = lane & 31, h = lane >> 5;
+  const int tr = threadIdx.x >> 3, c4 = threadIdx.x & 7;   // 8 threads write one token's 32 features: 128 contiguous bytes
+#pragma unroll
+  for (int mb = 0; mb < MT; ++mb) {
+    if (mb) __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(float4*)&red[wave][tok * TS + 8 * g + 4 * h] =
+          make_float4(acc[mb][4 * g], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]);
+    __syncthreads();
+    const float4 a = *(const float4*)&red[0][tr * TS + 4 * c4], b = *(const float4*)&red[1][tr * TS + 4 * c4],
+                 c = *(const float4*)&red[2][tr * TS + 4 * c4], d = *(const float4*)&red[3][tr * TS + 4 * c4];
+    float4 o;
+    o.x = ((a.x + b.x) + c.x) + d.x; o.y = ((a.y + b.y) + c.y) + d.y;
+    o.z = ((a.z + b.z) + c.z) + d.z; o.w = ((a.w + b.w) + c.w) + d.w;
+    *(float4*)(P + ((size_t)blockIdx.y * M + mb * 32 + tr) * N + nb * 32 + 4 * c4) = o;
+  }
+}
+
+// [W_hi | W_lo | W_hi] rows (rarc_enc32_split_weight) -> the fragment-major image the skinny GEMM streams: one workgroup per
+// (32 features, 16-wide k step): 2 fragments x 64 lanes x 8 halves
+__global__ __launch_bounds__(128) void rarc_e32_pack_weight_kernel(const half_t* __restrict__ w3, int K, half_t* __restrict__ wq) {
+  const int KS = K >> 4;
+  const size_t nb = blockIdx.x / KS;
+  const int ks = blockIdx.x % KS;
+  const int frag = threadIdx.x >> 6, lane = threadIdx.x & 63;        // 0: hi, 1: lo
+  const half_t* src = w3 + (nb * 32 + (lane & 31)) * 3 * (size_t)K + (size_t)frag * K + ks * 16 + 8 * (lane >> 5);
+  *(uint4*)(wq + (((nb * KS + ks) * 2 + frag) * 64 + lane) * 8) = *(const uint4*)src;
+}
+
+extern "C" int rarc_enc32_pack_query_weight(const uint16_t* d_w3, int n, int k, uint16_t* d_wq, void* stream) {
+  RARC_REQUIRE(d_w3 && d_wq, RARC_E_INVALID, "rarc_enc32_pack_query_weight: null pointer");
+  RARC_REQUIRE(n > 0 && k > 0 && n % 32 == 0 && k % 128 == 0, RARC_E_UNSUPPORTED,
+               "rarc_enc32_pack_query_weight: need n a multiple of 32 and k a multiple of 128 (got %d, %d)", n, k);
+  hipLaunchKernelGGL(rarc_e32_pack_weight_kernel, dim3((unsigned)((size_t)(n / 32) * (k / 16))), dim3(128), 0, (hipStream_t)stream,
+                     (const half_t*)d_w3, k, (half_t*)d_wq);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+#define E32Q_MAX_TOKENS 128   // the query path's largest forward
+#define E32Q_MAX_PARTS 16     // partial slabs a skinny product may come in
+
+// one skinny product: P[part][m][n] (part < *parts) = partial sums of A·Wᵀ over the part's k slices.  KR (k steps per wave) is
+// the largest of 8 / 4 / 2 that still gives the chip ~200 workgroups, bounded below by E32Q_MAX_PARTS slabs.
+static int e32_skinny_gemm(const uint16_t* xq, const uint16_t* wq, float* P, int m, int n, int k, int* parts, hipStream_t s) {
+  const int KS = k / 16, nb = n / 32, MT = m / 32;
+  static const int force_kr = getenv("RARC_E32Q_KR") ? atoi(getenv("RARC_E32Q_KR")) : 0;   // (A/B: 8 / 4 / 2)
+  int kr = 8;
+  while (kr > 2 && nb * ((KS + 4 * kr - 1) / (4 * kr)) < 200) kr >>= 1;
+  if (MT == 4 && kr > 4) kr = 4;                       // (registers: MT·KR fragments of activations are in flight)
+  if (force_kr == 8 || force_kr == 4 || force_kr == 2) kr = (MT == 4 && force_kr > 4) ? 4 : force_kr;
+  while (kr < 8 && (KS + 4 * kr - 1) / (4 * kr) > E32Q_MAX_PARTS) kr <<= 1;
+  const int S = (KS + 4 * kr - 1) / (4 * kr);
+  RARC_REQUIRE(S <= E32Q_MAX_PARTS && (MT == 1 || MT == 2 || MT == 4) && (MT < 4 || kr <= 4), RARC_E_UNSUPPORTED,
+               "fp32-class query path: product %d x %d x %d not supported", m, n, k);
+  *parts = S;
+  const dim3 grid(nb, S);
+#define E32Q_LAUNCH(MTV, KRV)                                                                                          \
+  hipLaunchKernelGGL((rarc_e32_skinny_gemm_kernel<MTV, KRV>), grid, dim3(256), 0, s, (const half_t*)wq, (const half_t*)xq, P, n, KS, m)
+  if (MT == 1) { if (kr == 8) E32Q_LAUNCH(1, 8); else if (kr == 4) E32Q_LAUNCH(1, 4); else E32Q_LAUNCH(1, 2); }
+  else if (MT == 2) { if (kr == 8) E32Q_LAUNCH(2, 8); else if (kr == 4) E32Q_LAUNCH(2, 4); else E32Q_LAUNCH(2, 2); }
+  else { if (kr == 4) E32Q_LAUNCH(4, 4); else E32Q_LAUNCH(4, 2); }
+#undef E32Q_LAUNCH
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -789,6 +939,20 @@ extern "C" int rarc_enc32_gemm(const uint16_t* d_a3, const float* d_ra, const ui
 }
 
 static inline size_t e32_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int e32_p_slabs(size_t m) { return m <= E32Q_MAX_TOKENS ? E32Q_MAX_PARTS : (m <= 2048 ? 4 : 1); }   // [M][wide] slabs of the product buffer
+
+// does the query path take this forward?  At most 128 tokens in whole 32-token blocks (32 / 64 / 128), every layer with its
+// fragment-major weight images; RARC_E32_QUERY=0 keeps the tile kernels (A/B, and the comparison in tests).
+static bool e32_query_takes(const RarcEnc32Model* model, long long m) {
+  const char* e = getenv("RARC_E32_QUERY");   // (read per call: tests switch it between forwards)
+  if (e && atoi(e) == 0) return false;
+  if (!(m == 32 || m == 64 || m == 128)) return false;
+  for (int l = 0; l < model->n_layers; ++l) {
+    const RarcEnc32Layer& Ly = model->layers[l];
+    if (!Ly.qkv_wq || !Ly.o_wq || !Ly.f1_wq || !Ly.f2_wq) return false;
+  }
+  return true;
+}
 
 extern "C" size_t rarc_enc32_workspace_bytes(int hidden, int inter, int n_tokens) {
   if (hidden <= 0 || inter <= 0 || n_tokens <= 0) return 0;
@@ -797,7 +961,7 @@ extern "C" size_t rarc_enc32_workspace_bytes(int hidden, int inter, int n_tokens
   return 2 * e32_align(M * H * 4)      // x (residual stream), ctx
          + e32_align(M * 3 * H * 2)    // split image of x / ctx
          + e32_align(M * 3 * I * 2)    // split image of the GELU output
-         + e32_align(M * wide * 4 * (M <= 2048 ? 4 : 1))   // raw GEMM products (small batches: up to four split-K partial slabs)
+         + e32_align(M * wide * 4 * e32_p_slabs(M))   // raw GEMM products (small batches: split-K partial slabs; the query path's come in up to sixteen)
          + 2 * e32_align(M * 4)        // row scales
          + e32_align(2 * M * 4);       // fused FFN1: output scales and their inverses
 }
@@ -818,8 +982,10 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   RARC_REQUIRE(!model->rel_bias || model->rel_span >= seq_len, RARC_E_INVALID,
                "rarc_enc32_forward: the relative-position bias spans %d positions, the batch is %d long", model->rel_span, seq_len);
   const long long m_ll = (long long)n_seq * seq_len;
-  RARC_REQUIRE(m_ll % 128 == 0 && m_ll < (1ll << 31), RARC_E_UNSUPPORTED,
-               "rarc_enc32_forward: n_seq*seq_len must be a multiple of 128 (got %lld)", m_ll);
+  const bool query = e32_query_takes(model, m_ll);
+  RARC_REQUIRE((m_ll % 128 == 0 || query) && m_ll < (1ll << 31), RARC_E_UNSUPPORTED,
+               "rarc_enc32_forward: n_seq*seq_len must be a multiple of 128 — or 32 / 64 when every layer carries its query-path "
+               "weight images (got %lld)", m_ll);
   const int M = (int)m_ll;
   RARC_REQUIRE(ws_bytes >= rarc_enc32_workspace_bytes(H, I, M), RARC_E_INVALID, "rarc_enc32_forward: workspace too small");
   hipStream_t hs = (hipStream_t)stream;
@@ -829,7 +995,7 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   float* ctx = (float*)w;               w += e32_align((size_t)M * H * 4);
   uint16_t* xs = (uint16_t*)w;          w += e32_align((size_t)M * 3 * H * 2);
   uint16_t* mids = (uint16_t*)w;        w += e32_align((size_t)M * 3 * I * 2);
-  const int p_slabs = M <= 2048 ? 4 : 1;                    // [M][wide] slabs the product buffer holds
+  const int p_slabs = e32_p_slabs((size_t)M);                // [M][wide] slabs the product buffer holds
   float* P = (float*)w;                 w += e32_align((size_t)M * wide * 4 * p_slabs);
   float* ra_a = (float*)w;              w += e32_align((size_t)M * 4);
   float* ra_b = (float*)w;              w += e32_align((size_t)M * 4);
@@ -837,7 +1003,7 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   const float eps = model->ln_eps;
 
   hipLaunchKernelGGL(rarc_e32_embed_kernel, dim3(M), dim3(256), 0, hs, d_ids, model->word, model->pos, model->type0,
-                     model->emb_g, model->emb_b, eps, seq_len, H, model->vocab, x, (half_t*)xs, ra_a);
+                     model->emb_g, model->emb_b, eps, seq_len, H, model->vocab, x, (half_t*)xs, ra_a, query);
   RARC_HIP_CHECK(hipGetLastError());
   const int q_blocks = (seq_len + 31) / 32;
   const int n_units = n_seq * model->heads * q_blocks;  // one wave each, four per workgroup
@@ -848,12 +1014,17 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   // head_dim 64: attention on the fp16 MFMA over split operands (round 4); RARC_E32_ATTN=mfma32 keeps the fp32-MFMA kernel (A/B)
   const char* attn_env = getenv("RARC_E32_ATTN");   // (read per call: tests switch it between forwards)
   const bool split_attention = !(attn_env && !strcmp(attn_env, "mfma32"));
-  const bool fuse_shape = rarc_gemm_f16_gelu_split_takes(M, I, 3 * H);   // FFN1's GELU in the GEMM epilogue (big batches)
+  const bool fuse_shape = !query && rarc_gemm_f16_gelu_split_takes(M, I, 3 * H);   // FFN1's GELU in the GEMM epilogue (big batches)
+  E32Fuse fq;            // what every row pass is told: where the split image goes (query path: fragment-major)
+  fq.frag = query;
+  // one projection: the tile kernels over the [hi | lo | hi] rows, or the query path's weight stream over the fragment images
+#define E32_PROJ(XS, W3, WQ, NN, KK, MAXP)                                                                       \
+  (query ? e32_skinny_gemm(XS, WQ, P, M, NN, KK, &parts, hs) : rarc_gemm_f16_f32out_parts(XS, W3, P, M, NN, 3 * (KK), MAXP, &parts, hs))
   for (int l = 0; l < model->n_layers; ++l) {
     const RarcEnc32Layer& Ly = model->layers[l];
     // fused q|k|v projection; its scales and bias are applied by the attention kernel's loads
     int parts = 1;   // (small batches: split-K into partial slabs that the consumer — attention loads, epilogue kernels — sums)
-    if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.qkv_w3, P, M, 3 * H, 3 * H, max_parts_qkv, &parts, hs)) != RARC_OK) return rc;
+    if ((rc = E32_PROJ(xs, Ly.qkv_w3, Ly.qkv_wq, 3 * H, H, max_parts_qkv)) != RARC_OK) return rc;
     const int qkv_parts = parts;
 #define E32_ATTN_LAUNCH(DHV, RELV)                                                                                     \
     hipLaunchKernelGGL((rarc_e32_attention_kernel<DHV, RELV>), dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw, \
@@ -875,11 +1046,11 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
 #undef E32_ATTN_LAUNCH
     RARC_HIP_CHECK(hipGetLastError());
     const bool fuse_gelu = fuse_shape && Ly.f1_colmax != nullptr;
-    E32Fuse fz2;
+    E32Fuse fz2 = fq;
     if (fuse_gelu) { fz2.colmax = Ly.f1_colmax; fz2.k = H; fz2.sg_out = sg; fz2.sg_rows = (size_t)M; }
-    if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs))) return rc;
+    if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs, 1, fq))) return rc;
     // attention output projection -> x = LayerNorm(proj + x)
-    if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.o_w3, P, M, H, 3 * H, max_parts, &parts, hs)) != RARC_OK) return rc;
+    if ((rc = E32_PROJ(xs, Ly.o_w3, Ly.o_wq, H, H, max_parts)) != RARC_OK) return rc;
     if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs, parts, fz2))) return rc;
     // FFN: the first projection with bias + GELU + split fused into its epilogue where the shape allows (big batches),
     // else the fp32 product and a row pass
@@ -889,12 +1060,13 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
         return rc == 1 ? RARC_E_INVALID : rc;   // (the shape was asked about above)
       ra_f2 = sg + M;
     } else {
-      if ((rc = rarc_gemm_f16_f32out_parts(xs, Ly.f1_w3, P, M, I, 3 * H, max_parts_i, &parts, hs)) != RARC_OK) return rc;
-      if ((rc = e32_epi<1>(P, ra_a, Ly.f1_rw, Ly.f1_b, nullptr, nullptr, nullptr, 0.f, M, I, nullptr, mids, ra_b, hs, parts))) return rc;
+      if ((rc = E32_PROJ(xs, Ly.f1_w3, Ly.f1_wq, I, H, max_parts_i)) != RARC_OK) return rc;
+      if ((rc = e32_epi<1>(P, ra_a, Ly.f1_rw, Ly.f1_b, nullptr, nullptr, nullptr, 0.f, M, I, nullptr, mids, ra_b, hs, parts, fq))) return rc;
     }
-    if ((rc = rarc_gemm_f16_f32out_parts(mids, Ly.f2_w3, P, M, H, 3 * I, max_parts, &parts, hs)) != RARC_OK) return rc;
-    if ((rc = e32_epi<2>(P, ra_f2, Ly.f2_rw, Ly.f2_b, x, Ly.ln2_g, Ly.ln2_b, eps, M, H, x, xs, ra_a, hs, parts))) return rc;
+    if ((rc = E32_PROJ(mids, Ly.f2_w3, Ly.f2_wq, H, I, max_parts)) != RARC_OK) return rc;
+    if ((rc = e32_epi<2>(P, ra_f2, Ly.f2_rw, Ly.f2_b, x, Ly.ln2_g, Ly.ln2_b, eps, M, H, x, xs, ra_a, hs, parts, fq))) return rc;
   }
+#undef E32_PROJ
   hipLaunchKernelGGL(rarc_e32_pool_kernel, dim3(n_seq), dim3(256), 0, hs, x, d_lens, seq_len, H, (normalize & 2) ? 1 : 0,
                      normalize & 1, d_out);
   RARC_HIP_CHECK(hipGetLastError());

@@ -114,7 +114,7 @@ class HipBertEncoder:
     a 1e-3-class approximation — for callers who would pass `model_kwargs={"torch_dtype": float16}`."""
 
     def __init__(self, state_dict: Dict[str, "np.ndarray"], num_heads: int, layer_norm_eps: float = 1e-12,
-                 device: int = 0, pooling: str = "cls", precision: str = "fp32"):
+                 device: int = 0, pooling: str = "cls", precision: str = "fp32", query_path: bool = True):
         import torch
 
         if not torch.cuda.is_available():
@@ -180,6 +180,10 @@ class HipBertEncoder:
                 lay["f1_colmax"] = torch.cat([lay["f1_w"].abs().amax(dim=0), lay["f1_b"].abs().amax().reshape(1)]).float().contiguous()
                 for nm in ("qkv", "o", "f1", "f2"):     # fp32 [n][k] -> split image fp16 [n][3k] + inverse row scales
                     lay[nm + "_w3"], lay[nm + "_rw"] = self._split_weight(lay.pop(nm + "_w"))
+                    # ... and the QUERY PATH's image of the same split weight (fragment-major [hi | lo], 4 bytes per
+                    # parameter): forwards of 32 / 64 / 128 tokens — a single embed_query — stream these instead of
+                    # running the 128 x 128 tile kernels (csrc/encoder_f32.hip, "The QUERY PATH")
+                    lay[nm + "_wq"] = self._pack_query_weight(lay[nm + "_w3"]) if query_path else None
             self.layers.append(lay)
             i += 1
         if not self.layers:
@@ -193,7 +197,8 @@ class HipBertEncoder:
         # host-side table of device pointers handed to rarc_enc_forward (tensors above keep the memory alive)
         LayerT, ModelT = (B.Enc32Layer, B.Enc32Model) if precision == "fp32" else (B.EncLayer, B.EncModel)
         self._layer_tab = (LayerT * len(self.layers))(*[
-            LayerT(**{k: v.data_ptr() for k, v in w.items()}) for w in self.layers])
+            LayerT(**{k: (None if v is None else v.data_ptr()) for k, v in w.items()}) for w in self.layers])
+        self.query_path = bool(query_path) and precision == "fp32"
         self.rel_bias, rel_span = None, 0
         if mp:   # [heads][2*span - 1] fp32: entry [h][key - query + span - 1] (csrc: added to the scaled scores)
             rel_span = min(self.max_pos, 512)
@@ -219,6 +224,17 @@ class HipBertEncoder:
                                                      t.cuda.current_stream(self.device).cuda_stream), "rarc_enc32_split_weight")
             t.cuda.current_stream(self.device).synchronize()     # w32 is released when this returns
         return w3, rw
+
+    def _pack_query_weight(self, w3):
+        t = self.torch
+        n, k = int(w3.shape[0]), int(w3.shape[1]) // 3
+        with t.cuda.device(self.device):
+            wq = t.empty(n * k * 2, dtype=t.float16, device=self.device)
+            B.check(self.lib.rarc_enc32_pack_query_weight(w3.data_ptr(), n, k, wq.data_ptr(),
+                                                          t.cuda.current_stream(self.device).cuda_stream), "rarc_enc32_pack_query_weight")
+        return wq
+
+    QUERY_PATH_TOKENS = (32, 64, 128)    # padded token counts the query path takes (RarcEnc32Layer.*_wq, include/rarc.h)
 
     def forward(self, input_ids, lengths=None, normalize: bool = True, non_blocking: bool = False):
         """`non_blocking`: the ids travel from PINNED host memory and the call returns as soon as the forward is enqueued
@@ -247,6 +263,10 @@ class HipBertEncoder:
             L = L32
         step = 128 // math.gcd(L, 128)
         n_pad = -(-n_seq // step) * step
+        if self.query_path and n_seq * L <= 128:
+            # the query path: 32 / 64 / 128 padded tokens — one 7-token query runs 32 tokens, not 4 x 32
+            fit = next((m for m in self.QUERY_PATH_TOKENS if m >= n_seq * L and m % L == 0), None)   # (none for 96 tokens)
+            n_pad = fit // L if fit else n_pad
         if n_pad != n_seq:
             ids = np.concatenate([ids, np.zeros((n_pad - n_seq, L), np.int32)])
             lens = np.concatenate([lens, np.ones(n_pad - n_seq, np.int32)])
@@ -282,8 +302,10 @@ class HipBertEncoder:
             raise ValueError("forward_device takes int32 device tensors [n_seq][seq_len], [n_seq]")
         n_seq, L = d_ids.shape
         M = n_seq * L
-        if M == 0 or M % 128 or L > min(self.max_pos, 512) or d_lens.shape != (n_seq,):
-            raise ValueError("n_seq * seq_len must be a positive multiple of 128 and seq_len within the position table")
+        if M == 0 or (M % 128 and not (self.query_path and M in self.QUERY_PATH_TOKENS)) or L > min(self.max_pos, 512) \
+                or d_lens.shape != (n_seq,):
+            raise ValueError("n_seq * seq_len must be a positive multiple of 128 (or 32 / 64 tokens with the query path) and "
+                             "seq_len within the position table")
         with t.cuda.device(self.device):
             st = t.cuda.current_stream(self.device).cuda_stream
             need = int(self._ws_bytes(self.hidden, self.inter, M))

@@ -44,7 +44,8 @@ class EncModel(ctypes.Structure):
 class Enc32Layer(ctypes.Structure):
     """RarcEnc32Layer (include/rarc.h): split fp16 weight images + fp32 scales / biases / LayerNorm of one layer."""
     _fields_ = [(n, c_void_p) for n in ("qkv_w3", "qkv_rw", "qkv_b", "o_w3", "o_rw", "o_b", "ln1_g", "ln1_b", "f1_w3", "f1_rw",
-                                        "f1_b", "f2_w3", "f2_rw", "f2_b", "ln2_g", "ln2_b", "f1_colmax")]
+                                        "f1_b", "f2_w3", "f2_rw", "f2_b", "ln2_g", "ln2_b", "f1_colmax",
+                                        "qkv_wq", "o_wq", "f1_wq", "f2_wq")]
 
 
 class Enc32Model(ctypes.Structure):
@@ -149,6 +150,7 @@ SIGNATURES = {
     "rarc_enc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                  c_void_p]),
     "rarc_enc32_split_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_enc32_pack_query_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc32_split_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rarc_enc32_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rarc_enc32_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

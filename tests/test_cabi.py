@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     lib = B.load_library()
     for name in _declared():
         assert hasattr(lib, name), f"{name} missing from librarc_hip.so"
-    assert lib.rarc_version() == 501
+    assert lib.rarc_version() == 600
     assert lib.rarc_padded_dim(1) == 128 and lib.rarc_padded_dim(768) == 768 and lib.rarc_padded_dim(769) == 896
     assert lib.rarc_search_workspace_bytes(16384) > 256 * 16384 * 8
 
