@@ -787,13 +787,24 @@ __global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restr
 // the fp32 accumulator; only the GROUPING of the k range differs from the tile kernels' (slices of KR·16 here), i.e. the
 // two forwards differ by fp32 summation order, not by method (tests/test_gpu_encoder_query.py bounds it).
 // ------------------------------------------------------------------------------------------
-template <int MT, int KR>   // MT: 32-token blocks (M = 32·MT), KR: k steps (of 16) per wave
-__global__ __launch_bounds__(256) void rarc_e32_skinny_gemm_kernel(const half_t* __restrict__ wq, const half_t* __restrict__ xq,
-                                                                   float* __restrict__ P, int N, int KS, int M) {
+// EPI 1 (FFN1): the whole k range inside ONE workgroup of WAVES waves (no partial slabs), and the row pass that used to follow —
+// bias + GELU + split, a launch of its own on 32 workgroups — is this kernel's epilogue: gelu(acc·ra·rw + b)·sg -> (hi, lo) ->
+// the fragment-major image FFN2 streams.  sg[m] is the power-of-two scale from the BOUND the LayerNorm pass in front of FFN1
+// computes (E32Fuse.colmax: sum_k |x_k| max_j |W1[j][k]| + max_j |b1[j]|  >=  every |gelu(.)| of the row), as for the tile
+// kernels' fused FFN1 (rarc_gemm256_f16_kernel<5>): no pass over the finished row is needed to know it.
+struct E32SkinnyEpi {
+  const float *ra = nullptr, *rw = nullptr, *bias = nullptr, *sg = nullptr;
+  half_t* outq = nullptr;
+};
+
+template <int MT, int KR, int WAVES, int EPI>   // MT: 32-token blocks (M = 32·MT), KR: k steps (of 16) per wave
+__global__ __launch_bounds__(WAVES * 64) void rarc_e32_skinny_gemm_kernel(const half_t* __restrict__ wq,
+                                                                          const half_t* __restrict__ xq, float* __restrict__ P,
+                                                                          int N, int KS, int M, const E32SkinnyEpi ep) {
   constexpr int TS = 36;   // floats per token row of a wave's tile in LDS (32 + 4: the rows start on different banks)
-  __shared__ __attribute__((aligned(16))) float red[4][32 * TS];
+  __shared__ __attribute__((aligned(16))) float red[WAVES][32 * TS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nb = blockIdx.x, ks0 = (blockIdx.y * 4 + wave) * KR;
+  const int nb = blockIdx.x, ks0 = (blockIdx.y * WAVES + wave) * KR;
   f32x16 acc[MT];
 #pragma unroll
   for (int mb = 0; mb < MT; ++mb) acc[mb] = (f32x16){0};
@@ -840,12 +851,30 @@ __global__ __launch_bounds__(256) void rarc_e32_skinny_gemm_kernel(const half_t*
       *(float4*)&red[wave][tok * TS + 8 * g + 4 * h] =
           make_float4(acc[mb][4 * g], acc[mb][4 * g + 1], acc[mb][4 * g + 2], acc[mb][4 * g + 3]);
     __syncthreads();
-    const float4 a = *(const float4*)&red[0][tr * TS + 4 * c4], b = *(const float4*)&red[1][tr * TS + 4 * c4],
-                 c = *(const float4*)&red[2][tr * TS + 4 * c4], d = *(const float4*)&red[3][tr * TS + 4 * c4];
-    float4 o;
-    o.x = ((a.x + b.x) + c.x) + d.x; o.y = ((a.y + b.y) + c.y) + d.y;
-    o.z = ((a.z + b.z) + c.z) + d.z; o.w = ((a.w + b.w) + c.w) + d.w;
-    *(float4*)(P + ((size_t)blockIdx.y * M + mb * 32 + tr) * N + nb * 32 + 4 * c4) = o;
+    if (threadIdx.x < 256) {
+      float4 o = *(const float4*)&red[0][tr * TS + 4 * c4];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) {     // wave order: the sum does not depend on which wave finished first
+        const float4 a = *(const float4*)&red[w][tr * TS + 4 * c4];
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+      }
+      if (EPI == 0) {
+        *(float4*)(P + ((size_t)blockIdx.y * M + mb * 32 + tr) * N + nb * 32 + 4 * c4) = o;
+      } else {
+        const size_t m = (size_t)mb * 32 + tr;
+        const int n = nb * 32 + 4 * c4;
+        const float ram = ep.ra[m], sgm = ep.sg[m];
+        const float4 w4 = *(const float4*)(ep.rw + n), b4 = *(const float4*)(ep.bias + n);
+        // (ra, rw, sg are powers of two: exact; the bias add rounds once, as in x·Wᵀ + b — rarc_e32_epi_kernel<., 1>'s arithmetic)
+        const float4 g4 = make_float4(e32_gelu(o.x * ram * w4.x + b4.x) * sgm, e32_gelu(o.y * ram * w4.y + b4.y) * sgm,
+                                      e32_gelu(o.z * ram * w4.z + b4.z) * sgm, e32_gelu(o.w * ram * w4.w + b4.w) * sgm);
+        half4_t hi, lo;
+        e32_split4(g4, 1.f, hi, lo);
+        half_t* dst = ep.outq + e32_frag_offset(m, n, N);
+        *(half4_t*)dst = hi;
+        *(half4_t*)(dst + 512) = lo;
+      }
+    }
   }
 }
 
@@ -888,11 +917,34 @@ static int e32_skinny_gemm(const uint16_t* xq, const uint16_t* wq, float* P, int
                "fp32-class query path: product %d x %d x %d not supported", m, n, k);
   *parts = S;
   const dim3 grid(nb, S);
+  const E32SkinnyEpi none;
 #define E32Q_LAUNCH(MTV, KRV)                                                                                          \
-  hipLaunchKernelGGL((rarc_e32_skinny_gemm_kernel<MTV, KRV>), grid, dim3(256), 0, s, (const half_t*)wq, (const half_t*)xq, P, n, KS, m)
+  hipLaunchKernelGGL((rarc_e32_skinny_gemm_kernel<MTV, KRV, 4, 0>), grid, dim3(256), 0, s, (const half_t*)wq, (const half_t*)xq, P, n, KS, m, none)
   if (MT == 1) { if (kr == 8) E32Q_LAUNCH(1, 8); else if (kr == 4) E32Q_LAUNCH(1, 4); else E32Q_LAUNCH(1, 2); }
   else if (MT == 2) { if (kr == 8) E32Q_LAUNCH(2, 8); else if (kr == 4) E32Q_LAUNCH(2, 4); else E32Q_LAUNCH(2, 2); }
   else { if (kr == 4) E32Q_LAUNCH(4, 4); else E32Q_LAUNCH(4, 2); }
+#undef E32Q_LAUNCH
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+// FFN1 of the query path with bias + GELU + split as the product's epilogue (EPI 1): needs the whole k range in one
+// workgroup of eight waves with all loads in flight — k <= 1024 at 32 / 64 tokens (KR 8), k <= 512 at 128 tokens (KR 4).
+static bool e32_skinny_gelu_takes(int m, int k) {
+  const char* e = getenv("RARC_E32Q_FUSE_GELU");   // (read per call: tests switch it between forwards)
+  if (e && atoi(e) == 0) return false;
+  const int KS = k / 16, MT = m / 32;
+  return MT == 4 ? KS <= 32 : KS <= 64;
+}
+static int e32_skinny_gemm_gelu(const uint16_t* xq, const uint16_t* wq, const float* ra, const float* rw, const float* bias,
+                                const float* sg, uint16_t* outq, int m, int n, int k, hipStream_t s) {
+  const int KS = k / 16, nb = n / 32, MT = m / 32;
+  E32SkinnyEpi ep;
+  ep.ra = ra; ep.rw = rw; ep.bias = bias; ep.sg = sg; ep.outq = (half_t*)outq;
+#define E32Q_LAUNCH(MTV, KRV)                                                                                          \
+  hipLaunchKernelGGL((rarc_e32_skinny_gemm_kernel<MTV, KRV, 8, 1>), dim3(nb, 1), dim3(512), 0, s, (const half_t*)wq, (const half_t*)xq, \
+                     (float*)nullptr, n, KS, m, ep)
+  if (MT == 1) E32Q_LAUNCH(1, 8); else if (MT == 2) E32Q_LAUNCH(2, 8); else E32Q_LAUNCH(4, 4);
 #undef E32Q_LAUNCH
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
@@ -1014,7 +1066,8 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   // head_dim 64: attention on the fp16 MFMA over split operands (round 4); RARC_E32_ATTN=mfma32 keeps the fp32-MFMA kernel (A/B)
   const char* attn_env = getenv("RARC_E32_ATTN");   // (read per call: tests switch it between forwards)
   const bool split_attention = !(attn_env && !strcmp(attn_env, "mfma32"));
-  const bool fuse_shape = !query && rarc_gemm_f16_gelu_split_takes(M, I, 3 * H);   // FFN1's GELU in the GEMM epilogue (big batches)
+  // FFN1's GELU in the GEMM epilogue: big batches (tile kernels), and the query path's weight stream
+  const bool fuse_shape = query ? e32_skinny_gelu_takes(M, H) : rarc_gemm_f16_gelu_split_takes(M, I, 3 * H);
   E32Fuse fq;            // what every row pass is told: where the split image goes (query path: fragment-major)
   fq.frag = query;
   // one projection: the tile kernels over the [hi | lo | hi] rows, or the query path's weight stream over the fragment images
@@ -1055,7 +1108,10 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     // FFN: the first projection with bias + GELU + split fused into its epilogue where the shape allows (big batches),
     // else the fp32 product and a row pass
     const float* ra_f2 = ra_b;
-    if (fuse_gelu) {
+    if (fuse_gelu && query) {
+      if ((rc = e32_skinny_gemm_gelu(xs, Ly.f1_wq, ra_a, Ly.f1_rw, Ly.f1_b, sg, mids, M, I, H, hs)) != RARC_OK) return rc;
+      ra_f2 = sg + M;
+    } else if (fuse_gelu) {
       if ((rc = rarc_gemm_f16_gelu_split(xs, Ly.f1_w3, ra_a, Ly.f1_rw, Ly.f1_b, sg, mids, M, I, 3 * H, hs)) != RARC_OK)
         return rc == 1 ? RARC_E_INVALID : rc;   // (the shape was asked about above)
       ra_f2 = sg + M;
