@@ -279,6 +279,38 @@ int rarc_search_f32(const float* d_corpus_f32, const uint16_t* d_image_f16, int6
                     const float* d_qmeta, const void* d_qblock, int nq, int k, int kprime, int64_t id_base,
                     float bin_lo, float bin_hi, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_status,
                     void* d_workspace, size_t workspace_bytes, int cand_cap, void* stream);
+/*
+ * ABI 600 — one batch in one call: rarc_prep_queries + the rarc_search_* of the row format, i.e. the whole of
+ *   VectorStore_Faiss.py:258-263 (`np.array([embedding]).astype(float32)`, `_normalize_vectors`, `index.search`)
+ * for up to 256 queries, with what the two-call form needs a launch each for folded into the kernels that run anyway:
+ *   d_status   RARC_MAX_QUERIES + 1 words; ZEROED by the query-prep kernel (the two-call form expects zeros from its caller)
+ *   flag_host  pinned host word or NULL: zeroed by the query-prep kernel and set non-zero by the finalize kernel when any query
+ *              is flagged — what a host otherwise copies out of d_status[RARC_MAX_QUERIES] behind the search; read it after an
+ *              event recorded behind this call has completed
+ *   gate_event hipEvent_t or NULL: the SCAN waits for it, the query prep and the seed pass in front of the scan do not.  Two
+ *              search contexts (each its own query block, workspace and stream) that gate their scans on each other's
+ *              completion run one batch's prep / seed under the other's finalize instead of behind it (config 2: 5 % per batch).
+ * row_format 0: fp16 rows (d_aux NULL) · 1: fp8 rows, d_aux = float row scales · 2: fp32 rows, d_aux = their fp16 image ·
+ *            3: fp16 rows, d_aux = int8 shadow image.  Everything else as in rarc_prep_queries / rarc_search_*.
+ */
+typedef struct RarcSearchBatch {
+  const void* d_rows; const void* d_aux; int row_format; int64_t n_rows; int d_pad; const float* d_qmeta;
+  const float* d_queries; int64_t ld_queries; int nq; int d; int normalize; float corpus_max_norm; void* d_qblock;
+  int k, kprime; int64_t id_base; float bin_lo, bin_hi;
+  int64_t* d_out_ids; float* d_out_scores; uint32_t* d_status; uint32_t* flag_host;
+  void* d_workspace; size_t workspace_bytes; int cand_cap;
+  void* gate_event;
+} RarcSearchBatch;
+int rarc_search_batch(const RarcSearchBatch* batch, void* stream);
+
+/*
+ * Measurement helper (ABI 600): stream n_bytes of device memory through every CU once (16-byte loads, eight in flight per lane,
+ * one persistent workgroup per CU) and return nothing but a checksum — the READ ceiling of this part's HBM as a kernel
+ * of the scan's shape can reach it, which bench.py reports next to the nominal 8 TB/s ("report against both").
+ * d_sink: 8 bytes of device memory.  Time it with events on `stream`.
+ */
+int rarc_stream_read(const void* d_src, size_t n_bytes, void* d_sink, void* stream);
+
 int rarc_repair_f32(const float* d_corpus_f32, int64_t n_rows, int d_pad, const void* d_qblock, int q, int k,
                     int64_t id_base, int64_t* d_out_ids, float* d_out_scores, uint32_t* d_found, void* d_workspace,
                     size_t workspace_bytes, void* stream);

@@ -90,6 +90,7 @@ struct FinParams {
   int64_t* out_ids;
   float* out_scores;
   uint32_t* status;
+  uint32_t* flag_host;   // pinned host word (or null): set non-zero when a query is flagged (RarcLaunchExtras)
 };
 
 constexpr int FIN_SURV = 4096;  // survivors of the final-threshold compaction that get ranked
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(FIN_THREADS) void rarc_finalize_kernel(const FinPar
     if (st) {  // one word the host can poll instead of scanning d_status
       atomicOr(&p.flags[1], st);
       atomicOr(&p.status[RARC_MAX_QUERIES], st);
+      if (p.flag_host) __hip_atomic_store(p.flag_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -232,6 +234,7 @@ int rarc_finalize_launch(const uint16_t* corpus, int d_pad, const float* q32, co
   p.out_ids = out_ids;
   p.out_scores = out_scores;
   p.status = status;
+  p.flag_host = rarc_launch_extras().flag_host;
   hipLaunchKernelGGL(rarc_finalize_kernel, dim3(nq), dim3(FIN_THREADS), 0, s, p);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
@@ -286,6 +289,7 @@ struct Fin8Params {
                             // thresholds live under an eps16 margin — too high for the int8 stage that follows: thr[q] is
                             // SET to L - eps8 (no k-th score yet: lowered by eps8 - eps16, which is valid too)
   const float* eps16;       // hybrid search: some candidates carry fp16 scores (error <= eps16[q]); null otherwise
+  uint32_t* flag_host;      // pinned host word (or null): set non-zero when a query is flagged (RarcLaunchExtras)
 };
 
 __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fin8Params p) {
@@ -695,6 +699,7 @@ __global__ __launch_bounds__(FIN8_THREADS) void rarc_finalize_q8_kernel(const Fi
     if (st) {
       atomicOr(&p.flags[1], st);
       atomicOr(&p.status[RARC_MAX_QUERIES], st);
+      if (p.flag_host) __hip_atomic_store(p.flag_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -732,6 +737,7 @@ int rarc_finalize_q8_launch(const void* corpus, const float* rowscale, int fmt, 
   p.tighten_thr = tighten ? (uint32_t*)ws.thr : nullptr;
   p.tighten_mode = tighten;
   p.eps16 = eps16;
+  p.flag_host = tighten ? nullptr : rarc_launch_extras().flag_host;
   // 8 waves stage 8 rows each up to 1536 bytes per row (97 KB); up to 3072 bytes: 4 waves; fp32 rows of 1024: 2 waves
   const size_t rbytes = (size_t)d_pad * (fmt == 2 ? 4 : (fmt ? 1 : 2));
   const int threads = rbytes <= 1536 ? FIN8_THREADS : (rbytes <= 3072 ? FIN8_THREADS / 2 : FIN8_THREADS / 4);

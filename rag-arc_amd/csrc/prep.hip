@@ -206,8 +206,14 @@ __global__ __launch_bounds__(256) void rarc_prep_queries_kernel(const float* in,
                                                                 int d_pad, int normalize, float corpus_max_norm,
                                                                 const float* qmeta, float* q32, half_t* q16,
                                                                 int8_t* q8, float* eps, float* eps8, float* qinv,
-                                                                float* hq, float* floor) {
+                                                                float* hq, float* floor, uint32_t* status_zero,
+                                                                uint32_t* flag_host) {
   __shared__ float row[PREP_MAX_D];
+  if (blockIdx.x == 0) {   // the search's status words start at zero (rarc_search_batch: no fill launch in front of the batch)
+    if (status_zero)
+      for (int i = threadIdx.x; i <= RARC_MAX_QUERIES; i += 256) status_zero[i] = 0u;
+    if (flag_host && threadIdx.x == 0) __hip_atomic_store(flag_host, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   __shared__ float s_nr;
   __shared__ uint32_t s_amax;
   __shared__ double s_red[4][4];
@@ -496,7 +502,8 @@ extern "C" int rarc_prep_queries(const float* d_in, int64_t ld_in, int nq, int d
   const RarcQb qb = rarc_qb_carve(d_qblock, d_pad);
   hipLaunchKernelGGL(rarc_prep_queries_kernel, dim3(RARC_MAX_QUERIES), dim3(256), 0, (hipStream_t)stream,
                      d_in, ld_in, nq, d, d_pad, normalize, corpus_max_norm, d_qmeta, qb.q32, (half_t*)qb.q16,
-                     qb.q8, qb.eps16, qb.eps8, qb.qinv, qb.hq, qb.floor);
+                     qb.q8, qb.eps16, qb.eps8, qb.qinv, qb.hq, qb.floor, rarc_launch_extras().status_zero,
+                     rarc_launch_extras().flag_host);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -536,6 +543,39 @@ extern "C" int rarc_synth_rows_f32(float* d_out_f32, int64_t ld_out, int d, int6
   if (n_rows == 0) return RARC_OK;
   hipLaunchKernelGGL(rarc_synth_kernel<false>, dim3(grid_for(n_rows, 4, 8192)), dim3(256), 0, (hipStream_t)stream,
                      (void*)d_out_f32, ld_out, d, d, first_row, n_rows, seed);
+  RARC_HIP_CHECK(hipGetLastError());
+  return RARC_OK;
+}
+
+
+// ---- measurement helper: the read ceiling of this part's HBM (rarc.h: rarc_stream_read) ----------------------------------
+// One persistent workgroup of 512 threads per CU (the scan's shape), every lane keeps eight 16-byte loads in flight over a
+// grid-strided sweep; the xor of everything read goes to d_sink so that nothing is optimised away.
+typedef uint32_t sr_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void rarc_stream_read_kernel(const sr_u32x4* __restrict__ src, size_t n16, unsigned long long* sink) {
+  const size_t stride = (size_t)gridDim.x * 512;
+  size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+  sr_u32x4 acc = {0, 0, 0, 0};
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    sr_u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= v[u];
+  }
+  for (; i < n16; i += stride) acc ^= __builtin_nontemporal_load(src + i);
+  const unsigned long long w = ((unsigned long long)(acc.x ^ acc.z) << 32) | (acc.y ^ acc.w);
+  if (w == 0x9e3779b97f4a7c15ull) atomicXor(sink, w);   // (practically never: the data decides; keeps the loads alive)
+}
+
+extern "C" int rarc_stream_read(const void* d_src, size_t n_bytes, void* d_sink, void* stream) {
+  RARC_REQUIRE(d_src && d_sink && ((uintptr_t)d_src % 16) == 0, RARC_E_INVALID, "rarc_stream_read: bad arguments");
+  if (n_bytes < 16) return RARC_OK;
+  int dev = 0, cus = 256;
+  RARC_HIP_CHECK(hipGetDevice(&dev));
+  RARC_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  hipLaunchKernelGGL(rarc_stream_read_kernel, dim3(cus), dim3(512), 0, (hipStream_t)stream, (const sr_u32x4*)d_src, n_bytes / 16,
+                     (unsigned long long*)d_sink);
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }

@@ -125,6 +125,11 @@ static bool roctx_ready() {
 void rarc_roctx_push(const char* name) { if (roctx_ready()) g_roctx_push(name); }
 void rarc_roctx_pop() { if (roctx_ready()) g_roctx_pop(); }
 
+RarcLaunchExtras& rarc_launch_extras() {
+  static thread_local RarcLaunchExtras x;
+  return x;
+}
+
 extern "C" int rarc_version(void) { return RARC_BUILD_VERSION; }
 extern "C" const char* rarc_last_error(void) { return g_err; }
 extern "C" int rarc_padded_dim(int d) {
@@ -383,4 +388,43 @@ extern "C" int rarc_topk_merge_packed(const int32_t* d_packed, int n_lists, int 
   RARC_REQUIRE(n_lists >= 1 && nq >= 0 && k >= 1, RARC_E_INVALID, "rarc_topk_merge_packed: bad sizes");
   if (nq == 0) return RARC_OK;
   return rarc_merge_launch((const int64_t*)d_packed, nullptr, n_lists, nq, k, d_out_ids, d_out_scores, (hipStream_t)stream, true);
+}
+
+
+// ---- one batch, one call (ABI 600): query prep + search, status words zeroed by the prep kernel, the any-flag word written
+//      to pinned host memory by the finalize kernel, the scan optionally gated on a neighbouring context's event ----
+extern "C" int rarc_search_batch(const RarcSearchBatch* b, void* stream) {
+  RARC_RANGE();
+  RARC_REQUIRE(b != nullptr, RARC_E_INVALID, "rarc_search_batch: null descriptor");
+  RARC_REQUIRE(b->row_format >= 0 && b->row_format <= 3, RARC_E_INVALID, "rarc_search_batch: row_format %d", b->row_format);
+  RARC_REQUIRE(b->d_status != nullptr, RARC_E_INVALID, "rarc_search_batch: null status");
+  RarcLaunchExtras& x = rarc_launch_extras();
+  struct Clear {   // whatever path returns: the extras are this call's only
+    RarcLaunchExtras& x;
+    ~Clear() { x = RarcLaunchExtras(); }
+  } clear{x};
+  x.status_zero = b->d_status;
+  x.flag_host = b->flag_host;
+  x.gate = (hipEvent_t)b->gate_event;
+  int rc = rarc_prep_queries(b->d_queries, b->ld_queries, b->nq, b->d, b->d_pad, b->normalize, b->corpus_max_norm, b->d_qmeta,
+                             b->d_qblock, stream);
+  if (rc) return rc;
+  switch (b->row_format) {
+    case 0:
+      return rarc_search_f16((const uint16_t*)b->d_rows, b->n_rows, b->d_pad, b->d_qmeta, b->d_qblock, b->nq, b->k, b->kprime,
+                             b->id_base, b->bin_lo, b->bin_hi, b->d_out_ids, b->d_out_scores, b->d_status, b->d_workspace,
+                             b->workspace_bytes, b->cand_cap, stream);
+    case 1:
+      return rarc_search_f8((const uint8_t*)b->d_rows, (const float*)b->d_aux, b->n_rows, b->d_pad, b->d_qmeta, b->d_qblock, b->nq,
+                            b->k, b->kprime, b->id_base, b->bin_lo, b->bin_hi, b->d_out_ids, b->d_out_scores, b->d_status,
+                            b->d_workspace, b->workspace_bytes, b->cand_cap, stream);
+    case 2:
+      return rarc_search_f32((const float*)b->d_rows, (const uint16_t*)b->d_aux, b->n_rows, b->d_pad, b->d_qmeta, b->d_qblock, b->nq,
+                             b->k, b->kprime, b->id_base, b->bin_lo, b->bin_hi, b->d_out_ids, b->d_out_scores, b->d_status,
+                             b->d_workspace, b->workspace_bytes, b->cand_cap, stream);
+    default:
+      return rarc_search_f16_shadow((const uint16_t*)b->d_rows, (const int8_t*)b->d_aux, b->n_rows, b->d_pad, b->d_qmeta, b->d_qblock,
+                                    b->nq, b->k, b->kprime, b->id_base, b->bin_lo, b->bin_hi, b->d_out_ids, b->d_out_scores,
+                                    b->d_status, b->d_workspace, b->workspace_bytes, b->cand_cap, stream);
+  }
 }

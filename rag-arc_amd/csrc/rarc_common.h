@@ -269,6 +269,28 @@ __host__ __device__ static inline float rarc_canon_tree(const float a[8]) {
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
 
+// What rarc_search_batch (rarc_api.hip, ABI 600) hands to the launchers underneath without widening every signature on the way:
+// set for the duration of ONE call on the calling thread, cleared before it returns.
+struct RarcLaunchExtras {
+  uint32_t* status_zero = nullptr;  // device, RARC_MAX_QUERIES + 1 words: zeroed by the query-prep kernel (no fill launch in front)
+  uint32_t* flag_host = nullptr;    // pinned host word: zeroed by the query-prep kernel, set non-zero by the finalize kernel of a
+                                    // flagged query (no copy launch behind the search; visible to the host once the stream's
+                                    // next event completes: a kernel's end releases its stores to system scope)
+  hipEvent_t gate = nullptr;        // the first SCAN launch waits for this event (the query prep and the seed pass in front
+                                    // of it do not): a neighbouring search context's finalize, see engine.py _PipelinedPair
+};
+RarcLaunchExtras& rarc_launch_extras();   // thread-local (rarc_api.hip)
+// the scan launchers call this right before their first scan kernel
+inline int rarc_gate_scan(hipStream_t s) {
+  RarcLaunchExtras& x = rarc_launch_extras();
+  if (x.gate) {
+    hipEvent_t g = x.gate;
+    x.gate = nullptr;
+    if (hipStreamWaitEvent(s, g, 0) != hipSuccess) return -2;
+  }
+  return 0;
+}
+
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));

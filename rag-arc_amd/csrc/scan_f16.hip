@@ -952,6 +952,7 @@ int rarc_scan_f16_launch(const uint16_t* corpus, int64_t n_rows, int d_pad, cons
   if ((uint32_t)grid > p.n_tiles) grid = (int)p.n_tiles;
   *grid_out = grid;
   if (p.n_tiles == 0) return RARC_OK;
+  RARC_REQUIRE(rarc_gate_scan(s) == 0, RARC_E_HIP, "rarc_scan_f16: hipStreamWaitEvent on the gate event failed");
 #define SCAN_CALL(DD) launch_scan<DD>(p, grid, s)
   RARC_DISPATCH_D(SCAN_CALL)
   return rc;

@@ -924,6 +924,7 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
                             eps8, ws, s, n_cuts ? (int64_t)cuts[0] * 32 : 0, floor);
   if (rc) return rc;
   if (p.n_tiles == 0) return RARC_OK;  // (the seed pass above still initialised thresholds, histograms and flags)
+  RARC_REQUIRE(rarc_gate_scan(s) == 0, RARC_E_HIP, "rarc_scan_q8: hipStreamWaitEvent on the gate event failed");
   uint32_t begin = 0;
   // Hybrid search of a SMALL shard (fp16 rows, no cascade cut: below ~2M rows).  There the int8 scan's weakness is its
   // start: the 4096-row sample puts the threshold two int8 error bounds under a k-th best score that is itself far below

@@ -56,6 +56,18 @@ class Enc32Model(ctypes.Structure):
                 ("rel_bias", c_void_p), ("rel_span", c_int)]
 
 
+class SearchBatch(ctypes.Structure):
+    """RarcSearchBatch (include/rarc.h): one batch — query prep + search — in one call."""
+    _fields_ = [("d_rows", c_void_p), ("d_aux", c_void_p), ("row_format", c_int), ("n_rows", c_int64), ("d_pad", c_int),
+                ("d_qmeta", c_void_p),
+                ("d_queries", c_void_p), ("ld_queries", c_int64), ("nq", c_int), ("d", c_int), ("normalize", c_int),
+                ("corpus_max_norm", c_float), ("d_qblock", c_void_p),
+                ("k", c_int), ("kprime", c_int), ("id_base", c_int64), ("bin_lo", c_float), ("bin_hi", c_float),
+                ("d_out_ids", c_void_p), ("d_out_scores", c_void_p), ("d_status", c_void_p), ("flag_host", c_void_p),
+                ("d_workspace", c_void_p), ("workspace_bytes", c_size_t), ("cand_cap", c_int),
+                ("gate_event", c_void_p)]
+
+
 class IoStats(ctypes.Structure):
     """RarcIoStats (include/rarc.h): what a shard-file transfer moved and how fast."""
     _fields_ = [("bytes", c_int64), ("seconds", c_double), ("file_seconds", c_double), ("copy_wait_seconds", c_double),
@@ -150,6 +162,8 @@ SIGNATURES = {
     "rarc_enc_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p,
                                  c_void_p]),
     "rarc_enc32_split_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rarc_search_batch": (c_int, [c_void_p, c_void_p]),
+    "rarc_stream_read": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "rarc_enc32_pack_query_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "rarc_enc32_split_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "rarc_enc32_gemm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -7,6 +7,7 @@ device memory and streams only; all arithmetic happens in the HIP kernels.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import threading
 from typing import Optional, Tuple
@@ -16,6 +17,11 @@ import numpy as np
 from . import binding as B
 
 _ROW_ALIGN = 32  # the scan reads whole 32-row tiles
+# pipelined contexts (FlatIndexF16._pipeline_context): hold a context's scan back until its partner's batch is complete
+# (RarcSearchBatch.gate_event)?  Measured at config 2, 400 steps, same box (tools/r06_gate.sh, profiles/r06_c2_pipeline.txt): one
+# context 0.449 ms per batch, two gated 0.442, two UNGATED 0.423 — a cross-stream event costs ~17 µs from its completion to
+# the waiting kernel's start, where the scan's workgroups simply take each CU as the partner's finalize leaves it.  Off.
+_PIPELINE_GATE = os.environ.get("RARC_PIPELINE_GATE", "0") == "1"
 _IO_RING: dict = {}            # the process's pinned staging ring for shard files (FlatIndexF16._io_staging)
 _IO_LOCK = threading.Lock()    # one shard-file transfer at a time per process: they share the ring
 
@@ -240,6 +246,9 @@ class FlatIndexF16:
         self._cap_eff = 0          # candidate capacity the workspace was allocated for (grows with k)
         self._qbuf = None
         self._version = 0          # bumped by every change of the rows (twin() contexts check it)
+        self._pair = None          # search_async's two pipelined contexts (_pipeline_context)
+        self._partner = None       # a pipelined context: the other one of the pair
+        self._fin_event = None     # ... and the event behind its last batch (the partner's next scan waits for it)
         self._parent = None        # twin(): the index whose rows this search context reads
         self._pins = _PinnedPool()  # pinned staging for answers (shared with the index's twins: copy.copy keeps the object)
         self._flags = _FlagPool()   # pinned status words, one per launch in flight
@@ -742,9 +751,30 @@ class FlatIndexF16:
             other._lock = threading.Lock()
             other._ws, other._qbuf, other._cap_eff = None, None, 0
             other._parent, other._parent_version = self, self._version
+            other._pair, other._partner, other._fin_event = None, None, None
             with t.cuda.device(self.device):
                 other._own_stream = t.cuda.Stream()
         return other
+
+    # the fp16-scan path (small shards: config 2) spends a sixth of a batch in small dependent kernels either side of the scan
+    # — query prep, seed pass, seed threshold in front of it (30 µs), finalize behind it (35 µs) — while the scan itself holds
+    # every CU.  search_async therefore alternates between TWO search contexts of the index (twin(): own query block, workspace
+    # and stream each) whose scans are gated on each other's completion (RarcSearchBatch.gate_event): batch i+1's prep / seed
+    # run under batch i's finalize, its scan starts when that finalize is done.  RARC_PIPELINE=0 keeps one context.
+    PIPELINE_MIN_ROWS = 65536
+
+    def _pipeline_context(self, k: int):
+        if self._parent is not None or self._own_stream is not None or os.environ.get("RARC_PIPELINE", "1") == "0":
+            return None
+        if self._use_q8(k) or self.ntotal < self.PIPELINE_MIN_ROWS:
+            return None
+        pair = self.__dict__.get("_pair")
+        if pair is None or pair[0]._parent_version != self._version:
+            a, b = self.twin(), self.twin()
+            a._partner, b._partner = b, a
+            pair = self._pair = [a, b, 0]
+        pair[2] ^= 1
+        return pair[pair[2]]
 
     def _rows_version(self) -> int:
         """Version of the rows a search reads (a twin reads its parent's)."""
@@ -877,6 +907,9 @@ class FlatIndexF16:
             raise ValueError("k out of range")
         if self._takes_wide_path(k):       # (the wide path runs to completion: its handle is born finished)
             return _FinishedSearch(self, *self.search_device(queries, k))
+        ctx = self._pipeline_context(k)
+        if ctx is not None:
+            return ctx.search_async(queries, k, to_host)
         self._check_twin()
         if self._own_stream is not None and t.cuda.current_stream(self.device) != self._own_stream:
             # a twin: enqueue on its side stream, behind whatever produced the queries on the caller's stream
@@ -897,17 +930,20 @@ class FlatIndexF16:
             h_ids, h_sc = slot.views(nq, k) if to_host else (None, None)
             for s0 in range(0, nq, B.MAX_QUERIES):
                 e0 = min(nq, s0 + B.MAX_QUERIES)
-                status = t.zeros(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)   # this launch's own words
-                self._search_chunk(q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], repair=False, status=status)
+                # this launch's own status words (zeroed by its query-prep kernel) and its one any-flag word in pinned host
+                # memory, written by the finalize kernel itself: no fill launch in front of the batch, no copy launch behind
+                # it.  The event is the batch's own: result() waits for THIS batch only, not for what was enqueued after it
+                status = t.empty(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)
+                flag_h = self._flags.acquire(t)
+                gate = self._partner._fin_event if (self._partner is not None and _PIPELINE_GATE) else None
+                self._search_chunk(q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], repair=False, status=status,
+                                   flag_host=flag_h.data_ptr(), gate=gate.cuda_event if gate is not None else 0)
                 if to_host:
                     h_ids[s0:e0].copy_(out_ids[s0:e0], non_blocking=True)
                     h_sc[s0:e0].copy_(out_sc[s0:e0], non_blocking=True)
-                # the batch's one status word goes to pinned host memory behind the search, with an event of its
-                # own: result() waits for THIS batch only, not for whatever was enqueued after it
-                flag_h = self._flags.acquire(t)
-                flag_h.copy_(status[B.MAX_QUERIES:], non_blocking=True)
                 done = t.cuda.Event()
                 done.record()
+                self._fin_event = done
                 parts.append(PendingSearch(self, q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], flag_h,
                                            status[:e0 - s0], done, stream=t.cuda.current_stream(self.device),
                                            version=self._rows_version(),
@@ -1093,23 +1129,40 @@ class FlatIndexF16:
         bound = float(q.norm(dim=1).max().item()) * max(self.max_norm, 1e-30) * 1.001
         return -bound, bound
 
-    def _search_chunk(self, q, k, out_ids, out_sc, repair, status=None) -> None:
+    def _search_chunk(self, q, k, out_ids, out_sc, repair, status=None, flag_host: int = 0, gate: int = 0) -> None:
+        """One batch of at most 256 queries through rarc_search_batch: query prep + seed + scan + finalize in one foreign
+        call; `status` (257 words) is zeroed by the prep kernel, `flag_host` (address of a pinned word, 0 = none) receives
+        the any-flag word, `gate` (a hipEvent_t, 0 = none) holds the scan back until a neighbouring context has finished."""
         t = self.torch
         ws = self._workspace(k)
         b = self._qbuf
         if status is None:
             status = b["status"]
-            status.zero_()
         nq = q.shape[0]
         stream = self._stream()
-        self._prep(q, k)
         lo, hi = self._bins(q)
         # the int8 path's threshold proof needs the k-th best approximate score, nothing beyond it (its 2·eps8
         # margin is the slack); the fp16 path's certificate wants k' > k candidates
         kp = k if self._use_q8(k) else self.kprime_for(k)
         rows_ptr = self._rows.data_ptr() if self._rows is not None else 0
         qm = self._qmeta.data_ptr() if (self._use_q8(k) and self._qmeta is not None and self.ntotal) else 0
-        self._call_search(rows_ptr, qm, nq, k, kp, lo, hi, out_ids, out_sc, status, ws, stream)
+        norm = 1 if self.metric == "cosine" else 0
+        fmt, aux = 0, 0
+        if self.storage == "f8":
+            fmt, aux = 1, (self._rowscale.data_ptr() if self._rowscale is not None else 0)
+        elif self.storage == "f32":
+            fmt, aux = 2, (self._image16.data_ptr() if self._image16 is not None else 0)
+        elif self.shadow and qm and self._shadow is not None:
+            fmt, aux = 3, self._shadow.data_ptr()
+        if q.stride(1) != 1:
+            q = q.contiguous()
+        batch = B.SearchBatch(rows_ptr, aux, fmt, self.ntotal, self.d_pad, qm,
+                              q.data_ptr(), q.stride(0), nq, self.dim, norm, max(self.max_norm, 1.0) if norm else self.max_norm,
+                              b["qblock"].data_ptr(),
+                              k, kp, self.id_base, lo, hi,
+                              out_ids.data_ptr(), out_sc.data_ptr(), status.data_ptr(), flag_host,
+                              ws.data_ptr(), ws.numel(), self._cap_eff, gate)
+        B.check(self.lib.rarc_search_batch(ctypes.byref(batch), stream), "rarc_search_batch")
         self.last_status = status[:nq]
         if not repair or self.ntotal == 0:
             return
@@ -1294,6 +1347,8 @@ class PendingSearch:
                                             words=[words[i] for i in self.repaired], launched_with=self.cand_cap)
                     stream.synchronize()
             self.index.last_repaired = self.repaired
+            if self.index._parent is not None:      # (a pipelined context of the index the caller holds)
+                self.index._parent.last_repaired = self.repaired
         return self.ids, self.scores
 
     def host_view(self):

@@ -64,7 +64,7 @@ def test_model_structs_match_the_header(tmp_path):
 
     pairs = [("RarcEncLayer", B.EncLayer), ("RarcEncModel", B.EncModel), ("RarcEnc32Layer", B.Enc32Layer),
              ("RarcEnc32Model", B.Enc32Model), ("RarcLmLayer", B.LmLayer), ("RarcLmModel", B.LmModel),
-             ("RarcIoStats", B.IoStats)]
+             ("RarcIoStats", B.IoStats), ("RarcSearchBatch", B.SearchBatch)]
     lines = []
     for cname, cls in pairs:
         lines.append(f'printf("%zu\\n", sizeof({cname}));')
