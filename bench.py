@@ -37,6 +37,52 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA peak (same guide)
+HBM_MEASURED = {"read_GBps": None, "copy_GBps": None}   # this box's ceilings, measured in this process (measure_hbm_peak)
+
+
+def measure_hbm_peak(torch, lib, B, dev, buf_bytes=8 << 30):
+    """report against nominal AND measured.  Two figures of THIS box, in THIS process, timed with events on the
+    current stream: (a) rarc_stream_read — a read-only sweep of 8 GiB by one persistent 512-thread workgroup per CU, eight 16-byte
+    loads in flight per lane: the ceiling of a kernel shaped like the scan; (b) a device-to-device copy of 4 GiB (read + write
+    bytes counted), the guide's 6.3 TB/s figure.  peak_measured = (a)."""
+    free = torch.cuda.mem_get_info(dev)[0]
+    buf_bytes = int(min(buf_bytes, max(1 << 28, free // 4)))
+    buf = torch.empty(buf_bytes, dtype=torch.uint8, device=dev)
+    buf.zero_()
+    sink = torch.zeros(1, dtype=torch.int64, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def best_of(fn, n=5):
+        out = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        return min(out[1:])          # (the first pass pages the buffer in)
+
+    ms_r = best_of(lambda: B.check(lib.rarc_stream_read(buf.data_ptr(), buf_bytes, sink.data_ptr(), st), "rarc_stream_read"))
+    half = buf_bytes // 2
+    ms_c = best_of(lambda: buf[half:2 * half].copy_(buf[:half]))
+    HBM_MEASURED["read_GBps"] = round(buf_bytes / (ms_r * 1e-3) / 1e9, 1)
+    HBM_MEASURED["copy_GBps"] = round(2 * half / (ms_c * 1e-3) / 1e9, 1)
+    del buf
+    torch.cuda.empty_cache()
+    return dict(HBM_MEASURED, bytes=buf_bytes, how="rarc_stream_read over 8 GiB (best of 4 after a warm-up pass); copy = torch "
+                "device-to-device copy of half of it, read + write bytes")
+
+
+def hbm_roofline(achieved_GBps, **extra):
+    """An HBM roofline object: nominal peak and the peak measured on this box (read-only stream), a fraction of each."""
+    out = {"bound": "hbm"}
+    out.update(extra)
+    out.update({"achieved": round(achieved_GBps, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_GBps / HBM_PEAK_GBS, 4)})
+    if HBM_MEASURED["read_GBps"]:
+        out["peak_measured"] = HBM_MEASURED["read_GBps"]
+        out["frac_of_measured"] = round(achieved_GBps / HBM_MEASURED["read_GBps"], 4)
+    return out
 
 
 def parse(argv=None):
@@ -213,12 +259,28 @@ def dry_run(a) -> None:
     dist.barrier()
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    # every rank's shard size, gathered the way a real run's ranks would report them
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([hi - lo], dtype=torch.int64))
     if rank == 0:
         want = torch.arange(0, a.k, dtype=torch.int64)   # the global best k rows are rows 0..k-1 (all on shard 0)
-        print(json.dumps({"metric": "dry run (gloo, no GPU): multi-rank plumbing only", "value": None, "dry_run": True,
-                          "n_gpus": world, "ranks": dist.get_world_size(), "backend": "gloo", "steps": a.steps,
+        ms = float(dt.item()) / max(1, a.steps) * 1e3
+        # the SAME keys a measured line carries (main() below), so that whatever parses SCALE_rNN.json can be rehearsed on it;
+        # value / roofline are null: nothing was measured
+        print(json.dumps({"metric": "queries/sec at fixed (N_corpus, d), exact top-k (ids bit-exact vs CPU oracle)",
+                          "value": None, "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": a.storage, "data": "none (dry run: stand-in local search, gloo, no GPU, no kernel)",
+                          "dry_run": True, "ranks": dist.get_world_size(), "backend": "gloo", "rccl_ranks": 0,
                           "rows_per_gpu": hi - lo, "merged_ids_ok": bool((ids == want).all()),
-                          "ms_per_step": round(float(dt.item()) / max(1, a.steps) * 1e3, 4)}), flush=True)
+                          "config": {"workload": f"DRY RUN of {rows}x{a.dim} row-sharded over {world} ranks, batch {a.batch}, top-{a.k}",
+                                     "n_corpus": rows, "d": a.dim, "batch": a.batch, "k": a.k, "rows_per_gpu": hi - lo,
+                                     "rows_per_rank": [int(x.item()) for x in sizes],
+                                     "exchange_ms_per_step": round(ms, 4),
+                                     "exchange": "one gloo all-gather of (id, score) + merge (the whole step of a dry run)"},
+                          "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                                       "traffic": None},
+                          "cpu_baseline": None}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -367,6 +429,7 @@ def main():
     from rag_arc_amd.hip.sharded import ShardedFlatSearch, shard_range, split_range
 
     lib = B.load_library()
+    measure_hbm_peak(torch, lib, B, dev)      # (every rank: their work stays symmetric; HBM_MEASURED feeds every hbm roofline below)
     d_pad = B.padded_dim(a.dim, 256 if a.storage == "f8" else 128)
     esize = 1 if a.storage == "f8" else 2
     rows = a.rows
@@ -466,11 +529,10 @@ def main():
                        "exchange": (f"pack + one {'RCCL' if a.backend == 'nccl' else a.backend} all-gather of (id, score) + merge") if use_dist else "none (one shard)",
                        "repaired_queries_last_step": flagged,
                        "full_size_check": check},
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": kname, "avg_launch_ms": round(scan_ms, 4),
-                         "algorithmic_bytes_per_launch": int(shard_bytes), "launches_timed": n_l,
-                         "launches_per_scan": launches_per_pass, "scan_ms_per_pass": round(scan_ms * launches_per_pass, 4)},
+            "roofline": hbm_roofline(ach, traffic=traffic, traffic_source=tsrc, kernel=kname, avg_launch_ms=round(scan_ms, 4),
+                                     algorithmic_bytes_per_launch=int(shard_bytes), launches_timed=n_l,
+                                     launches_per_scan=launches_per_pass, scan_ms_per_pass=round(scan_ms * launches_per_pass, 4),
+                                     hbm_measured=dict(HBM_MEASURED)),
         }
 
     # ---- config 2 / 3 (1M x 768, one GPU) and the CPU baseline on the same sample -----------------
@@ -491,10 +553,10 @@ def main():
                             "value": round(a.batch * steps2 / dt2, 1), "unit": "queries/s",
                             "ms_per_step": round(dt2 / steps2 * 1e3, 4), "scan_ms": round(scan2, 4),
                             "scan_GBps": round(bytes2 / (scan2 * 1e-3) / 1e9, 1),
-                            "roofline": {"bound": "hbm", "kernel": k2, "achieved": round(bytes2 / (scan2 * 1e-3) / 1e9, 1),
-                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                         "frac": round(bytes2 / (scan2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                         "mfma_TFLOPs": round(2.0 * a.batch * n2 * a.dim / (scan2 * 1e-3) / 1e12, 1)}}
+                            "pipeline": "two search contexts on two streams (engine.py _pipeline_context): a batch's prep / seed run under the previous batch's finalize",
+                            "roofline": hbm_roofline(bytes2 / (scan2 * 1e-3) / 1e9, kernel=k2,
+                                                     mfma_TFLOPs=round(2.0 * a.batch * n2 * a.dim / (scan2 * 1e-3) / 1e12, 1),
+                                                     end_to_end_frac=round(bytes2 / (dt2 / steps2) / 1e9 / HBM_PEAK_GBS, 4))}
         if not a.no_c3:
             result["c3"] = leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, ids2, n2, a, steps2, w2, passes_per_step, bytes2, k2,
                                   dev, local_rank)
@@ -677,8 +739,7 @@ def leg_c3(torch, dist, lib, B, ctypes, np, idx2, q, dense_ids, n2, a, steps, wa
         lib, B, ctypes, lambda: timed_loop(torch, dist, lambda: idx2.search_async(q, K), end_seeded, steps, warmup, False),
         8 * (steps + warmup) * passes_per_step + 16)
     scan = tot / max(1, steps + warmup)
-    scan_roof = {"bound": "hbm", "kernel": kname, "achieved": round(scan_bytes / (scan * 1e-3) / 1e9, 1),
-                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scan_bytes / (scan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    scan_roof = hbm_roofline(scan_bytes / (scan * 1e-3) / 1e9, kernel=kname)
     no_lm = {"workload": "the same loop with seeded fp16 (no, yes) logits in place of the LM forward: scan -> rerank score->order -> RRF",
              "value": round(nq * steps / dt0, 1), "unit": "queries/s", "ms_per_step": round(dt0 / steps * 1e3, 4),
              "scan_ms": round(scan, 4), "roofline": scan_roof}
@@ -842,7 +903,14 @@ def cpu_baseline_lm(torch, np, lm, sd_host, dense_ids, qidx_all, V, no_id, yes_i
 
 
 def cpu_baseline(np, idx2, q, ids2, sc2, n2, a):
-    """The CPU oracle (a port: faiss is absent) on the host cores, config 2 in full, + parity of the GPU answer."""
+    """The CPU baseline as SURVEY.md 8(d) defines it, config 2 in full, on this box's host cores, + parity of the GPU answer.
+    faiss is not on the box, so both figures are restatements (kind "port"):
+      * `value` / `nq1_value`: numpy fp32 — normalised queries, `Q @ D_chunkᵀ` through the host's BLAS (all its threads), top-k
+        by argpartition (oracle/cpu_ref.flat_search_blas_f32): batched B = 256 and the reference's own one-query-per-call
+        pattern (VectorStore_Faiss.py:258-263).  This is the sgemm-backed shape faiss's IndexFlatIP has for nq >= 20.
+      * `port_value` / `port_nq1_value`: the canonical-order oracle (oracle/rarc_oracle.c, AVX2 + OpenMP) — the parity checker,
+        whose ids and score bits the GPU answer is compared with.
+    Both score the SAME stored rows (the index's fp16 rows widened to fp32)."""
     from oracle import cpu_ref
 
     rows_h = idx2.rows.cpu().numpy().view(np.uint16)
@@ -856,13 +924,29 @@ def cpu_baseline(np, idx2, q, ids2, sc2, n2, a):
     for qi in range(n1):
         cpu_ref.flat_search_f16(rows_h, qn[qi:qi + 1], a.k)
     t_nq1 = (time.perf_counter() - t1) / n1
+    # the numpy / BLAS path over the same rows as fp32 (3 GB at 1M x 768)
+    rows32 = rows_h.view(np.float16)[:, :a.dim].astype(np.float32)
+    cpu_ref.flat_search_blas_f32(rows32[:65536], qn[:8], min(a.k, 10))             # (BLAS thread pool up, pages touched)
+    t2 = time.perf_counter()
+    bl_i, bl_s, blas_threads = cpu_ref.flat_search_blas_f32(rows32, qn, a.k)
+    t_blas = time.perf_counter() - t2
+    t3 = time.perf_counter()
+    for qi in range(n1):
+        cpu_ref.flat_search_blas_f32(rows32, qn[qi:qi + 1], a.k)
+    t_blas1 = (time.perf_counter() - t3) / n1
+    del rows32
     gpu_i = ids2.cpu().numpy()
     recall = float(np.mean([len(np.intersect1d(ref_i[b], gpu_i[b])) / float(a.k) for b in range(a.batch)]))
-    return {"value": round(a.batch / tcpu, 1), "unit": "queries/s", "cores": nthreads, "kind": "port",
-            "sample": f"oracle/rarc_oracle.c flat search, {a.batch} queries x {n2} rows x {a.dim} (config 2 in "
-                      f"full), {tcpu:.2f} s wall, {os.cpu_count()} host cpus",
-            "reference_style_nq1": {"value": round(1.0 / t_nq1, 1), "unit": "queries/s",
-                                    "sample": f"{n1} queries, one per call as the reference issues them"},
+    recall_blas = float(np.mean([len(np.intersect1d(bl_i[b], gpu_i[b])) / float(a.k) for b in range(a.batch)]))
+    return {"value": round(a.batch / t_blas, 1), "unit": "queries/s", "cores": blas_threads, "kind": "port",
+            "sample": f"numpy fp32 Q @ D_chunk^T (host BLAS, {blas_threads} threads) + argpartition top-{a.k}: {a.batch} queries x {n2} rows x "
+                      f"{a.dim} (config 2 in full) in {t_blas:.2f} s; {os.cpu_count()} host cpus; faiss is not installed on the box",
+            "nq1_value": round(1.0 / t_blas1, 1),
+            "nq1_sample": f"the same path, one query per call as the reference issues them, {n1} queries, {t_blas1 * 1e3:.1f} ms each",
+            "port_value": round(a.batch / tcpu, 1), "port_cores": nthreads,
+            "port_sample": f"oracle/rarc_oracle.c canonical-order flat search (AVX2 + OpenMP, {nthreads} threads), the same {a.batch} x {n2} x {a.dim}, {tcpu:.2f} s",
+            "port_nq1_value": round(1.0 / t_nq1, 1),
+            "blas_vs_canonical": {"max_abs_score_diff": float(np.abs(bl_s - ref_s).max()), f"recall_at_{a.k}_vs_gpu": round(recall_blas, 6)},
             "parity_vs_gpu": {"ids_bit_exact": bool(np.array_equal(ref_i, gpu_i)),
                               "scores_bit_exact": bool(np.array_equal(ref_s.view(np.uint32), sc2.cpu().numpy().view(np.uint32))),
                               f"recall_at_{a.k}": round(recall, 6)}}
@@ -900,10 +984,9 @@ def leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank, rows=
            "value": round(a.batch * steps / dt, 1), "unit": "queries/s", "ms_per_step": round(dt / steps * 1e3, 4),
            "scan_ms_per_pass": round(scan_ms, 4), "ingest_rows_per_s": round(rows / t_ingest, 1),
            "rows_beating_kth": int(beat), "queries_verified_by_exact_rescan": len(range(0, a.batch, 8)),
-           "roofline": {"bound": "hbm", "kernel": "rarc_scan_q8_kernel", "achieved": round(bytes_img / (scan_ms * 1e-3) / 1e9, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_img / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "algorithmic_bytes_per_pass": int(bytes_img),
-                        "end_to_end_frac": round(bytes_img / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+           "roofline": hbm_roofline(bytes_img / (scan_ms * 1e-3) / 1e9, kernel="rarc_scan_q8_kernel",
+                                    algorithmic_bytes_per_pass=int(bytes_img),
+                                    end_to_end_frac=round(bytes_img / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4))}
     del idx
     torch.cuda.empty_cache()
     return out
@@ -1240,6 +1323,9 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
                                 "mean": round(sum(lat) / len(lat), 3), "calls": len(lat),
                                 "queries_per_s": round(1e3 / (sum(lat) / len(lat)), 1),
                                 "engine_nq1_p50": round(_percentile(eng[2:], 50), 3)}
+    # (f2) the reference-shaped call WITH THE ENCODER IN IT: invoke(text) = tokenise -> embed_query (the
+    # fp32-class forward of a model of this dimension, 32 padded tokens: the query path) -> search -> Documents
+    out["invoke_latency_with_encoder_ms"] = api_encoder_latency(torch, np, a, dev, local_rank, idx, docs, K, big)
     # (g) MultiPathRetriever: dense + the supplied lexical list, RRF over all 256 queries in one launch
     lex = lexical_lists(torch, torch.from_numpy(ref_ids).to(dev), base + n_rows, K).cpu().numpy() - base
     lex_docs = {t: [Document(content=f"{r:0{width}d}", metadata={"path": "lexical"}, id=f"L{r}") for r in row.tolist()]
@@ -1269,6 +1355,92 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
     # (153.6 GB at 100M rows) stays allocated under the legs that follow
     del store, retriever, mp, fused, single, answers, docs, lex_docs
     gc.collect()
+    return out
+
+
+ENC_GEOMETRY = {384: ("bge-small", 384, 12, 1536, 12), 768: ("bge-base", 768, 12, 3072, 12), 1024: ("bge-large", 1024, 16, 4096, 24)}
+
+
+def seeded_bert_state_dict(torch, dev, H, FFN, LAYERS, VOCAB=30522, seed=5):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rnd = lambda *s: torch.randn(s, generator=g, device=dev) * 0.05
+    sd = {"embeddings.word_embeddings.weight": rnd(VOCAB, H), "embeddings.position_embeddings.weight": rnd(512, H),
+          "embeddings.token_type_embeddings.weight": rnd(2, H), "embeddings.LayerNorm.weight": 1.0 + rnd(H),
+          "embeddings.LayerNorm.bias": rnd(H)}
+    for i in range(LAYERS):
+        p = f"encoder.layer.{i}."
+        for nm, (o, c) in {"attention.self.query": (H, H), "attention.self.key": (H, H), "attention.self.value": (H, H),
+                           "attention.output.dense": (H, H), "intermediate.dense": (FFN, H), "output.dense": (H, FFN)}.items():
+            sd[p + nm + ".weight"], sd[p + nm + ".bias"] = rnd(o, c), rnd(o)
+        for nm in ("attention.output.LayerNorm", "output.LayerNorm"):
+            sd[p + nm + ".weight"], sd[p + nm + ".bias"] = 1.0 + rnd(H), rnd(H)
+    return sd
+
+
+def api_encoder_latency(torch, np, a, dev, local_rank, idx, docs, K, big):
+    """One query at a time, as the reference issues them (VectorStore_Faiss.py:240 `embed_query`, :258-263 search;
+    core/file_management/embeddings/huggingface.py:136-145), with a REAL encoder forward in the line: a seeded model of the
+    index's dimension (bge-base geometry for 768-d, bge-large for 1024-d, bge-small for 384-d), fp32-class precision, query
+    texts of 8..24 tokens (32 padded: the encoder's query path).  Reported: the whole `retriever.invoke` and its two halves
+    on their own."""
+    from rag_arc_amd.core.retrieval.dense import VectorStoreRetriever
+    from rag_arc_amd.encapsulation.database.vector_db.hip_flat import HipFlatVectorStore
+    from rag_arc_amd.encapsulation.embeddings.hip_bert import HipBertEmbeddings, HipBertEncoder
+
+    if a.dim not in ENC_GEOMETRY:
+        return {"skipped": f"no encoder geometry of dimension {a.dim}"}
+    name, H, HEADS, FFN, LAYERS = ENC_GEOMETRY[a.dim]
+    enc = HipBertEncoder(seeded_bert_state_dict(torch, dev, H, FFN, LAYERS), num_heads=HEADS, device=local_rank, precision="fp32")
+
+    def tokenize(text):          # [CLS] + 6..22 word pieces decided by the text + [SEP]  (no vocabulary ships offline)
+        h = int.from_bytes(text.encode()[-8:].rjust(8, b"0"), "little")
+        n = 6 + h % 17
+        return [101] + [1000 + (h * (j + 3) * 2654435761 >> 7) % 28000 for j in range(n)] + [102]
+
+    emb = HipBertEmbeddings(enc, tokenize, max_length=64)
+    store = HipFlatVectorStore(emb, device=local_rank).adopt(idx, docs)
+    retriever = VectorStoreRetriever(store)
+    qtexts = [f"what does passage {i} say about retrieval" for i in range(64)]
+    for t_ in qtexts[:6]:
+        retriever.invoke(t_, k=K)
+    # the answers are the engine's answers for the encoder's embedding
+    ok = True
+    for t_ in qtexts[:3]:
+        e = emb.embed_queries_device([t_])
+        want = idx.search_device(e, K)[0].cpu().numpy()[0] - int(getattr(idx, "id_base", 0))
+        ok = ok and [int(d.id) for d in retriever.invoke(t_, k=K)] == want.tolist()
+    n = 20 if big else 200
+    lat, enc_only, enc_list, search_only = [], [], [], []
+    for i in range(n):
+        t0 = time.perf_counter()
+        retriever.invoke(qtexts[i % 64], k=K)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    for i in range(min(n, 100)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e = emb.embed_queries_device([qtexts[i % 64]])
+        torch.cuda.synchronize()
+        enc_only.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        idx.search(e, K)
+        search_only.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        emb.embed_query(qtexts[i % 64])            # the reference's contract: a python list of floats
+        enc_list.append((time.perf_counter() - t0) * 1e3)
+    out = {"encoder": f"{name} geometry ({LAYERS} layers x {H}, seeded weights), fp32-class, query path "
+                      f"({'on' if enc.query_path else 'off'}): 32 padded tokens per query",
+           "p50": round(_percentile(lat[5:], 50), 3), "p99": round(_percentile(lat[5:], 99), 3),
+           "mean": round(sum(lat[5:]) / len(lat[5:]), 3), "calls": len(lat) - 5,
+           "queries_per_s": round(1e3 / (sum(lat[5:]) / len(lat[5:])), 1),
+           "embed_queries_device_p50": round(_percentile(enc_only[3:], 50), 3),
+           "embed_query_as_python_list_p50": round(_percentile(enc_list[3:], 50), 3),
+           "search_nq1_p50": round(_percentile(search_only[3:], 50), 3),
+           "answers_equal_engine_on_the_embedding": bool(ok)}
+    del store, retriever, emb, enc
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
     return out
 
 
@@ -1455,11 +1627,9 @@ def leg_c5(torch, dist, lib, B, ctypes, np, FlatIndexF16, ShardedFlatSearch, sha
            "encoder_ms": round(enc_ms, 4), "scan_ms": round(scan_ms, 4), "exchange_ms_per_step": round(exch, 4),
            "fused_entries_per_query": int(fn.min().item()),
            "full_size_check": {"queries_verified_by_exact_rescan": len(vq), "rows_beating_kth": int(beat)},
-           "roofline": {"bound": "hbm", "kernel": "rarc_scan_q8_kernel<1024, fp8>",
-                        "achieved": round(scan_bytes / (scan_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(scan_bytes / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "algorithmic_bytes_per_scan": int(scan_bytes),
-                        "int8_TOPs": round(2.0 * nq * (hi - lo) * H / (scan_ms * 1e-3) / 1e12, 1)},
+           "roofline": hbm_roofline(scan_bytes / (scan_ms * 1e-3) / 1e9, kernel="rarc_scan_q8_kernel<1024, fp8>",
+                                    algorithmic_bytes_per_scan=int(scan_bytes),
+                                    int8_TOPs=round(2.0 * nq * (hi - lo) * H / (scan_ms * 1e-3) / 1e12, 1)),
            "encoder_roofline": {"bound": "mfma", "achieved": round(mfma_flops / (enc_alone_ms * 1e-3) / 1e12, 1),
                                 "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": round(mfma_flops / (enc_alone_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF, 4),

@@ -179,6 +179,65 @@ def flat_search_f32(corpus_f32: np.ndarray, q32: np.ndarray, k: int, id_base: in
     return ids, sc, int(nt)
 
 
+def blas_threads() -> int:
+    """Threads the BLAS behind numpy's matmul will use (threadpoolctl when it is installed, else the CPU count)."""
+    try:
+        from threadpoolctl import threadpool_info
+
+        n = [int(i.get("num_threads", 0)) for i in threadpool_info() if i.get("user_api") == "blas"]
+        if n:
+            return max(n)
+    except Exception:  # noqa: BLE001
+        pass
+    return os.cpu_count() or 1
+
+
+def flat_search_blas_f32(corpus_f32: np.ndarray, q32: np.ndarray, k: int, chunk_rows: int = 131072, workers: int | None = None):
+    """The CPU BASELINE SURVEY.md §8(d) defines — "numpy fp32 `normalize` -> `D @ q` -> top-k" — i.e. what the reference's path
+    (VectorStore_Faiss.py:258-263: fp32 query, `index.search` on an IndexFlatIP) costs when its inner products come from the
+    host's BLAS, which is what faiss itself does for batches of 20 queries and more (sgemm over row blocks + a per-query
+    selection).  corpus_f32 [n][d] (rows already normalised, fp32 as faiss stores them), q32 [nq][d] normalised queries.
+    Scores are sgemm's (its summation order, not the canonical one): NOT the parity oracle — tests hold it to the canonical
+    oracle within 1e-5 and to the same ids wherever gaps exceed that.  Row chunks of `chunk_rows`: S = Q @ D_chunkᵀ [nq][chunk]
+    (BLAS, all its threads), then each query's top-k of the chunk by argpartition (a thread pool over the query rows: numpy
+    releases the GIL inside partition), merged into the running top-k.  Returns (ids int64 [nq][k], scores fp32 [nq][k]) ordered
+    by (score desc, id asc), and the BLAS thread count."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    D = np.ascontiguousarray(corpus_f32, dtype=np.float32)
+    Q = np.ascontiguousarray(q32, dtype=np.float32)
+    n, nq = D.shape[0], Q.shape[0]
+    k = min(int(k), n)
+    workers = workers or min(os.cpu_count() or 1, 64, max(1, nq))
+    best_s = np.full((nq, 0), -np.inf, np.float32)
+    best_i = np.zeros((nq, 0), np.int64)
+
+    def select(args):
+        S, lo, hi, kk = args
+        part = np.argpartition(-S[lo:hi], kk - 1, axis=1)[:, :kk]
+        return part
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        for c0 in range(0, n, chunk_rows):
+            c1 = min(n, c0 + chunk_rows)
+            S = Q @ D[c0:c1].T                                    # sgemm
+            kk = min(k, c1 - c0)
+            if nq >= 2 * workers:
+                step = -(-nq // workers)
+                parts = list(pool.map(select, [(S, lo, min(nq, lo + step), kk) for lo in range(0, nq, step)]))
+                part = np.concatenate(parts)
+            else:
+                part = select((S, 0, nq, kk))
+            cand_s = np.take_along_axis(S, part, axis=1)
+            best_s = np.concatenate([best_s, cand_s], axis=1)
+            best_i = np.concatenate([best_i, part.astype(np.int64) + c0], axis=1)
+            if best_s.shape[1] > 4 * k:                           # keep the running lists short
+                keep = np.argpartition(-best_s, k - 1, axis=1)[:, :k]
+                best_s, best_i = np.take_along_axis(best_s, keep, axis=1), np.take_along_axis(best_i, keep, axis=1)
+    order = np.lexsort((best_i, -best_s.astype(np.float64)), axis=1)[:, :k]       # (score desc, id asc)
+    return np.take_along_axis(best_i, order, axis=1), np.take_along_axis(best_s, order, axis=1), blas_threads()
+
+
 def pad_queries(q: np.ndarray, d_pad: int) -> np.ndarray:
     q = np.ascontiguousarray(q, dtype=np.float32)
     out = np.zeros((q.shape[0], d_pad), dtype=np.float32)

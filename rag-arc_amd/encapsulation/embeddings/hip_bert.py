@@ -414,6 +414,9 @@ class HipBertEmbeddings(Embeddings):
                 parts.append(self.encoder.forward(ids[s:e, :L], lens[s:e], self.normalize, non_blocking=True))
                 calls, tokens, padded = calls + 1, tokens + int(lens[s:e].sum()), padded + (e - s) * (-(-L // 32) * 32)
         cat = parts[0] if len(parts) == 1 else t.cat(parts)
+        if n == 1:      # a single query (embed_query): nothing to put back in order — no permutation upload, no index_copy launch
+            self.last_stats = dict(texts=1, encoder_calls=calls, tokens=tokens, padded_tokens=padded, tokenize_seconds=tok_s)
+            return cat
         out = t.empty_like(cat)
         perm = t.from_numpy(np.asarray(order, dtype=np.int64)).pin_memory().to(cat.device, non_blocking=True)
         out.index_copy_(0, perm, cat)

@@ -34,3 +34,38 @@ def test_more_gpus_than_devices_fails_loudly():
     have = torch.cuda.device_count()
     p = _run("--gpus", str(have + 2), "--steps", "1")
     assert p.returncode != 0 and "GPU(s) visible" in p.stderr and p.stdout.strip() == ""
+
+
+CONTRACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def test_eight_rank_dry_run_emits_the_contract_line():
+    """no 8-GPU box has run this tree, so the first one must not fail on plumbing.  `bench.py --gpus 8`
+    (here --dry-run: gloo, stand-in local search) starts its own eight ranks and relays ONE line with every key of the
+    driver's contract, n_gpus = 8, every rank's shard size (they cover the corpus exactly) and an exchange_ms_per_step."""
+    p = _run("--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "1", "--rows", "100000003", "--k", "100", "--batch", "16")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert CONTRACT_KEYS <= set(out), CONTRACT_KEYS - set(out)
+    assert out["n_gpus"] == 8 and out["ranks"] == 8 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "strong"
+    cfg = out["config"]
+    assert cfg["rows_per_gpu"] == 12500001 and len(cfg["rows_per_rank"]) == 8 and sum(cfg["rows_per_rank"]) == 100000003
+    assert max(cfg["rows_per_rank"]) - min(cfg["rows_per_rank"]) <= 8
+    assert isinstance(cfg["exchange_ms_per_step"], float) and out["merged_ids_ok"] is True
+    assert out["roofline"]["bound"] == "hbm" and out["value"] is None
+
+
+def test_a_measured_line_has_the_same_contract_keys_as_the_dry_run():
+    """The keys of the dry-run line are held against the literal result dict in bench.py's main(): if one side gains or loses a
+    contract key the other must follow."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    block = main[main.index("result = {"):main.index("# ---- config 2 / 3")]
+    for key in CONTRACT_KEYS - {"cpu_baseline"}:
+        assert f'"{key}":' in block, key
+    assert 'result["cpu_baseline"]' in main
+    for key in ("rows_per_gpu", "exchange_ms_per_step", "n_corpus"):
+        assert f'"{key}":' in block, key
