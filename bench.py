@@ -109,7 +109,8 @@ def parse(argv=None):
     ap.add_argument("--no-c5", action="store_true")
     ap.add_argument("--no-wide", action="store_true", help="skip the wide-row leg (10M x 1536 through rarc_search_wide)")
     ap.add_argument("--no-pairs", action="store_true", help="skip the all-pairs cosine leg (100k x 1024 entities, SURVEY 8(f) rank 4)")
-    ap.add_argument("--no-f32", action="store_true", help="skip the storage=f32 leg (10M x 768 fp32 rows)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the storage=f32 leg (fp32 rows at the largest size one GPU holds)")
+    ap.add_argument("--f32-rows", type=int, default=0, help="rows of the storage=f32 leg (0 = auto: 45M x 768 when 207 GB are free)")
     ap.add_argument("--no-api", action="store_true", help="skip the legs through the registered retriever (texts -> Documents)")
     ap.add_argument("--no-lm", action="store_true", help="config 3 without its cross-encoder's LM forward (seeded logits instead)")
     ap.add_argument("--c3-steps", type=int, default=2, help="timed steps of the config-3 leg (one step = 256 x 100 LM prompts, seconds)")
@@ -572,13 +573,6 @@ def main():
         if idx2 is not idx:
             del idx2
 
-    # ---- storage="f32": the reference's own row format, 10M x 768 (one GPU) ---------------------------
-    if world == 1 and a.storage == "f16" and not a.no_f32:
-        free = torch.cuda.mem_get_info(dev)[0]
-        if free > 60 * (1 << 30):
-            result["f32"] = leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank)
-        else:
-            result["f32"] = {"skipped": f"needs 60 GiB of free HBM next to the headline index, {free >> 30} GiB free"}
     # ---- rows wider than 1024 dimensions: 10M x 1536 through the wide path (one GPU) ----------------------
     if world == 1 and a.storage == "f16" and not a.no_wide:
         if torch.cuda.mem_get_info(dev)[0] > 45 * (1 << 30):
@@ -599,6 +593,22 @@ def main():
                     world, rank, local_rank, dev, use_dist)
         if rank == 0:
             result["c5"] = c5
+    # ---- storage="f32": the reference's own row format AT THE SCALE ONE GPU HOLDS (one GPU; after the headline index and
+    #      config 5's corpus are gone): fp32 rows + their fp16 image = 6 bytes per element — 45M x 768 = 207 GB of the 288 ----
+    if world == 1 and a.storage == "f16" and not a.no_f32:
+        import gc
+
+        searcher = idx = l_ids = l_sc = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        free = torch.cuda.mem_get_info(dev)[0]
+        per_row = B.padded_dim(a.dim) * 6 + 64
+        rows_f32 = a.f32_rows or int(min(45_000_000, max(1_000_000, (0.80 * free - (6 << 30)) // per_row)) // 1_000_000 * 1_000_000)
+        if free > rows_f32 * per_row + (4 << 30):
+            result["f32"] = leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank, rows=rows_f32)
+        else:
+            result["f32"] = {"skipped": f"{rows_f32} fp32 rows need {rows_f32 * per_row >> 30} GiB of HBM, {free >> 30} GiB free"}
+        torch.cuda.empty_cache()
     # ---- shard files: a 10M x dim fp16 shard streamed HBM -> file -> HBM by the library, one GPU --------------
     if world == 1 and not a.no_persist and a.storage == "f16":
         torch.cuda.empty_cache()

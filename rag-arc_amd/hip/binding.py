@@ -27,6 +27,13 @@ class RarcError(RuntimeError):
     """Raised for every non-zero status returned by librarc_hip.so."""
 
 
+class RarcUnsupported(RarcError, NotImplementedError):
+    """A search the reference's `IndexFlatIP.search` would answer (any d, any k: VectorStore_Faiss.py:262) that this backend
+    REFUSES — the storage x path matrix in INTEGRATION.md ("What the backend refuses").  A refusal is loud and happens before
+    anything is launched; the message names the configuration that does answer the call.  Also a NotImplementedError, the
+    type the reference's VectorStore base raises for what a store does not implement (VectorStoreBase.py:145-176)."""
+
+
 class EncLayer(ctypes.Structure):
     """RarcEncLayer (include/rarc.h): device pointers of one transformer layer."""
     _fields_ = [(n, c_void_p) for n in ("qkv_w", "qkv_b", "o_w", "o_b", "ln1_g", "ln1_b", "f1_w", "f1_b", "f2_w",

@@ -217,10 +217,10 @@ class FlatIndexF16:
         # WIDE path — score GEMM in chunks + select + canonical finalize (csrc/wide.hip) — as does k beyond 1024
         self.wide = self.d_pad > 1024
         if self.wide and (scan != "auto" or storage == "f8" or shadow or self.d_pad > B.WIDE_MAX_DPAD):
-            raise B.RarcError(f"dim {dim} pads to {self.d_pad}: rows wider than 1024 take the wide path (fp16 / fp32 rows, "
-                              f"scan='auto', at most {B.WIDE_MAX_DPAD} padded dimensions)")
+            raise B.RarcUnsupported(f"dim {dim} pads to {self.d_pad}: rows wider than 1024 take the wide path (storage 'f16' or "
+                                    f"'f32', scan='auto', no shadow image, at most {B.WIDE_MAX_DPAD} padded dimensions)")
         if not self.wide and self.d_pad > limit:
-            raise B.RarcError(f"dim {dim} pads to {self.d_pad} > {limit}: not supported by the {scan} scan kernel")
+            raise B.RarcUnsupported(f"dim {dim} pads to {self.d_pad} > {limit}: not supported by the {scan} scan kernel")
         # "q8": int8-prefilter scan (HBM-bound; its error margin costs candidates, which only matters on
         # small shards); "mfma16": fp16 MFMA scan + certificate (tight margin, matrix-pipe bound);
         # "auto": q8 from AUTO_Q8_ROWS rows up (and always beyond 768 dims), mfma16 below
@@ -849,9 +849,11 @@ class FlatIndexF16:
         if not (self.wide or k > B.MAX_K):
             return False
         if k > B.WIDE_MAX_K:
-            raise B.RarcError(f"k={k} exceeds the kernel limit {B.WIDE_MAX_K}")
+            raise B.RarcUnsupported(f"k={k} exceeds the limit of {B.WIDE_MAX_K} results per query (faiss has none: ask in pages of "
+                                    f"{B.WIDE_MAX_K} if a corpus-sized k is really meant)")
         if self.storage == "f8" or self.shadow:
-            raise B.RarcError(f"k={k} > {B.MAX_K} takes the wide path, which reads fp16 / fp32 rows (storage={self.storage})")
+            raise B.RarcUnsupported(f"k={k} > {B.MAX_K} takes the wide path, which reads fp16 / fp32 rows (storage={self.storage}): "
+                                    "store the rows as 'f16' or 'f32' for such k")
         return True
 
     def _rho(self) -> float:

@@ -57,8 +57,14 @@ def _worker(rank, world, port, n, d, nq, k, out_dir, backend="gloo"):
     rows = torch.zeros((max(cap, 32), d), dtype=torch.float16, device="cuda")
     B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d, d, lo, hi - lo, 1234, 0))
     wide = B.padded_dim(d) > 1024 or k > 1024                                            # (the wide path takes scan="auto" only)
-    idx = FlatIndexF16(d, device=dev, id_base=lo, scan="q8" if rank % 2 and not wide else "auto")     # mixed scan kernels across ranks
-    idx.add_rows_f16(rows, 1.001, n_valid=hi - lo)
+    if n in _F32_SIZES:       # storage="f32": the reference's own row format (the one mode inside 1e-5 on arbitrary inputs), sharded
+        x = torch.zeros((hi - lo, d), dtype=torch.float32, device="cuda")
+        B.check(lib.rarc_synth_rows_f32(x.data_ptr(), d, d, lo, hi - lo, 1234, 0))
+        idx = FlatIndexF16(d, device=dev, id_base=lo, storage="f32")
+        idx.add(x)
+    else:
+        idx = FlatIndexF16(d, device=dev, id_base=lo, scan="q8" if rank % 2 and not wide else "auto")     # mixed scan kernels across ranks
+        idx.add_rows_f16(rows, 1.001, n_valid=hi - lo)
     q = torch.zeros((nq, d), dtype=torch.float32, device="cuda")
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), d, d, 0, nq, 4321, 0))
     s = ShardedFlatSearch(idx)
@@ -74,11 +80,14 @@ def _worker(rank, world, port, n, d, nq, k, out_dir, backend="gloo"):
 
 
 # shapes: the register-resident scans; rows of 1536 dimensions and k = 1500 (the wide path, round 5) behind the same exchange
-_SHAPES = {"narrow": (300_001, 256, 96, 50), "wide_rows": (60_001, 1536, 40, 50), "wide_k": (40_001, 256, 24, 1500)}
+_SHAPES = {"narrow": (300_001, 256, 96, 50), "wide_rows": (60_001, 1536, 40, 50), "wide_k": (40_001, 256, 24, 1500),
+           "f32_rows": (200_003, 384, 64, 100)}
+_F32_SIZES = {200_003}      # (the worker tells the fp32-storage case by its row count)
 
 
 @pytest.mark.parametrize("world,backend,shape", [(2, "gloo", "narrow"), (8, "gloo", "narrow"), (2, "gloo", "wide_rows"),
-                                                 (4, "gloo", "wide_k"), (2, "nccl", "narrow"), (4, "nccl", "narrow"),
+                                                 (4, "gloo", "wide_k"), (4, "gloo", "f32_rows"), (2, "nccl", "f32_rows"),
+                                                 (2, "nccl", "narrow"), (4, "nccl", "narrow"),
                                                  (8, "nccl", "narrow"), (2, "nccl", "wide_rows")])
 def test_sharded_search_across_real_ranks(tmp_path, world, backend, shape):
     import torch
@@ -92,10 +101,16 @@ def test_sharded_search_across_real_ranks(tmp_path, world, backend, shape):
     port = 29650 + world + (20 if backend == "nccl" else 0) + 40 * list(_SHAPES).index(shape)
     mp.spawn(_worker, args=(world, port, n, d, nq, k, str(tmp_path), backend), nprocs=world, join=True)
     lib = B.load_library()
-    rows = torch.zeros((((n + 31) // 32) * 32, d), dtype=torch.float16, device="cuda")
-    B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d, d, 0, n, 1234, 0))
-    single = FlatIndexF16(d)
-    single.add_rows_f16(rows, 1.001, n_valid=n)
+    if n in _F32_SIZES:
+        x = torch.zeros((n, d), dtype=torch.float32, device="cuda")
+        B.check(lib.rarc_synth_rows_f32(x.data_ptr(), d, d, 0, n, 1234, 0))
+        single = FlatIndexF16(d, storage="f32")
+        single.add(x)
+    else:
+        rows = torch.zeros((((n + 31) // 32) * 32, d), dtype=torch.float16, device="cuda")
+        B.check(lib.rarc_synth_rows_f16(rows.data_ptr(), d, d, 0, n, 1234, 0))
+        single = FlatIndexF16(d)
+        single.add_rows_f16(rows, 1.001, n_valid=n)
     q = torch.zeros((nq, d), dtype=torch.float32, device="cuda")
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), d, d, 0, nq, 4321, 0))
     D, I = single.search(q, k)

@@ -138,3 +138,35 @@ def test_store_with_3072_dimensional_embeddings(hip, tmp_path):
     again = HipFlatVectorStore.load_local(str(tmp_path / "wide"), emb)
     assert [(d.id, s) for d, s in again.similarity_search_with_score(texts[77], k=9)] == \
         [(d.id, s) for d, s in store.similarity_search_with_score(texts[77], k=9)]
+
+
+def test_what_the_backend_refuses_is_refused_loudly_and_before_any_launch():
+    """faiss's IndexFlatIP takes any d and any k (VectorStore_Faiss.py:101-115, :262).  This backend answers d_pad <= 4096 and
+    k <= 8192 on fp16 / fp32 rows, d_pad <= 1024 and k <= 1024 on fp8 rows; everything else is REFUSED — RarcUnsupported (a
+    RarcError and a NotImplementedError), raised at construction or before the first kernel, the message naming the
+    configuration that does answer ("What the backend refuses").  Never a truncated or approximate answer."""
+    import torch
+
+    from rag_arc_amd.hip import binding as B
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    assert issubclass(B.RarcUnsupported, B.RarcError) and issubclass(B.RarcUnsupported, NotImplementedError)
+    with pytest.raises(B.RarcUnsupported, match="wide path"):
+        FlatIndexF16(1536, storage="f8")                              # fp8 rows wider than 1024 padded dimensions
+    with pytest.raises(B.RarcUnsupported):
+        FlatIndexF16(4200)                                            # beyond 4096 padded dimensions, any storage
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((9000, 256), device="cuda", generator=g)
+    q = torch.randn((3, 256), device="cuda", generator=g)
+    f8 = FlatIndexF16(256, storage="f8")
+    f8.add(x)
+    assert f8.search(q, 1000)[1].shape == (3, 1000)                   # the register-resident scan's whole range
+    with pytest.raises(B.RarcUnsupported, match="'f16' or 'f32'"):
+        f8.search(q, 2000)
+    with pytest.raises(B.RarcUnsupported):
+        f8.search_async(q, 2000)
+    f16 = FlatIndexF16(256)
+    f16.add(x)
+    assert f16.search(q, 8192)[1].shape == (3, 8192)                  # the wide path's whole range
+    with pytest.raises(B.RarcUnsupported, match="8192"):
+        f16.search(q, 8500)
