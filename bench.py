@@ -1166,7 +1166,7 @@ def leg_api(torch, np, lib, B, a, dev, local_rank, idx, n_rows, engine, via_regi
 
     # what the earlier legs of THIS process left on the heap (the LM's and the encoder's python objects, result dicts, ...) is not
     # part of a retrieval service: out of the cyclic collector's way before the leg builds its own docstore, back at the end
-    # (tools/gc_probe.py: in a process that holds the store and nothing else an answer's collection costs ~1 ms per 256 x 100)
+    # (tools/lab/gc_probe.py: in a process that holds the store and nothing else an answer's collection costs ~1 ms per 256 x 100)
     gc.collect()
     gc.freeze()
     K, NB, NQT = a.k, 256, 2048

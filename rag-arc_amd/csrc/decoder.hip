@@ -267,7 +267,7 @@ __device__ __forceinline__ void lm_softmax_tile(const f32x16& st, float scale2, 
   l_run += psum;
 }
 
-#ifdef LM_ATTN_TIMELINE   // measurement builds: s_memtime stamps of one workgroup's wave 0 (tools/lm_attn_timeline.py)
+#ifdef LM_ATTN_TIMELINE   // measurement builds: s_memtime stamps of one workgroup's wave 0 (tools/lab/lm_attn_timeline.py)
 __device__ unsigned long long g_lm_tl[512];
 extern "C" int rarc_lm_debug_timeline(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lm_tl), sizeof(unsigned long long) * (size_t)n);

@@ -741,7 +741,7 @@ __global__ __launch_bounds__(512, 1) void rarc_gemm256_f16_kernel(const half_t* 
 // pipeline's counted waits widened by exactly the stores in flight (vmcnt counts them, in order).
 //   ACT 0: C = A·Wᵀ (no bias: the reranker LM's projections);  ACT 3: silu(gate)·up over interleaved gate / up columns.
 // ------------------------------------------------------------------------------------------
-#ifdef G256S_TIMELINE   // measurement builds: s_memtime at the start of every k tile of one workgroup's stream (tools/gemm_seam_timeline.py)
+#ifdef G256S_TIMELINE   // measurement builds: s_memtime at the start of every k tile of one workgroup's stream (tools/lab/gemm_seam_timeline.py)
 __device__ unsigned long long g_g256s_tl[1024];
 extern "C" int rarc_gemm_debug_timeline(unsigned long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_g256s_tl), sizeof(unsigned long long) * (size_t)n);

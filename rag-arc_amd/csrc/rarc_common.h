@@ -252,7 +252,7 @@ __host__ __device__ static inline float rarc_canon_tree(const float a[8]) {
 // Round 4 — MFMA result settle.  hipcc's hazard recognizer counts EVERY instruction between an MFMA and the first VALU read of
 // its result as one wait state, an s_waitcnt too — and gfx950 retires an s_waitcnt whose counters are already satisfied without
 // spending an issue cycle.  With one to three of them inside a window the compiler sized exactly (12 states for
-// v_mfma_f32_32x32x16_f16: measured, tools/mfma_wait_probe.hip), the read comes one to three cycles early and sees the old
+// v_mfma_f32_32x32x16_f16: measured, tools/lab/mfma_wait_probe.hip), the read comes one to three cycles early and sees the old
 // register: random wrong rows, at a rate that follows how quickly the LDS happened to answer (rarc_e32_attention_split_kernel,
 // 1.5 % of forwards; a build with the accumulators in AGPRs: every forward).  Put this behind the LAST MFMA of a chain whose
 // result VALU code consumes soon: five real wait states on top of whatever the compiler inserts (inline asm is not counted).

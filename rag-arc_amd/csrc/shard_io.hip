@@ -98,7 +98,7 @@ void worker(IoJob* jp, int w) {
   if (hipSetDevice(job.device) != hipSuccess) { job.fail("hipSetDevice", "worker thread"); return; }
   // The DMA goes onto the CALLER's stream (HIP streams may be fed from several threads).  Measured on MI355X / ROCm 7.2:
   // every additional HIP stream costs the process 90-190 MB of host memory for good (one stream per worker: +730 MB on
-  // the first 8-thread call), and buys nothing — one stream carries the PCIe link's rate (tools/persist_rss_probe.py).
+  // the first 8-thread call), and buys nothing — one stream carries the PCIe link's rate (tools/lab/persist_rss_probe.py).
   const hipStream_t st = job.caller_stream;
   hipEvent_t ev[2] = {nullptr, nullptr};
   if (hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||

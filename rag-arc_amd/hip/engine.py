@@ -870,6 +870,17 @@ class FlatIndexF16:
         norm = 1 if self.metric == "cosine" else 0
         mn = max(self.max_norm, 1.0) if norm else self.max_norm
         stream = self._stream()
+        # metric "ip" takes rows and queries of any scale, and the wide path keeps its first chunk's scores as fp16 (finite by
+        # assumption: csrc/wide.hip).  |q·d| <= ||q||·max ||row||: where that bound passes 2^15 the QUERIES go in scaled by a
+        # power of two that brings it under (exact in fp32, and every later step is linear in q) and the scores come back
+        # multiplied by its inverse (exact) — an infinite first-chunk score would set an infinite threshold and drop every
+        # later row.  Cosine scores are at most 1: no read-back on that path.
+        unscale = 1.0
+        if not norm:
+            bound = float(q.norm(dim=1).max().item()) * float(self.max_norm) * 1.01
+            if bound >= 32768.0:
+                e = int(np.ceil(np.log2(bound / 32768.0))) + 1
+                q, unscale = q * (2.0 ** -e), 2.0 ** e
         B.check(self.lib.rarc_prep_queries(q.data_ptr(), q.shape[1], nq, self.dim, self.d_pad, norm, mn, 0,
                                            self._qbuf["qblock"].data_ptr(), stream), "rarc_prep_queries")
         first = ((max(16384, 2 * k) + 255) // 256) * 256 + 256   # the library's first chunk of rows (csrc/wide.hip) at its largest
@@ -892,6 +903,8 @@ class FlatIndexF16:
             self.last_wide_cap = cap          # (diagnostics: the capacity this batch was answered at)
             if not flagged:
                 self.last_repaired = []
+                if unscale != 1.0:
+                    out_sc.mul_(unscale)
                 return
             if cap >= sure:
                 raise B.RarcError("rarc_search_wide flagged a query at a capacity that holds every row")

@@ -126,7 +126,7 @@ def disassemble(kernel_substring: str, lib_path: str = LIB) -> Dict[str, List[st
 
 # ---- MFMA result -> first reader windows (round 4) -------------------------------------------------------------------------
 # Wait states gfx950 needs between an MFMA and a VALU (or accvgpr / LDS / store / permlane) read of its result, measured with
-# tools/mfma_wait_probe.hip (profiles/r04_mfma_wait_probe.txt): the first K at which no read came early.
+# tools/lab/mfma_wait_probe.hip (profiles/r04_mfma_wait_probe.txt): the first K at which no read came early.
 MFMA_RESULT_WAIT_STATES = {"v_mfma_f32_32x32x16_f16": 12, "v_mfma_i32_32x32x32_i8": 12, "v_mfma_f32_16x16x32_f16": 8,
                            "v_mfma_i32_16x16x64_i8": 8, "v_mfma_f32_32x32x2_f32": 18}
 # instructions the sequencer retires without an issue cycle when they have nothing to wait for: hipcc's hazard recognizer counts

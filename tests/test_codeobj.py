@@ -126,7 +126,7 @@ def test_the_scan_kernels_fast_path_swap_is_present_in_the_m16_instantiations():
 
 def test_no_mfma_result_is_read_early_once_s_waitcnt_counts_for_nothing():
     """Round 4.  hipcc sizes the gap between an MFMA and the first read of its result exactly (12 wait states for
-    v_mfma_f32_32x32x16_f16, what the hardware needs: tools/mfma_wait_probe.hip) — and counts an s_waitcnt inside the gap as one
+    v_mfma_f32_32x32x16_f16, what the hardware needs: tools/lab/mfma_wait_probe.hip) — and counts an s_waitcnt inside the gap as one
     of them, although gfx950 retires a satisfied s_waitcnt without an issue cycle.  Such a read then comes early whenever the LDS
     had already answered: rarc_e32_attention_split_kernel returned random wrong rows in 1.5 % of its forwards, a build with its
     accumulators in AGPRs in every one, and three instantiations of the LM's attention carried the same window.  RARC_MFMA_SETTLE

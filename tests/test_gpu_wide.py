@@ -170,3 +170,24 @@ def test_what_the_backend_refuses_is_refused_loudly_and_before_any_launch():
     assert f16.search(q, 8192)[1].shape == (3, 8192)                  # the wide path's whole range
     with pytest.raises(B.RarcUnsupported, match="8192"):
         f16.search(q, 8500)
+
+
+def test_inner_product_scores_beyond_the_fp16_range(hip, oracle):
+    """metric "ip" takes rows and queries of any scale (faiss does), and the wide path stores its first chunk's
+    scores as fp16.  Rows of norm ~60 against queries of norm ~2000 score up to 1e5 > 65504: an infinite first-chunk score
+    would set an infinite threshold and drop every better row of the later chunks.  The engine scales such queries by a power
+    of two on the way in and the scores back on the way out (both exact): ids and score bits are the oracle's — with the best
+    rows planted in the LAST chunk."""
+    rng = np.random.default_rng(99)
+    n, d, k = 90_000, 1536, 50
+    X = rng.standard_normal((n, d)).astype(np.float32) * 1.5               # ||row|| ~ 59
+    Q = rng.standard_normal((7, d)).astype(np.float32) * 50.0              # ||q|| ~ 1960
+    for j in range(7):                                                     # the best row of every query sits at the very end
+        X[n - 1 - j] = Q[j] / np.linalg.norm(Q[j]) * 60.0
+    idx = hip.FlatIndexF16(d, metric="ip")
+    idx.add(X)
+    D, I = idx.search(Q, k)
+    ref_I, ref_D = _oracle(oracle, X, Q, k, metric="ip")
+    assert float(ref_D.max()) > 65504.0 and np.isfinite(D).all()
+    assert [int(I[j, 0]) for j in range(7)] == [n - 1 - j for j in range(7)]
+    assert _same(D, I, ref_I, ref_D)
