@@ -540,8 +540,8 @@ def main():
     if world == 1 and a.storage == "f16" and not (a.no_c2 and a.no_c3):
         n2 = min(1_000_000, rows)
         idx2 = idx if rows == n2 else build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, 0, n2)
-        steps2 = max(a.steps, 50)
-        w2 = max(a.warmup, 5)
+        steps2 = max(a.steps, 400)      # (0.45 ms each: a fifth of a second; short runs of this leg vary by 5 % with the clocks the
+        w2 = max(a.warmup, 20)          #  100M-row scan in front of it left behind)
         (dt2, (ids2, sc2)), tot2, nl2 = scan_profile(
             lib, B, ctypes,
             lambda: timed_loop(torch, dist, lambda: idx2.search_async(q, a.k), lambda h: h.result(), steps2, w2, False),

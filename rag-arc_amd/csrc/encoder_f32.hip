@@ -733,6 +733,216 @@ __global__ __launch_bounds__(256, 2) void rarc_e32_attention_split_kernel(const 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6 — attention of the QUERY PATH: sequences of at most 32 padded tokens (one query block, one key tile), head_dim 64.
+// rarc_e32_attention_split_kernel is built for 512-token documents: shared K / V images of 32-key tiles in LDS, double
+// buffered, ONE wave per 32-query block doing the softmax of 1024 scores — at one tile and one block that is a single wave's
+// instruction stream, 11 µs per layer for a single query, more than any of its projections (a lone wave issues one VALU
+// instruction per four cycles; the first version of THIS kernel, one wave per head with everything in registers, took 14 µs).
+// Here a workgroup of FOUR waves owns a (sequence, head) and every phase is cut four ways on the 16 x 16 x 32 MFMA:
+//   A  all 256 threads fetch q, k, v (8 dims of one token each; split-K slabs summed on the way in), scale rows of q and k,
+//      columns of v (one power of two per COLUMN d, finer than the document kernel's per-block one), write (hi, lo) images;
+//   B  wave (kb, qb) multiplies the 16-key x 16-query block S^T[kb][qb] (6 MFMAs), does the softmax of ITS 256 scores — four
+//      expf per lane — and trades row maxima / sums with the wave of the other key half through LDS; p·2^11 -> (hi, lo) image;
+//   C  wave (qb, d half) multiplies two 16-d x 16-query blocks of O^T (6 MFMAs) and writes its part of the epilogue.
+// Same arithmetic class as the document kernel: (hi, lo) fp16 pairs of value · 2^e, products lo·hi, hi·lo, hi·hi in that order
+// into fp32 accumulators, libm expf, fp32 statistics.  Keys >= lens[seq] are masked and their V rows read as zero.
+// And the row pass that used to follow the attention — ctx -> split image for the output projection, a launch of its own on
+// 32 workgroups — is this kernel's epilogue: the power-of-two scale is taken per (token, HEAD) from the head's own 64 outputs
+// (no reduction across heads exists to wait for), rah[token][head] keeps its inverse, and the output projection's weight
+// stream multiplies each wave's partial product — a wave's k slice lies inside ONE head — by it before the slices are added
+// (E32SkinnyEpi.wave_scale).  ra_one[token] = 1: the projection's row pass has no row scale left to apply.
+// ------------------------------------------------------------------------------------------
+template <bool REL>
+__global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* __restrict__ P, const float* __restrict__ ra,
+                                                                  const float* __restrict__ rw, const float* __restrict__ bias,
+                                                                  const int32_t* __restrict__ lens, int H, int n_heads,
+                                                                  half_t* __restrict__ xq, float* __restrict__ rah,
+                                                                  float* __restrict__ ra_one, const float* __restrict__ rel,
+                                                                  int rel_span, int n_parts, size_t part_stride) {
+  constexpr int DH = 64, L = 32;
+  constexpr int QROW = DH + 8;   // halves per q / k row (+16 bytes: conflict-free ds_read_b128 fragments)
+  constexpr int TROW = L + 8;    // halves per V^T row (32 keys) / P^T row (32 keys)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) half_t qh[L * QROW], ql[L * QROW], kh[L * QROW], kl[L * QROW];
+  __shared__ __attribute__((aligned(16))) half_t vh[DH * TROW], vl[DH * TROW], ph[L * TROW], pl[L * TROW];
+  __shared__ __attribute__((aligned(16))) float sqinv[L], skinv[L], svinv[DH];
+  __shared__ uint32_t vmax[DH];
+  __shared__ float smax[2][L], ssum[2][L], somax[2][L];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / n_heads, hd = blockIdx.x % n_heads;
+  const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
+  if (tid < DH) vmax[tid] = 0u;
+  // ---- A: thread (token row = tid >> 3, c8 = tid & 7) owns dims 8 c8 .. + 7 of the row's q, k and v ----
+  const int row = tid >> 3, c8 = tid & 7;
+  const size_t mrow = (size_t)b * L + row;
+  float x[3][8];
+  {
+    const float r = ra[mrow];
+    const float* src = P + mrow * 3 * (size_t)H + hd * DH + 8 * c8;
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      const float* w = rw + part * H + hd * DH + 8 * c8;
+      const float* bb = bias + part * H + hd * DH + 8 * c8;
+#pragma unroll
+      for (int h4 = 0; h4 < 2; ++h4) {
+        const float4 pv = e32_sum_parts(src + part * H + 4 * h4, n_parts, part_stride);
+        const float4 s4 = *(const float4*)(w + 4 * h4), b4 = *(const float4*)(bb + 4 * h4);
+        x[part][4 * h4] = pv.x * r * s4.x + b4.x; x[part][4 * h4 + 1] = pv.y * r * s4.y + b4.y;
+        x[part][4 * h4 + 2] = pv.z * r * s4.z + b4.z; x[part][4 * h4 + 3] = pv.w * r * s4.w + b4.w;
+      }
+    }
+  }
+  if (row >= len) {   // a masked key's V row reads as zero: nothing of the padding reaches a result
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[2][e] = 0.f;
+  }
+  __syncthreads();    // vmax is zero
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicMax(&vmax[8 * c8 + e], __float_as_uint(fabsf(x[2][e])));   // (non-negative floats order as integers)
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {   // q, k: one scale per row = the maximum over the row's eight lanes
+    float mx = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(x[part][e]));
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    float sc, inv;
+    e32a_scale_of(mx, sc, inv);
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      half_t h_, l_;
+      e32a_split(x[part][e] * sc, h_, l_);
+      hi[e] = h_; lo[e] = l_;
+    }
+    *(half8*)((part ? kh : qh) + row * QROW + 8 * c8) = hi;
+    *(half8*)((part ? kl : ql) + row * QROW + 8 * c8) = lo;
+    if (c8 == 0) (part ? skinv : sqinv)[row] = inv;
+  }
+  __syncthreads();    // every column's maximum is in
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {   // v: one scale per column d; the images are V^T [d][key]
+    const int d = 8 * c8 + e;
+    float sc, inv;
+    e32a_scale_of(__uint_as_float(vmax[d]), sc, inv);
+    half_t h_, l_;
+    e32a_split(x[2][e] * sc, h_, l_);
+    vh[d * TROW + row] = h_;
+    vl[d * TROW + row] = l_;
+    if (row == 0) svinv[d] = inv;
+  }
+  __syncthreads();
+  // ---- B: wave (kb, qb): S^T block of keys 16kb.. x queries 16qb..; lane (query col c, rq) ends with keys 16kb + 4rq + e ----
+  const int c = lane & 15, rq = lane >> 4;
+  const int kb = wave & 1, qb = wave >> 1;
+  const int query = 16 * qb + c;
+  f32x4 st = {0, 0, 0, 0};
+  {
+    half8 akh[2], akl[2], bqh[2], bql[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      akh[s2] = *(const half8*)(kh + (16 * kb + c) * QROW + 32 * s2 + 8 * rq);
+      akl[s2] = *(const half8*)(kl + (16 * kb + c) * QROW + 32 * s2 + 8 * rq);
+      bqh[s2] = *(const half8*)(qh + query * QROW + 32 * s2 + 8 * rq);
+      bql[s2] = *(const half8*)(ql + query * QROW + 32 * s2 + 8 * rq);
+    }
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[0], bqh[0], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[1], bqh[1], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[0], bql[0], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[1], bql[1], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[0], bqh[0], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[1], bqh[1], st, 0, 0, 0);
+    RARC_MFMA_SETTLE(st);
+  }
+  float pr[4];
+  float tmax = -INFINITY;
+  {
+    const float4 ski = *(const float4*)(skinv + 16 * kb + 4 * rq);
+    const float fq = sqinv[query] * 0.125f;   // 1/sqrt(64) is a power of two
+    const float f[4] = {ski.x * fq, ski.y * fq, ski.z * fq, ski.w * fq};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int key = 16 * kb + 4 * rq + e;
+      float v = st[e] * f[e];
+      if (REL) {
+        int ri = key - query + rel_span - 1;
+        ri = ri < 0 ? 0 : (ri > 2 * rel_span - 2 ? 2 * rel_span - 2 : ri);
+        v += rel[(size_t)hd * (2 * rel_span - 1) + ri];
+      }
+      pr[e] = key < len ? v : -INFINITY;
+      tmax = fmaxf(tmax, pr[e]);
+    }
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+  if (rq == 0) smax[kb][query] = tmax;
+  __syncthreads();
+  const float m_all = fmaxf(smax[0][query], smax[1][query]);   // (key 0 is never masked: finite)
+  float psum = 0.f;
+  {
+    half4_t hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pe = (pr[e] == -INFINITY) ? 0.f : expf(pr[e] - m_all);
+      psum += pe;
+      half_t h_, l_;
+      e32a_split(pe * 2048.f, h_, l_);
+      hi[e] = h_; lo[e] = l_;
+    }
+    *(half4_t*)(ph + query * TROW + 16 * kb + 4 * rq) = hi;
+    *(half4_t*)(pl + query * TROW + 16 * kb + 4 * rq) = lo;
+  }
+  psum += __shfl_xor(psum, 16, 64);
+  psum += __shfl_xor(psum, 32, 64);
+  if (rq == 0) ssum[kb][query] = psum;
+  __syncthreads();
+  // ---- C: wave (qb, dpair = wave & 1): O^T blocks d = 16 db.. for db = 2 dpair, 2 dpair + 1, x queries 16qb.. ----
+  const int dpair = wave & 1;
+  const float inv_l = 0.00048828125f / (ssum[0][query] + ssum[1][query]);   // · 2^-11: p was split as p · 2^11
+  float cval[2][4];
+  float mo = 0.f;
+  {
+    const half8 bh = *(const half8*)(ph + query * TROW + 8 * rq), bl = *(const half8*)(pl + query * TROW + 8 * rq);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int db = 2 * dpair + i;
+      const half8 avh = *(const half8*)(vh + (16 * db + c) * TROW + 8 * rq), avl = *(const half8*)(vl + (16 * db + c) * TROW + 8 * rq);
+      f32x4 o = {0, 0, 0, 0};
+      o = __builtin_amdgcn_mfma_f32_16x16x32_f16(avl, bh, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_f16(avh, bl, o, 0, 0, 0);
+      o = __builtin_amdgcn_mfma_f32_16x16x32_f16(avh, bh, o, 0, 0, 0);
+      RARC_MFMA_SETTLE(o);
+      const float4 svi = *(const float4*)(svinv + 16 * db + 4 * rq);
+      cval[i][0] = o[0] * svi.x * inv_l; cval[i][1] = o[1] * svi.y * inv_l;
+      cval[i][2] = o[2] * svi.z * inv_l; cval[i][3] = o[3] * svi.w * inv_l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) mo = fmaxf(mo, fabsf(cval[i][e]));
+    }
+  }
+  mo = fmaxf(mo, __shfl_xor(mo, 16, 64));
+  mo = fmaxf(mo, __shfl_xor(mo, 32, 64));
+  if (rq == 0) somax[dpair][query] = mo;
+  __syncthreads();
+  // ---- epilogue: the (token, head) block of the output projection's operand, split under its own scale ----
+  float so, soinv;
+  e32_scale_of(fmaxf(somax[0][query], somax[1][query]), so, soinv);
+  const size_t mq = (size_t)b * L + query;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    half4_t hi, lo;
+    e32_split4(make_float4(cval[i][0], cval[i][1], cval[i][2], cval[i][3]), so, hi, lo);
+    half_t* dst = xq + e32_frag_offset(mq, hd * DH + 16 * (2 * dpair + i) + 4 * rq, H);
+    *(half4_t*)dst = hi;
+    *(half4_t*)(dst + 512) = lo;
+  }
+  if (dpair == 0 && rq == 0) {
+    rah[mq * n_heads + hd] = soinv;
+    if (hd == 0) ra_one[mq] = 1.f;
+  }
+}
+
 // pooling over fp32 hidden states: CLS row or the mean of the real tokens; optional canonical L2 normalisation
 __global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restrict__ hidden, const int32_t* __restrict__ lens,
                                                             int L, int H, int mean, int normalize, float* __restrict__ out) {
@@ -795,6 +1005,11 @@ __global__ __launch_bounds__(256) void rarc_e32_pool_kernel(const float* __restr
 struct E32SkinnyEpi {
   const float *ra = nullptr, *rw = nullptr, *bias = nullptr, *sg = nullptr;
   half_t* outq = nullptr;
+  // EPI 0 only — the activations were split under one scale per (token, group of `ks_per_group` k steps) instead of one per
+  // token (the query attention's per-head scales): wave_scale[token · n_groups + group] multiplies a wave's partial product
+  // before the slices are added.  A wave's k slice must lie inside one group (KR <= ks_per_group).
+  const float* wave_scale = nullptr;
+  int ks_per_group = 0, n_groups = 0;
 };
 
 template <int MT, int KR, int WAVES, int EPI>   // MT: 32-token blocks (M = 32·MT), KR: k steps (of 16) per wave
@@ -839,6 +1054,14 @@ __global__ __launch_bounds__(WAVES * 64) void rarc_e32_skinny_gemm_kernel(const 
       for (int i = 0; i < KR; ++i) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh[mb][i], acc[mb], 0, 0, 0);
     }
     RARC_MFMA_SETTLE(acc);
+    if (EPI == 0 && ep.wave_scale) {   // powers of two: exact
+#pragma unroll
+      for (int mb = 0; mb < MT; ++mb) {
+        const float ws = ep.wave_scale[(size_t)(mb * 32 + (lane & 31)) * ep.n_groups + ks0 / ep.ks_per_group];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mb][i] *= ws;
+      }
+    }
   }
   // lane (token = lane & 31, h = lane >> 5) holds features 8g + 4h + e in acc[4g + e]
   const int tok = lane & 31, h = lane >> 5;
@@ -901,29 +1124,41 @@ extern "C" int rarc_enc32_pack_query_weight(const uint16_t* d_w3, int n, int k, 
 
 #define E32Q_MAX_TOKENS 128   // the query path's largest forward
 #define E32Q_MAX_PARTS 16     // partial slabs a skinny product may come in
+#define E32Q_DEFAULT_WAVES 4  // waves per workgroup of the slab-writing weight stream (RARC_E32Q_WAVES overrides: A/B)
 
 // one skinny product: P[part][m][n] (part < *parts) = partial sums of A·Wᵀ over the part's k slices.  KR (k steps per wave) is
 // the largest of 8 / 4 / 2 that still gives the chip ~200 workgroups, bounded below by E32Q_MAX_PARTS slabs.
-static int e32_skinny_gemm(const uint16_t* xq, const uint16_t* wq, float* P, int m, int n, int k, int* parts, hipStream_t s) {
+static int e32_skinny_gemm(const uint16_t* xq, const uint16_t* wq, float* P, int m, int n, int k, int* parts, hipStream_t s,
+                           const float* wave_scale = nullptr, int ks_per_group = 0) {
   const int KS = k / 16, nb = n / 32, MT = m / 32;
   static const int force_kr = getenv("RARC_E32Q_KR") ? atoi(getenv("RARC_E32Q_KR")) : 0;   // (A/B: 8 / 4 / 2)
+  static const int waves_env = getenv("RARC_E32Q_WAVES") ? atoi(getenv("RARC_E32Q_WAVES")) : 0;   // (A/B: 4 / 8 waves per workgroup)
+  // waves per workgroup: 8 (two per SIMD) halves the number of partial slabs the consumer has to sum — the row passes and the
+  // attention read every slab — at the same number of loads in flight per wave
+  const int W = waves_env == 4 ? 4 : (waves_env == 8 ? 8 : E32Q_DEFAULT_WAVES);
   int kr = 8;
-  while (kr > 2 && nb * ((KS + 4 * kr - 1) / (4 * kr)) < 200) kr >>= 1;
+  // (measured flat, tools/r06_encq_ab.sh: 4 / 8 waves and KR 8 / 4 / 2 all land within 2 % of each other on a whole forward —
+  //  0.97 .. 1.00 ms for bge-large's single query; fewer, larger slices were the best of them, hence the low bar of ~100 workgroups)
+  while (kr > 2 && nb * ((KS + W * kr - 1) / (W * kr)) < 96) kr >>= 1;
   if (MT == 4 && kr > 4) kr = 4;                       // (registers: MT·KR fragments of activations are in flight)
   if (force_kr == 8 || force_kr == 4 || force_kr == 2) kr = (MT == 4 && force_kr > 4) ? 4 : force_kr;
-  while (kr < 8 && (KS + 4 * kr - 1) / (4 * kr) > E32Q_MAX_PARTS) kr <<= 1;
-  const int S = (KS + 4 * kr - 1) / (4 * kr);
+  while (kr < 8 && (KS + W * kr - 1) / (W * kr) > E32Q_MAX_PARTS) kr <<= 1;
+  if (wave_scale) while (kr > ks_per_group) kr >>= 1;      // a wave's slice inside one scale group
+  const int S = (KS + W * kr - 1) / (W * kr);
   RARC_REQUIRE(S <= E32Q_MAX_PARTS && (MT == 1 || MT == 2 || MT == 4) && (MT < 4 || kr <= 4), RARC_E_UNSUPPORTED,
                "fp32-class query path: product %d x %d x %d not supported", m, n, k);
   *parts = S;
   const dim3 grid(nb, S);
-  const E32SkinnyEpi none;
-#define E32Q_LAUNCH(MTV, KRV)                                                                                          \
-  hipLaunchKernelGGL((rarc_e32_skinny_gemm_kernel<MTV, KRV, 4, 0>), grid, dim3(256), 0, s, (const half_t*)wq, (const half_t*)xq, P, n, KS, m, none)
+  E32SkinnyEpi none;
+  none.wave_scale = wave_scale; none.ks_per_group = ks_per_group; none.n_groups = ks_per_group ? KS / ks_per_group : 0;
+#define E32Q_LAUNCH_W(MTV, KRV, WV)                                                                                    \
+  hipLaunchKernelGGL((rarc_e32_skinny_gemm_kernel<MTV, KRV, WV, 0>), grid, dim3(64 * WV), 0, s, (const half_t*)wq, (const half_t*)xq, P, n, KS, m, none)
+#define E32Q_LAUNCH(MTV, KRV) do { if (W == 8) E32Q_LAUNCH_W(MTV, KRV, 8); else E32Q_LAUNCH_W(MTV, KRV, 4); } while (0)
   if (MT == 1) { if (kr == 8) E32Q_LAUNCH(1, 8); else if (kr == 4) E32Q_LAUNCH(1, 4); else E32Q_LAUNCH(1, 2); }
   else if (MT == 2) { if (kr == 8) E32Q_LAUNCH(2, 8); else if (kr == 4) E32Q_LAUNCH(2, 4); else E32Q_LAUNCH(2, 2); }
   else { if (kr == 4) E32Q_LAUNCH(4, 4); else E32Q_LAUNCH(4, 2); }
 #undef E32Q_LAUNCH
+#undef E32Q_LAUNCH_W
   RARC_HIP_CHECK(hipGetLastError());
   return RARC_OK;
 }
@@ -1015,7 +1250,8 @@ extern "C" size_t rarc_enc32_workspace_bytes(int hidden, int inter, int n_tokens
          + e32_align(M * 3 * I * 2)    // split image of the GELU output
          + e32_align(M * wide * 4 * e32_p_slabs(M))   // raw GEMM products (small batches: split-K partial slabs; the query path's come in up to sixteen)
          + 2 * e32_align(M * 4)        // row scales
-         + e32_align(2 * M * 4);       // fused FFN1: output scales and their inverses
+         + e32_align(2 * M * 4)        // fused FFN1: output scales and their inverses
+         + e32_align(M * 16 * 4);      // query path: the attention output's inverse scale per (token, head)
 }
 
 extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_ids, const int32_t* d_lens, int n_seq,
@@ -1051,7 +1287,8 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
   float* P = (float*)w;                 w += e32_align((size_t)M * wide * 4 * p_slabs);
   float* ra_a = (float*)w;              w += e32_align((size_t)M * 4);
   float* ra_b = (float*)w;              w += e32_align((size_t)M * 4);
-  float* sg = (float*)w;                                                       // fused FFN1: [M] scales | [M] inverses
+  float* sg = (float*)w;                w += e32_align((size_t)2 * M * 4);     // fused FFN1: [M] scales | [M] inverses
+  float* rah = (float*)w;                                                      // query path: [M][heads] inverse scales of the attention output
   const float eps = model->ln_eps;
 
   hipLaunchKernelGGL(rarc_e32_embed_kernel, dim3(M), dim3(256), 0, hs, d_ids, model->word, model->pos, model->type0,
@@ -1083,7 +1320,18 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     hipLaunchKernelGGL((rarc_e32_attention_kernel<DHV, RELV>), dim3((n_units + 3) / 4), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw, \
                        Ly.qkv_b, d_lens, seq_len, H, model->heads, q_blocks, n_units, ctx, model->rel_bias, model->rel_span,     \
                        qkv_parts, (size_t)M * 3 * H)
-    if (H == model->heads * 64 && split_attention) {
+    // the query path's own attention (sequences of 32 padded tokens, head_dim 64): one wave per (sequence, head), the split
+    // image of its output written in place of the row pass below; RARC_E32Q_ATTN=0 keeps the document kernel + the row pass
+    const char* qa_env = getenv("RARC_E32Q_ATTN");
+    const bool query_attn = query && seq_len == 32 && H == model->heads * 64 && model->heads <= 16 && !(qa_env && atoi(qa_env) == 0);
+    if (query_attn) {
+#define E32Q_ATTN_LAUNCH(RELV)                                                                                               \
+      hipLaunchKernelGGL((rarc_e32q_attention_kernel<RELV>), dim3(n_seq * model->heads), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw,   \
+                         Ly.qkv_b, d_lens, H, model->heads, (half_t*)xs, rah, ra_b, model->rel_bias, model->rel_span, qkv_parts, \
+                         (size_t)M * 3 * H)
+      if (model->rel_bias) E32Q_ATTN_LAUNCH(true); else E32Q_ATTN_LAUNCH(false);
+#undef E32Q_ATTN_LAUNCH
+    } else if (H == model->heads * 64 && split_attention) {
       const int q_groups = (q_blocks + 3) / 4;
 #define E32_SPLIT_LAUNCH(RELV)                                                                                               \
       hipLaunchKernelGGL((rarc_e32_attention_split_kernel<RELV>), dim3(n_seq * model->heads * q_groups), dim3(256), 0, hs, P, ra_a, \
@@ -1101,9 +1349,12 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     const bool fuse_gelu = fuse_shape && Ly.f1_colmax != nullptr;
     E32Fuse fz2 = fq;
     if (fuse_gelu) { fz2.colmax = Ly.f1_colmax; fz2.k = H; fz2.sg_out = sg; fz2.sg_rows = (size_t)M; }
-    if ((rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs, 1, fq))) return rc;
+    if (!query_attn && (rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs, 1, fq)))
+      return rc;
     // attention output projection -> x = LayerNorm(proj + x)
-    if ((rc = E32_PROJ(xs, Ly.o_w3, Ly.o_wq, H, H, max_parts)) != RARC_OK) return rc;
+    if (query_attn) rc = e32_skinny_gemm(xs, Ly.o_wq, P, M, H, H, &parts, hs, rah, 4);   // (per-head scales: 4 k steps = 64 dims)
+    else rc = E32_PROJ(xs, Ly.o_w3, Ly.o_wq, H, H, max_parts);
+    if (rc != RARC_OK) return rc;
     if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs, parts, fz2))) return rc;
     // FFN: the first projection with bias + GELU + split fused into its epilogue where the shape allows (big batches),
     // else the fp32 product and a row pass

@@ -766,7 +766,7 @@ class FlatIndexF16:
     def _pipeline_context(self, k: int):
         if self._parent is not None or self._own_stream is not None or os.environ.get("RARC_PIPELINE", "1") == "0":
             return None
-        if self._use_q8(k) or self.ntotal < self.PIPELINE_MIN_ROWS:
+        if self.ntotal < self.PIPELINE_MIN_ROWS or (self._use_q8(k) and os.environ.get("RARC_PIPELINE_Q8", "0") != "1"):
             return None
         pair = self.__dict__.get("_pair")
         if pair is None or pair[0]._parent_version != self._version:
