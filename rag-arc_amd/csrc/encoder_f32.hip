@@ -122,8 +122,19 @@ __device__ __forceinline__ void e32_store_split(const E32Row<NV>& r, int n, half
 }
 
 // LayerNorm of the row in place (two-pass fp32 statistics, population variance, 1/sqrt exact-rounded)
+// gamma / beta (and whatever else a row pass multiplies the normalised row with) are fetched by the CALLER in front of its
+// first dependent load: behind the two block reductions' barriers the loads would be one more round trip to L2 on the critical
+// path of a pass that is nothing but latency at 32 rows (the query path)
 template <int NV>
-__device__ __forceinline__ void e32_layernorm(E32Row<NV>& r, int n, const float* gamma, const float* beta, float eps,
+__device__ __forceinline__ void e32_load_row_params(const float* p, int n, float4 (&out)[NV]) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (threadIdx.x + 256 * i) * 4;
+    out[i] = c < n ? *(const float4*)(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int NV>
+__device__ __forceinline__ void e32_layernorm(E32Row<NV>& r, int n, const float4 (&gam)[NV], const float4 (&bet)[NV], float eps,
                                               float* slot) {
   float s = 0.f;
 #pragma unroll
@@ -143,7 +154,7 @@ __device__ __forceinline__ void e32_layernorm(E32Row<NV>& r, int n, const float*
   for (int i = 0; i < NV; ++i) {
     const int c = (threadIdx.x + 256 * i) * 4;
     if (c < n) {
-      const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+      const float4 g = gam[i], b = bet[i];
       r.v[i].x = (r.v[i].x - mean) * rstd * g.x + b.x;
       r.v[i].y = (r.v[i].y - mean) * rstd * g.y + b.y;
       r.v[i].z = (r.v[i].z - mean) * rstd * g.z + b.z;
@@ -208,6 +219,13 @@ __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const
   const size_t m = blockIdx.x;
   E32Row<NV> r;
   const float ram = MODE == 3 ? 1.f : ra[m];
+  float4 gam[NV], bet[NV], cmx[NV];
+  float cm_last = 0.f;
+  if (MODE == 2) {
+    e32_load_row_params<NV>(gamma, n, gam);
+    e32_load_row_params<NV>(beta, n, bet);
+    if (fz.colmax) { e32_load_row_params<NV>(fz.colmax, n, cmx); cm_last = fz.colmax[fz.k]; }
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (threadIdx.x + 256 * i) * 4;
@@ -228,19 +246,19 @@ __global__ __launch_bounds__(256) void rarc_e32_epi_kernel(const float* P, const
       r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  if (MODE == 2) e32_layernorm<NV>(r, n, gamma, beta, eps, slot);
+  if (MODE == 2) e32_layernorm<NV>(r, n, gam, bet, eps, slot);
   if (MODE == 2 && fz.colmax) {   // the scale FFN1's fused epilogue will split gelu(.) of this row with
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (threadIdx.x + 256 * i) * 4;
       if (c < n) {
-        const float4 cm = *(const float4*)(fz.colmax + c);
+        const float4 cm = cmx[i];
         q += (fabsf(r.v[i].x) * cm.x + fabsf(r.v[i].y) * cm.y) + (fabsf(r.v[i].z) * cm.z + fabsf(r.v[i].w) * cm.w);
       }
     }
     const float l1 = e32_block_sum(q, slot);   // (slot[0..3]: every thread is past the LayerNorm's second barrier)
-    const float bound = l1 * 1.0001f + fz.colmax[fz.k];   // (1e-4: the rounding of the 1024-term sum, with room)
+    const float bound = l1 * 1.0001f + cm_last;   // (1e-4: the rounding of the 1024-term sum, with room)
     float sgs, sgi;
     e32_scale_of(bound, sgs, sgi);
     if (threadIdx.x == 0) {
@@ -279,7 +297,10 @@ __global__ __launch_bounds__(256) void rarc_e32_embed_kernel(const int32_t* __re
   } else {
     r.v[0] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  e32_layernorm<1>(r, H, gamma, beta, eps, slot);
+  float4 gam[1], bet[1];
+  e32_load_row_params<1>(gamma, H, gam);
+  e32_load_row_params<1>(beta, H, bet);
+  e32_layernorm<1>(r, H, gam, bet, eps, slot);
   if (c < H) *(float4*)(out32 + t * H + c) = r.v[0];
   e32_store_split<1>(r, H, frag ? out3 : out3 + t * 3 * H, ra_out + t, slot + 8, frag, t);
 }
