@@ -966,7 +966,8 @@ def leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank, rows=
     """storage="f32": the reference's own row format (fp32 rows in faiss, VectorStore_Faiss.py:170) — the one mode whose
     scores sit within north_star's 1e-5 of the float64 cosine on ARBITRARY fp32 embeddings (tests/test_gpu_storage_precision.py).
     The scan streams the rows' fp16 image (2 bytes per element, int8 prefilter with the image's own error bound added to
-    the margin); survivors are rescored canonically from the fp32 rows.  10M x 768, batch 256, k = 100."""
+    the margin); survivors are rescored canonically from the fp32 rows.  Round 6: at the size ONE GPU HOLDS — 45M x 768 = 138 GB of
+    fp32 rows + 69 GB of image (main() frees the other corpora first) —, batch 256, k = 100, 32 answers re-scanned exhaustively."""
     idx = FlatIndexF16(a.dim, metric="cosine", device=local_rank, storage="f32", capacity=rows)
     slab = 1 << 20
     buf = torch.empty((slab, a.dim), dtype=torch.float32, device=dev)
@@ -980,7 +981,7 @@ def leg_f32(torch, dist, lib, B, ctypes, FlatIndexF16, a, dev, local_rank, rows=
     del buf
     q = torch.empty((a.batch, a.dim), dtype=torch.float32, device=dev)
     B.check(lib.rarc_synth_rows_f32(q.data_ptr(), a.dim, a.dim, 0, a.batch, 4321, 0), "rarc_synth_rows_f32")
-    steps, warm = max(a.steps, 20), max(a.warmup, 3)
+    steps, warm = max(a.steps, 30), max(a.warmup, 10)   # (the leg runs behind config 5's encoder: ten batches to settle the clocks)
     passes = (a.batch + 255) // 256
     (dt, (ids, sc)), tot, nl = scan_profile(
         lib, B, ctypes,

@@ -1,6 +1,6 @@
 """Save / load of a corpus-scale shard in a FRESH process, with the host memory high-water mark taken from /proc.
 
-usage: python tools/lab/persist_probe.py --rows 10000000 --dim 768 --storage f16 --dir /tmp/x [--threads 8] [--no-direct]
+usage: python tools/persist_probe.py --rows 10000000 --dim 768 --storage f16 --dir /tmp/x [--threads 8] [--no-direct]
 Prints one JSON line: rows, bytes, save / load seconds and GB/s (native transfer phase and wall), VmHWM before / after
 (kB), whether the search after the load equals the search before it bit for bit, and the exhaustive on-device check of a
 query sample against the loaded rows (rarc_verify_batch: rows beating a k-th entry, answer entries that are not exact
@@ -12,7 +12,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 

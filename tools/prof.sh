@@ -7,6 +7,8 @@
 #                                        bench line + per-kernel trace (12500000 / 25000000 / 50000000 = 100M over 8 / 4 / 2 GPUs)
 #   tools/prof.sh pmc <rows> <dim> <f16|f8> [counters...]   a --pmc pass of the scan alone (tools/gpu_scan_only.py; own run, no
 #                                        trace options next to --pmc); default counter FETCH_SIZE -> HBM bytes per launch
+#   tools/prof.sh c2                     config 2 alone (1M x 768, two pipelined search contexts): bench line + per-kernel trace
+#   tools/prof.sh encq                   the encoder's query path: parity tests, latency against the tile kernels, per-kernel trace (tools/r06_encq.sh)
 #   tools/prof.sh api                    the plugin-surface legs only (bench.py `api` object)
 #   tools/prof.sh wide                   the wide-row leg (10M x 1536) with a kernel trace
 #   tools/prof.sh pairs                  the all-pairs cosine leg (100k x 1024 entities) with a kernel trace
@@ -33,6 +35,13 @@ case $what in
     export PROBE_ROWS=${1:-100000000} PROBE_DIM=${2:-768} PROBE_STORAGE=${3:-f16} PROBE_ITERS=3; shift; shift; shift
     timeout 900 rocprofv3 --pmc ${@:-FETCH_SIZE} -d "$O/pmc" -- python3 tools/gpu_scan_only.py > "$O/pmc.log" 2>&1
     python3 tools/pmc_summary.py "$O/pmc" all | tee "$O/pmc_summary.txt" | grep -i scan | head -6;;
+  c2)
+    timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --rows 1000000 --steps 400 --warmup 20 $QUIET --verify-queries 32 "$@" > "$O/c2.json" 2> "$O/c2.err"
+    stats "$O/kt" 12
+    python3 -c "import json; j=json.load(open('$O/c2.json')); print('C2 (profiled): ms/step', j['ms_per_step'], j['config']['full_size_check'])"
+    timeout 600 python3 bench.py --rows 1000000 --steps 400 --warmup 20 $QUIET --verify-queries 32 "$@" 2>/dev/null > "$O/c2_unprofiled.json"
+    python3 -c "import json; j=json.load(open('$O/c2_unprofiled.json')); print('C2 (unprofiled): ms/step', j['ms_per_step'], 'q/s', j['value'])";;
+  encq)  tools/r06_encq.sh;;
   api)   timeout 900 python3 bench.py --no-c3 --no-c5 --no-persist --no-ingest --no-f32 --no-wide --no-pairs "$@" > "$O/api.json" 2> "$O/api.err"; python3 -c "import json; print(json.dumps(json.load(open('$O/api.json'))['api'], indent=1))";;
   wide)  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/kt" -- python3 bench.py --rows 1000000 --no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-pairs --no-cpu-baseline --verify-queries 8 "$@" > "$O/wide.json" 2> "$O/wide.err"; stats "$O/kt" 10; python3 -c "import json; print(json.dumps(json.load(open('$O/wide.json'))['wide']))";;
   f32)   timeout 900 python3 bench.py --rows 1000000 --no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-wide --no-pairs --no-cpu-baseline --verify-queries 8 "$@" > "$O/f32.json" 2> "$O/f32.err"; python3 -c "import json; print(json.dumps(json.load(open('$O/f32.json'))['f32']))";;
