@@ -353,8 +353,8 @@ def scan_profile(lib, B, ctypes, fn, max_launches):
 
 
 def recorded_traffic(kernel, rows_per_launch, dim, storage="f16"):
-    """HBM bytes per scan from the committed PMC pass of the same shape (profiles/traffic_r05.json, falling back to the earlier rounds' files), or None."""
-    for name in ("traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
+    """HBM bytes per scan from the committed PMC pass of the same shape (profiles/traffic_r06.json, falling back to the earlier rounds' files), or None."""
+    for name in ("traffic_r06.json", "traffic_r05.json", "traffic_r04.json", "traffic_r03.json", "traffic_r02.json", "traffic_r01.json"):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             continue

@@ -399,6 +399,13 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
   // group B (waves 4-7) runs prune(t-1) then MFMA(t).  Each wave's VALU/LDS/VMEM epilogue thus
   // overlaps its SIMD partner's MFMA stream instead of idling the matrix pipe.
   const bool grp_b = wave >= SCAN_WAVES / 2;
+  // Round 6 — a wave whose 32 queries all lie at or beyond nq (zero rows of the query block) has nothing to multiply: its
+  // scores are zeros whatever the tile holds, and nobody reads them (the finalize runs nq workgroups).  It skips the MFMA
+  // chain and the pruning and keeps its part of the staging — DMA pieces, barriers, threshold traffic — exactly as it was, so
+  // the vector-memory order the waits count on does not change.  The reference's own call is ONE query (VectorStore_Faiss.py:
+  // 258-263): seven of the eight waves then leave the matrix pipe alone and the kernel runs at what HBM delivers
+  // instead of at the power-limited MFMA rate of a 256-query batch.  Same bits for every real query.
+  const bool idle_wave = (uint32_t)wave * 32u >= p.nq;
   uint32_t prev = 0xffffffffu;  // group B: tile whose scores are still in acc
 #if SCAN_MMA16
   f32x4 acc[4];
@@ -449,19 +456,19 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     // on its own, so the wave that is OUTSIDE its chain does the vector-memory issue (it may block on a full queue without
     // costing a matrix slot).  Group B: prune(t-1), DMA(t+2), MFMA(t); group A: MFMA(t), prune(t), DMA(t+2).  Pruning first
     // keeps its stores OLDER than the pieces, so "at most DPW outstanding" at the next barrier asks for nothing but DMA(t+1).
-    if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
+    if (!(ABL & 1) && !idle_wave && grp_b && prev != 0xffffffffu) prune(acc, prev);
     if (issued && (grp_b || (ABL & 4))) issue(nb, dma_tile);
     RARC_STAMP(1)
 #else
     if (issued && ((grp_b && !SCAN_DMA_B_INLOOP) || (ABL & 4))) issue(nb, dma_tile);  // group B (it prunes first anyway)
     RARC_STAMP(1)
     // group B prunes the PREVIOUS tile now, while group A (same SIMDs) already streams MFMAs
-    if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
+    if (!(ABL & 1) && !idle_wave && grp_b && prev != 0xffffffffu) prune(acc, prev);
 #endif
 
     // ---- 32 rows x 32 queries per wave: KS chained MFMAs fed by a 6-deep LDS read ring ----
 #if SCAN_MMA16
-    if (ABL & 4) {
+    if ((ABL & 4) || idle_wave) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { acc[j] = (f32x4){0}; asm volatile("" : "+v"(acc[j])); }
     } else {
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       RARC_STAMP(3)
     }
 #else
-    if (ABL & 4) {
+    if ((ABL & 4) || idle_wave) {
       acc = (f32x16){0};
       asm volatile("" : "+v"(acc));
     } else {
@@ -489,7 +496,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
       RARC_STAMP(3)
     }
 #endif
-    if (!(ABL & 1)) {  // group A prunes this tile right away; group B defers it to the next iteration
+    if (!(ABL & 1) && !idle_wave) {  // group A prunes this tile right away; group B defers it to the next iteration
       if (!grp_b) prune(acc, cur);
       else prev = cur;
     }
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     }
 #endif
   }
-  if (!(ABL & 1) && grp_b && prev != 0xffffffffu) prune(acc, prev);
+  if (!(ABL & 1) && !idle_wave && grp_b && prev != 0xffffffffu) prune(acc, prev);
   __syncthreads();
   if ((ABL & 64) && blockIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
