@@ -471,6 +471,8 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     if ((ABL & 4) || idle_wave) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { acc[j] = (f32x4){0}; asm volatile("" : "+v"(acc[j])); }
+      // (an idle wave of group A still owes the tile its DMA pieces: a working wave issues them from inside its MFMA chain)
+      if (idle_wave && !(ABL & 4) && !SCAN_DMA_OUTSIDE && issued && (SCAN_DMA_B_INLOOP || !grp_b)) issue(nb, dma_tile);
     } else {
       half8 ra[SCAN_RING16], rb[SCAN_RING16];
       if (ABL & 32) __builtin_amdgcn_s_setprio(1);
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(SCAN_WAVES * 64, 2) void rarc_scan_f16_kernel(const
     if ((ABL & 4) || idle_wave) {
       acc = (f32x16){0};
       asm volatile("" : "+v"(acc));
+      if (idle_wave && !(ABL & 4) && !SCAN_DMA_OUTSIDE && issued && (SCAN_DMA_B_INLOOP || !grp_b)) issue(nb, dma_tile);
     } else {
       half8 rg[SCAN_RING];
       if (ABL & 32) __builtin_amdgcn_s_setprio(1);
