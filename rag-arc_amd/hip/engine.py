@@ -915,14 +915,18 @@ class FlatIndexF16:
         """Enqueue one batch and return at once; `.result()` later performs the status read-back (and the rare
         repair).  Lets a caller keep the GPU queue full: launch batch i+1, then collect batch i.  Results are
         identical to search_device().  More than 256 queries are enqueued as consecutive 256-query launches.
-        to_host=True also enqueues the copy of the answer into pinned host memory RIGHT BEHIND the search — ahead of
-        whatever the caller enqueues next on this stream — so that `.host()` waits for this batch only."""
+        to_host=True: the answer is written into pinned host memory by the search's own finalize kernel — `.host()` /
+        `.host_view()` wait for this batch only and no device copy of the answer exists (`.result()` of such a handle returns
+        the pinned host tensors)."""
         t = self.torch
         if k < 1:
             raise ValueError("k out of range")
         if self._takes_wide_path(k):       # (the wide path runs to completion: its handle is born finished)
             return _FinishedSearch(self, *self.search_device(queries, k))
-        ctx = self._pipeline_context(k)
+        # (answers bound for the host — the store's batch calls — keep ONE context: behind them the time is python's (mapping
+        #  25,600 Documents per batch), a second context only adds its bookkeeping: 1M rows, batch_invoke 266 k vs 258 k q/s,
+        #  2048 queries in one call 218 k vs 185 k, tools/r06_api_ab.sh)
+        ctx = None if to_host else self._pipeline_context(k)
         if ctx is not None:
             return ctx.search_async(queries, k, to_host)
         self._check_twin()
@@ -937,12 +941,20 @@ class FlatIndexF16:
             if q.ndim != 2 or q.shape[1] != self.dim or q.shape[0] < 1:
                 raise ValueError(f"expected [nq][{self.dim}] queries, got {tuple(q.shape)}")
             nq = q.shape[0]
-            out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
-            out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
             parts = []
             # the answer's pinned staging slot belongs to the handle returned below until it is released / dies
             slot = self._pins.acquire(t, nq, k) if to_host else None
             h_ids, h_sc = slot.views(nq, k) if to_host else (None, None)
+            if to_host:
+                # to_host=True: the finalize kernel writes the answer STRAIGHT into the pinned slot (pinned host memory is
+                # device-addressable): no device copy of it exists and no copy launches follow the search — behind a
+                # neighbouring context's persistent scan a blit kernel does not get a CU until that scan ends, which held
+                # chunk i's answer back until chunk i+1 had been scanned (2048 queries in one call: 1.55 ms per chunk where
+                # a lone chunk takes 1.05).  result() of such a handle returns these pinned (host) tensors.
+                out_ids, out_sc = h_ids, h_sc
+            else:
+                out_ids = t.empty((nq, k), dtype=t.int64, device=self.device)
+                out_sc = t.empty((nq, k), dtype=t.float32, device=self.device)
             for s0 in range(0, nq, B.MAX_QUERIES):
                 e0 = min(nq, s0 + B.MAX_QUERIES)
                 # this launch's own status words (zeroed by its query-prep kernel) and its one any-flag word in pinned host
@@ -953,9 +965,6 @@ class FlatIndexF16:
                 gate = self._partner._fin_event if (self._partner is not None and _PIPELINE_GATE) else None
                 self._search_chunk(q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], repair=False, status=status,
                                    flag_host=flag_h.data_ptr(), gate=gate.cuda_event if gate is not None else 0)
-                if to_host:
-                    h_ids[s0:e0].copy_(out_ids[s0:e0], non_blocking=True)
-                    h_sc[s0:e0].copy_(out_sc[s0:e0], non_blocking=True)
                 done = t.cuda.Event()
                 done.record()
                 self._fin_event = done
@@ -1314,7 +1323,7 @@ class PendingSearch:
                  slot=None):
         self.index, self.q, self.k, self.ids, self.scores, self.flag, self.status = index, q, k, ids, scores, flag, status
         self.cand_cap = cand_cap   # the candidate capacity this batch was launched with
-        self.host_copy = host   # (ids, scores) pinned tensors the answer was copied into behind the search (to_host=True)
+        self.host_copy = host   # (ids, scores) pinned tensors the finalize kernel wrote the answer into (to_host=True)
         self.slot = slot        # the _PinSlot those tensors are views of: ours (shared with the sibling launches of one call)
         self.done = done        # event recorded behind the copy of the status word into pinned memory (`flag`)
         self.stream = stream    # the stream the search was enqueued on (a twin's side stream, else the caller's)
@@ -1358,8 +1367,14 @@ class PendingSearch:
                                       "repaired against the rows it scanned (collect results before add() / reset())")
                 stream = self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)
                 with self.index._lock, t.cuda.device(self.index.device), t.cuda.stream(stream):
-                    self.index._repair_rows(self.q, self.k, self.ids, self.scores, self.repaired,
+                    host_direct = not self.ids.is_cuda        # (to_host=True: the answer sits in pinned memory only)
+                    ids = self.ids.to(self.index.device) if host_direct else self.ids
+                    scores = self.scores.to(self.index.device) if host_direct else self.scores
+                    self.index._repair_rows(self.q, self.k, ids, scores, self.repaired,
                                             words=[words[i] for i in self.repaired], launched_with=self.cand_cap)
+                    if host_direct:                          # the repaired rows go back where the caller reads them
+                        self.ids.copy_(ids)
+                        self.scores.copy_(scores)
                     stream.synchronize()
             self.index.last_repaired = self.repaired
             if self.index._parent is not None:      # (a pipelined context of the index the caller holds)
@@ -1372,18 +1387,17 @@ class PendingSearch:
         handle dies, whichever comes first; nothing else can be handed that memory meanwhile.  A repaired batch — rare — is
         copied again (and then owns its arrays)."""
         ids, scores = self.result()
-        if self.host_copy is not None and not self.repaired:
+        if self.host_copy is not None:          # (written by the finalize kernel itself; a repair wrote its rows back too)
             return self.host_copy[1].numpy(), self.host_copy[0].numpy()
         t = self.index.torch
         with t.cuda.stream(self.stream if self.stream is not None else t.cuda.current_stream(self.index.device)):
             return self.index.to_host(ids, scores)
 
     def host(self):
-        """result() as numpy arrays the caller owns.  With to_host=True the copy to pinned memory was enqueued behind the
-        search and is complete once the batch's event is (nothing later on the stream is waited for); the staging slot is
-        released here."""
+        """result() as numpy arrays the caller owns.  With to_host=True the answer is in pinned memory once the batch's event
+        is complete (nothing later on the stream is waited for); the staging slot is released here."""
         scores, ids = self.host_view()
-        if self.host_copy is not None and not self.repaired:
+        if self.host_copy is not None:
             scores, ids = scores.copy(), ids.copy()
         self.release()
         return scores, ids
@@ -1418,7 +1432,7 @@ class PendingBatches:
 
     def host_view(self):
         ids, scores = self.result()
-        if self.host_copy is not None and not self.repaired:
+        if self.host_copy is not None:
             return self.host_copy[1].numpy(), self.host_copy[0].numpy()
         p = self.parts[0]
         t = p.index.torch
@@ -1427,7 +1441,7 @@ class PendingBatches:
 
     def host(self):
         scores, ids = self.host_view()
-        if self.host_copy is not None and not self.repaired:
+        if self.host_copy is not None:
             scores, ids = scores.copy(), ids.copy()
         self.release()
         return scores, ids
