@@ -880,6 +880,9 @@ int rarc_scan_q8_launch(const void* corpus, const float* rowscale, int fmt, int6
   RARC_HIP_CHECK(hipGetDevice(&dev));
   RARC_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   int grid = cus < RARC_MAX_WG ? cus : RARC_MAX_WG;
+  // RARC_SCAN_Q8_WGS=n: fewer persistent workgroups than CUs — the CUs left free are where a neighbouring search context's
+  // finalize (153 KB of LDS: it cannot share a CU with a scan workgroup) runs UNDER this scan (engine.py)
+  if (const char* e = getenv("RARC_SCAN_Q8_WGS")) { const int g = atoi(e); if (g >= 8 && g < grid) grid = g; }
   if ((uint32_t)grid > p.n_tiles) grid = (int)p.n_tiles;
   *grid_out = grid;
   auto launch = [&](const ScanQ8Params& pp) {
