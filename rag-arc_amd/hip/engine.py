@@ -795,6 +795,14 @@ class FlatIndexF16:
     def search(self, queries, k: int, repair: bool = True) -> Tuple[np.ndarray, np.ndarray]:
         """index.search: returns (scores fp32 [nq][k], ids int64 [nq][k]) like faiss (D, I);
         entries beyond ntotal are (-inf, -1)."""
+        if k < 1:
+            raise ValueError("k must be >= 1")
+        if repair and self.ntotal and not self._takes_wide_path(k):
+            # the answer lands in pinned memory straight from the finalize kernel (search_async(to_host=True)): no device
+            # copy of it, no copy launches, one event to wait for — what a single embed_query + search call pays per query
+            t = self.torch
+            q = t.as_tensor(queries, dtype=t.float32)
+            return self.search_async(q[None, :] if q.ndim == 1 else q, k, to_host=True).host()
         ids, scores = self.search_device(queries, k, repair=repair)
         return self.to_host(ids, scores)
 
