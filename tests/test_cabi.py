@@ -42,6 +42,25 @@ def test_argument_validation_needs_no_gpu():
         raise AssertionError("check() must raise")
 
 
+def test_round6_entries_validate_their_arguments_without_a_gpu():
+    """rarc_search_batch, rarc_enc32_pack_query_weight, rarc_stream_read (ABI 600): bad arguments come back as error codes with a
+    message before anything touches the device."""
+    import ctypes
+
+    lib = B.load_library()
+    assert lib.rarc_version() == 600
+    assert lib.rarc_search_batch(None, None) == -1 and b"null descriptor" in lib.rarc_last_error()
+    bad = B.SearchBatch()                      # all zeros: row_format 0, no status buffer
+    assert lib.rarc_search_batch(ctypes.byref(bad), None) == -1 and b"null status" in lib.rarc_last_error()
+    bad.row_format = 9
+    assert lib.rarc_search_batch(ctypes.byref(bad), None) == -1 and b"row_format" in lib.rarc_last_error()
+    assert lib.rarc_enc32_pack_query_weight(None, 32, 128, None, None) == -1
+    assert lib.rarc_enc32_pack_query_weight(ctypes.c_void_p(16), 33, 128, ctypes.c_void_p(16), None) == -4      # n not a multiple of 32
+    assert lib.rarc_enc32_pack_query_weight(ctypes.c_void_p(16), 32, 100, ctypes.c_void_p(16), None) == -4      # k not a multiple of 128
+    assert lib.rarc_stream_read(None, 1 << 20, None, None) == -1
+    assert lib.rarc_stream_read(ctypes.c_void_p(8), 1 << 20, ctypes.c_void_p(16), None) == -1                    # source not 16-byte aligned
+
+
 def test_engine_refuses_to_run_without_a_gpu():
     import pytest
     import torch
