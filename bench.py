@@ -94,8 +94,8 @@ def parse(argv=None):
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=100)
-    ap.add_argument("--storage", choices=("f16", "f8"), default="f16",
-                    help="row storage: fp16 (default) or fp8 e4m3fn + per-row scale (BASELINE config 5)")
+    ap.add_argument("--storage", choices=("f16", "f8", "f32"), default="f16",
+                    help="row storage: fp16 (default), fp8 e4m3fn + per-row scale (BASELINE config 5) or fp32 (the reference's own row format: the one mode inside 1e-5 on arbitrary embeddings)")
     ap.add_argument("--shadow", action="store_true",
                     help="keep the int8 image of the fp16 rows (+50%% HBM): the prefilter scan reads it instead")
     ap.add_argument("--scan", choices=("auto", "q8", "mfma16"), default="auto",
@@ -290,8 +290,8 @@ def dry_run(a) -> None:
 def build_index(torch, lib, B, FlatIndexF16, dev_index, dim, lo, hi, seed=1234, scan="auto", storage="f16", shadow=False):
     """HBM-resident shard holding global rows [lo, hi) of the synthetic corpus."""
     n = hi - lo
-    if storage == "f8":  # synthetic fp32 rows -> ingest kernel (normalise, per-row scale, e4m3fn), in slabs
-        idx = FlatIndexF16(dim, metric="cosine", device=dev_index, id_base=lo, storage="f8", capacity=n)
+    if storage in ("f8", "f32"):  # synthetic fp32 rows -> ingest kernel (normalise; e4m3fn + row scale, or fp32 + fp16 image), in slabs
+        idx = FlatIndexF16(dim, metric="cosine", device=dev_index, id_base=lo, storage=storage, capacity=n)
         slab = 1 << 20
         buf = torch.empty((min(slab, max(n, 1)), dim), dtype=torch.float32, device=torch.device("cuda", dev_index))
         for s0 in range(0, n, slab):
@@ -432,12 +432,13 @@ def main():
     lib = B.load_library()
     measure_hbm_peak(torch, lib, B, dev)      # (every rank: their work stays symmetric; HBM_MEASURED feeds every hbm roofline below)
     d_pad = B.padded_dim(a.dim, 256 if a.storage == "f8" else 128)
-    esize = 1 if a.storage == "f8" else 2
+    esize = 1 if a.storage == "f8" else 2               # bytes per element the SCAN streams (fp32 rows: their fp16 image)
+    held = 6 if a.storage == "f32" else esize            # bytes per element the index holds in HBM
     rows = a.rows
     if rows <= 0:  # auto: config 4's corpus if every rank's shard (+ slack) fits its HBM
         free = torch.cuda.mem_get_info(dev)[0]
         rows = 100_000_000
-        while rows > 1_000_000 and (rows / world) * d_pad * (esize + (1 if a.shadow else 0)) > 0.85 * free:
+        while rows > 1_000_000 and (rows / world) * d_pad * (held + (1 if a.shadow else 0)) > 0.85 * free:
             rows //= 10
     lo, hi = shard_range(rows, rank, world)
     idx = build_index(torch, lib, B, FlatIndexF16, local_rank, a.dim, lo, hi, scan=a.scan, storage=a.storage,
@@ -512,7 +513,7 @@ def main():
         traffic, tsrc = recorded_traffic(kname, hi - lo, a.dim, a.storage)
         if traffic:
             traffic = int(traffic / launches_per_pass)
-        store_txt = "fp8 (e4m3fn + row scale)" if a.storage == "f8" else "fp16"
+        store_txt = {"f8": "fp8 (e4m3fn + row scale)", "f32": "fp32 (+ fp16 image for the scan)"}.get(a.storage, "fp16")
         result = {
             "metric": "queries/sec at fixed (N_corpus, d), exact top-k (ids bit-exact vs CPU oracle)",
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
