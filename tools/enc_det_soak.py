@@ -10,7 +10,10 @@ H, heads, I, layers = 768, 12, 3072, 4
 L, NSEQ = int(os.environ.get("SOAK_LEN", 192)), int(os.environ.get("SOAK_SEQS", 48))   # 128 x 256: FFN1 takes the fused-GELU GEMM
 sd = cpu_ref.random_bert_state_dict(H, layers, heads, I, vocab=2000, max_pos=L, seed=13)
 rng = np.random.default_rng(13)
-lens = rng.integers(1, L + 1, NSEQ).astype(np.int32); lens[0] = L; lens[1] = 1; lens[2] = 32; lens[3] = 33
+lens = rng.integers(1, L + 1, NSEQ).astype(np.int32); lens[0] = L
+for i_, v_ in ((1, 1), (2, 32), (3, 33)):      # (a single query or a pair — the query path's shapes — has no such rows)
+    if i_ < NSEQ:
+        lens[i_] = min(v_, L)
 ids = rng.integers(1, 2000, (NSEQ, L)).astype(np.int32)
 for r, l in enumerate(lens):
     ids[r, l:] = 0
