@@ -1158,7 +1158,7 @@ static int e32_skinny_gemm(const uint16_t* xq, const uint16_t* wq, float* P, int
   // attention read every slab — at the same number of loads in flight per wave
   const int W = waves_env == 4 ? 4 : (waves_env == 8 ? 8 : E32Q_DEFAULT_WAVES);
   int kr = 8;
-  // (measured flat, tools/r06_encq_ab.sh: 4 / 8 waves and KR 8 / 4 / 2 all land within 2 % of each other on a whole forward —
+  // (measured flat, tools/r06/encq_ab.sh: 4 / 8 waves and KR 8 / 4 / 2 all land within 2 % of each other on a whole forward —
   //  0.97 .. 1.00 ms for bge-large's single query; fewer, larger slices were the best of them, hence the low bar of ~100 workgroups)
   while (kr > 2 && nb * ((KS + W * kr - 1) / (W * kr)) < 96) kr >>= 1;
   if (MT == 4 && kr > 4) kr = 4;                       // (registers: MT·KR fragments of activations are in flight)

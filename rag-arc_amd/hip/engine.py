@@ -18,7 +18,7 @@ from . import binding as B
 
 _ROW_ALIGN = 32  # the scan reads whole 32-row tiles
 # pipelined contexts (FlatIndexF16._pipeline_context): hold a context's scan back until its partner's batch is complete
-# (RarcSearchBatch.gate_event)?  Measured at config 2, 400 steps, same box (tools/r06_gate.sh, profiles/r06_c2_pipeline.txt): one
+# (RarcSearchBatch.gate_event)?  Measured at config 2, 400 steps, same box (tools/r06/gate.sh, profiles/r06_c2_pipeline.txt): one
 # context 0.449 ms per batch, two gated 0.442, two UNGATED 0.423 — a cross-stream event costs ~17 µs from its completion to
 # the waiting kernel's start, where the scan's workgroups simply take each CU as the partner's finalize leaves it.  Off.
 _PIPELINE_GATE = os.environ.get("RARC_PIPELINE_GATE", "0") == "1"
@@ -933,7 +933,7 @@ class FlatIndexF16:
             return _FinishedSearch(self, *self.search_device(queries, k))
         # (answers bound for the host — the store's batch calls — keep ONE context: behind them the time is python's (mapping
         #  25,600 Documents per batch), a second context only adds its bookkeeping: 1M rows, batch_invoke 266 k vs 258 k q/s,
-        #  2048 queries in one call 218 k vs 185 k, tools/r06_api_ab.sh)
+        #  2048 queries in one call 218 k vs 185 k, tools/r06/api_ab.sh)
         ctx = None if to_host else self._pipeline_context(k)
         if ctx is not None:
             return ctx.search_async(queries, k, to_host)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the plugin-surface legs at 1M rows with one search context (RARC_PIPELINE=0) and with two
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd "$R"
 for mode in 0 1; do
   RARC_PIPELINE=$mode timeout 900 python3 bench.py --rows 1000000 --no-c3 --no-c5 --no-persist --no-ingest --no-f32 --no-wide --no-pairs --no-cpu-baseline 2>/dev/null | python3 -c "
 import json,sys; j=json.loads(sys.stdin.read()); a=j['api']['c2']

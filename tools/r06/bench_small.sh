@@ -1,6 +1,6 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_bench_small; mkdir -p "$O"
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_bench_small; mkdir -p "$O"
 timeout 1200 python3 bench.py --rows 1000000 --no-c3 --no-c5 --no-persist --no-ingest --no-f32 --no-wide --no-pairs "$@" > "$O/bench.json" 2> "$O/bench.err"
 echo rc=$?; tail -5 "$O/bench.err"
 python3 - "$O/bench.json" <<'PY'

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the driver's command (python bench.py, no flags) timed by wall clock, + selected new tests in front
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_full_bench; mkdir -p "$O"
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_full_bench; mkdir -p "$O"
 if [ "${1:-tests}" = tests ]; then
   timeout 900 python3 -m pytest tests/test_gpu_wide.py tests/test_gpu_multirank.py tests/test_gpu_batching.py -x -q -m gpu -rs 2>&1 | tail -4 | tee "$O/pytest_tail.txt"
 fi

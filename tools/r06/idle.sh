@@ -1,7 +1,7 @@
 #!/bin/bash
 # fp16 scan with idle waves (nq < 256): parity suites that vary nq, then latency of small batches at 1M rows and the api leg
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd "$R"
 timeout 1200 python3 -m pytest tests/test_gpu_flat_search.py tests/test_gpu_hybrid_scan.py tests/test_gpu_fuzz_shapes.py tests/test_gpu_adversarial.py tests/test_gpu_reference_pin.py -x -q -m gpu 2>&1 | tail -3
 python3 - <<'PY'
 import sys, time, os

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rarc_search_batch + pipelined contexts: the whole GPU suite, then config 2 with and without the pipeline, the 12.5M-row shard step, timelines
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_pipe; mkdir -p "$O"
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_pipe; mkdir -p "$O"
 if [ "${1:-full}" = full ]; then timeout 1500 python3 -m pytest tests -m gpu -x -q -rs > "$O/pytest.log" 2>&1; tail -4 "$O/pytest.log"; fi
 QUIET="--no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-wide --no-pairs --no-cpu-baseline"
 for mode in 0 1; do

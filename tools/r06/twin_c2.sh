@@ -1,7 +1,7 @@
 #!/bin/bash
 # config 2 (1M x 768) with two search contexts on two streams (--twin): kernel timeline
 cd /tmp && export TMPDIR=/tmp
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_twin_c2; mkdir -p "$O"
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}; cd "$R"; O=$R/gpurun_out/r06_twin_c2; mkdir -p "$O"
 QUIET="--no-c2 --no-c3 --no-c5 --no-persist --no-ingest --no-api --no-f32 --no-wide --no-pairs --no-cpu-baseline"
 python3 bench.py --rows 1000000 --steps 200 --warmup 20 $QUIET --verify-queries 8 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('PLAIN ms/step', j['ms_per_step'])"
 python3 bench.py --rows 1000000 --steps 200 --warmup 20 --twin $QUIET --verify-queries 8 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('TWIN ms/step', j['ms_per_step'])"
