@@ -770,22 +770,33 @@ class FlatIndexF16:
             return None
         pair = self.__dict__.get("_pair")
         if pair is None or pair[0]._parent_version != self._version:
+            import weakref
+
             a, b = self.twin(), self.twin()
-            a._partner, b._partner = b, a
+            # (the pair belongs to this index and to nothing else: no reference cycle through it — contexts see their index and
+            #  each other weakly — so an index dropped by its last reference frees its rows at once, not at the cyclic
+            #  collector's next pass: the contexts share the row tensors)
+            a._partner, b._partner = weakref.proxy(b), weakref.proxy(a)
+            a._parent = b._parent = weakref.proxy(self)
             pair = self._pair = [a, b, 0]
         pair[2] ^= 1
         return pair[pair[2]]
 
     def _rows_version(self) -> int:
         """Version of the rows a search reads (a twin reads its parent's)."""
-        return self._parent._version if self._parent is not None else self._version
+        if self._parent is None:
+            return self._version
+        try:
+            return self._parent._version
+        except ReferenceError:          # a pipelined context whose index is gone: the rows it holds are the ones it was made for
+            return self._parent_version
 
     def _not_a_twin(self) -> None:
         if self._parent is not None:
             raise B.RarcError("a twin() search context is read-only: change the index it was taken from")
 
     def _check_twin(self) -> None:
-        if self._parent is not None and self._parent._version != self._parent_version:
+        if self._parent is not None and self._rows_version() != self._parent_version:
             raise B.RarcError("the index has changed since twin() was taken: take a new twin")
 
     @staticmethod
@@ -970,7 +981,12 @@ class FlatIndexF16:
                 # it.  The event is the batch's own: result() waits for THIS batch only, not for what was enqueued after it
                 status = t.empty(B.MAX_QUERIES + 1, dtype=t.int32, device=self.device)
                 flag_h = self._flags.acquire(t)
-                gate = self._partner._fin_event if (self._partner is not None and _PIPELINE_GATE) else None
+                gate = None
+                if self._partner is not None and _PIPELINE_GATE:
+                    try:
+                        gate = self._partner._fin_event
+                    except ReferenceError:
+                        gate = None
                 self._search_chunk(q[s0:e0], k, out_ids[s0:e0], out_sc[s0:e0], repair=False, status=status,
                                    flag_host=flag_h.data_ptr(), gate=gate.cuda_event if gate is not None else 0)
                 done = t.cuda.Event()
@@ -1386,7 +1402,10 @@ class PendingSearch:
                     stream.synchronize()
             self.index.last_repaired = self.repaired
             if self.index._parent is not None:      # (a pipelined context of the index the caller holds)
-                self.index._parent.last_repaired = self.repaired
+                try:
+                    self.index._parent.last_repaired = self.repaired
+                except ReferenceError:
+                    pass
         return self.ids, self.scores
 
     def host_view(self):

@@ -222,3 +222,38 @@ def test_2560_query_vectors_in_one_call_and_many_threads_keep_their_own_answers(
         assert np.array_equal(out[t][1], want_r[t * 256:t * 256 + 768]), t
         assert np.array_equal(out[t][0].view(np.uint32), want_s[t * 256:t * 256 + 768].view(np.uint32)), t
     assert store.index._pins.allocated <= 24, store.index._pins.allocated     # slots come back: the pool stays small
+
+
+def test_an_index_with_pipelined_contexts_frees_its_rows_when_dropped():
+    """search_async on the fp16-scan path runs over two internal search contexts that share the index's row tensors.  They see
+    their index (and each other) through weak references: dropping the index frees its HBM at once — no cyclic-collector pass
+    needed — and a handle that outlives the index still answers."""
+    import gc
+
+    import torch
+
+    from rag_arc_amd.hip.engine import FlatIndexF16
+
+    gc.collect()
+    torch.cuda.empty_cache()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        idx = FlatIndexF16(256, growable=False, scan="mfma16")                      # the fp16-scan path, whatever k
+        idx.add(torch.randn((400_000, 256), device="cuda", generator=g))            # 200 MB of rows
+        q = torch.randn((64, 256), device="cuda", generator=g)
+        want = idx.search_device(q, 10)[0].clone()
+        h1, h2 = idx.search_async(q, 10), idx.search_async(q, 10)
+        assert idx._pair is not None                                               # the pipelined contexts exist
+        assert torch.equal(h1.result()[0], want)
+        held = torch.cuda.memory_allocated() - base
+        assert held > 150 << 20
+        del idx, h1
+        left = torch.cuda.memory_allocated() - base
+        assert torch.equal(h2.result()[0], want)                                   # the handle (and through it ONE context) lives on
+        del h2
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() - base < 8 << 20, (held, left, torch.cuda.memory_allocated() - base)
+    finally:
+        gc.enable()
