@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void rarc_e32_attention_split_kernel(const 
 }
 
 // ------------------------------------------------------------------------------------------
-// Round 6 — attention of the QUERY PATH: sequences of at most 32 padded tokens (one query block, one key tile), head_dim 64.
+// Round 6 — attention of the QUERY PATH: sequences of at most 32 padded tokens (one query block, one key tile), head_dim 64 or 32.
 // rarc_e32_attention_split_kernel is built for 512-token documents: shared K / V images of 32-key tiles in LDS, double
 // buffered, ONE wave per 32-query block doing the softmax of 1024 scores — at one tile and one block that is a single wave's
 // instruction stream, 11 µs per layer for a single query, more than any of its projections (a lone wave issues one VALU
@@ -774,14 +774,14 @@ __global__ __launch_bounds__(256, 2) void rarc_e32_attention_split_kernel(const 
 // stream multiplies each wave's partial product — a wave's k slice lies inside ONE head — by it before the slices are added
 // (E32SkinnyEpi.wave_scale).  ra_one[token] = 1: the projection's row pass has no row scale left to apply.
 // ------------------------------------------------------------------------------------------
-template <bool REL>
+template <int DH, bool REL>   // DH: head_dim 64 (bge-base / -large, MPNet) or 32 (bge-small, MiniLM)
 __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* __restrict__ P, const float* __restrict__ ra,
                                                                   const float* __restrict__ rw, const float* __restrict__ bias,
                                                                   const int32_t* __restrict__ lens, int H, int n_heads,
                                                                   half_t* __restrict__ xq, float* __restrict__ rah,
                                                                   float* __restrict__ ra_one, const float* __restrict__ rel,
                                                                   int rel_span, int n_parts, size_t part_stride) {
-  constexpr int DH = 64, L = 32;
+  constexpr int L = 32, C8 = DH / 8;   // C8: threads per token row in phase A (8 dims each)
   constexpr int QROW = DH + 8;   // halves per q / k row (+16 bytes: conflict-free ds_read_b128 fragments)
   constexpr int TROW = L + 8;    // halves per V^T row (32 keys) / P^T row (32 keys)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -795,10 +795,11 @@ __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* _
   const int len = lens[b] < 1 ? 1 : (lens[b] > L ? L : lens[b]);
   if (tid < DH) vmax[tid] = 0u;
   // ---- A: thread (token row = tid >> 3, c8 = tid & 7) owns dims 8 c8 .. + 7 of the row's q, k and v ----
-  const int row = tid >> 3, c8 = tid & 7;
+  const bool loader = tid < L * C8;            // (head_dim 32: the first two waves fetch, all four multiply)
+  const int row = loader ? tid / C8 : 0, c8 = tid % C8;
   const size_t mrow = (size_t)b * L + row;
-  float x[3][8];
-  {
+  float x[3][8] = {};
+  if (loader) {
     const float r = ra[mrow];
     const float* src = P + mrow * 3 * (size_t)H + hd * DH + 8 * c8;
 #pragma unroll
@@ -814,13 +815,15 @@ __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* _
       }
     }
   }
-  if (row >= len) {   // a masked key's V row reads as zero: nothing of the padding reaches a result
+  if (row >= len || !loader) {   // a masked key's V row reads as zero: nothing of the padding reaches a result
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[2][e] = 0.f;
   }
   __syncthreads();    // vmax is zero
+  if (loader) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) atomicMax(&vmax[8 * c8 + e], __float_as_uint(fabsf(x[2][e])));   // (non-negative floats order as integers)
+    for (int e = 0; e < 8; ++e) atomicMax(&vmax[8 * c8 + e], __float_as_uint(fabsf(x[2][e])));   // (non-negative floats order as integers)
+  }
 #pragma unroll
   for (int part = 0; part < 2; ++part) {   // q, k: one scale per row = the maximum over the row's eight lanes
     float mx = 0.f;
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* _
     for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(x[part][e]));
     mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
+    if (C8 == 8) mx = fmaxf(mx, __shfl_xor(mx, 4, 64));
     float sc, inv;
     e32a_scale_of(mx, sc, inv);
     half8 hi, lo;
@@ -838,13 +841,16 @@ __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* _
       e32a_split(x[part][e] * sc, h_, l_);
       hi[e] = h_; lo[e] = l_;
     }
-    *(half8*)((part ? kh : qh) + row * QROW + 8 * c8) = hi;
-    *(half8*)((part ? kl : ql) + row * QROW + 8 * c8) = lo;
-    if (c8 == 0) (part ? skinv : sqinv)[row] = inv;
+    if (loader) {
+      *(half8*)((part ? kh : qh) + row * QROW + 8 * c8) = hi;
+      *(half8*)((part ? kl : ql) + row * QROW + 8 * c8) = lo;
+      if (c8 == 0) (part ? skinv : sqinv)[row] = inv;
+    }
   }
   __syncthreads();    // every column's maximum is in
 #pragma unroll
   for (int e = 0; e < 8; ++e) {   // v: one scale per column d; the images are V^T [d][key]
+    if (!loader) break;
     const int d = 8 * c8 + e;
     float sc, inv;
     e32a_scale_of(__uint_as_float(vmax[d]), sc, inv);
@@ -861,27 +867,28 @@ __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* _
   const int query = 16 * qb + c;
   f32x4 st = {0, 0, 0, 0};
   {
-    half8 akh[2], akl[2], bqh[2], bql[2];
+    constexpr int S2 = DH / 32;      // k steps of 32 over the head's dims
+    half8 akh[S2], akl[S2], bqh[S2], bql[S2];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < S2; ++s2) {
       akh[s2] = *(const half8*)(kh + (16 * kb + c) * QROW + 32 * s2 + 8 * rq);
       akl[s2] = *(const half8*)(kl + (16 * kb + c) * QROW + 32 * s2 + 8 * rq);
       bqh[s2] = *(const half8*)(qh + query * QROW + 32 * s2 + 8 * rq);
       bql[s2] = *(const half8*)(ql + query * QROW + 32 * s2 + 8 * rq);
     }
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[0], bqh[0], st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[1], bqh[1], st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[0], bql[0], st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[1], bql[1], st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[0], bqh[0], st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[1], bqh[1], st, 0, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < S2; ++s2) st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[s2], bqh[s2], st, 0, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < S2; ++s2) st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[s2], bql[s2], st, 0, 0, 0);
+#pragma unroll
+    for (int s2 = 0; s2 < S2; ++s2) st = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[s2], bqh[s2], st, 0, 0, 0);
     RARC_MFMA_SETTLE(st);
   }
   float pr[4];
   float tmax = -INFINITY;
   {
     const float4 ski = *(const float4*)(skinv + 16 * kb + 4 * rq);
-    const float fq = sqinv[query] * 0.125f;   // 1/sqrt(64) is a power of two
+    const float fq = sqinv[query] * (DH == 64 ? 0.125f : 0.17677669529663687f);   // 1/sqrt(head_dim); a power of two at 64
     const float f[4] = {ski.x * fq, ski.y * fq, ski.z * fq, ski.w * fq};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -922,13 +929,14 @@ __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* _
   // ---- C: wave (qb, dpair = wave & 1): O^T blocks d = 16 db.. for db = 2 dpair, 2 dpair + 1, x queries 16qb.. ----
   const int dpair = wave & 1;
   const float inv_l = 0.00048828125f / (ssum[0][query] + ssum[1][query]);   // · 2^-11: p was split as p · 2^11
-  float cval[2][4];
+  constexpr int NBW = DH / 32;     // 16-d blocks of O^T per wave
+  float cval[NBW][4];
   float mo = 0.f;
   {
     const half8 bh = *(const half8*)(ph + query * TROW + 8 * rq), bl = *(const half8*)(pl + query * TROW + 8 * rq);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int db = 2 * dpair + i;
+    for (int i = 0; i < NBW; ++i) {
+      const int db = NBW * dpair + i;
       const half8 avh = *(const half8*)(vh + (16 * db + c) * TROW + 8 * rq), avl = *(const half8*)(vl + (16 * db + c) * TROW + 8 * rq);
       f32x4 o = {0, 0, 0, 0};
       o = __builtin_amdgcn_mfma_f32_16x16x32_f16(avl, bh, o, 0, 0, 0);
@@ -951,10 +959,10 @@ __global__ __launch_bounds__(256) void rarc_e32q_attention_kernel(const float* _
   e32_scale_of(fmaxf(somax[0][query], somax[1][query]), so, soinv);
   const size_t mq = (size_t)b * L + query;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NBW; ++i) {
     half4_t hi, lo;
     e32_split4(make_float4(cval[i][0], cval[i][1], cval[i][2], cval[i][3]), so, hi, lo);
-    half_t* dst = xq + e32_frag_offset(mq, hd * DH + 16 * (2 * dpair + i) + 4 * rq, H);
+    half_t* dst = xq + e32_frag_offset(mq, hd * DH + 16 * (NBW * dpair + i) + 4 * rq, H);
     *(half4_t*)dst = hi;
     *(half4_t*)(dst + 512) = lo;
   }
@@ -1344,13 +1352,15 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     // the query path's own attention (sequences of 32 padded tokens, head_dim 64): one wave per (sequence, head), the split
     // image of its output written in place of the row pass below; RARC_E32Q_ATTN=0 keeps the document kernel + the row pass
     const char* qa_env = getenv("RARC_E32Q_ATTN");
-    const bool query_attn = query && seq_len == 32 && H == model->heads * 64 && model->heads <= 16 && !(qa_env && atoi(qa_env) == 0);
+    const int head_dim = H / model->heads;
+    const bool query_attn = query && seq_len == 32 && model->heads <= 16 && !(qa_env && atoi(qa_env) == 0);
     if (query_attn) {
-#define E32Q_ATTN_LAUNCH(RELV)                                                                                               \
-      hipLaunchKernelGGL((rarc_e32q_attention_kernel<RELV>), dim3(n_seq * model->heads), dim3(256), 0, hs, P, ra_a, Ly.qkv_rw,   \
-                         Ly.qkv_b, d_lens, H, model->heads, (half_t*)xs, rah, ra_b, model->rel_bias, model->rel_span, qkv_parts, \
-                         (size_t)M * 3 * H)
-      if (model->rel_bias) E32Q_ATTN_LAUNCH(true); else E32Q_ATTN_LAUNCH(false);
+#define E32Q_ATTN_LAUNCH(DHV, RELV)                                                                                          \
+      hipLaunchKernelGGL((rarc_e32q_attention_kernel<DHV, RELV>), dim3(n_seq * model->heads), dim3(256), 0, hs, P, ra_a,       \
+                         Ly.qkv_rw, Ly.qkv_b, d_lens, H, model->heads, (half_t*)xs, rah, ra_b, model->rel_bias, model->rel_span, \
+                         qkv_parts, (size_t)M * 3 * H)
+      if (head_dim == 64) { if (model->rel_bias) E32Q_ATTN_LAUNCH(64, true); else E32Q_ATTN_LAUNCH(64, false); }
+      else { if (model->rel_bias) E32Q_ATTN_LAUNCH(32, true); else E32Q_ATTN_LAUNCH(32, false); }
 #undef E32Q_ATTN_LAUNCH
     } else if (H == model->heads * 64 && split_attention) {
       const int q_groups = (q_blocks + 3) / 4;
@@ -1373,7 +1383,7 @@ extern "C" int rarc_enc32_forward(const RarcEnc32Model* model, const int32_t* d_
     if (!query_attn && (rc = e32_epi<3>(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, M, H, nullptr, xs, ra_b, hs, 1, fq)))
       return rc;
     // attention output projection -> x = LayerNorm(proj + x)
-    if (query_attn) rc = e32_skinny_gemm(xs, Ly.o_wq, P, M, H, H, &parts, hs, rah, 4);   // (per-head scales: 4 k steps = 64 dims)
+    if (query_attn) rc = e32_skinny_gemm(xs, Ly.o_wq, P, M, H, H, &parts, hs, rah, head_dim / 16);   // (per-head scales: a head = 4 or 2 k steps)
     else rc = E32_PROJ(xs, Ly.o_w3, Ly.o_wq, H, H, max_parts);
     if (rc != RARC_OK) return rc;
     if ((rc = e32_epi<2>(P, ra_b, Ly.o_rw, Ly.o_b, x, Ly.ln1_g, Ly.ln1_b, eps, M, H, x, xs, ra_a, hs, parts, fz2))) return rc;

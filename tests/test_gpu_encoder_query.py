@@ -42,7 +42,9 @@ def _tile_path(enc, ids, lens):
     (768, 3, 12, 3072, 1, 32),     # bge-base geometry (k ranges of 48 / 192 steps: six-slice groups, idle upper waves)
     (768, 2, 12, 3072, 2, 32),     # two queries: 64 tokens (MT = 2)
     (768, 2, 12, 3072, 4, 30),     # four queries: 128 tokens (MT = 4), ragged
-    (384, 2, 12, 1536, 3, 20),     # bge-small geometry, head_dim 32 (the fp32-MFMA attention), three queries -> 128 tokens
+    (384, 2, 12, 1536, 3, 20),     # bge-small geometry, head_dim 32 (the query attention's 32-dim form), three queries -> 128 tokens
+    (384, 3, 12, 1536, 1, 32),     # bge-small geometry, ONE query (BASELINE config 1's model): per-head scales over 2 k steps
+    (128, 2, 4, 256, 2, 9),        # head_dim 32, two short queries, ragged lengths
     (256, 2, 4, 512, 1, 64),       # one 64-token query: two query blocks in the attention
     (128, 1, 2, 256, 1, 100),      # one 100-token query: 128 tokens
 ])
