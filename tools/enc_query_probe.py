@@ -44,19 +44,20 @@ def timed(enc, tok, lens):
 
 for name in os.environ.get("PROBE_GEOS", "bge-large,bge-base").split(","):
     enc, g = build(*GEOS[name])
-    for n in (1, 2, 4):
-        tok = torch.randint(1, 30522, (n, 32), generator=g, device=dev).int()
-        lens = torch.full((n,), 32, dtype=torch.int32, device=dev)
+    for n, L in [(1, 32), (2, 32), (4, 32)] + ([(1, 64), (1, 128), (2, 64)] if os.environ.get("PROBE_LONG") else []):
+        tok = torch.randint(1, 30522, (n, L), generator=g, device=dev).int()
+        lens = torch.full((n,), L, dtype=torch.int32, device=dev)
         q_wall, q_one = timed(enc, tok, lens)
         # the tile kernels need a multiple of 128 tokens: the same sequences padded to 4 x 32 (what forward() did before round 6)
-        pad = torch.cat([tok, torch.zeros((4 - n, 32), dtype=torch.int32, device=dev)]) if n < 4 else tok
-        plens = torch.cat([lens, torch.ones(4 - n, dtype=torch.int32, device=dev)]) if n < 4 else lens
+        n128 = 128 // L          # the tile kernels take multiples of 128 tokens
+        pad = torch.cat([tok, torch.zeros((n128 - n, L), dtype=torch.int32, device=dev)]) if n < n128 else tok
+        plens = torch.cat([lens, torch.ones(n128 - n, dtype=torch.int32, device=dev)]) if n < n128 else lens
         os.environ["RARC_E32_QUERY"] = "0"
         t_wall, t_one = timed(enc, pad, plens)
         del os.environ["RARC_E32_QUERY"]
         a, b = enc.forward_device(tok, lens), None
         os.environ["RARC_E32_QUERY"] = "0"; b = enc.forward_device(pad, plens)[:n]; del os.environ["RARC_E32_QUERY"]
-        print(f"ENCQ {name} {n} x 32 tokens: query path {q_wall:.3f} ms back to back, {q_one:.3f} ms alone | tile kernels (4 x 32) "
+        print(f"ENCQ {name} {n} x {L} tokens: query path {q_wall:.3f} ms back to back, {q_one:.3f} ms alone | tile kernels ({n128} x {L}) "
               f"{t_wall:.3f} / {t_one:.3f} ms | max |diff| {float((a - b).abs().max()):.2e}")
     del enc
     torch.cuda.empty_cache()
