@@ -758,9 +758,10 @@ class FlatIndexF16:
 
     # the fp16-scan path (small shards: config 2) spends a sixth of a batch in small dependent kernels either side of the scan
     # — query prep, seed pass, seed threshold in front of it (30 µs), finalize behind it (35 µs) — while the scan itself holds
-    # every CU.  search_async therefore alternates between TWO search contexts of the index (twin(): own query block, workspace
-    # and stream each) whose scans are gated on each other's completion (RarcSearchBatch.gate_event): batch i+1's prep / seed
-    # run under batch i's finalize, its scan starts when that finalize is done.  RARC_PIPELINE=0 keeps one context.
+    # every CU.  search_async (answers that stay on the device) therefore alternates between TWO search contexts of the index
+    # (twin(): own query block, workspace and stream each): batch i+1's prep / seed run under batch i's finalize, and its scan's
+    # workgroups take each CU as that finalize leaves it (ungated by default: _PIPELINE_GATE above).  RARC_PIPELINE=0 keeps
+    # one context.
     PIPELINE_MIN_ROWS = 65536
 
     def _pipeline_context(self, k: int):
@@ -1373,7 +1374,8 @@ class PendingSearch:
             pass
 
     def result(self):
-        """(ids int64 [nq][k], scores fp32 [nq][k]) device tensors, exact.
+        """(ids int64 [nq][k], scores fp32 [nq][k]), exact: device tensors — or, for a to_host=True batch, the pinned host
+        tensors its finalize kernel wrote.
 
         A flagged query is repaired HERE, and the repair reuses the index's query block and workspace — which later
         batches of the same index (the other 256-query chunks of a PendingBatches, a twin's next batch) may still be
